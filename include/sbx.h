@@ -1,0 +1,210 @@
+/*
+ * sbx.h — C ABI of the MI355X-native reorder / convert / permute hot path.
+ *
+ * This is the drop-in boundary: every entry point below is what SparseBase's
+ * plug-in points would bind for this path.  Each function
+ * cites the reference interface (file:line under the SparseBase tree) whose
+ * work it replaces.
+ *
+ * Conventions
+ *  - Every array pointer is a DEVICE pointer on the handle's GPU unless the
+ *    parameter name ends in `_host`.
+ *  - No entry point allocates memory it hands back: the caller owns inputs and
+ *    outputs.  Scratch comes from the handle's grow-only arena (sbx_reserve
+ *    pre-sizes it, so steady-state calls never call hipMalloc).
+ *  - Work is enqueued on the handle's stream.  Functions documented as
+ *    "synchronous" wait for the stream internally (they need a device->host
+ *    read-back); all others return as soon as the work is enqueued.
+ *  - Return value: SBX_OK (0) or an sbx_status error code; nothing throws
+ *    across this boundary.  sbx_last_error() gives a message for the last
+ *    failing call on the handle.
+ *  - Index type: IDType and NNZType share one width (SBX_I32 or SBX_I64).
+ *    uint32 index arrays alias SBX_I32 (all dimensions must be < 2^31).
+ *  - Value type: the 0/4/8-byte payload that follows each nonzero.  The
+ *    arithmetic type matters only where the reference compares values
+ *    (std::less<pair<col,val>> between duplicate columns, format/csr.cc:143-156).
+ */
+#ifndef SBX_H_
+#define SBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBX_VERSION 100 /* 0.1.0 */
+
+typedef struct sbx_handle_s *sbx_handle_t;
+
+typedef enum sbx_status {
+  SBX_OK = 0,
+  SBX_ERR_BAD_ARG = 1,     /* null pointer / negative size / unknown enum   */
+  SBX_ERR_NO_DEVICE = 2,   /* no usable HIP device (fails loudly, no fallback) */
+  SBX_ERR_HIP = 3,         /* a HIP runtime call failed                      */
+  SBX_ERR_OOM = 4,         /* device allocation failed                       */
+  SBX_ERR_UNSUPPORTED = 5, /* type tuple / shape not built                   */
+  SBX_ERR_INTERNAL = 6
+} sbx_status;
+
+typedef enum sbx_index_type { SBX_I32 = 0, SBX_I64 = 1 } sbx_index_type;
+
+typedef enum sbx_value_type {
+  SBX_V_NONE = 0, /* ValueType = void, or vals == nullptr */
+  SBX_V_I32 = 1,
+  SBX_V_U32 = 2,
+  SBX_V_F32 = 3,
+  SBX_V_I64 = 4,
+  SBX_V_U64 = 5,
+  SBX_V_F64 = 6
+} sbx_value_type;
+
+/* flags for the conversion entry points */
+#define SBX_FLAG_MOVE 0x1u        /* move-conversion: only the index array that
+                                     changes shape is produced (col/val are
+                                     handed over by pointer on the host side) */
+#define SBX_FLAG_ROWS_SORTED 0x2u /* caller guarantees row[] is non-decreasing */
+
+/* ------------------------------------------------------------------ *
+ * Handle, memory and device utilities                                  *
+ * (replaces the raw cudaMalloc/cudaMemcpy calls of                     *
+ *  converter/converter_order_two_cuda.cu:11-105,                       *
+ *  context/cuda_context_cuda.cu:9-21, converter/converter_cuda.cu:12-21) */
+/* ------------------------------------------------------------------ */
+int sbx_version(void);
+const char *sbx_status_string(int status);
+int sbx_device_count(int *count_host);
+int sbx_can_access_peer(int device, int peer_device, int *can_host);
+
+int sbx_create(int device, sbx_handle_t *out);
+int sbx_destroy(sbx_handle_t h);
+int sbx_set_stream(sbx_handle_t h, void *hip_stream);
+int sbx_get_device(sbx_handle_t h, int *device_host);
+int sbx_reserve(sbx_handle_t h, size_t scratch_bytes);
+int sbx_sync(sbx_handle_t h);
+const char *sbx_last_error(sbx_handle_t h);
+
+int sbx_malloc(sbx_handle_t h, size_t bytes, void **dev_ptr_host);
+int sbx_free(sbx_handle_t h, void *dev_ptr);
+/* blocking copies (stream-ordered after prior work on the handle's stream) */
+int sbx_memcpy_h2d(sbx_handle_t h, void *dst_dev, const void *src_host, size_t bytes);
+int sbx_memcpy_d2h(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes);
+int sbx_memcpy_d2d(sbx_handle_t h, void *dst_dev, const void *src_dev, size_t bytes);
+int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, const void *src_dev,
+                    int src_device, size_t bytes);
+
+/* ------------------------------------------------------------------ *
+ * A1  COO constructor semantics — format/coo.cc:76-158                 *
+ * ------------------------------------------------------------------ */
+/* Lexicographic (row,col) non-decreasing test, format/coo.cc:96-108.  Synchronous. */
+int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz, const void *row,
+                      const void *col, int *sorted_host);
+/* In-place sort by (row,col), payload follows; format/coo.cc:110-157.
+ * Stable (the reference's std::sort leaves the order of duplicate coordinates
+ * unspecified).  val may be NULL.  Synchronous (one max-reduction read-back). */
+int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                 int64_t nnz, void *row, void *col, void *val);
+
+/* ------------------------------------------------------------------ *
+ * A4  CSR constructor semantics — format/csr.cc:78-159                 *
+ * ------------------------------------------------------------------ */
+/* 1 iff no row has col[j] < col[j-1]; format/csr.cc:102-116.  Synchronous. */
+int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                        const void *col, int *sorted_host);
+/* If any row is unsorted, sort EVERY row by (col,val) in place
+ * (format/csr.cc:118-157); otherwise leave the arrays untouched. */
+int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n,
+                      int64_t m, int64_t nnz, const void *row_ptr, void *col, void *val);
+
+/* ------------------------------------------------------------------ *
+ * A2/A2m  COO -> CSR — converter/converter_order_two.cc:163-212, :215-246
+ * row_ptr_out = exclusive scan of the row histogram; col/val copied verbatim.
+ * With SBX_FLAG_MOVE col_out/val_out are ignored (may be NULL).         */
+/* ------------------------------------------------------------------ */
+int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                   int64_t nnz, const void *row, const void *col, const void *val,
+                   void *row_ptr_out, void *col_out, void *val_out, unsigned flags);
+
+/* ------------------------------------------------------------------ *
+ * A3  CSR -> COO — converter/converter_order_two.cc:72-118, :131-160   *
+ * ------------------------------------------------------------------ */
+int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                   int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                   void *row_out, void *col_out, void *val_out, unsigned flags);
+
+/* ------------------------------------------------------------------ *
+ * A6  DegreeReorder::CalculateReorderCSR — reorder/degree_reorder.cc:22-62
+ * inv_perm_out[old_row] = new_row; ascending: (deg asc, id desc),        *
+ * descending: the exact reverse.                                         */
+/* ------------------------------------------------------------------ */
+int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                       int ascending, void *inv_perm_out);
+
+/* ------------------------------------------------------------------ *
+ * A7  RCMReorder::GetReorderCSR — reorder/rcm_reorder.cc:83-166 (+ :22-81)
+ * Parity is defined for structurally symmetric patterns with column-sorted
+ * rows (what the CSR constructor guarantees).  Synchronous.              */
+/* ------------------------------------------------------------------ */
+typedef struct sbx_rcm_stats {
+  int64_t components;       /* connected components incl. isolated vertices */
+  int64_t isolated;         /* vertices with an empty row                   */
+  int64_t small_components; /* components ordered by the batched kernel     */
+  int64_t large_components; /* components ordered by level-synchronous BFS  */
+  int64_t bfs_sweeps;       /* full BFS sweeps over the largest component   */
+  int64_t bfs_levels;       /* levels summed over those sweeps              */
+  int64_t edges_scanned;    /* adjacency entries visited (all sweeps)       */
+  int64_t largest_component;
+} sbx_rcm_stats;
+int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,
+                    const void *row_ptr, const void *col, void *inv_perm_out,
+                    sbx_rcm_stats *stats_host /* may be NULL */);
+
+/* ------------------------------------------------------------------ *
+ * A8  GrayReorder::GrayReorderingCSR — reorder/gray_reorder.cc:106-424 *
+ * Device stage: per-row degree, band count and Gray-decoded bitmap key. *
+ * key_out[i] (uint64) = decoded bitmap of row i computed with the row's  *
+ * class threshold (sparse rows: 0; dense rows: deg/resolution).          *
+ * counts_host[4] = {nnz_sparse, diag_sparse, nnz_dense, diag_dense}.     *
+ * Synchronous.  The ordering stage lives above the ABI.  */
+/* ------------------------------------------------------------------ */
+int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, int64_t nnz,
+                      const void *row_ptr, const void *col, int resolution, int nnz_threshold,
+                      void *degree_out, uint64_t *key_out, int64_t *counts_host);
+
+/* ------------------------------------------------------------------ *
+ * A13 ReorderBase::InversePermutation — bases/reorder_base.h:663-672   *
+ * ------------------------------------------------------------------ */
+int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_t n, const void *perm,
+                            void *inv_out);
+
+/* ------------------------------------------------------------------ *
+ * A5 (+A4) PermuteOrderTwo::PermuteOrderTwoCSR — permute/permute_order_two.cc:23-79
+ * row_order / col_order are inverse permutations (order[old] = new) or NULL
+ * (identity).  Output rows are sorted by (col,val) exactly when the CSR
+ * constructor would sort them (format/csr.cc:99-157).
+ * sbx_permute_csr_rows produces only new rows [row_begin,row_end): row_ptr_out
+ * receives row_end-row_begin+1 entries rebased to 0, col_out/val_out the
+ * shard's nonzeros; *shard_nnz_host gets the shard's nnz.  The row-range
+ * split is the multi-GPU decomposition.  Synchronous only
+ * when shard_nnz_host != NULL.                                           */
+/* ------------------------------------------------------------------ */
+int sbx_permute_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                    int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                    const void *row_order, const void *col_order, void *row_ptr_out,
+                    void *col_out, void *val_out);
+int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n,
+                         int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                         const void *val, const void *row_order, const void *col_order,
+                         int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out,
+                         void *val_out, int64_t out_capacity, int64_t *shard_nnz_host);
+
+/* PermuteOrderOne::PermuteArray — permute/permute_order_one.cc:18-37:
+ * out[order[i]] = vals[i]. */
+int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n,
+                      const void *order, const void *vals, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBX_H_ */

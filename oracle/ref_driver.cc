@@ -1,0 +1,211 @@
+// ref_driver.cc — thin C entry points around the REAL SparseBase reference.
+//
+// TEST INFRASTRUCTURE ONLY.  Compiled by oracle/Makefile against the headers
+// and sources where they lie under /root/reference/src (header-only mode, no
+// reference file is copied into this repository); the output goes to
+// oracle/_ref/libsbref.so, which is git-ignored.  It exists to (a) pin the
+// CPU restatement in sbx_oracle.cc, (b) generate tests/golden fixtures
+// (oracle/make_golden.py) and (c) optionally serve as bench.py's
+// cpu_baseline of kind "reference".
+//
+// Signatures mirror the orc_* functions of sbx_oracle.cc so that the same
+// ctypes prototypes drive both.  it/vt combinations built:
+//   it=0: <int,int,void|int|float>, plus <unsigned,unsigned,unsigned> (vt=2)
+//   it=1: <int64,int64,void|double>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "sparsebase/bases/reorder_base.h"
+#include "sparsebase/context/cpu_context.h"
+#include "sparsebase/format/coo.h"
+#include "sparsebase/format/csr.h"
+#include "sparsebase/permute/permute_order_two.h"
+#include "sparsebase/reorder/degree_reorder.h"
+#include "sparsebase/reorder/gray_reorder.h"
+#include "sparsebase/reorder/rcm_reorder.h"
+#include "sparsebase/utils/logger.h"
+
+// Padded, zeroing allocator: DegreeReorder indexes one element past `mr`
+// (reorder/degree_reorder.cc:41-45) and GrayReorder reads one element past
+// sparse_v_order (gray_reorder.cc:239-240).  64 zero bytes of slack make the
+// reference deterministic and give its intended result.
+// Bound locally with -Wl,-Bsymbolic so only this library uses it.
+void *operator new(std::size_t sz) {
+  void *p = std::calloc(1, sz + 64);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void *operator new[](std::size_t sz) {
+  void *p = std::calloc(1, sz + 64);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+
+using namespace sparsebase;
+
+namespace {
+
+struct Quiet {
+  Quiet() { utils::Logger::set_level(utils::LOG_LVL_NONE); }
+} quiet_;
+
+template <typename I, typename V>
+void t_coo_sort(int64_t n, int64_t m, int64_t nnz, I *row, I *col, V *val) {
+  // the constructor sorts the caller's arrays in place (format/coo.cc:147-155)
+  format::COO<I, I, V> coo((I)n, (I)m, (I)nnz, row, col, val, format::kNotOwned);
+}
+template <typename I, typename V>
+void t_csr_sort(int64_t n, int64_t m, I *rp, I *col, V *val) {
+  format::CSR<I, I, V> csr((I)n, (I)m, rp, col, val, format::kNotOwned);
+}
+template <typename I, typename V>
+void t_coo_to_csr(int64_t n, int64_t m, int64_t nnz, I *row, I *col, V *val, I *rp_out,
+                  I *col_out, V *val_out) {
+  context::CPUContext cpu;
+  format::COO<I, I, V> coo((I)n, (I)m, (I)nnz, row, col, val, format::kNotOwned, true);
+  auto *csr = coo.template Convert<format::CSR>(&cpu);
+  memcpy(rp_out, csr->get_row_ptr(), (n + 1) * sizeof(I));
+  memcpy(col_out, csr->get_col(), nnz * sizeof(I));
+  if constexpr (!std::is_same_v<V, void>)
+    if (val && val_out) memcpy(val_out, csr->get_vals(), nnz * sizeof(V));
+  delete csr;
+}
+template <typename I, typename V>
+void t_csr_to_coo(int64_t n, int64_t m, int64_t nnz, I *rp, I *col, V *val, I *row_out,
+                  I *col_out, V *val_out) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)m, rp, col, val, format::kNotOwned, true);
+  auto *coo = csr.template Convert<format::COO>(&cpu);
+  memcpy(row_out, coo->get_row(), nnz * sizeof(I));
+  memcpy(col_out, coo->get_col(), nnz * sizeof(I));
+  if constexpr (!std::is_same_v<V, void>)
+    if (val && val_out) memcpy(val_out, coo->get_vals(), nnz * sizeof(V));
+  delete coo;
+}
+template <typename I, typename V>
+void t_degree(int64_t n, int64_t m, I *rp, I *col, int ascending, I *inv) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)m, rp, col, nullptr, format::kNotOwned, true);
+  reorder::DegreeReorder<I, I, V> r(ascending != 0);
+  I *o = r.GetReorder(&csr, {&cpu}, false);
+  memcpy(inv, o, n * sizeof(I));
+  delete[] o;
+}
+template <typename I, typename V>
+void t_rcm(int64_t n, I *rp, I *col, I *inv) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)n, rp, col, nullptr, format::kNotOwned, true);
+  reorder::RCMReorder<I, I, V> r;
+  I *o = r.GetReorder(&csr, {&cpu}, false);
+  memcpy(inv, o, n * sizeof(I));
+  delete[] o;
+}
+template <typename I, typename V>
+void t_gray(int64_t n, int64_t m, I *rp, I *col, int res, int thr, int grp, I *inv) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)m, rp, col, nullptr, format::kNotOwned, true);
+  reorder::GrayReorder<I, I, V> r((reorder::BitMapSize)res, thr, grp);
+  I *o = r.GetReorder(&csr, {&cpu}, false);
+  memcpy(inv, o, n * sizeof(I));
+  delete[] o;
+}
+template <typename I, typename V>
+void t_permute(int64_t n, int64_t m, I *rp, I *col, V *val, I *row_order, I *col_order,
+               I *rp_out, I *col_out, V *val_out) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)m, rp, col, val, format::kNotOwned, true);
+  permute::PermuteOrderTwo<I, I, V> p(row_order, col_order);
+  auto *out = p.GetPermutation(&csr, {&cpu}, false);
+  auto *ocsr = out->template As<format::CSR>();
+  const int64_t nnz = rp[n];
+  memcpy(rp_out, ocsr->get_row_ptr(), (n + 1) * sizeof(I));
+  memcpy(col_out, ocsr->get_col(), nnz * sizeof(I));
+  if constexpr (!std::is_same_v<V, void>)
+    if (val && val_out) memcpy(val_out, ocsr->get_vals(), nnz * sizeof(V));
+  // the permuted CSR does not own its arrays (permute_order_two.cc:76-77)
+  I *a = ocsr->get_row_ptr();
+  I *b = ocsr->get_col();
+  V *c = ocsr->get_vals();
+  delete ocsr;
+  delete[] a;
+  delete[] b;
+  if constexpr (!std::is_same_v<V, void>) delete[] c;
+}
+
+}  // namespace
+
+// (it, vt) -> concrete tuple.  vt: 0 void, 1 int32, 2 uint32 (unsigned tuple), 3 float, 6 double
+#define TUPLE_SWITCH(it, vt, F, ...)                                                     \
+  do {                                                                                   \
+    if ((it) == 0 && (vt) == 0) { F(int, void, __VA_ARGS__); }                           \
+    else if ((it) == 0 && (vt) == 1) { F(int, int, __VA_ARGS__); }                       \
+    else if ((it) == 0 && (vt) == 2) { F(unsigned, unsigned, __VA_ARGS__); }             \
+    else if ((it) == 0 && (vt) == 3) { F(int, float, __VA_ARGS__); }                     \
+    else if ((it) == 1 && (vt) == 0) { F(long long, void, __VA_ARGS__); }                \
+    else if ((it) == 1 && (vt) == 6) { F(long long, double, __VA_ARGS__); }              \
+    else return -2;                                                                      \
+  } while (0)
+
+extern "C" {
+
+#define F_COO_SORT(I, V, ...) t_coo_sort<I, V>(n, m, nnz, (I *)row, (I *)col, (V *)val)
+int ref_coo_sort(int it, int vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
+                 void *val) {
+  TUPLE_SWITCH(it, vt, F_COO_SORT, 0);
+  return 0;
+}
+#define F_CSR_SORT(I, V, ...) t_csr_sort<I, V>(n, m, (I *)rp, (I *)col, (V *)val)
+int ref_csr_sort_rows(int it, int vt, int64_t n, int64_t m, void *rp, void *col, void *val) {
+  TUPLE_SWITCH(it, vt, F_CSR_SORT, 0);
+  return 0;
+}
+#define F_COO_CSR(I, V, ...)                                                          \
+  t_coo_to_csr<I, V>(n, m, nnz, (I *)row, (I *)col, (V *)val, (I *)rp_out, (I *)col_out, \
+                     (V *)val_out)
+int ref_coo_to_csr(int it, int vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
+                   void *val, void *rp_out, void *col_out, void *val_out) {
+  TUPLE_SWITCH(it, vt, F_COO_CSR, 0);
+  return 0;
+}
+#define F_CSR_COO(I, V, ...)                                                          \
+  t_csr_to_coo<I, V>(n, m, nnz, (I *)rp, (I *)col, (V *)val, (I *)row_out, (I *)col_out, \
+                     (V *)val_out)
+int ref_csr_to_coo(int it, int vt, int64_t n, int64_t m, int64_t nnz, void *rp, void *col,
+                   void *val, void *row_out, void *col_out, void *val_out) {
+  TUPLE_SWITCH(it, vt, F_CSR_COO, 0);
+  return 0;
+}
+#define F_DEGREE(I, V, ...) t_degree<I, V>(n, m, (I *)rp, (I *)col, ascending, (I *)inv)
+int ref_degree_reorder(int it, int vt, int64_t n, int64_t m, void *rp, void *col, int ascending,
+                       void *inv) {
+  TUPLE_SWITCH(it, vt, F_DEGREE, 0);
+  return 0;
+}
+#define F_RCM(I, V, ...) t_rcm<I, V>(n, (I *)rp, (I *)col, (I *)inv)
+int ref_rcm_reorder(int it, int vt, int64_t n, void *rp, void *col, void *inv) {
+  TUPLE_SWITCH(it, vt, F_RCM, 0);
+  return 0;
+}
+#define F_GRAY(I, V, ...) t_gray<I, V>(n, m, (I *)rp, (I *)col, res, thr, grp, (I *)inv)
+int ref_gray_reorder(int it, int vt, int64_t n, int64_t m, void *rp, void *col, int res, int thr,
+                     int grp, void *inv) {
+  TUPLE_SWITCH(it, vt, F_GRAY, 0);
+  return 0;
+}
+#define F_PERMUTE(I, V, ...)                                                              \
+  t_permute<I, V>(n, m, (I *)rp, (I *)col, (V *)val, (I *)row_order, (I *)col_order,      \
+                  (I *)rp_out, (I *)col_out, (V *)val_out)
+int ref_permute_csr(int it, int vt, int64_t n, int64_t m, void *rp, void *col, void *val,
+                    void *row_order, void *col_order, void *rp_out, void *col_out,
+                    void *val_out) {
+  TUPLE_SWITCH(it, vt, F_PERMUTE, 0);
+  return 0;
+}
+
+}  // extern "C"
