@@ -1,0 +1,498 @@
+// sbx_convert.hip — COO/CSR constructor checks, COO sort and the COO<->CSR
+// conversion functions as HIP kernels for gfx950.
+//
+//   A1  format/coo.cc:96-157           sbx_coo_is_sorted, sbx_coo_sort
+//   A2  converter_order_two.cc:163-246 sbx_coo_to_csr   (copy + move)
+//   A3  converter_order_two.cc:72-160  sbx_csr_to_coo   (copy + move)
+//   A4  format/csr.cc:102-116          sbx_csr_rows_sorted (the sort itself: sbx_permute.hip)
+//
+// All three conversions are single-pass streaming kernels (HBM-bound):
+//   COO->CSR  row_ptr comes from row-boundary detection on the row-sorted row[]
+//             (identical to exclusive_scan(histogram) there); col/val are copied
+//             in the same pass with 16-byte accesses.  Unsorted row[] (only
+//             reachable with ignore_sort=true) takes the histogram+scan path.
+//   CSR->COO  each 2048-nnz tile finds its row span with a wave-wide 64-ary
+//             search, scatters row heads into LDS, max-scans them and streams
+//             row ids + col/val copies out.
+#include "sbx_device.h"
+#include "sbx_internal.h"
+
+namespace {
+
+constexpr int CV_THREADS = 256;
+
+// 16-byte vector for streaming copies
+struct alignas(16) vec16 {
+  uint32_t x, y, z, w;
+};
+
+// Workgroup-cooperative copy of bytes [b0,b1) (both multiples of 4).
+template <bool ALIGNED16>
+__device__ __forceinline__ void block_copy_bytes(char *__restrict__ dst, const char *__restrict__ src, int64_t b0,
+                                                 int64_t b1) {
+  if (ALIGNED16) {
+    const int64_t nvec = (b1 - b0) >> 4;
+    const vec16 *s = (const vec16 *)(src + b0);
+    vec16 *d = (vec16 *)(dst + b0);
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) d[i] = s[i];
+    const int64_t tail = b0 + (nvec << 4);
+    const int64_t nw = (b1 - tail) >> 2;
+    if ((int64_t)threadIdx.x < nw)
+      ((uint32_t *)(dst + tail))[threadIdx.x] = ((const uint32_t *)(src + tail))[threadIdx.x];
+  } else {
+    const int64_t nw = (b1 - b0) >> 2;
+    const uint32_t *s = (const uint32_t *)(src + b0);
+    uint32_t *d = (uint32_t *)(dst + b0);
+    for (int64_t i = threadIdx.x; i < nw; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+// ------------------------------------------------------------------ A1 check
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_coo_is_sorted(const I *__restrict__ row, const I *__restrict__ col,
+                                                              int64_t nnz, int *__restrict__ unsorted) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < nnz; i += stride) {
+    const I pr = i ? row[i - 1] : (I)0, pc = i ? col[i - 1] : (I)0;
+    const I r = row[i], c = col[i];
+    bad |= (pr > r) || (pr == r && pc > c);
+  }
+  if (__any(bad) && sbx_lane() == 0) *unsorted = 1;
+}
+
+// ------------------------------------------------------------------ A1 sort helpers
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_pack_rc(const I *__restrict__ row, const I *__restrict__ col,
+                                                        uint64_t *__restrict__ key, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) key[i] = ((uint64_t)(uint32_t)row[i] << 32) | (uint64_t)(uint32_t)col[i];
+}
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_unpack_rc(const uint64_t *__restrict__ key, I *__restrict__ row,
+                                                          I *__restrict__ col, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    const uint64_t k = key[i];
+    row[i] = (I)(uint32_t)(k >> 32);
+    col[i] = (I)(uint32_t)k;
+  }
+}
+
+// ------------------------------------------------------------------ A2 COO -> CSR
+constexpr int GAP_INLINE = 64;  // longer runs of empty rows go to the gap queue
+
+struct GapEntry {
+  int64_t first, last, value;  // row_ptr[first..last] = value
+};
+
+template <typename I>
+__device__ __forceinline__ void emit_row_starts(I *__restrict__ rp, int64_t prev, int64_t r, int64_t value,
+                                                GapEntry *__restrict__ gaps, unsigned *__restrict__ ngaps,
+                                                unsigned gap_cap) {
+  // rows prev+1 .. r start at `value`
+  const int64_t len = r - prev;
+  if (len <= 0) return;
+  if (len <= GAP_INLINE) {
+    for (int64_t q = prev + 1; q <= r; q++) rp[q] = (I)value;
+  } else {
+    const unsigned slot = atomicAdd(ngaps, 1u);
+    if (slot < gap_cap) {
+      gaps[slot].first = prev + 1;
+      gaps[slot].last = r;
+      gaps[slot].value = value;
+    }
+  }
+}
+
+// One thread = 4 consecutive nonzeros.  MOVE: only row_ptr is produced.
+template <typename I, int VB, bool MOVE, bool ALIGNED16>
+__global__ __launch_bounds__(CV_THREADS) void k_coo_to_csr(const I *__restrict__ row, const I *__restrict__ col,
+                                                           const char *__restrict__ val, I *__restrict__ rp,
+                                                           I *__restrict__ col_out, char *__restrict__ val_out,
+                                                           int64_t n, int64_t nnz, GapEntry *__restrict__ gaps,
+                                                           unsigned *__restrict__ ngaps, unsigned gap_cap,
+                                                           int *__restrict__ unsorted) {
+  const int64_t nquads = (nnz + 3) >> 2;
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; q < nquads; q += stride) {
+    const int64_t i0 = q << 2;
+    I r[4];
+    const bool full = (i0 + 4 <= nnz);
+    if (full && ALIGNED16 && sizeof(I) == 4) {
+      const vec16 v = *(const vec16 *)(row + i0);
+      r[0] = (I)v.x; r[1] = (I)v.y; r[2] = (I)v.z; r[3] = (I)v.w;
+      if (!MOVE) {
+        *(vec16 *)(col_out + i0) = *(const vec16 *)(col + i0);
+        if (VB == 4) *(vec16 *)(val_out + i0 * 4) = *(const vec16 *)(val + i0 * 4);
+        if (VB == 8) {
+          *(vec16 *)(val_out + i0 * 8) = *(const vec16 *)(val + i0 * 8);
+          *(vec16 *)(val_out + i0 * 8 + 16) = *(const vec16 *)(val + i0 * 8 + 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = i0 + k;
+        r[k] = i < nnz ? row[i] : (I)0;
+        if (!MOVE && i < nnz) {
+          col_out[i] = col[i];
+          if (VB == 4) ((uint32_t *)val_out)[i] = ((const uint32_t *)val)[i];
+          if (VB == 8) ((uint64_t *)val_out)[i] = ((const uint64_t *)val)[i];
+        }
+      }
+    }
+    int64_t prev = i0 ? (int64_t)row[i0 - 1] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = i0 + k;
+      if (i < nnz) {
+        const int64_t cur = (int64_t)r[k];
+        bad |= cur < prev;
+        emit_row_starts<I>(rp, prev, cur, i, gaps, ngaps, gap_cap);
+        prev = cur;
+        if (i == nnz - 1) emit_row_starts<I>(rp, cur, n, nnz, gaps, ngaps, gap_cap);
+      }
+    }
+  }
+  if (__any(bad) && sbx_lane() == 0) *unsorted = 1;
+}
+
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_fill_gaps(I *__restrict__ rp, const GapEntry *__restrict__ gaps,
+                                                          const unsigned *__restrict__ ngaps, unsigned gap_cap) {
+  unsigned cnt = *ngaps;
+  if (cnt > gap_cap) cnt = gap_cap;
+  for (unsigned g = blockIdx.x; g < cnt; g += gridDim.x) {
+    const GapEntry e = gaps[g];
+    for (int64_t q = e.first + threadIdx.x; q <= e.last; q += blockDim.x) rp[q] = (I)e.value;
+  }
+}
+
+// ------------------------------------------------------------------ A3 CSR -> COO
+constexpr int EX_ITEMS = 8;
+constexpr int EX_TILE = CV_THREADS * EX_ITEMS;  // 2048 nonzeros per workgroup
+
+template <typename I, int VB, bool MOVE, bool ALIGNED16>
+__global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__ rp, const I *__restrict__ col,
+                                                           const char *__restrict__ val, I *__restrict__ row_out,
+                                                           I *__restrict__ col_out, char *__restrict__ val_out,
+                                                           int64_t n, int64_t nnz) {
+  __shared__ int s_head[EX_TILE];
+  __shared__ int64_t s_span[2];
+  __shared__ int s_wmax[CV_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * EX_TILE;
+  const int64_t t1 = (t0 + EX_TILE < nnz) ? t0 + EX_TILE : nnz;
+  const int cnt = (int)(t1 - t0);
+#pragma unroll
+  for (int k = 0; k < EX_ITEMS; k++) s_head[k * CV_THREADS + tid] = 0;
+  // row span of the tile: r_lo = last row with rp[r] <= t0, r_hi likewise for t1-1
+  if (tid < 64) {
+    const int64_t lo = sbx_wave_upper_bound<I>(rp, n + 1, (I)t0) - 1;
+    if (tid == 0) s_span[0] = lo;
+  } else if (tid < 128) {
+    const int64_t hi = sbx_wave_upper_bound<I>(rp, n + 1, (I)(t1 - 1)) - 1;
+    if (tid == 64) s_span[1] = hi;
+  }
+  __syncthreads();
+  const int64_t r_lo = s_span[0], r_hi = s_span[1];
+  // scatter row heads (relative row number at the row's first position in the tile)
+  for (int64_t r = r_lo + 1 + tid; r <= r_hi; r += CV_THREADS) {
+    const int p = (int)((int64_t)rp[r] - t0);
+    atomicMax(&s_head[p], (int)(r - r_lo));
+  }
+  // streaming copies overlap with the LDS phase
+  if (!MOVE) {
+    block_copy_bytes<ALIGNED16>((char *)col_out, (const char *)col, t0 * (int64_t)sizeof(I), t1 * (int64_t)sizeof(I));
+    if (VB) block_copy_bytes<ALIGNED16>(val_out, val, t0 * VB, t1 * VB);
+  }
+  __syncthreads();
+  // inclusive max-scan, thread-blocked (8 consecutive positions per thread)
+  int h[EX_ITEMS];
+  int run = 0;
+#pragma unroll
+  for (int k = 0; k < EX_ITEMS; k++) {
+    h[k] = s_head[tid * EX_ITEMS + k];
+    run = h[k] > run ? h[k] : run;
+    h[k] = run;
+  }
+  const int inc = sbx_wave_inclusive_max(run);
+  int excl = __shfl_up(inc, 1, 64);
+  if (sbx_lane() == 0) excl = 0;
+  if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < (tid >> 6); w++) woff = s_wmax[w] > woff ? s_wmax[w] : woff;
+  const int before = excl > woff ? excl : woff;
+  const int64_t base = t0 + (int64_t)tid * EX_ITEMS;
+  I out[EX_ITEMS];
+#pragma unroll
+  for (int k = 0; k < EX_ITEMS; k++) out[k] = (I)(r_lo + (h[k] > before ? h[k] : before));
+  if (tid * EX_ITEMS + EX_ITEMS <= cnt && ALIGNED16 && sizeof(I) == 4) {
+    vec16 a, b;
+    a.x = (uint32_t)out[0]; a.y = (uint32_t)out[1]; a.z = (uint32_t)out[2]; a.w = (uint32_t)out[3];
+    b.x = (uint32_t)out[4]; b.y = (uint32_t)out[5]; b.z = (uint32_t)out[6]; b.w = (uint32_t)out[7];
+    *(vec16 *)(row_out + base) = a;
+    *(vec16 *)(row_out + base + 4) = b;
+  } else {
+#pragma unroll
+    for (int k = 0; k < EX_ITEMS; k++)
+      if (tid * EX_ITEMS + k < cnt) row_out[base + k] = out[k];
+  }
+}
+
+// A4 check (format/csr.cc:102-116), nnz-parallel so power-law rows stay balanced:
+// row heads of the tile are flagged in LDS, then every entry is compared with
+// its predecessor (or with 0 at a row head).
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_csr_rows_sorted(const I *__restrict__ rp, const I *__restrict__ col,
+                                                                int64_t n, int64_t nnz, int *__restrict__ unsorted) {
+  __shared__ int s_head[EX_TILE];
+  __shared__ int64_t s_span[2];
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * EX_TILE;
+  const int64_t t1 = (t0 + EX_TILE < nnz) ? t0 + EX_TILE : nnz;
+#pragma unroll
+  for (int k = 0; k < EX_ITEMS; k++) s_head[k * CV_THREADS + tid] = 0;
+  if (tid < 64) {
+    const int64_t lo = sbx_wave_upper_bound<I>(rp, n + 1, (I)t0) - 1;
+    if (tid == 0) s_span[0] = lo;
+  } else if (tid < 128) {
+    const int64_t hi = sbx_wave_upper_bound<I>(rp, n + 1, (I)(t1 - 1)) - 1;
+    if (tid == 64) s_span[1] = hi;
+  }
+  __syncthreads();
+  const int64_t r_lo = s_span[0], r_hi = s_span[1];
+  for (int64_t r = r_lo + 1 + tid; r <= r_hi; r += CV_THREADS) s_head[(int)((int64_t)rp[r] - t0)] = 1;
+  if (tid == 0 && (int64_t)rp[r_lo] == t0) s_head[0] = 1;
+  __syncthreads();
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < EX_ITEMS; k++) {
+    const int64_t j = t0 + k * CV_THREADS + tid;
+    if (j < t1) {
+      const I c = col[j];
+      const I p = s_head[k * CV_THREADS + tid] ? (I)0 : col[j - 1];
+      bad |= c < p;
+    }
+  }
+  if (__any(bad) && sbx_lane() == 0) *unsorted = 1;
+}
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+#define SBX_REQUIRE(h, cond, msg)                       \
+  do {                                                  \
+    if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
+  } while (0)
+
+#define SBX_ONLY_I32(h, it)                                                                  \
+  do {                                                                                       \
+    if ((it) != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "%s: 64-bit indices not built yet", __func__); \
+  } while (0)
+
+extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz, const void *row, const void *col,
+                                 int *sorted_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, sorted_host && nnz >= 0 && (nnz == 0 || (row && col)), "bad argument");
+  SBX_ONLY_I32(h, it);
+  SBX_TRY(sbx_arena_begin(h));
+  *sorted_host = 1;
+  if (nnz == 0) return SBX_OK;
+  int *flag = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &flag));
+  SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_coo_is_sorted<int32_t>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), 0,
+                     h->stream, (const int32_t *)row, (const int32_t *)col, nnz, flag);
+  SBX_LAUNCH_CHECK(h);
+  int f = 0;
+  SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
+  *sorted_host = !f;
+  return SBX_OK;
+}
+
+extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                                   const void *col, int *sorted_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, sorted_host && n >= 0 && row_ptr, "bad argument");
+  SBX_ONLY_I32(h, it);
+  SBX_TRY(sbx_arena_begin(h));
+  *sorted_host = 1;
+  if (n == 0) return SBX_OK;
+  int32_t nnz32 = 0;
+  SBX_TRY(sbx_readback(h, &nnz32, (const int32_t *)row_ptr + n, sizeof(int32_t)));  // nnz_ = row_ptr[n], csr.cc:86
+  const int64_t nnz = nnz32;
+  if (nnz == 0) return SBX_OK;
+  int *flag = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &flag));
+  SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_csr_rows_sorted<int32_t>, dim3((unsigned)((nnz + EX_TILE - 1) / EX_TILE)), dim3(CV_THREADS), 0,
+                     h->stream, (const int32_t *)row_ptr, (const int32_t *)col, n, nnz, flag);
+  SBX_LAUNCH_CHECK(h);
+  int f = 0;
+  SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
+  *sorted_host = !f;
+  return SBX_OK;
+}
+
+extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                            void *row, void *col, void *val) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, nnz >= 0 && n >= 0 && m >= 0 && (nnz == 0 || (row && col)), "bad argument");
+  SBX_ONLY_I32(h, it);
+  const int vb = val ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  if (nnz <= 1) return SBX_OK;
+  int sorted = 0;
+  SBX_TRY(sbx_coo_is_sorted(h, it, nnz, row, col, &sorted));  // format/coo.cc:96-108
+  if (sorted) return SBX_OK;
+  SBX_TRY(sbx_arena_begin(h));
+  uint64_t *ka = nullptr, *kb = nullptr;
+  char *vtmp = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
+  if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
+  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
+  hipLaunchKernelGGL(k_pack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), 0, h->stream, (const int32_t *)row,
+                     (const int32_t *)col, ka, nnz);
+  sbx_radix_pass passes[16];
+  const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
+                                32 + sbx_bits_for(n > 0 ? (uint64_t)(n - 1) : 0), passes);
+  int in_b = 0;
+  SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, passes, np, &in_b));
+  if (in_b && vb) SBX_HIP(h, hipMemcpyAsync(val, vtmp, (size_t)nnz * vb, hipMemcpyDeviceToDevice, h->stream));
+  hipLaunchKernelGGL(k_unpack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), 0, h->stream,
+                     (const uint64_t *)(in_b ? kb : ka), (int32_t *)row, (int32_t *)col, nnz);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+namespace {
+
+template <int VB, bool MOVE>
+int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *row, const int32_t *col, const char *val,
+                      int32_t *rp, int32_t *col_out, char *val_out, GapEntry *gaps, unsigned *ngaps, unsigned gap_cap,
+                      int *unsorted) {
+  const bool al = aligned16(row) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
+  const int64_t nquads = (nnz + 3) >> 2;
+  const unsigned grid = sbx_grid_for(nquads, CV_THREADS, (int64_t)h->num_cus * 32);
+  if (al)
+    hipLaunchKernelGGL((k_coo_to_csr<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), 0, h->stream, row, col,
+                       val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
+  else
+    hipLaunchKernelGGL((k_coo_to_csr<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), 0, h->stream, row, col,
+                       val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+template <int VB, bool MOVE>
+int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *col, const char *val,
+                      int32_t *row_out, int32_t *col_out, char *val_out) {
+  const bool al = aligned16(row_out) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
+  const unsigned grid = (unsigned)((nnz + EX_TILE - 1) / EX_TILE);
+  if (al)
+    hipLaunchKernelGGL((k_csr_to_coo<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), 0, h->stream, rp, col,
+                       val, row_out, col_out, val_out, n, nnz);
+  else
+    hipLaunchKernelGGL((k_csr_to_coo<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), 0, h->stream, rp, col,
+                       val, row_out, col_out, val_out, n, nnz);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+__global__ __launch_bounds__(CV_THREADS) void k_row_hist_i32(const int32_t *__restrict__ row,
+                                                             int32_t *__restrict__ cnt, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) atomicAdd(&cnt[row[i]], 1);
+}
+
+}  // namespace
+
+extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                              const void *row, const void *col, const void *val, void *row_ptr_out, void *col_out,
+                              void *val_out, unsigned flags) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  (void)m;
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr_out && (nnz == 0 || row), "bad argument");
+  SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
+  SBX_ONLY_I32(h, it);
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  int32_t *rp = (int32_t *)row_ptr_out;
+  if (nnz == 0) return sbx_fill_i32(h, rp, 0, n + 1);
+  const unsigned gap_cap = (unsigned)((n + 1) / GAP_INLINE + 2);
+  GapEntry *gaps = nullptr;
+  unsigned *ngaps = nullptr;
+  int *unsorted = nullptr;
+  SBX_TRY(sbx_salloc(h, gap_cap, &gaps));
+  SBX_TRY(sbx_salloc(h, 2, &ngaps));
+  unsorted = (int *)(ngaps + 1);
+  SBX_HIP(h, hipMemsetAsync(ngaps, 0, 2 * sizeof(unsigned), h->stream));
+  const int32_t *r = (const int32_t *)row, *c = (const int32_t *)col;
+  const char *v = (const char *)val;
+  int32_t *co = (int32_t *)col_out;
+  char *vo = (char *)val_out;
+  int rc;
+  if (move) rc = launch_coo_to_csr<0, true>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 0) rc = launch_coo_to_csr<0, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 4) rc = launch_coo_to_csr<4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else rc = launch_coo_to_csr<8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  SBX_TRY(rc);
+  hipLaunchKernelGGL(k_fill_gaps<int32_t>, dim3(256), dim3(CV_THREADS), 0, h->stream, rp, (const GapEntry *)gaps,
+                     (const unsigned *)ngaps, gap_cap);
+  SBX_LAUNCH_CHECK(h);
+  if (!(flags & SBX_FLAG_ROWS_SORTED)) {
+    // unsorted row[] is only reachable with ignore_sort=true; the reference then
+    // still produces exclusive_scan(histogram(row)) (converter_order_two.cc:180-192)
+    int f = 0;
+    SBX_TRY(sbx_readback(h, &f, unsorted, sizeof(int)));
+    if (f) {
+      SBX_TRY(sbx_fill_i32(h, rp, 0, n + 1));
+      hipLaunchKernelGGL(k_row_hist_i32, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), 0, h->stream, r,
+                         rp, nnz);
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(sbx_exclusive_scan_i32(h, rp, rp, n + 1, nullptr));
+    }
+  }
+  return SBX_OK;
+}
+
+extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                              const void *row_ptr, const void *col, const void *val, void *row_out, void *col_out,
+                              void *val_out, unsigned flags) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  (void)m;
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || row_out), "bad argument");
+  SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
+  SBX_ONLY_I32(h, it);
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  if (nnz == 0) return SBX_OK;
+  const int32_t *rp = (const int32_t *)row_ptr, *c = (const int32_t *)col;
+  const char *v = (const char *)val;
+  int32_t *ro = (int32_t *)row_out, *co = (int32_t *)col_out;
+  char *vo = (char *)val_out;
+  if (move) return launch_csr_to_coo<0, true>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 0) return launch_csr_to_coo<0, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 4) return launch_csr_to_coo<4, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  return launch_csr_to_coo<8, false>(h, n, nnz, rp, c, v, ro, co, vo);
+}

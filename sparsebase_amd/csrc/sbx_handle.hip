@@ -1,0 +1,243 @@
+// sbx_handle.hip — handle life-cycle, scratch arena, memory/device utilities.
+// Replaces the raw CUDA runtime calls of the reference's device formats
+// (converter/converter_order_two_cuda.cu:11-105, context/cuda_context_cuda.cu:9-21,
+// converter/converter_cuda.cu:12-21) behind the C ABI of include/sbx.h.
+#include "sbx_internal.h"
+
+#include <new>
+
+static const size_t kArenaAlign = 256;
+static const size_t kPinnedBytes = 1 << 16;
+
+extern "C" int sbx_version(void) { return SBX_VERSION; }
+
+extern "C" const char *sbx_status_string(int status) {
+  switch (status) {
+    case SBX_OK: return "ok";
+    case SBX_ERR_BAD_ARG: return "bad argument";
+    case SBX_ERR_NO_DEVICE: return "no usable HIP device";
+    case SBX_ERR_HIP: return "HIP runtime error";
+    case SBX_ERR_OOM: return "out of device memory";
+    case SBX_ERR_UNSUPPORTED: return "unsupported type tuple or shape";
+    case SBX_ERR_INTERNAL: return "internal error";
+  }
+  return "unknown status";
+}
+
+extern "C" int sbx_device_count(int *count_host) {
+  if (!count_host) return SBX_ERR_BAD_ARG;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count_host = 0;
+    (void)hipGetLastError();
+    return SBX_ERR_NO_DEVICE;
+  }
+  *count_host = c;
+  return SBX_OK;
+}
+
+extern "C" int sbx_can_access_peer(int device, int peer_device, int *can_host) {
+  if (!can_host) return SBX_ERR_BAD_ARG;
+  if (device == peer_device) {
+    *can_host = 1;
+    return SBX_OK;
+  }
+  int can = 0;
+  hipError_t e = hipDeviceCanAccessPeer(&can, device, peer_device);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *can_host = 0;
+    return SBX_ERR_HIP;
+  }
+  *can_host = can;
+  return SBX_OK;
+}
+
+extern "C" int sbx_create(int device, sbx_handle_t *out) {
+  if (!out) return SBX_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return SBX_ERR_NO_DEVICE;  // loud: there is no CPU fallback behind this ABI
+  }
+  if (device < 0 || device >= count) return SBX_ERR_BAD_ARG;
+  sbx_handle_s *h = new (std::nothrow) sbx_handle_s();
+  if (!h) return SBX_ERR_INTERNAL;
+  h->device = device;
+  h->stream = nullptr;
+  h->cur_block = 0;
+  h->cur_off = 0;
+  h->call_bytes = 0;
+  h->high_water = 0;
+  h->pinned = nullptr;
+  h->pinned_bytes = 0;
+  h->err[0] = 0;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete h;
+    return SBX_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  h->num_cus = 256;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+  if (hipHostMalloc(&h->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+    delete h;
+    return SBX_ERR_OOM;
+  }
+  h->pinned_bytes = kPinnedBytes;
+  *out = h;
+  return SBX_OK;
+}
+
+extern "C" int sbx_destroy(sbx_handle_t h) {
+  if (!h) return SBX_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto &b : h->blocks) (void)hipFree(b.ptr);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  delete h;
+  return SBX_OK;
+}
+
+extern "C" int sbx_set_stream(sbx_handle_t h, void *hip_stream) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  h->stream = (hipStream_t)hip_stream;
+  return SBX_OK;
+}
+
+extern "C" int sbx_get_device(sbx_handle_t h, int *device_host) {
+  if (!h || !device_host) return SBX_ERR_BAD_ARG;
+  *device_host = h->device;
+  return SBX_OK;
+}
+
+extern "C" const char *sbx_last_error(sbx_handle_t h) { return h ? h->err : "null handle"; }
+
+extern "C" int sbx_sync(sbx_handle_t h) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  SBX_HIP(h, hipStreamSynchronize(h->stream));
+  return SBX_OK;
+}
+
+static int arena_add_block(sbx_handle_t h, size_t bytes) {
+  sbx_block b;
+  b.cap = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+  b.ptr = nullptr;
+  hipError_t e = hipMalloc((void **)&b.ptr, b.cap);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    SBX_FAIL(h, SBX_ERR_OOM, "scratch arena: hipMalloc(%zu) failed: %s", b.cap, hipGetErrorString(e));
+  }
+  h->blocks.push_back(b);
+  return SBX_OK;
+}
+
+extern "C" int sbx_reserve(sbx_handle_t h, size_t scratch_bytes) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  size_t have = 0;
+  if (h->blocks.size() == 1) have = h->blocks[0].cap;
+  if (have >= scratch_bytes) return SBX_OK;
+  SBX_HIP(h, hipStreamSynchronize(h->stream));
+  for (auto &b : h->blocks) (void)hipFree(b.ptr);
+  h->blocks.clear();
+  h->cur_block = 0;
+  h->cur_off = 0;
+  return arena_add_block(h, scratch_bytes);
+}
+
+int sbx_arena_begin(sbx_handle_t h) {
+  SBX_HIP(h, hipSetDevice(h->device));
+  if (h->blocks.size() > 1) {
+    // the previous call overflowed the first block: consolidate to one block
+    size_t total = 0;
+    for (auto &b : h->blocks) total += b.cap;
+    SBX_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto &b : h->blocks) (void)hipFree(b.ptr);
+    h->blocks.clear();
+    SBX_TRY(arena_add_block(h, total + total / 8));
+  }
+  h->cur_block = 0;
+  h->cur_off = 0;
+  h->call_bytes = 0;
+  return SBX_OK;
+}
+
+int sbx_arena_alloc(sbx_handle_t h, size_t bytes, void **out) {
+  bytes = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+  if (bytes == 0) bytes = kArenaAlign;
+  while (true) {
+    if (h->cur_block < h->blocks.size()) {
+      sbx_block &b = h->blocks[h->cur_block];
+      if (h->cur_off + bytes <= b.cap) {
+        *out = b.ptr + h->cur_off;
+        h->cur_off += bytes;
+        h->call_bytes += bytes;
+        if (h->call_bytes > h->high_water) h->high_water = h->call_bytes;
+        return SBX_OK;
+      }
+      h->cur_block++;
+      h->cur_off = 0;
+      continue;
+    }
+    size_t want = bytes;
+    if (!h->blocks.empty() && h->blocks.back().cap > want) want = h->blocks.back().cap;
+    if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+    SBX_TRY(arena_add_block(h, want));
+  }
+}
+
+int sbx_readback(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes) {
+  if (bytes > h->pinned_bytes) SBX_FAIL(h, SBX_ERR_INTERNAL, "readback of %zu bytes too large", bytes);
+  SBX_HIP(h, hipMemcpyAsync(h->pinned, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  SBX_HIP(h, hipStreamSynchronize(h->stream));
+  memcpy(dst_host, h->pinned, bytes);
+  return SBX_OK;
+}
+
+extern "C" int sbx_malloc(sbx_handle_t h, size_t bytes, void **dev_ptr_host) {
+  if (!h || !dev_ptr_host) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  *dev_ptr_host = nullptr;
+  if (bytes == 0) bytes = 1;
+  SBX_HIP(h, hipMalloc(dev_ptr_host, bytes));
+  return SBX_OK;
+}
+
+extern "C" int sbx_free(sbx_handle_t h, void *dev_ptr) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (!dev_ptr) return SBX_OK;
+  SBX_HIP(h, hipSetDevice(h->device));
+  SBX_HIP(h, hipFree(dev_ptr));
+  return SBX_OK;
+}
+
+static int copy_blocking(sbx_handle_t h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  if (!h || (bytes && (!dst || !src))) return SBX_ERR_BAD_ARG;
+  if (bytes == 0) return SBX_OK;
+  SBX_HIP(h, hipSetDevice(h->device));
+  SBX_HIP(h, hipMemcpyAsync(dst, src, bytes, kind, h->stream));
+  SBX_HIP(h, hipStreamSynchronize(h->stream));
+  return SBX_OK;
+}
+
+extern "C" int sbx_memcpy_h2d(sbx_handle_t h, void *dst_dev, const void *src_host, size_t bytes) {
+  return copy_blocking(h, dst_dev, src_host, bytes, hipMemcpyHostToDevice);
+}
+extern "C" int sbx_memcpy_d2h(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes) {
+  return copy_blocking(h, dst_host, src_dev, bytes, hipMemcpyDeviceToHost);
+}
+extern "C" int sbx_memcpy_d2d(sbx_handle_t h, void *dst_dev, const void *src_dev, size_t bytes) {
+  return copy_blocking(h, dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice);
+}
+extern "C" int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, const void *src_dev,
+                               int src_device, size_t bytes) {
+  if (!h || (bytes && (!dst_dev || !src_dev))) return SBX_ERR_BAD_ARG;
+  if (bytes == 0) return SBX_OK;
+  SBX_HIP(h, hipSetDevice(h->device));
+  SBX_HIP(h, hipMemcpyPeerAsync(dst_dev, dst_device, src_dev, src_device, bytes, h->stream));
+  SBX_HIP(h, hipStreamSynchronize(h->stream));
+  return SBX_OK;
+}

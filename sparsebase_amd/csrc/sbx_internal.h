@@ -1,0 +1,125 @@
+// sbx_internal.h — handle, scratch arena and launch helpers shared by the HIP
+// translation units of libsbx.  gfx950 (MI355X) only: wave64, 160 KiB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sbx.h"
+
+#define SBX_WAVE 64
+
+struct sbx_block {
+  char *ptr;
+  size_t cap;
+};
+
+struct sbx_handle_s {
+  int device;
+  hipStream_t stream;
+  // grow-only scratch arena: a list of device blocks, bump-allocated per call.
+  // After a call that needed more than one block the arena is consolidated
+  // into a single block, so steady-state calls never reach hipMalloc.
+  std::vector<sbx_block> blocks;
+  size_t cur_block;
+  size_t cur_off;
+  size_t call_bytes;  // bytes handed out during the current call
+  size_t high_water;
+  void *pinned;  // small pinned host buffer for device->host read-backs
+  size_t pinned_bytes;
+  int num_cus;
+  char err[512];
+};
+
+#define SBX_FAIL(h, code, ...)                       \
+  do {                                               \
+    snprintf((h)->err, sizeof((h)->err), __VA_ARGS__); \
+    return (code);                                   \
+  } while (0)
+
+#define SBX_HIP(h, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      snprintf((h)->err, sizeof((h)->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,  \
+               hipGetErrorString(e_));                                                    \
+      return e_ == hipErrorOutOfMemory ? SBX_ERR_OOM : SBX_ERR_HIP;                       \
+    }                                                                                     \
+  } while (0)
+
+#define SBX_TRY(expr)            \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != SBX_OK) return rc_; \
+  } while (0)
+
+#define SBX_LAUNCH_CHECK(h) SBX_HIP(h, hipGetLastError())
+
+// ---- arena -----------------------------------------------------------------
+int sbx_arena_begin(sbx_handle_t h);  // start of an API call: rewinds (and consolidates)
+int sbx_arena_alloc(sbx_handle_t h, size_t bytes, void **out);
+
+template <typename T>
+static inline int sbx_salloc(sbx_handle_t h, size_t count, T **out) {
+  void *p = nullptr;
+  int rc = sbx_arena_alloc(h, count * sizeof(T), &p);
+  *out = (T *)p;
+  return rc;
+}
+
+// blocking read-back of `bytes` (<= pinned buffer) from device memory
+int sbx_readback(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes);
+
+static inline int sbx_value_bytes(sbx_value_type vt) {
+  switch (vt) {
+    case SBX_V_NONE: return 0;
+    case SBX_V_I32: case SBX_V_U32: case SBX_V_F32: return 4;
+    case SBX_V_I64: case SBX_V_U64: case SBX_V_F64: return 8;
+  }
+  return -1;
+}
+static inline int sbx_index_bytes(sbx_index_type it) { return it == SBX_I32 ? 4 : 8; }
+
+static inline int sbx_bits_for(uint64_t max_value) {  // bits needed to represent values 0..max_value
+  int b = 0;
+  while (max_value) { b++; max_value >>= 1; }
+  return b;
+}
+
+static inline unsigned sbx_grid_for(int64_t work_items, int per_block, int64_t cap) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+// ---- primitives implemented in sbx_prims.hip --------------------------------
+// exclusive prefix sum; in == out allowed.  If total_out != nullptr the grand
+// total is stored there (device pointer).  T in {int32,int64,uint32,uint64}.
+int sbx_exclusive_scan_i32(sbx_handle_t h, const int32_t *in, int32_t *out, int64_t count,
+                           int32_t *total_out);
+int sbx_exclusive_scan_i64(sbx_handle_t h, const int64_t *in, int64_t *out, int64_t count,
+                           int64_t *total_out);
+int sbx_exclusive_scan_u32(sbx_handle_t h, const uint32_t *in, uint32_t *out, int64_t count,
+                           uint32_t *total_out);
+
+// A radix pass covers key bits [shift, shift+bits), bits <= 8.
+struct sbx_radix_pass {
+  int shift;
+  int bits;
+};
+// builds the pass list for significant bit ranges [lo0,hi0) u [lo1,hi1) (second may be empty)
+int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes /*>=16*/);
+
+// Stable LSD radix sort.  keys_a/vals_a hold the input; *_b are same-sized
+// temporaries.  payload_bytes in {0,4,8}; key_bytes in {4,8}.  On return
+// *result_in_b tells which buffer holds the sorted sequence.
+int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_a, void *keys_b,
+                   void *vals_a, void *vals_b, int64_t count, const sbx_radix_pass *passes,
+                   int num_passes, int *result_in_b);
+
+int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count);
+int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);

@@ -1,0 +1,564 @@
+// sbx_permute.hip — permutation apply and the CSR-constructor row sort.
+//
+//   A5  permute/permute_order_two.cc:23-79   sbx_permute_csr, sbx_permute_csr_rows
+//   A4  format/csr.cc:118-157                sbx_csr_sort_rows (and the sort A5 ends in)
+//   A13 bases/reorder_base.h:663-672         sbx_inverse_permutation
+//       permute/permute_order_one.cc:18-37   sbx_permute_array
+//
+// Data flow of one permute (new rows [row_begin,row_end) — the multi-GPU shard):
+//   k_invert        old_of_new[row_order[i]] = i                          (4n B r/w)
+//   k_new_degrees   row lengths in new order, long rows listed            (8n B)
+//   scan            -> row_ptr_out
+//   k_permute_tile  one workgroup per 1024 output nonzeros: gathers whole old rows
+//                   (col relabelled through col_order) into LDS, sorts every row
+//                   of <= 1024 entries there (all-pairs ranking for rows <= 32,
+//                   per-wave bitonic network otherwise) and streams them out.
+//   long rows       rows > 1024 entries: gathered into a compact buffer, sorted by
+//                   (row, col) with the device radix sort, scattered back.
+//   k_fix_dup_runs  only if some row was unsorted AND duplicate columns exist:
+//                   orders equal-column runs by value (std::less<pair<col,val>>).
+// HBM traffic per nonzero in the tile path is the compulsory 2*(I+V) bytes.
+#include "sbx_device.h"
+#include "sbx_internal.h"
+
+namespace {
+
+constexpr int PT_THREADS = 256;
+constexpr int PT_TILE = 1024;        // rows up to this many entries are sorted in LDS
+constexpr int PT_CAP = 2 * PT_TILE;  // LDS capacity of one tile, in entries
+constexpr int PT_ITEMS = PT_CAP / PT_THREADS;
+constexpr int PT_SHORT = 32;         // all-pairs rank sort up to this row length
+constexpr int PT_MAXMED = PT_CAP / (PT_SHORT + 1) + 2;
+
+struct PermState {            // device-resident flags/counters of one call
+  unsigned any_unsorted;      // some row had col[j] < col[j-1] after relabelling (csr.cc:102-116)
+  unsigned any_dup;           // some row holds a duplicate column
+  unsigned n_long;            // rows longer than PT_TILE
+  unsigned pad;
+  unsigned long long long_nnz;
+  unsigned long long total;   // nnz of the shard
+};
+
+template <int VB> struct ValT { typedef uint32_t type; };
+template <> struct ValT<8> { typedef uint64_t type; };
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_invert(const I *__restrict__ order, I *__restrict__ inv, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) inv[order[i]] = (I)i;
+}
+
+template <typename I, int VB>
+__global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ order, const char *__restrict__ vals,
+                                                       char *__restrict__ out, int64_t n) {
+  typedef typename ValT<VB>::type V;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) ((V *)out)[order[i]] = ((const V *)vals)[i];
+}
+
+// new-order row lengths for rows [rb0, rb0+nr); entry nr is zeroed for the scan
+template <typename I>
+__global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, const I *__restrict__ old_of_new,
+                                                     I *__restrict__ rpo, int64_t rb0, int64_t nr,
+                                                     I *__restrict__ long_rows, PermState *__restrict__ st) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i <= nr; i += stride) {
+    if (i == nr) {
+      rpo[i] = 0;
+      continue;
+    }
+    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + i] : rb0 + i;
+    const I d = rp[u + 1] - rp[u];
+    rpo[i] = d;
+    if (d > PT_TILE) {
+      const unsigned slot = atomicAdd(&st->n_long, 1u);
+      long_rows[slot] = (I)i;
+      atomicAdd(&st->long_nnz, (unsigned long long)d);
+    }
+  }
+}
+
+template <typename I>
+__global__ void k_store_total(const I *__restrict__ rpo, int64_t nr, PermState *__restrict__ st) {
+  st->total = (unsigned long long)rpo[nr];
+}
+
+// ---- wave-level bitonic network over LDS, arbitrary length -------------------
+// All comparators are ascending (first step of each merge is the mirrored
+// "flip"), so virtual +inf padding past `len` is never moved and an already
+// sorted row is left untouched.
+template <typename V, bool HASV>
+__device__ __forceinline__ void wave_bitonic_lds(volatile int *c, volatile V *v, int len) {
+  const int lane = sbx_lane();
+  int p2 = 1;
+  while (p2 < len) p2 <<= 1;
+  const int pairs = p2 >> 1;
+  for (int k = 2; k <= p2; k <<= 1) {
+    const int half = k >> 1;
+    // flip step: i = b*k + off, l = b*k + (k-1-off)
+    for (int q = lane; q < pairs; q += 64) {
+      const int b = q / half, off = q - b * half;
+      const int i = b * k + off, l = b * k + (k - 1 - off);
+      if (l < len) {
+        const int ci = c[i], cl = c[l];
+        if (ci > cl) {
+          c[i] = cl; c[l] = ci;
+          if (HASV) { const V t = v[i]; v[i] = v[l]; v[l] = t; }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = half >> 1; j > 0; j >>= 1) {
+      for (int q = lane; q < pairs; q += 64) {
+        const int i = 2 * j * (q / j) + (q % j), l = i + j;
+        if (l < len) {
+          const int ci = c[i], cl = c[l];
+          if (ci > cl) {
+            c[i] = cl; c[l] = ci;
+            if (HASV) { const V t = v[i]; v[i] = v[l]; v[l] = t; }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---- the tile kernel ----------------------------------------------------------
+// IDENT: csr_sort_rows mode (no row/col maps, input == output arrays allowed).
+template <typename I, int VB>
+__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
+    const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
+    const I *__restrict__ col_order, const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, int64_t rb0,
+    PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  constexpr bool HASV = VB != 0;
+  __shared__ int s_col[PT_CAP];
+  __shared__ V s_val[HASV ? PT_CAP : 1];
+  __shared__ int s_row[PT_CAP];
+  __shared__ int s_med[PT_MAXMED];
+  __shared__ int s_nmed;
+  __shared__ int64_t s_span[2];
+  __shared__ int s_wmax[PT_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t lo_t = (int64_t)blockIdx.x * PT_TILE, hi_t = lo_t + PT_TILE;
+
+  if (tid < 64) {
+    const int64_t a = sbx_wave_upper_bound<I>(rpo, nr + 1, (I)(lo_t - 1));  // first row starting at >= lo_t
+    if (tid == 0) s_span[0] = a;
+  } else if (tid < 128) {
+    const int64_t total = (int64_t)rpo[nr];
+    int64_t b = nr;
+    if (hi_t - 1 < total) b = sbx_wave_upper_bound<I>(rpo, nr + 1, (I)(hi_t - 1));
+    if (tid == 64) s_span[1] = b > nr ? nr : b;
+  }
+  if (tid == 0) s_nmed = 0;
+#pragma unroll
+  for (int k = 0; k < PT_ITEMS; k++) s_row[k * PT_THREADS + tid] = 0;
+  __syncthreads();
+  const int64_t ra = s_span[0];
+  int64_t rb = s_span[1];
+  if (ra >= rb) return;
+  if ((int64_t)rpo[rb] - (int64_t)rpo[rb - 1] > PT_TILE) rb--;  // a long row can only be the last one
+  if (ra >= rb) return;
+  const int64_t e0 = rpo[ra];
+  const int cnt = (int)((int64_t)rpo[rb] - e0);
+  if (cnt == 0) return;
+
+  // element -> local row map: scatter row heads, then inclusive max-scan
+  for (int64_t r = ra + 1 + tid; r < rb; r += PT_THREADS) {
+    const int p = (int)((int64_t)rpo[r] - e0);
+    if (p < cnt) atomicMax(&s_row[p], (int)(r - ra));
+  }
+  __syncthreads();
+  {
+    int hv[PT_ITEMS];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+      const int x = s_row[tid * PT_ITEMS + k];
+      run = x > run ? x : run;
+      hv[k] = run;
+    }
+    const int inc = sbx_wave_inclusive_max(run);
+    int excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0;
+    if (lane == 63) s_wmax[wv] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff = s_wmax[w] > woff ? s_wmax[w] : woff;
+    const int before = excl > woff ? excl : woff;
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) s_row[tid * PT_ITEMS + k] = hv[k] > before ? hv[k] : before;
+  }
+  __syncthreads();
+
+  // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
+  for (int p = tid; p < cnt; p += PT_THREADS) {
+    const int64_t r = ra + s_row[p];
+    const int64_t s = (int64_t)rpo[r] - e0;
+    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
+    const int64_t src = (int64_t)rp_in[u] + (p - s);
+    I c = col_in[src];
+    if (col_order) c = col_order[c];
+    s_col[p] = (int)c;
+    if (HASV) s_val[p] = ((const V *)val_in)[src];
+  }
+  __syncthreads();
+
+  // short rows: all-pairs stable ranking, written straight to their final slot
+  bool unsorted = false, dup = false;
+  for (int p = tid; p < cnt; p += PT_THREADS) {
+    const int64_t r = ra + s_row[p];
+    const int s = (int)((int64_t)rpo[r] - e0);
+    const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
+    const int c = s_col[p];
+    if (p > s && c < s_col[p - 1]) unsorted = true;
+    if (len <= PT_SHORT) {
+      int rank = 0;
+      for (int j = s; j < s + len; j++) {
+        const int cj = s_col[j];
+        rank += (cj < c) || (cj == c && j < p);
+        dup |= (cj == c) && (j != p);
+      }
+      const int64_t o = e0 + s + rank;
+      col_out[o] = (I)c;
+      if (HASV) ((V *)val_out)[o] = s_val[p];
+    } else if (p == s) {
+      const int slot = atomicAdd(&s_nmed, 1);
+      s_med[slot] = s_row[p];
+    }
+  }
+  __syncthreads();
+
+  // medium rows: one wave per row, bitonic network in LDS, coalesced write-out
+  const int nmed = s_nmed;
+  for (int k = wv; k < nmed; k += PT_THREADS / 64) {
+    const int64_t r = ra + s_med[k];
+    const int s = (int)((int64_t)rpo[r] - e0);
+    const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
+    wave_bitonic_lds<V, HASV>(s_col + s, s_val + (HASV ? s : 0), len);
+    for (int j = lane; j < len; j += 64) {
+      const int c = s_col[s + j];
+      if (j && c == s_col[s + j - 1]) dup = true;
+      col_out[e0 + s + j] = (I)c;
+      if (HASV) ((V *)val_out)[e0 + s + j] = s_val[s + j];
+    }
+  }
+  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+  if (__any(dup) && lane == 0) st->any_dup = 1;
+}
+
+// ---- long rows ----------------------------------------------------------------
+template <typename I, int VB>
+__global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in, const I *col_in, const char *val_in,
+                                                     const I *__restrict__ old_of_new, const I *__restrict__ col_order,
+                                                     const I *__restrict__ rpo, const I *__restrict__ long_rows,
+                                                     const uint32_t *__restrict__ loff, int n_long, int64_t rb0,
+                                                     uint64_t *__restrict__ keys, char *__restrict__ pay,
+                                                     PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  bool unsorted = false;
+  for (int k = blockIdx.x; k < n_long; k += gridDim.x) {
+    const int64_t r = long_rows[k];
+    const int64_t len = (int64_t)rpo[r + 1] - (int64_t)rpo[r];
+    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
+    const int64_t src0 = rp_in[u];
+    const uint32_t o0 = loff[k];
+    for (int64_t j = threadIdx.x; j < len; j += blockDim.x) {
+      I c = col_in[src0 + j];
+      if (col_order) c = col_order[c];
+      if (j) {
+        I pc = col_in[src0 + j - 1];
+        if (col_order) pc = col_order[pc];
+        unsorted |= c < pc;
+      }
+      keys[o0 + j] = ((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)c;
+      if (VB) ((V *)pay)[o0 + j] = ((const V *)val_in)[src0 + j];
+    }
+  }
+  if (__any(unsorted) && sbx_lane() == 0) st->any_unsorted = 1;
+}
+
+template <typename I, int VB>
+__global__ __launch_bounds__(256) void k_long_scatter(const uint64_t *__restrict__ keys, const char *__restrict__ pay,
+                                                      const I *__restrict__ rpo, const I *__restrict__ long_rows,
+                                                      const uint32_t *__restrict__ loff, int64_t long_nnz,
+                                                      I *__restrict__ col_out, char *__restrict__ val_out,
+                                                      PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool dup = false;
+  for (; p < long_nnz; p += stride) {
+    const uint64_t key = keys[p];
+    const uint32_t k = (uint32_t)(key >> 32);
+    const int64_t o = (int64_t)rpo[long_rows[k]] + (p - (int64_t)loff[k]);
+    col_out[o] = (I)(uint32_t)key;
+    if (VB) ((V *)val_out)[o] = ((const V *)pay)[p];
+    if (p && keys[p - 1] == key) dup = true;
+  }
+  if (__any(dup) && sbx_lane() == 0) st->any_dup = 1;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_long_lengths(const I *__restrict__ rpo, const I *__restrict__ long_rows,
+                                                      uint32_t *__restrict__ len, int n_long) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_long) len[k] = (uint32_t)(rpo[long_rows[k] + 1] - rpo[long_rows[k]]);
+}
+
+// ---- duplicate-column fix-up (format/csr.cc:143-156 pair ordering) -------------
+template <sbx_value_type VT> struct Typed;
+template <> struct Typed<SBX_V_I32> { typedef int32_t T; };
+template <> struct Typed<SBX_V_U32> { typedef uint32_t T; };
+template <> struct Typed<SBX_V_F32> { typedef float T; };
+template <> struct Typed<SBX_V_I64> { typedef int64_t T; };
+template <> struct Typed<SBX_V_U64> { typedef uint64_t T; };
+template <> struct Typed<SBX_V_F64> { typedef double T; };
+
+template <typename I, typename T>
+__global__ __launch_bounds__(256) void k_fix_dup_runs(const I *__restrict__ rpo, const I *__restrict__ col,
+                                                      T *__restrict__ val, int64_t nr,
+                                                      const PermState *__restrict__ st) {
+  if (!(st->any_unsorted && st->any_dup)) return;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < nr; r += stride) {
+    const int64_t s = rpo[r], e = rpo[r + 1];
+    int64_t a = s;
+    while (a < e) {
+      int64_t b = a + 1;
+      while (b < e && col[b] == col[a]) b++;
+      for (int64_t i = a + 1; i < b; i++) {  // insertion sort of the run by value
+        const T x = val[i];
+        int64_t j = i;
+        while (j > a && x < val[j - 1]) {
+          val[j] = val[j - 1];
+          j--;
+        }
+        val[j] = x;
+      }
+      a = b;
+    }
+  }
+}
+
+template <typename I>
+int launch_fix(sbx_handle_t h, sbx_value_type vt, const I *rpo, const I *col, void *val, int64_t nr, PermState *st) {
+  const unsigned grid = sbx_grid_for(nr, 256, 4096);
+#define FIX(VT)                                                                                              \
+  case VT:                                                                                                   \
+    hipLaunchKernelGGL((k_fix_dup_runs<I, typename Typed<VT>::T>), dim3(grid), dim3(256), 0, h->stream, rpo, col, \
+                       (typename Typed<VT>::T *)val, nr, (const PermState *)st);                            \
+    break;
+  switch (vt) {
+    FIX(SBX_V_I32) FIX(SBX_V_U32) FIX(SBX_V_F32) FIX(SBX_V_I64) FIX(SBX_V_U64) FIX(SBX_V_F64)
+    default: return SBX_OK;
+  }
+#undef FIX
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+// Sort stage shared by permute and csr_sort_rows: rows of `rpo` (nr rows, already
+// on device) are produced from the source CSR through the row/col maps.
+template <int VB>
+int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const int32_t *col_in, const char *val_in,
+               const int32_t *old_of_new, const int32_t *col_order, const int32_t *rpo, int32_t *col_out,
+               char *val_out, int64_t nr, int64_t rb0, int64_t m, int64_t total, const int32_t *long_rows,
+               unsigned n_long, int64_t long_nnz, PermState *st) {
+  typedef int32_t I;
+  if (total > 0) {
+    const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
+    hipLaunchKernelGGL((k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), 0, h->stream, rp_in, col_in, val_in,
+                       old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st);
+    SBX_LAUNCH_CHECK(h);
+  }
+  if (n_long) {
+    uint32_t *loff = nullptr;
+    uint64_t *ka = nullptr, *kb = nullptr;
+    char *pa = nullptr, *pb = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &loff));
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &ka));
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &kb));
+    if (VB) {
+      SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pa));
+      SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pb));
+    }
+    hipLaunchKernelGGL(k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), 0, h->stream, rpo, long_rows, loff,
+                       (int)n_long);
+    SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
+    hipLaunchKernelGGL((k_long_gather<I, VB>), dim3(n_long < 4096 ? n_long : 4096), dim3(256), 0, h->stream, rp_in,
+                       col_in, val_in, old_of_new, col_order, rpo, long_rows, (const uint32_t *)loff, (int)n_long, rb0,
+                       ka, pa, st);
+    SBX_LAUNCH_CHECK(h);
+    sbx_radix_pass passes[16];
+    const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
+                                  32 + sbx_bits_for((uint64_t)(n_long - 1)), passes);
+    int in_b = 0;
+    SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
+    hipLaunchKernelGGL((k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), 0, h->stream,
+                       (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
+                       (const uint32_t *)loff, long_nnz, col_out, val_out, st);
+    SBX_LAUNCH_CHECK(h);
+  }
+  if (VB) SBX_TRY(launch_fix<I>(h, vt, rpo, col_out, val_out, nr, st));
+  return SBX_OK;
+}
+
+}  // namespace
+
+#define SBX_REQUIRE(h, cond, msg)                                       \
+  do {                                                                  \
+    if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
+  } while (0)
+#define SBX_ONLY_I32(h, it)                                                                              \
+  do {                                                                                                   \
+    if ((it) != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "%s: 64-bit indices not built yet", __func__); \
+  } while (0)
+
+extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_t n, const void *perm,
+                                       void *inv_out) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && (n == 0 || (perm && inv_out)), "bad argument");
+  SBX_ONLY_I32(h, it);
+  SBX_TRY(sbx_arena_begin(h));
+  if (n == 0) return SBX_OK;
+  hipLaunchKernelGGL(k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), 0, h->stream,
+                     (const int32_t *)perm, (int32_t *)inv_out, n);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, const void *order,
+                                 const void *vals, void *out) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && (n == 0 || (order && vals && out)), "bad argument");
+  SBX_ONLY_I32(h, it);
+  const int vb = sbx_value_bytes(vt);
+  SBX_REQUIRE(h, vb == 4 || vb == 8, "value type must be 4 or 8 bytes");
+  SBX_TRY(sbx_arena_begin(h));
+  if (n == 0) return SBX_OK;
+  const unsigned grid = sbx_grid_for(n, 256, 8192);
+  if (vb == 4)
+    hipLaunchKernelGGL((k_permute_array<int32_t, 4>), dim3(grid), dim3(256), 0, h->stream, (const int32_t *)order,
+                       (const char *)vals, (char *)out, n);
+  else
+    hipLaunchKernelGGL((k_permute_array<int32_t, 8>), dim3(grid), dim3(256), 0, h->stream, (const int32_t *)order,
+                       (const char *)vals, (char *)out, n);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                                    int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                                    const void *row_order, const void *col_order, int64_t row_begin, int64_t row_end,
+                                    void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
+                                    int64_t *shard_nnz_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && row_ptr_out, "bad argument");
+  SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
+  SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
+  SBX_ONLY_I32(h, it);
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  typedef int32_t I;
+  const int64_t nr = row_end - row_begin;
+  I *rpo = (I *)row_ptr_out;
+  if (shard_nnz_host) *shard_nnz_host = 0;
+  if (nr == 0) return sbx_fill_i32(h, rpo, 0, 1);
+
+  PermState *st = nullptr;
+  I *old_of_new = nullptr, *long_rows = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &st));
+  {
+    int64_t cap_long = nnz / PT_TILE + 1;
+    if (cap_long > nr) cap_long = nr;
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
+  }
+  SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+  if (row_order) {
+    SBX_TRY(sbx_salloc(h, (size_t)n, &old_of_new));
+    hipLaunchKernelGGL(k_invert<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), 0, h->stream, (const I *)row_order,
+                       old_of_new, n);
+  }
+  hipLaunchKernelGGL(k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256), 0, h->stream,
+                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, st);
+  SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
+  hipLaunchKernelGGL(k_store_total<I>, dim3(1), dim3(1), 0, h->stream, (const I *)rpo, nr, st);
+  PermState hs;
+  SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
+  const int64_t total = (int64_t)hs.total;
+  if (shard_nnz_host) *shard_nnz_host = total;
+  if (total > out_capacity)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
+             (long long)out_capacity);
+  int rc;
+#define STAGE(VBX)                                                                                               \
+  rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, old_of_new,                 \
+                       (const I *)col_order, rpo, (I *)col_out, (char *)val_out, nr, row_begin, m, total, long_rows, \
+                       hs.n_long, (int64_t)hs.long_nnz, st)
+  if (vb == 0) STAGE(0);
+  else if (vb == 4) STAGE(4);
+  else STAGE(8);
+#undef STAGE
+  return rc;
+}
+
+extern "C" int sbx_permute_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                               const void *row_ptr, const void *col, const void *val, const void *row_order,
+                               const void *col_order, void *row_ptr_out, void *col_out, void *val_out) {
+  return sbx_permute_csr_rows(h, it, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, 0, n, row_ptr_out,
+                              col_out, val_out, nnz, nullptr);
+}
+
+// A4: the CSR constructor's "if any row is unsorted, sort every row" in place.
+extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                                 int64_t nnz, const void *row_ptr, void *col, void *val) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || col), "bad argument");
+  SBX_ONLY_I32(h, it);
+  if (nnz <= 1 || n == 0) return SBX_OK;
+  int sorted = 1;
+  SBX_TRY(sbx_csr_rows_sorted(h, it, n, row_ptr, col, &sorted));  // csr.cc:102-116
+  if (sorted) return SBX_OK;
+  // out-of-place into scratch, then copied back (tiles may read rows another
+  // tile has already rewritten if the sort ran in place across tiles)
+  const int vb = val ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  typedef int32_t I;
+  PermState *st = nullptr;
+  I *long_rows = nullptr, *deg = nullptr, *ctmp = nullptr;
+  char *vtmp = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &st));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
+  SBX_TRY(sbx_salloc(h, (size_t)n + 1, &deg));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
+  if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
+  SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+  hipLaunchKernelGGL(k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256), 0, h->stream,
+                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, st);
+  SBX_LAUNCH_CHECK(h);
+  PermState hs;
+  SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
+  int rc;
+#define STAGE(VBX)                                                                                              \
+  rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, nullptr, nullptr,          \
+                       (const I *)row_ptr, ctmp, vtmp, n, 0, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz, st)
+  if (vb == 0) STAGE(0);
+  else if (vb == 4) STAGE(4);
+  else STAGE(8);
+#undef STAGE
+  SBX_TRY(rc);
+  SBX_HIP(h, hipMemcpyAsync(col, ctmp, (size_t)nnz * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
+  if (vb) SBX_HIP(h, hipMemcpyAsync(val, vtmp, (size_t)nnz * vb, hipMemcpyDeviceToDevice, h->stream));
+  return SBX_OK;
+}

@@ -1,0 +1,318 @@
+// sbx_prims.hip — device-wide building blocks of the reorder/convert path:
+// exclusive scan (the "inclusive scan + shift" of converter_order_two.cc:185-192
+// and the bucket scans of degree_reorder.cc:36-38) and a stable LSD radix sort
+// (stands in for every std::sort on the path: format/coo.cc:133-146,
+// format/csr.cc:123-156 for long rows, degree/RCM key orderings).
+//
+// Radix sort pass = per-tile digit histogram -> device scan -> LDS-staged
+// stable scatter.  Ranking inside a tile is done with wave64 ballots (match-any
+// over the digit bits) and per-wave digit counters in LDS; keys and payloads
+// are reordered through LDS so the global writes are coalesced per bucket run.
+#include "sbx_device.h"
+#include "sbx_internal.h"
+
+// ---------------------------------------------------------------------------
+// fill
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill(T *__restrict__ dst, T value, int64_t count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) dst[i] = value;
+}
+
+int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count) {
+  if (count <= 0) return SBX_OK;
+  hipLaunchKernelGGL(k_fill<int32_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), 0, h->stream, dst, value, count);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count) {
+  if (count <= 0) return SBX_OK;
+  hipLaunchKernelGGL(k_fill<int64_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), 0, h->stream, dst, value, count);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan: reduce tiles -> scan tile sums (one workgroup) -> scan tiles
+// ---------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const T *__restrict__ in, T *__restrict__ partial,
+                                                              int64_t count) {
+  __shared__ T lds[SCAN_THREADS / 64 + 1];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const int64_t e = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
+    if (e < count) s += in[e];
+  }
+  s = sbx_block_sum<T, SCAN_THREADS>(s, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_partials(T *__restrict__ partial, int64_t nparts,
+                                                        T *__restrict__ total_out) {
+  __shared__ T lds[1024 / 64 + 1];
+  T carry = 0;
+  for (int64_t start = 0; start < nparts; start += 1024) {
+    const int64_t e = start + threadIdx.x;
+    const T v = e < nparts ? partial[e] : (T)0;
+    T tot;
+    const T ex = sbx_block_exclusive_sum<T, 1024>(v, lds, &tot);
+    if (e < nparts) partial[e] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T *__restrict__ in, T *__restrict__ out,
+                                                             const T *__restrict__ partial, int64_t count,
+                                                             T *__restrict__ total_out) {
+  __shared__ T lds[SCAN_THREADS / 64 + 1];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  T v[SCAN_ITEMS];
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < count) ? in[base + i] : (T)0;
+    s += v[i];
+  }
+  T tot;
+  T run = sbx_block_exclusive_sum<T, SCAN_THREADS>(s, lds, &tot);
+  if (partial) run += partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < count) out[base + i] = run;
+    run += v[i];
+  }
+  if (!partial && total_out && threadIdx.x == 0) *total_out = tot;
+}
+
+template <typename T>
+static int exclusive_scan_impl(sbx_handle_t h, const T *in, T *out, int64_t count, T *total_out) {
+  if (count <= 0) {
+    if (total_out) SBX_HIP(h, hipMemsetAsync(total_out, 0, sizeof(T), h->stream));
+    return SBX_OK;
+  }
+  const int64_t tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
+  if (tiles == 1) {
+    hipLaunchKernelGGL(k_scan_final<T>, dim3(1), dim3(SCAN_THREADS), 0, h->stream, in, out, (const T *)nullptr,
+                       count, total_out);
+    SBX_LAUNCH_CHECK(h);
+    return SBX_OK;
+  }
+  T *partial = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)tiles, &partial));
+  hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, h->stream, in, partial, count);
+  hipLaunchKernelGGL(k_scan_partials<T>, dim3(1), dim3(1024), 0, h->stream, partial, tiles, total_out);
+  hipLaunchKernelGGL(k_scan_final<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, h->stream, in, out,
+                     (const T *)partial, count, (T *)nullptr);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+int sbx_exclusive_scan_i32(sbx_handle_t h, const int32_t *in, int32_t *out, int64_t count, int32_t *total_out) {
+  return exclusive_scan_impl<int32_t>(h, in, out, count, total_out);
+}
+int sbx_exclusive_scan_i64(sbx_handle_t h, const int64_t *in, int64_t *out, int64_t count, int64_t *total_out) {
+  return exclusive_scan_impl<int64_t>(h, in, out, count, total_out);
+}
+int sbx_exclusive_scan_u32(sbx_handle_t h, const uint32_t *in, uint32_t *out, int64_t count, uint32_t *total_out) {
+  return exclusive_scan_impl<uint32_t>(h, in, out, count, total_out);
+}
+
+// ---------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------
+int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes) {
+  int np = 0;
+  const int lo[2] = {lo0, lo1}, hi[2] = {hi0, hi1};
+  for (int r = 0; r < 2; r++) {
+    int b = lo[r];
+    while (b < hi[r]) {
+      // spread the range's bits evenly over ceil(range/8) passes
+      const int remaining = hi[r] - b;
+      const int passes_left = (remaining + 7) / 8;
+      const int take = (remaining + passes_left - 1) / passes_left;
+      passes[np].shift = b;
+      passes[np].bits = take;
+      np++;
+      b += take;
+    }
+  }
+  return np;
+}
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+template <typename K, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const K *__restrict__ keys, int64_t count, int shift,
+                                                           unsigned mask, uint32_t *__restrict__ hist, int tiles) {
+  constexpr int TILE = RS_THREADS * ITEMS;
+  __shared__ uint32_t lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const int64_t e = base + (int64_t)i * RS_THREADS + threadIdx.x;
+    if (e < count) atomicAdd(&lh[(unsigned)(keys[e] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = lh[threadIdx.x];
+}
+
+template <typename K, typename P, int ITEMS, bool HAS_P>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+                                                              const P *__restrict__ vals_in, P *__restrict__ vals_out,
+                                                              int64_t count, int shift, int bits,
+                                                              const uint32_t *__restrict__ hist, int tiles) {
+  constexpr int TILE = RS_THREADS * ITEMS;
+  __shared__ K s_keys[TILE];
+  __shared__ P s_vals[HAS_P ? TILE : 1];
+  __shared__ uint32_t s_whist[RS_WAVES][256];
+  __shared__ uint32_t s_gofs[256];
+  __shared__ uint32_t s_scan[RS_WAVES + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  const int valid = (int)((count - base) < TILE ? (count - base) : TILE);
+  const unsigned mask = (1u << bits) - 1u;
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; i++) s_whist[i][tid] = 0;
+  __syncthreads();
+
+  K k[ITEMS];
+  P v[HAS_P ? ITEMS : 1];
+  uint32_t rank[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const int e = w * 64 * ITEMS + i * 64 + lane;
+    k[i] = e < valid ? keys_in[base + e] : (K) ~(K)0;
+    if (HAS_P) v[i] = e < valid ? vals_in[base + e] : (P)0;
+  }
+  volatile uint32_t *wh = s_whist[w];
+  const uint64_t lt = sbx_lanemask_lt();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const unsigned d = (unsigned)(k[i] >> shift) & mask;
+    uint64_t m = ~(uint64_t)0;
+    for (int b = 0; b < bits; b++) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const uint32_t prev = wh[d];
+    const uint32_t r = (uint32_t)__popcll(m & lt);
+    __builtin_amdgcn_wave_barrier();
+    if (r == 0) wh[d] = prev + (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    rank[i] = prev + r;
+  }
+  __syncthreads();
+  {
+    // thread `tid` owns digit `tid`
+    uint32_t c[RS_WAVES];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) {
+      c[i] = s_whist[i][tid];
+      tot += c[i];
+    }
+    uint32_t all;
+    uint32_t ex = sbx_block_exclusive_sum<uint32_t, RS_THREADS>(tot, s_scan, &all);
+    s_gofs[tid] = hist[(int64_t)tid * tiles + blockIdx.x] - ex;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) {
+      s_whist[i][tid] = ex;
+      ex += c[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const unsigned d = (unsigned)(k[i] >> shift) & mask;
+    const uint32_t pos = s_whist[w][d] + rank[i];
+    s_keys[pos] = k[i];
+    if (HAS_P) s_vals[pos] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const int j = i * RS_THREADS + tid;
+    if (j < valid) {
+      const K kk = s_keys[j];
+      const unsigned d = (unsigned)(kk >> shift) & mask;
+      const uint32_t o = s_gofs[d] + (uint32_t)j;
+      keys_out[o] = kk;
+      if (HAS_P) vals_out[o] = s_vals[j];
+    }
+  }
+}
+
+template <typename K, typename P, int ITEMS, bool HAS_P>
+static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t count, const sbx_radix_pass *passes,
+                           int np, int *result_in_b) {
+  constexpr int TILE = RS_THREADS * ITEMS;
+  *result_in_b = 0;
+  if (count <= 1 || np == 0) return SBX_OK;
+  if (count >= ((int64_t)1 << 32)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "radix sort: count %lld >= 2^32", (long long)count);
+  const int64_t tiles64 = (count + TILE - 1) / TILE;
+  const int tiles = (int)tiles64;
+  uint32_t *hist = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)256 * tiles, &hist));
+  K *src_k = ka, *dst_k = kb;
+  P *src_v = va, *dst_v = vb;
+  for (int p = 0; p < np; p++) {
+    const unsigned mask = (1u << passes[p].bits) - 1u;
+    hipLaunchKernelGGL((k_radix_hist<K, ITEMS>), dim3(tiles), dim3(RS_THREADS), 0, h->stream, (const K *)src_k, count,
+                       passes[p].shift, mask, hist, tiles);
+    SBX_TRY(sbx_exclusive_scan_u32(h, hist, hist, (int64_t)256 * tiles, nullptr));
+    hipLaunchKernelGGL((k_radix_scatter<K, P, ITEMS, HAS_P>), dim3(tiles), dim3(RS_THREADS), 0, h->stream,
+                       (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
+                       (const uint32_t *)hist, tiles);
+    SBX_LAUNCH_CHECK(h);
+    K *tk = src_k; src_k = dst_k; dst_k = tk;
+    P *tv = src_v; src_v = dst_v; dst_v = tv;
+    *result_in_b ^= 1;
+  }
+  return SBX_OK;
+}
+
+int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_a, void *keys_b, void *vals_a,
+                   void *vals_b, int64_t count, const sbx_radix_pass *passes, int num_passes, int *result_in_b) {
+  if (key_bytes == 4) {
+    if (payload_bytes == 0)
+      return radix_sort_impl<uint32_t, uint32_t, 16, false>(h, (uint32_t *)keys_a, (uint32_t *)keys_b, nullptr, nullptr,
+                                                            count, passes, num_passes, result_in_b);
+    if (payload_bytes == 4)
+      return radix_sort_impl<uint32_t, uint32_t, 16, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
+                                                           (uint32_t *)vals_a, (uint32_t *)vals_b, count, passes,
+                                                           num_passes, result_in_b);
+    if (payload_bytes == 8)
+      return radix_sort_impl<uint32_t, uint64_t, 16, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
+                                                           (uint64_t *)vals_a, (uint64_t *)vals_b, count, passes,
+                                                           num_passes, result_in_b);
+  } else if (key_bytes == 8) {
+    if (payload_bytes == 0)
+      return radix_sort_impl<uint64_t, uint32_t, 16, false>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
+                                                            count, passes, num_passes, result_in_b);
+    if (payload_bytes == 4)
+      return radix_sort_impl<uint64_t, uint32_t, 16, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
+                                                           (uint32_t *)vals_a, (uint32_t *)vals_b, count, passes,
+                                                           num_passes, result_in_b);
+    if (payload_bytes == 8)
+      return radix_sort_impl<uint64_t, uint64_t, 8, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
+                                                          (uint64_t *)vals_a, (uint64_t *)vals_b, count, passes,
+                                                          num_passes, result_in_b);
+  }
+  SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "radix sort: key_bytes=%d payload_bytes=%d", key_bytes, payload_bytes);
+}

@@ -1,0 +1,219 @@
+"""Tensor-level plumbing over the C ABI (include/sbx.h).
+
+torch owns the device buffers and the stream; every function here only
+marshals pointers into libsbx.so.  Nothing in this module computes on the CPU:
+if the HIP library or a GPU is missing the calls raise.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import capi
+
+_VT = {torch.int32: capi.V_I32, torch.float32: capi.V_F32, torch.int64: capi.V_I64,
+       torch.float64: capi.V_F64}
+_handles = {}
+_lock = threading.Lock()
+
+
+def _vt(val):
+    if val is None:
+        return capi.V_NONE
+    if val.dtype not in _VT:
+        raise TypeError(f"unsupported value dtype {val.dtype}")
+    return _VT[val.dtype]
+
+
+def _it(t):
+    if t.dtype == torch.int32:
+        return capi.SBX_I32
+    if t.dtype == torch.int64:
+        return capi.SBX_I64
+    raise TypeError(f"index tensors must be int32/int64, got {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_dev(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("sparsebase_amd.ops works on device tensors only (no CPU path)")
+        if not t.is_contiguous():
+            raise ValueError("tensors must be contiguous")
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise ValueError("all tensors must live on the same device")
+    return dev
+
+
+class Handle:
+    """One sbx handle per (device); bound to torch's current stream on every call."""
+
+    def __init__(self, device_index):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        rc = self.lib.sbx_create(int(device_index), C.byref(self.h))
+        if rc != capi.SBX_OK:
+            raise capi.SbxError(rc, "sbx_create failed (HIP hot path has no CPU fallback)")
+        self.device_index = device_index
+
+    def bind_stream(self):
+        s = torch.cuda.current_stream(self.device_index).cuda_stream
+        self.lib.sbx_set_stream(self.h, C.c_void_p(s))
+
+    def check(self, rc):
+        if rc != capi.SBX_OK:
+            raise capi.SbxError(rc, self.lib.sbx_last_error(self.h).decode())
+
+    def reserve(self, nbytes):
+        self.check(self.lib.sbx_reserve(self.h, C.c_size_t(nbytes)))
+
+
+def handle_for(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _lock:
+        if idx not in _handles:
+            _handles[idx] = Handle(idx)
+    hd = _handles[idx]
+    hd.bind_stream()
+    return hd
+
+
+# ----------------------------------------------------------------------------- A1 / A4
+def coo_is_sorted(row, col):
+    hd = handle_for(_check_dev(row, col))
+    out = C.c_int(0)
+    hd.check(hd.lib.sbx_coo_is_sorted(hd.h, _it(row), row.numel(), _p(row), _p(col), C.byref(out)))
+    return bool(out.value)
+
+
+def coo_sort_(n, m, row, col, val=None):
+    """In place, like the COO constructor (format/coo.cc:110-157)."""
+    hd = handle_for(_check_dev(row, col, val))
+    hd.check(hd.lib.sbx_coo_sort(hd.h, _it(row), _vt(val), n, m, row.numel(), _p(row), _p(col), _p(val)))
+
+
+def csr_rows_sorted(row_ptr, col):
+    hd = handle_for(_check_dev(row_ptr, col))
+    out = C.c_int(0)
+    hd.check(hd.lib.sbx_csr_rows_sorted(hd.h, _it(row_ptr), row_ptr.numel() - 1, _p(row_ptr), _p(col), C.byref(out)))
+    return bool(out.value)
+
+
+def csr_sort_rows_(n, m, row_ptr, col, val=None):
+    """In place, like the CSR constructor (format/csr.cc:99-157)."""
+    hd = handle_for(_check_dev(row_ptr, col, val))
+    hd.check(hd.lib.sbx_csr_sort_rows(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val)))
+
+
+# ----------------------------------------------------------------------------- A2 / A3
+def coo_to_csr(n, m, row, col, val=None, move=False, rows_sorted=False, out=None):
+    hd = handle_for(_check_dev(row, col, val))
+    nnz = row.numel()
+    if out is None:
+        rp = torch.empty(n + 1, dtype=row.dtype, device=row.device)
+        co = None if move else torch.empty_like(col)
+        vo = None if (move or val is None) else torch.empty_like(val)
+    else:
+        rp, co, vo = out
+    flags = (capi.FLAG_MOVE if move else 0) | (capi.FLAG_ROWS_SORTED if rows_sorted else 0)
+    hd.check(hd.lib.sbx_coo_to_csr(hd.h, _it(row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(rp), _p(co),
+                                   _p(vo), flags))
+    return (rp, col, val) if move else (rp, co, vo)
+
+
+def csr_to_coo(n, m, row_ptr, col, val=None, move=False, out=None):
+    hd = handle_for(_check_dev(row_ptr, col, val))
+    nnz = col.numel()
+    if out is None:
+        ro = torch.empty(nnz, dtype=row_ptr.dtype, device=row_ptr.device)
+        co = None if move else torch.empty_like(col)
+        vo = None if (move or val is None) else torch.empty_like(val)
+    else:
+        ro, co, vo = out
+    flags = capi.FLAG_MOVE if move else 0
+    hd.check(hd.lib.sbx_csr_to_coo(hd.h, _it(row_ptr), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(ro),
+                                   _p(co), _p(vo), flags))
+    return (ro, col, val) if move else (ro, co, vo)
+
+
+# ----------------------------------------------------------------------------- reorderers
+def degree_reorder(row_ptr, ascending=True, out=None):
+    hd = handle_for(_check_dev(row_ptr))
+    n = row_ptr.numel() - 1
+    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device) if out is None else out
+    hd.check(hd.lib.sbx_degree_reorder(hd.h, _it(row_ptr), n, _p(row_ptr), int(bool(ascending)), _p(inv)))
+    return inv
+
+
+def rcm_reorder(row_ptr, col, out=None, return_stats=False):
+    hd = handle_for(_check_dev(row_ptr, col))
+    n = row_ptr.numel() - 1
+    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device) if out is None else out
+    stats = capi.RcmStats()
+    hd.check(hd.lib.sbx_rcm_reorder(hd.h, _it(row_ptr), n, col.numel(), _p(row_ptr), _p(col), _p(inv),
+                                    C.byref(stats)))
+    if return_stats:
+        return inv, {k: getattr(stats, k) for k, _ in capi.RcmStats._fields_}
+    return inv
+
+
+def gray_row_keys(m, row_ptr, col, resolution, nnz_threshold):
+    hd = handle_for(_check_dev(row_ptr, col))
+    n = row_ptr.numel() - 1
+    deg = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
+    key = torch.empty(n, dtype=torch.int64, device=row_ptr.device)  # uint64 bit pattern
+    counts = (C.c_int64 * 4)()
+    hd.check(hd.lib.sbx_gray_row_keys(hd.h, _it(row_ptr), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
+                                      int(nnz_threshold), _p(deg), _p(key), counts))
+    return deg, key, list(counts)
+
+
+# ----------------------------------------------------------------------------- permutation
+def inverse_permutation(perm):
+    hd = handle_for(_check_dev(perm))
+    inv = torch.empty_like(perm)
+    hd.check(hd.lib.sbx_inverse_permutation(hd.h, _it(perm), perm.numel(), _p(perm), _p(inv)))
+    return inv
+
+
+def permute_csr(n, m, row_ptr, col, val, row_order, col_order, out=None):
+    hd = handle_for(_check_dev(row_ptr, col, val, row_order, col_order))
+    if out is None:
+        rpo = torch.empty_like(row_ptr)
+        co = torch.empty_like(col)
+        vo = None if val is None else torch.empty_like(val)
+    else:
+        rpo, co, vo = out
+    hd.check(hd.lib.sbx_permute_csr(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val),
+                                    _p(row_order), _p(col_order), _p(rpo), _p(co), _p(vo)))
+    return rpo, co, vo
+
+
+def permute_csr_rows(n, m, row_ptr, col, val, row_order, col_order, row_begin, row_end, capacity=None):
+    """One row-range shard of the permuted matrix (the multi-GPU decomposition)."""
+    hd = handle_for(_check_dev(row_ptr, col, val, row_order, col_order))
+    nr = row_end - row_begin
+    capacity = col.numel() if capacity is None else capacity
+    rpo = torch.empty(nr + 1, dtype=row_ptr.dtype, device=row_ptr.device)
+    co = torch.empty(capacity, dtype=col.dtype, device=col.device)
+    vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+    got = C.c_int64(0)
+    hd.check(hd.lib.sbx_permute_csr_rows(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
+                                         _p(val), _p(row_order), _p(col_order), row_begin, row_end, _p(rpo), _p(co),
+                                         _p(vo), capacity, C.byref(got)))
+    k = got.value
+    return rpo, co[:k], (None if vo is None else vo[:k])
+
+
+def permute_array(order, vals):
+    hd = handle_for(_check_dev(order, vals))
+    out = torch.empty_like(vals)
+    hd.check(hd.lib.sbx_permute_array(hd.h, _it(order), _vt(vals), order.numel(), _p(order), _p(vals), _p(out)))
+    return out

@@ -1,0 +1,365 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle, the
+reference's own known-answer vectors and the reference-generated golden fixtures.
+Bit-exact everywhere (integer / index / byte-payload work).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from sparsebase_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    from sparsebase_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return None if t is None else t.cpu().numpy()
+
+
+def same(got, want):
+    for g, w in zip(got, want):
+        if w is None:
+            assert g is None
+        else:
+            assert np.array_equal(host(g) if torch.is_tensor(g) else g, w)
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "reference_tests.json")) as f:
+        return json.load(f)
+
+
+def a32(x):
+    return np.array(x, np.int32)
+
+
+# ----------------------------------------------------------------------------- reference KATs
+def test_kat_conversions(ops, kat):
+    for name in ("converter_12x9", "format_4x4"):
+        k = kat[name]
+        rp, col, val = ops.coo_to_csr(k["n"], k["m"], dev(a32(k["coo_row"])), dev(a32(k["coo_col"])),
+                                      dev(a32(k["coo_vals"])))
+        assert host(rp).tolist() == k["csr_row_ptr"]
+        assert host(col).tolist() == k["csr_col"] and host(val).tolist() == k["csr_vals"]
+        ro, co, vo = ops.csr_to_coo(k["n"], k["m"], dev(a32(k["csr_row_ptr"])), dev(a32(k["csr_col"])),
+                                    dev(a32(k["csr_vals"])))
+        assert host(ro).tolist() == k["coo_row"]
+        assert host(co).tolist() == k["coo_col"] and host(vo).tolist() == k["coo_vals"]
+        # move conversions hand col/vals over untouched (converter_order_two_tests.cc:216-240)
+        c_in = dev(a32(k["coo_col"]))
+        rp2, c2, _ = ops.coo_to_csr(k["n"], k["m"], dev(a32(k["coo_row"])), c_in, None, move=True)
+        assert host(rp2).tolist() == k["csr_row_ptr"] and c2.data_ptr() == c_in.data_ptr()
+
+
+def test_kat_ctor_sorts(ops, kat):
+    k = kat["format_4x4"]
+    r, c, v = dev(a32(k["coo_row_shuffled"])), dev(a32(k["coo_col_shuffled"])), dev(a32(k["coo_vals_shuffled"]))
+    assert not ops.coo_is_sorted(r, c)
+    ops.coo_sort_(4, 4, r, c, v)
+    assert (host(r).tolist(), host(c).tolist(), host(v).tolist()) == (k["coo_row"], k["coo_col"], k["coo_vals"])
+    assert ops.coo_is_sorted(r, c)
+    r, c = dev(a32(k["coo_row_shuffled"])), dev(a32(k["coo_col_shuffled"]))
+    ops.coo_sort_(4, 4, r, c, None)  # ValueType = void (coo_tests.cc:104-114)
+    assert (host(r).tolist(), host(c).tolist()) == (k["coo_row"], k["coo_col"])
+
+    rp = dev(a32(k["csr_row_ptr"]))
+    c, v = dev(a32(k["csr_col_shuffled"])), dev(a32(k["csr_vals_shuffled"]))
+    assert not ops.csr_rows_sorted(rp, c)
+    ops.csr_sort_rows_(4, 4, rp, c, v)
+    assert (host(c).tolist(), host(v).tolist()) == (k["csr_col"], k["csr_vals"])
+    assert ops.csr_rows_sorted(rp, c)
+    c = dev(a32(k["csr_col_shuffled"]))
+    ops.csr_sort_rows_(4, 4, rp, c, None)
+    assert host(c).tolist() == k["csr_col"]
+
+
+def test_kat_permute(ops, kat):
+    k = kat["functionality_3x3"]
+    rp, col, val = dev(a32(k["row_ptr"])), dev(a32(k["cols"])), dev(a32(k["vals"]))
+    r, c = dev(a32(k["r_reorder_vector"])), dev(a32(k["c_reorder_vector"]))
+    out = ops.permute_csr(3, 3, rp, col, val, r, None)
+    assert [host(x).tolist() for x in out] == [k["r_row_ptr"], k["r_cols"], k["r_vals"]]
+    out = ops.permute_csr(3, 3, rp, col, val, None, c)
+    assert [host(x).tolist() for x in out] == [k["c_row_ptr"], k["c_cols"], k["c_vals"]]
+    out = ops.permute_csr(3, 3, rp, col, val, r, c)
+    assert [host(x).tolist() for x in out] == [k["rc_row_ptr"], k["rc_cols"], k["rc_vals"]]
+    back = ops.permute_csr(3, 3, *out, ops.inverse_permutation(r), ops.inverse_permutation(c))
+    assert [host(x).tolist() for x in back] == [k["row_ptr"], k["cols"], k["vals"]]
+    assert host(ops.inverse_permutation(dev(a32(k["perm_array"])))).tolist() == k["inverse_perm_array"]
+    arr = ops.permute_array(dev(a32(k["inverse_perm_array"])), dev(np.array(k["original_array"], np.float32)))
+    assert np.allclose(host(arr), np.array(k["reordered_array"], np.float32))
+    assert host(ops.degree_reorder(rp, True)).tolist() == k["degree_asc"]
+    assert host(ops.degree_reorder(rp, False)).tolist() == k["degree_desc"]
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    z = np.load(os.path.join(golden_dir, "small_cases.npz"))
+    with open(os.path.join(golden_dir, "small_cases.json")) as f:
+        return z, json.load(f)
+
+
+def test_golden_degree_and_permute(ops, small):
+    z, meta = small
+    for name in meta:
+        rp, col = z[f"{name}/row_ptr"], z[f"{name}/col"]
+        n = len(rp) - 1
+        assert np.array_equal(host(ops.degree_reorder(dev(rp), True)), z[f"{name}/degree_asc"]), name
+        assert np.array_equal(host(ops.degree_reorder(dev(rp), False)), z[f"{name}/degree_desc"]), name
+        if n == 0 or f"{name}/perm_order" not in z:
+            continue
+        order, val = z[f"{name}/perm_order"], z[f"{name}/perm_val"]
+        for tag, ro, co in (("rc", order, order), ("r", order, None), ("rcm", z[f"{name}/rcm"], z[f"{name}/rcm"])):
+            got = ops.permute_csr(n, n, dev(rp), dev(col), dev(val), dev(ro), dev(co))
+            same(got, [z[f"{name}/permute_{tag}/row_ptr"], z[f"{name}/permute_{tag}/col"],
+                       z[f"{name}/permute_{tag}/val"]])
+
+
+def test_golden_rect_convert_and_sort(ops, small):
+    z, _ = small
+    for k in range(4):
+        name = f"rect{k}"
+        n, m = (int(x) for x in z[f"{name}/dims"])
+        r, c, v = dev(z[f"{name}/coo_row"]), dev(z[f"{name}/coo_col"]), dev(z[f"{name}/coo_val"])
+        ops.coo_sort_(n, m, r, c, v)
+        same((r, c, v), (z[f"{name}/sorted_row"], z[f"{name}/sorted_col"], z[f"{name}/sorted_val"]))
+        csr = ops.coo_to_csr(n, m, r, c, v)
+        same(csr, (z[f"{name}/csr_row_ptr"], z[f"{name}/csr_col"], z[f"{name}/csr_val"]))
+        same(ops.csr_to_coo(n, m, *csr), (z[f"{name}/sorted_row"], z[f"{name}/sorted_col"], z[f"{name}/sorted_val"]))
+        uc, uv = dev(z[f"{name}/unsorted_col"]), dev(z[f"{name}/unsorted_val"])
+        ops.csr_sort_rows_(n, m, csr[0], uc, uv)
+        same((uc, uv), (z[f"{name}/resorted_col"], z[f"{name}/resorted_val"]))
+
+
+def test_golden_ash958(ops, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ash958.npz"))
+    n, m, nnz = (int(x) for x in z["dims"])
+    r, c = dev(z["file_row"]), dev(z["file_col"])
+    ops.coo_sort_(n, m, r, c, None)  # the .mtx is column-major: exercises the COO-ctor sort
+    rp, cc, _ = ops.coo_to_csr(n, m, r, c, None)
+    same((rp, cc), (z["row_ptr"], z["col"]))
+    dasc = ops.degree_reorder(rp, True)
+    assert np.array_equal(host(dasc), z["degree_asc"])
+    assert np.array_equal(host(ops.degree_reorder(rp, False)), z["degree_desc"])
+    prp, pcol, _ = ops.permute_csr(n, m, rp, cc, None, dasc, None)
+    same((prp, pcol), (z["rowwise_row_ptr"], z["rowwise_col"]))
+
+
+# ----------------------------------------------------------------------------- oracle, seeded inputs
+@pytest.mark.parametrize("seed", range(8))
+def test_convert_vs_oracle(ops, oracle, seed):
+    g = np.random.default_rng(seed)
+    n, m = int(g.integers(1, 5000)), int(g.integers(1, 5000))
+    nnz = int(g.integers(0, 200000))
+    rp, col = synth.random_rect_csr(n, m, nnz, seed, sort_rows=(seed % 2 == 0), dup_frac=0.05 if seed % 3 == 0 else 0)
+    for val in (None, g.integers(-99, 99, len(col)).astype(np.int32), g.random(len(col)).astype(np.float32),
+                g.random(len(col))):
+        want_c, want_v = oracle.csr_sort_rows(rp, col, val)
+        c, v = dev(col), dev(val)
+        assert ops.csr_rows_sorted(dev(rp), c) == oracle.csr_rows_sorted(rp, col)
+        ops.csr_sort_rows_(n, m, dev(rp), c, v)
+        same((c, v), (want_c, want_v))
+        coo = ops.csr_to_coo(n, m, dev(rp), c, v)
+        want_coo = oracle.csr_to_coo(rp, want_c, want_v)
+        same(coo, want_coo)
+        same(ops.coo_to_csr(n, m, *coo), oracle.coo_to_csr(n, *want_coo))
+        same(ops.coo_to_csr(n, m, *coo, rows_sorted=True), oracle.coo_to_csr(n, *want_coo))
+        rp_m, _, _ = ops.coo_to_csr(n, m, coo[0], coo[1], coo[2], move=True)
+        assert np.array_equal(host(rp_m), rp)
+        # shuffled COO -> ctor sort (distinct coordinates: ties are unspecified in the reference)
+        key = np.unique(want_coo[0].astype(np.int64) * m + want_coo[1])
+        p = g.permutation(len(key))
+        rr, cc = (key // m).astype(np.int32)[p], (key % m).astype(np.int32)[p]
+        vv = None if val is None else val[: len(key)].copy()
+        r_d, c_d, v_d = dev(rr), dev(cc), dev(vv)
+        ops.coo_sort_(n, m, r_d, c_d, v_d)
+        same((r_d, c_d, v_d), oracle.coo_sort(rr, cc, vv))
+
+
+def test_coo_to_csr_unsorted_rows(ops, oracle):
+    # ignore_sort=true input: row_ptr is still exclusive_scan(histogram(row))
+    g = np.random.default_rng(5)
+    n, nnz = 777, 20000
+    row = g.integers(0, n, nnz).astype(np.int32)
+    col = g.integers(0, n, nnz).astype(np.int32)
+    val = g.random(nnz).astype(np.float32)
+    same(ops.coo_to_csr(n, n, dev(row), dev(col), dev(val)), oracle.coo_to_csr(n, row, col, val))
+
+
+def test_convert_edge_cases(ops, oracle):
+    # empty matrix, empty leading/trailing rows, one giant gap of empty rows, single nnz
+    z = np.zeros(0, np.int32)
+    same(ops.coo_to_csr(5, 5, dev(z), dev(z), None), oracle.coo_to_csr(5, z, z, None))
+    row = np.array([70000, 70000, 70001, 299999], np.int32)
+    col = np.array([1, 5, 2, 0], np.int32)
+    val = np.array([1.5, 2.5, 3.5, 4.5], np.float64)
+    n = 300007
+    want = oracle.coo_to_csr(n, row, col, val)
+    got = ops.coo_to_csr(n, n, dev(row), dev(col), dev(val))
+    same(got, want)
+    same(ops.csr_to_coo(n, n, *got), (row, col, val))
+    one = np.array([3], np.int32)
+    same(ops.coo_to_csr(9, 9, dev(one), dev(one), None), oracle.coo_to_csr(9, one, one, None))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_permute_vs_oracle(ops, oracle, seed):
+    g = np.random.default_rng(40 + seed)
+    if seed < 3:
+        rp, col = synth.rmat_symmetric(12 + seed, 8, seed=seed)  # power-law: short, medium and long rows
+        n = m = len(rp) - 1
+    else:
+        n, m = int(g.integers(2, 3000)), int(g.integers(2, 3000))
+        rp, col = synth.random_rect_csr(n, m, int(g.integers(1, 100000)), seed, dup_frac=0.1 if seed == 4 else 0)
+    ro = synth.random_permutation(n, seed)
+    co = synth.random_permutation(m, seed + 1)
+    for val in (None, g.integers(-5, 5, len(col)).astype(np.int32), g.random(len(col)).astype(np.float32),
+                g.random(len(col))):
+        for r, c in ((ro, co), (ro, None), (None, co), (None, None)):
+            got = ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(r), dev(c))
+            same(got, oracle.permute_csr(rp, col, val, r, c))
+
+
+def test_permute_long_rows_and_duplicates(ops, oracle):
+    # a few very long rows (radix path), medium rows (bitonic path), duplicates with values
+    g = np.random.default_rng(3)
+    n, m = 64, 50000
+    lens = np.array([0, 1, 2, 40, 33, 1024, 1025, 5000, 20000] + [int(x) for x in g.integers(0, 300, n - 9)])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(g.integers(0, m, l)) for l in lens]).astype(np.int32)  # sorted, with duplicates
+    val = g.integers(-3, 3, len(col)).astype(np.int32)
+    ro, co = synth.random_permutation(n, 1), synth.random_permutation(m, 2)
+    for v in (val, val.astype(np.float32), None):
+        same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
+        # identity maps: nothing is unsorted, so duplicates must keep their input order
+        same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
+
+
+def test_permute_row_shards(ops, oracle):
+    rp, col = synth.rmat_symmetric(13, 8, seed=9)
+    n = len(rp) - 1
+    val = (np.arange(len(col)) % 97).astype(np.float32)
+    order = synth.random_permutation(n, 4)
+    want_rp, want_col, want_val = oracle.permute_csr(rp, col, val, order, order)
+    cuts = [0, n // 3, n // 3, n - 5, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        srp, scol, sval = ops.permute_csr_rows(n, n, dev(rp), dev(col), dev(val), dev(order), dev(order), a, b)
+        lo, hi = want_rp[a], want_rp[b]
+        assert np.array_equal(host(srp), want_rp[a:b + 1] - lo)
+        assert np.array_equal(host(scol), want_col[lo:hi]) and np.array_equal(host(sval), want_val[lo:hi])
+
+
+@pytest.mark.parametrize("name", ["rmat16_ef8", "banded_64k_w16", "sym_128k"])
+def test_golden_digests_degree_permute(ops, golden_dir, name):
+    import hashlib
+
+    def digest(*arrays):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(np.ascontiguousarray(host(a) if torch.is_tensor(a) else a).tobytes())
+        return h.hexdigest()
+
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        d = json.load(f)[name]
+    rp, col = getattr(synth, d["generator"])(**d["args"])
+    n = len(rp) - 1
+    assert digest(rp, col) == d["input"]
+    assert digest(ops.degree_reorder(dev(rp), True)) == d["degree_asc"]
+    assert digest(ops.degree_reorder(dev(rp), False)) == d["degree_desc"]
+    val = (np.arange(len(col)) % 1021).astype(np.float32)
+    order = synth.random_permutation(n, seed=77)
+    assert digest(*ops.permute_csr(n, n, dev(rp), dev(col), dev(val), dev(order), None)) == d["permute_random_rowwise"]
+
+
+def test_gray_row_keys(ops, oracle):
+    for seed, (res, thr) in enumerate([(32, 10), (16, 20), (64, 2), (16, 0)]):
+        rp, col = synth.rmat_symmetric(12, 8, seed=seed) if seed % 2 == 0 else synth.banded_symmetric(4096, 40, 9, seed)
+        n = len(rp) - 1
+        deg, key, counts = ops.gray_row_keys(n, dev(rp), dev(col), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, n, res, thr)
+        assert np.array_equal(host(deg), wdeg)
+        assert np.array_equal(host(key).view(np.uint64), wkey)
+        assert list(counts) == wcounts.tolist()
+
+
+# ----------------------------------------------------------------------------- RCM
+def test_rcm_kat_and_small_fixtures(ops, kat, small):
+    k = kat["functionality_3x3"]
+    assert host(ops.rcm_reorder(dev(a32(k["row_ptr"])), dev(a32(k["cols"])))).tolist() == k["rcm"]
+    z, meta = small
+    for name in meta:
+        rp, col = z[f"{name}/row_ptr"], z[f"{name}/col"]
+        got = host(ops.rcm_reorder(dev(rp), dev(col)))
+        assert np.array_equal(got, z[f"{name}/rcm"]), name
+
+
+def test_rcm_chesapeake(ops, golden_dir):
+    z = np.load(os.path.join(golden_dir, "chesapeake.npz"))
+    rcm = ops.rcm_reorder(dev(z["row_ptr"]), dev(z["col"]))
+    assert np.array_equal(host(rcm), z["rcm"])
+    prp, pcol, _ = ops.permute_csr(40, 40, dev(z["row_ptr"]), dev(z["col"]), None, rcm, rcm)
+    same((prp, pcol), (z["permute_rcm_row_ptr"], z["permute_rcm_col"]))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rcm_vs_oracle_random(ops, oracle, seed):
+    g = np.random.default_rng(seed)
+    n = int(2 ** g.integers(6, 15))
+    rp, col = synth.random_symmetric_graph(n, avg_deg=1 + seed % 7, seed=seed, n_blocks=1 + seed % 5,
+                                           isolated_frac=0.05 * (seed % 4))
+    got, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
+    assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
+
+
+@pytest.mark.parametrize("maker", ["path", "path_shuffled", "star", "clique", "grid", "grid_shuffled", "two_hubs"])
+def test_rcm_structured(ops, oracle, maker):
+    if maker == "path":
+        rp, col = synth.path_graph(3000)
+    elif maker == "path_shuffled":
+        rp, col = synth.path_graph(2049, shuffle_seed=3)
+    elif maker == "star":
+        rp, col = synth.star_graph(5000, centre=77)   # hub with > 1024 neighbours (chunked expansion)
+    elif maker == "clique":
+        rp, col = synth.clique_graph(300)
+    elif maker == "grid":
+        rp, col = synth.grid_graph(40, 300)
+    elif maker == "grid_shuffled":
+        rp, col = synth.grid_graph(128, 128, shuffle_seed=5)
+    else:
+        s1, d1 = synth.symmetrize(np.full(6000, 10), np.arange(100, 6100))
+        s2, d2 = synth.symmetrize(np.full(6000, 20), np.arange(3000, 9000))
+        rp, col = synth.csr_from_edges(9100, np.concatenate([s1, s2]), np.concatenate([d1, d2]))
+    assert np.array_equal(host(ops.rcm_reorder(dev(rp), dev(col))), oracle.rcm_reorder(rp, col))
+
+
+@pytest.mark.parametrize("name", ["rmat16_ef8", "rmat18_ef8", "banded_64k_w4096", "sym_128k"])
+def test_rcm_golden_digests(ops, golden_dir, name):
+    import hashlib
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        d = json.load(f)[name]
+    rp, col = getattr(synth, d["generator"])(**d["args"])
+    n = len(rp) - 1
+    rcm = ops.rcm_reorder(dev(rp), dev(col))
+    assert hashlib.sha256(host(rcm).tobytes()).hexdigest() == d["rcm"]
+    val = (np.arange(len(col)) % 1021).astype(np.float32)
+    out = ops.permute_csr(n, n, dev(rp), dev(col), dev(val), rcm, rcm)
+    h = hashlib.sha256()
+    for a in out:
+        h.update(host(a).tobytes())
+    assert h.hexdigest() == d["permute_rcm"]
