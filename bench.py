@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — RCM reorder + CSR permute on a 100M-nnz power-law (RMAT) CSR (BASELINE config 3).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = RCMReorder::GetReorder on the device-resident CSR followed by
+Permute2D(order, order) (the canonical reorder->permute pipeline,
+experiment/experiment_helper.h:81-97), inputs already in HBM.  value = rows
+processed by all ranks / time (Mrows/s).  RCM's BFS is a global sequential
+dependency and stays single-GPU (north_star), so with N ranks every rank runs the
+pipeline on its own RMAT instance (independent objects, weak scaling, no
+data-path collective); the row-range sharded permutation apply with its RCCL
+all-gather of row_ptr — the step that does shard — is timed as well and reported
+in "permute_apply" on the same JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel, algorithmic bytes / HIP-event time measured live
+                through the library's per-kernel event hooks over the timed steps
+  cpu_baseline  the real reference (oracle/_ref) or the oracle port timed on the
+                host cores, rank 0 at N=1 only, on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=22, help="RMAT scale (2^scale rows)")
+    ap.add_argument("--edge-factor", type=int, default=13, help="~100M nnz after symmetrisation at scale 22")
+    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true")
+    return ap.parse_args()
+
+
+def kernel_alg_bytes(name, n, nnz, stats, launches):
+    """ALGORITHMIC bytes moved by all launches of one kernel group during one step
+    (DESIGN.md "Algorithmic bytes").  I = Z = V = 4 bytes."""
+    if name == "permute_tile":
+        return 16 * nnz + 12 * n + 8          # SURVEY §8d Permute2D figure
+    if name in ("bfs_expand", "bfs_heavy"):
+        # every BFS sweep reads each adjacency entry of the component once (4 B) and,
+        # per visited vertex, row_ptr (8 B) + distance/parent words (8 B)
+        return 4 * stats["edges_scanned"] + 16 * stats["largest_component"] * stats["bfs_sweeps"]
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sparsebase_amd import ops, synth
+
+    # ---- synthetic input: one RMAT instance per rank (seeded by rank), resident in HBM
+    rp, col = synth.rmat_symmetric_torch(args.scale, args.edge_factor, seed=1 + rank, device=dev)
+    n, nnz = rp.numel() - 1, col.numel()
+    val = (torch.arange(nnz, device=dev, dtype=torch.int32) % 1021).to(torch.float32)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    out = (torch.empty_like(rp), torch.empty_like(col), torch.empty_like(val))
+    torch.cuda.synchronize()
+
+    def step():
+        ops.rcm_reorder(rp, col, out=order)
+        ops.permute_csr(n, n, rp, col, val, order, order, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.profile_enable(True, dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    prof = ops.profile_report(dev)
+    ops.profile_enable(False, dev)
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    value = n * world * args.steps / wall / 1e6  # Mrows/s, whole job
+
+    # statistics of one RCM call (levels / sweeps / edges) for the roofline arithmetic
+    _, stats = ops.rcm_reorder(rp, col, out=order, return_stats=True)
+
+    # ---- dominant kernel + roofline (live HIP events recorded by the library on its stream)
+    roofline = None
+    if prof:
+        per_step = {k: (ms / args.steps, cnt / args.steps) for k, (ms, cnt) in prof.items()}
+        dom = max(per_step, key=lambda k: per_step[k][0])
+        ms_step, launches_step = per_step[dom]
+        alg = kernel_alg_bytes(dom, n, nnz, stats, launches_step)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        roofline = {
+            "bound": "hbm", "kernel": dom,
+            "achieved": None if alg is None else alg / launches_step / (ms_step / launches_step) / 1e6,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if alg is None else alg / ms_step / 1e6 / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "avg_launch_ms": ms_step / launches_step, "launches_per_step": launches_step,
+            "alg_bytes_per_step": alg,
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
+        }
+
+    # ---- the step that shards: row-range permutation apply + RCCL all-gather of row_ptr
+    permute_apply = None
+    if not args.no_sharded:
+        from sparsebase_amd import sharded
+        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).to(torch.int32)
+        if world > 1:
+            dist.broadcast(perm, 0)
+            # every rank permutes rank 0's matrix layout-wise identical? No: each rank holds its own
+            # instance; for the sharded apply all ranks must hold the SAME matrix -> regenerate seed 1.
+            if rank != 0:
+                rp_s, col_s = synth.rmat_symmetric_torch(args.scale, args.edge_factor, seed=1, device=dev)
+            else:
+                rp_s, col_s = rp, col
+            val_s = (torch.arange(col_s.numel(), device=dev, dtype=torch.int32) % 1021).to(torch.float32)
+        else:
+            rp_s, col_s, val_s = rp, col, val
+        n_s, nnz_s = rp_s.numel() - 1, col_s.numel()
+        ranges = sharded.row_ranges(n_s, world)
+
+        def sharded_step():
+            if world > 1:
+                return sharded.permute_csr_sharded(n_s, n_s, rp_s, col_s, val_s, perm, perm, ranges=ranges)
+            return ops.permute_csr(n_s, n_s, rp_s, col_s, val_s, perm, perm, out=out)
+
+        sharded_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sharded_step()
+        barrier()
+        w = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        alg = 16 * nnz_s + 12 * n_s + 8
+        permute_apply = {
+            "workload": f"Permute2D(random order) of one RMAT scale-{args.scale} CSR, new-row ranges over {world} GPU(s), "
+                        "all-gather of row_ptr" if world > 1 else f"Permute2D(random order), RMAT scale-{args.scale}, 1 GPU",
+            "scaling": "strong", "value": n_s * args.steps / w / 1e6, "unit": "Mrows/s", "ms_per_step": w / args.steps * 1e3,
+            "alg_gbs": alg * args.steps / w / 1e9, "frac_of_hbm_peak": alg * args.steps / w / 1e9 / (HBM_PEAK_GBS * world),
+        }
+
+    # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args, synth)
+
+    if rank == 0:
+        line = {
+            "metric": "Mrows/s, RCM reorder + CSR permute, 100M-nnz power-law (RMAT) CSR",
+            "value": value, "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"RCMReorder + Permute2D(order,order) on symmetric RMAT scale {args.scale} "
+                                   f"(a,b,c=.57,.19,.19, edge factor {args.edge_factor}) CSR <int32,int32,float32>, "
+                                   "one instance per GPU",
+                       "rows": n, "nnz": nnz, "rcm": stats},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "permute_apply": permute_apply,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, synth):
+    """Times the reference pipeline on the host: real reference if oracle/_ref is present
+    ("reference"), else the oracle restatement ("port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    rp_t, col_t = synth.rmat_symmetric_torch(args.cpu_scale, args.edge_factor, seed=1)
+    rp, col = rp_t.cpu().numpy(), col_t.cpu().numpy()
+    n, nnz = len(rp) - 1, len(col)
+    val = (np.arange(nnz) % 1021).astype(np.float32)
+    if orc.ref_available():
+        impl, kind = orc.Ref(), "reference"
+        cores = os.cpu_count()  # OpenMP default; only the CSR-ctor loops (format/csr.cc:102,123) are parallel
+    else:
+        impl, kind = orc.Oracle(), "port"
+        cores = 1
+    t0 = time.perf_counter()
+    order = impl.rcm_reorder(rp, col)
+    t1 = time.perf_counter()
+    impl.permute_csr(rp, col, val, order, order, m=n) if kind == "reference" else impl.permute_csr(rp, col, val, order, order)
+    t2 = time.perf_counter()
+    return {"value": n / (t2 - t0) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": kind,
+            "sample": f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition",
+            "rcm_s": t1 - t0, "permute_s": t2 - t1}
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,15 @@ int sbx_reserve(sbx_handle_t h, size_t scratch_bytes);
 int sbx_sync(sbx_handle_t h);
 const char *sbx_last_error(sbx_handle_t h);
 
+/* Optional per-kernel profiler: when enabled every kernel the library launches is
+ * bracketed by HIP events on the handle's stream.  sbx_profile_query(index) drains
+ * the events (synchronous) and returns the accumulated device time and launch
+ * count of kernel group `index` (names via sbx_profile_kernel_name). */
+int sbx_profile_enable(sbx_handle_t h, int on);
+int sbx_profile_kernel_count(void);
+const char *sbx_profile_kernel_name(int index);
+int sbx_profile_query(sbx_handle_t h, int index, double *total_ms_host, int64_t *launches_host);
+
 int sbx_malloc(sbx_handle_t h, size_t bytes, void **dev_ptr_host);
 int sbx_free(sbx_handle_t h, void *dev_ptr);
 /* blocking copies (stream-ordered after prior work on the handle's stream) */

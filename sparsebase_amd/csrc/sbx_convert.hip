@@ -313,8 +313,7 @@ extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz,
   int *flag = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &flag));
   SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_coo_is_sorted<int32_t>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), 0,
-                     h->stream, (const int32_t *)row, (const int32_t *)col, nnz, flag);
+  SBX_KLAUNCH(h, SBX_K_CHECK, k_coo_is_sorted<int32_t>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), (const int32_t *)row, (const int32_t *)col, nnz, flag);
   SBX_LAUNCH_CHECK(h);
   int f = 0;
   SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
@@ -337,8 +336,7 @@ extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n,
   int *flag = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &flag));
   SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_csr_rows_sorted<int32_t>, dim3((unsigned)((nnz + EX_TILE - 1) / EX_TILE)), dim3(CV_THREADS), 0,
-                     h->stream, (const int32_t *)row_ptr, (const int32_t *)col, n, nnz, flag);
+  SBX_KLAUNCH(h, SBX_K_CHECK, k_csr_rows_sorted<int32_t>, dim3((unsigned)((nnz + EX_TILE - 1) / EX_TILE)), dim3(CV_THREADS), (const int32_t *)row_ptr, (const int32_t *)col, n, nnz, flag);
   SBX_LAUNCH_CHECK(h);
   int f = 0;
   SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
@@ -364,7 +362,7 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
-  hipLaunchKernelGGL(k_pack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), 0, h->stream, (const int32_t *)row,
+  SBX_KLAUNCH(h, SBX_K_MISC, k_pack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), (const int32_t *)row,
                      (const int32_t *)col, ka, nnz);
   sbx_radix_pass passes[16];
   const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
@@ -372,7 +370,7 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
   int in_b = 0;
   SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, passes, np, &in_b));
   if (in_b && vb) SBX_HIP(h, hipMemcpyAsync(val, vtmp, (size_t)nnz * vb, hipMemcpyDeviceToDevice, h->stream));
-  hipLaunchKernelGGL(k_unpack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_MISC, k_unpack_rc<int32_t>, dim3(grid), dim3(CV_THREADS),
                      (const uint64_t *)(in_b ? kb : ka), (int32_t *)row, (int32_t *)col, nnz);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -388,10 +386,10 @@ int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *row
   const int64_t nquads = (nnz + 3) >> 2;
   const unsigned grid = sbx_grid_for(nquads, CV_THREADS, (int64_t)h->num_cus * 32);
   if (al)
-    hipLaunchKernelGGL((k_coo_to_csr<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), 0, h->stream, row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   else
-    hipLaunchKernelGGL((k_coo_to_csr<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), 0, h->stream, row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -403,10 +401,10 @@ int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp,
   const bool al = aligned16(row_out) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const unsigned grid = (unsigned)((nnz + EX_TILE - 1) / EX_TILE);
   if (al)
-    hipLaunchKernelGGL((k_csr_to_coo<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), 0, h->stream, rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz);
   else
-    hipLaunchKernelGGL((k_csr_to_coo<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), 0, h->stream, rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -454,7 +452,7 @@ extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   else if (vb == 4) rc = launch_coo_to_csr<4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
   else rc = launch_coo_to_csr<8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
   SBX_TRY(rc);
-  hipLaunchKernelGGL(k_fill_gaps<int32_t>, dim3(256), dim3(CV_THREADS), 0, h->stream, rp, (const GapEntry *)gaps,
+  SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_fill_gaps<int32_t>, dim3(256), dim3(CV_THREADS), rp, (const GapEntry *)gaps,
                      (const unsigned *)ngaps, gap_cap);
   SBX_LAUNCH_CHECK(h);
   if (!(flags & SBX_FLAG_ROWS_SORTED)) {
@@ -464,7 +462,7 @@ extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type 
     SBX_TRY(sbx_readback(h, &f, unsorted, sizeof(int)));
     if (f) {
       SBX_TRY(sbx_fill_i32(h, rp, 0, n + 1));
-      hipLaunchKernelGGL(k_row_hist_i32, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), 0, h->stream, r,
+      SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_row_hist_i32, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r,
                          rp, nnz);
       SBX_LAUNCH_CHECK(h);
       SBX_TRY(sbx_exclusive_scan_i32(h, rp, rp, n + 1, nullptr));

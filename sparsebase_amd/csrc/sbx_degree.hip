@@ -54,7 +54,7 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   SBX_TRY(sbx_salloc(h, 1, &mx));
   SBX_HIP(h, hipMemsetAsync(mx, 0, sizeof(unsigned), h->stream));
   const unsigned grid = sbx_grid_for(n, 256, 4096);
-  hipLaunchKernelGGL(k_degree_keys<int32_t>, dim3(grid), dim3(256), 0, h->stream, (const int32_t *)row_ptr, ka, ia, n,
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<int32_t>, dim3(grid), dim3(256), (const int32_t *)row_ptr, ka, ia, n,
                      mx);
   SBX_LAUNCH_CHECK(h);
   unsigned max_deg = 0;
@@ -63,7 +63,7 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   const int np = sbx_radix_plan(0, sbx_bits_for(max_deg), 0, 0, passes);
   int in_b = 0;
   SBX_TRY(sbx_radix_sort(h, 4, 4, ka, kb, ia, ib, n, passes, np, &in_b));
-  hipLaunchKernelGGL(k_degree_invert<int32_t>, dim3(grid), dim3(256), 0, h->stream, (const uint32_t *)(in_b ? ib : ia),
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_invert<int32_t>, dim3(grid), dim3(256), (const uint32_t *)(in_b ? ib : ia),
                      (int32_t *)inv_perm_out, n, ascending);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;

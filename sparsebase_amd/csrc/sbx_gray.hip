@@ -164,10 +164,10 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   }
   SBX_HIP(h, hipMemsetAsync(cnt, 0, 2 * sizeof(GrayCounts), h->stream));
   const int64_t band = m / 128;  // :138
-  hipLaunchKernelGGL(k_gray_short<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_short<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
                      (const int32_t *)row_ptr, (const int32_t *)col, n, width, band, bits, nnz_threshold,
                      (int32_t *)degree_out, key_out, cnt, long_list, n_long);
-  hipLaunchKernelGGL(k_gray_long<int32_t>, dim3(sbx_grid_for(n, 4, (int64_t)h->num_cus * 8)), dim3(256), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long<int32_t>, dim3(sbx_grid_for(n, 4, (int64_t)h->num_cus * 8)), dim3(256),
                      (const int32_t *)row_ptr, (const int32_t *)col, n, width, band, bits, nnz_threshold, key_out, cnt,
                      (const int32_t *)long_list, (const unsigned *)n_long);
   SBX_LAUNCH_CHECK(h);

@@ -74,6 +74,11 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->pinned = nullptr;
   h->pinned_bytes = 0;
   h->err[0] = 0;
+  h->prof_on = false;
+  for (int i = 0; i < SBX_K_COUNT; i++) {
+    h->prof_ms[i] = 0.0;
+    h->prof_launches[i] = 0;
+  }
   if (hipSetDevice(device) != hipSuccess) {
     delete h;
     return SBX_ERR_HIP;
@@ -96,6 +101,11 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto &b : h->blocks) (void)hipFree(b.ptr);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  for (auto &r : h->prof_pending) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  for (auto &e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
   return SBX_OK;
 }
@@ -239,5 +249,77 @@ extern "C" int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, co
   SBX_HIP(h, hipSetDevice(h->device));
   SBX_HIP(h, hipMemcpyPeerAsync(dst_dev, dst_device, src_dev, src_device, bytes, h->stream));
   SBX_HIP(h, hipStreamSynchronize(h->stream));
+  return SBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// HIP-event profiler (used by bench.py for the live per-kernel roofline figures)
+// ---------------------------------------------------------------------------
+const char *const sbx_kernel_names[SBX_K_COUNT] = {
+    "scan",          "radix_hist",   "radix_scatter", "coo_to_csr", "csr_to_coo", "permute_tile",
+    "permute_long",  "permute_prep", "bfs_expand",    "bfs_heavy",  "level_order", "cc",
+    "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "misc"};
+
+static hipEvent_t prof_event(sbx_handle_t h) {
+  if (!h->prof_pool.empty()) {
+    hipEvent_t e = h->prof_pool.back();
+    h->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void sbx_prof_begin(sbx_handle_t h, int kid) {
+  sbx_prof_rec r;
+  r.kid = kid;
+  r.start = prof_event(h);
+  r.stop = prof_event(h);
+  (void)hipEventRecord(r.start, h->stream);
+  h->prof_pending.push_back(r);
+}
+
+void sbx_prof_end(sbx_handle_t h) { (void)hipEventRecord(h->prof_pending.back().stop, h->stream); }
+
+static void prof_drain(sbx_handle_t h) {
+  for (auto &r : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      h->prof_ms[r.kid] += ms;
+      h->prof_launches[r.kid] += 1;
+    }
+    h->prof_pool.push_back(r.start);
+    h->prof_pool.push_back(r.stop);
+  }
+  h->prof_pending.clear();
+}
+
+extern "C" int sbx_profile_enable(sbx_handle_t h, int on) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  prof_drain(h);
+  if (on) {
+    for (int i = 0; i < SBX_K_COUNT; i++) {
+      h->prof_ms[i] = 0.0;
+      h->prof_launches[i] = 0;
+    }
+  }
+  h->prof_on = on != 0;
+  return SBX_OK;
+}
+
+extern "C" int sbx_profile_kernel_count(void) { return SBX_K_COUNT; }
+
+extern "C" const char *sbx_profile_kernel_name(int index) {
+  return (index >= 0 && index < SBX_K_COUNT) ? sbx_kernel_names[index] : nullptr;
+}
+
+extern "C" int sbx_profile_query(sbx_handle_t h, int index, double *total_ms_host, int64_t *launches_host) {
+  if (!h || index < 0 || index >= SBX_K_COUNT || !total_ms_host || !launches_host) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  prof_drain(h);
+  *total_ms_host = h->prof_ms[index];
+  *launches_host = h->prof_launches[index];
   return SBX_OK;
 }

@@ -12,6 +12,35 @@
 
 #define SBX_WAVE 64
 
+// kernel groups for the optional HIP-event profiler (sbx_profile_*)
+enum sbx_kernel_id {
+  SBX_K_SCAN = 0,
+  SBX_K_RADIX_HIST,
+  SBX_K_RADIX_SCATTER,
+  SBX_K_COO_TO_CSR,
+  SBX_K_CSR_TO_COO,
+  SBX_K_PERMUTE_TILE,
+  SBX_K_PERMUTE_LONG,
+  SBX_K_PERMUTE_PREP,
+  SBX_K_BFS_EXPAND,
+  SBX_K_BFS_HEAVY,
+  SBX_K_LEVEL_ORDER,
+  SBX_K_CC,
+  SBX_K_RCM_SMALL,
+  SBX_K_RCM_MISC,
+  SBX_K_GRAY,
+  SBX_K_DEGREE,
+  SBX_K_CHECK,
+  SBX_K_MISC,
+  SBX_K_COUNT
+};
+extern const char *const sbx_kernel_names[SBX_K_COUNT];
+
+struct sbx_prof_rec {
+  int kid;
+  hipEvent_t start, stop;
+};
+
 struct sbx_block {
   char *ptr;
   size_t cap;
@@ -31,8 +60,26 @@ struct sbx_handle_s {
   void *pinned;  // small pinned host buffer for device->host read-backs
   size_t pinned_bytes;
   int num_cus;
+  // profiler: when on, every kernel launch is bracketed by HIP events on the
+  // handle's stream; sbx_profile_query drains them into the accumulators
+  bool prof_on;
+  std::vector<sbx_prof_rec> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[SBX_K_COUNT];
+  long long prof_launches[SBX_K_COUNT];
   char err[512];
 };
+
+void sbx_prof_begin(sbx_handle_t h, int kid);
+void sbx_prof_end(sbx_handle_t h);
+
+// every kernel launch of the library goes through this macro
+#define SBX_KLAUNCH(h, kid, kernel, grid, block, ...)                        \
+  do {                                                                       \
+    if ((h)->prof_on) sbx_prof_begin((h), (kid));                            \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);    \
+    if ((h)->prof_on) sbx_prof_end((h));                                     \
+  } while (0)
 
 #define SBX_FAIL(h, code, ...)                       \
   do {                                               \

@@ -352,7 +352,7 @@ int launch_fix(sbx_handle_t h, sbx_value_type vt, const I *rpo, const I *col, vo
   const unsigned grid = sbx_grid_for(nr, 256, 4096);
 #define FIX(VT)                                                                                              \
   case VT:                                                                                                   \
-    hipLaunchKernelGGL((k_fix_dup_runs<I, typename Typed<VT>::T>), dim3(grid), dim3(256), 0, h->stream, rpo, col, \
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_fix_dup_runs<I, typename Typed<VT>::T>), dim3(grid), dim3(256), rpo, col, \
                        (typename Typed<VT>::T *)val, nr, (const PermState *)st);                            \
     break;
   switch (vt) {
@@ -374,7 +374,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
-    hipLaunchKernelGGL((k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), 0, h->stream, rp_in, col_in, val_in,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rp_in, col_in, val_in,
                        old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st);
     SBX_LAUNCH_CHECK(h);
   }
@@ -389,10 +389,10 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
       SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pa));
       SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pb));
     }
-    hipLaunchKernelGGL(k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), 0, h->stream, rpo, long_rows, loff,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), rpo, long_rows, loff,
                        (int)n_long);
     SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
-    hipLaunchKernelGGL((k_long_gather<I, VB>), dim3(n_long < 4096 ? n_long : 4096), dim3(256), 0, h->stream, rp_in,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(n_long < 4096 ? n_long : 4096), dim3(256), rp_in,
                        col_in, val_in, old_of_new, col_order, rpo, long_rows, (const uint32_t *)loff, (int)n_long, rb0,
                        ka, pa, st);
     SBX_LAUNCH_CHECK(h);
@@ -401,7 +401,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
                                   32 + sbx_bits_for((uint64_t)(n_long - 1)), passes);
     int in_b = 0;
     SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
-    hipLaunchKernelGGL((k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), 0, h->stream,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256),
                        (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
                        (const uint32_t *)loff, long_nnz, col_out, val_out, st);
     SBX_LAUNCH_CHECK(h);
@@ -428,7 +428,7 @@ extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_
   SBX_ONLY_I32(h, it);
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
-  hipLaunchKernelGGL(k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
                      (const int32_t *)perm, (int32_t *)inv_out, n);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -445,10 +445,10 @@ extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   if (n == 0) return SBX_OK;
   const unsigned grid = sbx_grid_for(n, 256, 8192);
   if (vb == 4)
-    hipLaunchKernelGGL((k_permute_array<int32_t, 4>), dim3(grid), dim3(256), 0, h->stream, (const int32_t *)order,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, (k_permute_array<int32_t, 4>), dim3(grid), dim3(256), (const int32_t *)order,
                        (const char *)vals, (char *)out, n);
   else
-    hipLaunchKernelGGL((k_permute_array<int32_t, 8>), dim3(grid), dim3(256), 0, h->stream, (const int32_t *)order,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, (k_permute_array<int32_t, 8>), dim3(grid), dim3(256), (const int32_t *)order,
                        (const char *)vals, (char *)out, n);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -485,14 +485,14 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   if (row_order) {
     SBX_TRY(sbx_salloc(h, (size_t)n, &old_of_new));
-    hipLaunchKernelGGL(k_invert<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), 0, h->stream, (const I *)row_order,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_order,
                        old_of_new, n);
   }
-  hipLaunchKernelGGL(k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
                      (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, st);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
-  hipLaunchKernelGGL(k_store_total<I>, dim3(1), dim3(1), 0, h->stream, (const I *)rpo, nr, st);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   const int64_t total = (int64_t)hs.total;
@@ -544,7 +544,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-  hipLaunchKernelGGL(k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256), 0, h->stream,
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
                      (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, st);
   SBX_LAUNCH_CHECK(h);
   PermState hs;

@@ -23,13 +23,13 @@ __global__ __launch_bounds__(256) void k_fill(T *__restrict__ dst, T value, int6
 
 int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count) {
   if (count <= 0) return SBX_OK;
-  hipLaunchKernelGGL(k_fill<int32_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), 0, h->stream, dst, value, count);
+  SBX_KLAUNCH(h, SBX_K_MISC, k_fill<int32_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), dst, value, count);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count) {
   if (count <= 0) return SBX_OK;
-  hipLaunchKernelGGL(k_fill<int64_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), 0, h->stream, dst, value, count);
+  SBX_KLAUNCH(h, SBX_K_MISC, k_fill<int64_t>, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), dst, value, count);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
@@ -104,16 +104,16 @@ static int exclusive_scan_impl(sbx_handle_t h, const T *in, T *out, int64_t coun
   }
   const int64_t tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
   if (tiles == 1) {
-    hipLaunchKernelGGL(k_scan_final<T>, dim3(1), dim3(SCAN_THREADS), 0, h->stream, in, out, (const T *)nullptr,
+    SBX_KLAUNCH(h, SBX_K_SCAN, k_scan_final<T>, dim3(1), dim3(SCAN_THREADS), in, out, (const T *)nullptr,
                        count, total_out);
     SBX_LAUNCH_CHECK(h);
     return SBX_OK;
   }
   T *partial = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)tiles, &partial));
-  hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, h->stream, in, partial, count);
-  hipLaunchKernelGGL(k_scan_partials<T>, dim3(1), dim3(1024), 0, h->stream, partial, tiles, total_out);
-  hipLaunchKernelGGL(k_scan_final<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, h->stream, in, out,
+  SBX_KLAUNCH(h, SBX_K_SCAN, k_scan_reduce<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), in, partial, count);
+  SBX_KLAUNCH(h, SBX_K_SCAN, k_scan_partials<T>, dim3(1), dim3(1024), partial, tiles, total_out);
+  SBX_KLAUNCH(h, SBX_K_SCAN, k_scan_final<T>, dim3((unsigned)tiles), dim3(SCAN_THREADS), in, out,
                      (const T *)partial, count, (T *)nullptr);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
@@ -273,10 +273,10 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   P *src_v = va, *dst_v = vb;
   for (int p = 0; p < np; p++) {
     const unsigned mask = (1u << passes[p].bits) - 1u;
-    hipLaunchKernelGGL((k_radix_hist<K, ITEMS>), dim3(tiles), dim3(RS_THREADS), 0, h->stream, (const K *)src_k, count,
+    SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_radix_hist<K, ITEMS>), dim3(tiles), dim3(RS_THREADS), (const K *)src_k, count,
                        passes[p].shift, mask, hist, tiles);
     SBX_TRY(sbx_exclusive_scan_u32(h, hist, hist, (int64_t)256 * tiles, nullptr));
-    hipLaunchKernelGGL((k_radix_scatter<K, P, ITEMS, HAS_P>), dim3(tiles), dim3(RS_THREADS), 0, h->stream,
+    SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_radix_scatter<K, P, ITEMS, HAS_P>), dim3(tiles), dim3(RS_THREADS),
                        (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
                        (const uint32_t *)hist, tiles);
     SBX_LAUNCH_CHECK(h);

@@ -498,7 +498,7 @@ struct BfsResult {
 // device-resident dv->root).  CM selects Cuthill-McKee child order.
 template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
-  hipLaunchKernelGGL(k_bfs_start, dim3(1), dim3(1), 0, h->stream, b.dist, b.q, b.dv, fixed_root);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.dist, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   while (true) {
@@ -506,9 +506,9 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
     unsigned grid = (waves_needed + 3) / 4;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_bfs_expand, dim3(grid), dim3(256), 0, h->stream, b.rp, b.col, (const I *)(b.q + off), fsize,
+    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
                        level + 1, b.dist, b.ppos, b.nf_list, b.heavy, b.dv);
-    hipLaunchKernelGGL(k_bfs_expand_heavy, dim3(max_grid), dim3(256), 0, h->stream, b.rp, b.col,
+    SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
                        (const I *)(b.q + off), level + 1, b.dist, b.ppos, b.nf_list, (const unsigned *)b.heavy, b.dv);
     SBX_LAUNCH_CHECK(h);
     unsigned nf = 0;
@@ -516,18 +516,18 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
     if (nf == 0) break;
     I *q_next = b.q + off + fsize;
     if (nf <= RCM_LDS_SORT) {
-      hipLaunchKernelGGL((k_level_sort_small<CM>), dim3(1), dim3(1024), 0, h->stream, (const I *)b.nf_list, nf,
+      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_sort_small<CM>), dim3(1), dim3(1024), (const I *)b.nf_list, nf,
                          (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
-      hipLaunchKernelGGL((k_level_keys<CM>), dim3(g), dim3(256), 0, h->stream, (const I *)b.nf_list, nf,
+      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
                          (const unsigned *)b.ppos, b.drank, b.ka);
       sbx_radix_pass passes[16];
       const int np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32,
                                     32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       int in_b = 0;
       SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
-      hipLaunchKernelGGL((k_level_emit<CM>), dim3(g), dim3(256), 0, h->stream, (const uint64_t *)(in_b ? b.kb : b.ka),
+      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256), (const uint64_t *)(in_b ? b.kb : b.ka),
                          nf, b.dorder, q_next, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
@@ -590,17 +590,17 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
 
   const unsigned gn = sbx_grid_for(n, 256, 8192);
   // (1) connected components; the root of each tree is the component's smallest id
-  hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(256), 0, h->stream, rp, col, label, n);
-  hipLaunchKernelGGL(k_cc_hook_small, dim3(gn), dim3(256), 0, h->stream, rp, col, label, n, big_list, dv);
-  hipLaunchKernelGGL(k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), 0, h->stream, rp, col, label,
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list, dv);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
                      (const I *)big_list, (const RcmDev *)dv);
-  hipLaunchKernelGGL(k_cc_finalize, dim3(gn), dim3(256), 0, h->stream, label, csize, n);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), label, csize, n);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
-  hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, h->stream, (const I *)label, (const I *)csize,
+  SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gn), dim3(256), (const I *)label, (const I *)csize,
                      (const I *)cbase, inv, small_list, large_list, n, dv);
   // (2) global (degree,id) rank used by the Cuthill-McKee keys
-  hipLaunchKernelGGL(k_deg_keys, dim3(gn), dim3(256), 0, h->stream, rp, dkey_a, did_a, n, dv);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(gn), dim3(256), rp, dkey_a, did_a, n, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
@@ -611,12 +611,12 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     int in_b = 0;
     SBX_TRY(sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n, passes, np, &in_b));
     dorder = in_b ? did_b : did_a;
-    hipLaunchKernelGGL(k_rank_from_order, dim3(gn), dim3(256), 0, h->stream, dorder, drank, n);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(gn), dim3(256), dorder, drank, n);
     SBX_LAUNCH_CHECK(h);
   }
   // (3) small components: one lane each
   if (hd.n_small) {
-    hipLaunchKernelGGL(k_rcm_small, dim3((hd.n_small + 63) / 64), dim3(64), 0, h->stream, rp, col,
+    SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_small + 63) / 64), dim3(64), rp, col,
                        (const I *)small_list, (const I *)csize, (const I *)cbase, dist, q, inv, dv);
     SBX_LAUNCH_CHECK(h);
   }
@@ -649,11 +649,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         if (e > ecc) ecc = e;
         const bool path = (int64_t)r.count == ecc + 1;
         if (!path && prev_ecc != ecc) {
-          hipLaunchKernelGGL(k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), 0, h->stream, rp,
+          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
                              (const I *)(q + r.last_offset), r.last_size, dv);
-          hipLaunchKernelGGL(k_set_root_from_best, dim3(1), dim3(1), 0, h->stream, (const I *)(q + r.last_offset), dv);
+          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
         }
-        hipLaunchKernelGGL(k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256), 0, h->stream,
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
                            (const I *)q, r.count, dist, ppos);
         SBX_LAUNCH_CHECK(h);
         if (path) break;
@@ -666,7 +666,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         SBX_FAIL(h, SBX_ERR_INTERNAL,
                  "sbx_rcm_reorder: BFS reached %u of %d vertices of a component (pattern not symmetric?)", r.count,
                  sizes[c]);
-      hipLaunchKernelGGL(k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256), 0, h->stream,
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
                          (const I *)q, r.count, bases[c], inv);
       SBX_LAUNCH_CHECK(h);
       if (sizes[c] > largest) {

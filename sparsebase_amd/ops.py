@@ -75,6 +75,25 @@ class Handle:
         self.check(self.lib.sbx_reserve(self.h, C.c_size_t(nbytes)))
 
 
+def profile_enable(on=True, device=None):
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    hd = handle_for(dev)
+    hd.check(hd.lib.sbx_profile_enable(hd.h, int(bool(on))))
+
+
+def profile_report(device=None):
+    """{kernel group: (total_ms, launches)} accumulated since profile_enable(True)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    hd = handle_for(dev)
+    out = {}
+    for i in range(hd.lib.sbx_profile_kernel_count()):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        hd.check(hd.lib.sbx_profile_query(hd.h, i, C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            out[hd.lib.sbx_profile_kernel_name(i).decode()] = (ms.value, cnt.value)
+    return out
+
+
 def handle_for(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     with _lock:
