@@ -276,53 +276,86 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
 }
 
 // ------------------------------------------------------------------ large components: BFS machinery
-__global__ void k_bfs_start(unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root) {
+// BFS bookkeeping (sized by the measured scatter ceilings of the chip: scattered
+// atomics run at ~27 G/s, scattered 4-byte loads at ~70 G/s from a 16 MB table and
+// ~180 G/s from an L2-resident one):
+//   vbits  one bit per vertex, set for every vertex of the levels already ORDERED
+//          (updated only between expansions, so plain loads are exact); n/8 bytes,
+//          L2-resident, filters every edge that points backwards;
+//   ppos   position of the smallest-position parent seen so far for a vertex of the
+//          level being built (UNSEEN = untouched).  A relaxed agent-scope load shows
+//          whether this edge can still lower it; only then the atomicMin is issued.
+//          The winner of the UNSEEN -> p transition appends the vertex to the frontier.
+__global__ void k_bfs_start(unsigned *__restrict__ vbits, I *__restrict__ q, RcmDev *__restrict__ dv,
+                            I fixed_root) {
   const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
   dv->root = (unsigned)r;
-  dist[r] = 0;
+  vbits[r >> 5] = 1u << (r & 31);  // the bitmap was cleared by the host for this sweep
   q[0] = r;
   dv->nf = 0;
   dv->n_heavy = 0;
   dv->best = ~0ull;
 }
 
-__device__ __forceinline__ void bfs_visit(I v, unsigned p, unsigned next_level, unsigned *dist, unsigned *ppos,
-                                          I *__restrict__ nf_list, RcmDev *__restrict__ dv, bool active) {
+// Winners are staged per wave in LDS and appended to the frontier in batches: one
+// hot counter word sustains only ~88 returning atomics per microsecond, so the
+// append must not cost one atomic per ballot.
+constexpr int RCM_STAGE = 512;  // staged vertices per wave
+
+struct WaveStage {
+  I *buf;        // this wave's LDS slice
+  unsigned cnt;  // wave-uniform fill level
+};
+
+__device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
+  if (st.cnt == 0) return;
+  unsigned base = 0;
+  if (sbx_lane() == 0) base = atomicAdd(&dv->nf, st.cnt);
+  base = __shfl(base, 0, 64);
+  __builtin_amdgcn_wave_barrier();
+  for (unsigned i = sbx_lane(); i < st.cnt; i += 64) nf_list[base + i] = st.buf[i];
+  __builtin_amdgcn_wave_barrier();
+  st.cnt = 0;
+}
+
+__device__ __forceinline__ void bfs_visit(I v, unsigned p, const unsigned *__restrict__ vbits, unsigned *ppos,
+                                          WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv,
+                                          bool active) {
   bool won = false;
-  if (active) {
-    unsigned d = dist[v];
-    if (d == UNSEEN) {
-      const unsigned old = atomicCAS(&dist[v], UNSEEN, next_level);
-      won = (old == UNSEEN);
-      d = won ? next_level : old;
-    }
-    if (d == next_level) atomicMin(&ppos[v], p);
+  if (active && !((vbits[v >> 5] >> (v & 31)) & 1u)) {
+    const unsigned cur = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur > p) won = (atomicMin(&ppos[v], p) == UNSEEN);
   }
   const uint64_t winners = __ballot(won);
   if (winners) {
-    unsigned base = 0;
-    const int leader = __builtin_ctzll(winners);
-    if (sbx_lane() == leader) base = atomicAdd(&dv->nf, (unsigned)__popcll(winners));
-    base = __shfl(base, leader, 64);
-    if (won) nf_list[base + __popcll(winners & sbx_lanemask_lt())] = v;
+    if (won) st.buf[st.cnt + __popcll(winners & sbx_lanemask_lt())] = v;
+    st.cnt += (unsigned)__popcll(winners);
+    if (st.cnt > RCM_STAGE - 64) stage_flush(st, nf_list, dv);
   }
 }
 
 // one wave per frontier vertex; hubs are queued for k_bfs_expand_heavy
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
-                                                    unsigned next_level, unsigned *dist, unsigned *ppos,
-                                                    I *__restrict__ nf_list, unsigned *__restrict__ heavy,
+                                                    unsigned next_level, const unsigned *__restrict__ vbits,
+                                                    unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
                                                     RcmDev *__restrict__ dv) {
+  __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u};
   unsigned long long scanned = 0;
   for (int64_t p = wave; p < fsize; p += nwaves) {
     const I u = frontier[p];
     const I s = rp[u], e = rp[u + 1];
     if (e - s > RCM_LIGHT) {
-      if (lane == 0) heavy[atomicAdd(&dv->n_heavy, 1u)] = (unsigned)p;
+      // hub: queue one descriptor (position, chunk) per 1024-neighbour chunk
+      const unsigned nchunks = (unsigned)((e - s + RCM_CHUNK - 1) / RCM_CHUNK);
+      unsigned slot = 0;
+      if (lane == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
+      slot = __shfl(slot, 0, 64);
+      for (unsigned c = lane; c < nchunks; c += 64) heavy[slot + c] = ((uint64_t)p << 32) | c;
       continue;
     }
     scanned += (unsigned)(e - s);
@@ -330,39 +363,40 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
       const I j = j0 + lane;
       const bool act = j < e;
       const I v = act ? col[j] : 0;
-      bfs_visit(v, (unsigned)p, next_level, dist, ppos, nf_list, dv, act);
+      bfs_visit(v, (unsigned)p, vbits, ppos, st, nf_list, dv, act);
     }
   }
+  stage_flush(st, nf_list, dv);
   if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
 }
 
 __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
                                                           const I *__restrict__ frontier, unsigned next_level,
-                                                          unsigned *dist, unsigned *ppos, I *__restrict__ nf_list,
-                                                          const unsigned *__restrict__ heavy,
+                                                          const unsigned *__restrict__ vbits, unsigned *ppos,
+                                                          I *__restrict__ nf_list,
+                                                          const uint64_t *__restrict__ heavy,
                                                           RcmDev *__restrict__ dv) {
-  const unsigned nh = dv->n_heavy;
-  unsigned chunk_base = 0;  // running chunk index over all hubs, identical in every workgroup
-  for (unsigned h = 0; h < nh; h++) {
-    const unsigned p = heavy[h];
+  __shared__ I s_stage[4][RCM_STAGE];
+  const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u};
+  unsigned long long scanned = 0;
+  for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
+    const uint64_t desc = heavy[d];
+    const unsigned p = (unsigned)(desc >> 32), c = (unsigned)desc;
     const I u = frontier[p];
     const I s = rp[u], e = rp[u + 1];
-    const unsigned nchunks = (unsigned)((e - s + RCM_CHUNK - 1) / RCM_CHUNK);
-    // chunks of this hub owned by this workgroup: (chunk_base + c) % gridDim.x == blockIdx.x
-    unsigned c = (blockIdx.x + gridDim.x - chunk_base % gridDim.x) % gridDim.x;
-    for (; c < nchunks; c += gridDim.x) {
-      const I cs = s + (I)c * RCM_CHUNK;
-      const I ce = (cs + RCM_CHUNK < e) ? cs + RCM_CHUNK : e;
-      for (I j0 = cs; j0 < ce; j0 += 256) {
-        const I j = j0 + (I)threadIdx.x;
-        const bool act = j < ce;
-        const I v = act ? col[j] : 0;
-        bfs_visit(v, p, next_level, dist, ppos, nf_list, dv, act);
-      }
-      if (threadIdx.x == 0) atomicAdd(&dv->edges, (unsigned long long)(ce - cs));
+    const I cs = s + (I)c * RCM_CHUNK;
+    const I ce = (cs + RCM_CHUNK < e) ? cs + RCM_CHUNK : e;
+    for (I j0 = cs; j0 < ce; j0 += 256) {
+      const I j = j0 + (I)threadIdx.x;
+      const bool act = j < ce;
+      const I v = act ? col[j] : 0;
+      bfs_visit(v, p, vbits, ppos, st, nf_list, dv, act);
     }
-    chunk_base += nchunks;
+    scanned += (unsigned long long)(ce - cs);
   }
+  stage_flush(st, nf_list, dv);
+  if (threadIdx.x == 0 && scanned) atomicAdd(&dv->edges, scanned);
 }
 
 template <bool CM>
@@ -380,12 +414,14 @@ __global__ __launch_bounds__(256) void k_level_keys(const I *__restrict__ nf_lis
 template <bool CM>
 __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__ key, unsigned nf,
                                                     const uint32_t *__restrict__ dorder, I *__restrict__ q_level,
-                                                    RcmDev *__restrict__ dv) {
+                                                    unsigned *__restrict__ vbits, RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; j < nf; j += stride) {
     const uint32_t lo = (uint32_t)key[j];
-    q_level[j] = (I)(CM ? dorder[lo] : lo);
+    const I v = (I)(CM ? dorder[lo] : lo);
+    q_level[j] = v;
+    atomicOr(&vbits[v >> 5], 1u << (v & 31));  // this level is now ordered
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     dv->nf = 0;
@@ -399,7 +435,8 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
                                                            const unsigned *__restrict__ ppos,
                                                            const uint32_t *__restrict__ drank,
                                                            const uint32_t *__restrict__ dorder,
-                                                           I *__restrict__ q_level, RcmDev *__restrict__ dv) {
+                                                           I *__restrict__ q_level, unsigned *__restrict__ vbits,
+                                                           RcmDev *__restrict__ dv) {
   __shared__ uint64_t s_key[RCM_LDS_SORT];
   unsigned p2 = 1;
   while (p2 < nf) p2 <<= 1;
@@ -430,7 +467,9 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
   }
   for (unsigned j = threadIdx.x; j < nf; j += blockDim.x) {
     const uint32_t lo = (uint32_t)s_key[j];
-    q_level[j] = (I)(CM ? dorder[lo] : lo);
+    const I v = (I)(CM ? dorder[lo] : lo);
+    q_level[j] = v;
+    atomicOr(&vbits[v >> 5], 1u << (v & 31));
   }
   if (threadIdx.x == 0) {
     dv->nf = 0;
@@ -457,15 +496,10 @@ __global__ void k_set_root_from_best(const I *__restrict__ level, RcmDev *__rest
   dv->root = (unsigned)level[(unsigned)dv->best];
 }
 
-__global__ __launch_bounds__(256) void k_reset_visited(const I *__restrict__ q, unsigned cnt, unsigned *dist,
-                                                       unsigned *ppos) {
+__global__ __launch_bounds__(256) void k_reset_visited(const I *__restrict__ q, unsigned cnt, unsigned *ppos) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; j < cnt; j += stride) {
-    const I v = q[j];
-    dist[v] = UNSEEN;
-    ppos[v] = UNSEEN;
-  }
+  for (; j < cnt; j += stride) ppos[q[j]] = UNSEEN;
 }
 
 __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q, unsigned cnt, I base,
@@ -477,10 +511,10 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
 
 struct BfsBuffers {
   const I *rp, *col;
-  unsigned *dist, *ppos;
+  unsigned *vbits, *ppos;
   I *q;         // visiting order of the current BFS (levels concatenated)
   I *nf_list;   // unordered next frontier
-  unsigned *heavy;
+  uint64_t *heavy;
   uint64_t *ka, *kb;
   const uint32_t *drank, *dorder;
   RcmDev *dv;
@@ -498,7 +532,8 @@ struct BfsResult {
 // device-resident dv->root).  CM selects Cuthill-McKee child order.
 template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.dist, b.q, b.dv, fixed_root);
+  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((b.n + 31) / 32) * sizeof(unsigned), h->stream));
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.vbits, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   while (true) {
@@ -507,9 +542,10 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
     SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
-                       level + 1, b.dist, b.ppos, b.nf_list, b.heavy, b.dv);
+                       level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.dv);
     SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
-                       (const I *)(b.q + off), level + 1, b.dist, b.ppos, b.nf_list, (const unsigned *)b.heavy, b.dv);
+                       (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
+                       (const uint64_t *)b.heavy, b.dv);
     SBX_LAUNCH_CHECK(h);
     unsigned nf = 0;
     SBX_TRY(sbx_readback(h, &nf, &b.dv->nf, sizeof(unsigned)));
@@ -517,7 +553,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
     I *q_next = b.q + off + fsize;
     if (nf <= RCM_LDS_SORT) {
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_sort_small<CM>), dim3(1), dim3(1024), (const I *)b.nf_list, nf,
-                         (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.dv);
+                         (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
@@ -528,7 +564,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
       int in_b = 0;
       SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256), (const uint64_t *)(in_b ? b.kb : b.ka),
-                         nf, b.dorder, q_next, b.dv);
+                         nf, b.dorder, q_next, b.vbits, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
     off += fsize;
@@ -562,8 +598,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   RcmDev *dv;
   uint32_t *dkey_a, *dkey_b, *did_a, *did_b, *drank;
   I *label, *csize, *cbase, *small_list, *large_list, *big_list, *q, *nf_list;
-  unsigned *dist, *ppos, *heavy;
-  uint64_t *ka, *kb;
+  unsigned *dist, *ppos, *vbits;
+  uint64_t *ka, *kb, *heavy;
   SBX_TRY(sbx_salloc(h, 1, &dv));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_a));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_b));
@@ -580,7 +616,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)n, &nf_list));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dist));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ppos));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &heavy));
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &vbits));
+  SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
   SBX_TRY(sbx_salloc(h, (size_t)n, &kb));
   SBX_HIP(h, hipMemsetAsync(dv, 0, sizeof(RcmDev), h->stream));
@@ -632,7 +669,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     }
     SBX_HIP(h, hipStreamSynchronize(h->stream));
     BfsBuffers b;
-    b.rp = rp; b.col = col; b.dist = dist; b.ppos = ppos; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
+    b.rp = rp; b.col = col; b.vbits = vbits; b.ppos = ppos; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
     b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
     for (unsigned c = 0; c < hd.n_large; c++) {
       // pseudo-peripheral search from the component's smallest vertex (:22-81)
@@ -654,7 +691,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
           SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
         }
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
-                           (const I *)q, r.count, dist, ppos);
+                           (const I *)q, r.count, ppos);
         SBX_LAUNCH_CHECK(h);
         if (path) break;
       }

@@ -1,0 +1,124 @@
+// sparsebase/hip/device.h — the only place of the host layer that touches the C
+// ABI's handle/memory entry points (include/sbx.h).  One sbx handle per device,
+// created on first use; every failure becomes a utils::HIPDeviceException — there
+// is no CPU fallback anywhere behind these calls.
+#ifndef SPARSEBASE_HIP_DEVICE_H_
+#define SPARSEBASE_HIP_DEVICE_H_
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "sbx.h"
+#include "sparsebase/utils/exception.h"
+
+namespace sparsebase::hip {
+
+inline int DeviceCount() {
+  int c = 0;
+  if (sbx_device_count(&c) != SBX_OK) return 0;
+  return c;
+}
+
+// device used when host-resident formats are staged through the GPU
+inline int DefaultDevice() {
+  const char *e = std::getenv("SBX_DEVICE");
+  return e ? std::atoi(e) : 0;
+}
+
+class Device {
+ public:
+  static Device &Get(int device_id) {
+    static std::mutex mu;
+    static std::map<int, Device *> devices;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = devices.find(device_id);
+    if (it != devices.end()) return *it->second;
+    sbx_handle_t h = nullptr;
+    const int rc = sbx_create(device_id, &h);
+    if (rc != SBX_OK)
+      throw utils::HIPDeviceException(std::string("cannot open HIP device ") + std::to_string(device_id) + ": " +
+                                      sbx_status_string(rc) + " (the reorder/convert path has no CPU fallback)");
+    auto *d = new Device(device_id, h);
+    devices[device_id] = d;
+    return *d;
+  }
+  sbx_handle_t handle() const { return h_; }
+  int id() const { return id_; }
+  void Check(int rc) const {
+    if (rc != SBX_OK)
+      throw utils::HIPDeviceException(std::string("sbx: ") + sbx_status_string(rc) + ": " + sbx_last_error(h_));
+  }
+  void *Malloc(size_t bytes) const {
+    void *p = nullptr;
+    Check(sbx_malloc(h_, bytes, &p));
+    return p;
+  }
+  void Free(void *p) const { sbx_free(h_, p); }
+  void ToDevice(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_h2d(h_, dst, src, bytes)); }
+  void ToHost(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2h(h_, dst, src, bytes)); }
+  void Copy(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2d(h_, dst, src, bytes)); }
+  void Sync() const { Check(sbx_sync(h_)); }
+
+  template <typename T>
+  T *Upload(const T *host, size_t count) const {
+    if (host == nullptr) return nullptr;
+    T *d = static_cast<T *>(Malloc(count * sizeof(T)));
+    ToDevice(d, host, count * sizeof(T));
+    return d;
+  }
+  template <typename T>
+  T *Download(const T *dev, size_t count) const {  // returns new T[count]; caller owns
+    if (dev == nullptr) return nullptr;
+    T *hptr = new T[count];
+    ToHost(hptr, dev, count * sizeof(T));
+    return hptr;
+  }
+
+ private:
+  Device(int id, sbx_handle_t h) : id_(id), h_(h) {}
+  int id_;
+  sbx_handle_t h_;
+};
+
+// RAII device allocation used for staging host-resident formats through the GPU
+template <typename T>
+class Staged {
+ public:
+  Staged(const Device &d, size_t count) : d_(d), count_(count), p_(static_cast<T *>(d.Malloc(count * sizeof(T)))) {}
+  Staged(const Device &d, const T *host, size_t count) : Staged(d, count) {
+    if (host) d_.ToDevice(p_, host, count * sizeof(T));
+  }
+  ~Staged() { d_.Free(p_); }
+  Staged(const Staged &) = delete;
+  Staged &operator=(const Staged &) = delete;
+  T *get() const { return p_; }
+  void ToHost(T *host) const { d_.ToHost(host, p_, count_ * sizeof(T)); }
+
+ private:
+  const Device &d_;
+  size_t count_;
+  T *p_;
+};
+
+// C ABI type tags for a C++ type tuple
+template <typename IDType>
+constexpr sbx_index_type IndexTag() {
+  static_assert(sizeof(IDType) == 4 || sizeof(IDType) == 8, "index type must be 32 or 64 bit");
+  return sizeof(IDType) == 4 ? SBX_I32 : SBX_I64;
+}
+template <typename V>
+constexpr sbx_value_type ValueTag() {
+  if constexpr (std::is_same_v<V, void>) return SBX_V_NONE;
+  else if constexpr (std::is_floating_point_v<V>) return sizeof(V) == 4 ? SBX_V_F32 : SBX_V_F64;
+  else if constexpr (std::is_signed_v<V>) return sizeof(V) == 4 ? SBX_V_I32 : SBX_V_I64;
+  else return sizeof(V) == 4 ? SBX_V_U32 : SBX_V_U64;
+}
+template <typename V>
+constexpr size_t ValueBytes() {
+  if constexpr (std::is_same_v<V, void>) return 0;
+  else return sizeof(V);
+}
+
+}  // namespace sparsebase::hip
+#endif
