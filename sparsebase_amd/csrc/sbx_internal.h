@@ -21,6 +21,7 @@ enum sbx_kernel_id {
   SBX_K_CSR_TO_COO,
   SBX_K_PERMUTE_TILE,
   SBX_K_PERMUTE_LONG,
+  SBX_K_PERMUTE_BLOCK,
   SBX_K_PERMUTE_PREP,
   SBX_K_BFS_EXPAND,
   SBX_K_BFS_HEAVY,

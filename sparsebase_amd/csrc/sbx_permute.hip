@@ -29,12 +29,15 @@ constexpr int PT_CAP = 2 * PT_TILE;  // LDS capacity of one tile, in entries
 constexpr int PT_ITEMS = PT_CAP / PT_THREADS;
 constexpr int PT_SHORT = 32;         // all-pairs rank sort up to this row length
 constexpr int PT_MAXMED = PT_CAP / (PT_SHORT + 1) + 2;
+constexpr int BR_THREADS = 1024;     // one workgroup sorts one row of up to BR_CAP entries in LDS
+template <int VB> struct BlockRowCap { static constexpr int value = 16384; };
+template <> struct BlockRowCap<8> { static constexpr int value = 8192; };
 
 struct PermState {            // device-resident flags/counters of one call
   unsigned any_unsorted;      // some row had col[j] < col[j-1] after relabelling (csr.cc:102-116)
   unsigned any_dup;           // some row holds a duplicate column
-  unsigned n_long;            // rows longer than PT_TILE
-  unsigned pad;
+  unsigned n_long;            // rows longer than the block-row capacity (global radix path)
+  unsigned n_block;           // rows in (PT_TILE, capacity]: one workgroup each
   unsigned long long long_nnz;
   unsigned long long total;   // nnz of the shard
 };
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ ord
 template <typename I>
 __global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, const I *__restrict__ old_of_new,
                                                      I *__restrict__ rpo, int64_t rb0, int64_t nr,
-                                                     I *__restrict__ long_rows, PermState *__restrict__ st) {
+                                                     I *__restrict__ long_rows, I *__restrict__ block_rows,
+                                                     int block_cap, PermState *__restrict__ st) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i <= nr; i += stride) {
@@ -73,10 +77,12 @@ __global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, c
     const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + i] : rb0 + i;
     const I d = rp[u + 1] - rp[u];
     rpo[i] = d;
-    if (d > PT_TILE) {
+    if (d > block_cap) {
       const unsigned slot = atomicAdd(&st->n_long, 1u);
       long_rows[slot] = (I)i;
       atomicAdd(&st->long_nnz, (unsigned long long)d);
+    } else if (d > PT_TILE) {
+      block_rows[atomicAdd(&st->n_block, 1u)] = (I)i;
     }
   }
 }
@@ -93,15 +99,16 @@ __global__ void k_store_total(const I *__restrict__ rpo, int64_t nr, PermState *
 template <typename V, bool HASV>
 __device__ __forceinline__ void wave_bitonic_lds(volatile int *c, volatile V *v, int len) {
   const int lane = sbx_lane();
-  int p2 = 1;
-  while (p2 < len) p2 <<= 1;
-  const int pairs = p2 >> 1;
-  for (int k = 2; k <= p2; k <<= 1) {
-    const int half = k >> 1;
+  int lg = 0;
+  while ((1 << lg) < len) lg++;
+  const int pairs = (1 << lg) >> 1;
+  for (int kb = 1; kb <= lg; kb++) {  // block size k = 1 << kb
+    const int hb = kb - 1;            // log2(half)
+    const int k = 1 << kb, half = 1 << hb;
     // flip step: i = b*k + off, l = b*k + (k-1-off)
     for (int q = lane; q < pairs; q += 64) {
-      const int b = q / half, off = q - b * half;
-      const int i = b * k + off, l = b * k + (k - 1 - off);
+      const int b = q >> hb, off = q & (half - 1);
+      const int i = (b << kb) + off, l = (b << kb) + (k - 1 - off);
       if (l < len) {
         const int ci = c[i], cl = c[l];
         if (ci > cl) {
@@ -111,9 +118,10 @@ __device__ __forceinline__ void wave_bitonic_lds(volatile int *c, volatile V *v,
       }
     }
     __builtin_amdgcn_wave_barrier();
-    for (int j = half >> 1; j > 0; j >>= 1) {
+    for (int jb = hb - 1; jb >= 0; jb--) {  // stride j = 1 << jb
+      const int j = 1 << jb;
       for (int q = lane; q < pairs; q += 64) {
-        const int i = 2 * j * (q / j) + (q % j), l = i + j;
+        const int i = ((q >> jb) << (jb + 1)) + (q & (j - 1)), l = i + j;
         if (l < len) {
           const int ci = c[i], cl = c[l];
           if (ci > cl) {
@@ -252,6 +260,125 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   if (__any(dup) && lane == 0) st->any_dup = 1;
 }
 
+// ---- rows of (PT_TILE, capacity] entries: one workgroup per row, LDS radix sort ----
+// The row is gathered (relabelled) into LDS once, sorted there by a stable LSD radix
+// sort over the significant column bits (ballot match-any ranking, per-wave digit
+// counters; every thread keeps its items in registers across the in-place scatter)
+// and streamed out: HBM sees each nonzero exactly once in and once out.
+struct RowPasses {
+  int n;
+  int shift[4];
+  int bits[4];
+};
+
+template <typename I, int VB>
+__global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
+    const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
+    const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out,
+    char *val_out, int64_t rb0, RowPasses passes, PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  constexpr bool HASV = VB != 0;
+  constexpr int CAP = BlockRowCap<VB>::value;
+  constexpr int ITEMS = CAP / BR_THREADS;
+  constexpr int WAVES = BR_THREADS / 64;
+  __shared__ int s_key[CAP];
+  __shared__ V s_val[HASV ? CAP : 1];
+  __shared__ unsigned s_whist[WAVES][256];
+  __shared__ unsigned s_scan[WAVES + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t r = block_rows[blockIdx.x];
+  const int64_t e0 = rpo[r];
+  const int len = (int)((int64_t)rpo[r + 1] - e0);
+  const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
+  const int64_t src0 = rp_in[u];
+  for (int i = tid; i < CAP; i += BR_THREADS) {
+    int c = 0x7FFFFFFF;  // padding: sorts last, never written out
+    if (i < len) {
+      I cc = col_in[src0 + i];
+      if (col_order) cc = col_order[cc];
+      c = (int)cc;
+      if (HASV) s_val[i] = ((const V *)val_in)[src0 + i];
+    }
+    s_key[i] = c;
+  }
+  __syncthreads();
+  bool unsorted = false;
+  for (int i = tid + 1; i < len; i += BR_THREADS) unsorted |= s_key[i] < s_key[i - 1];
+  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+
+  volatile unsigned *wh = s_whist[w];
+  const uint64_t lt = sbx_lanemask_lt();
+  for (int pass = 0; pass < passes.n; pass++) {
+    const int shift = passes.shift[pass], bits = passes.bits[pass];
+    const unsigned mask = (1u << bits) - 1u;
+    for (int i = tid; i < 256 * WAVES; i += BR_THREADS) (&s_whist[0][0])[i] = 0;
+    int k[ITEMS];
+    V v[HASV ? ITEMS : 1];
+    unsigned rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const int e = w * 64 * ITEMS + i * 64 + lane;
+      k[i] = s_key[e];
+      if (HASV) v[i] = s_val[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const unsigned d = ((unsigned)k[i] >> shift) & mask;
+      uint64_t m = ~(uint64_t)0;
+      for (int b = 0; b < bits; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const unsigned prev = wh[d];
+      const unsigned rk = (unsigned)__popcll(m & lt);
+      __builtin_amdgcn_wave_barrier();
+      if (rk == 0) wh[d] = prev + (unsigned)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      rank[i] = prev + rk;
+    }
+    __syncthreads();
+    {
+      unsigned c[WAVES];
+      unsigned tot = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+          c[i] = s_whist[i][tid];
+          tot += c[i];
+        }
+      }
+      unsigned all;
+      unsigned ex = sbx_block_exclusive_sum<unsigned, BR_THREADS>(tot, s_scan, &all);
+      if (tid < 256) {
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+          s_whist[i][tid] = ex;
+          ex += c[i];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const unsigned d = ((unsigned)k[i] >> shift) & mask;
+      const unsigned pos = s_whist[w][d] + rank[i];
+      s_key[pos] = k[i];
+      if (HASV) s_val[pos] = v[i];
+    }
+    __syncthreads();
+  }
+  bool dup = false;
+  for (int i = tid; i < len; i += BR_THREADS) {
+    const int c = s_key[i];
+    if (i && c == s_key[i - 1]) dup = true;
+    col_out[e0 + i] = (I)c;
+    if (HASV) ((V *)val_out)[e0 + i] = s_val[i];
+  }
+  if (__any(dup) && lane == 0) st->any_dup = 1;
+}
+
 // ---- long rows ----------------------------------------------------------------
 template <typename I, int VB>
 __global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in, const I *col_in, const char *val_in,
@@ -370,12 +497,24 @@ template <int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const int32_t *col_in, const char *val_in,
                const int32_t *old_of_new, const int32_t *col_order, const int32_t *rpo, int32_t *col_out,
                char *val_out, int64_t nr, int64_t rb0, int64_t m, int64_t total, const int32_t *long_rows,
-               unsigned n_long, int64_t long_nnz, PermState *st) {
+               unsigned n_long, int64_t long_nnz, const int32_t *block_rows, unsigned n_block, PermState *st) {
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rp_in, col_in, val_in,
                        old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st);
+    SBX_LAUNCH_CHECK(h);
+  }
+  if (n_block) {
+    RowPasses rpasses;
+    sbx_radix_pass pl[16];
+    rpasses.n = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, pl);
+    for (int i = 0; i < rpasses.n && i < 4; i++) {
+      rpasses.shift[i] = pl[i].shift;
+      rpasses.bits[i] = pl[i].bits;
+    }
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB>), dim3(n_block), dim3(BR_THREADS), rp_in, col_in,
+                val_in, old_of_new, col_order, rpo, block_rows, col_out, val_out, rb0, rpasses, st);
     SBX_LAUNCH_CHECK(h);
   }
   if (n_long) {
@@ -475,12 +614,14 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   if (nr == 0) return sbx_fill_i32(h, rpo, 0, 1);
 
   PermState *st = nullptr;
-  I *old_of_new = nullptr, *long_rows = nullptr;
+  I *old_of_new = nullptr, *long_rows = nullptr, *block_rows = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   {
     int64_t cap_long = nnz / PT_TILE + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long, &block_rows));
   }
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   if (row_order) {
@@ -489,7 +630,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
                        old_of_new, n);
   }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, st);
+                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, block_rows, block_cap, st);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
@@ -504,7 +645,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
 #define STAGE(VBX)                                                                                               \
   rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, old_of_new,                 \
                        (const I *)col_order, rpo, (I *)col_out, (char *)val_out, nr, row_begin, m, total, long_rows, \
-                       hs.n_long, (int64_t)hs.long_nnz, st)
+                       hs.n_long, (int64_t)hs.long_nnz, block_rows, hs.n_block, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
@@ -536,23 +677,26 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_TRY(sbx_arena_begin(h));
   typedef int32_t I;
   PermState *st = nullptr;
-  I *long_rows = nullptr, *deg = nullptr, *ctmp = nullptr;
+  I *long_rows = nullptr, *block_rows = nullptr, *deg = nullptr, *ctmp = nullptr;
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   char *vtmp = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &block_rows));
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &deg));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, st);
+                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, block_rows, block_cap, st);
   SBX_LAUNCH_CHECK(h);
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   int rc;
 #define STAGE(VBX)                                                                                              \
   rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, nullptr, nullptr,          \
-                       (const I *)row_ptr, ctmp, vtmp, n, 0, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz, st)
+                       (const I *)row_ptr, ctmp, vtmp, n, 0, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz, block_rows, \
+                       hs.n_block, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);

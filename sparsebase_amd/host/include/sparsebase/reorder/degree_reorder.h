@@ -10,7 +10,7 @@ namespace sparsebase::reorder {
 
 struct DegreeReorderParams : utils::Parameters {
   bool ascending;
-  explicit DegreeReorderParams(bool ascending) : ascending(ascending) {}
+  DegreeReorderParams(bool ascending) : ascending(ascending) {}
 };
 
 template <typename IDType, typename NNZType, typename ValueType>

@@ -1,0 +1,364 @@
+// GPU tests of the host layer: the hot-path cases of the reference's own suites,
+// re-expressed against this library (same fixtures, same assertions), plus the device
+// formats.  Sources of the cases (under /root/reference/tests/suites/sparsebase/):
+//   converter/converter_order_two_tests.cc:9-48,205-252,303-351   COO<->CSR copy / move / self
+//   format/coo_tests.cc:77-115, format/csr_tests.cc:80-115        constructor sorts
+//   permute/permute_order_two_tests.cc:27-91                      row / row+col / inverse
+//   reorder/{degree,rcm,gray}_reorder_tests.cc, reorder_tests.cc:27-125, bases/reorder_base_tests.cc
+//   converter/converter_order_two_cuda_tests.cu:11-49             host<->device round trips
+// Fixtures: functionality_common.inc:6-44, converter/common.inc:5-16, format/common.inc:4-12.
+#include <algorithm>
+#include <memory>
+#include <numeric>
+
+#include "minitest.h"
+#include "sparsebase/sparsebase.h"
+
+using namespace sparsebase;
+typedef format::CSR<int, int, int> CSR3;
+typedef format::COO<int, int, int> COO3;
+typedef format::HIPCSR<int, int, int> DCSR3;
+typedef format::HIPCOO<int, int, int> DCOO3;
+
+// functionality_common.inc
+static const int n = 3, nnz = 4;
+static int row_ptr[n + 1] = {0, 2, 3, 4}, cols[nnz] = {1, 2, 0, 0}, rows[nnz] = {0, 0, 1, 2}, vals[nnz] = {1, 2, 3, 4};
+static int r_reorder_vector[3] = {1, 2, 0}, r_row_ptr[n + 1] = {0, 1, 3, 4}, r_cols[nnz] = {0, 1, 2, 0},
+           r_vals[nnz] = {4, 1, 2, 3};
+static int c_reorder_vector[3] = {2, 0, 1};
+static int rc_row_ptr[n + 1] = {0, 1, 3, 4}, rc_cols[nnz] = {2, 0, 1, 2}, rc_vals[nnz] = {4, 1, 2, 3};
+static int inverse_perm_array[3] = {2, 0, 1}, perm_array[3] = {1, 2, 0};
+static float original_array[3] = {0.0f, 0.1f, 0.2f}, reordered_array[3] = {0.1f, 0.2f, 0.0f};
+// converter/common.inc
+static const int cn = 12, cm = 9, cnnz = 7;
+static int coo_row[7]{0, 0, 1, 3, 5, 10, 11}, coo_col[7]{0, 2, 1, 3, 3, 8, 7}, coo_vals[7]{3, 5, 7, 9, 15, 11, 13};
+static int csr_row_ptr[13]{0, 2, 3, 3, 4, 4, 5, 5, 5, 5, 5, 6, 7}, csr_col[7]{0, 2, 1, 3, 3, 8, 7},
+    csr_vals[7]{3, 5, 7, 9, 15, 11, 13};
+
+static context::CPUContext cpu_context;
+static std::unique_ptr<context::HIPContext> hip_context;
+
+template <typename A, typename B>
+static bool same(const A *a, const B *b, size_t count) {
+  for (size_t i = 0; i < count; i++)
+    if (!(a[i] == (A)b[i])) return false;
+  return true;
+}
+template <typename T>
+static bool is_permutation_of_iota(const T *p, size_t count) {
+  std::vector<char> seen(count, 0);
+  for (size_t i = 0; i < count; i++) {
+    if ((size_t)p[i] >= count || seen[p[i]]) return false;
+    seen[p[i]] = 1;
+  }
+  return true;
+}
+template <typename T>
+static std::vector<T> fetch(hip::Device &dev, const T *d, size_t count) {
+  std::vector<T> h(count);
+  if (count) dev.ToHost(h.data(), d, count * sizeof(T));
+  return h;
+}
+
+// ------------------------------------------------------------------ converter_order_two_tests.cc
+TEST(ConverterOrderTwo, COOToCSR) {
+  COO3 coo(cn, cm, cnnz, coo_row, coo_col, coo_vals, format::kNotOwned);
+  converter::ConverterOrderTwo<int, int, int> conv;
+  auto *csr = conv.Convert<CSR3>(&coo, &cpu_context);  // copy
+  EXPECT_TRUE(same(csr->get_row_ptr(), csr_row_ptr, cn + 1));
+  EXPECT_TRUE(same(csr->get_col(), csr_col, cnnz));
+  EXPECT_TRUE(same(csr->get_vals(), csr_vals, cnnz));
+  EXPECT_NE(csr->get_col(), coo.get_col());
+  EXPECT_NE(csr->get_vals(), coo.get_vals());
+  delete csr;
+  // move: col/vals are handed over by pointer (:236-240)
+  int *r = new int[7], *c = new int[7], *v = new int[7];
+  std::copy(coo_row, coo_row + 7, r);
+  std::copy(coo_col, coo_col + 7, c);
+  std::copy(coo_vals, coo_vals + 7, v);
+  COO3 owned(cn, cm, cnnz, r, c, v, format::kOwned);
+  auto *moved = conv.Convert<CSR3>(&owned, &cpu_context, true);
+  EXPECT_TRUE(same(moved->get_row_ptr(), csr_row_ptr, cn + 1));
+  EXPECT_EQ(moved->get_col(), c);
+  EXPECT_EQ(moved->get_vals(), v);
+  EXPECT_FALSE(owned.ColIsOwned());
+  delete moved;
+}
+
+TEST(ConverterOrderTwo, CSRToCOO) {
+  CSR3 csr(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  auto *coo = csr.Convert<format::COO>(&cpu_context);  // member syntax (format_conversion.cc:18-19)
+  EXPECT_TRUE(same(coo->get_row(), coo_row, cnnz));
+  EXPECT_TRUE(same(coo->get_col(), coo_col, cnnz));
+  EXPECT_TRUE(same(coo->get_vals(), coo_vals, cnnz));
+  EXPECT_NE(coo->get_col(), csr.get_col());
+  delete coo;
+  int *rp = new int[13], *c = new int[7], *v = new int[7];
+  std::copy(csr_row_ptr, csr_row_ptr + 13, rp);
+  std::copy(csr_col, csr_col + 7, c);
+  std::copy(csr_vals, csr_vals + 7, v);
+  CSR3 owned(cn, cm, rp, c, v, format::kOwned);
+  auto *moved = owned.Convert<format::COO>(&cpu_context, true);
+  EXPECT_TRUE(same(moved->get_row(), coo_row, cnnz));
+  EXPECT_EQ(moved->get_col(), c);
+  EXPECT_EQ(moved->get_vals(), v);
+  delete moved;
+}
+
+TEST(ConverterOrderTwo, SelfConversionReturnsTheSource) {
+  CSR3 csr(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  EXPECT_EQ(csr.Convert<format::CSR>(&cpu_context), &csr);  // :303-351
+  COO3 coo(cn, cm, cnnz, coo_row, coo_col, coo_vals, format::kNotOwned);
+  EXPECT_EQ(coo.Convert<format::COO>(&cpu_context), &coo);
+}
+
+TEST(ConverterOrderTwo, VoidValuesAndOtherTuples) {
+  format::COO<int, int, void> coo(cn, cm, cnnz, coo_row, coo_col, nullptr, format::kNotOwned);
+  auto *csr = coo.Convert<format::CSR>(&cpu_context);
+  EXPECT_TRUE(same(csr->get_row_ptr(), csr_row_ptr, cn + 1));
+  EXPECT_TRUE(same(csr->get_col(), csr_col, cnnz));
+  EXPECT_EQ(csr->get_vals(), (void *)nullptr);
+  delete csr;
+  unsigned ur[7], uc[7];
+  float fv[7];
+  for (int i = 0; i < 7; i++) { ur[i] = coo_row[i]; uc[i] = coo_col[i]; fv[i] = (float)coo_vals[i]; }
+  format::COO<unsigned, unsigned, float> ucoo(cn, cm, cnnz, ur, uc, fv, format::kNotOwned);
+  auto *ucsr = ucoo.Convert<format::CSR>(&cpu_context);
+  EXPECT_TRUE(same(ucsr->get_row_ptr(), csr_row_ptr, cn + 1));
+  EXPECT_TRUE(same(ucsr->get_vals(), csr_vals, cnnz));
+  delete ucsr;
+}
+
+// ------------------------------------------------------------------ coo_tests.cc / csr_tests.cc (Sort)
+TEST(COO, Sort) {
+  const int want_row[4]{0, 0, 1, 3}, want_col[4]{0, 2, 1, 3}, want_vals[4]{4, 5, 7, 9};
+  int r[4]{0, 0, 3, 1}, c[4]{2, 0, 3, 1}, v[4]{5, 4, 9, 7};
+  COO3 coo(4, 4, 4, r, c, v, format::kNotOwned);
+  EXPECT_TRUE(same(coo.get_row(), want_row, 4) && same(coo.get_col(), want_col, 4) && same(coo.get_vals(), want_vals, 4));
+  EXPECT_TRUE(same(r, want_row, 4));  // sorted in place on the caller's arrays
+  int r2[4]{0, 0, 3, 1}, c2[4]{2, 0, 3, 1}, v2[4]{5, 4, 9, 7};
+  COO3 keep(4, 4, 4, r2, c2, v2, format::kNotOwned, true);  // ignore_sort
+  const int orig_r[4]{0, 0, 3, 1}, orig_c[4]{2, 0, 3, 1};
+  EXPECT_TRUE(same(keep.get_row(), orig_r, 4) && same(keep.get_col(), orig_c, 4));
+  int r3[4]{0, 0, 3, 1}, c3[4]{2, 0, 3, 1};
+  format::COO<int, int, void> pattern(4, 4, 4, r3, c3, nullptr, format::kNotOwned);
+  EXPECT_EQ(pattern.get_vals(), (void *)nullptr);
+  EXPECT_TRUE(same(pattern.get_row(), want_row, 4) && same(pattern.get_col(), want_col, 4));
+}
+
+TEST(CSR, Sort) {
+  const int want_col[4]{0, 2, 1, 3}, want_vals[4]{4, 5, 7, 9};
+  int rp[5]{0, 2, 3, 3, 4}, c[4]{2, 0, 1, 3}, v[4]{5, 4, 7, 9};
+  CSR3 csr(4, 4, rp, c, v, format::kNotOwned);
+  EXPECT_TRUE(same(csr.get_col(), want_col, 4) && same(csr.get_vals(), want_vals, 4));
+  int c2[4]{2, 0, 1, 3}, v2[4]{5, 4, 7, 9};
+  CSR3 keep(4, 4, rp, c2, v2, format::kNotOwned, true);
+  const int orig_c[4]{2, 0, 1, 3};
+  EXPECT_TRUE(same(keep.get_col(), orig_c, 4));
+  int c3[4]{2, 0, 1, 3};
+  format::CSR<int, int, void> pattern(4, 4, rp, c3, nullptr, format::kNotOwned);
+  EXPECT_TRUE(same(pattern.get_col(), want_col, 4));
+}
+
+// ------------------------------------------------------------------ permute_order_two_tests.cc
+TEST(PermuteOrderTwo, RowWise) {
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  COO3 global_coo(n, n, nnz, rows, cols, vals, format::kNotOwned);
+  permute::PermuteOrderTwo<int, int, int> transformer(r_reorder_vector, nullptr);
+  EXPECT_THROW(transformer.GetPermutation(&global_coo, {&cpu_context}, false),
+               utils::DirectExecutionNotAvailableException<std::vector<std::type_index>>);
+  auto *out = transformer.GetPermutation(&global_csr, {&cpu_context}, false)->As<format::CSR>();
+  EXPECT_TRUE(same(out->get_row_ptr(), r_row_ptr, n + 1) && same(out->get_col(), r_cols, nnz) &&
+              same(out->get_vals(), r_vals, nnz));
+  delete out;
+  // a COO input is converted when allowed
+  auto *via = transformer.GetPermutation(&global_coo, {&cpu_context}, true)->As<format::CSR>();
+  EXPECT_TRUE(same(via->get_row_ptr(), r_row_ptr, n + 1) && same(via->get_col(), r_cols, nnz));
+  delete via;
+}
+
+TEST(PermuteOrderTwo, RowColWiseAndInverse) {
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  permute::PermuteOrderTwo<int, int, int> transformer(r_reorder_vector, c_reorder_vector);
+  auto *perm = transformer.GetPermutation(&global_csr, {&cpu_context}, false)->As<format::CSR>();
+  EXPECT_TRUE(same(perm->get_row_ptr(), rc_row_ptr, n + 1) && same(perm->get_col(), rc_cols, nnz) &&
+              same(perm->get_vals(), rc_vals, nnz));
+  auto *inv_r = bases::ReorderBase::InversePermutation(r_reorder_vector, n);
+  auto *inv_c = bases::ReorderBase::InversePermutation(c_reorder_vector, n);
+  permute::PermuteOrderTwo<int, int, int> back(inv_r, inv_c);
+  auto *orig = back.GetPermutation(perm, {&cpu_context}, false)->As<format::CSR>();
+  EXPECT_TRUE(same(orig->get_row_ptr(), row_ptr, n + 1) && same(orig->get_col(), cols, nnz) &&
+              same(orig->get_vals(), vals, nnz));
+  delete orig;
+  delete perm;
+  delete[] inv_r;
+  delete[] inv_c;
+}
+
+TEST(PermuteOrderOne, ArrayAndInversePermutation) {
+  auto *inv = bases::ReorderBase::InversePermutation(perm_array, 3);
+  EXPECT_TRUE(same(inv, inverse_perm_array, 3));
+  delete[] inv;
+  format::Array<float> arr(3, original_array, format::kNotOwned);
+  auto *out = bases::ReorderBase::Permute1D(inverse_perm_array, &arr, {&cpu_context}, true)->As<format::Array>();
+  EXPECT_TRUE(same(out->get_vals(), reordered_array, 3));
+  delete out;
+}
+
+// ------------------------------------------------------------------ reorderers
+template <typename I>
+static void check_degree_ordering(I *order, I nrows, const I *rp, bool ascending) {  // functionality_common.inc:67-90
+  EXPECT_TRUE(is_permutation_of_iota(order, nrows));
+  std::vector<I> perm(nrows);
+  for (I i = 0; i < nrows; i++) perm[order[i]] = i;
+  for (I i = 0; i + 1 < nrows; i++) {
+    const I a = rp[perm[i] + 1] - rp[perm[i]], b = rp[perm[i + 1] + 1] - rp[perm[i + 1]];
+    EXPECT_TRUE(ascending ? a <= b : a >= b);
+  }
+}
+
+TEST(Reorderers, DegreeRCMGrayOnTheFixture) {
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  COO3 global_coo(n, n, nnz, rows, cols, vals, format::kNotOwned);
+  for (bool asc : {true, false}) {
+    reorder::DegreeReorder<int, int, int> reorder(asc);
+    auto *order = reorder.GetReorder(&global_csr, {&cpu_context}, true);
+    check_degree_ordering(order, n, row_ptr, asc);
+    const int want_asc[3] = {2, 1, 0}, want_desc[3] = {0, 1, 2};
+    EXPECT_TRUE(same(order, asc ? want_asc : want_desc, 3));
+    delete[] order;
+    EXPECT_THROW(reorder.GetReorder(&global_coo, {&cpu_context}, false),
+                 utils::DirectExecutionNotAvailableException<std::vector<std::type_index>>);
+    auto *via = reorder.GetReorder(&global_coo, {&cpu_context}, true);
+    check_degree_ordering(via, n, row_ptr, asc);
+    delete[] via;
+  }
+  reorder::RCMReorder<int, int, int> rcm;
+  auto *order = rcm.GetReorder(&global_csr, {&cpu_context}, true);
+  const int want_rcm[3] = {1, 2, 0};
+  EXPECT_TRUE(same(order, want_rcm, 3));
+  delete[] order;
+  reorder::GrayReorder<int, int, int> gray(reorder::BitSize16, 100, 10);
+  order = gray.GetReorder(&global_csr, {&cpu_context}, true);
+  const int want_gray[3] = {2, 0, 1};
+  EXPECT_TRUE(same(order, want_gray, 3));
+  delete[] order;
+}
+
+TEST(Reorderers, CachedReturnsTheConvertedInput) {  // reorder_tests.cc:27-125
+  COO3 global_coo(n, n, nnz, rows, cols, vals, format::kNotOwned);
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  reorder::DegreeReorder<int, int, int> reorder(true);
+  auto cached = reorder.GetReorderCached(&global_coo, {&cpu_context}, true);
+  EXPECT_EQ(std::get<0>(cached).size(), (size_t)1);
+  EXPECT_EQ(std::get<0>(cached)[0].size(), (size_t)1);
+  auto *conv = std::get<0>(cached)[0][0]->AsAbsolute<CSR3>();
+  EXPECT_TRUE(same(conv->get_row_ptr(), row_ptr, n + 1) && same(conv->get_col(), cols, nnz));
+  delete conv;
+  delete[] std::get<1>(cached);
+  auto direct = reorder.GetReorderCached(&global_csr, {&cpu_context}, true);
+  EXPECT_EQ(std::get<0>(direct)[0].size(), (size_t)0);
+  delete[] std::get<1>(direct);
+  // explicit params override the instance's (reorderer.h:62-72)
+  reorder::DegreeReorderParams desc(false);
+  auto *o = reorder.GetReorder(&global_csr, &desc, {&cpu_context}, true);
+  check_degree_ordering(o, n, row_ptr, false);
+  delete[] o;
+}
+
+TEST(ReorderBase, Facade) {  // bases/reorder_base_tests.cc:31-92
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  COO3 global_coo(n, n, nnz, rows, cols, vals, format::kNotOwned);
+  auto *o = bases::ReorderBase::Reorder<reorder::RCMReorder>({}, &global_csr, {&cpu_context}, true);
+  EXPECT_TRUE(is_permutation_of_iota(o, n));
+  delete[] o;
+  o = bases::ReorderBase::Reorder<reorder::DegreeReorder>({true}, &global_coo, {&cpu_context}, true);
+  check_degree_ordering(o, n, row_ptr, true);
+  delete[] o;
+  o = bases::ReorderBase::Reorder<reorder::GrayReorder>({reorder::BitSize16, 10, 5}, &global_csr, {&cpu_context}, true);
+  EXPECT_TRUE(is_permutation_of_iota(o, n));
+  delete[] o;
+  auto cached = bases::ReorderBase::ReorderCached<reorder::DegreeReorder>({true}, &global_coo, {&cpu_context});
+  EXPECT_EQ(cached.first.size(), (size_t)1);
+  delete cached.first[0];
+  delete[] cached.second;
+  auto *p = bases::ReorderBase::Permute2DRowWise<format::CSR>(r_reorder_vector, &global_csr, {&cpu_context}, true);
+  EXPECT_TRUE(same(p->get_row_ptr(), r_row_ptr, n + 1) && same(p->get_col(), r_cols, nnz) && same(p->get_vals(), r_vals, nnz));
+  delete p;
+  auto *q = bases::ReorderBase::Permute2DRowColumnWise(r_reorder_vector, c_reorder_vector, &global_coo,
+                                                       {&cpu_context}, true);
+  EXPECT_TRUE(same(q->As<format::CSR>()->get_col(), rc_cols, nnz));
+  delete q;
+  EXPECT_THROW(bases::ReorderBase::Permute2D(r_reorder_vector, &global_coo, {&cpu_context}, false),
+               utils::DirectExecutionNotAvailableException<std::vector<std::type_index>>);
+  auto *as_coo = bases::ReorderBase::Permute2DRowWise<format::COO>(r_reorder_vector, &global_csr, {&cpu_context},
+                                                                  true, true);
+  const int want_rows[4] = {0, 1, 1, 2};
+  EXPECT_TRUE(same(as_coo->get_row(), want_rows, nnz) && same(as_coo->get_col(), r_cols, nnz));
+  delete as_coo;
+}
+
+// ------------------------------------------------------------------ device formats
+TEST(HIPFormats, RoundTripsAndDeviceOperators) {  // converter_order_two_cuda_tests.cu:11-49
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  auto *dcsr = global_csr.Convert<format::HIPCSR>(hip_context.get());
+  EXPECT_TRUE(dcsr->get_context()->IsEquivalent(hip_context.get()));
+  auto &dev = dcsr->device();
+  EXPECT_TRUE(same(fetch(dev, dcsr->get_row_ptr(), n + 1).data(), row_ptr, n + 1));
+  auto *back = dcsr->Convert<format::CSR>(&cpu_context);
+  EXPECT_TRUE(same(back->get_row_ptr(), row_ptr, n + 1) && same(back->get_col(), cols, nnz) && same(back->get_vals(), vals, nnz));
+  delete back;
+  // a host CSR cannot become an HIPCSR when only the CPU is offered
+  EXPECT_THROW(global_csr.Convert<format::HIPCSR>(&cpu_context), utils::ConversionException);
+  // device CSR -> device COO -> device CSR, copy and move, all in HBM
+  auto *dcoo = dcsr->Convert<format::HIPCOO>(hip_context.get());
+  EXPECT_TRUE(same(fetch(dev, dcoo->get_row(), nnz).data(), rows, nnz));
+  EXPECT_NE(dcoo->get_col(), dcsr->get_col());
+  auto *dcsr2 = dcoo->Convert<format::HIPCSR>(hip_context.get(), true);  // move: col pointer handed over
+  int *moved_col = dcsr2->get_col();
+  EXPECT_EQ(moved_col, dcoo->get_col());
+  EXPECT_TRUE(same(fetch(dev, dcsr2->get_row_ptr(), n + 1).data(), row_ptr, n + 1));
+  // COO on the host -> CSR on the device: a two-hop chain found by the graph search
+  COO3 global_coo(n, n, nnz, rows, cols, vals, format::kNotOwned);
+  auto *chain = global_coo.Convert<format::HIPCSR>(hip_context.get());
+  EXPECT_TRUE(same(fetch(dev, chain->get_col(), nnz).data(), cols, nnz));
+  delete chain;
+  // operators on device-resident input
+  reorder::RCMReorder<int, int, int> rcm;
+  auto *o = rcm.GetReorder(dcsr, {hip_context.get()}, false);
+  const int want_rcm[3] = {1, 2, 0};
+  EXPECT_TRUE(same(o, want_rcm, 3));
+  delete[] o;
+  permute::PermuteOrderTwo<int, int, int> perm(r_reorder_vector, c_reorder_vector);
+  auto *pd = perm.GetPermutation(dcsr, {hip_context.get()}, false)->As<format::HIPCSR>();
+  EXPECT_TRUE(same(fetch(dev, pd->get_col(), nnz).data(), rc_cols, nnz));
+  EXPECT_TRUE(same(fetch(dev, pd->get_vals(), nnz).data(), rc_vals, nnz));
+  delete pd;
+  // an HIPCOO input reaches a {HIPCSR} operator through the device conversion
+  auto *o2 = rcm.GetReorder(dcoo, {hip_context.get()}, true);
+  EXPECT_TRUE(same(o2, want_rcm, 3));
+  delete[] o2;
+  // device constructor sorts like the host one
+  int rp4[5]{0, 2, 3, 3, 4}, c4[4]{2, 0, 1, 3}, v4[4]{5, 4, 7, 9};
+  auto &d0 = hip::Device::Get(hip_context->device_id);
+  DCSR3 sorted(4, 4, 4, d0.Upload(rp4, 5), d0.Upload(c4, 4), d0.Upload(v4, 4), *hip_context, format::kOwned);
+  const int want_col[4]{0, 2, 1, 3}, want_vals[4]{4, 5, 7, 9};
+  EXPECT_TRUE(same(fetch(d0, sorted.get_col(), 4).data(), want_col, 4));
+  EXPECT_TRUE(same(fetch(d0, sorted.get_vals(), 4).data(), want_vals, 4));
+  std::unique_ptr<format::Format> clone(sorted.Clone());
+  EXPECT_NE(clone->AsAbsolute<DCSR3>()->get_col(), sorted.get_col());
+  delete dcsr2;
+  delete dcoo;
+  delete dcsr;
+  EXPECT_THROW(context::HIPContext bad(hip::DeviceCount() + 3), utils::HIPDeviceException);
+}
+
+int main() {
+  if (hip::DeviceCount() < 1) {
+    std::printf("test_reference_suite needs a GPU (the path has no CPU fallback)\n");
+    return 2;
+  }
+  utils::Logger::set_level(utils::LOG_LVL_NONE);
+  hip_context.reset(new context::HIPContext(0));
+  return minitest::run_all();
+}
