@@ -10,16 +10,21 @@
 //   k_new_degrees   row lengths in new order, long rows listed            (8n B)
 //   scan            -> row_ptr_out
 //   k_permute_tile  one workgroup per 1024 output nonzeros: gathers whole old rows
-//                   (col relabelled through col_order) into LDS, sorts every row
-//                   of <= 1024 entries there (all-pairs ranking for rows <= 32,
-//                   per-wave bitonic network otherwise) and streams them out.
-//   long rows       rows > 1024 entries: gathered into a compact buffer, sorted by
+//                   (col relabelled through col_order) into LDS and sorts every row
+//                   of <= 1024 entries there: all-pairs ranking when the tile only
+//                   holds rows <= 32, otherwise one tile-wide stable LDS radix sort
+//                   on the composite key (local row, column); streams them out.
+//   k_permute_block_rows  rows of 1K..16K entries: one 1024-thread workgroup per
+//                   row, LDS radix sort over the column bits.
+//   long rows       longer rows: gathered into a compact buffer, sorted by
 //                   (row, col) with the device radix sort, scattered back.
 //   k_fix_dup_runs  only if some row was unsorted AND duplicate columns exist:
 //                   orders equal-column runs by value (std::less<pair<col,val>>).
 // HBM traffic per nonzero in the tile path is the compulsory 2*(I+V) bytes.
 #include "sbx_device.h"
 #include "sbx_internal.h"
+
+#include <stdlib.h>
 
 namespace {
 
@@ -92,62 +97,20 @@ __global__ void k_store_total(const I *__restrict__ rpo, int64_t nr, PermState *
   st->total = (unsigned long long)rpo[nr];
 }
 
-// ---- wave-level bitonic network over LDS, arbitrary length -------------------
-// All comparators are ascending (first step of each merge is the mirrored
-// "flip"), so virtual +inf padding past `len` is never moved and an already
-// sorted row is left untouched.
-template <typename V, bool HASV>
-__device__ __forceinline__ void wave_bitonic_lds(volatile int *c, volatile V *v, int len) {
-  const int lane = sbx_lane();
-  int lg = 0;
-  while ((1 << lg) < len) lg++;
-  const int pairs = (1 << lg) >> 1;
-  for (int kb = 1; kb <= lg; kb++) {  // block size k = 1 << kb
-    const int hb = kb - 1;            // log2(half)
-    const int k = 1 << kb, half = 1 << hb;
-    // flip step: i = b*k + off, l = b*k + (k-1-off)
-    for (int q = lane; q < pairs; q += 64) {
-      const int b = q >> hb, off = q & (half - 1);
-      const int i = (b << kb) + off, l = (b << kb) + (k - 1 - off);
-      if (l < len) {
-        const int ci = c[i], cl = c[l];
-        if (ci > cl) {
-          c[i] = cl; c[l] = ci;
-          if (HASV) { const V t = v[i]; v[i] = v[l]; v[l] = t; }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int jb = hb - 1; jb >= 0; jb--) {  // stride j = 1 << jb
-      const int j = 1 << jb;
-      for (int q = lane; q < pairs; q += 64) {
-        const int i = ((q >> jb) << (jb + 1)) + (q & (j - 1)), l = i + j;
-        if (l < len) {
-          const int ci = c[i], cl = c[l];
-          if (ci > cl) {
-            c[i] = cl; c[l] = ci;
-            if (HASV) { const V t = v[i]; v[i] = v[l]; v[l] = t; }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
 // ---- the tile kernel ----------------------------------------------------------
 // IDENT: csr_sort_rows mode (no row/col maps, input == output arrays allowed).
 template <typename I, int VB>
 __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
     const I *__restrict__ col_order, const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, int64_t rb0,
-    PermState *__restrict__ st) {
+    PermState *__restrict__ st, int col_bits, int dbg) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   __shared__ int s_col[PT_CAP];
   __shared__ V s_val[HASV ? PT_CAP : 1];
   __shared__ int s_row[PT_CAP];
-  __shared__ int s_med[PT_MAXMED];
+  __shared__ unsigned s_whist[PT_THREADS / 64][256];
+  __shared__ unsigned s_scan[PT_THREADS / 64 + 1];
   __shared__ int s_nmed;
   __shared__ int64_t s_span[2];
   __shared__ int s_wmax[PT_THREADS / 64];
@@ -203,6 +166,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     for (int k = 0; k < PT_ITEMS; k++) s_row[tid * PT_ITEMS + k] = hv[k] > before ? hv[k] : before;
   }
   __syncthreads();
+  if (dbg == 3) return;
 
   // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
   for (int p = tid; p < cnt; p += PT_THREADS) {
@@ -211,21 +175,37 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
     const int64_t src = (int64_t)rp_in[u] + (p - s);
     I c = col_in[src];
-    if (col_order) c = col_order[c];
+    if (col_order && dbg != 1) c = col_order[c];
     s_col[p] = (int)c;
     if (HASV) s_val[p] = ((const V *)val_in)[src];
   }
   __syncthreads();
+  if (dbg == 2) {  // diagnostic: write the gathered rows unsorted
+    for (int p = tid; p < cnt; p += PT_THREADS) {
+      col_out[e0 + p] = (I)s_col[p];
+      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+    }
+    return;
+  }
 
-  // short rows: all-pairs stable ranking, written straight to their final slot
-  bool unsorted = false, dup = false;
+  // classify the tile: rows <= PT_SHORT only -> all-pairs ranking; otherwise one
+  // tile-wide stable LSD radix sort on the composite key (local row, column)
+  bool unsorted = false, dup = false, has_medium = false;
   for (int p = tid; p < cnt; p += PT_THREADS) {
     const int64_t r = ra + s_row[p];
     const int s = (int)((int64_t)rpo[r] - e0);
-    const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
-    const int c = s_col[p];
-    if (p > s && c < s_col[p - 1]) unsorted = true;
-    if (len <= PT_SHORT) {
+    if (p > s && s_col[p] < s_col[p - 1]) unsorted = true;
+    if (p == s && (int64_t)rpo[r + 1] - (int64_t)rpo[r] > PT_SHORT) has_medium = true;
+  }
+  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+  if (__any(has_medium) && lane == 0) s_nmed = 1;
+  __syncthreads();
+  if (s_nmed == 0) {
+    for (int p = tid; p < cnt; p += PT_THREADS) {
+      const int64_t r = ra + s_row[p];
+      const int s = (int)((int64_t)rpo[r] - e0);
+      const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
+      const int c = s_col[p];
       int rank = 0;
       for (int j = s; j < s + len; j++) {
         const int cj = s_col[j];
@@ -235,28 +215,93 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       const int64_t o = e0 + s + rank;
       col_out[o] = (I)c;
       if (HASV) ((V *)val_out)[o] = s_val[p];
-    } else if (p == s) {
-      const int slot = atomicAdd(&s_nmed, 1);
-      s_med[slot] = s_row[p];
     }
+    if (__any(dup) && lane == 0) st->any_dup = 1;
+    return;
   }
-  __syncthreads();
 
-  // medium rows: one wave per row, bitonic network in LDS, coalesced write-out
-  const int nmed = s_nmed;
-  for (int k = wv; k < nmed; k += PT_THREADS / 64) {
-    const int64_t r = ra + s_med[k];
-    const int s = (int)((int64_t)rpo[r] - e0);
-    const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
-    wave_bitonic_lds<V, HASV>(s_col + s, s_val + (HASV ? s : 0), len);
-    for (int j = lane; j < len; j += 64) {
-      const int c = s_col[s + j];
-      if (j && c == s_col[s + j - 1]) dup = true;
-      col_out[e0 + s + j] = (I)c;
-      if (HASV) ((V *)val_out)[e0 + s + j] = s_val[s + j];
+  // ---- tile-wide LDS radix sort: passes over the column bits, then the local-row bits
+  int row_bits = 0;
+  for (int64_t t = rb - ra - 1; t > 0; t >>= 1) row_bits++;
+  const int total_bits[2] = {col_bits, row_bits};
+  volatile unsigned *wh = s_whist[wv];
+  const uint64_t lt = sbx_lanemask_lt();
+  for (int part = 0; part < 2; part++) {
+    int done = 0;
+    while (done < total_bits[part]) {
+      const int remaining = total_bits[part] - done;
+      const int passes_left = (remaining + 7) >> 3;
+      const int bits = (remaining + passes_left - 1) / passes_left;
+      const unsigned mask = (1u << bits) - 1u;
+      const int shift = done;
+#pragma unroll
+      for (int i = 0; i < PT_THREADS / 64; i++) s_whist[i][tid] = 0;
+      int kc[PT_ITEMS], kr[PT_ITEMS];
+      V kv[HASV ? PT_ITEMS : 1];
+      unsigned rank[PT_ITEMS];
+#pragma unroll
+      for (int i = 0; i < PT_ITEMS; i++) {
+        const int e = wv * 64 * PT_ITEMS + i * 64 + lane;
+        const bool ok = e < cnt;
+        kc[i] = ok ? s_col[e] : 0x7FFFFFFF;
+        kr[i] = ok ? s_row[e] : 0x7FFFFFFF;
+        if (HASV) kv[i] = ok ? s_val[e] : (V)0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PT_ITEMS; i++) {
+        const unsigned d = ((unsigned)(part ? kr[i] : kc[i]) >> shift) & mask;
+        uint64_t m = ~(uint64_t)0;
+        for (int bb = 0; bb < bits; bb++) {
+          const bool bit = (d >> bb) & 1u;
+          const uint64_t bal = __ballot(bit);
+          m &= bit ? bal : ~bal;
+        }
+        const unsigned prev = wh[d];
+        const unsigned rk = (unsigned)__popcll(m & lt);
+        __builtin_amdgcn_wave_barrier();
+        if (rk == 0) wh[d] = prev + (unsigned)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = prev + rk;
+      }
+      __syncthreads();
+      {
+        unsigned c4[PT_THREADS / 64];
+        unsigned tot = 0;
+#pragma unroll
+        for (int i = 0; i < PT_THREADS / 64; i++) {
+          c4[i] = s_whist[i][tid];
+          tot += c4[i];
+        }
+        unsigned all;
+        unsigned ex = sbx_block_exclusive_sum<unsigned, PT_THREADS>(tot, s_scan, &all);
+#pragma unroll
+        for (int i = 0; i < PT_THREADS / 64; i++) {
+          s_whist[i][tid] = ex;
+          ex += c4[i];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PT_ITEMS; i++) {
+        const unsigned d = ((unsigned)(part ? kr[i] : kc[i]) >> shift) & mask;
+        const unsigned pos = s_whist[wv][d] + rank[i];
+        if (pos < (unsigned)PT_CAP) {
+          s_col[pos] = kc[i];
+          s_row[pos] = kr[i];
+          if (HASV) s_val[pos] = kv[i];
+        }
+      }
+      __syncthreads();
+      done += bits;
     }
   }
-  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+  for (int p = tid; p < cnt; p += PT_THREADS) {
+    const int c = s_col[p];
+    if (p && c == s_col[p - 1] && s_row[p] == s_row[p - 1]) dup = true;
+    col_out[e0 + p] = (I)c;
+    if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+  }
   if (__any(dup) && lane == 0) st->any_dup = 1;
 }
 
@@ -501,8 +546,10 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
+    static const int dbg = getenv("SBX_DEBUG_TILE_MODE") ? atoi(getenv("SBX_DEBUG_TILE_MODE")) : 0;
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rp_in, col_in, val_in,
-                       old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st);
+                       old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st,
+                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), dbg);
     SBX_LAUNCH_CHECK(h);
   }
   if (n_block) {

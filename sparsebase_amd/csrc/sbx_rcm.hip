@@ -159,10 +159,19 @@ __global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, c
   }
 }
 
-// label[v] = root; component sizes with wave-aggregated atomics
+// label[v] = root; component sizes.  Equal roots are combined inside the wave, and the
+// workgroup's dominant root (the giant component) is accumulated in LDS and flushed
+// once, so the giant's counter word is not hammered by one atomic per wave.
 __global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ csize, int64_t n) {
+  __shared__ I s_major;
+  __shared__ unsigned s_major_cnt;
   int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (threadIdx.x == 0) {
+    s_major = -1;
+    s_major_cnt = 0;
+  }
+  __syncthreads();
   for (int64_t vb = v0 - sbx_lane(); vb < n; vb += stride) {
     const int64_t v = vb + sbx_lane();
     I root = -1;
@@ -171,16 +180,26 @@ __global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ 
       while (root != parent[root]) root = parent[root];
       parent[v] = root;
     }
-    // aggregate equal roots inside the wave (the giant component dominates)
     uint64_t todo = __ballot(root >= 0);
     while (todo) {
       const int leader = __builtin_ctzll(todo);
       const I lr = __shfl(root, leader, 64);
       const uint64_t same = __ballot(root == lr) & todo;
-      if (sbx_lane() == leader) atomicAdd(&csize[lr], (I)__popcll(same));
+      if (sbx_lane() == leader) {
+        const unsigned cnt = (unsigned)__popcll(same);
+        if (cnt >= 32) {  // a dominant root: try to own the workgroup's LDS accumulator
+          const I prev = atomicCAS(&s_major, (I)-1, lr);
+          if (prev == -1 || prev == lr) atomicAdd(&s_major_cnt, cnt);
+          else atomicAdd(&csize[lr], (I)cnt);
+        } else {
+          atomicAdd(&csize[lr], (I)cnt);
+        }
+      }
       todo &= ~same;
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_major_cnt) atomicAdd(&csize[s_major], (I)s_major_cnt);
 }
 
 // classify components: singletons are final here; small / large roots are listed
@@ -334,7 +353,13 @@ __device__ __forceinline__ void bfs_visit(I v, unsigned p, const unsigned *__res
   }
 }
 
-// one wave per frontier vertex; hubs are queued for k_bfs_expand_heavy
+// Light expansion: RCM_GROUP lanes per frontier vertex (4 vertices per wave) because
+// the kernel is bound by the dependent-load chain frontier -> row_ptr -> col -> bitmap,
+// not by lanes; hubs (> RCM_LIGHT neighbours) are queued as 1024-neighbour chunk
+// descriptors for k_bfs_expand_heavy.
+constexpr int RCM_GROUP = 16;
+constexpr int RCM_VPW = 64 / RCM_GROUP;  // frontier vertices per wave
+
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
@@ -344,29 +369,37 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
+  const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
   WaveStage st{s_stage[sbx_wave_in_block()], 0u};
   unsigned long long scanned = 0;
-  for (int64_t p = wave; p < fsize; p += nwaves) {
-    const I u = frontier[p];
-    const I s = rp[u], e = rp[u + 1];
+  for (int64_t p0 = wave * RCM_VPW; p0 < fsize; p0 += nwaves * RCM_VPW) {
+    const int64_t p = p0 + grp;
+    I s = 0, e = 0;
+    if (p < fsize) {
+      const I u = frontier[p];
+      s = rp[u];
+      e = rp[u + 1];
+    }
     if (e - s > RCM_LIGHT) {
       // hub: queue one descriptor (position, chunk) per 1024-neighbour chunk
       const unsigned nchunks = (unsigned)((e - s + RCM_CHUNK - 1) / RCM_CHUNK);
       unsigned slot = 0;
-      if (lane == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
-      slot = __shfl(slot, 0, 64);
-      for (unsigned c = lane; c < nchunks; c += 64) heavy[slot + c] = ((uint64_t)p << 32) | c;
-      continue;
+      if (gl == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
+      slot = __shfl(slot, grp * RCM_GROUP, 64);
+      for (unsigned c = gl; c < nchunks; c += RCM_GROUP) heavy[slot + c] = ((uint64_t)p << 32) | c;
+      e = s;  // nothing to do inline
     }
-    scanned += (unsigned)(e - s);
-    for (I j0 = s; j0 < e; j0 += 64) {
-      const I j = j0 + lane;
+    if (gl == 0) scanned += (unsigned)(e - s);
+    I j = s + gl;
+    while (__any(j < e)) {
       const bool act = j < e;
       const I v = act ? col[j] : 0;
       bfs_visit(v, (unsigned)p, vbits, ppos, st, nf_list, dv, act);
+      j += RCM_GROUP;
     }
   }
   stage_flush(st, nf_list, dv);
+  scanned = sbx_wave_sum(scanned);
   if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
 }
 
@@ -537,7 +570,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   while (true) {
-    const unsigned waves_needed = fsize;
+    const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
     unsigned grid = (waves_needed + 3) / 4;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
