@@ -139,13 +139,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   const int cnt = (int)((int64_t)rpo[rb] - e0);
   if (cnt == 0) return;
 
-  // element -> local row map: scatter row heads, then inclusive max-scan
-  for (int64_t r = ra + 1 + tid; r < rb; r += PT_THREADS) {
-    const int p = (int)((int64_t)rpo[r] - e0);
-    if (p < cnt) atomicMax(&s_row[p], (int)(r - ra));
-  }
-  __syncthreads();
-  {
+  // element -> local row map.  Normal tiles: scatter row heads, then inclusive max-scan.
+  // Tiles whose row range is dominated by empty rows (e.g. the isolated vertices RCM
+  // packs at the end) would walk millions of heads: they locate each element's row by
+  // binary search instead.
+  const int64_t nrows_range = rb - ra;
+  if (nrows_range <= 4 * PT_CAP) {
+    for (int64_t r = ra + 1 + tid; r < rb; r += PT_THREADS) {
+      const int p = (int)((int64_t)rpo[r] - e0);
+      if (p < cnt) atomicMax(&s_row[p], (int)(r - ra));
+    }
+    __syncthreads();
     int hv[PT_ITEMS];
     int run = 0;
 #pragma unroll
@@ -164,6 +168,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const int before = excl > woff ? excl : woff;
 #pragma unroll
     for (int k = 0; k < PT_ITEMS; k++) s_row[tid * PT_ITEMS + k] = hv[k] > before ? hv[k] : before;
+  } else {
+    for (int p = tid; p < cnt; p += PT_THREADS) {
+      const int64_t target = e0 + p;  // last row r in [ra, rb) with rpo[r] <= target
+      int64_t lo = ra, hi = rb;       // invariant: rpo[lo] <= target, answer in [lo, hi)
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rpo[mid] <= target) lo = mid;
+        else hi = mid;
+      }
+      s_row[p] = (int)(lo - ra);
+    }
   }
   __syncthreads();
   if (dbg == 3) return;
@@ -220,9 +235,32 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     return;
   }
 
-  // ---- tile-wide LDS radix sort: passes over the column bits, then the local-row bits
+  // ---- tile-wide LDS radix sort: passes over the column bits, then the row bits.
+  // The row part of the key is the DENSE rank of the element's row among the rows
+  // present in the tile (prefix count of row heads), so it never exceeds 11 bits
+  // however many empty rows the range contains.
+  {
+    int flag[PT_ITEMS];
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+      const int p = tid * PT_ITEMS + k;
+      const bool head = p < cnt && (p == 0 || s_row[p] != s_row[p - 1]);
+      local += head;
+      flag[k] = local;
+    }
+    int all;
+    const int ex = sbx_block_exclusive_sum<int, PT_THREADS>(local, (int *)s_scan, &all);
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+      const int p = tid * PT_ITEMS + k;
+      if (p < cnt) s_row[p] = ex + flag[k] - 1;
+    }
+    if (tid == 0) s_nmed = all;  // number of rows present
+  }
+  __syncthreads();
   int row_bits = 0;
-  for (int64_t t = rb - ra - 1; t > 0; t >>= 1) row_bits++;
+  for (int t = s_nmed - 1; t > 0; t >>= 1) row_bits++;
   const int total_bits[2] = {col_bits, row_bits};
   volatile unsigned *wh = s_whist[wv];
   const uint64_t lt = sbx_lanemask_lt();
