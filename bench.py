@@ -55,9 +55,15 @@ def kernel_alg_bytes(name, n, nnz, stats, launches):
     if name == "permute_tile":
         return 16 * nnz + 12 * n + 8          # SURVEY §8d Permute2D figure
     if name in ("bfs_expand", "bfs_heavy"):
-        # every BFS sweep reads each adjacency entry of the component once (4 B) and,
-        # per visited vertex, row_ptr (8 B) + distance/parent words (8 B)
-        return 4 * stats["edges_scanned"] + 16 * stats["largest_component"] * stats["bfs_sweeps"]
+        # top-down: every scanned adjacency entry once (4 B) and, per frontier vertex,
+        # row_ptr (8 B) + parent-position word read+write (8 B)
+        td = stats["edges_scanned"] - stats["edges_scanned_bottom_up"]
+        return 4 * td + 16 * stats["largest_component"] * stats["bfs_sweeps"]
+    if name == "bfs_bottom_up":
+        # bottom-up: scanned adjacency entries (4 B each) + the visited bitmap (n/8 B) per launch
+        return 4 * stats["edges_scanned_bottom_up"] + int(launches * n / 8)
+    if name == "permute_block":
+        return None
     return None
 
 

@@ -163,6 +163,7 @@ typedef struct sbx_rcm_stats {
   int64_t bfs_sweeps;       /* full BFS sweeps over the largest component   */
   int64_t bfs_levels;       /* levels summed over those sweeps              */
   int64_t edges_scanned;    /* adjacency entries visited (all sweeps)       */
+  int64_t edges_scanned_bottom_up; /* ... of which by the bottom-up kernel   */
   int64_t largest_component;
 } sbx_rcm_stats;
 int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,

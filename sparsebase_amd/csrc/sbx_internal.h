@@ -25,6 +25,7 @@ enum sbx_kernel_id {
   SBX_K_PERMUTE_PREP,
   SBX_K_BFS_EXPAND,
   SBX_K_BFS_HEAVY,
+  SBX_K_BFS_BOTTOMUP,
   SBX_K_LEVEL_ORDER,
   SBX_K_CC,
   SBX_K_RCM_SMALL,

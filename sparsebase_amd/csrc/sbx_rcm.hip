@@ -53,6 +53,8 @@ struct RcmDev {                 // device-resident scalars
   unsigned pad;
   unsigned long long best;      // (degree<<32 | position) minimum over the deepest level
   unsigned long long edges;     // adjacency entries scanned (statistics)
+  unsigned long long fedges;    // sum of degrees of the level being built (direction heuristic)
+  unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -305,15 +307,18 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
 //          level being built (UNSEEN = untouched).  A relaxed agent-scope load shows
 //          whether this edge can still lower it; only then the atomicMin is issued.
 //          The winner of the UNSEEN -> p transition appends the vertex to the frontier.
-__global__ void k_bfs_start(unsigned *__restrict__ vbits, I *__restrict__ q, RcmDev *__restrict__ dv,
-                            I fixed_root) {
+__global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
+                            unsigned *__restrict__ lpos, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root) {
   const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
   dv->root = (unsigned)r;
-  vbits[r >> 5] = 1u << (r & 31);  // the bitmap was cleared by the host for this sweep
+  vbits[r >> 5] = 1u << (r & 31);  // both bitmaps were cleared by the host for this sweep
+  fbits[r >> 5] = 1u << (r & 31);
+  lpos[r] = 0;
   q[0] = r;
   dv->nf = 0;
   dv->n_heavy = 0;
   dv->best = ~0ull;
+  dv->fedges = (unsigned long long)(rp[r + 1] - rp[r]);  // degree sum of level 0
 }
 
 // Winners are staged per wave in LDS and appended to the frontier in batches: one
@@ -322,9 +327,15 @@ __global__ void k_bfs_start(unsigned *__restrict__ vbits, I *__restrict__ q, Rcm
 constexpr int RCM_STAGE = 512;  // staged vertices per wave
 
 struct WaveStage {
-  I *buf;        // this wave's LDS slice
-  unsigned cnt;  // wave-uniform fill level
+  I *buf;                  // this wave's LDS slice
+  unsigned cnt;            // wave-uniform fill level
+  unsigned long long deg;  // per-lane: degrees of the vertices this lane appended
 };
+
+__device__ __forceinline__ void stage_finish(WaveStage &st, RcmDev *__restrict__ dv) {
+  const unsigned long long d = sbx_wave_sum(st.deg);
+  if (sbx_lane() == 0 && d) atomicAdd(&dv->fedges, d);
+}
 
 __device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
   if (st.cnt == 0) return;
@@ -337,20 +348,29 @@ __device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_li
   st.cnt = 0;
 }
 
-__device__ __forceinline__ void bfs_visit(I v, unsigned p, const unsigned *__restrict__ vbits, unsigned *ppos,
-                                          WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv,
-                                          bool active) {
+// appends v (for lanes with `won`) to the staged frontier; all lanes of the wave call it
+__device__ __forceinline__ void stage_push(I v, bool won, const I *__restrict__ rp, WaveStage &st,
+                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
+  const uint64_t winners = __ballot(won);
+  if (winners) {
+    if (won) {
+      st.buf[st.cnt + __popcll(winners & sbx_lanemask_lt())] = v;
+      st.deg += (unsigned long long)(rp[v + 1] - rp[v]);
+    }
+    st.cnt += (unsigned)__popcll(winners);
+    if (st.cnt > RCM_STAGE - 64) stage_flush(st, nf_list, dv);
+  }
+}
+
+__device__ __forceinline__ void bfs_visit(I v, unsigned p, const I *__restrict__ rp,
+                                          const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
+                                          I *__restrict__ nf_list, RcmDev *__restrict__ dv, bool active) {
   bool won = false;
   if (active && !((vbits[v >> 5] >> (v & 31)) & 1u)) {
     const unsigned cur = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur > p) won = (atomicMin(&ppos[v], p) == UNSEEN);
   }
-  const uint64_t winners = __ballot(won);
-  if (winners) {
-    if (won) st.buf[st.cnt + __popcll(winners & sbx_lanemask_lt())] = v;
-    st.cnt += (unsigned)__popcll(winners);
-    if (st.cnt > RCM_STAGE - 64) stage_flush(st, nf_list, dv);
-  }
+  stage_push(v, won, rp, st, nf_list, dv);
 }
 
 // Light expansion: RCM_GROUP lanes per frontier vertex (4 vertices per wave) because
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u};
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
   unsigned long long scanned = 0;
   for (int64_t p0 = wave * RCM_VPW; p0 < fsize; p0 += nwaves * RCM_VPW) {
     const int64_t p = p0 + grp;
@@ -394,11 +414,12 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
     while (__any(j < e)) {
       const bool act = j < e;
       const I v = act ? col[j] : 0;
-      bfs_visit(v, (unsigned)p, vbits, ppos, st, nf_list, dv, act);
+      bfs_visit(v, (unsigned)p, rp, vbits, ppos, st, nf_list, dv, act);
       j += RCM_GROUP;
     }
   }
   stage_flush(st, nf_list, dv);
+  stage_finish(st, dv);
   scanned = sbx_wave_sum(scanned);
   if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
 }
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
                                                           RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
   const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u};
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
   unsigned long long scanned = 0;
   for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
     const uint64_t desc = heavy[d];
@@ -424,12 +445,87 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
       const I j = j0 + (I)threadIdx.x;
       const bool act = j < ce;
       const I v = act ? col[j] : 0;
-      bfs_visit(v, p, vbits, ppos, st, nf_list, dv, act);
+      bfs_visit(v, p, rp, vbits, ppos, st, nf_list, dv, act);
     }
     scanned += (unsigned long long)(ce - cs);
   }
   stage_flush(st, nf_list, dv);
+  stage_finish(st, dv);
   if (threadIdx.x == 0 && scanned) atomicAdd(&dv->edges, scanned);
+}
+
+// Bottom-up expansion (direction-optimising BFS): instead of the frontier pushing along
+// its edges with atomics, every still-unvisited vertex of the component pulls — it scans
+// its own adjacency, keeps the smallest level position among neighbours that are in the
+// current frontier (fbits / lpos) and, if it found one, joins the next level.  No atomics
+// on vertex state, no hot words; chosen by the host when the frontier owns more edges
+// than the unvisited remainder.
+__global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
+                                                       const I *__restrict__ label, I comp_label,
+                                                       const unsigned *__restrict__ vbits,
+                                                       const unsigned *__restrict__ fbits,
+                                                       const unsigned *__restrict__ lpos, unsigned *__restrict__ ppos,
+                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv) {
+  __shared__ I s_stage[4][RCM_STAGE];
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int lane = sbx_lane();
+  const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  unsigned long long scanned = 0;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t v = base + lane;
+    bool cand = false;
+    I s = 0, e = 0;
+    if (v < n && !((vbits[v >> 5] >> (v & 31)) & 1u)) {
+      s = rp[v];
+      e = rp[v + 1];
+      cand = (e > s) && label[v] == comp_label;
+    }
+    uint64_t todo = __ballot(cand);
+    while (todo) {
+      // the next RCM_VPW candidates, one per 16-lane group
+      uint64_t t = todo;
+      int pick = -1;
+      for (int g = 0; g < RCM_VPW; g++) {
+        const int c = t ? __builtin_ctzll(t) : -1;
+        if (g == grp) pick = c;
+        if (t) t &= t - 1;
+      }
+      todo = t;
+      const I cs = __shfl(s, pick < 0 ? 0 : pick, 64), ce = __shfl(e, pick < 0 ? 0 : pick, 64);
+      unsigned best = UNSEEN;
+      I j = (pick < 0 ? 0 : cs) + gl;
+      const I jend = pick < 0 ? 0 : ce;
+      while (__any(j < jend)) {
+        if (j < jend) {
+          const I u = col[j];
+          if ((fbits[u >> 5] >> (u & 31)) & 1u) {
+            const unsigned lp = lpos[u];
+            best = lp < best ? lp : best;
+          }
+        }
+        j += RCM_GROUP;
+      }
+      if (gl == 0 && pick >= 0) scanned += (unsigned)(ce - cs);
+#pragma unroll
+      for (int d = RCM_GROUP / 2; d >= 1; d >>= 1) {
+        const unsigned o = __shfl_xor(best, d, 64);
+        best = o < best ? o : best;
+      }
+      const bool found = (gl == 0) && pick >= 0 && best != UNSEEN;
+      const I nv = (I)(base + (pick < 0 ? 0 : pick));
+      if (found) ppos[nv] = best;
+      stage_push(nv, found, rp, st, nf_list, dv);
+    }
+  }
+  stage_flush(st, nf_list, dv);
+  stage_finish(st, dv);
+  scanned = sbx_wave_sum(scanned);
+  if (lane == 0 && scanned) {
+    atomicAdd(&dv->edges, scanned);
+    atomicAdd(&dv->edges_bu, scanned);
+  }
 }
 
 template <bool CM>
@@ -447,7 +543,8 @@ __global__ __launch_bounds__(256) void k_level_keys(const I *__restrict__ nf_lis
 template <bool CM>
 __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__ key, unsigned nf,
                                                     const uint32_t *__restrict__ dorder, I *__restrict__ q_level,
-                                                    unsigned *__restrict__ vbits, RcmDev *__restrict__ dv) {
+                                                    unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
+                                                    unsigned *__restrict__ lpos, RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; j < nf; j += stride) {
@@ -455,10 +552,13 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
     const I v = (I)(CM ? dorder[lo] : lo);
     q_level[j] = v;
     atomicOr(&vbits[v >> 5], 1u << (v & 31));  // this level is now ordered
+    atomicOr(&fbits[v >> 5], 1u << (v & 31));  // ... and is the next frontier
+    lpos[v] = (unsigned)j;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     dv->nf = 0;
     dv->n_heavy = 0;
+    dv->fedges = 0;
   }
 }
 
@@ -469,6 +569,7 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
                                                            const uint32_t *__restrict__ drank,
                                                            const uint32_t *__restrict__ dorder,
                                                            I *__restrict__ q_level, unsigned *__restrict__ vbits,
+                                                           unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
                                                            RcmDev *__restrict__ dv) {
   __shared__ uint64_t s_key[RCM_LDS_SORT];
   unsigned p2 = 1;
@@ -503,10 +604,13 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
     const I v = (I)(CM ? dorder[lo] : lo);
     q_level[j] = v;
     atomicOr(&vbits[v >> 5], 1u << (v & 31));
+    atomicOr(&fbits[v >> 5], 1u << (v & 31));
+    lpos[v] = j;
   }
   if (threadIdx.x == 0) {
     dv->nf = 0;
     dv->n_heavy = 0;
+    dv->fedges = 0;
   }
 }
 
@@ -544,7 +648,9 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
 
 struct BfsBuffers {
   const I *rp, *col;
-  unsigned *vbits, *ppos;
+  unsigned *vbits, *fbits, *lpos, *ppos;
+  const I *label;
+  int64_t nnz;
   I *q;         // visiting order of the current BFS (levels concatenated)
   I *nf_list;   // unordered next frontier
   uint64_t *heavy;
@@ -562,42 +668,62 @@ struct BfsResult {
 };
 
 // One ordered BFS over the component containing the root (fixed_root >= 0, or the
-// device-resident dv->root).  CM selects Cuthill-McKee child order.
+// device-resident dv->root).  CM selects Cuthill-McKee child order.  Direction per
+// level: top-down (frontier pushes) unless the frontier is large and owns more than
+// half as many edges as the still-unvisited remainder — then bottom-up (pull).
 template <bool CM>
-int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, BfsResult *out) {
-  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((b.n + 31) / 32) * sizeof(unsigned), h->stream));
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.vbits, b.q, b.dv, fixed_root);
+int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
+  const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
+  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, bm_bytes, h->stream));
+  SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
+  int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
+  int64_t frontier_edges = -1;    // degree sum of the current frontier (-1: level 0, read lazily)
   while (true) {
-    const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
-    unsigned grid = (waves_needed + 3) / 4;
-    if (grid > max_grid) grid = max_grid;
-    if (grid < 1) grid = 1;
-    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
-                       level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.dv);
-    SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
-                       (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
-                       (const uint64_t *)b.heavy, b.dv);
+    bool bottom_up = false;
+    if (frontier_edges >= 0 && fsize >= 8192) bottom_up = 2 * frontier_edges > remaining;
+    if (bottom_up) {
+      SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
+                  (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
+                  b.n, b.dv);
+    } else {
+      const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
+      unsigned grid = (waves_needed + 3) / 4;
+      if (grid > max_grid) grid = max_grid;
+      if (grid < 1) grid = 1;
+      SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
+                  level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.dv);
+      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
+                  (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
+                  (const uint64_t *)b.heavy, b.dv);
+    }
     SBX_LAUNCH_CHECK(h);
-    unsigned nf = 0;
-    SBX_TRY(sbx_readback(h, &nf, &b.dv->nf, sizeof(unsigned)));
+    RcmDev hd;
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    const unsigned nf = hd.nf;
     if (nf == 0) break;
+    if (frontier_edges < 0) remaining -= (int64_t)0;  // level 0's degree is part of hd.fedges history below
+    frontier_edges = (int64_t)hd.fedges;              // degree sum of the level just discovered
+    remaining -= frontier_edges;
+    if (remaining < 0) remaining = 0;
     I *q_next = b.q + off + fsize;
+    SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
     if (nf <= RCM_LDS_SORT) {
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_sort_small<CM>), dim3(1), dim3(1024), (const I *)b.nf_list, nf,
-                         (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.dv);
+                  (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.fbits, b.lpos, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
-                         (const unsigned *)b.ppos, b.drank, b.ka);
+                  (const unsigned *)b.ppos, b.drank, b.ka);
       sbx_radix_pass passes[16];
       const int np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32,
                                     32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       int in_b = 0;
       SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
-      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256), (const uint64_t *)(in_b ? b.kb : b.ka),
-                         nf, b.dorder, q_next, b.vbits, b.dv);
+      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256),
+                  (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
     off += fsize;
@@ -631,7 +757,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   RcmDev *dv;
   uint32_t *dkey_a, *dkey_b, *did_a, *did_b, *drank;
   I *label, *csize, *cbase, *small_list, *large_list, *big_list, *q, *nf_list;
-  unsigned *dist, *ppos, *vbits;
+  unsigned *dist, *ppos, *vbits, *fbits, *lpos;
   uint64_t *ka, *kb, *heavy;
   SBX_TRY(sbx_salloc(h, 1, &dv));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_a));
@@ -650,6 +776,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)n, &dist));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ppos));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &vbits));
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &fbits));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &lpos));
   SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
   SBX_TRY(sbx_salloc(h, (size_t)n, &kb));
@@ -702,7 +830,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     }
     SBX_HIP(h, hipStreamSynchronize(h->stream));
     BfsBuffers b;
-    b.rp = rp; b.col = col; b.vbits = vbits; b.ppos = ppos; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
+    b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = label;
+    b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
     b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
     for (unsigned c = 0; c < hd.n_large; c++) {
       // pseudo-peripheral search from the component's smallest vertex (:22-81)
@@ -711,7 +840,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       I fixed = roots[c];
       while (prev_ecc != ecc) {
         prev_ecc = ecc;
-        SBX_TRY(run_bfs<false>(h, b, fixed, &r));
+        SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
         fixed = -1;  // later sweeps start from the device-resident root
         sweeps++;
         levels += r.levels;
@@ -729,7 +858,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         if (path) break;
       }
       // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
-      SBX_TRY(run_bfs<true>(h, b, -1, &r));
+      SBX_TRY(run_bfs<true>(h, b, -1, roots[c], &r));
       sweeps++;
       levels += r.levels;
       if ((int64_t)r.count != (int64_t)sizes[c])
@@ -754,6 +883,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     stats_host->bfs_sweeps = sweeps_max;
     stats_host->bfs_levels = levels_max;
     stats_host->edges_scanned = (int64_t)fin.edges;
+    stats_host->edges_scanned_bottom_up = (int64_t)fin.edges_bu;
     stats_host->largest_component = largest;
     stats_host->components = -1;  // filled by callers that need it (count of roots); not tracked on device
     stats_host->isolated = -1;

@@ -70,3 +70,52 @@ def test_examples_gpu(built, tmp_path, golden_dir):
     out = run(os.path.join(built, "format_conversion"))
     assert out.split() == ["CSR", "10,20,30,40,50,60,", "0,1,1,2,3,3,", "0,2,4,6,6,6,6,", "COO",
                            "10,20,30,40,50,60,", "0,0,1,1,2,2,", "0,1,1,2,3,3,"]
+
+
+def _run_cli(built, tmp_path, kind, rp, col, n, m, extra=()):
+    (tmp_path / "rp.bin").write_bytes(np.ascontiguousarray(rp, np.int32).tobytes())
+    (tmp_path / "col.bin").write_bytes(np.ascontiguousarray(col, np.int32).tobytes())
+    out = tmp_path / "out.bin"
+    run(os.path.join(built, "reorder_cli"), kind, str(tmp_path / "rp.bin"), str(tmp_path / "col.bin"), str(out),
+        str(n), str(m), *[str(x) for x in extra])
+    return np.frombuffer(out.read_bytes(), np.int32)
+
+
+@pytest.mark.gpu
+def test_cpp_api_reorderers_vs_reference_fixtures(built, tmp_path, golden_dir):
+    """Gray (device keys + host ordering stage), RCM and Degree through the C++ API, host and device formats."""
+    import json
+    z = np.load(os.path.join(golden_dir, "small_cases.npz"))
+    with open(os.path.join(golden_dir, "small_cases.json")) as f:
+        meta = json.load(f)
+    checked = 0
+    for name, info in meta.items():
+        rp, col = z[f"{name}/row_ptr"], z[f"{name}/col"]
+        n = len(rp) - 1
+        if n == 0:
+            continue
+        for res, thr, grp in info["gray"]:
+            for dev_flag in ((), ("--device",)):
+                got = _run_cli(built, tmp_path, "gray", rp, col, n, n, (res, thr, grp) + dev_flag)
+                assert np.array_equal(got, z[f"{name}/gray_{res}_{thr}_{grp}"]), (name, res, thr, grp, dev_flag)
+                checked += 1
+        if name in ("rmat12", "sym_d", "grid_shuffled"):
+            assert np.array_equal(_run_cli(built, tmp_path, "rcm", rp, col, n, n, ("--device",)), z[f"{name}/rcm"])
+            assert np.array_equal(_run_cli(built, tmp_path, "degree_desc", rp, col, n, n), z[f"{name}/degree_desc"])
+    assert checked >= 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rmat16_ef8", "banded_64k_w16", "banded_64k_w4096"])
+def test_cpp_api_gray_digests(built, tmp_path, golden_dir, name):
+    """n >= 64K rows: large enough that std::sort's tie order matters (SURVEY.md §A.4)."""
+    import hashlib
+    import json
+    from sparsebase_amd import synth
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        d = json.load(f)[name]
+    rp, col = getattr(synth, d["generator"])(**d["args"])
+    n = len(rp) - 1
+    for res, thr, grp, key in ((32, 10, 4, "gray_32_10_4"), (16, 20, 1, "gray_16_20_1")):
+        got = _run_cli(built, tmp_path, "gray", rp, col, n, n, (res, thr, grp))
+        assert hashlib.sha256(got.tobytes()).hexdigest() == d[key], (name, key)

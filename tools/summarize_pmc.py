@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel-group HBM traffic.
+
+MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB-units of 1024 B as reported by
+rocprofv3; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced
+streaming read (16 B/lane), so it is doubled for the streaming kernels; other access widths
+are uncalibrated (both raw and doubled figures are kept; `hbm_bytes_per_launch` uses the
+doubled read side, i.e. an upper bound for the scattered kernels).
+usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json>
+"""
+import csv, glob, json, sys, collections
+
+GROUPS = [("k_bfs_bottom_up", "bfs_bottom_up"), ("k_bfs_expand_heavy", "bfs_heavy"), ("k_bfs_expand", "bfs_expand"),
+          ("k_permute_tile", "permute_tile"), ("k_permute_block_rows", "permute_block"), ("k_long_", "permute_long"),
+          ("k_radix_scatter", "radix_scatter"), ("k_radix_hist", "radix_hist"), ("k_scan_", "scan"),
+          ("k_cc_", "cc"), ("k_classify", "cc"), ("k_level_", "level_order"), ("k_coo_to_csr", "coo_to_csr"),
+          ("k_csr_to_coo", "csr_to_coo"), ("k_gray", "gray"), ("k_degree", "degree")]
+
+def group_of(name):
+    for pat, g in GROUPS:
+        if pat in name:
+            return g
+    return None
+
+def load(d, counter):
+    tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            g = group_of(r["Kernel_Name"])
+            if g is None:
+                continue
+            tot[g] += float(r["Counter_Value"]); cnt[g] += 1
+    return tot, cnt
+
+ft, fc = load(sys.argv[1], "FETCH_SIZE")
+wt, wc = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for g in sorted(set(ft) | set(wt)):
+    launches = max(fc.get(g, 0), wc.get(g, 0)) or 1
+    fetch = ft.get(g, 0.0) * 1024 / max(fc.get(g, 1), 1)
+    write = wt.get(g, 0.0) * 1024 / max(wc.get(g, 1), 1)
+    out[g] = {"launches_profiled": launches, "fetch_bytes_raw_per_launch": fetch, "write_bytes_per_launch": write,
+              "hbm_bytes_per_launch": 2 * fetch + write,
+              "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (exact for 16 B/lane streaming reads; upper bound otherwise)"}
+json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
