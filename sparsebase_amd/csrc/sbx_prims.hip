@@ -4,10 +4,12 @@
 // (stands in for every std::sort on the path: format/coo.cc:133-146,
 // format/csr.cc:123-156 for long rows, degree/RCM key orderings).
 //
-// Radix sort pass = per-tile digit histogram -> device scan -> LDS-staged
-// stable scatter.  Ranking inside a tile is done with wave64 ballots (match-any
-// over the digit bits) and per-wave digit counters in LDS; keys and payloads
-// are reordered through LDS so the global writes are coalesced per bucket run.
+// Radix sort ("onesweep"): one upfront kernel builds the digit histograms of all
+// passes, then every pass is ONE kernel: tiles rank their keys in LDS with wave64
+// ballots (match-any over the digit bits) and per-wave digit counters, get their
+// global bucket offsets by decoupled look-back over per-tile status words, and
+// write keys/payloads out through LDS so the stores are coalesced per bucket run.
+// Traffic per pass: one read + one write of (key, payload).
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -153,42 +155,74 @@ int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes) {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_MAX_PASSES = 8;
 
-template <typename K, int ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const K *__restrict__ keys, int64_t count, int shift,
-                                                           unsigned mask, uint32_t *__restrict__ hist, int tiles) {
-  constexpr int TILE = RS_THREADS * ITEMS;
-  __shared__ uint32_t lh[256];
-  lh[threadIdx.x] = 0;
+struct RadixPlan {
+  int n;
+  int shift[RS_MAX_PASSES];
+  int bits[RS_MAX_PASSES];
+};
+
+// Upfront digit histograms of every pass in one read of the keys.
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
+                                                              unsigned long long *__restrict__ ghist) {
+  __shared__ unsigned lh[RS_MAX_PASSES][256];
+  for (int i = threadIdx.x; i < RS_MAX_PASSES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * TILE;
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const int64_t e = base + (int64_t)i * RS_THREADS + threadIdx.x;
-    if (e < count) atomicAdd(&lh[(unsigned)(keys[e] >> shift) & mask], 1u);
+  int64_t i = (int64_t)blockIdx.x * RS_THREADS + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * RS_THREADS;
+  for (; i < count; i += stride) {
+    const K k = keys[i];
+    for (int p = 0; p < plan.n; p++)
+      atomicAdd(&lh[p][(unsigned)(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
   }
   __syncthreads();
-  hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = lh[threadIdx.x];
+  for (int p = 0; p < plan.n; p++) {
+    const unsigned c = lh[p][threadIdx.x];
+    if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)c);
+  }
 }
 
+// exclusive scan of each pass's 256 bins (one workgroup)
+__global__ __launch_bounds__(RS_THREADS) void k_onesweep_bins(unsigned long long *__restrict__ ghist, int np) {
+  __shared__ unsigned long long lds[RS_THREADS / 64 + 1];
+  for (int p = 0; p < np; p++) {
+    const unsigned long long v = ghist[p * 256 + threadIdx.x];
+    unsigned long long tot;
+    const unsigned long long ex = sbx_block_exclusive_sum<unsigned long long, RS_THREADS>(v, lds, &tot);
+    ghist[p * 256 + threadIdx.x] = ex;
+  }
+}
+
+// One digit pass in a single kernel.  Tiles take a ticket (so a tile only ever waits
+// for tiles that already run), rank their keys in LDS exactly like a classic scatter
+// pass, and obtain the number of equal-digit keys in all earlier tiles by decoupled
+// look-back over per-(tile,digit) status words: (value << 2) | flag, flag 1 = this
+// tile's own count, 2 = inclusive prefix.  Each word is a self-contained granule
+// written/read with relaxed agent-scope atomics, so no fence is needed.
 template <typename K, typename P, int ITEMS, bool HAS_P>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+__global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const P *__restrict__ vals_in, P *__restrict__ vals_out,
                                                               int64_t count, int shift, int bits,
-                                                              const uint32_t *__restrict__ hist, int tiles) {
+                                                              const unsigned long long *__restrict__ gbase,
+                                                              unsigned long long *state, unsigned *ticket) {
   constexpr int TILE = RS_THREADS * ITEMS;
   __shared__ K s_keys[TILE];
   __shared__ P s_vals[HAS_P ? TILE : 1];
   __shared__ uint32_t s_whist[RS_WAVES][256];
   __shared__ uint32_t s_gofs[256];
   __shared__ uint32_t s_scan[RS_WAVES + 1];
+  __shared__ unsigned s_tile;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t base = (int64_t)blockIdx.x * TILE;
-  const int valid = (int)((count - base) < TILE ? (count - base) : TILE);
-  const unsigned mask = (1u << bits) - 1u;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
   for (int i = 0; i < RS_WAVES; i++) s_whist[i][tid] = 0;
   __syncthreads();
+  const unsigned tile = s_tile;
+  const int64_t base = (int64_t)tile * TILE;
+  const int valid = (int)((count - base) < TILE ? (count - base) : TILE);
+  const unsigned mask = (1u << bits) - 1u;
 
   K k[ITEMS];
   P v[HAS_P ? ITEMS : 1];
@@ -227,9 +261,29 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const K *__restric
       c[i] = s_whist[i][tid];
       tot += c[i];
     }
+    // keys past `valid` were given the all-ones key: do not count them globally
+    uint32_t tot_valid = tot;
+    if ((unsigned)tid == mask) tot_valid -= (uint32_t)(TILE - valid);
     uint32_t all;
     uint32_t ex = sbx_block_exclusive_sum<uint32_t, RS_THREADS>(tot, s_scan, &all);
-    s_gofs[tid] = hist[(int64_t)tid * tiles + blockIdx.x] - ex;
+    // ---- decoupled look-back for digit `tid`
+    unsigned long long *mine = state + (size_t)tile * 256 + tid;
+    unsigned long long before = 0;
+    if (tile == 0) {
+      __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t t = (int64_t)tile - 1;; t--) {
+        unsigned long long wv;
+        while (((wv = __hip_atomic_load(state + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &
+                3ull) == 0ull)
+          __builtin_amdgcn_s_sleep(1);
+        before += wv >> 2;
+        if ((wv & 3ull) == 2ull) break;
+      }
+      __hip_atomic_store(mine, ((before + tot_valid) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_gofs[tid] = (uint32_t)(gbase[tid] + before) - ex;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) {
       s_whist[i][tid] = ex;
@@ -264,21 +318,33 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   constexpr int TILE = RS_THREADS * ITEMS;
   *result_in_b = 0;
   if (count <= 1 || np == 0) return SBX_OK;
+  if (np > RS_MAX_PASSES) SBX_FAIL(h, SBX_ERR_INTERNAL, "radix sort: %d passes requested", np);
   if (count >= ((int64_t)1 << 32)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "radix sort: count %lld >= 2^32", (long long)count);
-  const int64_t tiles64 = (count + TILE - 1) / TILE;
-  const int tiles = (int)tiles64;
-  uint32_t *hist = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)256 * tiles, &hist));
+  const int64_t tiles = (count + TILE - 1) / TILE;
+  RadixPlan plan;
+  plan.n = np;
+  for (int p = 0; p < np; p++) {
+    plan.shift[p] = passes[p].shift;
+    plan.bits[p] = passes[p].bits;
+  }
+  // scratch: [np*256 bins][np tickets (padded)][np * tiles * 256 status words], zeroed once
+  const size_t bins_words = (size_t)np * 256, ticket_words = 32, state_words = (size_t)np * tiles * 256;
+  unsigned long long *scratch = nullptr;
+  SBX_TRY(sbx_salloc(h, bins_words + ticket_words + state_words, &scratch));
+  SBX_HIP(h, hipMemsetAsync(scratch, 0, (bins_words + ticket_words + state_words) * sizeof(unsigned long long),
+                            h->stream));
+  unsigned long long *ghist = scratch;
+  unsigned *tickets = (unsigned *)(scratch + bins_words);
+  unsigned long long *state = scratch + bins_words + ticket_words;
+  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>), dim3(sbx_grid_for(count, RS_THREADS * 8, (int64_t)h->num_cus * 8)),
+              dim3(RS_THREADS), (const K *)ka, count, plan, ghist);
+  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, k_onesweep_bins, dim3(1), dim3(RS_THREADS), ghist, np);
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
   for (int p = 0; p < np; p++) {
-    const unsigned mask = (1u << passes[p].bits) - 1u;
-    SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_radix_hist<K, ITEMS>), dim3(tiles), dim3(RS_THREADS), (const K *)src_k, count,
-                       passes[p].shift, mask, hist, tiles);
-    SBX_TRY(sbx_exclusive_scan_u32(h, hist, hist, (int64_t)256 * tiles, nullptr));
-    SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_radix_scatter<K, P, ITEMS, HAS_P>), dim3(tiles), dim3(RS_THREADS),
-                       (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
-                       (const uint32_t *)hist, tiles);
+    SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P>), dim3((unsigned)tiles), dim3(RS_THREADS),
+                (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
+                (const unsigned long long *)(ghist + (size_t)p * 256), state + (size_t)p * tiles * 256, tickets + p);
     SBX_LAUNCH_CHECK(h);
     K *tk = src_k; src_k = dst_k; dst_k = tk;
     P *tv = src_v; src_v = dst_v; dst_v = tv;
