@@ -306,7 +306,7 @@ extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz,
                                  int *sorted_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, sorted_host && nnz >= 0 && (nnz == 0 || (row && col)), "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_coo_is_sorted(h, nnz, row, col, sorted_host);
   SBX_TRY(sbx_arena_begin(h));
   *sorted_host = 1;
   if (nnz == 0) return SBX_OK;
@@ -325,7 +325,7 @@ extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n,
                                    const void *col, int *sorted_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, sorted_host && n >= 0 && row_ptr, "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_csr_rows_sorted(h, n, row_ptr, col, sorted_host);
   SBX_TRY(sbx_arena_begin(h));
   *sorted_host = 1;
   if (n == 0) return SBX_OK;
@@ -348,7 +348,7 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
                             void *row, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, nnz >= 0 && n >= 0 && m >= 0 && (nnz == 0 || (row && col)), "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_coo_sort(h, vt, n, m, nnz, row, col, val);
   const int vb = val ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   if (nnz <= 1) return SBX_OK;
@@ -427,8 +427,9 @@ extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr_out && (nnz == 0 || row), "bad argument");
   SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
-  SBX_ONLY_I32(h, it);
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  if (it == SBX_I64)
+    return sbx_i64_coo_to_csr(h, vt, n, m, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
   const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
@@ -479,8 +480,9 @@ extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || row_out), "bad argument");
   SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
-  SBX_ONLY_I32(h, it);
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  if (it == SBX_I64)
+    return sbx_i64_csr_to_coo(h, vt, n, m, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
   const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));

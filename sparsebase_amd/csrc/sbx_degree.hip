@@ -42,7 +42,7 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
                                   void *inv_perm_out) {
   if (!h) return SBX_ERR_BAD_ARG;
   if (n < 0 || !row_ptr || (n > 0 && !inv_perm_out)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_degree_reorder: bad argument");
-  if (it != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_degree_reorder: 64-bit indices not built yet");
+  if (it == SBX_I64) return sbx_i64_degree_reorder(h, n, row_ptr, ascending, inv_perm_out);
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
   uint32_t *ka, *kb, *ia, *ib;

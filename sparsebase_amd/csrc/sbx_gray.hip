@@ -140,7 +140,9 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   if (!h) return SBX_ERR_BAD_ARG;
   if (n < 0 || m < 0 || !row_ptr || !counts_host || (n > 0 && (!degree_out || !key_out)) || (nnz > 0 && !col))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_row_keys: bad argument");
-  if (it != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_gray_row_keys: 64-bit indices not built yet");
+  if (it == SBX_I64)
+    return sbx_i64_gray_row_keys(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, degree_out, key_out,
+                                 counts_host);
   int bits = resolution;
   if (m < bits) bits = (int)m;  // gray_reorder.cc:206-208
   if (bits <= 0 || bits > 64) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_row_keys: resolution must be in 1..64");

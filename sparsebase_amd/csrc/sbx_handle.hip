@@ -71,6 +71,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->cur_off = 0;
   h->call_bytes = 0;
   h->high_water = 0;
+  h->nest = 0;
   h->pinned = nullptr;
   h->pinned_bytes = 0;
   h->err[0] = 0;
@@ -160,6 +161,7 @@ extern "C" int sbx_reserve(sbx_handle_t h, size_t scratch_bytes) {
 
 int sbx_arena_begin(sbx_handle_t h) {
   SBX_HIP(h, hipSetDevice(h->device));
+  if (h->nest > 0) return SBX_OK;  // nested entry point: keep the caller's scratch alive
   if (h->blocks.size() > 1) {
     // the previous call overflowed the first block: consolidate to one block
     size_t total = 0;
@@ -257,7 +259,7 @@ extern "C" int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, co
 // ---------------------------------------------------------------------------
 const char *const sbx_kernel_names[SBX_K_COUNT] = {
     "scan",          "radix_hist",   "radix_scatter", "coo_to_csr", "csr_to_coo", "permute_tile",
-    "permute_long",  "permute_block", "permute_prep", "bfs_expand",    "bfs_heavy",  "bfs_bottom_up",  "level_order", "cc",
+    "permute_long",  "permute_block", "permute_prep", "bfs_expand",    "bfs_heavy",  "bfs_bottom_up", "bfs_small_levels",  "level_order", "cc",
     "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "misc"};
 
 static hipEvent_t prof_event(sbx_handle_t h) {

@@ -1,0 +1,240 @@
+// sbx_i64.hip — SBX_I64 support: 64-bit IDType/NNZType arrays (the reference's
+// <int64,int64,double> tuple).  Every BASELINE configuration has n, m, nnz < 2^31, so
+// the 64-bit entry points narrow their index arrays to int32 scratch copies (with an
+// overflow check), run the int32 kernels and widen the index outputs back; values are
+// opaque payload and pass through untouched.  Arrays with entries >= 2^31 return
+// SBX_ERR_UNSUPPORTED (native 64-bit kernels: DESIGN.md "Next").
+#include "sbx_device.h"
+#include "sbx_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_narrow(const int64_t *__restrict__ in, int32_t *__restrict__ out,
+                                                int64_t count, int *__restrict__ overflow) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < count; i += stride) {
+    const int64_t v = in[i];
+    bad |= (v < 0) || (v > 0x7FFFFFFFll);
+    out[i] = (int32_t)v;
+  }
+  if (__any(bad) && sbx_lane() == 0) *overflow = 1;
+}
+
+__global__ __launch_bounds__(256) void k_widen(const int32_t *__restrict__ in, int64_t *__restrict__ out,
+                                               int64_t count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) out[i] = (int64_t)in[i];
+}
+
+}  // namespace
+
+int sbx_i64_begin(sbx_handle_t h, int **overflow_flag_dev) {
+  SBX_TRY(sbx_arena_begin(h));
+  h->nest++;
+  int rc = sbx_salloc(h, 1, overflow_flag_dev);
+  if (rc == SBX_OK && hipMemsetAsync(*overflow_flag_dev, 0, sizeof(int), h->stream) != hipSuccess) rc = SBX_ERR_HIP;
+  if (rc != SBX_OK) h->nest--;
+  return rc;
+}
+
+void sbx_i64_end(sbx_handle_t h) {
+  if (h->nest > 0) h->nest--;
+}
+
+int sbx_narrow_i64(sbx_handle_t h, const void *src_i64, int64_t count, int32_t **out, int *overflow_flag_dev) {
+  *out = nullptr;
+  if (!src_i64) return SBX_OK;
+  SBX_TRY(sbx_salloc(h, (size_t)(count > 0 ? count : 1), out));
+  if (count > 0) {
+    SBX_KLAUNCH(h, SBX_K_MISC, k_narrow, dim3(sbx_grid_for(count, 256, 8192)), dim3(256), (const int64_t *)src_i64, *out,
+                count, overflow_flag_dev);
+    SBX_LAUNCH_CHECK(h);
+  }
+  return SBX_OK;
+}
+
+int sbx_widen_i32(sbx_handle_t h, const int32_t *src, void *dst_i64, int64_t count) {
+  if (!src || !dst_i64 || count <= 0) return SBX_OK;
+  SBX_KLAUNCH(h, SBX_K_MISC, k_widen, dim3(sbx_grid_for(count, 256, 8192)), dim3(256), src, (int64_t *)dst_i64, count);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev) {
+  int f = 0;
+  SBX_TRY(sbx_readback(h, &f, overflow_flag_dev, sizeof(int)));
+  if (f)
+    SBX_FAIL(h, SBX_ERR_UNSUPPORTED,
+             "64-bit index array holds a value outside [0, 2^31): native 64-bit kernels are not built yet");
+  return SBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 64-bit entry points: narrow -> int32 entry point -> widen
+// ---------------------------------------------------------------------------
+namespace {
+struct Scope {  // leaves nesting mode on every return path
+  sbx_handle_t h;
+  explicit Scope(sbx_handle_t h) : h(h) {}
+  ~Scope() { sbx_i64_end(h); }
+};
+}  // namespace
+
+#define I64_BEGIN()                       \
+  int *ovf = nullptr;                     \
+  SBX_TRY(sbx_i64_begin(h, &ovf));        \
+  Scope scope_(h)
+#define NARROW(name, src, count) \
+  int32_t *name = nullptr;       \
+  SBX_TRY(sbx_narrow_i64(h, src, count, &name, ovf))
+#define SCRATCH32(name, count, want) \
+  int32_t *name = nullptr;           \
+  if (want) SBX_TRY(sbx_salloc(h, (size_t)((count) > 0 ? (count) : 1), &name))
+
+int sbx_i64_coo_is_sorted(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host) {
+  I64_BEGIN();
+  NARROW(r, row, nnz);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_coo_is_sorted(h, SBX_I32, nnz, r, c, sorted_host);
+}
+
+int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
+                     void *val) {
+  I64_BEGIN();
+  NARROW(r, row, nnz);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_coo_sort(h, SBX_I32, vt, n, m, nnz, r, c, val));
+  SBX_TRY(sbx_widen_i32(h, r, row, nnz));
+  return sbx_widen_i32(h, c, col, nnz);
+}
+
+static int read_nnz_i64(sbx_handle_t h, const void *row_ptr, int64_t n, int64_t *nnz) {
+  return sbx_readback(h, nnz, (const int64_t *)row_ptr + n, sizeof(int64_t));
+}
+
+int sbx_i64_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host) {
+  I64_BEGIN();
+  int64_t nnz = 0;
+  SBX_TRY(read_nnz_i64(h, row_ptr, n, &nnz));
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_csr_rows_sorted(h, SBX_I32, n, rp, c, sorted_host);
+}
+
+int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                          void *col, void *val) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_csr_sort_rows(h, SBX_I32, vt, n, m, nnz, rp, c, val));
+  return sbx_widen_i32(h, c, col, nnz);
+}
+
+int sbx_i64_coo_to_csr(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
+                       const void *col, const void *val, void *row_ptr_out, void *col_out, void *val_out,
+                       unsigned flags) {
+  I64_BEGIN();
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  NARROW(r, row, nnz);
+  NARROW(c, move ? nullptr : col, nnz);
+  SCRATCH32(rp, n + 1, true);
+  SCRATCH32(co, nnz, !move && col_out);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_coo_to_csr(h, SBX_I32, vt, n, m, nnz, r, c, val, rp, co, val_out, flags));
+  SBX_TRY(sbx_widen_i32(h, rp, row_ptr_out, n + 1));
+  return sbx_widen_i32(h, co, col_out, nnz);
+}
+
+int sbx_i64_csr_to_coo(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                       const void *col, const void *val, void *row_out, void *col_out, void *val_out,
+                       unsigned flags) {
+  I64_BEGIN();
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, move ? nullptr : col, nnz);
+  SCRATCH32(ro, nnz, true);
+  SCRATCH32(co, nnz, !move && col_out);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_csr_to_coo(h, SBX_I32, vt, n, m, nnz, rp, c, val, ro, co, val_out, flags));
+  SBX_TRY(sbx_widen_i32(h, ro, row_out, nnz));
+  return sbx_widen_i32(h, co, col_out, nnz);
+}
+
+int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SCRATCH32(inv, n, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_degree_reorder(h, SBX_I32, n, rp, ascending, inv));
+  return sbx_widen_i32(h, inv, inv_perm_out, n);
+}
+
+int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                        void *inv_perm_out, sbx_rcm_stats *stats_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SCRATCH32(inv, n, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_rcm_reorder(h, SBX_I32, n, nnz, rp, c, inv, stats_host));
+  return sbx_widen_i32(h, inv, inv_perm_out, n);
+}
+
+int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
+                          int64_t *counts_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SCRATCH32(deg, n, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_gray_row_keys(h, SBX_I32, n, m, nnz, rp, c, resolution, nnz_threshold, deg, key_out, counts_host));
+  return sbx_widen_i32(h, deg, degree_out, n);
+}
+
+int sbx_i64_inverse_permutation(sbx_handle_t h, int64_t n, const void *perm, void *inv_out) {
+  I64_BEGIN();
+  NARROW(p, perm, n);
+  SCRATCH32(inv, n, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_inverse_permutation(h, SBX_I32, n, p, inv));
+  return sbx_widen_i32(h, inv, inv_out, n);
+}
+
+int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                             const void *col, const void *val, const void *row_order, const void *col_order,
+                             int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                             int64_t out_capacity, int64_t *shard_nnz_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  NARROW(ro, row_order, n);
+  int32_t *co = nullptr;
+  if (col_order == row_order && n == m) co = ro;
+  else SBX_TRY(sbx_narrow_i64(h, col_order, m, &co, ovf));
+  const int64_t nr = row_end - row_begin;
+  SCRATCH32(rpo, nr + 1, true);
+  SCRATCH32(colo, out_capacity, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  int64_t got = 0;
+  SBX_TRY(sbx_permute_csr_rows(h, SBX_I32, vt, n, m, nnz, rp, c, val, ro, co, row_begin, row_end, rpo, colo, val_out,
+                               out_capacity, &got));
+  if (shard_nnz_host) *shard_nnz_host = got;
+  SBX_TRY(sbx_widen_i32(h, rpo, row_ptr_out, nr + 1));
+  return sbx_widen_i32(h, colo, col_out, got);
+}
+
+int sbx_i64_permute_array(sbx_handle_t h, sbx_value_type vt, int64_t n, const void *order, const void *vals,
+                          void *out) {
+  I64_BEGIN();
+  NARROW(o, order, n);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_permute_array(h, SBX_I32, vt, n, o, vals, out);
+}

@@ -26,6 +26,7 @@ enum sbx_kernel_id {
   SBX_K_BFS_EXPAND,
   SBX_K_BFS_HEAVY,
   SBX_K_BFS_BOTTOMUP,
+  SBX_K_BFS_SMALL,
   SBX_K_LEVEL_ORDER,
   SBX_K_CC,
   SBX_K_RCM_SMALL,
@@ -59,6 +60,7 @@ struct sbx_handle_s {
   size_t cur_off;
   size_t call_bytes;  // bytes handed out during the current call
   size_t high_water;
+  int nest;  // > 0 while an API entry point calls another one: the arena is not rewound
   void *pinned;  // small pinned host buffer for device->host read-backs
   size_t pinned_bytes;
   int num_cus;
@@ -171,4 +173,38 @@ int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_
                    int num_passes, int *result_in_b);
 
 int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count);
+
+// ---- 64-bit index arrays (sbx_i64.hip): narrowed to the int32 kernels when every value fits
+struct sbx_narrowed {
+  int32_t *ptr;  // int32 copy in the arena (nullptr if the source was nullptr)
+};
+int sbx_narrow_i64(sbx_handle_t h, const void *src_i64, int64_t count, int32_t **out, int *overflow_flag_dev);
+int sbx_widen_i32(sbx_handle_t h, const int32_t *src, void *dst_i64, int64_t count);
+int sbx_i64_begin(sbx_handle_t h, int **overflow_flag_dev);          // arena_begin + nesting on
+int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev);     // synchronous overflow check
+void sbx_i64_end(sbx_handle_t h);
+int sbx_i64_coo_is_sorted(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host);
+int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
+                     void *val);
+int sbx_i64_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host);
+int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                          void *col, void *val);
+int sbx_i64_coo_to_csr(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
+                       const void *col, const void *val, void *row_ptr_out, void *col_out, void *val_out,
+                       unsigned flags);
+int sbx_i64_csr_to_coo(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                       const void *col, const void *val, void *row_out, void *col_out, void *val_out, unsigned flags);
+int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out);
+int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                        void *inv_perm_out, sbx_rcm_stats *stats_host);
+int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
+                          int64_t *counts_host);
+int sbx_i64_inverse_permutation(sbx_handle_t h, int64_t n, const void *perm, void *inv_out);
+int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                             const void *col, const void *val, const void *row_order, const void *col_order,
+                             int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                             int64_t out_capacity, int64_t *shard_nnz_host);
+int sbx_i64_permute_array(sbx_handle_t h, sbx_value_type vt, int64_t n, const void *order, const void *vals,
+                          void *out);
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);

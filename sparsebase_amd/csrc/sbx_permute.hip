@@ -649,7 +649,7 @@ extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_
                                        void *inv_out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (perm && inv_out)), "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_inverse_permutation(h, n, perm, inv_out);
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
@@ -662,7 +662,7 @@ extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_ty
                                  const void *vals, void *out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (order && vals && out)), "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_permute_array(h, vt, n, order, vals, out);
   const int vb = sbx_value_bytes(vt);
   SBX_REQUIRE(h, vb == 4 || vb == 8, "value type must be 4 or 8 bytes");
   SBX_TRY(sbx_arena_begin(h));
@@ -687,8 +687,10 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && row_ptr_out, "bad argument");
   SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
   SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
-  SBX_ONLY_I32(h, it);
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  if (it == SBX_I64)
+    return sbx_i64_permute_csr_rows(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
+                                    row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
   const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
@@ -750,7 +752,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
                                  int64_t nnz, const void *row_ptr, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || col), "bad argument");
-  SBX_ONLY_I32(h, it);
+  if (it == SBX_I64) return sbx_i64_csr_sort_rows(h, vt, n, m, nnz, row_ptr, col, val);
   if (nnz <= 1 || n == 0) return SBX_OK;
   int sorted = 1;
   SBX_TRY(sbx_csr_rows_sorted(h, it, n, row_ptr, col, &sorted));  // csr.cc:102-116

@@ -31,6 +31,8 @@
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace {
@@ -55,6 +57,11 @@ struct RcmDev {                 // device-resident scalars
   unsigned long long edges;     // adjacency entries scanned (statistics)
   unsigned long long fedges;    // sum of degrees of the level being built (direction heuristic)
   unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
+  // hand-off state of the persistent small-level kernel
+  unsigned sl_off, sl_fsize, sl_level, sl_total;
+  unsigned sl_status;           // SL_DONE / SL_STOP_READY / SL_STOP_EXPANDED
+  unsigned sl_pad;
+  unsigned long long sl_edges;  // degree sum of the levels the kernel ordered
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -362,6 +369,28 @@ __device__ __forceinline__ void stage_push(I v, bool won, const I *__restrict__ 
   }
 }
 
+// Visits up to 4 neighbours per lane in phases (bitmap tests, then coherent ppos
+// pre-checks, then the atomics) so that 4 independent loads per lane are in flight
+// instead of one 3-deep dependent chain per neighbour.
+__device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, unsigned p, const I *__restrict__ rp,
+                                           const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
+                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
+  unsigned unv = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (((actmask >> k) & 1u) && !((vbits[v[k] >> 5] >> (v[k] & 31)) & 1u)) unv |= 1u << k;
+  unsigned cur[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    cur[k] = ((unv >> k) & 1u) ? __hip_atomic_load(&ppos[v[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  unsigned won = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (((unv >> k) & 1u) && cur[k] > p && atomicMin(&ppos[v[k]], p) == UNSEEN) won |= 1u << k;
+#pragma unroll
+  for (int k = 0; k < 4; k++) stage_push(v[k], (won >> k) & 1u, rp, st, nf_list, dv);
+}
+
 __device__ __forceinline__ void bfs_visit(I v, unsigned p, const I *__restrict__ rp,
                                           const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv, bool active) {
@@ -379,6 +408,7 @@ __device__ __forceinline__ void bfs_visit(I v, unsigned p, const I *__restrict__
 // descriptors for k_bfs_expand_heavy.
 constexpr int RCM_GROUP = 16;
 constexpr int RCM_VPW = 64 / RCM_GROUP;  // frontier vertices per wave
+constexpr int RCM_BU_INLINE = 16;        // bottom-up: candidates up to this degree get one lane each
 
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
@@ -412,10 +442,16 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
     if (gl == 0) scanned += (unsigned)(e - s);
     I j = s + gl;
     while (__any(j < e)) {
-      const bool act = j < e;
-      const I v = act ? col[j] : 0;
-      bfs_visit(v, (unsigned)p, rp, vbits, ppos, st, nf_list, dv, act);
-      j += RCM_GROUP;
+      I v[4];
+      unsigned act = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const I jk = j + k * RCM_GROUP;
+        v[k] = jk < e ? col[jk] : 0;
+        if (jk < e) act |= 1u << k;
+      }
+      bfs_visit4(v, act, (unsigned)p, rp, vbits, ppos, st, nf_list, dv);
+      j += 4 * RCM_GROUP;
     }
   }
   stage_flush(st, nf_list, dv);
@@ -441,11 +477,16 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
     const I s = rp[u], e = rp[u + 1];
     const I cs = s + (I)c * RCM_CHUNK;
     const I ce = (cs + RCM_CHUNK < e) ? cs + RCM_CHUNK : e;
-    for (I j0 = cs; j0 < ce; j0 += 256) {
-      const I j = j0 + (I)threadIdx.x;
-      const bool act = j < ce;
-      const I v = act ? col[j] : 0;
-      bfs_visit(v, p, rp, vbits, ppos, st, nf_list, dv, act);
+    {
+      I v[4];
+      unsigned act = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const I j = cs + k * 256 + (I)threadIdx.x;
+        v[k] = j < ce ? col[j] : 0;
+        if (j < ce) act |= 1u << k;
+      }
+      bfs_visit4(v, act, p, rp, vbits, ppos, st, nf_list, dv);
     }
     scanned += (unsigned long long)(ce - cs);
   }
@@ -465,7 +506,8 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
                                                        const unsigned *__restrict__ vbits,
                                                        const unsigned *__restrict__ fbits,
                                                        const unsigned *__restrict__ lpos, unsigned *__restrict__ ppos,
-                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv) {
+                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv,
+                                                       int dbg) {
   __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -482,7 +524,33 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       e = rp[v + 1];
       cand = (e > s) && label[v] == comp_label;
     }
-    uint64_t todo = __ballot(cand);
+    // low-degree candidates: one lane each (64 independent load chains per wave; the
+    // rows of consecutive vertices are adjacent in col[], so the lanes share lines)
+    const bool small = cand && (e - s) <= RCM_BU_INLINE;
+    if (dbg != 1 && dbg != 3 && __any(small)) {
+      // three unrolled phases keep RCM_BU_INLINE independent loads in flight per lane
+      // instead of a 3-deep dependent chain per neighbour
+      const int dg = small ? (int)(e - s) : 0;
+      I us[RCM_BU_INLINE];
+#pragma unroll
+      for (int k = 0; k < RCM_BU_INLINE; k++) us[k] = k < dg ? col[s + k] : (I)-1;
+      unsigned hit = 0;
+#pragma unroll
+      for (int k = 0; k < RCM_BU_INLINE; k++)
+        if (us[k] >= 0 && ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u)) hit |= 1u << k;
+      unsigned best = UNSEEN;
+#pragma unroll
+      for (int k = 0; k < RCM_BU_INLINE; k++) {
+        const unsigned lp = ((hit >> k) & 1u) ? lpos[us[k]] : UNSEEN;
+        best = lp < best ? lp : best;
+      }
+      if (small) scanned += (unsigned)dg;
+      const bool found = small && best != UNSEEN;
+      if (found) ppos[v] = best;
+      stage_push((I)v, found, rp, st, nf_list, dv);
+    }
+    uint64_t todo = __ballot(cand && !small);
+    if (dbg == 1 || dbg == 2) todo = 0;
     while (todo) {
       // the next RCM_VPW candidates, one per 16-lane group
       uint64_t t = todo;
@@ -498,14 +566,19 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       I j = (pick < 0 ? 0 : cs) + gl;
       const I jend = pick < 0 ? 0 : ce;
       while (__any(j < jend)) {
-        if (j < jend) {
-          const I u = col[j];
-          if ((fbits[u >> 5] >> (u & 31)) & 1u) {
-            const unsigned lp = lpos[u];
-            best = lp < best ? lp : best;
-          }
+        I us[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) us[k] = (j + k * RCM_GROUP) < jend ? col[j + k * RCM_GROUP] : (I)-1;
+        unsigned hit = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (us[k] >= 0 && ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u)) hit |= 1u << k;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned lp = ((hit >> k) & 1u) ? lpos[us[k]] : UNSEEN;
+          best = lp < best ? lp : best;
         }
-        j += RCM_GROUP;
+        j += 4 * RCM_GROUP;
       }
       if (gl == 0 && pick >= 0) scanned += (unsigned)(ce - cs);
 #pragma unroll
@@ -614,6 +687,151 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
   }
 }
 
+// ---- persistent small-level kernel ------------------------------------------------
+// Deep, narrow BFS (banded / grid / road-like graphs, and the first and last levels of
+// every sweep) is launch-latency bound when each level costs a host round trip.  One
+// 1024-thread workgroup therefore runs consecutive levels on its own for as long as
+// the frontier stays small: expand (atomicMin on ppos, winners listed in LDS and in
+// nf_list), order the level with an LDS bitonic sort of the 64-bit keys, publish it
+// (q, visited/frontier bitmaps, level positions) and go on.  It hands back to the host
+// loop at a level boundary when the frontier or its edge count outgrows the budget
+// (SL_STOP_READY), or right after an expansion whose result does not fit LDS
+// (SL_STOP_EXPANDED: nf_list / dv->nf / dv->fedges are exactly what the general
+// expansion kernels would have left).
+constexpr unsigned SL_DONE = 0, SL_STOP_READY = 1, SL_STOP_EXPANDED = 2;
+constexpr int SL_MAXF = 1024;    // frontier vertices handled in-kernel
+constexpr int SL_MAXE = 32768;   // frontier adjacency entries handled in-kernel
+constexpr int SL_CAP = 2048;     // next-level vertices that fit the LDS sort
+
+template <bool CM>
+__global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__ rp, const I *__restrict__ col,
+                                                           I *q, unsigned *vbits, unsigned *fbits, unsigned *lpos,
+                                                           unsigned *ppos, I *nf_list,
+                                                           const uint32_t *__restrict__ drank,
+                                                           const uint32_t *__restrict__ dorder, unsigned off,
+                                                           unsigned fsize, unsigned level, unsigned total,
+                                                           RcmDev *dv) {
+  __shared__ uint64_t s_key[SL_CAP];
+  __shared__ I s_front[SL_MAXF];
+  __shared__ unsigned s_cnt;
+  __shared__ unsigned long long s_deg[1024 / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long ordered_edges = 0, scanned = 0;
+  unsigned status = SL_STOP_READY;
+  if (fsize <= SL_MAXF)
+    for (unsigned i = tid; i < fsize; i += 1024) s_front[i] = q[off + i];
+  __syncthreads();
+  while (true) {
+    if (fsize > SL_MAXF) break;  // status stays SL_STOP_READY
+    // degree sum of the frontier
+    unsigned long long dsum = 0;
+    for (unsigned i = tid; i < fsize; i += 1024) dsum += (unsigned long long)(rp[s_front[i] + 1] - rp[s_front[i]]);
+    dsum = sbx_block_sum<unsigned long long, 1024>(dsum, s_deg);
+    if (tid == 0) {
+      s_cnt = 0;
+      dv->fedges = dsum;  // what the host's direction heuristic expects for this frontier
+    }
+    if (dsum > (unsigned long long)SL_MAXE) break;  // SL_STOP_READY
+    __syncthreads();
+    // ---- expand: one wave per frontier vertex
+    unsigned long long wdeg = 0;
+    for (unsigned p = w; p < fsize; p += 16) {
+      const I u = s_front[p];
+      const I s0 = rp[u], e0 = rp[u + 1];
+      for (I j = s0 + lane; j < e0; j += 64) {
+        const I v = col[j];
+        const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((word >> (v & 31)) & 1u) continue;
+        if (atomicMin(&ppos[v], p) == UNSEEN) {
+          const unsigned slot = atomicAdd(&s_cnt, 1u);
+          if (slot < (unsigned)SL_CAP) s_key[slot] = (uint64_t)(uint32_t)v;  // in-kernel copy (LDS)
+          nf_list[slot] = v;  // complete list for the hand-off case
+          wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
+        }
+      }
+    }
+    scanned += dsum;
+    wdeg = sbx_block_sum<unsigned long long, 1024>(wdeg, s_deg);
+    const unsigned nf = s_cnt;
+    if (nf == 0) {
+      status = SL_DONE;
+      break;
+    }
+    if (nf > (unsigned)SL_CAP) {  // cannot order it here: leave it to the host path
+      if (tid == 0) {
+        dv->nf = nf;
+        dv->fedges = wdeg;
+      }
+      status = SL_STOP_EXPANDED;
+      break;
+    }
+    ordered_edges += wdeg;  // degrees of the vertices discovered (and ordered) in-kernel
+    // ---- order the new level: bitonic sort of (parent position, id | degree rank)
+    unsigned p2 = 1;
+    while (p2 < nf) p2 <<= 1;
+    for (unsigned j = tid; j < p2; j += 1024) {
+      uint64_t k = ~0ull;
+      if (j < nf) {
+        const I v = (I)(uint32_t)s_key[j];
+        const unsigned pp = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = ((uint64_t)pp << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+      }
+      s_key[j] = k;
+    }
+    __syncthreads();
+    for (unsigned k = 2; k <= p2; k <<= 1) {
+      for (unsigned j = k >> 1; j > 0; j >>= 1) {
+        for (unsigned t = tid; t < p2; t += 1024) {
+          const unsigned l = t ^ j;
+          if (l > t) {
+            const uint64_t a = s_key[t], b = s_key[l];
+            const bool up = (t & k) == 0;
+            if ((a > b) == up) {
+              s_key[t] = b;
+              s_key[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- publish: clear the old frontier bits, write q / bitmaps / positions of the new level
+    for (unsigned i = tid; i < fsize; i += 1024) {
+      const I u = s_front[i];
+      atomicAnd(&fbits[u >> 5], ~(1u << (u & 31)));
+    }
+    __syncthreads();
+    const unsigned noff = off + fsize;
+    for (unsigned j = tid; j < nf; j += 1024) {
+      const uint32_t lo = (uint32_t)s_key[j];
+      const I v = (I)(CM ? dorder[lo] : lo);
+      q[noff + j] = v;
+      atomicOr(&vbits[v >> 5], 1u << (v & 31));
+      atomicOr(&fbits[v >> 5], 1u << (v & 31));
+      lpos[v] = j;
+      if (j < (unsigned)SL_MAXF) s_front[j] = v;
+    }
+    off = noff;
+    fsize = nf;
+    total += nf;
+    level++;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    dv->sl_off = off;
+    dv->sl_fsize = fsize;
+    dv->sl_level = level;
+    dv->sl_total = total;
+    dv->sl_status = status;
+    dv->sl_edges = ordered_edges;
+    if (status != SL_STOP_EXPANDED) {
+      dv->nf = 0;
+      dv->n_heavy = 0;
+    }
+    atomicAdd(&dv->edges, scanned);
+  }
+}
+
 // deepest level: vertex of strictly smallest degree, first in queue order (:64-75)
 __global__ __launch_bounds__(256) void k_pick_root(const I *__restrict__ rp, const I *__restrict__ level,
                                                    unsigned lsize, RcmDev *__restrict__ dv) {
@@ -670,7 +888,7 @@ struct BfsResult {
 // One ordered BFS over the component containing the root (fixed_root >= 0, or the
 // device-resident dv->root).  CM selects Cuthill-McKee child order.  Direction per
 // level: top-down (frontier pushes) unless the frontier is large and owns more than
-// half as many edges as the still-unvisited remainder — then bottom-up (pull).
+// four times as many edges as the still-unvisited remainder — then bottom-up (pull).
 template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
@@ -679,15 +897,40 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
+  static const int dbg_bu = getenv("SBX_DEBUG_BU_MODE") ? atoi(getenv("SBX_DEBUG_BU_MODE")) : 0;
   int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
   int64_t frontier_edges = -1;    // degree sum of the current frontier (-1: level 0, read lazily)
+  bool try_small = true;  // false right after the small-level kernel declined this very frontier
   while (true) {
+    bool expanded_by_small = false;
+    RcmDev hd;
+    if (try_small && fsize <= (unsigned)SL_MAXF) {
+      SBX_KLAUNCH(h, SBX_K_BFS_SMALL, (k_bfs_small_levels<CM>), dim3(1), dim3(1024), b.rp, b.col, b.q, b.vbits, b.fbits,
+                  b.lpos, b.ppos, b.nf_list, b.drank, b.dorder, off, fsize, level, total, b.dv);
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+      remaining -= (int64_t)hd.sl_edges;
+      if (remaining < 0) remaining = 0;
+      off = hd.sl_off;
+      fsize = hd.sl_fsize;
+      level = hd.sl_level;
+      total = hd.sl_total;
+      if (hd.sl_status == SL_DONE) break;
+      if (hd.sl_status == SL_STOP_READY) {
+        frontier_edges = (int64_t)hd.fedges;
+        try_small = false;  // expand this frontier with the general kernels
+        continue;
+      }
+      expanded_by_small = true;  // SL_STOP_EXPANDED: nf_list / nf / fedges are ready for ordering
+    }
+    try_small = true;
+    if (!expanded_by_small) {
     bool bottom_up = false;
-    if (frontier_edges >= 0 && fsize >= 8192) bottom_up = 2 * frontier_edges > remaining;
+    if (frontier_edges >= 0 && fsize >= 8192) bottom_up = frontier_edges > 4 * remaining;
     if (bottom_up) {
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
-                  b.n, b.dv);
+                  b.n, b.dv, dbg_bu);
     } else {
       const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
       unsigned grid = (waves_needed + 3) / 4;
@@ -700,8 +943,8 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                   (const uint64_t *)b.heavy, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
-    RcmDev hd;
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    }
     const unsigned nf = hd.nf;
     if (nf == 0) break;
     if (frontier_edges < 0) remaining -= (int64_t)0;  // level 0's degree is part of hd.fedges history below
@@ -745,7 +988,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   if (!h) return SBX_ERR_BAD_ARG;
   if (n < 0 || nnz < 0 || !row_ptr || (n > 0 && !inv_perm_out) || (nnz > 0 && !col_v))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: bad argument");
-  if (it != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_rcm_reorder: 64-bit indices not built yet");
+  if (it == SBX_I64) return sbx_i64_rcm_reorder(h, n, nnz, row_ptr, col_v, inv_perm_out, stats_host);
   if (n >= ((int64_t)1 << 31) - 1 || nnz >= ((int64_t)1 << 31))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: dimension exceeds int32");
   if (stats_host) memset(stats_host, 0, sizeof(*stats_host));

@@ -1,0 +1,94 @@
+"""Full-size BASELINE configurations on the GPU (C2, C3, C5): bit-exact comparison with the oracle
+where the oracle finishes in seconds, otherwise size-independent properties (permutation-ness,
+round trips, sortedness, idempotence, checksums)."""
+import numpy as np
+import pytest
+
+from sparsebase_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible")
+    from sparsebase_amd import ops as _ops
+    return _ops
+
+
+def test_c2_coo_to_csr_10m_uniform(ops, oracle):
+    n = m = 1 << 20
+    row, col, val = synth.uniform_random_coo_torch(n, m, 10_000_000, seed=3)
+    rp, co, vo = ops.coo_to_csr(n, m, row, col, val, rows_sorted=True)
+    want = oracle.coo_to_csr(n, row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy())
+    assert np.array_equal(rp.cpu().numpy(), want[0])
+    assert np.array_equal(co.cpu().numpy(), want[1]) and np.array_equal(vo.cpu().numpy(), want[2])
+    # without the hint (sortedness detected on the device) and as a move conversion
+    assert torch.equal(ops.coo_to_csr(n, m, row, col, val)[0], rp)
+    assert torch.equal(ops.coo_to_csr(n, m, row, col, None, move=True)[0], rp)
+    # CSR -> COO round trip, and the COO-constructor sort of a shuffled copy (config 2B)
+    back = ops.csr_to_coo(n, m, rp, co, vo)
+    assert torch.equal(back[0], row) and torch.equal(back[1], col) and torch.equal(back[2], val)
+    p = torch.randperm(row.numel(), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    r2, c2, v2 = row[p].contiguous(), col[p].contiguous(), val[p].contiguous()
+    assert not ops.coo_is_sorted(r2, c2)
+    ops.coo_sort_(n, m, r2, c2, v2)
+    assert torch.equal(r2, row) and torch.equal(c2, col) and torch.equal(v2, val)
+
+
+@pytest.fixture(scope="module")
+def c3():
+    rp, col = synth.rmat_symmetric_torch(22, 13, seed=1)
+    val = (torch.arange(col.numel(), device="cuda", dtype=torch.int32) % 1021).to(torch.float32)
+    return rp, col, val
+
+
+def test_c3_rcm_100m_bit_exact_vs_oracle(ops, oracle, c3):
+    rp, col, _ = c3
+    order, stats = ops.rcm_reorder(rp, col, return_stats=True)
+    want = oracle.rcm_reorder(rp.cpu().numpy(), col.cpu().numpy())
+    assert np.array_equal(order.cpu().numpy(), want), stats
+
+
+def test_c3_permute_100m_properties(ops, c3):
+    rp, col, val = c3
+    n, nnz = rp.numel() - 1, col.numel()
+    order = ops.rcm_reorder(rp, col)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device="cuda"))  # a permutation
+    prp, pcol, pval = ops.permute_csr(n, n, rp, col, val, order, order)
+    assert int(prp[-1]) == nnz and int(prp[0]) == 0
+    assert ops.csr_rows_sorted(prp, pcol)                                   # every row sorted
+    deg_old = (rp[1:] - rp[:-1]).long()
+    deg_new = (prp[1:] - prp[:-1]).long()
+    assert torch.equal(deg_new[order.long()], deg_old)                     # row lengths moved with the rows
+    assert int(pcol.long().sum()) == int(order.long()[col.long()].sum())   # column relabelling checksum
+    assert float(pval.double().sum()) == float(val.double().sum())         # payload multiset checksum
+    before = pcol.clone()
+    ops.csr_sort_rows_(n, n, prp, pcol, pval)                               # idempotent
+    assert torch.equal(before, pcol)
+    inv = ops.inverse_permutation(order)
+    brp, bcol, bval = ops.permute_csr(n, n, prp, pcol, pval, inv, inv)     # inverse restores the matrix
+    assert torch.equal(brp, rp) and torch.equal(bcol, col) and torch.equal(bval, val)
+    ro, co, vo = ops.csr_to_coo(n, n, prp, pcol, pval)                     # CSR -> COO -> CSR round trip
+    assert ops.coo_is_sorted(ro, co)
+    rrp, rcol, rval = ops.coo_to_csr(n, n, ro, co, vo, rows_sorted=True)
+    assert torch.equal(rrp, prp) and torch.equal(rcol, pcol) and torch.equal(rval, pval)
+    # degree reorder: non-decreasing degrees along the new order
+    dinv = ops.degree_reorder(rp, True)
+    perm = torch.empty_like(dinv)
+    perm[dinv.long()] = torch.arange(n, device="cuda", dtype=torch.int32)
+    assert bool((deg_old[perm.long()][1:] >= deg_old[perm.long()][:-1]).all())
+
+
+@pytest.mark.parametrize("half_bandwidth", [64, (1 << 22) // 16])
+def test_c5_gray_keys_100m_banded(ops, oracle, half_bandwidth):
+    n = 1 << 22
+    rp, col = synth.banded_symmetric_torch(n, half_bandwidth, per_row=12, seed=2)
+    for res, thr in ((32, 10), (16, 20)):
+        deg, key, counts = ops.gray_row_keys(n, rp, col, res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp.cpu().numpy(), col.cpu().numpy(), n, res, thr)
+        assert np.array_equal(deg.cpu().numpy(), wdeg)
+        assert np.array_equal(key.cpu().numpy().view(np.uint64), wkey)
+        assert list(counts) == wcounts.tolist()

@@ -363,3 +363,53 @@ def test_rcm_golden_digests(ops, golden_dir, name):
     for a in out:
         h.update(host(a).tobytes())
     assert h.hexdigest() == d["permute_rcm"]
+
+
+# ----------------------------------------------------------------------------- 64-bit indices (<int64,int64,double>)
+def test_int64_tuple_all_ops(ops, oracle):
+    g = np.random.default_rng(77)
+    rp32, col32 = synth.rmat_symmetric(11, 8, seed=4)
+    rp, col = rp32.astype(np.int64), col32.astype(np.int64)
+    n = len(rp) - 1
+    val = g.random(len(col))
+    order = synth.random_permutation(n, 5, np.int64)
+    assert np.array_equal(host(ops.rcm_reorder(dev(rp), dev(col))), oracle.rcm_reorder(rp, col))
+    assert np.array_equal(host(ops.degree_reorder(dev(rp), False)), oracle.degree_reorder(rp, False))
+    same(ops.permute_csr(n, n, dev(rp), dev(col), dev(val), dev(order), dev(order)),
+         oracle.permute_csr(rp, col, val, order, order))
+    same(ops.permute_csr(n, n, dev(rp), dev(col), dev(val), dev(order), None), oracle.permute_csr(rp, col, val, order, None))
+    assert np.array_equal(host(ops.inverse_permutation(dev(order))), oracle.inverse_permutation(order))
+    coo = ops.csr_to_coo(n, n, dev(rp), dev(col), dev(val))
+    same(coo, oracle.csr_to_coo(rp, col, val))
+    same(ops.coo_to_csr(n, n, *coo), (rp, col, val))
+    p = g.permutation(len(col))
+    r, c, v = dev(host(coo[0])[p]), dev(col[p]), dev(val[p])
+    assert not ops.coo_is_sorted(r, c)
+    ops.coo_sort_(n, n, r, c, v)
+    same((r, c, v), (host(coo[0]), col, val))
+    ucol, uval = col.copy(), val.copy()
+    for i in range(n):
+        q = g.permutation(rp[i + 1] - rp[i])
+        ucol[rp[i]:rp[i + 1]] = ucol[rp[i]:rp[i + 1]][q]
+        uval[rp[i]:rp[i + 1]] = uval[rp[i]:rp[i + 1]][q]
+    dc, dv_ = dev(ucol), dev(uval)
+    assert not ops.csr_rows_sorted(dev(rp), dc)
+    ops.csr_sort_rows_(n, n, dev(rp), dc, dv_)
+    same((dc, dv_), (col, val))
+    deg, key, counts = ops.gray_row_keys(n, dev(rp), dev(col), 32, 10)
+    wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, n, 32, 10)
+    assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+    assert list(counts) == wcounts.tolist()
+    srp, scol, sval = ops.permute_csr_rows(n, n, dev(rp), dev(col), dev(val), dev(order), dev(order), n // 4, n // 2)
+    want = oracle.permute_csr(rp, col, val, order, order)
+    lo, hi = want[0][n // 4], want[0][n // 2]
+    assert np.array_equal(host(srp), want[0][n // 4:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
+
+
+def test_int64_values_beyond_int32_are_refused(ops):
+    from sparsebase_amd import capi
+    rp = np.array([0, 1, 2], np.int64)
+    col = np.array([0, 1 << 33], np.int64)
+    with pytest.raises(capi.SbxError) as e:
+        ops.csr_rows_sorted(dev(rp), dev(col))
+    assert e.value.status == 5  # SBX_ERR_UNSUPPORTED, loudly
