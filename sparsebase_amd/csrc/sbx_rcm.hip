@@ -33,6 +33,7 @@
 
 #include <stdlib.h>
 
+#include <utility>
 #include <vector>
 
 namespace {
@@ -52,6 +53,7 @@ struct RcmDev {                 // device-resident scalars
   unsigned n_cc_big;            // high-degree vertices queued by the CC hook kernel
   unsigned max_deg;
   unsigned root;                // current BFS root of the component being ordered
+  unsigned first_vertex;        // smallest vertex id with a non-empty row (UNSEEN if none)
   unsigned pad;
   unsigned long long best;      // (degree<<32 | position) minimum over the deepest level
   unsigned long long edges;     // adjacency entries scanned (statistics)
@@ -69,15 +71,20 @@ __global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, uint
                                                   uint32_t *__restrict__ id, int64_t n, RcmDev *__restrict__ dv) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned mx = 0;
+  unsigned mx = 0, fv = UNSEEN;
   for (; v < n; v += stride) {
     const unsigned d = (unsigned)(rp[v + 1] - rp[v]);
     key[v] = d;
     id[v] = (uint32_t)v;
     mx = d > mx ? d : mx;
+    if (d) fv = (unsigned)v < fv ? (unsigned)v : fv;
   }
   mx = sbx_wave_max(mx);
-  if (sbx_lane() == 0 && mx) atomicMax(&dv->max_deg, mx);
+  fv = sbx_wave_min(fv);
+  if (sbx_lane() == 0 && mx) {
+    atomicMax(&dv->max_deg, mx);
+    atomicMin(&dv->first_vertex, fv);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_rank_from_order(const uint32_t *__restrict__ dorder,
@@ -135,10 +142,11 @@ __global__ __launch_bounds__(256) void k_cc_init(const I *__restrict__ rp, const
 // low-degree vertices: one lane per vertex; others queued for the wave kernel
 __global__ __launch_bounds__(256) void k_cc_hook_small(const I *__restrict__ rp, const I *__restrict__ col,
                                                        I *parent, int64_t n, I *__restrict__ big_list,
-                                                       RcmDev *__restrict__ dv) {
+                                                       const unsigned *__restrict__ cbits, RcmDev *__restrict__ dv) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; v < n; v += stride) {
+    if ((cbits[v >> 5] >> (v & 31)) & 1u) continue;  // member of the component the first sweep covered
     const I s = rp[v], e = rp[v + 1];
     if (e - s > 16) {
       big_list[atomicAdd(&dv->n_cc_big, 1u)] = (I)v;
@@ -171,7 +179,9 @@ __global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, c
 // label[v] = root; component sizes.  Equal roots are combined inside the wave, and the
 // workgroup's dominant root (the giant component) is accumulated in LDS and flushed
 // once, so the giant's counter word is not hammered by one atomic per wave.
-__global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ csize, int64_t n) {
+__global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ csize, int64_t n,
+                                                     const unsigned *__restrict__ cbits, I first_root,
+                                                     I first_size) {
   __shared__ I s_major;
   __shared__ unsigned s_major_cnt;
   int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,9 +195,13 @@ __global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ 
     const int64_t v = vb + sbx_lane();
     I root = -1;
     if (v < n) {
-      root = parent[v];
-      while (root != parent[root]) root = parent[root];
-      parent[v] = root;
+      if ((cbits[v >> 5] >> (v & 31)) & 1u) {
+        parent[v] = first_root;  // labelled by the first sweep; its size is known
+      } else {
+        root = parent[v];
+        while (root != parent[root]) root = parent[root];
+        parent[v] = root;
+      }
     }
     uint64_t todo = __ballot(root >= 0);
     while (todo) {
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ 
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_major_cnt) atomicAdd(&csize[s_major], (I)s_major_cnt);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && first_size > 0) csize[first_root] = first_size;
 }
 
 // classify components: singletons are final here; small / large roots are listed
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
     if (v < n && !((vbits[v >> 5] >> (v & 31)) & 1u)) {
       s = rp[v];
       e = rp[v + 1];
-      cand = (e > s) && label[v] == comp_label;
+      cand = (e > s) && (label == nullptr || label[v] == comp_label);
     }
     // low-degree candidates: one lane each (64 independent load chains per wave; the
     // rows of consecutive vertices are adjacent in col[], so the lanes share lines)
@@ -1000,7 +1015,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   RcmDev *dv;
   uint32_t *dkey_a, *dkey_b, *did_a, *did_b, *drank;
   I *label, *csize, *cbase, *small_list, *large_list, *big_list, *q, *nf_list;
-  unsigned *dist, *ppos, *vbits, *fbits, *lpos;
+  unsigned *dist, *ppos, *vbits, *fbits, *cbits, *lpos;
+  I *q_small;
   uint64_t *ka, *kb, *heavy;
   SBX_TRY(sbx_salloc(h, 1, &dv));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_a));
@@ -1020,6 +1036,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)n, &ppos));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &vbits));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &fbits));
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &cbits));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &q_small));
   SBX_TRY(sbx_salloc(h, (size_t)n, &lpos));
   SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
@@ -1030,35 +1048,66 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_HIP(h, hipMemsetAsync(ppos, 0xFF, (size_t)n * sizeof(unsigned), h->stream));
 
   const unsigned gn = sbx_grid_for(n, 256, 8192);
-  // (1) connected components; the root of each tree is the component's smallest id
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n);
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list, dv);
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
-                     (const I *)big_list, (const RcmDev *)dv);
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), label, csize, n);
-  SBX_LAUNCH_CHECK(h);
-  SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
-  SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gn), dim3(256), (const I *)label, (const I *)csize,
-                     (const I *)cbase, inv, small_list, large_list, n, dv);
-  // (2) global (degree,id) rank used by the Cuthill-McKee keys
+  const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
+  // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
+  SBX_HIP(h, hipMemsetAsync(&dv->first_vertex, 0xFF, sizeof(unsigned), h->stream));
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(gn), dim3(256), rp, dkey_a, did_a, n, dv);
   SBX_LAUNCH_CHECK(h);
-  RcmDev hd;
-  SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
+  RcmDev hd0;
+  SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
   const uint32_t *dorder;
   {
     sbx_radix_pass passes[16];
-    const int np = sbx_radix_plan(0, sbx_bits_for(hd.max_deg), 0, 0, passes);
+    const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
     int in_b = 0;
     SBX_TRY(sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n, passes, np, &in_b));
     dorder = in_b ? did_b : did_a;
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(gn), dim3(256), dorder, drank, n);
     SBX_LAUNCH_CHECK(h);
   }
+  BfsBuffers b;
+  b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
+  b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
+  b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
+  // (2) The smallest non-isolated vertex v0 is the smallest id of its component, i.e. the
+  // start of that component's pseudo-peripheral search.  Its first BFS sweep is needed
+  // anyway and yields the component's membership for free, so the union-find below only
+  // has to label what that sweep did not reach (for power-law inputs: a sliver).
+  const I v0 = hd0.first_vertex == UNSEEN ? (I)-1 : (I)hd0.first_vertex;
+  BfsResult r0;
+  r0.count = 0;
+  SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));
+  if (v0 >= 0) {
+    SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
+    SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  // (3) connected components of the rest; the root of each tree is the component's smallest id
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list,
+              (const unsigned *)cbits, dv);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
+              (const I *)big_list, (const RcmDev *)dv);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), label, csize, n, (const unsigned *)cbits,
+              v0 >= 0 ? v0 : (I)0, (I)r0.count);
+  SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
+  SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gn), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
+              small_list, large_list, n, dv);
+  SBX_LAUNCH_CHECK(h);
+  RcmDev hd;
+  SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
+  b.label = label;
+  const bool first_is_large = r0.count > (unsigned)RCM_SMALL;
+  if (v0 >= 0 && !first_is_large) {
+    // the pre-swept component is handled by the batched kernel: drop the sweep's marks
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r0.count, 256, 4096)), dim3(256), (const I *)q,
+                r0.count, ppos);
+    SBX_LAUNCH_CHECK(h);
+  }
   // (3) small components: one lane each
   if (hd.n_small) {
     SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_small + 63) / 64), dim3(64), rp, col,
-                       (const I *)small_list, (const I *)csize, (const I *)cbase, dist, q, inv, dv);
+                       (const I *)small_list, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
     SBX_LAUNCH_CHECK(h);
   }
   // (4) large components: host-driven level-synchronous BFS
@@ -1072,18 +1121,27 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       SBX_HIP(h, hipMemcpyAsync(&bases[c], cbase + roots[c], sizeof(I), hipMemcpyDeviceToHost, h->stream));
     }
     SBX_HIP(h, hipStreamSynchronize(h->stream));
-    BfsBuffers b;
-    b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = label;
-    b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
-    b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
+    // the pre-swept component goes first: its sweep state (q, ppos) is still live
+    for (unsigned c = 1; c < hd.n_large; c++)
+      if (first_is_large && roots[c] == v0) {
+        std::swap(roots[c], roots[0]);
+        std::swap(sizes[c], sizes[0]);
+        std::swap(bases[c], bases[0]);
+      }
     for (unsigned c = 0; c < hd.n_large; c++) {
       // pseudo-peripheral search from the component's smallest vertex (:22-81)
       BfsResult r;
       int64_t prev_ecc = -1, ecc = 0, sweeps = 0, levels = 0;
       I fixed = roots[c];
+      bool have_first_sweep = first_is_large && roots[c] == v0;
       while (prev_ecc != ecc) {
         prev_ecc = ecc;
-        SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
+        if (have_first_sweep) {
+          r = r0;  // sweep (2) above was exactly this component's first sweep
+          have_first_sweep = false;
+        } else {
+          SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
+        }
         fixed = -1;  // later sweeps start from the device-resident root
         sweeps++;
         levels += r.levels;
