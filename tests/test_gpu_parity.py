@@ -413,3 +413,75 @@ def test_int64_values_beyond_int32_are_refused(ops):
     with pytest.raises(capi.SbxError) as e:
         ops.csr_rows_sorted(dev(rp), dev(col))
     assert e.value.status == 5  # SBX_ERR_UNSUPPORTED, loudly
+
+
+# ----------------------------------------------------------------------------- degenerate / ragged shapes
+def _check_all_ops(ops, oracle, rp, col, m, seed=0):
+    n, nnz = len(rp) - 1, len(col)
+    g = np.random.default_rng(seed)
+    val = g.integers(-4, 4, nnz).astype(np.int32)
+    drp, dcol, dval = dev(rp), dev(col), dev(val)
+    for asc in (True, False):
+        assert np.array_equal(host(ops.degree_reorder(drp, asc)), oracle.degree_reorder(rp, asc))
+    ro = synth.random_permutation(n, seed + 1) if n else np.zeros(0, np.int32)
+    co = synth.random_permutation(m, seed + 2) if m else np.zeros(0, np.int32)
+    for r, c in ((ro, co), (ro, None), (None, co)):
+        same(ops.permute_csr(n, m, drp, dcol, dval, dev(r), dev(c)), oracle.permute_csr(rp, col, val, r, c))
+    coo = ops.csr_to_coo(n, m, drp, dcol, dval)
+    same(coo, oracle.csr_to_coo(rp, col, val))
+    same(ops.coo_to_csr(n, m, *coo), oracle.coo_to_csr(n, *oracle.csr_to_coo(rp, col, val)))
+    assert ops.csr_rows_sorted(drp, dcol) == oracle.csr_rows_sorted(rp, col)
+    if n == m:
+        # symmetrise the pattern for RCM
+        r_idx = np.repeat(np.arange(n), np.diff(rp))
+        s, d = synth.symmetrize(r_idx, col.astype(np.int64))
+        srp, scol = synth.csr_from_edges(n, s, d) if n else (np.zeros(1, np.int32), np.zeros(0, np.int32))
+        assert np.array_equal(host(ops.rcm_reorder(dev(srp), dev(scol))), oracle.rcm_reorder(srp, scol))
+        if n >= 1 and (n < 16 or n % 16 == 0):
+            deg, key, counts = ops.gray_row_keys(m, dev(srp), dev(scol), 16, 3)
+            wdeg, wkey, wcounts = oracle.gray_row_keys(srp, scol, m, 16, 3)
+            assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+            assert list(counts) == wcounts.tolist()
+
+
+def test_degenerate_shapes(ops, oracle):
+    z = np.zeros(0, np.int32)
+    _check_all_ops(ops, oracle, np.zeros(1, np.int32), z, 0)                       # 0 x 0
+    _check_all_ops(ops, oracle, np.zeros(6, np.int32), z, 5)                       # all rows empty
+    _check_all_ops(ops, oracle, np.array([0, 1], np.int32), np.array([0], np.int32), 1)   # 1 x 1
+    _check_all_ops(ops, oracle, np.array([0, 0, 0, 3, 3], np.int32), np.array([0, 1, 3], np.int32), 4)
+    # one dense row among empty ones; wide rectangular; tall rectangular
+    _check_all_ops(ops, oracle, np.array([0, 0, 3000, 3000], np.int32), np.arange(3000, dtype=np.int32), 3000)
+    rp, col = synth.random_rect_csr(3, 5000, 4000, 1)
+    _check_all_ops(ops, oracle, rp, col, 5000)
+    rp, col = synth.random_rect_csr(5000, 3, 4000, 2, dup_frac=0.5)
+    _check_all_ops(ops, oracle, rp, col, 3)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rcm_many_midsize_components(ops, oracle, seed):
+    # disjoint union of paths, grids, stars and cliques of 65..600 vertices with shuffled ids:
+    # every component takes the host-driven large-component route
+    g = np.random.default_rng(seed)
+    parts, offset = [], 0
+    for k in range(12):
+        kind = (seed + k) % 4
+        if kind == 0:
+            rp, col = synth.path_graph(int(g.integers(65, 400)), shuffle_seed=k)
+        elif kind == 1:
+            rp, col = synth.grid_graph(int(g.integers(8, 20)), int(g.integers(9, 30)), shuffle_seed=k)
+        elif kind == 2:
+            rp, col = synth.star_graph(int(g.integers(70, 300)), centre=3)
+        else:
+            rp, col = synth.clique_graph(int(g.integers(65, 90)))
+        r_idx = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        parts.append((r_idx + offset, col.astype(np.int64) + offset))
+        offset += len(rp) - 1
+    n = offset + 7  # a few isolated vertices at the end
+    relabel = g.permutation(n)
+    src = relabel[np.concatenate([p[0] for p in parts])]
+    dst = relabel[np.concatenate([p[1] for p in parts])]
+    rp, col = synth.csr_from_edges(n, src, dst)
+    got, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
+    assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
+    assert stats["large_components"] >= 10
