@@ -24,8 +24,6 @@
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
-#include <stdlib.h>
-
 namespace {
 
 constexpr int PT_THREADS = 256;
@@ -103,7 +101,7 @@ template <typename I, int VB>
 __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
     const I *__restrict__ col_order, const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, int64_t rb0,
-    PermState *__restrict__ st, int col_bits, int dbg) {
+    PermState *__restrict__ st, int col_bits) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   __shared__ int s_col[PT_CAP];
@@ -181,7 +179,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     }
   }
   __syncthreads();
-  if (dbg == 3) return;
 
   // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
   for (int p = tid; p < cnt; p += PT_THREADS) {
@@ -190,19 +187,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
     const int64_t src = (int64_t)rp_in[u] + (p - s);
     I c = col_in[src];
-    if (col_order && dbg != 1) c = col_order[c];
+    if (col_order) c = col_order[c];
     s_col[p] = (int)c;
     if (HASV) s_val[p] = ((const V *)val_in)[src];
   }
   __syncthreads();
-  if (dbg == 2) {  // diagnostic: write the gathered rows unsorted
-    for (int p = tid; p < cnt; p += PT_THREADS) {
-      col_out[e0 + p] = (I)s_col[p];
-      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
-    }
-    return;
-  }
-
   // classify the tile: rows <= PT_SHORT only -> all-pairs ranking; otherwise one
   // tile-wide stable LSD radix sort on the composite key (local row, column)
   bool unsorted = false, dup = false, has_medium = false;
@@ -584,10 +573,9 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
-    static const int dbg = getenv("SBX_DEBUG_TILE_MODE") ? atoi(getenv("SBX_DEBUG_TILE_MODE")) : 0;
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rp_in, col_in, val_in,
                        old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st,
-                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), dbg);
+                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
     SBX_LAUNCH_CHECK(h);
   }
   if (n_block) {

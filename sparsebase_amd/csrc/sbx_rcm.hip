@@ -31,8 +31,6 @@
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
-#include <stdlib.h>
-
 #include <utility>
 #include <vector>
 
@@ -521,8 +519,7 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
                                                        const unsigned *__restrict__ vbits,
                                                        const unsigned *__restrict__ fbits,
                                                        const unsigned *__restrict__ lpos, unsigned *__restrict__ ppos,
-                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv,
-                                                       int dbg) {
+                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -542,7 +539,7 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
     // low-degree candidates: one lane each (64 independent load chains per wave; the
     // rows of consecutive vertices are adjacent in col[], so the lanes share lines)
     const bool small = cand && (e - s) <= RCM_BU_INLINE;
-    if (dbg != 1 && dbg != 3 && __any(small)) {
+    if (__any(small)) {
       // three unrolled phases keep RCM_BU_INLINE independent loads in flight per lane
       // instead of a 3-deep dependent chain per neighbour
       const int dg = small ? (int)(e - s) : 0;
@@ -565,7 +562,6 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       stage_push((I)v, found, rp, st, nf_list, dv);
     }
     uint64_t todo = __ballot(cand && !small);
-    if (dbg == 1 || dbg == 2) todo = 0;
     while (todo) {
       // the next RCM_VPW candidates, one per 16-lane group
       uint64_t t = todo;
@@ -632,7 +628,8 @@ template <bool CM>
 __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__ key, unsigned nf,
                                                     const uint32_t *__restrict__ dorder, I *__restrict__ q_level,
                                                     unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                                                    unsigned *__restrict__ lpos, RcmDev *__restrict__ dv) {
+                                                    unsigned *__restrict__ lpos, int mark_frontier,
+                                                    RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; j < nf; j += stride) {
@@ -640,8 +637,10 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
     const I v = (I)(CM ? dorder[lo] : lo);
     q_level[j] = v;
     atomicOr(&vbits[v >> 5], 1u << (v & 31));  // this level is now ordered
-    atomicOr(&fbits[v >> 5], 1u << (v & 31));  // ... and is the next frontier
-    lpos[v] = (unsigned)j;
+    if (mark_frontier) {  // only a bottom-up expansion reads the frontier bitmap / positions
+      atomicOr(&fbits[v >> 5], 1u << (v & 31));
+      lpos[v] = (unsigned)j;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     dv->nf = 0;
@@ -658,7 +657,7 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
                                                            const uint32_t *__restrict__ dorder,
                                                            I *__restrict__ q_level, unsigned *__restrict__ vbits,
                                                            unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
-                                                           RcmDev *__restrict__ dv) {
+                                                           int mark_frontier, RcmDev *__restrict__ dv) {
   __shared__ uint64_t s_key[RCM_LDS_SORT];
   unsigned p2 = 1;
   while (p2 < nf) p2 <<= 1;
@@ -692,8 +691,10 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
     const I v = (I)(CM ? dorder[lo] : lo);
     q_level[j] = v;
     atomicOr(&vbits[v >> 5], 1u << (v & 31));
-    atomicOr(&fbits[v >> 5], 1u << (v & 31));
-    lpos[v] = j;
+    if (mark_frontier) {
+      atomicOr(&fbits[v >> 5], 1u << (v & 31));
+      lpos[v] = j;
+    }
   }
   if (threadIdx.x == 0) {
     dv->nf = 0;
@@ -912,7 +913,6 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
-  static const int dbg_bu = getenv("SBX_DEBUG_BU_MODE") ? atoi(getenv("SBX_DEBUG_BU_MODE")) : 0;
   int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
   int64_t frontier_edges = -1;    // degree sum of the current frontier (-1: level 0, read lazily)
   bool try_small = true;  // false right after the small-level kernel declined this very frontier
@@ -940,12 +940,11 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     }
     try_small = true;
     if (!expanded_by_small) {
-    bool bottom_up = false;
-    if (frontier_edges >= 0 && fsize >= 8192) bottom_up = frontier_edges > 4 * remaining;
+    const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && frontier_edges > 4 * remaining;
     if (bottom_up) {
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
-                  b.n, b.dv, dbg_bu);
+                  b.n, b.dv);
     } else {
       const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
       unsigned grid = (waves_needed + 3) / 4;
@@ -967,10 +966,14 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     remaining -= frontier_edges;
     if (remaining < 0) remaining = 0;
     I *q_next = b.q + off + fsize;
-    SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
+    // direction of the NEXT expansion is already decidable: the frontier marks (bitmap +
+    // level positions) are only written when it will be bottom-up
+    const bool next_bottom_up = nf >= 8192 && frontier_edges > 4 * remaining;
+    const int mark_frontier = next_bottom_up ? 1 : 0;
+    if (mark_frontier) SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
     if (nf <= RCM_LDS_SORT) {
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_sort_small<CM>), dim3(1), dim3(1024), (const I *)b.nf_list, nf,
-                  (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.fbits, b.lpos, b.dv);
+                  (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
@@ -981,7 +984,8 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       int in_b = 0;
       SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256),
-                  (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, b.dv);
+                  (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier,
+                  b.dv);
     }
     SBX_LAUNCH_CHECK(h);
     off += fsize;
