@@ -156,6 +156,7 @@ int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes) {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAX_PASSES = 8;
+constexpr int RS_LOOKBACK = 8;  // predecessor status words fetched per look-back round
 
 struct RadixPlan {
   int n;
@@ -273,13 +274,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
       __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t t = (int64_t)tile - 1;; t--) {
-        unsigned long long wv;
-        while (((wv = __hip_atomic_load(state + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &
-                3ull) == 0ull)
-          __builtin_amdgcn_s_sleep(1);
-        before += wv >> 2;
-        if ((wv & 3ull) == 2ull) break;
+      // windowed look-back: fetch up to RS_LOOKBACK predecessor words at once (independent
+      // loads), consume them nearest-first; a word that is not published yet is re-polled
+      int64_t t = (int64_t)tile - 1;
+      bool done = false;
+      while (!done) {
+        unsigned long long wv[RS_LOOKBACK];
+#pragma unroll
+        for (int i = 0; i < RS_LOOKBACK; i++)
+          wv[i] = (t - i >= 0) ? __hip_atomic_load(state + (size_t)(t - i) * 256 + tid, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)
+                               : 2ull;  // before tile 0: an empty inclusive prefix
+        int consumed = 0;
+        bool stall = false;
+#pragma unroll
+        for (int i = 0; i < RS_LOOKBACK; i++) {
+          const bool active = !done && !stall;
+          const unsigned flag = (unsigned)(wv[i] & 3ull);
+          if (active && flag == 0u) {
+            stall = true;  // not published yet: resume the walk at this tile
+          } else if (active) {
+            before += wv[i] >> 2;
+            consumed++;
+            if (flag == 2u) done = true;
+          }
+        }
+        t -= consumed;
+        if (stall) __builtin_amdgcn_s_sleep(1);
       }
       __hip_atomic_store(mine, ((before + tot_valid) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
