@@ -180,11 +180,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
         alg = 16 * nnz_s + 12 * n_s + 8
+        rowwise = None
+        if world == 1:  # the row-wise variant (no column relabel gather, rows stay ordered): a pure gather
+            ops.permute_csr(n_s, n_s, rp_s, col_s, val_s, perm, None, out=out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ops.permute_csr(n_s, n_s, rp_s, col_s, val_s, perm, None, out=out)
+            torch.cuda.synchronize()
+            w1 = time.perf_counter() - t1
+            rowwise = {"workload": "Permute2DRowWise(random order), same matrix", "value": n_s * args.steps / w1 / 1e6,
+                       "unit": "Mrows/s", "ms_per_step": w1 / args.steps * 1e3, "alg_gbs": alg * args.steps / w1 / 1e9,
+                       "frac_of_hbm_peak": alg * args.steps / w1 / 1e9 / HBM_PEAK_GBS}
         permute_apply = {
             "workload": f"Permute2D(random order) of one RMAT scale-{args.scale} CSR, new-row ranges over {world} GPU(s), "
                         "all-gather of row_ptr" if world > 1 else f"Permute2D(random order), RMAT scale-{args.scale}, 1 GPU",
             "scaling": "strong", "value": n_s * args.steps / w / 1e6, "unit": "Mrows/s", "ms_per_step": w / args.steps * 1e3,
             "alg_gbs": alg * args.steps / w / 1e9, "frac_of_hbm_peak": alg * args.steps / w / 1e9 / (HBM_PEAK_GBS * world),
+            "rowwise": rowwise,
         }
 
     # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload

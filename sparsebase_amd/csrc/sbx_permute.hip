@@ -43,6 +43,8 @@ struct PermState {            // device-resident flags/counters of one call
   unsigned n_block;           // rows in (PT_TILE, capacity]: one workgroup each
   unsigned long long long_nnz;
   unsigned long long total;   // nnz of the shard
+  unsigned long_unsorted;     // some row of the global-radix class is out of order
+  unsigned pad2;
 };
 
 template <int VB> struct ValT { typedef uint32_t type; };
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   __shared__ unsigned s_whist[PT_THREADS / 64][256];
   __shared__ unsigned s_scan[PT_THREADS / 64 + 1];
   __shared__ int s_nmed;
+  __shared__ int s_tile_unsorted;
   __shared__ int64_t s_span[2];
   __shared__ int s_wmax[PT_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -124,7 +127,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     if (hi_t - 1 < total) b = sbx_wave_upper_bound<I>(rpo, nr + 1, (I)(hi_t - 1));
     if (tid == 64) s_span[1] = b > nr ? nr : b;
   }
-  if (tid == 0) s_nmed = 0;
+  if (tid == 0) {
+    s_nmed = 0;
+    s_tile_unsorted = 0;
+  }
 #pragma unroll
   for (int k = 0; k < PT_ITEMS; k++) s_row[k * PT_THREADS + tid] = 0;
   __syncthreads();
@@ -201,9 +207,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     if (p > s && s_col[p] < s_col[p - 1]) unsorted = true;
     if (p == s && (int64_t)rpo[r + 1] - (int64_t)rpo[r] > PT_SHORT) has_medium = true;
   }
-  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+  if (__any(unsorted) && lane == 0) {
+    st->any_unsorted = 1;
+    s_tile_unsorted = 1;
+  }
   if (__any(has_medium) && lane == 0) s_nmed = 1;
   __syncthreads();
+  if (s_tile_unsorted == 0) {
+    // every row of the tile is already in column order (row-wise permutes, identity
+    // column maps, orders that preserve locality): a stable sort would not move
+    // anything, so stream the gathered rows out as they are
+    for (int p = tid; p < cnt; p += PT_THREADS) {
+      const int c = s_col[p];
+      if (p && c == s_col[p - 1] && s_row[p] == s_row[p - 1]) dup = true;
+      col_out[e0 + p] = (I)c;
+      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+    }
+    if (__any(dup) && lane == 0) st->any_dup = 1;
+    return;
+  }
   if (s_nmed == 0) {
     for (int p = tid; p < cnt; p += PT_THREADS) {
       const int64_t r = ra + s_row[p];
@@ -376,11 +398,19 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
   __syncthreads();
   bool unsorted = false;
   for (int i = tid + 1; i < len; i += BR_THREADS) unsorted |= s_key[i] < s_key[i - 1];
-  if (__any(unsorted) && lane == 0) st->any_unsorted = 1;
+  if (tid == 0) s_scan[BR_THREADS / 64] = 0;
+  __syncthreads();
+  if (__any(unsorted) && lane == 0) {
+    st->any_unsorted = 1;
+    s_scan[BR_THREADS / 64] = 1;
+  }
+  __syncthreads();
+  const int npass = s_scan[BR_THREADS / 64] ? passes.n : 0;  // an ordered row needs no sort
+  __syncthreads();
 
   volatile unsigned *wh = s_whist[w];
   const uint64_t lt = sbx_lanemask_lt();
-  for (int pass = 0; pass < passes.n; pass++) {
+  for (int pass = 0; pass < npass; pass++) {
     const int shift = passes.shift[pass], bits = passes.bits[pass];
     const unsigned mask = (1u << bits) - 1u;
     for (int i = tid; i < 256 * WAVES; i += BR_THREADS) (&s_whist[0][0])[i] = 0;
@@ -479,7 +509,10 @@ __global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in
       if (VB) ((V *)pay)[o0 + j] = ((const V *)val_in)[src0 + j];
     }
   }
-  if (__any(unsorted) && sbx_lane() == 0) st->any_unsorted = 1;
+  if (__any(unsorted) && sbx_lane() == 0) {
+    st->any_unsorted = 1;
+    st->long_unsorted = 1;
+  }
 }
 
 template <typename I, int VB>
@@ -612,7 +645,9 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
     const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
                                   32 + sbx_bits_for((uint64_t)(n_long - 1)), passes);
     int in_b = 0;
-    SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
+    PermState hs2;  // rows that are already ordered (row-wise permutes) skip the sort
+    SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
+    if (hs2.long_unsorted) SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256),
                        (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
                        (const uint32_t *)loff, long_nnz, col_out, val_out, st);
