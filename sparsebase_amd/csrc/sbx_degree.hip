@@ -24,8 +24,14 @@ __global__ __launch_bounds__(256) void k_degree_keys(const I *__restrict__ rp, u
     id[j] = (uint32_t)u;
     mx = d > mx ? d : mx;
   }
+  __shared__ unsigned s_mx[4];  // one atomic per workgroup: the result word is hot
   mx = sbx_wave_max(mx);
-  if (sbx_lane() == 0 && mx) atomicMax(max_deg, mx);
+  if (sbx_lane() == 0) s_mx[sbx_wave_in_block()] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; i++) mx = s_mx[i] > mx ? s_mx[i] : mx;
+    if (mx) atomicMax(max_deg, mx);
+  }
 }
 
 template <typename I>
@@ -53,7 +59,7 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   SBX_TRY(sbx_salloc(h, (size_t)n, &ib));
   SBX_TRY(sbx_salloc(h, 1, &mx));
   SBX_HIP(h, hipMemsetAsync(mx, 0, sizeof(unsigned), h->stream));
-  const unsigned grid = sbx_grid_for(n, 256, 4096);
+  const unsigned grid = sbx_grid_for(n, 256, 1024);
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<int32_t>, dim3(grid), dim3(256), (const int32_t *)row_ptr, ka, ia, n,
                      mx);
   SBX_LAUNCH_CHECK(h);

@@ -117,3 +117,16 @@ __device__ __forceinline__ int64_t sbx_wave_upper_bound(const T *__restrict__ ar
   }
   return lo;
 }
+
+// Wave-aggregated append: lanes with `want` get consecutive slots from *counter with a
+// single returning atomic per wave (one hot word sustains only ~88 atomics/us on MI355X).
+// All 64 lanes must call it.
+__device__ __forceinline__ unsigned sbx_wave_append(unsigned *counter, bool want) {
+  const uint64_t m = __ballot(want);
+  if (!m) return 0;
+  const int leader = __builtin_ctzll(m);
+  unsigned base = 0;
+  if (sbx_lane() == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+  base = __shfl(base, leader, 64);
+  return base + (unsigned)__popcll(m & sbx_lanemask_lt());
+}

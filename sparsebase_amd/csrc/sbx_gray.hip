@@ -39,14 +39,17 @@ __global__ __launch_bounds__(256) void k_gray_short(const I *__restrict__ rp, co
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
-  for (; i < n; i += stride) {
-    const I s = rp[i], e = rp[i + 1];
+  // wave-uniform trip count so that the aggregated append below sees all 64 lanes
+  for (int64_t ib = i - sbx_lane(); ib < n; ib += stride) {
+    i = ib + sbx_lane();
+    const bool in = i < n;
+    const I s = in ? rp[i] : 0, e = in ? rp[i + 1] : 0;
     const int64_t d = (int64_t)e - (int64_t)s;
-    degree_out[i] = (I)d;
-    if (d > GR_INLINE) {
-      long_list[atomicAdd(n_long, 1u)] = (I)i;
-      continue;
-    }
+    if (in) degree_out[i] = (I)d;
+    const bool is_long = in && d > GR_INLINE;
+    const unsigned slot = sbx_wave_append(n_long, is_long);
+    if (is_long) long_list[slot] = (I)i;
+    if (!in || is_long) continue;
     uint64_t bm = 0;
     unsigned in_band = 0;
     const int64_t thr = (d <= nnz_threshold) ? 0 : d / bits;  // == 0 unless bits < GR_INLINE

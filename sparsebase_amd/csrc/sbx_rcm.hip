@@ -77,11 +77,24 @@ __global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, uint
     mx = d > mx ? d : mx;
     if (d) fv = (unsigned)v < fv ? (unsigned)v : fv;
   }
+  // one pair of atomics per workgroup: the two result words are hot
+  __shared__ unsigned s_mx[4], s_fv[4];
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
-  if (sbx_lane() == 0 && mx) {
-    atomicMax(&dv->max_deg, mx);
-    atomicMin(&dv->first_vertex, fv);
+  if (sbx_lane() == 0) {
+    s_mx[sbx_wave_in_block()] = mx;
+    s_fv[sbx_wave_in_block()] = fv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; i++) {
+      mx = s_mx[i] > mx ? s_mx[i] : mx;
+      fv = s_fv[i] < fv ? s_fv[i] : fv;
+    }
+    if (mx) {
+      atomicMax(&dv->max_deg, mx);
+      atomicMin(&dv->first_vertex, fv);
+    }
   }
 }
 
@@ -141,15 +154,17 @@ __global__ __launch_bounds__(256) void k_cc_init(const I *__restrict__ rp, const
 __global__ __launch_bounds__(256) void k_cc_hook_small(const I *__restrict__ rp, const I *__restrict__ col,
                                                        I *parent, int64_t n, I *__restrict__ big_list,
                                                        const unsigned *__restrict__ cbits, RcmDev *__restrict__ dv) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; v < n; v += stride) {
-    if ((cbits[v >> 5] >> (v & 31)) & 1u) continue;  // member of the component the first sweep covered
-    const I s = rp[v], e = rp[v + 1];
-    if (e - s > 16) {
-      big_list[atomicAdd(&dv->n_cc_big, 1u)] = (I)v;
-      continue;
-    }
+  for (int64_t vb = v0 - sbx_lane(); vb < n; vb += stride) {  // wave-uniform trip count
+    const int64_t v = vb + sbx_lane();
+    // members of the component the first sweep covered are already labelled
+    const bool todo = v < n && !((cbits[v >> 5] >> (v & 31)) & 1u);
+    const I s = todo ? rp[v] : 0, e = todo ? rp[v + 1] : 0;
+    const bool big = todo && (e - s > 16);
+    const unsigned slot = sbx_wave_append(&dv->n_cc_big, big);
+    if (big) big_list[slot] = (I)v;
+    if (!todo || big) continue;
     for (I j = s; j < e; j++) {
       const I u = col[j];
       if (u < (I)v) cc_hook(parent, (I)v, u);
@@ -1055,7 +1070,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
   // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
   SBX_HIP(h, hipMemsetAsync(&dv->first_vertex, 0xFF, sizeof(unsigned), h->stream));
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(gn), dim3(256), rp, dkey_a, did_a, n, dv);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(sbx_grid_for(n, 256, 1024)), dim3(256), rp, dkey_a, did_a, n, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd0;
   SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
