@@ -16,8 +16,6 @@
 
 namespace {
 
-constexpr int GR_INLINE = 16;  // rows up to this length are done by one lane
-
 __device__ __forceinline__ uint64_t gray_decode(uint64_t g) {
   // prefix xor from the top: b = g ^ g>>1 ^ g>>2 ...
   g ^= g >> 1; g ^= g >> 2; g ^= g >> 4; g ^= g >> 8; g ^= g >> 16; g ^= g >> 32;
@@ -28,110 +26,266 @@ struct GrayCounts {
   unsigned long long nnz_sparse, diag_sparse, nnz_dense, diag_dense;
 };
 
-// short rows: one lane per row (threshold is always 0 there because deg < resolution)
-template <typename I>
-__global__ __launch_bounds__(256) void k_gray_short(const I *__restrict__ rp, const I *__restrict__ col, int64_t n,
-                                                    int64_t width, int64_t band, int bits, int nnz_threshold,
-                                                    I *__restrict__ degree_out, uint64_t *__restrict__ key_out,
-                                                    GrayCounts *__restrict__ counts, I *__restrict__ long_list,
-                                                    unsigned *__restrict__ n_long) {
-  __shared__ unsigned long long lds[256 / 64 + 1];
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// The whole stage is nonzero-parallel, so it is balanced under any degree distribution and
+// every col load is a coalesced 32 B/lane read: a workgroup owns GT_TILE consecutive
+// nonzeros, finds the rows under them (row heads scattered into LDS from a per-tile row
+// table), and reduces per row in LDS.  A row owns the LDS words under its own nonzeros:
+// two of them hold the 64-bit OR of column-block bits when its threshold deg/resolution
+// is 0, `resolution` of them hold per-block counts otherwise (then deg >= resolution, so
+// the words exist).  Rows cut by a tile boundary accumulate in a global slot indexed by
+// the tile they start in (at most one such row per tile) and are finished by k_gray_finish.
+constexpr int GT_THREADS = 256;
+constexpr int GT_ITEMS = 8;
+constexpr int GT_TILE = GT_THREADS * GT_ITEMS;  // nonzeros per workgroup
+constexpr int GT_SLACK = 64;                    // words past the tile end / for the row entering from the left
+
+__device__ __forceinline__ bool gray_counted(int64_t d, int bits, int nnz_threshold) {
+  return d > nnz_threshold && d >= bits;  // thr = d / bits > 0
+}
+
+// degree_out, keys of empty rows, and tile_row[t] = last row r with row_ptr[r] <= min(t*GT_TILE, nnz)
+__global__ __launch_bounds__(256) void k_gray_prep(const int32_t *__restrict__ rp, int64_t n, int64_t nnz,
+                                                   int64_t ntiles, int32_t *__restrict__ degree_out,
+                                                   unsigned long long *__restrict__ key_out,
+                                                   int32_t *__restrict__ tile_row) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
-  // wave-uniform trip count so that the aggregated append below sees all 64 lanes
-  for (int64_t ib = i - sbx_lane(); ib < n; ib += stride) {
-    i = ib + sbx_lane();
-    const bool in = i < n;
-    const I s = in ? rp[i] : 0, e = in ? rp[i + 1] : 0;
-    const int64_t d = (int64_t)e - (int64_t)s;
-    if (in) degree_out[i] = (I)d;
-    const bool is_long = in && d > GR_INLINE;
-    const unsigned slot = sbx_wave_append(n_long, is_long);
-    if (is_long) long_list[slot] = (I)i;
-    if (!in || is_long) continue;
-    uint64_t bm = 0;
-    unsigned in_band = 0;
-    const int64_t thr = (d <= nnz_threshold) ? 0 : d / bits;  // == 0 unless bits < GR_INLINE
-    if (thr == 0) {
-      for (I j = s; j < e; j++) {
-        const int64_t c = col[j];
-        bm |= (uint64_t)1 << (c / width);
-        const int64_t dist = c >= i ? c - i : i - c;
-        in_band += dist <= band;
-      }
-    } else {
-      // tiny resolution (m < 16 clamps it): count per block the slow way
-      for (int b = 0; b < bits; b++) {
-        int64_t cnt = 0;
-        for (I j = s; j < e; j++) cnt += ((int64_t)col[j] / width) == b;
-        if (cnt > thr) bm |= (uint64_t)1 << b;
-      }
-      for (I j = s; j < e; j++) {
-        const int64_t c = col[j];
-        const int64_t dist = c >= i ? c - i : i - c;
-        in_band += dist <= band;
-      }
+  const int64_t total = n > ntiles + 1 ? n : ntiles + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (i < n) {
+      const int32_t d = rp[i + 1] - rp[i];
+      degree_out[i] = d;
+      if (d == 0) key_out[i] = 0;
     }
-    key_out[i] = gray_decode(bm);
-    if (d <= nnz_threshold) { c_ns += d; c_ds += in_band; }
-    else { c_nd += d; c_dd += in_band; }
-  }
-  c_ns = sbx_block_sum<unsigned long long, 256>(c_ns, lds);
-  c_ds = sbx_block_sum<unsigned long long, 256>(c_ds, lds);
-  c_nd = sbx_block_sum<unsigned long long, 256>(c_nd, lds);
-  c_dd = sbx_block_sum<unsigned long long, 256>(c_dd, lds);
-  if (threadIdx.x == 0) {
-    if (c_ns) atomicAdd(&counts->nnz_sparse, c_ns);
-    if (c_ds) atomicAdd(&counts->diag_sparse, c_ds);
-    if (c_nd) atomicAdd(&counts->nnz_dense, c_nd);
-    if (c_dd) atomicAdd(&counts->diag_dense, c_dd);
+    if (i <= ntiles) {
+      const int64_t pos = i * GT_TILE < nnz ? i * GT_TILE : nnz;
+      int64_t lo = 0, hi = n;  // last r in [0,n] with rp[r] <= pos
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if ((int64_t)rp[mid] <= pos) lo = mid; else hi = mid - 1;
+      }
+      tile_row[i] = (int32_t)lo;
+    }
   }
 }
 
-// longer rows: one wave per row, coalesced reads, per-wave block counters in LDS
-template <typename I>
-__global__ __launch_bounds__(256) void k_gray_long(const I *__restrict__ rp, const I *__restrict__ col, int64_t n,
-                                                   int64_t width, int64_t band, int bits, int nnz_threshold,
-                                                   uint64_t *__restrict__ key_out, GrayCounts *__restrict__ counts,
-                                                   const I *__restrict__ long_list,
-                                                   const unsigned *__restrict__ n_long) {
-  __shared__ unsigned s_cnt[4][64];
-  const int lane = sbx_lane(), wv = sbx_wave_in_block();
-  const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
-  const int64_t total = *n_long;
-  for (int64_t k = wave; k < total; k += nwaves) {
-    const int64_t i = long_list[k];
-    const I s = rp[i], e = rp[i + 1];
-    const int64_t d = (int64_t)e - (int64_t)s;
-    s_cnt[wv][lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    unsigned in_band = 0;
-    for (int64_t j = (int64_t)s + lane; j < e; j += 64) {
-      const int64_t c = col[j];
-      atomicAdd(&s_cnt[wv][c / width], 1u);
-      const int64_t dist = c >= i ? c - i : i - c;
-      in_band += dist <= band;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int64_t thr = (d <= nnz_threshold) ? 0 : d / bits;
-    const bool set = lane < bits && (int64_t)s_cnt[wv][lane] > thr;
-    const uint64_t bm = __ballot(set);
-    in_band = sbx_wave_sum(in_band);
-    if (lane == 0) {
-      key_out[i] = gray_decode(bm);
-      if (d <= nnz_threshold) { c_ns += d; c_ds += in_band; }
-      else { c_nd += d; c_dd += in_band; }
-    }
-    __builtin_amdgcn_wave_barrier();
+__global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restrict__ rp,
+                                                          const int32_t *__restrict__ col, int64_t nnz,
+                                                          const int32_t *__restrict__ tile_row, uint32_t width,
+                                                          uint32_t magic, uint32_t band, int bits, int nnz_threshold,
+                                                          unsigned long long *__restrict__ key_out,
+                                                          int32_t *__restrict__ fix_row,
+                                                          unsigned *__restrict__ slot_acc,
+                                                          unsigned *__restrict__ tile_counts) {
+  __shared__ unsigned long long s_head[GT_TILE];   // (row - r_lo) << 32 | degree at the row's first nonzero
+  __shared__ unsigned s_acc[GT_TILE + 2 * GT_SLACK];
+  __shared__ int s_wmax[GT_THREADS / 64];
+  __shared__ unsigned long long s_red[GT_THREADS / 64][4];
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * GT_TILE;
+  const int64_t t1 = (t0 + GT_TILE < nnz) ? t0 + GT_TILE : nnz;
+  const int cnt = (int)(t1 - t0);
+#pragma unroll
+  for (int k = 0; k < GT_ITEMS; k++) {
+    s_head[k * GT_THREADS + tid] = 0;
+    s_acc[k * GT_THREADS + tid] = 0;
   }
-  if (lane == 0) {
-    if (c_ns) atomicAdd(&counts->nnz_sparse, c_ns);
-    if (c_ds) atomicAdd(&counts->diag_sparse, c_ds);
-    if (c_nd) atomicAdd(&counts->nnz_dense, c_nd);
-    if (c_dd) atomicAdd(&counts->diag_dense, c_dd);
+  if (tid < 2 * GT_SLACK) s_acc[GT_TILE + tid] = 0;
+  const int64_t r_lo = tile_row[blockIdx.x], r_end = tile_row[blockIdx.x + 1];
+  const int64_t lo_start = rp[r_lo];
+  const int lo_deg = (int)(rp[r_lo + 1] - lo_start);
+  // this thread's nonzeros: GT_ITEMS consecutive ones
+  const int p0 = tid * GT_ITEMS;
+  int32_t c[GT_ITEMS];
+  if (p0 + GT_ITEMS <= cnt && ((uintptr_t)col & 15) == 0) {
+    const int4 *src = (const int4 *)(col + t0 + p0);
+    const int4 a = src[0], b = src[1];
+    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < GT_ITEMS; k++) c[k] = (p0 + k < cnt) ? col[t0 + p0 + k] : 0;
+  }
+  __syncthreads();
+  if (r_end - r_lo <= 4 * GT_TILE) {
+    for (int64_t r = r_lo + 1 + tid; r <= r_end; r += GT_THREADS) {
+      const int64_t s = rp[r];
+      const int64_t p = s - t0;
+      if (p < cnt)  // empty rows share the position of the next non-empty one, which has the largest id
+        atomicMax(&s_head[p], ((unsigned long long)(r - r_lo) << 32) | (unsigned)(rp[r + 1] - s));
+    }
+  } else {
+    // mostly empty rows: a position is a head iff the last row with row_ptr <= pos starts exactly there
+    for (int k = 0; k < GT_ITEMS; k++) {
+      const int p = p0 + k;
+      if (p >= cnt || p == 0) continue;
+      int64_t lo = r_lo, hi = r_end;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if ((int64_t)rp[mid] <= t0 + p) lo = mid; else hi = mid - 1;
+      }
+      if ((int64_t)rp[lo] == t0 + p && lo > r_lo)
+        s_head[p] = ((unsigned long long)(lo - r_lo) << 32) | (unsigned)(rp[lo + 1] - rp[lo]);
+    }
+  }
+  __syncthreads();
+  // which row is open when this thread starts: position+1 of the last head before p0 (0: r_lo)
+  unsigned long long hd[GT_ITEMS];
+  int last = 0;
+  unsigned headmask = 0;
+#pragma unroll
+  for (int k = 0; k < GT_ITEMS; k++) {
+    hd[k] = s_head[p0 + k];
+    if (hd[k]) {
+      last = p0 + k + 1;
+      headmask |= 1u << k;
+    }
+  }
+  const int inc = sbx_wave_inclusive_max(last);
+  int open = __shfl_up(inc, 1, 64);
+  if (sbx_lane() == 0) open = 0;
+  if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
+  __syncthreads();
+  for (int w = 0; w < (tid >> 6); w++) open = s_wmax[w] > open ? s_wmax[w] : open;
+  int row = (int)r_lo;
+  int d = lo_deg, base = GT_TILE + GT_SLACK;
+  if (open) {
+    const unsigned long long hv = s_head[open - 1];
+    row = (int)r_lo + (int)(hv >> 32);
+    d = (int)(unsigned)hv;
+    base = open - 1;
+  }
+  // The loop is written select-style (the 8 steps are unrolled and every branch that is
+  // left costs the whole wave): ~20 VALU ops per nonzero is what 8 TB/s allows.
+  unsigned long long acc = 0;
+  unsigned ns = 0, ds = 0, dd = 0, nvalid = 0;
+  unsigned run = 0, prev = 0xFFFFFFFFu;
+#pragma unroll
+  for (int k = 0; k < GT_ITEMS; k++) {
+    if (p0 + k >= cnt) break;
+    nvalid++;
+    const bool hk = hd[k] != 0;
+    if (hk) {
+      row = (int)r_lo + (int)(hd[k] >> 32);
+      d = (int)(unsigned)hd[k];
+      base = p0 + k;
+    }
+    const bool counted = d > nnz_threshold && d >= bits;
+    const bool closes = (k == GT_ITEMS - 1) || (p0 + k + 1 >= cnt) || (k + 1 < GT_ITEMS && hd[k + 1 < GT_ITEMS ? k + 1 : k] != 0);
+    unsigned bkt = __umulhi((unsigned)c[k], magic);  // c / width, one short at most
+    bkt += ((unsigned)c[k] - bkt * width) >= width;
+    const int diff = c[k] - row;
+    const bool inb = (unsigned)(diff < 0 ? -diff : diff) <= band;
+    const bool sparse = d <= nnz_threshold;
+    ns += sparse;
+    ds += sparse && inb;
+    dd += !sparse && inb;
+    const unsigned long long bit = 1ull << bkt;
+    acc = hk ? bit : (acc | bit);
+    const bool same = !hk && bkt == prev;
+    run = same ? run + 1 : 1;
+    prev = bkt;
+    if (counted) {
+      // sorted rows give long runs of one block: one LDS atomic per run
+      bool flush = closes;
+      if (!closes) {
+        unsigned nb = __umulhi((unsigned)c[k + 1 < GT_ITEMS ? k + 1 : k], magic);
+        nb += ((unsigned)c[k + 1 < GT_ITEMS ? k + 1 : k] - nb * width) >= width;
+        flush = nb != bkt;
+      }
+      if (flush) {
+        atomicAdd(&s_acc[base + bkt], run);
+        prev = 0xFFFFFFFFu;
+      }
+    } else if (closes) {
+      if (d == 1) key_out[row] = gray_decode(acc);
+      else {
+        atomicOr(&s_acc[base], (unsigned)acc);
+        if (bits > 32) atomicOr(&s_acc[base + 1], (unsigned)(acc >> 32));
+      }
+    }
+  }
+  unsigned long long c_ns = ns, c_ds = ds, c_nd = nvalid - ns, c_dd = dd;
+  __syncthreads();
+  // finish the rows whose head this thread owns; thread 0 also the row entering from the left
+  auto finish_row = [&](int64_t r, int rd, int rb, bool starts, bool ends) {
+    const bool rc = gray_counted(rd, bits, nnz_threshold);
+    if (!rc && rd == 1) return;  // written where its nonzero was read
+    if (starts && ends) {
+      unsigned long long key = 0;
+      if (rc) {
+        const unsigned thr = (unsigned)(rd / bits);
+        for (int b = 0; b < bits; b++) key |= (unsigned long long)(s_acc[rb + b] > thr) << b;
+      } else {
+        key = (unsigned long long)s_acc[rb] | ((unsigned long long)s_acc[rb + 1] << 32);
+      }
+      key_out[r] = gray_decode(key);
+    } else {
+      unsigned *slot = slot_acc + (size_t)(starts ? (int64_t)blockIdx.x : lo_start / GT_TILE) * 64;
+      if (rc) {
+        for (int b = 0; b < bits; b++) {
+          const unsigned v = s_acc[rb + b];
+          if (v) atomicAdd(&slot[b], v);
+        }
+      } else {
+        if (s_acc[rb]) atomicOr(&slot[0], s_acc[rb]);
+        if (s_acc[rb + 1]) atomicOr(&slot[1], s_acc[rb + 1]);
+      }
+      if (starts) fix_row[blockIdx.x] = (int32_t)r;
+    }
+  };
+  if (tid == 0) finish_row(r_lo, lo_deg, GT_TILE + GT_SLACK, lo_start >= t0, lo_start + lo_deg <= t1);
+  while (headmask) {
+    const int k = __builtin_ctz(headmask);
+    headmask &= headmask - 1;
+    const unsigned long long hv = s_head[p0 + k];
+    finish_row(r_lo + (int64_t)(hv >> 32), (int)(unsigned)hv, p0 + k, true, p0 + k + (int)(unsigned)hv <= cnt);
+  }
+  c_ns = sbx_wave_sum(c_ns); c_ds = sbx_wave_sum(c_ds); c_nd = sbx_wave_sum(c_nd); c_dd = sbx_wave_sum(c_dd);
+  if (sbx_lane() == 0) {
+    s_red[tid >> 6][0] = c_ns; s_red[tid >> 6][1] = c_ds; s_red[tid >> 6][2] = c_nd; s_red[tid >> 6][3] = c_dd;
+  }
+  __syncthreads();
+  // four hot counter words would serialize ~50 K workgroups: per-tile partials, summed by k_gray_finish
+  if (tid < 4) {
+    unsigned t = 0;
+    for (int w = 0; w < GT_THREADS / 64; w++) t += (unsigned)s_red[w][tid];
+    tile_counts[(size_t)blockIdx.x * 4 + tid] = t;
+  }
+}
+
+// rows cut by a tile boundary: key from the slot of the tile they start in; band counters summed
+__global__ __launch_bounds__(256) void k_gray_finish(const int32_t *__restrict__ rp, int bits, int nnz_threshold,
+                                                     const int32_t *__restrict__ fix_row,
+                                                     const unsigned *__restrict__ slot_acc,
+                                                     const unsigned *__restrict__ tile_counts, int64_t ntiles,
+                                                     unsigned long long *__restrict__ key_out,
+                                                     GrayCounts *__restrict__ counts) {
+  __shared__ unsigned long long s_red[4][4];
+  unsigned long long part[4] = {0, 0, 0, 0};
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 tc = *(const uint4 *)(tile_counts + (size_t)t * 4);
+    part[0] += tc.x; part[1] += tc.y; part[2] += tc.z; part[3] += tc.w;
+    const int32_t r = fix_row[t];
+    if (r < 0) continue;
+    const int64_t d = (int64_t)rp[r + 1] - (int64_t)rp[r];
+    const unsigned *slot = slot_acc + (size_t)t * 64;
+    unsigned long long key = 0;
+    if (gray_counted(d, bits, nnz_threshold)) {
+      const unsigned thr = (unsigned)(d / bits);
+      for (int b = 0; b < bits; b++) key |= (unsigned long long)(slot[b] > thr) << b;
+    } else {
+      key = (unsigned long long)slot[0] | ((unsigned long long)slot[1] << 32);
+    }
+    key_out[r] = gray_decode(key);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const unsigned long long v = sbx_wave_sum(part[q]);
+    if (sbx_lane() == 0) s_red[threadIdx.x >> 6][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (t) atomicAdd(&counts->nnz_sparse + threadIdx.x, t);
   }
 }
 
@@ -158,23 +312,35 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   counts_host[0] = counts_host[1] = counts_host[2] = counts_host[3] = 0;
   if (n == 0) return SBX_OK;
   GrayCounts *cnt = nullptr;
-  int32_t *long_list = nullptr;
-  unsigned *n_long = nullptr;
-  SBX_TRY(sbx_salloc(h, 2, &cnt));  // second slot holds the long-row counter
-  n_long = (unsigned *)(cnt + 1);
-  {
-    int64_t cap = nnz / (GR_INLINE + 1) + 1;
-    if (cap > n) cap = n;
-    SBX_TRY(sbx_salloc(h, (size_t)cap, &long_list));
-  }
-  SBX_HIP(h, hipMemsetAsync(cnt, 0, 2 * sizeof(GrayCounts), h->stream));
+  SBX_TRY(sbx_salloc(h, 1, &cnt));
+  SBX_HIP(h, hipMemsetAsync(cnt, 0, sizeof(GrayCounts), h->stream));
   const int64_t band = m / 128;  // :138
-  SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_short<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
-                     (const int32_t *)row_ptr, (const int32_t *)col, n, width, band, bits, nnz_threshold,
-                     (int32_t *)degree_out, key_out, cnt, long_list, n_long);
-  SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long<int32_t>, dim3(sbx_grid_for(n, 4, (int64_t)h->num_cus * 8)), dim3(256),
-                     (const int32_t *)row_ptr, (const int32_t *)col, n, width, band, bits, nnz_threshold, key_out, cnt,
-                     (const int32_t *)long_list, (const unsigned *)n_long);
+  // c / width = umulhi(c, magic) or that + 1 (c < 2^31): magic = floor(2^32 / width), saturated for width 1
+  const uint64_t mg = ((uint64_t)1 << 32) / (uint64_t)width;
+  const uint32_t magic = mg > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mg;
+  const int64_t ntiles = (nnz + GT_TILE - 1) / GT_TILE;
+  int32_t *fix_row = nullptr, *tile_row = nullptr;
+  unsigned *slot_acc = nullptr;
+  SBX_TRY(sbx_salloc(h, ntiles + 1, &fix_row));
+  SBX_TRY(sbx_salloc(h, ntiles + 1, &tile_row));
+  SBX_TRY(sbx_salloc(h, (ntiles + 1) * 64, &slot_acc));
+  unsigned *tile_counts = nullptr;
+  SBX_TRY(sbx_salloc(h, (ntiles + 1) * 4, &tile_counts));
+  SBX_HIP(h, hipMemsetAsync(fix_row, 0xFF, (size_t)(ntiles + 1) * sizeof(int32_t), h->stream));
+  SBX_HIP(h, hipMemsetAsync(slot_acc, 0, (size_t)(ntiles + 1) * 64 * sizeof(unsigned), h->stream));
+  const int32_t *rp = (const int32_t *)row_ptr, *cl = (const int32_t *)col;
+  unsigned long long *keys = (unsigned long long *)key_out;
+  const int64_t prep_items = n > ntiles + 1 ? n : ntiles + 1;
+  SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_prep, dim3(sbx_grid_for(prep_items, 256, (int64_t)h->num_cus * 16)), dim3(256),
+              rp, n, nnz, ntiles, (int32_t *)degree_out, keys, tile_row);
+  if (ntiles > 0) {
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_tile, dim3((unsigned)ntiles), dim3(GT_THREADS), rp, cl, nnz,
+                (const int32_t *)tile_row, (uint32_t)width, magic, (uint32_t)band, bits, nnz_threshold, keys, fix_row,
+                slot_acc, tile_counts);
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_finish, dim3(sbx_grid_for(ntiles, 256, (int64_t)h->num_cus)), dim3(256),
+                rp, bits, nnz_threshold, (const int32_t *)fix_row, (const unsigned *)slot_acc,
+                (const unsigned *)tile_counts, ntiles, keys, cnt);
+  }
   SBX_LAUNCH_CHECK(h);
   GrayCounts hc;
   SBX_TRY(sbx_readback(h, &hc, cnt, sizeof(GrayCounts)));
