@@ -124,10 +124,13 @@ def main():
     # ---- dominant kernel + roofline (live HIP events recorded by the library on its stream)
     roofline = None
     if prof:
-        per_step = {k: (ms / args.steps, cnt / args.steps) for k, (ms, cnt) in prof.items()}
+        per_step = {k: (ms / args.steps, cnt / args.steps) for k, (ms, cnt, _) in prof.items()}
+        declared = {k: nb / args.steps for k, (_, _, nb) in prof.items() if nb}
         dom = max(per_step, key=lambda k: per_step[k][0])
         ms_step, launches_step = per_step[dom]
         alg = kernel_alg_bytes(dom, n, nnz, stats, launches_step)
+        if alg is None:
+            alg = declared.get(dom)   # groups whose record counts only the library knows (radix passes)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):

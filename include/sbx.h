@@ -93,6 +93,9 @@ int sbx_profile_enable(sbx_handle_t h, int on);
 int sbx_profile_kernel_count(void);
 const char *sbx_profile_kernel_name(int index);
 int sbx_profile_query(sbx_handle_t h, int index, double *total_ms_host, int64_t *launches_host);
+/* algorithmic bytes the launch sites of group `index` declared while profiling was on (0 if the
+ * group declares none): what the kernel has to move, not what it did move. */
+int sbx_profile_query_bytes(sbx_handle_t h, int index, int64_t *alg_bytes_host);
 
 int sbx_malloc(sbx_handle_t h, size_t bytes, void **dev_ptr_host);
 int sbx_free(sbx_handle_t h, void *dev_ptr);

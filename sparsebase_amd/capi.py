@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sbx_profile_kernel_count": ([], _int),
     "sbx_profile_kernel_name": ([_int], C.c_char_p),
     "sbx_profile_query": ([_H, _int, C.POINTER(C.c_double), C.POINTER(_i64)], _int),
+    "sbx_profile_query_bytes": ([_H, _int, C.POINTER(_i64)], _int),
     "sbx_malloc": ([_H, _sz, C.POINTER(_vp)], _int),
     "sbx_free": ([_H, _vp], _int),
     "sbx_memcpy_h2d": ([_H, _vp, _vp, _sz], _int),

@@ -79,6 +79,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   for (int i = 0; i < SBX_K_COUNT; i++) {
     h->prof_ms[i] = 0.0;
     h->prof_launches[i] = 0;
+    h->prof_bytes[i] = 0;
   }
   if (hipSetDevice(device) != hipSuccess) {
     delete h;
@@ -305,6 +306,8 @@ extern "C" int sbx_profile_enable(sbx_handle_t h, int on) {
     for (int i = 0; i < SBX_K_COUNT; i++) {
       h->prof_ms[i] = 0.0;
       h->prof_launches[i] = 0;
+      h->prof_bytes[i] = 0;
+    h->prof_bytes[i] = 0;
     }
   }
   h->prof_on = on != 0;
@@ -323,5 +326,11 @@ extern "C" int sbx_profile_query(sbx_handle_t h, int index, double *total_ms_hos
   prof_drain(h);
   *total_ms_host = h->prof_ms[index];
   *launches_host = h->prof_launches[index];
+  return SBX_OK;
+}
+
+extern "C" int sbx_profile_query_bytes(sbx_handle_t h, int index, int64_t *alg_bytes_host) {
+  if (!h || index < 0 || index >= SBX_K_COUNT || !alg_bytes_host) return SBX_ERR_BAD_ARG;
+  *alg_bytes_host = (int64_t)h->prof_bytes[index];
   return SBX_OK;
 }

@@ -71,6 +71,7 @@ struct sbx_handle_s {
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[SBX_K_COUNT];
   long long prof_launches[SBX_K_COUNT];
+  long long prof_bytes[SBX_K_COUNT];  // algorithmic bytes declared by the launch sites (sbx_prof_bytes)
   char err[512];
 };
 
@@ -83,6 +84,12 @@ void sbx_prof_end(sbx_handle_t h);
     if ((h)->prof_on) sbx_prof_begin((h), (kid));                            \
     hipLaunchKernelGGL(kernel, grid, block, 0, (h)->stream, __VA_ARGS__);    \
     if ((h)->prof_on) sbx_prof_end((h));                                     \
+  } while (0)
+
+// algorithmic bytes of the launches just issued for kernel group `kid` (profiling runs only)
+#define SBX_PROF_BYTES(h, kid, bytes)                          \
+  do {                                                         \
+    if ((h)->prof_on) (h)->prof_bytes[(kid)] += (long long)(bytes); \
   } while (0)
 
 #define SBX_FAIL(h, code, ...)                       \

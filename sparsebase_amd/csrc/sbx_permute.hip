@@ -97,6 +97,147 @@ __global__ void k_store_total(const I *__restrict__ rpo, int64_t nr, PermState *
   st->total = (unsigned long long)rpo[nr];
 }
 
+// ---- row-wise permute: no column relabel, so rows keep their internal order and the
+// permute is a segmented copy.  One workgroup per PC_TILE output nonzeros: row heads of
+// the tile are scattered into LDS with their (source - destination) offset, a max-scan
+// gives every position its offset, then a strided pass copies col/val (reads coalesced
+// per row piece, writes fully coalesced) and checks the order inside rows.  If any row
+// turns out unsorted (possible only for inputs that never went through a CSR
+// constructor) the caller discards the result and runs the sorting pipeline.
+// (row length, source offset) in new-row order for rows [rb0, rb0+nr), written from the
+// old-row side (sequential reads, one 8-byte scatter per row) so no inverse permutation is needed
+template <typename I>
+__global__ __launch_bounds__(256) void k_rowwise_prep(const I *__restrict__ rp, const I *__restrict__ row_order,
+                                                      int64_t n, int64_t rb0, int64_t nr, int2 *__restrict__ rec) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; u < n; u += stride) {
+    const int64_t r = (row_order ? (int64_t)row_order[u] : u) - rb0;
+    if (r < 0 || r >= nr) continue;
+    const I s = rp[u];
+    rec[r] = make_int2((int)(rp[u + 1] - s), (int)s);
+  }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_rowwise_lengths(const int2 *__restrict__ rec, int64_t nr, I *__restrict__ deg_out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r <= nr; r += stride) deg_out[r] = r < nr ? (I)rec[r].x : (I)0;
+}
+
+// tile_row[t] = last row r with rpo[r] <= min(t * tile, total)
+template <typename I>
+__global__ __launch_bounds__(256) void k_tile_rows(const I *__restrict__ rpo, int64_t nr, int64_t total, int tile,
+                                                   int64_t ntiles, I *__restrict__ tile_row) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  const int64_t pos = t * tile < total ? t * tile : total;
+  int64_t lo = 0, hi = nr;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if ((int64_t)rpo[mid] <= pos) lo = mid; else hi = mid - 1;
+  }
+  tile_row[t] = (I)lo;
+}
+
+constexpr int PC_THREADS = 256;
+constexpr int PC_ITEMS = 8;
+constexpr int PC_TILE = PC_THREADS * PC_ITEMS;
+
+template <typename I, int VB>
+__global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restrict__ rec, const I *__restrict__ tile_row,
+                                                             const I *__restrict__ col_in,
+                                                             const char *__restrict__ val_in,
+                                                             const I *__restrict__ rpo, I *__restrict__ col_out,
+                                                             char *__restrict__ val_out, int64_t nr, int64_t total,
+                                                             PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  __shared__ unsigned long long s_head[PC_TILE];  // (row - r_lo) << 32 | (source - destination) at the row's first nonzero
+  __shared__ int s_delta[PC_TILE];
+  __shared__ int s_col[PC_TILE];
+  __shared__ int s_wmax[PC_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * PC_TILE;
+  const int64_t t1 = t0 + PC_TILE < total ? t0 + PC_TILE : total;
+  const int cnt = (int)(t1 - t0);
+#pragma unroll
+  for (int k = 0; k < PC_ITEMS; k++) s_head[k * PC_THREADS + tid] = 0;
+  // rows under the tile: r_lo owns position 0; rows up to r_hi may start inside (r_hi itself at t1: skipped)
+  const int64_t r_lo = tile_row[blockIdx.x], r_hi = tile_row[blockIdx.x + 1];
+  __syncthreads();
+  const int64_t lo_start = rpo[r_lo];
+  const int delta_lo = (int)((int64_t)rec[r_lo].y - lo_start);
+  if (r_hi - r_lo <= 4 * PC_TILE) {
+    for (int64_t r = r_lo + 1 + tid; r <= r_hi; r += PC_THREADS) {
+      const int64_t s = rpo[r];
+      if (s >= t1) continue;
+      const int delta = (int)((int64_t)rec[r].y - s);
+      // empty rows share the position of the next non-empty one, which has the largest id
+      atomicMax(&s_head[s - t0], ((unsigned long long)(r - r_lo) << 32) | (unsigned)delta);
+    }
+  } else {
+    for (int k = 0; k < PC_ITEMS; k++) {
+      const int p = tid * PC_ITEMS + k;
+      if (p >= cnt || p == 0) continue;
+      int64_t lo = r_lo, hi = r_hi;  // last row with rpo[r] <= t0 + p
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if ((int64_t)rpo[mid] <= t0 + p) lo = mid; else hi = mid - 1;
+      }
+      if ((int64_t)rpo[lo] == t0 + p && lo > r_lo)
+        s_head[p] = ((unsigned long long)(lo - r_lo) << 32) | (unsigned)(int)((int64_t)rec[lo].y - (t0 + p));
+    }
+  }
+  __syncthreads();
+  {  // every position gets the offset of the row it belongs to
+    const int p0 = tid * PC_ITEMS;
+    unsigned long long hd[PC_ITEMS];
+    int last = 0;
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++) {
+      hd[k] = s_head[p0 + k];
+      if (hd[k]) last = p0 + k + 1;
+    }
+    const int inc = sbx_wave_inclusive_max(last);
+    int open = __shfl_up(inc, 1, 64);
+    if (sbx_lane() == 0) open = 0;
+    if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); w++) open = s_wmax[w] > open ? s_wmax[w] : open;
+    int delta = open ? (int)(unsigned)s_head[open - 1] : delta_lo;
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++) {
+      if (hd[k]) delta = (int)(unsigned)hd[k];
+      s_delta[p0 + k] = delta;
+    }
+  }
+  __syncthreads();
+  int c[PC_ITEMS];
+#pragma unroll
+  for (int k = 0; k < PC_ITEMS; k++) {
+    const int p = k * PC_THREADS + tid;
+    if (p < cnt) {
+      const int64_t src = t0 + p + s_delta[p];
+      c[k] = col_in[src];
+      col_out[t0 + p] = c[k];
+      if (VB) ((V *)val_out)[t0 + p] = ((const V *)val_in)[src];
+      s_col[p] = c[k];
+    }
+  }
+  __syncthreads();
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < PC_ITEMS; k++) {
+    const int p = k * PC_THREADS + tid;
+    if (p < cnt && s_head[p] == 0) {
+      if (p > 0) bad |= s_col[p - 1] > c[k];
+      else if (lo_start < t0) bad |= col_in[t0 + delta_lo - 1] > c[k];  // the row began in the previous tile
+    }
+  }
+  if (__any(bad) && sbx_lane() == 0) st->any_unsorted = 1;
+}
+
 // ---- the tile kernel ----------------------------------------------------------
 // IDENT: csr_sort_rows mode (no row/col maps, input == output arrays allowed).
 template <typename I, int VB>
@@ -726,6 +867,48 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   PermState *st = nullptr;
   I *old_of_new = nullptr, *long_rows = nullptr, *block_rows = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
+  if (!col_order) {
+    // row-wise: a segmented copy; sorted input rows (every CSR that went through a constructor) end here
+    int2 *rec = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
+    SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
+                (const I *)row_order, n, row_begin, nr, rec);
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_lengths<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
+                (const int2 *)rec, nr, rpo);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
+    int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
+    if (nr != n) {
+      int32_t t32 = 0;
+      SBX_TRY(sbx_readback(h, &t32, rpo + nr, sizeof(int32_t)));
+      total = t32;
+    }
+    if (shard_nnz_host) *shard_nnz_host = total;
+    if (total > out_capacity)
+      SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
+               (long long)out_capacity);
+    if (total == 0) return SBX_OK;
+    const unsigned tiles = (unsigned)((total + PC_TILE - 1) / PC_TILE);
+    I *tile_row = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_row));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_rows<I>, dim3(tiles / 256 + 1), dim3(256), (const I *)rpo, nr, total,
+                PC_TILE, (int64_t)tiles, tile_row);
+#define COPY(VBX)                                                                                              \
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_copy<I, VBX>), dim3(tiles), dim3(PC_THREADS), (const int2 *)rec, \
+              (const I *)tile_row, (const I *)col, (const char *)val, (const I *)rpo, (I *)col_out, (char *)val_out, \
+              nr, total, st)
+    if (vb == 0) COPY(0);
+    else if (vb == 4) COPY(4);
+    else COPY(8);
+#undef COPY
+    SBX_LAUNCH_CHECK(h);
+    SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, total * (int64_t)(2 * (sizeof(I) + vb)));
+    PermState hc;
+    SBX_TRY(sbx_readback(h, &hc, st, sizeof(PermState)));
+    if (!hc.any_unsorted) return SBX_OK;
+    // some input row is out of order: redo with the sorting pipeline below
+  }
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   {
     int64_t cap_long = nnz / PT_TILE + 1;

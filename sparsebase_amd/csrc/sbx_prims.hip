@@ -360,12 +360,15 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>), dim3(sbx_grid_for(count, RS_THREADS * 8, (int64_t)h->num_cus * 8)),
               dim3(RS_THREADS), (const K *)ka, count, plan, ghist);
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, k_onesweep_bins, dim3(1), dim3(RS_THREADS), ghist, np);
+  SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
   for (int p = 0; p < np; p++) {
     SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P>), dim3((unsigned)tiles), dim3(RS_THREADS),
                 (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
                 (const unsigned long long *)(ghist + (size_t)p * 256), state + (size_t)p * tiles * 256, tickets + p);
+    // a pass reads and writes every (key, payload) record once
+    SBX_PROF_BYTES(h, SBX_K_RADIX_SCATTER, 2 * count * (int64_t)(sizeof(K) + (HAS_P ? sizeof(P) : 0)));
     SBX_LAUNCH_CHECK(h);
     K *tk = src_k; src_k = dst_k; dst_k = tk;
     P *tv = src_v; src_v = dst_v; dst_v = tv;

@@ -367,11 +367,6 @@ struct WaveStage {
   unsigned long long deg;  // per-lane: degrees of the vertices this lane appended
 };
 
-__device__ __forceinline__ void stage_finish(WaveStage &st, RcmDev *__restrict__ dv) {
-  const unsigned long long d = sbx_wave_sum(st.deg);
-  if (sbx_lane() == 0 && d) atomicAdd(&dv->fedges, d);
-}
-
 __device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
   if (st.cnt == 0) return;
   unsigned base = 0;
@@ -380,6 +375,42 @@ __device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_li
   __builtin_amdgcn_wave_barrier();
   for (unsigned i = sbx_lane(); i < st.cnt; i += 64) nf_list[base + i] = st.buf[i];
   __builtin_amdgcn_wave_barrier();
+  st.cnt = 0;
+}
+
+// Kernel epilogue for a 256-thread workgroup: what is still staged is appended with one
+// returning atomic per workgroup, and the degree / edge counters get one atomic each
+// (8192 waves x 3 atomics on one cache line cost more than a small level's expansion).
+// `scanned` is a per-lane partial.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void stage_end_block(WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv,
+                                                unsigned long long scanned, bool bottom_up) {
+  __shared__ unsigned s_cnt[4];
+  __shared__ unsigned long long s_deg[4], s_scan[4];
+  __shared__ unsigned s_base;
+  const int w = sbx_wave_in_block();
+  const unsigned long long d = sbx_wave_sum(st.deg);
+  scanned = sbx_wave_sum(scanned);
+  if (sbx_lane() == 0) {
+    s_cnt[w] = st.cnt;
+    s_deg[w] = d;
+    s_scan[w] = scanned;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const unsigned long long dsum = s_deg[0] + s_deg[1] + s_deg[2] + s_deg[3];
+    const unsigned long long ssum = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    s_base = tot ? atomicAdd(&dv->nf, tot) : 0u;
+    if (dsum) atomicAdd(&dv->fedges, dsum);
+    if (ssum) {
+      atomicAdd(&dv->edges, ssum);
+      if (bottom_up) atomicAdd(&dv->edges_bu, ssum);
+    }
+  }
+  __syncthreads();
+  unsigned base = s_base;
+  for (int q = 0; q < w; q++) base += s_cnt[q];
+  for (unsigned i = sbx_lane(); i < st.cnt; i += 64) nf_list[base + i] = st.buf[i];
   st.cnt = 0;
 }
 
@@ -482,10 +513,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
       j += 4 * RCM_GROUP;
     }
   }
-  stage_flush(st, nf_list, dv);
-  stage_finish(st, dv);
-  scanned = sbx_wave_sum(scanned);
-  if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
+  stage_end_block(st, nf_list, dv, scanned, false);
 }
 
 __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
@@ -518,9 +546,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
     }
     scanned += (unsigned long long)(ce - cs);
   }
-  stage_flush(st, nf_list, dv);
-  stage_finish(st, dv);
-  if (threadIdx.x == 0 && scanned) atomicAdd(&dv->edges, scanned);
+  stage_end_block(st, nf_list, dv, threadIdx.x == 0 ? scanned : 0ull, false);
 }
 
 // Bottom-up expansion (direction-optimising BFS): instead of the frontier pushing along
@@ -618,13 +644,7 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       stage_push(nv, found, rp, st, nf_list, dv);
     }
   }
-  stage_flush(st, nf_list, dv);
-  stage_finish(st, dv);
-  scanned = sbx_wave_sum(scanned);
-  if (lane == 0 && scanned) {
-    atomicAdd(&dv->edges, scanned);
-    atomicAdd(&dv->edges_bu, scanned);
-  }
+  stage_end_block(st, nf_list, dv, scanned, true);
 }
 
 template <bool CM>

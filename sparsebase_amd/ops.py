@@ -89,8 +89,10 @@ def profile_report(device=None):
     for i in range(hd.lib.sbx_profile_kernel_count()):
         ms, cnt = C.c_double(0), C.c_int64(0)
         hd.check(hd.lib.sbx_profile_query(hd.h, i, C.byref(ms), C.byref(cnt)))
+        nb = C.c_int64(0)
+        hd.check(hd.lib.sbx_profile_query_bytes(hd.h, i, C.byref(nb)))
         if cnt.value:
-            out[hd.lib.sbx_profile_kernel_name(i).decode()] = (ms.value, cnt.value)
+            out[hd.lib.sbx_profile_kernel_name(i).decode()] = (ms.value, cnt.value, nb.value)
     return out
 
 

@@ -251,6 +251,46 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
 
 
+def test_permute_rowwise_copy_path(ops, oracle):
+    """Row-wise permutes run as a segmented copy; unsorted input rows must fall back to the sorting
+    pipeline, and tiles that span thousands of empty rows take the per-position search."""
+    g = np.random.default_rng(11)
+    # (a) sorted rows, long runs of empty rows between the non-empty ones, shards
+    n, m = 60000, 4096
+    lens = np.zeros(n, dtype=np.int64)
+    idx = g.choice(n, 300, replace=False)
+    lens[idx] = g.integers(1, 200, 300)
+    lens[idx[:3]] = (3000, 20000, 2048)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(g.choice(max(m, l), l, replace=False)) % m if l > m else
+                          np.sort(g.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+    col = np.concatenate([np.sort(col[rp[i]:rp[i + 1]]) for i in range(n)]).astype(np.int32)
+    val = g.random(len(col)).astype(np.float32)
+    ro = synth.random_permutation(n, 5)
+    want = oracle.permute_csr(rp, col, val, ro, None)
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), None), want)
+    same(ops.permute_csr(n, m, dev(rp), dev(col), None, dev(ro), None), oracle.permute_csr(rp, col, None, ro, None))
+    for a, b in ((0, 7), (7, n // 2), (n // 2, n)):
+        srp, scol, sval = ops.permute_csr_rows(n, m, dev(rp), dev(col), dev(val), dev(ro), None, a, b)
+        lo, hi = want[0][a], want[0][b]
+        assert np.array_equal(host(srp), want[0][a:b + 1] - lo)
+        assert np.array_equal(host(scol), want[1][lo:hi]) and np.array_equal(host(sval), want[2][lo:hi])
+    # (b) one unsorted row far into the matrix (also one exactly at a tile boundary): full sort semantics
+    rp2, col2 = synth.rmat_symmetric(13, 8, seed=2)
+    n2 = len(rp2) - 1
+    val2 = g.integers(-4, 4, len(col2)).astype(np.int32)
+    ro2 = synth.random_permutation(n2, 6)
+    for victim in (int(np.argmax(np.diff(rp2))), int(np.searchsorted(rp2, 2048, side="right") - 1)):
+        c = col2.copy()
+        a, b = rp2[victim], rp2[victim + 1]
+        if b - a >= 2:
+            c[a], c[b - 1] = c[b - 1], c[a]
+        same(ops.permute_csr(n2, n2, dev(rp2), dev(c), dev(val2), dev(ro2), None),
+             oracle.permute_csr(rp2, c, val2, ro2, None))
+        same(ops.permute_csr(n2, n2, dev(rp2), dev(c), dev(val2), None, None),
+             oracle.permute_csr(rp2, c, val2, None, None))
+
+
 def test_permute_row_shards(ops, oracle):
     rp, col = synth.rmat_symmetric(13, 8, seed=9)
     n = len(rp) - 1
