@@ -32,7 +32,9 @@ constexpr int PT_CAP = 2 * PT_TILE;  // LDS capacity of one tile, in entries
 constexpr int PT_ITEMS = PT_CAP / PT_THREADS;
 constexpr int PT_SHORT = 32;         // all-pairs rank sort up to this row length
 constexpr int PT_MAXMED = PT_CAP / (PT_SHORT + 1) + 2;
-constexpr int BR_THREADS = 1024;     // one workgroup sorts one row of up to BR_CAP entries in LDS
+// one workgroup sorts one row in LDS; four capacity classes so a 1100-entry row does not pay for 16384 slots
+constexpr int BR_CLASSES = 4;
+__host__ __device__ constexpr int br_cap(int cls) { return 2048 << cls; }  // 2048, 4096, 8192, 16384
 template <int VB> struct BlockRowCap { static constexpr int value = 16384; };
 template <> struct BlockRowCap<8> { static constexpr int value = 8192; };
 
@@ -40,7 +42,7 @@ struct PermState {            // device-resident flags/counters of one call
   unsigned any_unsorted;      // some row had col[j] < col[j-1] after relabelling (csr.cc:102-116)
   unsigned any_dup;           // some row holds a duplicate column
   unsigned n_long;            // rows longer than the block-row capacity (global radix path)
-  unsigned n_block;           // rows in (PT_TILE, capacity]: one workgroup each
+  unsigned n_block[BR_CLASSES];  // rows in (PT_TILE, capacity], by capacity class: one workgroup each
   unsigned long long long_nnz;
   unsigned long long total;   // nnz of the shard
   unsigned long_unsorted;     // some row of the global-radix class is out of order
@@ -71,7 +73,8 @@ template <typename I>
 __global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, const I *__restrict__ old_of_new,
                                                      I *__restrict__ rpo, int64_t rb0, int64_t nr,
                                                      I *__restrict__ long_rows, I *__restrict__ block_rows,
-                                                     int block_cap, PermState *__restrict__ st) {
+                                                     int64_t block_stride, int block_cap,
+                                                     PermState *__restrict__ st) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i <= nr; i += stride) {
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, c
       long_rows[slot] = (I)i;
       atomicAdd(&st->long_nnz, (unsigned long long)d);
     } else if (d > PT_TILE) {
-      block_rows[atomicAdd(&st->n_block, 1u)] = (I)i;
+      const int cls = d <= br_cap(0) ? 0 : d <= br_cap(1) ? 1 : d <= br_cap(2) ? 2 : 3;
+      block_rows[cls * block_stride + atomicAdd(&st->n_block[cls], 1u)] = (I)i;
     }
   }
 }
@@ -506,14 +510,13 @@ struct RowPasses {
   int bits[4];
 };
 
-template <typename I, int VB>
+template <typename I, int VB, int CAP, int BR_THREADS>
 __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
     const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
     const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out,
     char *val_out, int64_t rb0, RowPasses passes, PermState *__restrict__ st) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
-  constexpr int CAP = BlockRowCap<VB>::value;
   constexpr int ITEMS = CAP / BR_THREADS;
   constexpr int WAVES = BR_THREADS / 64;
   __shared__ int s_key[CAP];
@@ -623,32 +626,38 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
 }
 
 // ---- long rows ----------------------------------------------------------------
+// flat over the nonzeros of all long rows (a workgroup per row would leave the longest row as a straggler)
 template <typename I, int VB>
 __global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in, const I *col_in, const char *val_in,
                                                      const I *__restrict__ old_of_new, const I *__restrict__ col_order,
-                                                     const I *__restrict__ rpo, const I *__restrict__ long_rows,
-                                                     const uint32_t *__restrict__ loff, int n_long, int64_t rb0,
-                                                     uint64_t *__restrict__ keys, char *__restrict__ pay,
+                                                     const I *__restrict__ long_rows,
+                                                     const uint32_t *__restrict__ loff, int n_long, int64_t long_nnz,
+                                                     int64_t rb0, uint64_t *__restrict__ keys, char *__restrict__ pay,
                                                      PermState *__restrict__ st) {
   typedef typename ValT<VB>::type V;
   bool unsorted = false;
-  for (int k = blockIdx.x; k < n_long; k += gridDim.x) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < long_nnz; e += stride) {
+    int lo = 0, hi = n_long - 1;  // last k with loff[k] <= e
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)loff[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int k = lo;
+    const int64_t j = e - (int64_t)loff[k];
     const int64_t r = long_rows[k];
-    const int64_t len = (int64_t)rpo[r + 1] - (int64_t)rpo[r];
     const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
     const int64_t src0 = rp_in[u];
-    const uint32_t o0 = loff[k];
-    for (int64_t j = threadIdx.x; j < len; j += blockDim.x) {
-      I c = col_in[src0 + j];
-      if (col_order) c = col_order[c];
-      if (j) {
-        I pc = col_in[src0 + j - 1];
-        if (col_order) pc = col_order[pc];
-        unsorted |= c < pc;
-      }
-      keys[o0 + j] = ((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)c;
-      if (VB) ((V *)pay)[o0 + j] = ((const V *)val_in)[src0 + j];
+    I c = col_in[src0 + j];
+    if (col_order) c = col_order[c];
+    if (j) {
+      I pc = col_in[src0 + j - 1];
+      if (col_order) pc = col_order[pc];
+      unsorted |= c < pc;
     }
+    keys[e] = ((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)c;
+    if (VB) ((V *)pay)[e] = ((const V *)val_in)[src0 + j];
   }
   if (__any(unsorted) && sbx_lane() == 0) {
     st->any_unsorted = 1;
@@ -743,7 +752,8 @@ template <int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const int32_t *col_in, const char *val_in,
                const int32_t *old_of_new, const int32_t *col_order, const int32_t *rpo, int32_t *col_out,
                char *val_out, int64_t nr, int64_t rb0, int64_t m, int64_t total, const int32_t *long_rows,
-               unsigned n_long, int64_t long_nnz, const int32_t *block_rows, unsigned n_block, PermState *st) {
+               unsigned n_long, int64_t long_nnz, const int32_t *block_rows, const unsigned *n_block,
+               int64_t block_stride, PermState *st) {
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
@@ -752,7 +762,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
                 sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
     SBX_LAUNCH_CHECK(h);
   }
-  if (n_block) {
+  if (n_block[0] | n_block[1] | n_block[2] | n_block[3]) {
     RowPasses rpasses;
     sbx_radix_pass pl[16];
     rpasses.n = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, pl);
@@ -760,8 +770,16 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
       rpasses.shift[i] = pl[i].shift;
       rpasses.bits[i] = pl[i].bits;
     }
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB>), dim3(n_block), dim3(BR_THREADS), rp_in, col_in,
-                val_in, old_of_new, col_order, rpo, block_rows, col_out, val_out, rb0, rpasses, st);
+#define BLOCK_ROWS(CLS, THREADS)                                                                                  \
+  if (n_block[CLS])                                                                                               \
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
+                dim3(THREADS), rp_in, col_in, val_in, old_of_new, col_order, rpo, block_rows + (CLS)*block_stride, \
+                col_out, val_out, rb0, rpasses, st)
+    BLOCK_ROWS(0, 256);
+    BLOCK_ROWS(1, 512);
+    BLOCK_ROWS(2, 1024);
+    if constexpr (VB != 8) BLOCK_ROWS(3, 1024);  // 8-byte values: 16384 entries do not fit LDS, those rows are "long"
+#undef BLOCK_ROWS
     SBX_LAUNCH_CHECK(h);
   }
   if (n_long) {
@@ -778,9 +796,9 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), rpo, long_rows, loff,
                        (int)n_long);
     SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(n_long < 4096 ? n_long : 4096), dim3(256), rp_in,
-                       col_in, val_in, old_of_new, col_order, rpo, long_rows, (const uint32_t *)loff, (int)n_long, rb0,
-                       ka, pa, st);
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), rp_in,
+                       col_in, val_in, old_of_new, col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz,
+                       rb0, ka, pa, st);
     SBX_LAUNCH_CHECK(h);
     sbx_radix_pass passes[16];
     const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
@@ -910,11 +928,13 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     // some input row is out of order: redo with the sorting pipeline below
   }
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
+  int64_t block_stride = 0;
   {
     int64_t cap_long = nnz / PT_TILE + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
-    SBX_TRY(sbx_salloc(h, (size_t)cap_long, &block_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
+    block_stride = cap_long;
   }
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   if (row_order) {
@@ -923,7 +943,8 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
                        old_of_new, n);
   }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, block_rows, block_cap, st);
+                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, block_rows, block_stride,
+                     block_cap, st);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
@@ -938,7 +959,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
 #define STAGE(VBX)                                                                                               \
   rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, old_of_new,                 \
                        (const I *)col_order, rpo, (I *)col_out, (char *)val_out, nr, row_begin, m, total, long_rows, \
-                       hs.n_long, (int64_t)hs.long_nnz, block_rows, hs.n_block, st)
+                       hs.n_long, (int64_t)hs.long_nnz, block_rows, hs.n_block, block_stride, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
@@ -975,13 +996,13 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   char *vtmp = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &block_rows));
+  SBX_TRY(sbx_salloc(h, (size_t)n * BR_CLASSES, &block_rows));
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &deg));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, block_rows, block_cap, st);
+                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, block_rows, n, block_cap, st);
   SBX_LAUNCH_CHECK(h);
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
@@ -989,7 +1010,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
 #define STAGE(VBX)                                                                                              \
   rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, nullptr, nullptr,          \
                        (const I *)row_ptr, ctmp, vtmp, n, 0, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz, block_rows, \
-                       hs.n_block, st)
+                       hs.n_block, (int64_t)n, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);

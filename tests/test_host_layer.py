@@ -18,8 +18,11 @@ def built():
     return BIN
 
 
-def run(path, *args, ok=(0,)):
-    p = subprocess.run([path, *args], capture_output=True, text=True, timeout=600)
+def run(path, *args, ok=(0,), timeout=120):
+    try:
+        p = subprocess.run([path, *args], capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:  # a hung kernel must fail the test with its command line, not block the suite
+        raise AssertionError(f"TIMEOUT after {timeout}s: {path} {' '.join(map(str, args))}\n{e.stdout}\n{e.stderr}")
     assert p.returncode in ok, f"{path} rc={p.returncode}\n{p.stdout}\n{p.stderr}"
     return p.stdout
 
