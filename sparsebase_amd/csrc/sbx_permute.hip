@@ -68,23 +68,21 @@ __global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ ord
   for (; i < n; i += stride) ((V *)out)[order[i]] = ((const V *)vals)[i];
 }
 
-// new-order row lengths for rows [rb0, rb0+nr); entry nr is zeroed for the scan
+// row lengths (for the scan; entry nr zeroed) and the lists of rows too long for the tile kernel
 template <typename I>
-__global__ __launch_bounds__(256) void k_new_degrees(const I *__restrict__ rp, const I *__restrict__ old_of_new,
-                                                     I *__restrict__ rpo, int64_t rb0, int64_t nr,
-                                                     I *__restrict__ long_rows, I *__restrict__ block_rows,
-                                                     int64_t block_stride, int block_cap,
-                                                     PermState *__restrict__ st) {
+__global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ rec, I *__restrict__ rpo, int64_t nr,
+                                                      I *__restrict__ long_rows, I *__restrict__ block_rows,
+                                                      int64_t block_stride, int block_cap,
+                                                      PermState *__restrict__ st) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i <= nr; i += stride) {
     if (i == nr) {
-      rpo[i] = 0;
+      if (rpo) rpo[i] = 0;
       continue;
     }
-    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + i] : rb0 + i;
-    const I d = rp[u + 1] - rp[u];
-    rpo[i] = d;
+    const I d = (I)rec[i].x;
+    if (rpo) rpo[i] = d;
     if (d > block_cap) {
       const unsigned slot = atomicAdd(&st->n_long, 1u);
       long_rows[slot] = (I)i;
@@ -246,15 +244,17 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
 // IDENT: csr_sort_rows mode (no row/col maps, input == output arrays allowed).
 template <typename I, int VB>
 __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
-    const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
-    const I *__restrict__ col_order, const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, int64_t rb0,
-    PermState *__restrict__ st, int col_bits) {
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   __shared__ int s_col[PT_CAP];
   __shared__ V s_val[HASV ? PT_CAP : 1];
-  __shared__ int s_row[PT_CAP];
+  __shared__ int s_row[PT_CAP];  // row heads -> source offset of every entry -> row length -> dense row rank (radix key)
   __shared__ unsigned s_whist[PT_THREADS / 64][256];
+  // first position of the entry's row in the tile; dead before the radix passes start, so it lives in the histogram space
+  unsigned short *s_hp = (unsigned short *)&s_whist[0][0];
+  static_assert(sizeof(unsigned short) * PT_CAP <= sizeof(unsigned) * (PT_THREADS / 64) * 256, "s_hp must fit s_whist");
   __shared__ unsigned s_scan[PT_THREADS / 64 + 1];
   __shared__ int s_nmed;
   __shared__ int s_tile_unsorted;
@@ -288,35 +288,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   const int cnt = (int)((int64_t)rpo[rb] - e0);
   if (cnt == 0) return;
 
-  // element -> local row map.  Normal tiles: scatter row heads, then inclusive max-scan.
-  // Tiles whose row range is dominated by empty rows (e.g. the isolated vertices RCM
-  // packs at the end) would walk millions of heads: they locate each element's row by
-  // binary search instead.
+  // Row heads into LDS (tiles whose row range is dominated by empty rows — e.g. the
+  // isolated vertices RCM packs at the end — would walk millions of heads: they test
+  // each position by binary search instead), then a max-scan of head positions gives every
+  // entry its row; the row's (length, source offset) record is fetched once per row piece.
   const int64_t nrows_range = rb - ra;
   if (nrows_range <= 4 * PT_CAP) {
     for (int64_t r = ra + 1 + tid; r < rb; r += PT_THREADS) {
       const int p = (int)((int64_t)rpo[r] - e0);
       if (p < cnt) atomicMax(&s_row[p], (int)(r - ra));
     }
-    __syncthreads();
-    int hv[PT_ITEMS];
-    int run = 0;
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) {
-      const int x = s_row[tid * PT_ITEMS + k];
-      run = x > run ? x : run;
-      hv[k] = run;
-    }
-    const int inc = sbx_wave_inclusive_max(run);
-    int excl = __shfl_up(inc, 1, 64);
-    if (lane == 0) excl = 0;
-    if (lane == 63) s_wmax[wv] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wv; w++) woff = s_wmax[w] > woff ? s_wmax[w] : woff;
-    const int before = excl > woff ? excl : woff;
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) s_row[tid * PT_ITEMS + k] = hv[k] > before ? hv[k] : before;
   } else {
     for (int p = tid; p < cnt; p += PT_THREADS) {
       const int64_t target = e0 + p;  // last row r in [ra, rb) with rpo[r] <= target
@@ -326,31 +307,64 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
         if ((int64_t)rpo[mid] <= target) lo = mid;
         else hi = mid;
       }
-      s_row[p] = (int)(lo - ra);
+      if ((int64_t)rpo[lo] == target) s_row[p] = (int)(lo - ra);
     }
   }
   __syncthreads();
-
-  // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
-  for (int p = tid; p < cnt; p += PT_THREADS) {
-    const int64_t r = ra + s_row[p];
-    const int64_t s = (int64_t)rpo[r] - e0;
-    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
-    const int64_t src = (int64_t)rp_in[u] + (p - s);
-    I c = col_in[src];
-    if (col_order) c = col_order[c];
-    s_col[p] = (int)c;
-    if (HASV) s_val[p] = ((const V *)val_in)[src];
+  {
+    const int p0 = tid * PT_ITEMS;
+    int hd[PT_ITEMS];
+    int last = 0;
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+      hd[k] = s_row[p0 + k];
+      if (hd[k]) last = p0 + k + 1;
+    }
+    const int inc = sbx_wave_inclusive_max(last);
+    int open = __shfl_up(inc, 1, 64);
+    if (lane == 0) open = 0;
+    if (lane == 63) s_wmax[wv] = inc;
+    __syncthreads();
+    for (int w = 0; w < wv; w++) open = s_wmax[w] > open ? s_wmax[w] : open;
+    int hp = open ? open - 1 : 0;
+    int2 rc = rec[ra + (open ? s_row[open - 1] : 0)];
+    __syncthreads();  // every carry-in has been read: s_row can be overwritten
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++) {
+      const int p = p0 + k;
+      if (hd[k]) {
+        hp = p;
+        rc = rec[ra + hd[k]];
+      }
+      if (p < cnt) {
+        s_row[p] = (int)((int64_t)rc.y - (e0 + hp));  // source index = e0 + p + this
+        s_hp[p] = (unsigned short)hp;
+      }
+      hd[k] = rc.x;  // row length, stored once the offsets have been consumed
+    }
+    __syncthreads();
+    // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
+    for (int p = tid; p < cnt; p += PT_THREADS) {
+      const int64_t src = e0 + p + s_row[p];
+      I c = col_in[src];
+      if (col_order) c = col_order[c];
+      s_col[p] = (int)c;
+      if (HASV) s_val[p] = ((const V *)val_in)[src];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PT_ITEMS; k++)
+      if (p0 + k < cnt) s_row[p0 + k] = hd[k];
   }
   __syncthreads();
+
   // classify the tile: rows <= PT_SHORT only -> all-pairs ranking; otherwise one
   // tile-wide stable LSD radix sort on the composite key (local row, column)
   bool unsorted = false, dup = false, has_medium = false;
   for (int p = tid; p < cnt; p += PT_THREADS) {
-    const int64_t r = ra + s_row[p];
-    const int s = (int)((int64_t)rpo[r] - e0);
+    const int s = (int)s_hp[p];
     if (p > s && s_col[p] < s_col[p - 1]) unsorted = true;
-    if (p == s && (int64_t)rpo[r + 1] - (int64_t)rpo[r] > PT_SHORT) has_medium = true;
+    if (p == s && s_row[p] > PT_SHORT) has_medium = true;
   }
   if (__any(unsorted) && lane == 0) {
     st->any_unsorted = 1;
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     // anything, so stream the gathered rows out as they are
     for (int p = tid; p < cnt; p += PT_THREADS) {
       const int c = s_col[p];
-      if (p && c == s_col[p - 1] && s_row[p] == s_row[p - 1]) dup = true;
+      if (p && c == s_col[p - 1] && s_hp[p] == s_hp[p - 1]) dup = true;
       col_out[e0 + p] = (I)c;
       if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
     }
@@ -373,9 +387,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   }
   if (s_nmed == 0) {
     for (int p = tid; p < cnt; p += PT_THREADS) {
-      const int64_t r = ra + s_row[p];
-      const int s = (int)((int64_t)rpo[r] - e0);
-      const int len = (int)((int64_t)rpo[r + 1] - (int64_t)rpo[r]);
+      const int s = (int)s_hp[p], len = s_row[p];
       const int c = s_col[p];
       int rank = 0;
       for (int j = s; j < s + len; j++) {
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
 #pragma unroll
     for (int k = 0; k < PT_ITEMS; k++) {
       const int p = tid * PT_ITEMS + k;
-      const bool head = p < cnt && (p == 0 || s_row[p] != s_row[p - 1]);
+      const bool head = p < cnt && (p == 0 || s_hp[p] != s_hp[p - 1]);
       local += head;
       flag[k] = local;
     }
@@ -512,9 +524,9 @@ struct RowPasses {
 
 template <typename I, int VB, int CAP, int BR_THREADS>
 __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
-    const I *__restrict__ rp_in, const I *col_in, const char *val_in, const I *__restrict__ old_of_new,
-    const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out,
-    char *val_out, int64_t rb0, RowPasses passes, PermState *__restrict__ st) {
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out, char *val_out, RowPasses passes,
+    PermState *__restrict__ st) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int ITEMS = CAP / BR_THREADS;
@@ -527,8 +539,7 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
   const int64_t r = block_rows[blockIdx.x];
   const int64_t e0 = rpo[r];
   const int len = (int)((int64_t)rpo[r + 1] - e0);
-  const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
-  const int64_t src0 = rp_in[u];
+  const int64_t src0 = rec[r].y;
   for (int i = tid; i < CAP; i += BR_THREADS) {
     int c = 0x7FFFFFFF;  // padding: sorts last, never written out
     if (i < len) {
@@ -628,11 +639,11 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
 // ---- long rows ----------------------------------------------------------------
 // flat over the nonzeros of all long rows (a workgroup per row would leave the longest row as a straggler)
 template <typename I, int VB>
-__global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in, const I *col_in, const char *val_in,
-                                                     const I *__restrict__ old_of_new, const I *__restrict__ col_order,
+__global__ __launch_bounds__(256) void k_long_gather(const int2 *__restrict__ rec, const I *col_in, const char *val_in,
+                                                     const I *__restrict__ col_order,
                                                      const I *__restrict__ long_rows,
                                                      const uint32_t *__restrict__ loff, int n_long, int64_t long_nnz,
-                                                     int64_t rb0, uint64_t *__restrict__ keys, char *__restrict__ pay,
+                                                     uint64_t *__restrict__ keys, char *__restrict__ pay,
                                                      PermState *__restrict__ st) {
   typedef typename ValT<VB>::type V;
   bool unsorted = false;
@@ -646,9 +657,7 @@ __global__ __launch_bounds__(256) void k_long_gather(const I *__restrict__ rp_in
     }
     const int k = lo;
     const int64_t j = e - (int64_t)loff[k];
-    const int64_t r = long_rows[k];
-    const int64_t u = old_of_new ? (int64_t)old_of_new[rb0 + r] : rb0 + r;
-    const int64_t src0 = rp_in[u];
+    const int64_t src0 = rec[long_rows[k]].y;
     I c = col_in[src0 + j];
     if (col_order) c = col_order[c];
     if (j) {
@@ -749,17 +758,15 @@ int launch_fix(sbx_handle_t h, sbx_value_type vt, const I *rpo, const I *col, vo
 // Sort stage shared by permute and csr_sort_rows: rows of `rpo` (nr rows, already
 // on device) are produced from the source CSR through the row/col maps.
 template <int VB>
-int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const int32_t *col_in, const char *val_in,
-               const int32_t *old_of_new, const int32_t *col_order, const int32_t *rpo, int32_t *col_out,
-               char *val_out, int64_t nr, int64_t rb0, int64_t m, int64_t total, const int32_t *long_rows,
-               unsigned n_long, int64_t long_nnz, const int32_t *block_rows, const unsigned *n_block,
-               int64_t block_stride, PermState *st) {
+int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t *col_in, const char *val_in,
+               const int32_t *col_order, const int32_t *rpo, int32_t *col_out, char *val_out, int64_t nr, int64_t m,
+               int64_t total, const int32_t *long_rows, unsigned n_long, int64_t long_nnz, const int32_t *block_rows,
+               const unsigned *n_block, int64_t block_stride, PermState *st) {
   typedef int32_t I;
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rp_in, col_in, val_in,
-                       old_of_new, col_order, rpo, col_out, val_out, nr, rb0, st,
-                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rec, col_in, val_in,
+                col_order, rpo, col_out, val_out, nr, st, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
     SBX_LAUNCH_CHECK(h);
   }
   if (n_block[0] | n_block[1] | n_block[2] | n_block[3]) {
@@ -773,8 +780,8 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
 #define BLOCK_ROWS(CLS, THREADS)                                                                                  \
   if (n_block[CLS])                                                                                               \
     SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
-                dim3(THREADS), rp_in, col_in, val_in, old_of_new, col_order, rpo, block_rows + (CLS)*block_stride, \
-                col_out, val_out, rb0, rpasses, st)
+                dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, col_out,     \
+                val_out, rpasses, st)
     BLOCK_ROWS(0, 256);
     BLOCK_ROWS(1, 512);
     BLOCK_ROWS(2, 1024);
@@ -796,9 +803,8 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int32_t *rp_in, const in
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), rpo, long_rows, loff,
                        (int)n_long);
     SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), rp_in,
-                       col_in, val_in, old_of_new, col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz,
-                       rb0, ka, pa, st);
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), rec,
+                       col_in, val_in, col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz, ka, pa, st);
     SBX_LAUNCH_CHECK(h);
     sbx_radix_pass passes[16];
     const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
@@ -882,31 +888,46 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   if (shard_nnz_host) *shard_nnz_host = 0;
   if (nr == 0) return sbx_fill_i32(h, rpo, 0, 1);
 
+  // (row length, source offset) per new row, written from the old-row side; lengths -> scan -> row_ptr_out
   PermState *st = nullptr;
-  I *old_of_new = nullptr, *long_rows = nullptr, *block_rows = nullptr;
+  int2 *rec = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
-  if (!col_order) {
-    // row-wise: a segmented copy; sorted input rows (every CSR that went through a constructor) end here
-    int2 *rec = nullptr;
-    SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
-    SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
-                (const I *)row_order, n, row_begin, nr, rec);
+  SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
+  SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
+              (const I *)row_order, n, row_begin, nr, rec);
+  I *long_rows = nullptr, *block_rows = nullptr;
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
+  int64_t block_stride = 0;
+  if (col_order) {  // the sorting pipeline needs the rows that do not fit a tile listed by class
+    int64_t cap_long = nnz / PT_TILE + 1;
+    if (cap_long > nr) cap_long = nr;
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
+    block_stride = cap_long;
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
+                (const int2 *)rec, rpo, nr, long_rows, block_rows, block_stride, block_cap, st);
+  } else {
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_lengths<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
                 (const int2 *)rec, nr, rpo);
-    SBX_LAUNCH_CHECK(h);
-    SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
-    int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
-    if (nr != n) {
-      int32_t t32 = 0;
-      SBX_TRY(sbx_readback(h, &t32, rpo + nr, sizeof(int32_t)));
-      total = t32;
-    }
-    if (shard_nnz_host) *shard_nnz_host = total;
-    if (total > out_capacity)
-      SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
-               (long long)out_capacity);
-    if (total == 0) return SBX_OK;
+  }
+  SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
+  int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
+  PermState hs;
+  memset(&hs, 0, sizeof(hs));
+  if (nr != n || col_order) {
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
+    SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
+    total = (int64_t)hs.total;
+  }
+  if (shard_nnz_host) *shard_nnz_host = total;
+  if (total > out_capacity)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
+             (long long)out_capacity);
+  if (total == 0) return SBX_OK;
+  if (!col_order) {
+    // row-wise: a segmented copy; sorted input rows (every CSR that went through a constructor) end here
     const unsigned tiles = (unsigned)((total + PC_TILE - 1) / PC_TILE);
     I *tile_row = nullptr;
     SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_row));
@@ -925,41 +946,23 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     PermState hc;
     SBX_TRY(sbx_readback(h, &hc, st, sizeof(PermState)));
     if (!hc.any_unsorted) return SBX_OK;
-    // some input row is out of order: redo with the sorting pipeline below
-  }
-  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
-  int64_t block_stride = 0;
-  {
+    // some input row is out of order: redo with the sorting pipeline (row_ptr_out is already final)
     int64_t cap_long = nnz / PT_TILE + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
+    SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
+                (const int2 *)rec, (I *)nullptr, nr, long_rows, block_rows, block_stride, block_cap, st);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   }
-  SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-  if (row_order) {
-    SBX_TRY(sbx_salloc(h, (size_t)n, &old_of_new));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_order,
-                       old_of_new, n);
-  }
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)old_of_new, rpo, row_begin, nr, long_rows, block_rows, block_stride,
-                     block_cap, st);
-  SBX_LAUNCH_CHECK(h);
-  SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
-  PermState hs;
-  SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
-  const int64_t total = (int64_t)hs.total;
-  if (shard_nnz_host) *shard_nnz_host = total;
-  if (total > out_capacity)
-    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
-             (long long)out_capacity);
   int rc;
-#define STAGE(VBX)                                                                                               \
-  rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, old_of_new,                 \
-                       (const I *)col_order, rpo, (I *)col_out, (char *)val_out, nr, row_begin, m, total, long_rows, \
-                       hs.n_long, (int64_t)hs.long_nnz, block_rows, hs.n_block, block_stride, st)
+#define STAGE(VBX)                                                                                                  \
+  rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
+                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, hs.n_long, (int64_t)hs.long_nnz,     \
+                       block_rows, hs.n_block, block_stride, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
@@ -991,26 +994,29 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_TRY(sbx_arena_begin(h));
   typedef int32_t I;
   PermState *st = nullptr;
-  I *long_rows = nullptr, *block_rows = nullptr, *deg = nullptr, *ctmp = nullptr;
+  I *long_rows = nullptr, *block_rows = nullptr, *ctmp = nullptr;
+  int2 *rec = nullptr;
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   char *vtmp = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &rec));
   SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
   SBX_TRY(sbx_salloc(h, (size_t)n * BR_CLASSES, &block_rows));
-  SBX_TRY(sbx_salloc(h, (size_t)n + 1, &deg));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_degrees<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
-                     (const I *)row_ptr, (const I *)nullptr, deg, (int64_t)0, n, long_rows, block_rows, n, block_cap, st);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
+              (const I *)nullptr, n, (int64_t)0, n, rec);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
+              (const int2 *)rec, (I *)nullptr, n, long_rows, block_rows, n, block_cap, st);
   SBX_LAUNCH_CHECK(h);
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   int rc;
-#define STAGE(VBX)                                                                                              \
-  rc = sort_stage<VBX>(h, vt, (const I *)row_ptr, (const I *)col, (const char *)val, nullptr, nullptr,          \
-                       (const I *)row_ptr, ctmp, vtmp, n, 0, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz, block_rows, \
-                       hs.n_block, (int64_t)n, st)
+#define STAGE(VBX)                                                                                               \
+  rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)nullptr,          \
+                       (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz,    \
+                       block_rows, hs.n_block, (int64_t)n, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);

@@ -270,6 +270,9 @@ def test_permute_rowwise_copy_path(ops, oracle):
     want = oracle.permute_csr(rp, col, val, ro, None)
     same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), None), want)
     same(ops.permute_csr(n, m, dev(rp), dev(col), None, dev(ro), None), oracle.permute_csr(rp, col, None, ro, None))
+    co = synth.random_permutation(m, 8)  # the sorting pipeline over the same mostly-empty row ranges
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co)), oracle.permute_csr(rp, col, val, ro, co))
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), None, dev(co)), oracle.permute_csr(rp, col, val, None, co))
     for a, b in ((0, 7), (7, n // 2), (n // 2, n)):
         srp, scol, sval = ops.permute_csr_rows(n, m, dev(rp), dev(col), dev(val), dev(ro), None, a, b)
         lo, hi = want[0][a], want[0][b]
