@@ -6,21 +6,23 @@
 //       permute/permute_order_one.cc:18-37   sbx_permute_array
 //
 // Data flow of one permute (new rows [row_begin,row_end) — the multi-GPU shard):
-//   k_invert        old_of_new[row_order[i]] = i                          (4n B r/w)
-//   k_new_degrees   row lengths in new order, long rows listed            (8n B)
-//   scan            -> row_ptr_out
+//   k_rowwise_prep  from the old-row side: rec[row_order[u]] = (length, source offset)   (12n B r, 8n B w)
+//   lengths / k_rec_classify -> scan -> row_ptr_out; rows too long for a tile listed by class
+//   no column map:  k_permute_copy, a segmented copy (+ in-row order check; unsorted input
+//                   rows redo the call through the sorting kernels below)
+//   column map:
 //   k_permute_tile  one workgroup per 1024 output nonzeros: gathers whole old rows
 //                   (col relabelled through col_order) into LDS and sorts every row
 //                   of <= 1024 entries there: all-pairs ranking when the tile only
 //                   holds rows <= 32, otherwise one tile-wide stable LDS radix sort
 //                   on the composite key (local row, column); streams them out.
-//   k_permute_block_rows  rows of 1K..16K entries: one 1024-thread workgroup per
-//                   row, LDS radix sort over the column bits.
+//   k_permute_block_rows  rows of 1K..16K entries: one workgroup per row in four
+//                   capacity classes, LDS radix sort over the column bits.
 //   long rows       longer rows: gathered into a compact buffer, sorted by
 //                   (row, col) with the device radix sort, scattered back.
 //   k_fix_dup_runs  only if some row was unsorted AND duplicate columns exist:
 //                   orders equal-column runs by value (std::less<pair<col,val>>).
-// HBM traffic per nonzero in the tile path is the compulsory 2*(I+V) bytes.
+// HBM traffic per nonzero in the copy, tile and block paths is the compulsory 2*(I+V) bytes.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 

@@ -256,15 +256,13 @@ def test_permute_rowwise_copy_path(ops, oracle):
     pipeline, and tiles that span thousands of empty rows take the per-position search."""
     g = np.random.default_rng(11)
     # (a) sorted rows, long runs of empty rows between the non-empty ones, shards
-    n, m = 60000, 4096
+    n, m = 600000, 4096  # ~2000 empty rows between non-empty ones: tiles take the per-position search
     lens = np.zeros(n, dtype=np.int64)
     idx = g.choice(n, 300, replace=False)
     lens[idx] = g.integers(1, 200, 300)
     lens[idx[:3]] = (3000, 20000, 2048)
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    col = np.concatenate([np.sort(g.choice(max(m, l), l, replace=False)) % m if l > m else
-                          np.sort(g.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
-    col = np.concatenate([np.sort(col[rp[i]:rp[i + 1]]) for i in range(n)]).astype(np.int32)
+    col = np.concatenate([np.sort(g.choice(max(m, l), l, replace=False) % m) for l in lens[np.sort(idx)]]).astype(np.int32)
     val = g.random(len(col)).astype(np.float32)
     ro = synth.random_permutation(n, 5)
     want = oracle.permute_csr(rp, col, val, ro, None)
