@@ -146,6 +146,21 @@ int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t
                    void *row_out, void *col_out, void *val_out, unsigned flags);
 
 /* ------------------------------------------------------------------ *
+ * A14  COO -> CSC — converter/converter_order_two.cc:21-70: stable counting sort of the
+ * nonzeros by column (within a column they keep their input order), followed by what the
+ * CSC constructor does (format/csc.cc:99-157: if any column's rows are out of order, every
+ * column's (row, value) pairs are sorted).  col_ptr_out has m + 1 entries; the reference
+ * sizes it by the ROW count (:32-33) and is only safe for n == m, where the two agree.
+ * A15  CSR -> CSC — :120-128: CSR -> COO -> CSC (the transpose when rows are sorted). */
+/* ------------------------------------------------------------------ */
+int sbx_coo_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                   int64_t nnz, const void *row, const void *col, const void *val,
+                   void *col_ptr_out, void *row_out, void *val_out);
+int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                   int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                   void *col_ptr_out, void *row_out, void *val_out);
+
+/* ------------------------------------------------------------------ *
  * A6  DegreeReorder::CalculateReorderCSR — reorder/degree_reorder.cc:22-62
  * inv_perm_out[old_row] = new_row; ascending: (deg asc, id desc),        *
  * descending: the exact reverse.                                         */

@@ -20,6 +20,7 @@
 #include "sparsebase/bases/reorder_base.h"
 #include "sparsebase/context/cpu_context.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
 #include "sparsebase/permute/permute_order_two.h"
 #include "sparsebase/reorder/degree_reorder.h"
@@ -87,6 +88,27 @@ void t_csr_to_coo(int64_t n, int64_t m, int64_t nnz, I *rp, I *col, V *val, I *r
   if constexpr (!std::is_same_v<V, void>)
     if (val && val_out) memcpy(val_out, coo->get_vals(), nnz * sizeof(V));
   delete coo;
+}
+// square matrices only: the reference sizes col_ptr by the row count (converter_order_two.cc:32-33)
+template <typename I, typename V, typename Src>
+void csc_out(Src *src, int64_t n, int64_t nnz, bool has_val, I *cp_out, I *row_out, V *val_out) {
+  context::CPUContext cpu;
+  auto *csc = src->template Convert<format::CSC>(&cpu);
+  memcpy(cp_out, csc->get_col_ptr(), (n + 1) * sizeof(I));
+  memcpy(row_out, csc->get_row(), nnz * sizeof(I));
+  if constexpr (!std::is_same_v<V, void>)
+    if (has_val && val_out) memcpy(val_out, csc->get_vals(), nnz * sizeof(V));
+  delete csc;
+}
+template <typename I, typename V>
+void t_coo_to_csc(int64_t n, int64_t nnz, I *row, I *col, V *val, I *cp_out, I *row_out, V *val_out) {
+  format::COO<I, I, V> coo((I)n, (I)n, (I)nnz, row, col, val, format::kNotOwned, true);
+  csc_out<I, V>(&coo, n, nnz, val != nullptr, cp_out, row_out, val_out);
+}
+template <typename I, typename V>
+void t_csr_to_csc(int64_t n, int64_t nnz, I *rp, I *col, V *val, I *cp_out, I *row_out, V *val_out) {
+  format::CSR<I, I, V> csr((I)n, (I)n, rp, col, val, format::kNotOwned, true);
+  csc_out<I, V>(&csr, n, nnz, val != nullptr, cp_out, row_out, val_out);
 }
 template <typename I, typename V>
 void t_degree(int64_t n, int64_t m, I *rp, I *col, int ascending, I *inv) {
@@ -179,6 +201,20 @@ int ref_coo_to_csr(int it, int vt, int64_t n, int64_t m, int64_t nnz, void *row,
 int ref_csr_to_coo(int it, int vt, int64_t n, int64_t m, int64_t nnz, void *rp, void *col,
                    void *val, void *row_out, void *col_out, void *val_out) {
   TUPLE_SWITCH(it, vt, F_CSR_COO, 0);
+  return 0;
+}
+#define F_COO_CSC(I, V, ...) \
+  t_coo_to_csc<I, V>(n, nnz, (I *)row, (I *)col, (V *)val, (I *)cp_out, (I *)row_out, (V *)val_out)
+int ref_coo_to_csc(int it, int vt, int64_t n, int64_t nnz, void *row, void *col, void *val, void *cp_out,
+                   void *row_out, void *val_out) {
+  TUPLE_SWITCH(it, vt, F_COO_CSC, 0);
+  return 0;
+}
+#define F_CSR_CSC(I, V, ...) \
+  t_csr_to_csc<I, V>(n, nnz, (I *)rp, (I *)col, (V *)val, (I *)cp_out, (I *)row_out, (V *)val_out)
+int ref_csr_to_csc(int it, int vt, int64_t n, int64_t nnz, void *rp, void *col, void *val, void *cp_out,
+                   void *row_out, void *val_out) {
+  TUPLE_SWITCH(it, vt, F_CSR_CSC, 0);
   return 0;
 }
 #define F_DEGREE(I, V, ...) t_degree<I, V>(n, m, (I *)rp, (I *)col, ascending, (I *)inv)

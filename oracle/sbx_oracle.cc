@@ -169,6 +169,43 @@ void csr_to_coo(int vt, int64_t n, int64_t nnz, const I *rp, const I *col, const
 }
 
 // ---------------------------------------------------------------------------
+// A14 COO -> CSC    converter/converter_order_two.cc:21-70
+// Column histogram + inclusive scan (:45-50), then every nonzero in input order goes to
+// the next free slot of its column (:53-62): a stable counting sort by column.  The CSC
+// constructor that receives the arrays (:66-68 -> format/csc.cc:99-157) checks every
+// column and, if any has decreasing rows, sorts every column's (row, value) pairs — the
+// same procedure as the CSR constructor with the roles of the dimensions swapped.
+// The reference sizes col_ptr and its counters by n, the ROW count (:32-33), which is
+// only memory-safe for n == m; this restatement uses m + 1 entries (equal when square).
+// A15 CSR -> CSC    :120-128 = CSR -> COO -> CSC.
+// ---------------------------------------------------------------------------
+template <typename I>
+void coo_to_csc(int vt, int64_t n, int64_t m, int64_t nnz, const I *row, const I *col, const void *val,
+                I *cp_out, I *row_out, void *val_out) {
+  (void)n;
+  const int vb = (val && val_out) ? vbytes(vt) : 0;
+  std::vector<int64_t> start(m + 1, 0);
+  for (int64_t i = 0; i < nnz; i++) start[col[i] + 1]++;
+  for (int64_t c = 1; c <= m; c++) start[c] += start[c - 1];
+  for (int64_t c = 0; c <= m; c++) cp_out[c] = (I)start[c];
+  std::vector<int64_t> next(start.begin(), start.end() - 1);
+  for (int64_t i = 0; i < nnz; i++) {
+    const int64_t o = next[col[i]]++;
+    row_out[o] = row[i];
+    if (vb) memcpy((char *)val_out + o * vb, (const char *)val + i * vb, vb);
+  }
+  csr_sort_rows<I>(vb ? vt : V_NONE, m, cp_out, row_out, vb ? val_out : nullptr);  // csc.cc:99-157
+}
+
+template <typename I>
+void csr_to_csc(int vt, int64_t n, int64_t m, int64_t nnz, const I *rp, const I *col, const void *val,
+                I *cp_out, I *row_out, void *val_out) {
+  std::vector<I> rows(nnz > 0 ? nnz : 1);
+  csr_to_coo<I>(V_NONE, n, nnz, rp, col, nullptr, rows.data(), nullptr, nullptr);
+  coo_to_csc<I>(vt, n, m, nnz, rows.data(), col, val, cp_out, row_out, val_out);
+}
+
+// ---------------------------------------------------------------------------
 // A6  DegreeReorder   reorder/degree_reorder.cc:22-62
 // Intended semantics (the reference indexes `mr` one past its end, :41-45):
 // rows placed from the END of their degree bucket in id order, i.e. the final
@@ -519,6 +556,22 @@ void orc_csr_to_coo(int it, int vt, int64_t n, int64_t nnz, const void *rp, cons
                                (int32_t *)row_out, (int32_t *)col_out, val_out),
            csr_to_coo<int64_t>(vt, n, nnz, (const int64_t *)rp, (const int64_t *)col, val,
                                (int64_t *)row_out, (int64_t *)col_out, val_out));
+}
+void orc_coo_to_csc(int it, int vt, int64_t n, int64_t m, int64_t nnz, const void *row, const void *col,
+                    const void *val, void *cp_out, void *row_out, void *val_out) {
+  DISPATCH(it,
+           coo_to_csc<int32_t>(vt, n, m, nnz, (const int32_t *)row, (const int32_t *)col, val,
+                               (int32_t *)cp_out, (int32_t *)row_out, val_out),
+           coo_to_csc<int64_t>(vt, n, m, nnz, (const int64_t *)row, (const int64_t *)col, val,
+                               (int64_t *)cp_out, (int64_t *)row_out, val_out));
+}
+void orc_csr_to_csc(int it, int vt, int64_t n, int64_t m, int64_t nnz, const void *rp, const void *col,
+                    const void *val, void *cp_out, void *row_out, void *val_out) {
+  DISPATCH(it,
+           csr_to_csc<int32_t>(vt, n, m, nnz, (const int32_t *)rp, (const int32_t *)col, val,
+                               (int32_t *)cp_out, (int32_t *)row_out, val_out),
+           csr_to_csc<int64_t>(vt, n, m, nnz, (const int64_t *)rp, (const int64_t *)col, val,
+                               (int64_t *)cp_out, (int64_t *)row_out, val_out));
 }
 void orc_degree_reorder(int it, int64_t n, const void *rp, int ascending, void *inv) {
   DISPATCH(it, degree_reorder<int32_t>(n, (const int32_t *)rp, ascending, (int32_t *)inv),

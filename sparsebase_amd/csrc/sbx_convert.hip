@@ -5,6 +5,8 @@
 //   A2  converter_order_two.cc:163-246 sbx_coo_to_csr   (copy + move)
 //   A3  converter_order_two.cc:72-160  sbx_csr_to_coo   (copy + move)
 //   A4  format/csr.cc:102-116          sbx_csr_rows_sorted (the sort itself: sbx_permute.hip)
+//   A14 converter_order_two.cc:21-70   sbx_coo_to_csc   (stable counting sort by column)
+//   A15 converter_order_two.cc:120-128 sbx_csr_to_csc   (CSR -> COO -> CSC)
 //
 // All three conversions are single-pass streaming kernels (HBM-bound):
 //   COO->CSR  row_ptr comes from row-boundary detection on the row-sorted row[]
@@ -417,6 +419,71 @@ __global__ __launch_bounds__(CV_THREADS) void k_row_hist_i32(const int32_t *__re
   for (; i < nnz; i += stride) atomicAdd(&cnt[row[i]], 1);
 }
 
+// ---------------------------------------------------------------- A14 COO -> CSC helpers
+__global__ __launch_bounds__(CV_THREADS) void k_csc_keys(const int32_t *__restrict__ col, uint32_t *__restrict__ key,
+                                                         uint32_t *__restrict__ idx, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    key[i] = (uint32_t)col[i];
+    idx[i] = (uint32_t)i;
+  }
+}
+
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_csc_gather(const uint32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ row,
+                                                           const char *__restrict__ val,
+                                                           int32_t *__restrict__ row_out, char *__restrict__ val_out,
+                                                           int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    const uint32_t j = idx[i];
+    row_out[i] = row[j];
+    if (VB == 4) ((uint32_t *)val_out)[i] = ((const uint32_t *)val)[j];
+    if (VB == 8) ((uint64_t *)val_out)[i] = ((const uint64_t *)val)[j];
+  }
+}
+
+struct NestGuard {  // the conversions below call other entry points: keep this call's scratch alive
+  sbx_handle_t h;
+  explicit NestGuard(sbx_handle_t h) : h(h) { h->nest++; }
+  ~NestGuard() { h->nest--; }
+};
+
+// col_ptr_out[m+1], row_out[nnz], val_out[nnz] from COO arrays (arena already begun, nesting on)
+int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const int32_t *row,
+                    const int32_t *col, const char *val, int32_t *col_ptr_out, int32_t *row_out, char *val_out) {
+  if (nnz == 0) return sbx_fill_i32(h, col_ptr_out, 0, m + 1);
+  const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
+  uint32_t *ka = nullptr, *kb = nullptr, *ia = nullptr, *ib = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ia));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ib));
+  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
+  SBX_KLAUNCH(h, SBX_K_CSC, k_csc_keys, dim3(grid), dim3(CV_THREADS), col, ka, ia, nnz);
+  SBX_LAUNCH_CHECK(h);
+  // the reference's placement loop (:53-62) is a stable counting sort on the column: a stable
+  // LSD radix sort over the column bits moves (column, source index) to the same places
+  sbx_radix_pass passes[16];
+  const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, passes);
+  int in_b = 0;
+  SBX_TRY(sbx_radix_sort(h, 4, 4, ka, kb, ia, ib, nnz, passes, np, &in_b));
+  const uint32_t *skey = in_b ? kb : ka, *sidx = in_b ? ib : ia;
+  if (vb == 0) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<0>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
+  else if (vb == 4) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<4>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
+  else SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<8>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_CSC, nnz * (int64_t)(8 + 2 * (4 + vb)));
+  // col_ptr = exclusive scan of the column histogram = row-pointer construction over the sorted columns
+  SBX_TRY(sbx_coo_to_csr(h, SBX_I32, SBX_V_NONE, m, n, nnz, skey, nullptr, nullptr, col_ptr_out, nullptr, nullptr,
+                         SBX_FLAG_MOVE));
+  // the CSC constructor (format/csc.cc:99-157) then sorts every column's (row, value) pairs if any is out of order
+  return sbx_csr_sort_rows(h, SBX_I32, vb ? vt : SBX_V_NONE, m, n, nnz, col_ptr_out, row_out, vb ? val_out : nullptr);
+}
+
 }  // namespace
 
 extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
@@ -495,4 +562,44 @@ extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   if (vb == 0) return launch_csr_to_coo<0, false>(h, n, nnz, rp, c, v, ro, co, vo);
   if (vb == 4) return launch_csr_to_coo<4, false>(h, n, nnz, rp, c, v, ro, co, vo);
   return launch_csr_to_coo<8, false>(h, n, nnz, rp, c, v, ro, co, vo);
+}
+
+// A14: COO -> CSC.  The reference sizes col_ptr by the ROW count (converter_order_two.cc:32-33) and so
+// only works for n == m; here col_ptr_out has m + 1 entries (identical for square matrices).
+extern "C" int sbx_coo_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                              const void *row, const void *col, const void *val, void *col_ptr_out, void *row_out,
+                              void *val_out) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && col_ptr_out && (nnz == 0 || (row && col && row_out)), "bad argument");
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,
+              "dimension exceeds int32");
+  if (it == SBX_I64) return sbx_i64_coo_to_csc(h, vt, n, m, nnz, row, col, val, col_ptr_out, row_out, val_out);
+  SBX_REQUIRE(h, !(val && val_out) || sbx_value_bytes(vt) >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  NestGuard guard(h);
+  return coo_to_csc_core(h, vt, n, m, nnz, (const int32_t *)row, (const int32_t *)col, (const char *)val,
+                         (int32_t *)col_ptr_out, (int32_t *)row_out, (char *)val_out);
+}
+
+// A15: CSR -> CSC = CSR -> COO (row ids expanded into scratch) -> CSC
+extern "C" int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
+                              const void *row_ptr, const void *col, const void *val, void *col_ptr_out, void *row_out,
+                              void *val_out) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && col_ptr_out && (nnz == 0 || (col && row_out)),
+              "bad argument");
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,
+              "dimension exceeds int32");
+  if (it == SBX_I64) return sbx_i64_csr_to_csc(h, vt, n, m, nnz, row_ptr, col, val, col_ptr_out, row_out, val_out);
+  SBX_REQUIRE(h, !(val && val_out) || sbx_value_bytes(vt) >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  NestGuard guard(h);
+  int32_t *rows = nullptr;
+  if (nnz > 0) {
+    SBX_TRY(sbx_salloc(h, (size_t)nnz, &rows));
+    SBX_TRY(sbx_csr_to_coo(h, SBX_I32, SBX_V_NONE, n, m, nnz, row_ptr, nullptr, nullptr, rows, nullptr, nullptr,
+                           SBX_FLAG_MOVE));
+  }
+  return coo_to_csc_core(h, vt, n, m, nnz, rows, (const int32_t *)col, (const char *)val, (int32_t *)col_ptr_out,
+                         (int32_t *)row_out, (char *)val_out);
 }

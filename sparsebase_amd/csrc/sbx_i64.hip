@@ -167,6 +167,32 @@ int sbx_i64_csr_to_coo(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
   return sbx_widen_i32(h, co, col_out, nnz);
 }
 
+int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
+                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
+  I64_BEGIN();
+  NARROW(r, row, nnz);
+  NARROW(c, col, nnz);
+  SCRATCH32(cp, m + 1, true);
+  SCRATCH32(ro, nnz, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_coo_to_csc(h, SBX_I32, vt, n, m, nnz, r, c, val, cp, ro, val_out));
+  SBX_TRY(sbx_widen_i32(h, cp, col_ptr_out, m + 1));
+  return sbx_widen_i32(h, ro, row_out, nnz);
+}
+
+int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SCRATCH32(cp, m + 1, true);
+  SCRATCH32(ro, nnz, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_csr_to_csc(h, SBX_I32, vt, n, m, nnz, rp, c, val, cp, ro, val_out));
+  SBX_TRY(sbx_widen_i32(h, cp, col_ptr_out, m + 1));
+  return sbx_widen_i32(h, ro, row_out, nnz);
+}
+
 int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
   I64_BEGIN();
   NARROW(rp, row_ptr, n + 1);

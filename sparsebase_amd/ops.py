@@ -164,6 +164,29 @@ def csr_to_coo(n, m, row_ptr, col, val=None, move=False, out=None):
     return (ro, col, val) if move else (ro, co, vo)
 
 
+def coo_to_csc(n, m, row, col, val=None):
+    """COO -> CSC (col_ptr[m+1], row[nnz], val[nnz]); converter_order_two.cc:21-70."""
+    hd = handle_for(_check_dev(row, col, val))
+    nnz = col.numel()
+    cp = torch.empty(m + 1, dtype=row.dtype, device=row.device)
+    ro = torch.empty_like(row)
+    vo = None if val is None else torch.empty_like(val)
+    hd.check(hd.lib.sbx_coo_to_csc(hd.h, _it(row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(cp), _p(ro), _p(vo)))
+    return cp, ro, vo
+
+
+def csr_to_csc(n, m, row_ptr, col, val=None):
+    """CSR -> CSC (the transpose when rows are sorted); converter_order_two.cc:120-128."""
+    hd = handle_for(_check_dev(row_ptr, col, val))
+    nnz = col.numel()
+    cp = torch.empty(m + 1, dtype=row_ptr.dtype, device=row_ptr.device)
+    ro = torch.empty_like(col)
+    vo = None if val is None else torch.empty_like(val)
+    hd.check(hd.lib.sbx_csr_to_csc(hd.h, _it(row_ptr), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(cp),
+                                   _p(ro), _p(vo)))
+    return cp, ro, vo
+
+
 # ----------------------------------------------------------------------------- reorderers
 def degree_reorder(row_ptr, ascending=True, out=None):
     hd = handle_for(_check_dev(row_ptr))

@@ -91,6 +91,24 @@ class Oracle:
                                 _p(val), _p(ro), _p(co), _p(vo))
         return ro, co, vo
 
+    def coo_to_csc(self, n, m, row, col, val=None):
+        nnz = len(row)
+        cp = np.empty(m + 1, row.dtype)
+        ro = np.empty(nnz, row.dtype)
+        vo = None if val is None else np.empty_like(val)
+        self.lib.orc_coo_to_csc(it_of(row), vt_of(val), C.c_int64(n), C.c_int64(m), C.c_int64(nnz), _p(row), _p(col),
+                                _p(val), _p(cp), _p(ro), _p(vo))
+        return cp, ro, vo
+
+    def csr_to_csc(self, m, rp, col, val=None):
+        n, nnz = len(rp) - 1, len(col)
+        cp = np.empty(m + 1, rp.dtype)
+        ro = np.empty(nnz, rp.dtype)
+        vo = None if val is None else np.empty_like(val)
+        self.lib.orc_csr_to_csc(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(m), C.c_int64(nnz), _p(rp), _p(col),
+                                _p(val), _p(cp), _p(ro), _p(vo))
+        return cp, ro, vo
+
     def degree_reorder(self, rp, ascending=True, col=None, m=None):
         n = len(rp) - 1
         inv = np.empty(n, rp.dtype)
@@ -196,6 +214,26 @@ class Ref:
         self._chk(self.lib.ref_csr_to_coo(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(m),
                                           C.c_int64(nnz), _p(rp), _p(col), _p(val), _p(ro), _p(co), _p(vo)))
         return ro, co, vo
+
+    def coo_to_csc(self, n, m, row, col, val=None):
+        assert n == m, "the reference's COO->CSC is only memory-safe for square matrices"
+        nnz = len(row)
+        cp = np.empty(n + 1, row.dtype)
+        ro = np.empty(nnz, row.dtype)
+        vo = None if val is None else np.empty_like(val)
+        self._chk(self.lib.ref_coo_to_csc(it_of(row), vt_of(val), C.c_int64(n), C.c_int64(nnz), _p(row), _p(col),
+                                          _p(val), _p(cp), _p(ro), _p(vo)))
+        return cp, ro, vo
+
+    def csr_to_csc(self, m, rp, col, val=None):
+        n, nnz = len(rp) - 1, len(col)
+        assert n == m, "the reference's CSR->CSC is only memory-safe for square matrices"
+        cp = np.empty(n + 1, rp.dtype)
+        ro = np.empty(nnz, rp.dtype)
+        vo = None if val is None else np.empty_like(val)
+        self._chk(self.lib.ref_csr_to_csc(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(nnz), _p(rp), _p(col),
+                                          _p(val), _p(cp), _p(ro), _p(vo)))
+        return cp, ro, vo
 
     def degree_reorder(self, rp, ascending=True, col=None, m=None):
         n = len(rp) - 1

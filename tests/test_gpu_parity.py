@@ -48,6 +48,56 @@ def a32(x):
     return np.array(x, np.int32)
 
 
+# ----------------------------------------------------------------------------- CSC conversions
+def test_kat_csc(ops, kat):
+    # converter/converter_order_two_tests.cc:49-100, common.inc:14-16 (the reference pads col_ptr to n + 1 entries)
+    k = kat["converter_12x9"]
+    n, m = k["n"], k["m"]
+    for cp, ro, vo in (ops.csr_to_csc(n, m, dev(a32(k["csr_row_ptr"])), dev(a32(k["csr_col"])), dev(a32(k["csr_vals"]))),
+                       ops.coo_to_csc(n, m, dev(a32(k["coo_row"])), dev(a32(k["coo_col"])), dev(a32(k["coo_vals"])))):
+        assert host(cp).tolist() == k["csc_col_ptr"][:m + 1]
+        assert host(ro).tolist() == k["csc_row"] and host(vo).tolist() == k["csc_vals"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_csc_vs_oracle(ops, oracle, seed):
+    g = np.random.default_rng(700 + seed)
+    n, m = (int(g.integers(1, 3000)), int(g.integers(1, 3000))) if seed else (1 << 15, 1 << 15)
+    nnz = int(g.integers(0, 200000)) if seed else 600000
+    row = g.integers(0, n, nnz).astype(np.int32)
+    col = g.integers(0, m, nnz).astype(np.int32)
+    if seed % 2 == 0:
+        o = np.lexsort((col, row))
+        row, col = row[o], col[o]
+    else:  # shuffled input: distinct coordinates so the constructor's unstable pair sort is well defined
+        key = np.unique(row.astype(np.int64) * m + col)
+        key = key[g.permutation(len(key))]
+        row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    nnz = len(row)
+    for val in (None, g.integers(-9, 9, nnz).astype(np.int32), g.random(nnz).astype(np.float32), g.random(nnz)):
+        same(ops.coo_to_csc(n, m, dev(row), dev(col), dev(val)), oracle.coo_to_csc(n, m, row, col, val))
+    srow, scol, _ = oracle.coo_sort(row, col, None)
+    rp, cc, _ = oracle.coo_to_csr(n, srow, scol)
+    val = g.random(nnz).astype(np.float32)
+    same(ops.csr_to_csc(n, m, dev(rp), dev(cc), dev(val)), oracle.csr_to_csc(m, rp, cc, val))
+    # int64 tuple
+    same(ops.csr_to_csc(n, m, dev(rp.astype(np.int64)), dev(cc.astype(np.int64)), dev(val.astype(np.float64))),
+         oracle.csr_to_csc(m, rp.astype(np.int64), cc.astype(np.int64), val.astype(np.float64)))
+    # transposing twice restores the CSR
+    cp, ro, vo = ops.csr_to_csc(n, m, dev(rp), dev(cc), dev(val))
+    back = ops.csr_to_csc(m, n, cp, ro, vo)
+    same(back, (rp, cc, val))
+
+
+def test_csc_degenerate(ops, oracle):
+    z = np.zeros(0, np.int32)
+    same(ops.coo_to_csc(5, 7, dev(z), dev(z), None), oracle.coo_to_csc(5, 7, z, z, None))
+    same(ops.csr_to_csc(3, 4, dev(np.zeros(4, np.int32)), dev(z), None), oracle.csr_to_csc(4, np.zeros(4, np.int32), z, None))
+    one = np.array([2], np.int32)
+    same(ops.coo_to_csc(3, 3, dev(one), dev(one), dev(np.array([1.5], np.float32))),
+         oracle.coo_to_csc(3, 3, one, one, np.array([1.5], np.float32)))
+
+
 # ----------------------------------------------------------------------------- reference KATs
 def test_kat_conversions(ops, kat):
     for name in ("converter_12x9", "format_4x4"):
