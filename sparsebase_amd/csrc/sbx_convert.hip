@@ -452,31 +452,79 @@ struct NestGuard {  // the conversions below call other entry points: keep this 
   ~NestGuard() { h->nest--; }
 };
 
+// (column key, payload) records for the stable sort: the payload carries the row (and a
+// 4-byte value) itself, so nothing has to be gathered through an index afterwards
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_csc_pack(const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                                         const char *__restrict__ val, uint32_t *__restrict__ key,
+                                                         void *__restrict__ pay, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    key[i] = (uint32_t)col[i];
+    if (VB == 4) ((uint64_t *)pay)[i] = (uint64_t)(uint32_t)row[i] | ((uint64_t)((const uint32_t *)val)[i] << 32);
+    else ((uint32_t *)pay)[i] = (uint32_t)row[i];
+  }
+}
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_csc_unpack(const void *__restrict__ pay, int32_t *__restrict__ row_out,
+                                                           char *__restrict__ val_out, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    if (VB == 4) {
+      const uint64_t p = ((const uint64_t *)pay)[i];
+      row_out[i] = (int32_t)(uint32_t)p;
+      ((uint32_t *)val_out)[i] = (uint32_t)(p >> 32);
+    } else {
+      row_out[i] = (int32_t)((const uint32_t *)pay)[i];
+    }
+  }
+}
+
 // col_ptr_out[m+1], row_out[nnz], val_out[nnz] from COO arrays (arena already begun, nesting on)
 int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const int32_t *row,
                     const int32_t *col, const char *val, int32_t *col_ptr_out, int32_t *row_out, char *val_out) {
   if (nnz == 0) return sbx_fill_i32(h, col_ptr_out, 0, m + 1);
   const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
-  uint32_t *ka = nullptr, *kb = nullptr, *ia = nullptr, *ib = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
-  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
-  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ia));
-  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ib));
   const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
-  SBX_KLAUNCH(h, SBX_K_CSC, k_csc_keys, dim3(grid), dim3(CV_THREADS), col, ka, ia, nnz);
-  SBX_LAUNCH_CHECK(h);
   // the reference's placement loop (:53-62) is a stable counting sort on the column: a stable
-  // LSD radix sort over the column bits moves (column, source index) to the same places
+  // LSD radix sort over the column bits moves the records to the same places
   sbx_radix_pass passes[16];
   const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, passes);
+  uint32_t *ka = nullptr, *kb = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
+  const uint32_t *skey = nullptr;
   int in_b = 0;
-  SBX_TRY(sbx_radix_sort(h, 4, 4, ka, kb, ia, ib, nnz, passes, np, &in_b));
-  const uint32_t *skey = in_b ? kb : ka, *sidx = in_b ? ib : ia;
-  if (vb == 0) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<0>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
-  else if (vb == 4) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<4>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
-  else SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<8>, dim3(grid), dim3(CV_THREADS), sidx, row, val, row_out, val_out, nnz);
-  SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_CSC, nnz * (int64_t)(8 + 2 * (4 + vb)));
+  if (vb != 8) {
+    const int pb = vb == 4 ? 8 : 4;
+    char *pa = nullptr, *pbuf = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)nnz * pb, &pa));
+    SBX_TRY(sbx_salloc(h, (size_t)nnz * pb, &pbuf));
+    if (vb == 4) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_pack<4>, dim3(grid), dim3(CV_THREADS), row, col, val, ka, (void *)pa, nnz);
+    else SBX_KLAUNCH(h, SBX_K_CSC, k_csc_pack<0>, dim3(grid), dim3(CV_THREADS), row, col, val, ka, (void *)pa, nnz);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_radix_sort(h, 4, pb, ka, kb, pa, pbuf, nnz, passes, np, &in_b));
+    const void *sp = in_b ? pbuf : pa;
+    if (vb == 4) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_unpack<4>, dim3(grid), dim3(CV_THREADS), sp, row_out, val_out, nnz);
+    else SBX_KLAUNCH(h, SBX_K_CSC, k_csc_unpack<0>, dim3(grid), dim3(CV_THREADS), sp, row_out, val_out, nnz);
+    SBX_LAUNCH_CHECK(h);
+    SBX_PROF_BYTES(h, SBX_K_CSC, 2 * nnz * (int64_t)(8 + vb));
+  } else {
+    // 8-byte values: 12-byte payloads are not a radix record size, sort (column, source index) and gather
+    uint32_t *ia = nullptr, *ib = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)nnz, &ia));
+    SBX_TRY(sbx_salloc(h, (size_t)nnz, &ib));
+    SBX_KLAUNCH(h, SBX_K_CSC, k_csc_keys, dim3(grid), dim3(CV_THREADS), col, ka, ia, nnz);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_radix_sort(h, 4, 4, ka, kb, ia, ib, nnz, passes, np, &in_b));
+    SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather<8>, dim3(grid), dim3(CV_THREADS), (const uint32_t *)(in_b ? ib : ia), row,
+                val, row_out, val_out, nnz);
+    SBX_LAUNCH_CHECK(h);
+    SBX_PROF_BYTES(h, SBX_K_CSC, nnz * (int64_t)(8 + 2 * (4 + vb)));
+  }
+  skey = in_b ? kb : ka;
   // col_ptr = exclusive scan of the column histogram = row-pointer construction over the sorted columns
   SBX_TRY(sbx_coo_to_csr(h, SBX_I32, SBX_V_NONE, m, n, nnz, skey, nullptr, nullptr, col_ptr_out, nullptr, nullptr,
                          SBX_FLAG_MOVE));

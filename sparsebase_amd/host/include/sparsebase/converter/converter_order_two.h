@@ -5,6 +5,8 @@
 // Every function below ends in a HIP kernel behind the C ABI:
 //   COO -> CSR   sbx_coo_to_csr  (converter_order_two.cc:163-212, move :215-246)
 //   CSR -> COO   sbx_csr_to_coo  (converter_order_two.cc:72-118,  move :131-160)
+//   COO -> CSC   sbx_coo_to_csc  (converter_order_two.cc:21-70)
+//   CSR -> CSC   sbx_csr_to_csc  (converter_order_two.cc:120-128)
 // Host-resident formats (CPUContext) are staged through the default device and the
 // result is delivered back to host arrays, so existing call sites such as
 // coo->Convert<format::CSR>(&cpu_context) keep working unchanged; device-resident
@@ -13,10 +15,13 @@
 // applied on the device before anything is copied back.
 #ifndef SPARSEBASE_CONVERTER_CONVERTER_ORDER_TWO_H_
 #define SPARSEBASE_CONVERTER_CONVERTER_ORDER_TWO_H_
+#include <vector>
+
 #include "sparsebase/context/cpu_context.h"
 #include "sparsebase/context/hip_context.h"
 #include "sparsebase/converter/converter.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
 #include "sparsebase/format/hip_formats.h"
 
@@ -150,6 +155,136 @@ format::Format *CsrCooMoveConditionalFunction(format::Format *source, context::C
   I *col = csr->release_col();    // converter_order_two.cc:134-135
   V *vals = csr->release_vals();
   return new format::COO<I, N, V>(n, m, (N)nnz, row, col, vals, format::kOwned, false);
+}
+
+// ------------------------------------------------------------------ CSC (host formats, staged)
+namespace detail {
+// Device col_ptr arrays have max(n, m) + 1 entries (format/csc.h): the C ABI fills the first
+// m + 1, the rest repeat nnz exactly like the reference's n + 1-entry array does for n > m.
+template <typename N>
+void PadColPtr(const hip::Device &dev, N *d_col_ptr, size_t m, size_t ptr_count, size_t nnz) {
+  if (ptr_count <= m) return;
+  std::vector<N> tail(ptr_count - m, (N)nnz);
+  dev.ToDevice(d_col_ptr + m + 1, tail.data(), tail.size() * sizeof(N));
+}
+// runs sbx_coo_to_csc / sbx_csr_to_csc on device-resident inputs; returns owned device arrays
+template <typename I, typename N, typename V, bool FROM_CSR>
+void ToCscOnDevice(const hip::Device &dev, I n, I m, size_t nnz, const void *d_first, const I *d_col,
+                   const void *d_val, N **cp_out, I **row_out, void **val_out) {
+  const size_t pc = format::CSC<I, N, V>::PtrCount(n, m);
+  N *cp = (N *)dev.Malloc((pc + 1) * sizeof(N));
+  I *row = (I *)dev.Malloc((nnz ? nnz : 1) * sizeof(I));
+  void *val = d_val ? dev.Malloc(nnz * hip::ValueBytes<V>()) : nullptr;
+  const int rc = FROM_CSR ? sbx_csr_to_csc(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
+                                           d_first, d_col, d_val, cp, row, val)
+                          : sbx_coo_to_csc(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
+                                           d_first, d_col, d_val, cp, row, val);
+  if (rc != SBX_OK) {
+    dev.Free(cp);
+    dev.Free(row);
+    if (val) dev.Free(val);
+    dev.Check(rc);
+  }
+  PadColPtr<N>(dev, cp, (size_t)m, pc, nnz);
+  *cp_out = cp;
+  *row_out = row;
+  *val_out = val;
+}
+template <typename I, typename N, typename V, bool FROM_CSR>
+format::Format *StagedToCsc(I n, I m, size_t nnz, const void *first, size_t first_count, const I *col, const V *vals) {
+  auto &dev = hip::Device::Get(hip::DefaultDevice());
+  hip::Staged<I> d_first(dev, (const I *)first, first_count), d_col(dev, col, nnz);
+  void *d_val = UploadValues<V>(dev, vals, nnz);
+  N *d_cp = nullptr;
+  I *d_row = nullptr;
+  void *d_val_out = nullptr;
+  try {
+    ToCscOnDevice<I, N, V, FROM_CSR>(dev, n, m, nnz, d_first.get(), d_col.get(), d_val, &d_cp, &d_row, &d_val_out);
+  } catch (...) {
+    if (d_val) dev.Free(d_val);
+    throw;
+  }
+  const size_t pc = format::CSC<I, N, V>::PtrCount(n, m);
+  N *col_ptr = dev.Download(d_cp, pc + 1);
+  I *row = dev.Download(d_row, nnz);
+  V *out_vals = DownloadValues<V>(dev, d_val_out, nnz);
+  dev.Free(d_cp);
+  dev.Free(d_row);
+  if (d_val_out) dev.Free(d_val_out);
+  if (d_val) dev.Free(d_val);
+  // the constructor's sort already ran on the device (sbx_*_to_csc ends with it)
+  return new format::CSC<I, N, V>(n, m, col_ptr, row, out_vals, format::kOwned, true);
+}
+}  // namespace detail
+
+template <typename I, typename N, typename V>
+format::Format *CooCscFunctionConditional(format::Format *source, context::Context *) {
+  static_assert(sizeof(I) == sizeof(N), "IDType and NNZType must have the same width");
+  auto *coo = source->AsAbsolute<format::COO<I, N, V>>();
+  const auto dims = coo->get_dimensions();
+  const size_t nnz = coo->get_num_nnz();
+  return detail::StagedToCsc<I, N, V, false>((I)dims[0], (I)dims[1], nnz, coo->get_row(), nnz, coo->get_col(),
+                                             coo->get_vals());
+}
+template <typename I, typename N, typename V>
+format::Format *CsrCscFunctionConditional(format::Format *source, context::Context *) {
+  static_assert(sizeof(I) == sizeof(N), "IDType and NNZType must have the same width");
+  auto *csr = source->AsAbsolute<format::CSR<I, N, V>>();
+  const auto dims = csr->get_dimensions();
+  return detail::StagedToCsc<I, N, V, true>((I)dims[0], (I)dims[1], csr->get_num_nnz(), csr->get_row_ptr(),
+                                            (size_t)dims[0] + 1, csr->get_col(), csr->get_vals());
+}
+
+// CSC <-> HIPCSC copies and the in-HBM conversions
+template <typename I, typename N, typename V>
+format::Format *CscHIPCscConditionalFunction(format::Format *source, context::Context *to) {
+  auto *csc = source->AsAbsolute<format::CSC<I, N, V>>();
+  const auto dims = csc->get_dimensions();
+  const size_t nnz = csc->get_num_nnz();
+  const int did = detail::DeviceOf(to);
+  auto &dev = hip::Device::Get(did);
+  N *d_cp = dev.Upload(csc->get_col_ptr(), csc->ptr_count() + 1);
+  I *d_row = dev.Upload(csc->get_row(), nnz);
+  V *d_val = (V *)detail::UploadValues<V>(dev, csc->get_vals(), nnz);
+  return new format::HIPCSC<I, N, V>((I)dims[0], (I)dims[1], (N)nnz, d_cp, d_row, d_val, context::HIPContext(did),
+                                     format::kOwned, true);
+}
+template <typename I, typename N, typename V>
+format::Format *HIPCscCscConditionalFunction(format::Format *source, context::Context *) {
+  auto *d = source->AsAbsolute<format::HIPCSC<I, N, V>>();
+  const auto dims = d->get_dimensions();
+  const size_t nnz = d->get_num_nnz();
+  auto &dev = d->device();
+  N *cp = dev.Download(d->get_col_ptr(), d->ptr_count() + 1);
+  I *row = dev.Download(d->get_row(), nnz);
+  V *val = detail::DownloadValues<V>(dev, d->get_vals(), nnz);
+  return new format::CSC<I, N, V>((I)dims[0], (I)dims[1], cp, row, val, format::kOwned, true);
+}
+template <typename I, typename N, typename V>
+format::Format *HIPCooHIPCscFunction(format::Format *source, context::Context *) {
+  auto *coo = source->AsAbsolute<format::HIPCOO<I, N, V>>();
+  const auto dims = coo->get_dimensions();
+  auto &dev = coo->device();
+  N *cp = nullptr;
+  I *row = nullptr;
+  void *val = nullptr;
+  detail::ToCscOnDevice<I, N, V, false>(dev, (I)dims[0], (I)dims[1], coo->get_num_nnz(), coo->get_row(), coo->get_col(),
+                                        coo->get_vals(), &cp, &row, &val);
+  return new format::HIPCSC<I, N, V>((I)dims[0], (I)dims[1], (N)coo->get_num_nnz(), cp, row, (V *)val,
+                                     context::HIPContext(dev.id()), format::kOwned, true);
+}
+template <typename I, typename N, typename V>
+format::Format *HIPCsrHIPCscFunction(format::Format *source, context::Context *) {
+  auto *csr = source->AsAbsolute<format::HIPCSR<I, N, V>>();
+  const auto dims = csr->get_dimensions();
+  auto &dev = csr->device();
+  N *cp = nullptr;
+  I *row = nullptr;
+  void *val = nullptr;
+  detail::ToCscOnDevice<I, N, V, true>(dev, (I)dims[0], (I)dims[1], csr->get_num_nnz(), csr->get_row_ptr(),
+                                       csr->get_col(), csr->get_vals(), &cp, &row, &val);
+  return new format::HIPCSC<I, N, V>((I)dims[0], (I)dims[1], (N)csr->get_num_nnz(), cp, row, (V *)val,
+                                     context::HIPContext(dev.id()), format::kOwned, true);
 }
 
 // ------------------------------------------------------------------ host <-> device copies
@@ -292,13 +427,21 @@ class ConverterOrderTwo : public ConverterImpl<ConverterOrderTwo<IDType, NNZType
     typedef ValueType V;
     const auto csr = CSR<I, N, V>::get_id_static(), coo = COO<I, N, V>::get_id_static();
     const auto dcsr = HIPCSR<I, N, V>::get_id_static(), dcoo = HIPCOO<I, N, V>::get_id_static();
+    const auto csc = CSC<I, N, V>::get_id_static(), dcsc = HIPCSC<I, N, V>::get_id_static();
     // host formats, results on the host (reference converter_order_two.cc:258-340)
     this->RegisterConversionFunction(coo, csr, CooCsrFunctionConditional<I, N, V>, detail::ToCPU);
     this->RegisterConversionFunction(csr, coo, CsrCooFunctionConditional<I, N, V>, detail::ToCPU);
     this->RegisterConversionFunction(coo, csr, CooCsrMoveConditionalFunction<I, N, V>, detail::ToCPU, true);
     this->RegisterConversionFunction(csr, coo, CsrCooMoveConditionalFunction<I, N, V>, detail::ToCPU, true);
+    // the reference registers the two CSC functions as copy AND as move conversions (:273-286, :326-340)
+    for (bool move : {false, true}) {
+      this->RegisterConversionFunction(coo, csc, CooCscFunctionConditional<I, N, V>, detail::ToCPU, move);
+      this->RegisterConversionFunction(csr, csc, CsrCscFunctionConditional<I, N, V>, detail::ToCPU, move);
+    }
     // host <-> device copies (reference: CsrCUDACsr / CUDACsrCsr, converter_order_two_cuda.cu)
     for (bool move : {false, true}) {
+      this->RegisterConversionFunction(csc, dcsc, CscHIPCscConditionalFunction<I, N, V>, detail::ToHIP, move);
+      this->RegisterConversionFunction(dcsc, csc, HIPCscCscConditionalFunction<I, N, V>, detail::ToCPU, move);
       this->RegisterConversionFunction(csr, dcsr, CsrHIPCsrConditionalFunction<I, N, V>, detail::ToHIP, move);
       this->RegisterConversionFunction(dcsr, csr, HIPCsrCsrConditionalFunction<I, N, V>, detail::ToCPU, move);
       this->RegisterConversionFunction(coo, dcoo, CooHIPCooConditionalFunction<I, N, V>, detail::ToHIP, move);
@@ -309,6 +452,10 @@ class ConverterOrderTwo : public ConverterImpl<ConverterOrderTwo<IDType, NNZType
     this->RegisterConversionFunction(dcsr, dcoo, HIPCsrHIPCooFunction<I, N, V, false>, detail::OnHIP);
     this->RegisterConversionFunction(dcoo, dcsr, HIPCooHIPCsrFunction<I, N, V, true>, detail::OnHIP, true);
     this->RegisterConversionFunction(dcsr, dcoo, HIPCsrHIPCooFunction<I, N, V, true>, detail::OnHIP, true);
+    for (bool move : {false, true}) {
+      this->RegisterConversionFunction(dcoo, dcsc, HIPCooHIPCscFunction<I, N, V>, detail::OnHIP, move);
+      this->RegisterConversionFunction(dcsr, dcsc, HIPCsrHIPCscFunction<I, N, V>, detail::OnHIP, move);
+    }
   }
 };
 

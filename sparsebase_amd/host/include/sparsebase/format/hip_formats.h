@@ -1,4 +1,4 @@
-// sparsebase/format/hip_formats.h — device-resident formats HIPCSR / HIPCOO / HIPArray
+// sparsebase/format/hip_formats.h — device-resident formats HIPCSR / HIPCOO / HIPCSC / HIPArray
 // (MI355X counterparts of the reference's CUDACSR / CUDAArray,
 // format/cuda_csr_cuda.cuh:20-59, cuda_array_cuda.cuh).  They own (or borrow) raw
 // device pointers on the GPU named by their HIPContext.  Constructors keep the
@@ -165,6 +165,61 @@ class HIPCOO : public utils::IdentifiableImplementation<HIPCOO<IDType, NNZType, 
     p = detail::OwnedPtr<T>(raw, BlankDeleter<T>());
     return raw;
   }
+};
+
+// Device-resident CSC.  col_ptr has max(n, m) + 1 entries like the host CSC (csc.h).
+template <typename IDType, typename NNZType, typename ValueType>
+class HIPCSC : public utils::IdentifiableImplementation<HIPCSC<IDType, NNZType, ValueType>,
+                                                        FormatOrderTwo<IDType, NNZType, ValueType>> {
+ public:
+  static size_t PtrCount(DimensionType n, DimensionType m) { return (size_t)(n > m ? n : m); }
+  HIPCSC(IDType n, IDType m, NNZType nnz, NNZType *col_ptr, IDType *row, ValueType *vals,
+         context::HIPContext context, Ownership own = kOwned, bool ignore_sort = false)
+      : col_ptr_(detail::HoldDevice(col_ptr, own, context.device_id)),
+        row_(detail::HoldDevice(row, own, context.device_id)),
+        vals_(detail::HoldDevice(vals, own, context.device_id)) {
+    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
+    this->order_ = 2;
+    this->dimension_ = {(DimensionType)n, (DimensionType)m};
+    this->nnz_ = (DimensionType)nnz;
+    this->context_ = std::unique_ptr<context::Context>(new context::HIPContext(context));
+    if (!ignore_sort && nnz > 1) {  // format/csc.cc:99-157 on the device
+      auto &dev = device();
+      dev.Check(sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(),
+                                  (int64_t)PtrCount(n, m), n, (int64_t)nnz, col_ptr, row, vals));
+    }
+  }
+  HIPCSC(const HIPCSC &rhs)
+      : col_ptr_(nullptr, BlankDeleter<NNZType>()), row_(nullptr, BlankDeleter<IDType>()),
+        vals_(nullptr, BlankDeleter<ValueType>()) {
+    const int did = rhs.get_hip_context()->device_id;
+    auto &dev = hip::Device::Get(did);
+    const size_t nnz = rhs.nnz_;
+    col_ptr_ = detail::HoldDevice(detail::CloneDevice(dev, rhs.get_col_ptr(), (rhs.ptr_count() + 1) * sizeof(NNZType)),
+                                  kOwned, did);
+    row_ = detail::HoldDevice(detail::CloneDevice(dev, rhs.get_row(), nnz * sizeof(IDType)), kOwned, did);
+    vals_ = detail::HoldDevice(
+        (ValueType *)detail::CloneDevice(dev, (const char *)rhs.get_vals(), nnz * hip::ValueBytes<ValueType>()), kOwned,
+        did);
+    this->order_ = 2;
+    this->dimension_ = rhs.dimension_;
+    this->nnz_ = rhs.nnz_;
+    this->context_ = std::unique_ptr<context::Context>(new context::HIPContext(did));
+  }
+  Format *Clone() const override { return new HIPCSC(*this); }
+  ~HIPCSC() override = default;
+
+  size_t ptr_count() const { return PtrCount(this->dimension_[0], this->dimension_[1]); }
+  NNZType *get_col_ptr() const { return col_ptr_.get(); }
+  IDType *get_row() const { return row_.get(); }
+  ValueType *get_vals() const { return vals_.get(); }
+  context::HIPContext *get_hip_context() const { return static_cast<context::HIPContext *>(this->get_context()); }
+  hip::Device &device() const { return hip::Device::Get(get_hip_context()->device_id); }
+
+ protected:
+  detail::OwnedPtr<NNZType> col_ptr_;
+  detail::OwnedPtr<IDType> row_;
+  detail::OwnedPtr<ValueType> vals_;
 };
 
 template <typename ValueType>

@@ -8,6 +8,7 @@
 #include "sparsebase/converter/converter_order_two.h"
 #include "sparsebase/format/array.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
 #include "sparsebase/format/hip_formats.h"
 #include "sparsebase/utils/logger.h"

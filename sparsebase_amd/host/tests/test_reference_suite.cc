@@ -2,6 +2,7 @@
 // re-expressed against this library (same fixtures, same assertions), plus the device
 // formats.  Sources of the cases (under /root/reference/tests/suites/sparsebase/):
 //   converter/converter_order_two_tests.cc:9-48,205-252,303-351   COO<->CSR copy / move / self
+//   converter/converter_order_two_tests.cc:49-160                 CSR->CSC direct, cached, multi-step
 //   format/coo_tests.cc:77-115, format/csr_tests.cc:80-115        constructor sorts
 //   permute/permute_order_two_tests.cc:27-91                      row / row+col / inverse
 //   reorder/{degree,rcm,gray}_reorder_tests.cc, reorder_tests.cc:27-125, bases/reorder_base_tests.cc
@@ -19,6 +20,8 @@ typedef format::CSR<int, int, int> CSR3;
 typedef format::COO<int, int, int> COO3;
 typedef format::HIPCSR<int, int, int> DCSR3;
 typedef format::HIPCOO<int, int, int> DCOO3;
+typedef format::CSC<int, int, int> CSC3;
+typedef format::HIPCSC<int, int, int> DCSC3;
 
 // functionality_common.inc
 static const int n = 3, nnz = 4;
@@ -34,6 +37,8 @@ static const int cn = 12, cm = 9, cnnz = 7;
 static int coo_row[7]{0, 0, 1, 3, 5, 10, 11}, coo_col[7]{0, 2, 1, 3, 3, 8, 7}, coo_vals[7]{3, 5, 7, 9, 15, 11, 13};
 static int csr_row_ptr[13]{0, 2, 3, 3, 4, 4, 5, 5, 5, 5, 5, 6, 7}, csr_col[7]{0, 2, 1, 3, 3, 8, 7},
     csr_vals[7]{3, 5, 7, 9, 15, 11, 13};
+static int csc_col_ptr[13]{0, 1, 2, 3, 5, 5, 5, 5, 6, 7, 7, 7, 7}, csc_row[7]{0, 1, 0, 3, 5, 11, 10},
+    csc_vals[7]{3, 7, 5, 9, 15, 13, 11};
 
 static context::CPUContext cpu_context;
 static std::unique_ptr<context::HIPContext> hip_context;
@@ -127,6 +132,109 @@ TEST(ConverterOrderTwo, VoidValuesAndOtherTuples) {
   EXPECT_TRUE(same(ucsr->get_row_ptr(), csr_row_ptr, cn + 1));
   EXPECT_TRUE(same(ucsr->get_vals(), csr_vals, cnnz));
   delete ucsr;
+}
+
+// converter_order_two_tests.cc:49-160: compare_cscs checks n + 1 entries of col_ptr (common.inc:68)
+static void expect_csc(format::Format *f) {
+  auto *csc = f->AsAbsolute<CSC3>();
+  EXPECT_EQ((int)csc->get_num_nnz(), cnnz);
+  EXPECT_EQ((int)csc->get_dimensions()[0], cn);
+  EXPECT_EQ((int)csc->get_dimensions()[1], cm);
+  EXPECT_TRUE(same(csc->get_col_ptr(), csc_col_ptr, cn + 1));
+  EXPECT_TRUE(same(csc->get_row(), csc_row, cnnz));
+  EXPECT_TRUE(same(csc->get_vals(), csc_vals, cnnz));
+}
+
+TEST(ConverterOrderTwo, CSRToCSCMultipleContextsAndMultiStep) {
+  CSR3 csr(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  context::CPUContext cpu1, cpu2;
+  converter::ConverterOrderTwo<int, int, int> conv;
+  CSC3 correct(cn, cm, csc_col_ptr, csc_row, csc_vals, format::kNotOwned);  // the fixture is a valid CSC (sorted)
+  EXPECT_EQ((int)correct.get_num_nnz(), cnnz);
+  auto *a = conv.Convert<CSC3>(&csr, {&cpu1, &cpu2}, false);  // templated
+  expect_csc(a);
+  delete a;
+  auto *b = conv.Convert(&csr, CSC3::get_id_static(), {&cpu1, &cpu2}, false);  // non-templated
+  expect_csc(b);
+  delete b;
+  auto *c = csr.Convert<format::CSC>({&cpu1, &cpu2}, false);  // member
+  expect_csc(c);
+  delete c;
+  // remove the direct CSR->CSC function: the chain CSR -> COO -> CSC must be found (:77-99)
+  conv.ClearConversionFunctions(CSR3::get_id_static(), CSC3::get_id_static(), false);
+  auto *d = conv.Convert<CSC3>(&csr, {&cpu1, &cpu2}, false);
+  expect_csc(d);
+  delete d;
+  auto chain = conv.ConvertCached(&csr, CSC3::get_id_static(), {&cpu1}, false);  // :142-150
+  EXPECT_EQ(chain.size(), (size_t)2);
+  if (chain.size() == 2) {
+    expect_csc(chain[1]);
+    auto *mid = chain[0]->AsAbsolute<COO3>();
+    EXPECT_TRUE(same(mid->get_row(), coo_row, cnnz));
+    EXPECT_TRUE(same(mid->get_col(), coo_col, cnnz));
+  }
+  for (auto *f : chain) delete f;
+}
+
+TEST(ConverterOrderTwo, CSRToCSCCached) {  // :101-133
+  CSR3 csr(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  converter::ConverterOrderTwo<int, int, int> conv;
+  auto out = conv.ConvertCached(&csr, CSC3::get_id_static(), {&cpu_context}, false);
+  EXPECT_EQ(out.size(), (size_t)1);
+  if (!out.empty()) expect_csc(out[0]);
+  for (auto *f : out) delete f;
+}
+
+TEST(ConverterOrderTwo, COOToCSCAndUnsortedColumns) {
+  COO3 coo(cn, cm, cnnz, coo_row, coo_col, coo_vals, format::kNotOwned);
+  auto *csc = coo.Convert<format::CSC>(&cpu_context);
+  expect_csc(csc);
+  delete csc;
+  // the CSC constructor sorts every column's (row, value) pairs when one is out of order (csc.cc:99-157)
+  int cp[4] = {0, 2, 3, 4}, r[4] = {2, 0, 1, 0}, v[4] = {7, 8, 9, 10};
+  format::CSC<int, int, int> fixed(3, 3, cp, r, v, format::kNotOwned);
+  const int want_r[4] = {0, 2, 1, 0}, want_v[4] = {8, 7, 9, 10};
+  EXPECT_TRUE(same(r, want_r, 4));
+  EXPECT_TRUE(same(v, want_v, 4));
+  // rectangular the other way (m > n), where the reference overflows: col_ptr has m + 1 entries
+  int wr[3] = {0, 1, 1}, wc[3] = {4, 0, 4}, wv[3] = {1, 2, 3};
+  COO3 wide(2, 5, 3, wr, wc, wv, format::kNotOwned);
+  auto *wcsc = wide.Convert<format::CSC>(&cpu_context);
+  const int want_cp[6] = {0, 1, 1, 1, 1, 3}, want_row[3] = {1, 0, 1}, want_val[3] = {2, 1, 3};
+  EXPECT_EQ((int)wcsc->get_num_nnz(), 3);
+  EXPECT_TRUE(same(wcsc->get_col_ptr(), want_cp, 6));
+  EXPECT_TRUE(same(wcsc->get_row(), want_row, 3));
+  EXPECT_TRUE(same(wcsc->get_vals(), want_val, 3));
+  delete wcsc;
+}
+
+TEST(HIPFormats, CSCOnDevice) {
+  CSR3 csr(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  auto *dcsr = csr.Convert<format::HIPCSR>(hip_context.get());
+  auto *dcsc = dcsr->Convert<format::HIPCSC>(hip_context.get());  // sbx_csr_to_csc in HBM
+  auto &dev = dcsc->device();
+  EXPECT_TRUE(same(fetch(dev, dcsc->get_col_ptr(), cn + 1).data(), csc_col_ptr, cn + 1));
+  EXPECT_TRUE(same(fetch(dev, dcsc->get_row(), cnnz).data(), csc_row, cnnz));
+  EXPECT_TRUE(same(fetch(dev, dcsc->get_vals(), cnnz).data(), csc_vals, cnnz));
+  auto *back = dcsc->Convert<format::CSC>(&cpu_context);  // D2H
+  expect_csc(back);
+  delete back;
+  auto *copy = static_cast<DCSC3 *>(dcsc->Clone());
+  EXPECT_TRUE(same(fetch(dev, copy->get_row(), cnnz).data(), csc_row, cnnz));
+  delete copy;
+  // host CSR straight to a device CSC: CSR -> HIPCSR -> HIPCSC (or CSR -> CSC -> HIPCSC), either chain is two hops
+  auto *direct = csr.Convert<format::HIPCSC>(hip_context.get());
+  EXPECT_TRUE(same(fetch(dev, direct->get_row(), cnnz).data(), csc_row, cnnz));
+  delete direct;
+  COO3 coo(cn, cm, cnnz, coo_row, coo_col, coo_vals, format::kNotOwned);
+  auto *dcoo = coo.Convert<format::HIPCOO>(hip_context.get());
+  auto *dcsc2 = dcoo->Convert<format::HIPCSC>(hip_context.get());
+  EXPECT_TRUE(same(fetch(dev, dcsc2->get_col_ptr(), cn + 1).data(), csc_col_ptr, cn + 1));
+  EXPECT_TRUE(same(fetch(dev, dcsc2->get_vals(), cnnz).data(), csc_vals, cnnz));
+  delete dcsc2;
+  delete dcoo;
+  delete dcsc;
+  delete dcsr;
 }
 
 // ------------------------------------------------------------------ coo_tests.cc / csr_tests.cc (Sort)
