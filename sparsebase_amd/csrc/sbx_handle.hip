@@ -88,11 +88,18 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   hipDeviceProp_t prop;
   h->num_cus = 256;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
-  if (hipHostMalloc(&h->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+  // coherent (fine-grained) so that a kernel's system-scope stores are visible to a polling host
+  if (hipHostMalloc(&h->pinned, kPinnedBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
     delete h;
     return SBX_ERR_OOM;
   }
   h->pinned_bytes = kPinnedBytes;
+  h->rb_seq = 0;
+  {
+    const char *e = getenv("SBX_READBACK_POLL");
+    h->rb_poll = !(e && e[0] == '0');
+  }
+  memset(h->pinned, 0, kPinnedBytes);
   *out = h;
   return SBX_OK;
 }
@@ -202,11 +209,51 @@ int sbx_arena_alloc(sbx_handle_t h, size_t bytes, void **out) {
   }
 }
 
+// Small device->host read-backs sit on the critical path of every BFS level.  A copy engine
+// transfer + hipStreamSynchronize costs ~20 us; instead one wave copies the words into the
+// coherent pinned buffer, fences at system scope and stores a sequence number the host
+// polls (word 0 of the buffer).  The poll is bounded: after ~1 ms without the number the host
+// falls back to hipStreamSynchronize, which also surfaces a failed kernel.
+static const size_t kReadbackHeader = 64;  // sequence word + padding to keep the payload 64-byte aligned
+
+__global__ void k_readback(unsigned *__restrict__ dst, const unsigned *__restrict__ src, unsigned words,
+                           unsigned *seq_word, unsigned seq) {
+  for (unsigned i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int sbx_readback(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes) {
-  if (bytes > h->pinned_bytes) SBX_FAIL(h, SBX_ERR_INTERNAL, "readback of %zu bytes too large", bytes);
-  SBX_HIP(h, hipMemcpyAsync(h->pinned, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
-  SBX_HIP(h, hipStreamSynchronize(h->stream));
-  memcpy(dst_host, h->pinned, bytes);
+  if (bytes + kReadbackHeader > h->pinned_bytes) SBX_FAIL(h, SBX_ERR_INTERNAL, "readback of %zu bytes too large", bytes);
+  char *payload = (char *)h->pinned + kReadbackHeader;
+  if (!h->rb_poll || (bytes & 3) || ((uintptr_t)src_dev & 3)) {
+    SBX_HIP(h, hipMemcpyAsync(payload, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    SBX_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(dst_host, payload, bytes);
+    return SBX_OK;
+  }
+  volatile unsigned *seq_word = (volatile unsigned *)h->pinned;
+  const unsigned seq = ++h->rb_seq;
+  hipLaunchKernelGGL(k_readback, dim3(1), dim3(64), 0, h->stream, (unsigned *)payload, (const unsigned *)src_dev,
+                     (unsigned)(bytes >> 2), (unsigned *)h->pinned, seq);
+  SBX_HIP(h, hipGetLastError());
+  bool seen = false;
+  for (int spin = 0; spin < 200000; spin++) {
+    if (*seq_word == seq) {
+      seen = true;
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!seen) {
+    SBX_HIP(h, hipStreamSynchronize(h->stream));
+    if (*seq_word != seq) SBX_FAIL(h, SBX_ERR_INTERNAL, "read-back kernel did not publish its sequence number");
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  memcpy(dst_host, payload, bytes);
   return SBX_OK;
 }
 

@@ -64,6 +64,8 @@ struct sbx_handle_s {
   int nest;  // > 0 while an API entry point calls another one: the arena is not rewound
   void *pinned;  // small pinned host buffer for device->host read-backs
   size_t pinned_bytes;
+  unsigned rb_seq;  // sequence number of the last polled read-back (sbx_readback)
+  bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
   int num_cus;
   // profiler: when on, every kernel launch is bracketed by HIP events on the
   // handle's stream; sbx_profile_query drains them into the accumulators

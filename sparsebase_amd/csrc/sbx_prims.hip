@@ -185,28 +185,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
   }
 }
 
-// exclusive scan of each pass's 256 bins (one workgroup)
-__global__ __launch_bounds__(RS_THREADS) void k_onesweep_bins(unsigned long long *__restrict__ ghist, int np) {
-  __shared__ unsigned long long lds[RS_THREADS / 64 + 1];
-  for (int p = 0; p < np; p++) {
-    const unsigned long long v = ghist[p * 256 + threadIdx.x];
-    unsigned long long tot;
-    const unsigned long long ex = sbx_block_exclusive_sum<unsigned long long, RS_THREADS>(v, lds, &tot);
-    ghist[p * 256 + threadIdx.x] = ex;
-  }
-}
-
 // One digit pass in a single kernel.  Tiles take a ticket (so a tile only ever waits
 // for tiles that already run), rank their keys in LDS exactly like a classic scatter
 // pass, and obtain the number of equal-digit keys in all earlier tiles by decoupled
 // look-back over per-(tile,digit) status words: (value << 2) | flag, flag 1 = this
 // tile's own count, 2 = inclusive prefix.  Each word is a self-contained granule
-// written/read with relaxed agent-scope atomics, so no fence is needed.
+// written/read with relaxed agent-scope atomics, so no fence is needed.  `ghist` holds the
+// pass's raw digit counts; every tile scans them itself (256 values) instead of paying a
+// separate one-workgroup launch per sort.
 template <typename K, typename P, int ITEMS, bool HAS_P>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const P *__restrict__ vals_in, P *__restrict__ vals_out,
                                                               int64_t count, int shift, int bits,
-                                                              const unsigned long long *__restrict__ gbase,
+                                                              const unsigned long long *__restrict__ ghist,
                                                               unsigned long long *state, unsigned *ticket) {
   constexpr int TILE = RS_THREADS * ITEMS;
   __shared__ K s_keys[TILE];
@@ -214,6 +205,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
   __shared__ uint32_t s_whist[RS_WAVES][256];
   __shared__ uint32_t s_gofs[256];
   __shared__ uint32_t s_scan[RS_WAVES + 1];
+  __shared__ unsigned long long s_scan64[RS_WAVES + 1];
   __shared__ unsigned s_tile;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(ticket, 1u);
@@ -267,6 +259,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
     if ((unsigned)tid == mask) tot_valid -= (uint32_t)(TILE - valid);
     uint32_t all;
     uint32_t ex = sbx_block_exclusive_sum<uint32_t, RS_THREADS>(tot, s_scan, &all);
+    unsigned long long gall;  // first output position of digit `tid` = exclusive scan of the global counts
+    const unsigned long long gbase =
+        sbx_block_exclusive_sum<unsigned long long, RS_THREADS>(ghist[tid], s_scan64, &gall);
     // ---- decoupled look-back for digit `tid`
     unsigned long long *mine = state + (size_t)tile * 256 + tid;
     unsigned long long before = 0;
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
       }
       __hip_atomic_store(mine, ((before + tot_valid) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_gofs[tid] = (uint32_t)(gbase[tid] + before) - ex;
+    s_gofs[tid] = (uint32_t)(gbase + before) - ex;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) {
       s_whist[i][tid] = ex;
@@ -359,7 +354,6 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   unsigned long long *state = scratch + bins_words + ticket_words;
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>), dim3(sbx_grid_for(count, RS_THREADS * 8, (int64_t)h->num_cus * 8)),
               dim3(RS_THREADS), (const K *)ka, count, plan, ghist);
-  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, k_onesweep_bins, dim3(1), dim3(RS_THREADS), ghist, np);
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
