@@ -95,6 +95,8 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   }
   h->pinned_bytes = kPinnedBytes;
   h->rb_seq = 0;
+  h->rs_pool = nullptr;
+  h->rs_next = 0;
   {
     const char *e = getenv("SBX_READBACK_POLL");
     h->rb_poll = !(e && e[0] == '0');
@@ -110,6 +112,7 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto &b : h->blocks) (void)hipFree(b.ptr);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->rs_pool) (void)hipFree(h->rs_pool);
   for (auto &r : h->prof_pending) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
@@ -121,6 +124,11 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
 
 extern "C" int sbx_set_stream(sbx_handle_t h, void *hip_stream) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (h->stream != (hipStream_t)hip_stream) {
+    // scratch (arena, radix slot pool, pinned read-back buffer) is reused in stream order: drain the old stream
+    SBX_HIP(h, hipSetDevice(h->device));
+    SBX_HIP(h, hipStreamSynchronize(h->stream));
+  }
   h->stream = (hipStream_t)hip_stream;
   return SBX_OK;
 }
@@ -207,6 +215,21 @@ int sbx_arena_alloc(sbx_handle_t h, size_t bytes, void **out) {
     if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
     SBX_TRY(arena_add_block(h, want));
   }
+}
+
+int sbx_radix_slot(sbx_handle_t h, void **slot) {
+  if (!h->rs_pool) {
+    SBX_HIP(h, hipMalloc(&h->rs_pool, (size_t)SBX_RS_SLOTS * SBX_RS_SLOT_BYTES));
+    h->rs_next = SBX_RS_SLOTS;  // forces the first memset
+  }
+  if (h->rs_next >= SBX_RS_SLOTS) {
+    // every earlier user of the pool was enqueued on this stream, so the memset is ordered after them
+    SBX_HIP(h, hipMemsetAsync(h->rs_pool, 0, (size_t)SBX_RS_SLOTS * SBX_RS_SLOT_BYTES, h->stream));
+    h->rs_next = 0;
+  }
+  *slot = (char *)h->rs_pool + (size_t)h->rs_next * SBX_RS_SLOT_BYTES;
+  h->rs_next++;
+  return SBX_OK;
 }
 
 // Small device->host read-backs sit on the critical path of every BFS level.  A copy engine

@@ -64,6 +64,10 @@ struct sbx_handle_s {
   int nest;  // > 0 while an API entry point calls another one: the arena is not rewound
   void *pinned;  // small pinned host buffer for device->host read-backs
   size_t pinned_bytes;
+  // pool of pre-zeroed (digit histogram + ticket) slots for the radix sort: one memset per
+  // SBX_RS_SLOTS sorts instead of one per sort (every memset is a launch on the critical path)
+  void *rs_pool;
+  int rs_next;
   unsigned rb_seq;  // sequence number of the last polled read-back (sbx_readback)
   bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
   int num_cus;
@@ -130,6 +134,11 @@ static inline int sbx_salloc(sbx_handle_t h, size_t count, T **out) {
   *out = (T *)p;
   return rc;
 }
+
+#define SBX_RS_SLOTS 32
+#define SBX_RS_SLOT_BYTES (8 * 256 * 8 + 256)  /* RS_MAX_PASSES x 256 u64 counts + tickets */
+// next zeroed radix slot (device pointer); re-zeroes the pool in stream order when it wraps
+int sbx_radix_slot(sbx_handle_t h, void **slot);
 
 // blocking read-back of `bytes` (<= pinned buffer) from device memory
 int sbx_readback(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes);

@@ -167,8 +167,13 @@ struct RadixPlan {
 // Upfront digit histograms of every pass in one read of the keys.
 template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
-                                                              unsigned long long *__restrict__ ghist) {
+                                                              unsigned long long *__restrict__ ghist,
+                                                              unsigned long long *__restrict__ state,
+                                                              size_t state_words) {
   __shared__ unsigned lh[RS_MAX_PASSES][256];
+  // the look-back status words of all passes are only touched by the pass kernels: clear them here
+  for (size_t j = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; j < state_words; j += (size_t)gridDim.x * RS_THREADS)
+    state[j] = 0;
   for (int i = threadIdx.x; i < RS_MAX_PASSES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * RS_THREADS + threadIdx.x;
@@ -343,17 +348,18 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
     plan.shift[p] = passes[p].shift;
     plan.bits[p] = passes[p].bits;
   }
-  // scratch: [np*256 bins][np tickets (padded)][np * tiles * 256 status words], zeroed once
-  const size_t bins_words = (size_t)np * 256, ticket_words = 32, state_words = (size_t)np * tiles * 256;
-  unsigned long long *scratch = nullptr;
-  SBX_TRY(sbx_salloc(h, bins_words + ticket_words + state_words, &scratch));
-  SBX_HIP(h, hipMemsetAsync(scratch, 0, (bins_words + ticket_words + state_words) * sizeof(unsigned long long),
-                            h->stream));
-  unsigned long long *ghist = scratch;
-  unsigned *tickets = (unsigned *)(scratch + bins_words);
-  unsigned long long *state = scratch + bins_words + ticket_words;
+  // zeroed (bins, tickets) slot from the handle's pool; the per-(pass, tile, digit) status words are
+  // cleared by the histogram kernel
+  static_assert(RS_MAX_PASSES * 256 * 8 + 256 <= SBX_RS_SLOT_BYTES, "radix slot too small");
+  void *slot = nullptr;
+  SBX_TRY(sbx_radix_slot(h, &slot));
+  unsigned long long *ghist = (unsigned long long *)slot;
+  unsigned *tickets = (unsigned *)((char *)slot + (size_t)RS_MAX_PASSES * 256 * 8);
+  const size_t state_words = (size_t)np * tiles * 256;
+  unsigned long long *state = nullptr;
+  SBX_TRY(sbx_salloc(h, state_words, &state));
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>), dim3(sbx_grid_for(count, RS_THREADS * 8, (int64_t)h->num_cus * 8)),
-              dim3(RS_THREADS), (const K *)ka, count, plan, ghist);
+              dim3(RS_THREADS), (const K *)ka, count, plan, ghist, state, state_words);
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
