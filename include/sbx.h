@@ -161,6 +161,24 @@ int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t
                    void *col_ptr_out, void *row_out, void *val_out);
 
 /* ------------------------------------------------------------------ *
+ * Reorder-quality features: single-pass reductions over a device CSR.
+ *   sbx_csr_degrees              feature/degrees.cc:93-105      degrees_out[i] = row_ptr[i+1] - row_ptr[i]
+ *   sbx_csr_degree_distribution  feature/degree_distribution.cc:152-167
+ *                                dist_out[i] = degree / (FeatureType)nnz, FeatureType float (4) or double (8)
+ *   sbx_csr_bandwidth            feature/bandwidth.cc:93-112    max over nonzeros of |i - j| + 1 (0 if none)
+ *   sbx_csr_profile              feature/profile.cc:91-105      sum over rows of i - min(i, smallest column);
+ *                                returned exactly in 64 bits (the reference accumulates in IDType)
+ * The two scalar results are written to host memory; the calls are synchronous.            */
+/* ------------------------------------------------------------------ */
+int sbx_csr_degrees(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, void *degrees_out);
+int sbx_csr_degree_distribution(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,
+                                const void *row_ptr, int feature_bytes, void *dist_out);
+int sbx_csr_bandwidth(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
+                      const void *col, int64_t *bandwidth_host);
+int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
+                    const void *col, int64_t *profile_host);
+
+/* ------------------------------------------------------------------ *
  * A6  DegreeReorder::CalculateReorderCSR — reorder/degree_reorder.cc:22-62
  * inv_perm_out[old_row] = new_row; ascending: (deg asc, id desc),        *
  * descending: the exact reverse.                                         */

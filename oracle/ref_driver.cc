@@ -19,6 +19,10 @@
 
 #include "sparsebase/bases/reorder_base.h"
 #include "sparsebase/context/cpu_context.h"
+#include "sparsebase/feature/bandwidth.h"
+#include "sparsebase/feature/degree_distribution.h"
+#include "sparsebase/feature/degrees.h"
+#include "sparsebase/feature/profile.h"
 #include "sparsebase/format/coo.h"
 #include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
@@ -109,6 +113,32 @@ template <typename I, typename V>
 void t_csr_to_csc(int64_t n, int64_t nnz, I *rp, I *col, V *val, I *cp_out, I *row_out, V *val_out) {
   format::CSR<I, I, V> csr((I)n, (I)n, rp, col, val, format::kNotOwned, true);
   csc_out<I, V>(&csr, n, nnz, val != nullptr, cp_out, row_out, val_out);
+}
+template <typename I, typename V>
+void t_features(int64_t n, I *rp, I *col, int64_t *bandwidth, int64_t *profile, I *degrees, float *dist_f,
+                double *dist_d) {
+  context::CPUContext cpu;
+  format::CSR<I, I, V> csr((I)n, (I)n, rp, col, nullptr, format::kNotOwned, true);
+  feature::Bandwidth<I, I, V> bw;
+  int *b = bw.GetBandwidth(&csr, {&cpu}, false);
+  *bandwidth = *b;
+  delete b;
+  feature::Profile<I, I, V> pf;
+  I *p = pf.GetProfile(&csr, {&cpu}, false);
+  *profile = (int64_t)*p;
+  delete p;
+  feature::Degrees<I, I, V> dg;
+  I *d = dg.GetDegrees(&csr, {&cpu}, false);
+  memcpy(degrees, d, n * sizeof(I));
+  delete[] d;
+  feature::DegreeDistribution<I, I, V, float> df;
+  float *f = df.GetDistribution(&csr, {&cpu}, false);
+  memcpy(dist_f, f, n * sizeof(float));
+  delete[] f;
+  feature::DegreeDistribution<I, I, V, double> dd;
+  double *g = dd.GetDistribution(&csr, {&cpu}, false);
+  memcpy(dist_d, g, n * sizeof(double));
+  delete[] g;
 }
 template <typename I, typename V>
 void t_degree(int64_t n, int64_t m, I *rp, I *col, int ascending, I *inv) {
@@ -215,6 +245,14 @@ int ref_coo_to_csc(int it, int vt, int64_t n, int64_t nnz, void *row, void *col,
 int ref_csr_to_csc(int it, int vt, int64_t n, int64_t nnz, void *rp, void *col, void *val, void *cp_out,
                    void *row_out, void *val_out) {
   TUPLE_SWITCH(it, vt, F_CSR_CSC, 0);
+  return 0;
+}
+// all four features of one square CSR (profile is returned as the reference's IDType value, widened)
+int ref_features(int it, int64_t n, void *rp, void *col, int64_t *bandwidth, int64_t *profile, void *degrees,
+                 float *dist_f, double *dist_d) {
+  if (it == 0) t_features<int, int>(n, (int *)rp, (int *)col, bandwidth, profile, (int *)degrees, dist_f, dist_d);
+  else t_features<long long, double>(n, (long long *)rp, (long long *)col, bandwidth, profile, (long long *)degrees,
+                                     dist_f, dist_d);
   return 0;
 }
 #define F_DEGREE(I, V, ...) t_degree<I, V>(n, m, (I *)rp, (I *)col, ascending, (I *)inv)

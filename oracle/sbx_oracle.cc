@@ -206,6 +206,41 @@ void csr_to_csc(int vt, int64_t n, int64_t m, int64_t nnz, const I *rp, const I 
 }
 
 // ---------------------------------------------------------------------------
+// Features
+//   bandwidth   feature/bandwidth.cc:93-112: max over nonzeros of |i - j| + 1, 0 without nonzeros
+//   profile     feature/profile.cc:91-105:   sum over rows of i - min(i, smallest column of the row); the
+//               reference accumulates in IDType — this returns the exact sum, callers narrow it
+//   degrees     feature/degrees.cc:93-105
+//   degree distribution  feature/degree_distribution.cc:152-167: degree / (FeatureType)num_edges
+// ---------------------------------------------------------------------------
+template <typename I>
+int64_t csr_bandwidth(int64_t n, const I *rp, const I *col) {
+  int64_t bw = 0;
+  for (int64_t i = 0; i < n; i++)
+    for (I k = rp[i]; k < rp[i + 1]; k++) {
+      const int64_t j = col[k];
+      const int64_t d = (i >= j ? i - j : j - i) + 1;
+      if (bw < d) bw = d;
+    }
+  return bw;
+}
+template <typename I>
+int64_t csr_profile(int64_t n, const I *rp, const I *col) {
+  int64_t sum = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t j = i;
+    for (I k = rp[i]; k < rp[i + 1]; k++)
+      if (j > col[k]) j = col[k];
+    sum += i - j;
+  }
+  return sum;
+}
+template <typename I, typename F>
+void csr_degree_distribution(int64_t n, int64_t nnz, const I *rp, F *out) {
+  for (int64_t i = 0; i < n; i++) out[i] = (rp[i + 1] - rp[i]) / (F)nnz;
+}
+
+// ---------------------------------------------------------------------------
 // A6  DegreeReorder   reorder/degree_reorder.cc:22-62
 // Intended semantics (the reference indexes `mr` one past its end, :41-45):
 // rows placed from the END of their degree bucket in id order, i.e. the final
@@ -572,6 +607,24 @@ void orc_csr_to_csc(int it, int vt, int64_t n, int64_t m, int64_t nnz, const voi
                                (int32_t *)cp_out, (int32_t *)row_out, val_out),
            csr_to_csc<int64_t>(vt, n, m, nnz, (const int64_t *)rp, (const int64_t *)col, val,
                                (int64_t *)cp_out, (int64_t *)row_out, val_out));
+}
+int64_t orc_csr_bandwidth(int it, int64_t n, const void *rp, const void *col) {
+  if (it == 0) return csr_bandwidth<int32_t>(n, (const int32_t *)rp, (const int32_t *)col);
+  return csr_bandwidth<int64_t>(n, (const int64_t *)rp, (const int64_t *)col);
+}
+int64_t orc_csr_profile(int it, int64_t n, const void *rp, const void *col) {
+  if (it == 0) return csr_profile<int32_t>(n, (const int32_t *)rp, (const int32_t *)col);
+  return csr_profile<int64_t>(n, (const int64_t *)rp, (const int64_t *)col);
+}
+void orc_csr_degrees(int it, int64_t n, const void *rp, void *out) {
+  if (it == 0) for (int64_t i = 0; i < n; i++) ((int32_t *)out)[i] = ((const int32_t *)rp)[i + 1] - ((const int32_t *)rp)[i];
+  else for (int64_t i = 0; i < n; i++) ((int64_t *)out)[i] = ((const int64_t *)rp)[i + 1] - ((const int64_t *)rp)[i];
+}
+void orc_csr_degree_distribution(int it, int fbytes, int64_t n, int64_t nnz, const void *rp, void *out) {
+  if (it == 0 && fbytes == 4) csr_degree_distribution<int32_t, float>(n, nnz, (const int32_t *)rp, (float *)out);
+  else if (it == 0) csr_degree_distribution<int32_t, double>(n, nnz, (const int32_t *)rp, (double *)out);
+  else if (fbytes == 4) csr_degree_distribution<int64_t, float>(n, nnz, (const int64_t *)rp, (float *)out);
+  else csr_degree_distribution<int64_t, double>(n, nnz, (const int64_t *)rp, (double *)out);
 }
 void orc_degree_reorder(int it, int64_t n, const void *rp, int ascending, void *inv) {
   DISPATCH(it, degree_reorder<int32_t>(n, (const int32_t *)rp, ascending, (int32_t *)inv),

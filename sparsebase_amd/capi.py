@@ -66,6 +66,10 @@ PROTOTYPES = {
     "sbx_csr_to_coo": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _u], _int),
     "sbx_coo_to_csc": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _int),
     "sbx_csr_to_csc": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _int),
+    "sbx_csr_degrees": ([_H, _int, _i64, _vp, _vp], _int),
+    "sbx_csr_degree_distribution": ([_H, _int, _i64, _i64, _vp, _int, _vp], _int),
+    "sbx_csr_bandwidth": ([_H, _int, _i64, _i64, _vp, _vp, C.POINTER(_i64)], _int),
+    "sbx_csr_profile": ([_H, _int, _i64, _i64, _vp, _vp, C.POINTER(_i64)], _int),
     "sbx_degree_reorder": ([_H, _int, _i64, _vp, _int, _vp], _int),
     "sbx_rcm_reorder": ([_H, _int, _i64, _i64, _vp, _vp, _vp, C.POINTER(RcmStats)], _int),
     "sbx_gray_row_keys": ([_H, _int, _i64, _i64, _i64, _vp, _vp, _int, _int, _vp, _vp, C.POINTER(_i64)], _int),

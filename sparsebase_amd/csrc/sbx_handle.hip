@@ -331,7 +331,7 @@ extern "C" int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, co
 const char *const sbx_kernel_names[SBX_K_COUNT] = {
     "scan",          "radix_hist",   "radix_scatter", "coo_to_csr", "csr_to_coo", "permute_tile",
     "permute_long",  "permute_block", "permute_prep", "bfs_expand",    "bfs_heavy",  "bfs_bottom_up", "bfs_small_levels",  "level_order", "cc",
-    "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "csc",  "misc"};
+    "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "csc",  "feature", "misc"};
 
 static hipEvent_t prof_event(sbx_handle_t h) {
   if (!h->prof_pool.empty()) {

@@ -193,6 +193,41 @@ int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
   return sbx_widen_i32(h, ro, row_out, nnz);
 }
 
+int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SCRATCH32(deg, n, true);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  SBX_TRY(sbx_csr_degrees(h, SBX_I32, n, rp, deg));
+  return sbx_widen_i32(h, deg, degrees_out, n);
+}
+
+int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
+                                    void *dist_out) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_csr_degree_distribution(h, SBX_I32, n, nnz, rp, feature_bytes, dist_out);
+}
+
+int sbx_i64_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                          int64_t *bandwidth_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_csr_bandwidth(h, SBX_I32, n, nnz, rp, c, bandwidth_host);
+}
+
+int sbx_i64_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                        int64_t *profile_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  NARROW(c, col, nnz);
+  SBX_TRY(sbx_i64_check(h, ovf));
+  return sbx_csr_profile(h, SBX_I32, n, nnz, rp, c, profile_host);
+}
+
 int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
   I64_BEGIN();
   NARROW(rp, row_ptr, n + 1);

@@ -35,6 +35,7 @@ enum sbx_kernel_id {
   SBX_K_DEGREE,
   SBX_K_CHECK,
   SBX_K_CSC,
+  SBX_K_FEATURE,
   SBX_K_MISC,
   SBX_K_COUNT
 };
@@ -217,6 +218,13 @@ int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
 int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
+int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out);
+int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
+                                    void *dist_out);
+int sbx_i64_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                          int64_t *bandwidth_host);
+int sbx_i64_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                        int64_t *profile_host);
 int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out);
 int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
                         void *inv_perm_out, sbx_rcm_stats *stats_host);

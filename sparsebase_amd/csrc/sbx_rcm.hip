@@ -361,6 +361,12 @@ __global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbi
 // append must not cost one atomic per ballot.
 constexpr int RCM_STAGE = 512;  // staged vertices per wave
 
+// bottom-up is chosen when the frontier owns more than this many times the edges of the unvisited rest
+static double bu_ratio() {
+  static const double r = getenv("SBX_DEBUG_BU_RATIO") ? atof(getenv("SBX_DEBUG_BU_RATIO")) : 4.0;
+  return r;
+}
+
 struct WaveStage {
   I *buf;                  // this wave's LDS slice
   unsigned cnt;            // wave-uniform fill level
@@ -975,7 +981,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     }
     try_small = true;
     if (!expanded_by_small) {
-    const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && frontier_edges > 4 * remaining;
+    const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
     if (bottom_up) {
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
@@ -1003,7 +1009,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     I *q_next = b.q + off + fsize;
     // direction of the NEXT expansion is already decidable: the frontier marks (bitmap +
     // level positions) are only written when it will be bottom-up
-    const bool next_bottom_up = nf >= 8192 && frontier_edges > 4 * remaining;
+    const bool next_bottom_up = nf >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
     const int mark_frontier = next_bottom_up ? 1 : 0;
     if (mark_frontier) SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
     if (nf <= RCM_LDS_SORT) {

@@ -187,6 +187,39 @@ def csr_to_csc(n, m, row_ptr, col, val=None):
     return cp, ro, vo
 
 
+# ----------------------------------------------------------------------------- features
+def csr_degrees(row_ptr):
+    hd = handle_for(_check_dev(row_ptr))
+    n = row_ptr.numel() - 1
+    out = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
+    hd.check(hd.lib.sbx_csr_degrees(hd.h, _it(row_ptr), n, _p(row_ptr), _p(out)))
+    return out
+
+
+def csr_degree_distribution(row_ptr, nnz, dtype=torch.float32):
+    hd = handle_for(_check_dev(row_ptr))
+    n = row_ptr.numel() - 1
+    out = torch.empty(n, dtype=dtype, device=row_ptr.device)
+    hd.check(hd.lib.sbx_csr_degree_distribution(hd.h, _it(row_ptr), n, nnz, _p(row_ptr), out.element_size(), _p(out)))
+    return out
+
+
+def csr_bandwidth(row_ptr, col):
+    hd = handle_for(_check_dev(row_ptr, col))
+    out = C.c_int64(0)
+    hd.check(hd.lib.sbx_csr_bandwidth(hd.h, _it(row_ptr), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
+                                      C.byref(out)))
+    return out.value
+
+
+def csr_profile(row_ptr, col):
+    hd = handle_for(_check_dev(row_ptr, col))
+    out = C.c_int64(0)
+    hd.check(hd.lib.sbx_csr_profile(hd.h, _it(row_ptr), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
+                                    C.byref(out)))
+    return out.value
+
+
 # ----------------------------------------------------------------------------- reorderers
 def degree_reorder(row_ptr, ascending=True, out=None):
     hd = handle_for(_check_dev(row_ptr))

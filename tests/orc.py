@@ -54,6 +54,8 @@ class Oracle:
         self.lib.orc_csr_rows_sorted.restype = C.c_int
         self.lib.orc_gray_reorder.restype = C.c_int
         self.lib.orc_gray_row_keys.restype = C.c_int
+        self.lib.orc_csr_bandwidth.restype = C.c_int64
+        self.lib.orc_csr_profile.restype = C.c_int64
 
     def coo_is_sorted(self, row, col):
         return bool(self.lib.orc_coo_is_sorted(it_of(row), C.c_int64(len(row)), _p(row), _p(col)))
@@ -90,6 +92,23 @@ class Oracle:
         self.lib.orc_csr_to_coo(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(nnz), _p(rp), _p(col),
                                 _p(val), _p(ro), _p(co), _p(vo))
         return ro, co, vo
+
+    def csr_bandwidth(self, rp, col):
+        return int(self.lib.orc_csr_bandwidth(it_of(rp), C.c_int64(len(rp) - 1), _p(rp), _p(col)))
+
+    def csr_profile(self, rp, col):
+        return int(self.lib.orc_csr_profile(it_of(rp), C.c_int64(len(rp) - 1), _p(rp), _p(col)))
+
+    def csr_degrees(self, rp):
+        out = np.empty(len(rp) - 1, rp.dtype)
+        self.lib.orc_csr_degrees(it_of(rp), C.c_int64(len(rp) - 1), _p(rp), _p(out))
+        return out
+
+    def csr_degree_distribution(self, rp, nnz, dtype=np.float32):
+        out = np.empty(len(rp) - 1, dtype)
+        self.lib.orc_csr_degree_distribution(it_of(rp), out.itemsize, C.c_int64(len(rp) - 1), C.c_int64(nnz), _p(rp),
+                                             _p(out))
+        return out
 
     def coo_to_csc(self, n, m, row, col, val=None):
         nnz = len(row)
@@ -214,6 +233,16 @@ class Ref:
         self._chk(self.lib.ref_csr_to_coo(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(m),
                                           C.c_int64(nnz), _p(rp), _p(col), _p(val), _p(ro), _p(co), _p(vo)))
         return ro, co, vo
+
+    def features(self, rp, col):
+        """(bandwidth, profile as IDType, degrees, float distribution, double distribution) of a square CSR."""
+        n = len(rp) - 1
+        bw, pf = C.c_int64(0), C.c_int64(0)
+        deg = np.empty(n, rp.dtype)
+        df, dd = np.empty(n, np.float32), np.empty(n, np.float64)
+        self._chk(self.lib.ref_features(it_of(rp), C.c_int64(n), _p(rp), _p(col), C.byref(bw), C.byref(pf), _p(deg),
+                                        _p(df), _p(dd)))
+        return bw.value, pf.value, deg, df, dd
 
     def coo_to_csc(self, n, m, row, col, val=None):
         assert n == m, "the reference's COO->CSC is only memory-safe for square matrices"

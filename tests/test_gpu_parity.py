@@ -98,6 +98,34 @@ def test_csc_degenerate(ops, oracle):
          oracle.coo_to_csc(3, 3, one, one, np.array([1.5], np.float32)))
 
 
+# ----------------------------------------------------------------------------- features
+@pytest.mark.parametrize("seed", range(4))
+def test_features_vs_oracle(ops, oracle, seed):
+    g = np.random.default_rng(950 + seed)
+    if seed == 0:
+        rp, col = synth.rmat_symmetric(15, 8, seed=3)           # hubs: rows far longer than a workgroup's share
+    elif seed == 1:
+        rp, col = synth.banded_symmetric(50000, 37, per_row=6, seed=2)
+    else:
+        n = int(g.integers(1, 5000))
+        key = np.unique(g.integers(0, n * n, int(g.integers(0, 60000))))
+        rp, col, _ = oracle.coo_to_csr(n, (key // n).astype(np.int32), (key % n).astype(np.int32))
+        if seed == 3 and len(col) > 2:                           # unsorted rows
+            col = col[::-1].copy()
+            rp = (len(col) - rp[::-1]).astype(np.int32)
+    for dt in (np.int32, np.int64):
+        r, c = rp.astype(dt), col.astype(dt)
+        assert ops.csr_bandwidth(dev(r), dev(c)) == oracle.csr_bandwidth(r, c)
+        assert ops.csr_profile(dev(r), dev(c)) == oracle.csr_profile(r, c)
+        assert np.array_equal(host(ops.csr_degrees(dev(r))), oracle.csr_degrees(r))
+        if len(c):
+            for tdt, ndt in ((torch.float32, np.float32), (torch.float64, np.float64)):
+                assert np.array_equal(host(ops.csr_degree_distribution(dev(r), len(c), tdt)),
+                                      oracle.csr_degree_distribution(r, len(c), ndt))
+    z = np.zeros(0, np.int32)
+    assert ops.csr_bandwidth(dev(np.zeros(5, np.int32)), dev(z)) == 0 and ops.csr_profile(dev(np.zeros(5, np.int32)), dev(z)) == 0
+
+
 # ----------------------------------------------------------------------------- reference KATs
 def test_kat_conversions(ops, kat):
     for name in ("converter_12x9", "format_4x4"):
