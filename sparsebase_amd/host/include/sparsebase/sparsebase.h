@@ -7,6 +7,10 @@
 #include "sparsebase/converter/converter_order_one.h"
 #include "sparsebase/converter/converter_order_two.h"
 #include "sparsebase/format/array.h"
+#include "sparsebase/feature/bandwidth.h"
+#include "sparsebase/feature/degree_distribution.h"
+#include "sparsebase/feature/degrees.h"
+#include "sparsebase/feature/profile.h"
 #include "sparsebase/format/coo.h"
 #include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"

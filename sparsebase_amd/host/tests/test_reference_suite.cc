@@ -7,6 +7,7 @@
 //   permute/permute_order_two_tests.cc:27-91                      row / row+col / inverse
 //   reorder/{degree,rcm,gray}_reorder_tests.cc, reorder_tests.cc:27-125, bases/reorder_base_tests.cc
 //   converter/converter_order_two_cuda_tests.cu:11-49             host<->device round trips
+//   feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc  reorder-quality features
 // Fixtures: functionality_common.inc:6-44, converter/common.inc:5-16, format/common.inc:4-12.
 #include <algorithm>
 #include <memory>
@@ -235,6 +236,92 @@ TEST(HIPFormats, CSCOnDevice) {
   delete dcoo;
   delete dcsc;
   delete dcsr;
+}
+
+// ------------------------------------------------------------------ feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc
+TEST(Features, BandwidthProfileDegreesDistribution) {
+  const int fn = 7, fnnz = 12;  // bandwidth_tests.cc:33-48, profile_tests.cc:33-48
+  int frp[fn + 1] = {0, 2, 2, 5, 7, 9, 11, 12}, fcol[fnnz] = {2, 3, 0, 3, 4, 0, 2, 2, 5, 4, 6, 5};
+  format::CSR<int, int, void> csr(fn, fn, frp, fcol, nullptr, format::kNotOwned);
+  feature::Bandwidth<int, int, void> bw;
+  EXPECT_EQ(bw.get_sub_ids().size(), (size_t)1);
+  EXPECT_TRUE(bw.get_sub_ids()[0] == std::type_index(typeid(bw)));
+  auto subs = bw.get_subs();
+  EXPECT_EQ(subs.size(), (size_t)1);
+  EXPECT_TRUE(std::type_index(typeid(*subs[0])) == std::type_index(typeid(bw)));
+  EXPECT_NE(subs[0], (utils::Extractable *)&bw);
+  delete subs[0];
+  utils::Parameters p1;
+  int *b = feature::Bandwidth<int, int, void>::GetBandwidthCSR({&csr}, &p1);
+  EXPECT_EQ(*b, 4);
+  delete b;
+  for (bool convert : {true, false}) {
+    b = bw.GetBandwidth(&csr, {&cpu_context}, convert);
+    EXPECT_EQ(*b, 4);
+    delete b;
+  }
+  auto fmap = bw.Extract(&csr, {&cpu_context}, true);
+  EXPECT_EQ(fmap.size(), (size_t)1);
+  EXPECT_EQ(*std::any_cast<int *>(fmap[bw.get_id()]), 4);
+  delete std::any_cast<int *>(fmap[bw.get_id()]);
+  feature::Profile<int, int, void> pf;
+  int *p = pf.GetProfile(&csr, {&cpu_context}, true);
+  EXPECT_EQ(*p, 9);
+  delete p;
+  auto cached = pf.GetProfileCached(&csr, {&cpu_context}, true);
+  EXPECT_EQ(*std::get<1>(cached), 9);
+  delete std::get<1>(cached);
+  // degrees + distribution on the converter fixture; a COO input needs a conversion (degrees_tests.cc:75)
+  CSR3 c12(cn, cm, csr_row_ptr, csr_col, csr_vals, format::kNotOwned);
+  feature::Degrees<int, int, int> dg;
+  int *deg = dg.GetDegrees(&c12, {&cpu_context}, true);
+  for (int i = 0; i < cn; i++) EXPECT_EQ(deg[i], csr_row_ptr[i + 1] - csr_row_ptr[i]);
+  delete[] deg;
+  COO3 coo(cn, cm, cnnz, coo_row, coo_col, coo_vals, format::kNotOwned);
+  EXPECT_THROW(dg.GetDegrees(&coo, {&cpu_context}, false), utils::DirectExecutionNotAvailableException<std::vector<std::type_index>>);
+  deg = dg.GetDegrees(&coo, {&cpu_context}, true);
+  for (int i = 0; i < cn; i++) EXPECT_EQ(deg[i], csr_row_ptr[i + 1] - csr_row_ptr[i]);
+  delete[] deg;
+  feature::DegreeDistribution<int, int, int, float> dd;
+  float *dist = dd.GetDistribution(&c12, {&cpu_context}, true);
+  for (int i = 0; i < cn; i++) EXPECT_EQ(dist[i], (csr_row_ptr[i + 1] - csr_row_ptr[i]) / (float)cnnz);
+  delete[] dist;
+  // device-resident input: the {HIPCSR} implementation, nothing staged
+  auto *dcsr = csr.Convert<format::HIPCSR>(hip_context.get());
+  b = bw.GetBandwidth(dcsr, {hip_context.get()}, false);
+  EXPECT_EQ(*b, 4);
+  delete b;
+  p = pf.GetProfile(dcsr, {hip_context.get()}, false);
+  EXPECT_EQ(*p, 9);
+  delete p;
+  delete dcsr;
+  // what the features are for: RCM lowers the bandwidth of a shuffled band matrix
+  {
+    const int gn = 400;
+    std::vector<int> perm(gn), grp(gn + 1, 0), gcol;
+    std::iota(perm.begin(), perm.end(), 0);
+    for (int i = gn - 1; i > 0; i--) std::swap(perm[i], perm[(i * 7919 + 13) % (i + 1)]);
+    std::vector<std::vector<int>> adj(gn);
+    for (int i = 0; i < gn; i++)
+      for (int d = -2; d <= 2; d++)
+        if (d != 0 && i + d >= 0 && i + d < gn) adj[perm[i]].push_back(perm[i + d]);
+    for (int i = 0; i < gn; i++) {
+      std::sort(adj[i].begin(), adj[i].end());
+      gcol.insert(gcol.end(), adj[i].begin(), adj[i].end());
+      grp[i + 1] = (int)gcol.size();
+    }
+    format::CSR<int, int, void> g(gn, gn, grp.data(), gcol.data(), nullptr, format::kNotOwned);
+    int *before = bw.GetBandwidth(&g, {&cpu_context}, true);
+    int *order = bases::ReorderBase::Reorder<reorder::RCMReorder>({}, &g, {&cpu_context}, true);
+    auto *pg = bases::ReorderBase::Permute2D(order, &g, {&cpu_context}, true);
+    int *after = bw.GetBandwidth(pg, {&cpu_context}, true);
+    EXPECT_TRUE(*after <= 5);
+    EXPECT_TRUE(*after < *before);
+    delete before;
+    delete after;
+    delete[] order;
+    delete pg;
+  }
 }
 
 // ------------------------------------------------------------------ coo_tests.cc / csr_tests.cc (Sort)

@@ -99,6 +99,12 @@ def test_csc_degenerate(ops, oracle):
 
 
 # ----------------------------------------------------------------------------- features
+def test_kat_features(ops, kat):
+    k = kat["feature_7x7"]  # feature/bandwidth_tests.cc:33-48, feature/profile_tests.cc:33-48
+    rp, col = dev(a32(k["row_ptr"])), dev(a32(k["col"]))
+    assert ops.csr_bandwidth(rp, col) == k["bandwidth"] and ops.csr_profile(rp, col) == k["profile"]
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_features_vs_oracle(ops, oracle, seed):
     g = np.random.default_rng(950 + seed)
