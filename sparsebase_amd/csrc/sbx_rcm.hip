@@ -756,9 +756,11 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
 // (SL_STOP_EXPANDED: nf_list / dv->nf / dv->fedges are exactly what the general
 // expansion kernels would have left).
 constexpr unsigned SL_DONE = 0, SL_STOP_READY = 1, SL_STOP_EXPANDED = 2;
-constexpr int SL_MAXF = 1024;    // frontier vertices handled in-kernel
-constexpr int SL_MAXE = 32768;   // frontier adjacency entries handled in-kernel
-constexpr int SL_CAP = 2048;     // next-level vertices that fit the LDS sort
+constexpr int SL_MAXF = 4096;    // frontier vertices handled in-kernel
+constexpr int SL_MAXE = 32768;   // frontier adjacency entries handled in-kernel (32 per thread)
+constexpr int SL_CAP = 8192;     // next-level vertices that fit the LDS sort
+constexpr int SL_FPT = SL_MAXF / 1024;  // frontier entries per thread in the degree scan
+static_assert(SL_MAXE <= 32 * 1024, "the plain sweep keeps one winner bit per entry of a thread's run");
 
 template <bool CM>
 __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__ rp, const I *__restrict__ col,
@@ -770,6 +772,9 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
                                                            RcmDev *dv) {
   __shared__ uint64_t s_key[SL_CAP];
   __shared__ I s_front[SL_MAXF];
+  __shared__ I s_start[SL_MAXF];          // rp[u] of every frontier vertex
+  __shared__ unsigned s_eoff[SL_MAXF];    // exclusive prefix of the frontier degrees
+  __shared__ unsigned s_escan[1024 / 64 + 1];
   __shared__ unsigned s_cnt;
   __shared__ unsigned long long s_deg[1024 / 64 + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -780,23 +785,48 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
   __syncthreads();
   while (true) {
     if (fsize > SL_MAXF) break;  // status stays SL_STOP_READY
-    // degree sum of the frontier
-    unsigned long long dsum = 0;
-    for (unsigned i = tid; i < fsize; i += 1024) dsum += (unsigned long long)(rp[s_front[i] + 1] - rp[s_front[i]]);
-    dsum = sbx_block_sum<unsigned long long, 1024>(dsum, s_deg);
+    // adjacency offsets of the frontier: s_start[i] = rp[u_i], s_eoff[i] = degrees of u_0..u_{i-1}
+    unsigned dl[SL_FPT];
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < SL_FPT; k++) {
+      const unsigned i = (unsigned)tid * SL_FPT + k;
+      dl[k] = 0;
+      if (i < fsize) {
+        const I u = s_front[i];
+        const I s0 = rp[u];
+        s_start[i] = s0;
+        dl[k] = (unsigned)(rp[u + 1] - s0);
+      }
+      mine += dl[k];
+    }
+    unsigned etotal;
+    unsigned run = sbx_block_exclusive_sum<unsigned, 1024>(mine, s_escan, &etotal);
+#pragma unroll
+    for (int k = 0; k < SL_FPT; k++) {
+      const unsigned i = (unsigned)tid * SL_FPT + k;
+      if (i < fsize) s_eoff[i] = run;
+      run += dl[k];
+    }
+    const unsigned long long dsum = etotal;
     if (tid == 0) {
       s_cnt = 0;
       dv->fedges = dsum;  // what the host's direction heuristic expects for this frontier
     }
     if (dsum > (unsigned long long)SL_MAXE) break;  // SL_STOP_READY
     __syncthreads();
-    // ---- expand: one wave per frontier vertex
+    // ---- expand, flattened over the frontier's adjacency entries: thread -> entry e, its frontier
+    // position by binary search in the LDS prefix (a wave per vertex left 60 of 64 lanes idle on meshes)
     unsigned long long wdeg = 0;
-    for (unsigned p = w; p < fsize; p += 16) {
-      const I u = s_front[p];
-      const I s0 = rp[u], e0 = rp[u + 1];
-      for (I j = s0 + lane; j < e0; j += 64) {
-        const I v = col[j];
+    if (CM) {
+      for (unsigned e = tid; e < etotal; e += 1024) {
+        unsigned lo = 0, hi = fsize - 1;  // last i with s_eoff[i] <= e
+        while (lo < hi) {
+          const unsigned mid = (lo + hi + 1) >> 1;
+          if (s_eoff[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const unsigned p = lo;
+        const I v = col[s_start[p] + (I)(e - s_eoff[p])];
         const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((word >> (v & 31)) & 1u) continue;
         if (atomicMin(&ppos[v], p) == UNSEEN) {
@@ -806,6 +836,65 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
           wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
         }
       }
+    } else {
+      // Plain BFS order is (parent position, id) = the order of the WINNING adjacency entries in
+      // the flattened entry numbering (rows are column-sorted), so the new level needs no sort:
+      // pass 1 settles the smallest parent position of every neighbour, pass 2 walks the entries
+      // in order (a contiguous run per thread), keeps those that won and compacts them.
+      for (unsigned e = tid; e < etotal; e += 1024) {
+        unsigned lo = 0, hi = fsize - 1;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi + 1) >> 1;
+          if (s_eoff[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const I v = col[s_start[lo] + (I)(e - s_eoff[lo])];
+        const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!((word >> (v & 31)) & 1u)) atomicMin(&ppos[v], lo);
+      }
+      __syncthreads();
+      const unsigned per = (etotal + 1023u) / 1024u;  // <= SL_MAXE / 1024 = 32 entries per thread
+      const unsigned e0 = (unsigned)tid * per;
+      const unsigned e1 = e0 + per < etotal ? e0 + per : etotal;
+      unsigned won = 0, cntw = 0;
+      unsigned pfirst = 0;
+      if (e0 < etotal) {
+        unsigned lo = 0, hi = fsize - 1;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi + 1) >> 1;
+          if (s_eoff[mid] <= e0) lo = mid; else hi = mid - 1;
+        }
+        pfirst = lo;
+        unsigned pcur = lo;
+        for (unsigned e = e0; e < e1; e++) {
+          while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
+          const I j = s_start[pcur] + (I)(e - s_eoff[pcur]);
+          const I v = col[j];
+          const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool w1 = !((word >> (v & 31)) & 1u) &&
+                    __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pcur;
+          if (w1 && e > s_eoff[pcur] && col[j - 1] == v) w1 = false;  // duplicate entry: the first one counts
+          if (w1) {
+            won |= 1u << (e - e0);
+            cntw++;
+          }
+        }
+      }
+      unsigned nfw;
+      unsigned slot = sbx_block_exclusive_sum<unsigned, 1024>(cntw, s_escan, &nfw);
+      if (tid == 0) s_cnt = nfw;
+      unsigned pcur = pfirst;
+      for (unsigned e = e0; won; e++) {
+        while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
+        if (won & 1u) {
+          const I v = col[s_start[pcur] + (I)(e - s_eoff[pcur])];
+          if (slot < (unsigned)SL_CAP) s_key[slot] = (uint64_t)(uint32_t)v;
+          nf_list[slot] = v;
+          wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
+          slot++;
+        }
+        won >>= 1;
+      }
+      __syncthreads();
     }
     scanned += dsum;
     wdeg = sbx_block_sum<unsigned long long, 1024>(wdeg, s_deg);
@@ -823,33 +912,36 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       break;
     }
     ordered_edges += wdeg;  // degrees of the vertices discovered (and ordered) in-kernel
-    // ---- order the new level: bitonic sort of (parent position, id | degree rank)
-    unsigned p2 = 1;
-    while (p2 < nf) p2 <<= 1;
-    for (unsigned j = tid; j < p2; j += 1024) {
-      uint64_t k = ~0ull;
-      if (j < nf) {
-        const I v = (I)(uint32_t)s_key[j];
-        const unsigned pp = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k = ((uint64_t)pp << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+    // ---- order the new level (Cuthill-McKee sweep): bitonic sort of (parent position, degree rank);
+    // the plain sweep's compaction above already produced the final order
+    if (CM) {
+      unsigned p2 = 1;
+      while (p2 < nf) p2 <<= 1;
+      for (unsigned j = tid; j < p2; j += 1024) {
+        uint64_t k = ~0ull;
+        if (j < nf) {
+          const I v = (I)(uint32_t)s_key[j];
+          const unsigned pp = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          k = ((uint64_t)pp << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+        }
+        s_key[j] = k;
       }
-      s_key[j] = k;
-    }
-    __syncthreads();
-    for (unsigned k = 2; k <= p2; k <<= 1) {
-      for (unsigned j = k >> 1; j > 0; j >>= 1) {
-        for (unsigned t = tid; t < p2; t += 1024) {
-          const unsigned l = t ^ j;
-          if (l > t) {
-            const uint64_t a = s_key[t], b = s_key[l];
-            const bool up = (t & k) == 0;
-            if ((a > b) == up) {
-              s_key[t] = b;
-              s_key[l] = a;
+      __syncthreads();
+      for (unsigned k = 2; k <= p2; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+          for (unsigned t = tid; t < p2; t += 1024) {
+            const unsigned l = t ^ j;
+            if (l > t) {
+              const uint64_t a = s_key[t], b = s_key[l];
+              const bool up = (t & k) == 0;
+              if ((a > b) == up) {
+                s_key[t] = b;
+                s_key[l] = a;
+              }
             }
           }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
     // ---- publish: clear the old frontier bits, write q / bitmaps / positions of the new level
@@ -933,6 +1025,7 @@ struct BfsBuffers {
   const uint32_t *drank, *dorder;
   RcmDev *dv;
   int64_t n;
+  unsigned max_deg;  // largest degree of the graph: no hub kernel launches when nothing exceeds RCM_LIGHT
 };
 
 struct BfsResult {
@@ -993,9 +1086,10 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       if (grid < 1) grid = 1;
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
                   level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.dv);
-      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
-                  (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
-                  (const uint64_t *)b.heavy, b.dv);
+      if (b.max_deg > (unsigned)RCM_LIGHT)  // mesh-like inputs have no hubs: one launch less per level
+        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
+                    (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
+                    (const uint64_t *)b.heavy, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
@@ -1114,6 +1208,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
   b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
+  b.max_deg = hd0.max_deg;
   // (2) The smallest non-isolated vertex v0 is the smallest id of its component, i.e. the
   // start of that component's pseudo-peripheral search.  Its first BFS sweep is needed
   // anyway and yields the component's membership for free, so the union-find below only
