@@ -760,6 +760,7 @@ constexpr int SL_MAXF = 4096;    // frontier vertices handled in-kernel
 constexpr int SL_MAXE = 32768;   // frontier adjacency entries handled in-kernel (32 per thread)
 constexpr int SL_CAP = 8192;     // next-level vertices that fit the LDS sort
 constexpr int SL_FPT = SL_MAXF / 1024;  // frontier entries per thread in the degree scan
+constexpr int SL_GROUP = 64;            // children of one parent ordered by counting (longer: bitonic sort)
 static_assert(SL_MAXE <= 32 * 1024, "the plain sweep keeps one winner bit per entry of a thread's run");
 
 template <bool CM>
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
   __shared__ I s_start[SL_MAXF];          // rp[u] of every frontier vertex
   __shared__ unsigned s_eoff[SL_MAXF];    // exclusive prefix of the frontier degrees
   __shared__ unsigned s_escan[1024 / 64 + 1];
+  __shared__ uint16_t s_rank[SL_CAP];     // Cuthill-McKee sweep: where an entry moves inside its parent's group
   __shared__ unsigned s_cnt;
   __shared__ unsigned long long s_deg[1024 / 64 + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -818,29 +820,13 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
     // ---- expand, flattened over the frontier's adjacency entries: thread -> entry e, its frontier
     // position by binary search in the LDS prefix (a wave per vertex left 60 of 64 lanes idle on meshes)
     unsigned long long wdeg = 0;
-    if (CM) {
-      for (unsigned e = tid; e < etotal; e += 1024) {
-        unsigned lo = 0, hi = fsize - 1;  // last i with s_eoff[i] <= e
-        while (lo < hi) {
-          const unsigned mid = (lo + hi + 1) >> 1;
-          if (s_eoff[mid] <= e) lo = mid; else hi = mid - 1;
-        }
-        const unsigned p = lo;
-        const I v = col[s_start[p] + (I)(e - s_eoff[p])];
-        const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((word >> (v & 31)) & 1u) continue;
-        if (atomicMin(&ppos[v], p) == UNSEEN) {
-          const unsigned slot = atomicAdd(&s_cnt, 1u);
-          if (slot < (unsigned)SL_CAP) s_key[slot] = (uint64_t)(uint32_t)v;  // in-kernel copy (LDS)
-          nf_list[slot] = v;  // complete list for the hand-off case
-          wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
-        }
-      }
-    } else {
+    {
       // Plain BFS order is (parent position, id) = the order of the WINNING adjacency entries in
       // the flattened entry numbering (rows are column-sorted), so the new level needs no sort:
       // pass 1 settles the smallest parent position of every neighbour, pass 2 walks the entries
-      // in order (a contiguous run per thread), keeps those that won and compacts them.
+      // in order (a contiguous run per thread), keeps those that won and compacts them.  The
+      // Cuthill-McKee sweep gets its children grouped by parent the same way and then only
+      // orders each parent's group by degree rank.
       for (unsigned e = tid; e < etotal; e += 1024) {
         unsigned lo = 0, hi = fsize - 1;
         while (lo < hi) {
@@ -887,7 +873,8 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
         while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
         if (won & 1u) {
           const I v = col[s_start[pcur] + (I)(e - s_eoff[pcur])];
-          if (slot < (unsigned)SL_CAP) s_key[slot] = (uint64_t)(uint32_t)v;
+          if (slot < (unsigned)SL_CAP)
+            s_key[slot] = CM ? (((uint64_t)pcur << 32) | (uint64_t)drank[v]) : (uint64_t)(uint32_t)v;
           nf_list[slot] = v;
           wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
           slot++;
@@ -912,52 +899,76 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       break;
     }
     ordered_edges += wdeg;  // degrees of the vertices discovered (and ordered) in-kernel
-    // ---- order the new level (Cuthill-McKee sweep): bitonic sort of (parent position, degree rank);
-    // the plain sweep's compaction above already produced the final order
+    // ---- Cuthill-McKee sweep: s_key holds (parent position << 32 | degree rank), grouped by parent.
+    // Groups of <= SL_GROUP children (every mesh) are ordered by counting smaller ranks inside the
+    // group; a longer group (a hub) falls back to a bitonic sort of the whole level.
     if (CM) {
-      unsigned p2 = 1;
-      while (p2 < nf) p2 <<= 1;
-      for (unsigned j = tid; j < p2; j += 1024) {
-        uint64_t k = ~0ull;
-        if (j < nf) {
-          const I v = (I)(uint32_t)s_key[j];
-          const unsigned pp = __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          k = ((uint64_t)pp << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
-        }
-        s_key[j] = k;
+      unsigned maxc = 0;
+      for (unsigned j = tid; j < nf; j += 1024) {
+        const uint64_t kj = s_key[j];
+        const uint32_t pj = (uint32_t)(kj >> 32);
+        unsigned a = j, bnd = j + 1;
+        while (a > 0 && (uint32_t)(s_key[a - 1] >> 32) == pj && j - a < (unsigned)SL_GROUP) a--;
+        while (bnd < nf && (uint32_t)(s_key[bnd] >> 32) == pj && bnd - a <= (unsigned)SL_GROUP) bnd++;
+        const unsigned c = bnd - a;
+        maxc = c > maxc ? c : maxc;
+        unsigned r = 0;
+        if (c <= (unsigned)SL_GROUP)
+          for (unsigned i = a; i < bnd; i++) r += (uint32_t)s_key[i] < (uint32_t)kj;
+        s_rank[j] = (uint16_t)(a + r - j + SL_GROUP);  // destination - source, biased to stay non-negative
       }
+      maxc = sbx_wave_max(maxc);
+      if (lane == 0) s_escan[w] = maxc;
       __syncthreads();
-      for (unsigned k = 2; k <= p2; k <<= 1) {
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
-          for (unsigned t = tid; t < p2; t += 1024) {
-            const unsigned l = t ^ j;
-            if (l > t) {
-              const uint64_t a = s_key[t], b = s_key[l];
-              const bool up = (t & k) == 0;
-              if ((a > b) == up) {
-                s_key[t] = b;
-                s_key[l] = a;
+      maxc = 0;
+      for (int i = 0; i < 1024 / 64; i++) maxc = s_escan[i] > maxc ? s_escan[i] : maxc;
+      __syncthreads();
+      if (maxc <= (unsigned)SL_GROUP) {
+        uint64_t mine[SL_CAP / 1024];
+#pragma unroll
+        for (int k = 0; k < SL_CAP / 1024; k++) {
+          const unsigned j = (unsigned)tid + k * 1024u;
+          mine[k] = j < nf ? s_key[j] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SL_CAP / 1024; k++) {
+          const unsigned j = (unsigned)tid + k * 1024u;
+          if (j < nf) s_key[j + s_rank[j] - SL_GROUP] = mine[k];
+        }
+        __syncthreads();
+      } else {
+        unsigned p2 = 1;
+        while (p2 < nf) p2 <<= 1;
+        for (unsigned j = nf + tid; j < p2; j += 1024) s_key[j] = ~0ull;
+        __syncthreads();
+        for (unsigned k = 2; k <= p2; k <<= 1) {
+          for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned t = tid; t < p2; t += 1024) {
+              const unsigned l = t ^ j;
+              if (l > t) {
+                const uint64_t x = s_key[t], y = s_key[l];
+                const bool up = (t & k) == 0;
+                if ((x > y) == up) {
+                  s_key[t] = y;
+                  s_key[l] = x;
+                }
               }
             }
+            __syncthreads();
           }
-          __syncthreads();
         }
       }
     }
-    // ---- publish: clear the old frontier bits, write q / bitmaps / positions of the new level
-    for (unsigned i = tid; i < fsize; i += 1024) {
-      const I u = s_front[i];
-      atomicAnd(&fbits[u >> 5], ~(1u << (u & 31)));
-    }
-    __syncthreads();
+    // ---- publish: q and the visited bitmap.  The frontier bitmap / level positions are only read by
+    // the bottom-up kernel, which cannot follow a frontier this small: the host marks them
+    // (k_mark_frontier) in the rare case it wants bottom-up right after this kernel stops.
     const unsigned noff = off + fsize;
     for (unsigned j = tid; j < nf; j += 1024) {
       const uint32_t lo = (uint32_t)s_key[j];
       const I v = (I)(CM ? dorder[lo] : lo);
       q[noff + j] = v;
       atomicOr(&vbits[v >> 5], 1u << (v & 31));
-      atomicOr(&fbits[v >> 5], 1u << (v & 31));
-      lpos[v] = j;
       if (j < (unsigned)SL_MAXF) s_front[j] = v;
     }
     off = noff;
@@ -978,6 +989,16 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       dv->n_heavy = 0;
     }
     atomicAdd(&dv->edges, scanned);
+  }
+}
+
+// frontier bitmap + level positions of q[0..fsize) for a bottom-up expansion (fbits cleared by the host)
+__global__ __launch_bounds__(256) void k_mark_frontier(const I *__restrict__ frontier, unsigned fsize,
+                                                       unsigned *__restrict__ fbits, unsigned *__restrict__ lpos) {
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < fsize; j += gridDim.x * blockDim.x) {
+    const I v = frontier[j];
+    atomicOr(&fbits[v >> 5], 1u << (v & 31));
+    lpos[v] = j;
   }
 }
 
@@ -1050,6 +1071,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
   int64_t frontier_edges = -1;    // degree sum of the current frontier (-1: level 0, read lazily)
   bool try_small = true;  // false right after the small-level kernel declined this very frontier
+  bool frontier_unmarked = false;  // the current frontier was published by the small-level kernel (no fbits/lpos)
   while (true) {
     bool expanded_by_small = false;
     RcmDev hd;
@@ -1068,14 +1090,21 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       if (hd.sl_status == SL_STOP_READY) {
         frontier_edges = (int64_t)hd.fedges;
         try_small = false;  // expand this frontier with the general kernels
+        frontier_unmarked = true;
         continue;
       }
       expanded_by_small = true;  // SL_STOP_EXPANDED: nf_list / nf / fedges are ready for ordering
     }
     try_small = true;
     if (!expanded_by_small) {
+    // (frontier_unmarked is consumed by the expansion right below)
     const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
     if (bottom_up) {
+      if (frontier_unmarked) {
+        SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_mark_frontier, dim3(sbx_grid_for(fsize, 256, 1024)), dim3(256),
+                    (const I *)(b.q + off), fsize, b.fbits, b.lpos);
+      }
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
                   b.n, b.dv);
@@ -1094,6 +1123,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     }
+    frontier_unmarked = false;
     const unsigned nf = hd.nf;
     if (nf == 0) break;
     if (frontier_edges < 0) remaining -= (int64_t)0;  // level 0's degree is part of hd.fedges history below

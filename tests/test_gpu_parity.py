@@ -452,7 +452,8 @@ def test_rcm_vs_oracle_random(ops, oracle, seed):
     assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
 
 
-@pytest.mark.parametrize("maker", ["path", "path_shuffled", "star", "clique", "grid", "grid_shuffled", "two_hubs"])
+@pytest.mark.parametrize("maker", ["path", "path_shuffled", "star", "clique", "grid", "grid_shuffled", "grid_wide",
+                                   "bushy_tree", "two_hubs"])
 def test_rcm_structured(ops, oracle, maker):
     if maker == "path":
         rp, col = synth.path_graph(3000)
@@ -466,6 +467,22 @@ def test_rcm_structured(ops, oracle, maker):
         rp, col = synth.grid_graph(40, 300)
     elif maker == "grid_shuffled":
         rp, col = synth.grid_graph(128, 128, shuffle_seed=5)
+    elif maker == "grid_wide":
+        rp, col = synth.grid_graph(1500, 700, shuffle_seed=9)   # frontiers of ~700-1400 vertices for ~2000 levels
+    elif maker == "bushy_tree":
+        # every vertex gets 1..130 children: parent groups on both sides of the 64-children counting limit
+        g = np.random.default_rng(17)
+        src, dst, nxt, frontier = [], [], 1, [0]
+        while nxt < 60000 and frontier:
+            new = []
+            for u in frontier:
+                c = int(g.integers(1, 131)) if g.random() < 0.2 else int(g.integers(1, 4))
+                for _ in range(c):
+                    src.append(u); dst.append(nxt); new.append(nxt); nxt += 1
+            frontier = new[:400]
+        ids = g.permutation(nxt)
+        s_, d_ = synth.symmetrize(ids[np.array(src)], ids[np.array(dst)])
+        rp, col = synth.csr_from_edges(nxt, s_, d_)
     else:
         s1, d1 = synth.symmetrize(np.full(6000, 10), np.arange(100, 6100))
         s2, d2 = synth.symmetrize(np.full(6000, 20), np.arange(3000, 9000))
