@@ -1,4 +1,5 @@
-"""Row-range sharded permutation apply across the GPUs of one node.
+"""Row-range sharded permutation apply and format conversion across the GPUs of one node
+(SURVEY.md §8e).
 
 Decomposition: new row i depends only on old row old_of_new[i] and the replicated
 col_order table, so rank r owns new rows [lo_r, hi_r).  Every rank holds the input
@@ -99,6 +100,65 @@ def permute_csr_sharded(n, m, row_ptr, col, val, row_order, col_order, group=Non
         lcol = _gather_v(lcol, offsets, group)
         lval = None if lval is None else _gather_v(lval, offsets, group)
     return grp, lcol, lval, (lo, hi), offsets
+
+
+def coo_to_csr_shard(m, row, col, val, lo, hi, a, b):
+    """HIP path of one COO -> CSR shard: rows [lo, hi) = nonzeros [a, b) of the row-sorted COO."""
+    from . import ops
+    return ops.coo_to_csr(hi - lo, m, row[a:b] - lo, col[a:b], None if val is None else val[a:b], rows_sorted=True)
+
+
+def csr_to_coo_shard(m, row_ptr, col, val, lo, hi, a, b):
+    """HIP path of one CSR -> COO shard (global row ids)."""
+    from . import ops
+    r, c, v = ops.csr_to_coo(hi - lo, m, row_ptr[lo:hi + 1] - row_ptr[lo], col[a:b], None if val is None else val[a:b])
+    return r + lo, c, v
+
+
+def coo_to_csr_sharded(n, m, row, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False):
+    """Sharded COO -> CSR of a row-sorted COO (replicated input, like the permute): rank r owns rows
+    [lo_r, hi_r); its nonzeros are the contiguous slice found by binary search on the sorted row array,
+    converted locally (sbx_coo_to_csr on rebased row ids), and the row_ptr segments are stitched with
+    the same two all-gathers.  Returns (global_row_ptr, local_col, local_val, (lo, hi), offsets).
+
+    shard_fn(lo, hi, a, b) -> (rebased_row_ptr, col, val) for rows [lo, hi) = nonzeros [a, b)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ranges = row_ranges(n, world) if ranges is None else ranges
+    lo, hi = ranges[rank]
+    bounds = torch.searchsorted(row, torch.tensor([lo, hi], dtype=row.dtype, device=row.device), right=False)
+    a, b = int(bounds[0]), int(bounds[1])
+    if shard_fn is None:
+        def shard_fn(lo_, hi_, a_, b_):
+            return coo_to_csr_shard(m, row, col, val, lo_, hi_, a_, b_)
+    lrp, lcol, lval = shard_fn(lo, hi, a, b)
+    grp, offsets = stitch_row_ptr(lrp, ranges, group)
+    if gather_entries:
+        lcol = _gather_v(lcol, offsets, group)
+        lval = None if lval is None else _gather_v(lval, offsets, group)
+    return grp, lcol, lval, (lo, hi), offsets
+
+
+def csr_to_coo_sharded(n, m, row_ptr, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False):
+    """Sharded CSR -> COO: rank r expands the row ids of rows [lo_r, hi_r) (nonzeros
+    [row_ptr[lo], row_ptr[hi])); no collective is needed unless the caller wants every rank to hold the
+    whole COO (gather_entries).  Returns (local_row, local_col, local_val, (lo, hi), (a, b))."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ranges = row_ranges(n, world) if ranges is None else ranges
+    lo, hi = ranges[rank]
+    a, b = int(row_ptr[lo]), int(row_ptr[hi])
+    if shard_fn is None:
+        def shard_fn(lo_, hi_, a_, b_):
+            return csr_to_coo_shard(m, row_ptr, col, val, lo_, hi_, a_, b_)
+    lrow, lcol, lval = shard_fn(lo, hi, a, b)
+    if gather_entries:
+        cuts = torch.tensor([int(row_ptr[l]) for l, _ in ranges] + [int(row_ptr[ranges[-1][1]])], dtype=torch.int64,
+                            device=row_ptr.device)
+        lrow = _gather_v(lrow, cuts, group)
+        lcol = _gather_v(lcol, cuts, group)
+        lval = None if lval is None else _gather_v(lval, cuts, group)
+    return lrow, lcol, lval, (lo, hi), (a, b)
 
 
 def _gather_v(local, offsets, group=None):

@@ -390,6 +390,23 @@ def test_permute_row_shards(ops, oracle):
         assert np.array_equal(host(scol), want_col[lo:hi]) and np.array_equal(host(sval), want_val[lo:hi])
 
 
+def test_convert_row_shards(ops, oracle):
+    """The per-rank computation of the sharded conversions (sparsebase_amd/sharded.py) on one GPU."""
+    from sparsebase_amd import sharded
+    rp, col = synth.rmat_symmetric(13, 8, seed=11)
+    n = len(rp) - 1
+    val = (np.arange(len(col)) % 53).astype(np.float32)
+    row, col2, val2 = oracle.csr_to_coo(rp, col, val)
+    drow, dcol, dval, drp = dev(row), dev(col2), dev(val2), dev(rp)
+    for lo, hi in sharded.row_ranges(n, 3) + [(5, 5), (0, n)]:
+        a, b = int(rp[lo]), int(rp[hi])
+        lrp, lc, lv = sharded.coo_to_csr_shard(n, drow, dcol, dval, lo, hi, a, b)
+        assert np.array_equal(host(lrp), rp[lo:hi + 1] - rp[lo])
+        assert np.array_equal(host(lc), col[a:b]) and np.array_equal(host(lv), val[a:b])
+        r, c, v = sharded.csr_to_coo_shard(n, drp, dev(col), dev(val), lo, hi, a, b)
+        assert np.array_equal(host(r), row[a:b]) and np.array_equal(host(c), col2[a:b]) and np.array_equal(host(v), val2[a:b])
+
+
 @pytest.mark.parametrize("name", ["rmat16_ef8", "banded_64k_w16", "sym_128k"])
 def test_golden_digests_degree_permute(ops, golden_dir, name):
     import hashlib
