@@ -104,6 +104,30 @@ __global__ __launch_bounds__(FT_THREADS) void k_profile(const int32_t *__restric
   }
 }
 
+// column-sorted rows (every CSR that went through a constructor): the smallest column is the first one
+__global__ __launch_bounds__(FT_THREADS) void k_profile_sorted(const int32_t *__restrict__ rp,
+                                                               const int32_t *__restrict__ col, int64_t n,
+                                                               unsigned long long *__restrict__ partial) {
+  __shared__ unsigned long long s_sum[FT_THREADS / 64];
+  unsigned long long sum = 0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int32_t s0 = rp[i];
+    if (rp[i + 1] > s0) {
+      const int64_t c = col[s0];
+      if (c < i) sum += (unsigned long long)(i - c);
+    }
+  }
+  sum = sbx_wave_sum(sum);
+  if (sbx_lane() == 0) s_sum[sbx_wave_in_block()] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < FT_THREADS / 64; w++) sum += s_sum[w];
+    partial[blockIdx.x] = sum;
+  }
+}
+
 // single workgroup: reduce the per-workgroup partials
 __global__ __launch_bounds__(FT_THREADS) void k_feature_finish(const unsigned *__restrict__ pmax,
                                                                const unsigned long long *__restrict__ psum, int count,
@@ -222,14 +246,28 @@ extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_arena_begin(h));
   if (nnz == 0 || n == 0) return SBX_OK;
   NestGuard guard(h);
-  int32_t *rows = nullptr, *rowmin = nullptr;
-  SBX_TRY(expand_rows(h, n, nnz, (const int32_t *)row_ptr, &rows));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &rowmin));
   const unsigned grid_n = sbx_grid_for(n, FT_THREADS, (int64_t)h->num_cus * 8);
   unsigned long long *partial = nullptr;
   FeatureAcc *acc = nullptr;
   SBX_TRY(sbx_salloc(h, grid_n, &partial));
   SBX_TRY(sbx_salloc(h, 1, &acc));
+  int sorted = 0;  // one streaming pass over col; unsorted rows only exist for ignore_sort CSRs
+  SBX_TRY(sbx_csr_rows_sorted(h, SBX_I32, n, row_ptr, col, &sorted));
+  if (sorted) {
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile_sorted, dim3(grid_n), dim3(FT_THREADS), (const int32_t *)row_ptr,
+                (const int32_t *)col, n, partial);
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
+                (const unsigned long long *)partial, (int)grid_n, acc);
+    SBX_LAUNCH_CHECK(h);
+    SBX_PROF_BYTES(h, SBX_K_FEATURE, 4 * nnz + 4 * (n + 1));
+    FeatureAcc hs;
+    SBX_TRY(sbx_readback(h, &hs, acc, sizeof(FeatureAcc)));
+    *profile_host = (int64_t)hs.profile;
+    return SBX_OK;
+  }
+  int32_t *rows = nullptr, *rowmin = nullptr;
+  SBX_TRY(expand_rows(h, n, nnz, (const int32_t *)row_ptr, &rows));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &rowmin));
   SBX_KLAUNCH(h, SBX_K_FEATURE, k_iota, dim3(grid_n), dim3(FT_THREADS), rowmin, n);  // j starts at i (:99)
   SBX_KLAUNCH(h, SBX_K_FEATURE, k_row_min_col, dim3((unsigned)((nnz + FT_THREADS * FT_ITEMS - 1) / (FT_THREADS * FT_ITEMS))),
               dim3(FT_THREADS), (const int32_t *)rows, (const int32_t *)col, nnz, rowmin);
