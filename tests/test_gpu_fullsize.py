@@ -82,6 +82,32 @@ def test_c3_permute_100m_properties(ops, c3):
     assert bool((deg_old[perm.long()][1:] >= deg_old[perm.long()][:-1]).all())
 
 
+def test_c3_csc_and_features_100m(ops, oracle, c3):
+    """§8(f) rows at full size: transpose twice = identity, the transpose of a symmetric pattern has the same
+    row_ptr/col, features against the oracle, and RCM lowers the profile of the power-law matrix."""
+    rp, col, val = c3
+    n, nnz = rp.numel() - 1, col.numel()
+    cp, ro, vo = ops.csr_to_csc(n, n, rp, col, val)
+    assert torch.equal(cp, rp) and torch.equal(ro, col)                    # structurally symmetric input
+    assert float(vo.double().sum()) == float(val.double().sum())
+    back = ops.csr_to_csc(n, n, cp, ro, vo)
+    assert torch.equal(back[0], rp) and torch.equal(back[1], col) and torch.equal(back[2], val)
+    row = ops.csr_to_coo(n, n, rp, col, None, move=True)[0]
+    cp2, ro2, vo2 = ops.coo_to_csc(n, n, row, col, val)
+    assert torch.equal(cp2, cp) and torch.equal(ro2, ro) and torch.equal(vo2, vo)
+    hrp, hcol = rp.cpu().numpy(), col.cpu().numpy()
+    assert ops.csr_bandwidth(rp, col) == oracle.csr_bandwidth(hrp, hcol)
+    before = ops.csr_profile(rp, col)
+    assert before == oracle.csr_profile(hrp, hcol)
+    deg = ops.csr_degrees(rp)
+    assert int(deg.long().sum()) == nnz
+    dist = ops.csr_degree_distribution(rp, nnz, torch.float64)
+    assert abs(float(dist.sum()) - 1.0) < 1e-9
+    order = ops.rcm_reorder(rp, col)
+    prp, pcol, _ = ops.permute_csr(n, n, rp, col, None, order, order)
+    assert ops.csr_profile(prp, pcol) < before
+
+
 @pytest.mark.parametrize("half_bandwidth", [64, (1 << 22) // 16])
 def test_c5_gray_keys_100m_banded(ops, oracle, half_bandwidth):
     n = 1 << 22
