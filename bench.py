@@ -249,14 +249,33 @@ def run_cpu_baseline(args, synth):
     else:
         impl, kind = orc.Oracle(), "port"
         cores = 1
-    t0 = time.perf_counter()
-    order = impl.rcm_reorder(rp, col)
-    t1 = time.perf_counter()
-    impl.permute_csr(rp, col, val, order, order, m=n) if kind == "reference" else impl.permute_csr(rp, col, val, order, order)
-    t2 = time.perf_counter()
-    return {"value": n / (t2 - t0) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": kind,
-            "sample": f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition",
-            "rcm_s": t1 - t0, "permute_s": t2 - t1}
+    def run_once():
+        t0 = time.perf_counter()
+        order = impl.rcm_reorder(rp, col)
+        t1 = time.perf_counter()
+        if kind == "reference":
+            impl.permute_csr(rp, col, val, order, order, m=n)
+        else:
+            impl.permute_csr(rp, col, val, order, order)
+        return t1 - t0, time.perf_counter() - t1
+
+    rcm_s, permute_s = run_once()
+    out = {"value": n / (rcm_s + permute_s) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": kind,
+           "sample": f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition",
+           "rcm_s": rcm_s, "permute_s": permute_s}
+    if kind == "reference":
+        # only the CSR constructor's two loops are OpenMP-parallel in the reference (format/csr.cc:102,123):
+        # the same run with one thread (SURVEY §8d asks for both)
+        try:
+            import ctypes
+            omp = ctypes.CDLL("libgomp.so.1")
+            omp.omp_set_num_threads(1)
+            r1, p1 = run_once()
+            omp.omp_set_num_threads(int(cores))
+            out["one_thread"] = {"value": n / (r1 + p1) / 1e6, "rcm_s": r1, "permute_s": p1}
+        except OSError:
+            pass
+    return out
 
 
 if __name__ == "__main__":
