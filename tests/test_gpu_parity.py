@@ -440,6 +440,28 @@ def test_gray_row_keys(ops, oracle):
         assert list(counts) == wcounts.tolist()
 
 
+def test_gray_row_keys_long_rows_and_odd_widths(ops, oracle):
+    """Rows that span several 2048-nonzero tiles in both classes (threshold 0: OR across tiles; counted: per-block
+    counts across tiles), column-block widths that are not powers of two, resolution 64, single-entry and empty rows."""
+    g = np.random.default_rng(23)
+    n, m = 700, 6400
+    lens = g.integers(0, 40, n)
+    lens[[3, 4, 5, 300, 699]] = (5000, 6399, 2048, 6400, 4097)
+    lens[[0, 1, 2, 698]] = (0, 1, 0, 1)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(g.choice(m, l, replace=False)) for l in lens]).astype(np.int32)
+    for res, thr in ((64, 10), (32, 10), (64, 20000), (32, 4096), (16, 0), (50, 10)):
+        deg, key, counts = ops.gray_row_keys(m, dev(rp), dev(col), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, res, thr)
+        assert np.array_equal(host(deg), wdeg), (res, thr)
+        assert np.array_equal(host(key).view(np.uint64), wkey), (res, thr)
+        assert list(counts) == wcounts.tolist(), (res, thr)
+    # int64 tuple goes through the same kernels
+    deg, key, counts = ops.gray_row_keys(m, dev(rp.astype(np.int64)), dev(col.astype(np.int64)), 64, 10)
+    wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, 64, 10)
+    assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+
+
 # ----------------------------------------------------------------------------- RCM
 def test_rcm_kat_and_small_fixtures(ops, kat, small):
     k = kat["functionality_3x3"]
