@@ -324,12 +324,14 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
     # a few very long rows (radix path), medium rows (bitonic path), duplicates with values
     g = np.random.default_rng(3)
     n, m = 64, 50000
-    lens = np.array([0, 1, 2, 40, 33, 1024, 1025, 5000, 20000] + [int(x) for x in g.integers(0, 300, n - 9)])
+    # one row in every sort class: tile (<= 1024), block rows of 2048 / 4096 / 8192 / 16384 slots, global radix
+    lens = np.array([0, 1, 2, 40, 33, 1024, 1025, 2048, 2049, 3000, 4096, 4097, 5000, 8192, 8193, 9000, 16384, 16385,
+                     20000] + [int(x) for x in g.integers(0, 300, n - 19)])
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     col = np.concatenate([np.sort(g.integers(0, m, l)) for l in lens]).astype(np.int32)  # sorted, with duplicates
     val = g.integers(-3, 3, len(col)).astype(np.int32)
     ro, co = synth.random_permutation(n, 1), synth.random_permutation(m, 2)
-    for v in (val, val.astype(np.float32), None):
+    for v in (val, val.astype(np.float32), None, val.astype(np.float64), val.astype(np.int64)):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
         # identity maps: nothing is unsorted, so duplicates must keep their input order
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
