@@ -2,7 +2,9 @@
 // files and writes the inverse permutation; used by tests/test_host_layer.py to check the
 // C++ API end to end (Gray's device keys + host ordering stage in particular) against
 // fixtures produced by the real reference.
-// Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device]
+// Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time]
+// --time repeats the call once and prints the second (warm) call's wall time in seconds on stdout
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -27,8 +29,11 @@ int main(int argc, char **argv) {
   auto rp = read_bin(argv[2]);
   auto col = read_bin(argv[3]);
   const int n = atoi(argv[5]), m = atoi(argv[6]);
-  bool on_device = false;
-  for (int i = 7; i < argc; i++) on_device |= !strcmp(argv[i], "--device");
+  bool on_device = false, timed = false;
+  for (int i = 7; i < argc; i++) {
+    on_device |= !strcmp(argv[i], "--device");
+    timed |= !strcmp(argv[i], "--time");
+  }
   utils::Logger::set_level(utils::LOG_LVL_NONE);
   context::CPUContext cpu;
   format::CSR<int, int, void> csr(n, m, rp.data(), col.data(), nullptr, format::kNotOwned, true);
@@ -42,18 +47,28 @@ int main(int argc, char **argv) {
     input = dcsr.get();
     ctxs = {gpu.get()};
   }
-  int *order = nullptr;
-  if (kind == "rcm") {
-    reorder::RCMReorder<int, int, void> r;
-    order = r.GetReorder(input, ctxs, false);
-  } else if (kind == "degree_asc" || kind == "degree_desc") {
-    reorder::DegreeReorder<int, int, void> r(kind == "degree_asc");
-    order = r.GetReorder(input, ctxs, false);
-  } else if (kind == "gray") {
-    reorder::GrayReorder<int, int, void> r((reorder::BitMapSize)atoi(argv[7]), atoi(argv[8]), atoi(argv[9]));
-    order = r.GetReorder(input, ctxs, false);
-  } else {
-    return 1;
+  auto run = [&]() -> int * {
+    if (kind == "rcm") {
+      reorder::RCMReorder<int, int, void> r;
+      return r.GetReorder(input, ctxs, false);
+    }
+    if (kind == "degree_asc" || kind == "degree_desc") {
+      reorder::DegreeReorder<int, int, void> r(kind == "degree_asc");
+      return r.GetReorder(input, ctxs, false);
+    }
+    if (kind == "gray") {
+      reorder::GrayReorder<int, int, void> r((reorder::BitMapSize)atoi(argv[7]), atoi(argv[8]), atoi(argv[9]));
+      return r.GetReorder(input, ctxs, false);
+    }
+    return nullptr;
+  };
+  int *order = run();
+  if (!order) return 1;
+  if (timed) {
+    delete[] order;
+    const auto t0 = std::chrono::steady_clock::now();
+    order = run();
+    std::printf("%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   std::ofstream out(argv[4], std::ios::binary);
   out.write((const char *)order, (size_t)n * sizeof(int));
