@@ -1,0 +1,287 @@
+// sbx_dec2bin.h — exact decimal -> binary floating point for the Matrix Market parser.
+//
+// value = w * 10^q10 with w < 2^64 (at most 19 significant decimal digits) is converted to
+// the nearest double / float, ties to even — the result strtod / strtof (and therefore
+// `istream >> double/float`, which the reference reader uses, io/mtx_reader.cc:331) produce.
+// No floating-point arithmetic is involved: the value is formed exactly in multi-limb
+// integers (w * 5^q for q >= 0; a 64-bit restoring division w * 2^s / 5^-q with the
+// remainder as sticky bit for q < 0) and rounded once, so there are no double-rounding or
+// "hard case" fallbacks.  Compiles for the device (HIP) and for the host (g++: the CPU unit
+// test tests/test_dec2bin.py checks it against strtod/strtof on millions of random inputs).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SBX_HD __host__ __device__ __forceinline__
+#else
+#define SBX_HD inline
+#endif
+
+#define SBX_POW5_MAX 400   /* |q10| up to here is converted exactly; beyond: 0 / inf by magnitude */
+#define SBX_POW5_LIMBS 16  /* 5^400 has 929 bits */
+
+// table[k * SBX_POW5_LIMBS + i] = limb i (little endian) of 5^k, k = 0..SBX_POW5_MAX
+static inline void sbx_pow5_table_fill(uint64_t *table) {
+  for (int i = 0; i < SBX_POW5_LIMBS; i++) table[i] = 0;
+  table[0] = 1;
+  for (int k = 1; k <= SBX_POW5_MAX; k++) {
+    const uint64_t *prev = table + (size_t)(k - 1) * SBX_POW5_LIMBS;
+    uint64_t *cur = table + (size_t)k * SBX_POW5_LIMBS;
+    unsigned __int128 carry = 0;
+    for (int i = 0; i < SBX_POW5_LIMBS; i++) {
+      const unsigned __int128 t = (unsigned __int128)prev[i] * 5u + carry;
+      cur[i] = (uint64_t)t;
+      carry = t >> 64;
+    }
+  }
+}
+
+namespace sbx_d2b {
+
+SBX_HD int clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)x);
+#else
+  return __builtin_clzll(x);
+#endif
+}
+
+// number of significant limbs / bits of a little-endian multi-limb integer
+SBX_HD int limbs_of(const uint64_t *a, int n) {
+  while (n > 0 && a[n - 1] == 0) n--;
+  return n;
+}
+SBX_HD int bits_of(const uint64_t *a, int n) {
+  n = limbs_of(a, n);
+  return n == 0 ? 0 : 64 * n - clz64(a[n - 1]);
+}
+
+// Rounds the exact value  mant * 2^e2  (+ something in (0, 2^e2) if sticky)  with mant in [2^63, 2^64)
+// to a binary format with P significand bits (incl. the hidden one), minimum normal exponent EMIN and
+// maximum EMAX (IEEE: double 53/-1022/1023, float 24/-126/127).  Returns the IEEE bit pattern without sign.
+template <int P, int EMIN, int EMAX, int EXP_BITS>
+SBX_HD uint64_t round_pack(uint64_t mant, int e2, bool sticky) {
+  // value = mant * 2^e2 = 1.xxx * 2^(e2 + 63)
+  int exp = e2 + 63;                 // unbiased exponent of the leading bit
+  int drop = 64 - P;                 // bits to drop for a normal number
+  if (exp < EMIN) drop += EMIN - exp;  // subnormal: fewer significand bits
+  uint64_t kept;
+  bool round_bit, rest;
+  if (drop >= 65) {                  // far below the smallest subnormal
+    kept = 0;
+    round_bit = false;
+    rest = true;
+  } else if (drop == 64) {
+    kept = 0;
+    round_bit = (mant >> 63) & 1u;
+    rest = sticky || (mant & 0x7FFFFFFFFFFFFFFFull) != 0;
+  } else {
+    kept = mant >> drop;
+    round_bit = (mant >> (drop - 1)) & 1u;
+    rest = sticky || (mant & ((1ull << (drop - 1)) - 1ull)) != 0;
+  }
+  if (round_bit && (rest || (kept & 1u))) kept++;  // nearest, ties to even
+  if (exp < EMIN) {
+    // subnormal (or rounded up to the smallest normal: the pattern below is then exactly that)
+    return kept;  // biased exponent field 0 (or 1 if kept reached 2^(P-1))
+  }
+  if (kept >> P) {  // significand overflowed to P+1 bits
+    kept >>= 1;
+    exp++;
+  }
+  if (exp > EMAX) return (uint64_t)((1u << EXP_BITS) - 1u) << (P - 1);  // infinity
+  return ((uint64_t)(exp - EMIN + 1) << (P - 1)) | (kept & ((1ull << (P - 1)) - 1ull));
+}
+
+// exact (mant, e2, sticky) with mant in [2^63, 2^64) for w * 10^q10, w != 0, |q10| <= SBX_POW5_MAX
+SBX_HD void exact_scale(uint64_t w, int q10, const uint64_t *pow5, uint64_t *mant, int *e2, bool *sticky) {
+  if (q10 >= 0) {
+    // N = w * 5^q (SBX_POW5_LIMBS + 1 limbs), value = N * 2^q
+    const uint64_t *p5 = pow5 + (size_t)q10 * SBX_POW5_LIMBS;
+    uint64_t n[SBX_POW5_LIMBS + 1];
+    unsigned __int128 carry = 0;
+    for (int i = 0; i < SBX_POW5_LIMBS; i++) {
+      const unsigned __int128 t = (unsigned __int128)p5[i] * w + carry;
+      n[i] = (uint64_t)t;
+      carry = t >> 64;
+    }
+    n[SBX_POW5_LIMBS] = (uint64_t)carry;
+    const int nl = limbs_of(n, SBX_POW5_LIMBS + 1);
+    const int lz = clz64(n[nl - 1]);
+    // top 64 bits of N
+    uint64_t top = n[nl - 1] << lz;
+    bool st = false;
+    if (nl >= 2) {
+      if (lz) top |= n[nl - 2] >> (64 - lz);
+      st = lz ? (n[nl - 2] << lz) != 0 : n[nl - 2] != 0;
+      for (int i = 0; i + 2 < nl; i++) st |= n[i] != 0;
+    }
+    *mant = top;
+    *sticky = st;
+    *e2 = q10 + (64 * nl - lz) - 64;  // N = top * 2^(bits - 64)
+    return;
+  }
+  // q < 0: value = w / (5^k * 2^k).  Restoring division with 64 quotient bits.
+  const int k = -q10;
+  const uint64_t *d = pow5 + (size_t)k * SBX_POW5_LIMBS;
+  const int dl = limbs_of(d, SBX_POW5_LIMBS);
+  const int dbits = 64 * dl - clz64(d[dl - 1]);
+  const int wbits = 64 - clz64(w);
+  // rem = w << (dbits - wbits): same bit length as d, so rem / d is in (1/2, 2)
+  uint64_t rem[SBX_POW5_LIMBS + 1];
+  for (int i = 0; i <= SBX_POW5_LIMBS; i++) rem[i] = 0;
+  int sh = dbits - wbits;  // may be negative when 5^k is shorter than w (small k)
+  int s_total;             // value = (quotient stream) * 2^(-s_total - k) with quotient = rem0 * 2^i / d
+  if (sh >= 0) {
+    rem[sh >> 6] = w << (sh & 63);
+    if ((sh & 63) && (sh >> 6) + 1 <= SBX_POW5_LIMBS) rem[(sh >> 6) + 1] = w >> (64 - (sh & 63));
+    s_total = sh;
+  } else {
+    // d is shorter than w: scale d up instead (compare against d << -sh), i.e. divide w by d * 2^-sh
+    rem[0] = w;
+    s_total = sh;  // negative: quotient is larger by 2^-sh
+  }
+  const int rl = dl + 1 > 2 ? dl + 1 : 2;  // limbs that can be non-zero in rem / shifted d
+  uint64_t dd[SBX_POW5_LIMBS + 1];
+  for (int i = 0; i <= SBX_POW5_LIMBS; i++) dd[i] = i < dl ? d[i] : 0;
+  if (sh < 0) {  // dd = d << (-sh), still fits: its bit length becomes wbits <= 64
+    const int up = -sh;
+    uint64_t lo = d[0] << up;  // dl == 1 here because dbits < wbits <= 64
+    dd[0] = lo;
+    dd[1] = 0;
+  }
+  // produce quotient bits until the leading 1 has been seen and 63 more follow
+  uint64_t q = 0;
+  int produced = 0;  // quotient bits after the leading one, inclusive
+  int steps = 0;
+  while (produced < 64) {
+    // compare rem >= dd over rl limbs
+    bool ge = true;
+    for (int i = rl - 1; i >= 0; i--) {
+      if (rem[i] != dd[i]) {
+        ge = rem[i] > dd[i];
+        break;
+      }
+    }
+    if (ge) {
+      unsigned __int128 borrow = 0;
+      for (int i = 0; i < rl; i++) {
+        const unsigned __int128 t = (unsigned __int128)rem[i] - dd[i] - borrow;
+        rem[i] = (uint64_t)t;
+        borrow = (t >> 64) & 1u;
+      }
+    }
+    if (produced > 0 || ge) {
+      q = (q << 1) | (ge ? 1u : 0u);
+      produced++;
+    }
+    steps++;
+    if (produced < 64) {  // rem <<= 1
+      for (int i = rl - 1; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+      rem[0] <<= 1;
+    }
+  }
+  bool st = false;
+  for (int i = 0; i < rl; i++) st |= rem[i] != 0;
+  *mant = q;
+  *sticky = st;
+  // quotient bit j (j = 0 first step) has weight 2^-j relative to rem0/dd; q collects `steps` bits:
+  // rem0 / dd = q * 2^-(steps - 1) (+ remainder), and w / d = (rem0 / dd) * 2^(-s_total)
+  *e2 = -(steps - 1) - s_total - k;
+}
+
+template <int P, int EMIN, int EMAX, int EXP_BITS>
+SBX_HD uint64_t convert(uint64_t w, int q10, const uint64_t *pow5) {
+  if (w == 0) return 0;
+  if (q10 > SBX_POW5_MAX) return (uint64_t)((1u << EXP_BITS) - 1u) << (P - 1);  // >= 10^401: infinity in both formats
+  if (q10 < -SBX_POW5_MAX) return 0;  // < 2^64 * 10^-401: below half the smallest subnormal
+  uint64_t mant;
+  int e2;
+  bool sticky;
+  exact_scale(w, q10, pow5, &mant, &e2, &sticky);
+  return round_pack<P, EMIN, EMAX, EXP_BITS>(mant, e2, sticky);
+}
+
+}  // namespace sbx_d2b
+
+// ---- token -> (sign, w, q10): the characters `istream >> double` consumes (libstdc++ num_get: digits, one
+// '.', an exponent) — no hex floats, no inf/nan.  status: 0 ok, 1 malformed, 2 more than 19 significant
+// digits with a non-zero tail (not representable in w; refused rather than rounded twice).
+struct sbx_decimal {
+  uint64_t w;
+  int q10;
+  int neg;
+  int status;
+};
+
+SBX_HD sbx_decimal sbx_parse_decimal(const char *s, int64_t len) {
+  sbx_decimal r;
+  r.w = 0; r.q10 = 0; r.neg = 0; r.status = 1;
+  int64_t i = 0;
+  if (i < len && (s[i] == '+' || s[i] == '-')) { r.neg = s[i] == '-'; i++; }
+  int digits = 0;       // significant digits taken into w
+  int any = 0;          // any digit seen at all
+  int dropped = 0;      // integer-part digits that did not fit (all zero, or status 2)
+  int frac_taken = 0;   // fractional digits taken into w (or skipped leading zeros of 0.000x)
+  bool tail_nonzero = false;
+  for (; i < len && s[i] >= '0' && s[i] <= '9'; i++) {
+    any = 1;
+    const int dgt = s[i] - '0';
+    if (digits == 0 && dgt == 0) continue;  // leading zero
+    if (digits < 19) { r.w = r.w * 10u + (uint64_t)dgt; digits++; }
+    else { dropped++; tail_nonzero |= dgt != 0; }
+  }
+  if (i < len && s[i] == '.') {
+    i++;
+    for (; i < len && s[i] >= '0' && s[i] <= '9'; i++) {
+      any = 1;
+      const int dgt = s[i] - '0';
+      if (digits == 0 && dgt == 0) { frac_taken++; continue; }  // 0.000x: scale only
+      if (digits < 19) { r.w = r.w * 10u + (uint64_t)dgt; digits++; frac_taken++; }
+      else tail_nonzero |= dgt != 0;
+    }
+  }
+  if (!any) return r;
+  long e = 0;
+  if (i < len && (s[i] == 'e' || s[i] == 'E')) {
+    i++;
+    int eneg = 0;
+    if (i < len && (s[i] == '+' || s[i] == '-')) { eneg = s[i] == '-'; i++; }
+    if (!(i < len && s[i] >= '0' && s[i] <= '9')) return r;  // "1e" / "1e+": malformed
+    for (; i < len && s[i] >= '0' && s[i] <= '9'; i++)
+      if (e < 100000) e = e * 10 + (s[i] - '0');
+    if (eneg) e = -e;
+  }
+  if (i != len) return r;  // trailing garbage inside the token
+  long q = e + dropped - frac_taken;
+  if (q > 200000) q = 200000;
+  if (q < -200000) q = -200000;
+  r.q10 = (int)q;
+  r.status = tail_nonzero ? 2 : 0;
+  return r;
+}
+
+// token -> signed 64-bit integer (what `istream >> IDType` consumes): status 0 ok, 1 malformed / overflow
+SBX_HD int sbx_parse_integer(const char *s, int64_t len, long long *out) {
+  int64_t i = 0;
+  int neg = 0;
+  if (i < len && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+  if (i >= len) return 1;
+  unsigned long long v = 0;
+  for (; i < len; i++) {
+    if (s[i] < '0' || s[i] > '9') return 1;
+    if (v > 922337203685477580ull) return 1;
+    v = v * 10u + (unsigned)(s[i] - '0');
+    if (v > 9223372036854775807ull) return 1;
+  }
+  *out = neg ? -(long long)v : (long long)v;
+  return 0;
+}
+
+// IEEE bit patterns (sign applied by the caller)
+SBX_HD uint64_t sbx_decimal_to_double_bits(uint64_t w, int q10, const uint64_t *pow5) {
+  return sbx_d2b::convert<53, -1022, 1023, 11>(w, q10, pow5);
+}
+SBX_HD uint32_t sbx_decimal_to_float_bits(uint64_t w, int q10, const uint64_t *pow5) {
+  return (uint32_t)sbx_d2b::convert<24, -126, 127, 8>(w, q10, pow5);
+}
