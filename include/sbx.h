@@ -161,6 +161,28 @@ int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t
                    void *col_ptr_out, void *row_out, void *val_out);
 
 /* ------------------------------------------------------------------ *
+ * Matrix Market ingest — io/mtx_reader.cc:307-495 MTXReader::ReadCoordinateIntoCOO.
+ * text_dev: the bytes of the file AFTER the size line ("M N L"), resident on the device; the banner
+ * and the size line are parsed by the caller.  `entries` = L, `fields` = tokens per entry (2 for
+ * pattern files, 3 otherwise; with fields == 3 and val_out == NULL the values are skipped).  Tokens are
+ * whitespace separated exactly like the reference's `fin >> m >> n >> w`; values of type vt are parsed as
+ * decimal integers (I32/U32/I64/U64) or converted exactly to float/double (the result of strtof/strtod).
+ * symmetry: 0 general, 1 symmetric, 2 skew-symmetric: unless SBX_MTX_UPPER_TRIANGLE every entry is
+ * followed by its mirror (symmetric: off-diagonal entries only, :441-447; skew: negated value, :452-454);
+ * with SBX_MTX_UPPER_TRIANGLE the entry is stored as (min, max) instead (:368-384).  SBX_MTX_ZERO_INDEX
+ * subtracts 1 from both indices (:334-337).  Outputs need capacity >= entries (2 * entries when mirrors
+ * are produced); *nnz_host receives the number of nonzeros written.  The COO constructor's sort is the
+ * caller's next step (sbx_coo_sort).  Malformed tokens -> SBX_ERR_BAD_ARG; values with more than 19
+ * significant digits and a non-zero tail -> SBX_ERR_UNSUPPORTED.  Synchronous.                 */
+/* ------------------------------------------------------------------ */
+#define SBX_MTX_ZERO_INDEX 1u
+#define SBX_MTX_UPPER_TRIANGLE 2u
+int sbx_mtx_parse_coordinate(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, const void *text_dev,
+                             int64_t bytes, int64_t n_rows, int64_t n_cols, int64_t entries, int fields,
+                             int symmetry, unsigned flags, int64_t capacity, void *row_out, void *col_out,
+                             void *val_out, int64_t *nnz_host);
+
+/* ------------------------------------------------------------------ *
  * Reorder-quality features: single-pass reductions over a device CSR.
  *   sbx_csr_degrees              feature/degrees.cc:93-105      degrees_out[i] = row_ptr[i+1] - row_ptr[i]
  *   sbx_csr_degree_distribution  feature/degree_distribution.cc:152-167

@@ -24,6 +24,7 @@
 #include "sparsebase/feature/degrees.h"
 #include "sparsebase/feature/profile.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/io/mtx_reader.h"
 #include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
 #include "sparsebase/permute/permute_order_two.h"
@@ -190,6 +191,26 @@ void t_permute(int64_t n, int64_t m, I *rp, I *col, V *val, I *row_order, I *col
   if constexpr (!std::is_same_v<V, void>) delete[] c;
 }
 
+// the real MTXReader on a file: COO arrays as its ReadCOO() returns them (constructor sort applied)
+template <typename I, typename V>
+int t_mtx_read(const char *path, int zero_index, int upper, int64_t cap, I *row, I *col, V *val, int64_t *dims) {
+  io::MTXReader<I, I, V> reader(path, zero_index != 0, upper != 0);
+  format::COO<I, I, V> *coo = reader.ReadCOO();
+  const int64_t nnz = coo->get_num_nnz();
+  dims[0] = coo->get_dimensions()[0];
+  dims[1] = coo->get_dimensions()[1];
+  dims[2] = nnz;
+  int rc = 0;
+  if (nnz > cap) rc = -3;
+  else {
+    memcpy(row, coo->get_row(), nnz * sizeof(I));
+    memcpy(col, coo->get_col(), nnz * sizeof(I));
+    if constexpr (!std::is_same_v<V, void>)
+      if (val && coo->get_vals()) memcpy(val, coo->get_vals(), nnz * sizeof(V));
+  }
+  delete coo;
+  return rc;
+}
 }  // namespace
 
 // (it, vt) -> concrete tuple.  vt: 0 void, 1 int32, 2 uint32 (unsigned tuple), 3 float, 6 double
@@ -247,6 +268,20 @@ int ref_csr_to_csc(int it, int vt, int64_t n, int64_t nnz, void *rp, void *col, 
   TUPLE_SWITCH(it, vt, F_CSR_CSC, 0);
   return 0;
 }
+int ref_mtx_read(int it, int vt, const char *path, int zero_index, int upper, int64_t cap, void *row, void *col,
+                 void *val, int64_t *dims) {
+  try {
+    if (it == 0 && vt == 0) return t_mtx_read<int, void>(path, zero_index, upper, cap, (int *)row, (int *)col, (void *)nullptr, dims);
+    if (it == 0 && vt == 1) return t_mtx_read<int, int>(path, zero_index, upper, cap, (int *)row, (int *)col, (int *)val, dims);
+    if (it == 0 && vt == 3) return t_mtx_read<int, float>(path, zero_index, upper, cap, (int *)row, (int *)col, (float *)val, dims);
+    if (it == 0 && vt == 6) return t_mtx_read<int, double>(path, zero_index, upper, cap, (int *)row, (int *)col, (double *)val, dims);
+    if (it == 1 && vt == 6) return t_mtx_read<long long, double>(path, zero_index, upper, cap, (long long *)row, (long long *)col, (double *)val, dims);
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return -2;
+}
+
 // all four features of one square CSR (profile is returned as the reference's IDType value, widened)
 int ref_features(int it, int64_t n, void *rp, void *col, int64_t *bandwidth, int64_t *profile, void *degrees,
                  float *dist_f, double *dist_d) {

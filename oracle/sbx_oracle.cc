@@ -23,6 +23,8 @@
 #include <cstdint>
 #include <cstring>
 #include <queue>
+#include <sstream>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -203,6 +205,51 @@ void csr_to_csc(int vt, int64_t n, int64_t m, int64_t nnz, const I *rp, const I 
   std::vector<I> rows(nnz > 0 ? nnz : 1);
   csr_to_coo<I>(V_NONE, n, nnz, rp, col, nullptr, rows.data(), nullptr, nullptr);
   coo_to_csc<I>(vt, n, m, nnz, rows.data(), col, val, cp_out, row_out, val_out);
+}
+
+// ---------------------------------------------------------------------------
+// Matrix Market coordinate section -> COO   io/mtx_reader.cc:307-495 (ReadCoordinateIntoCOO)
+// The same stream extractions as the reference (`fin >> m >> n [>> w]` into IDType / ValueType
+// variables), on the bytes that follow the size line.  Returns 0, or 1 when the stream failed.
+// ---------------------------------------------------------------------------
+template <typename I, typename V>
+int mtx_parse(const char *text, int64_t bytes, int64_t L, int fields, int symmetry, int zero_index, int upper,
+              I *row, I *col, V *val, int64_t *nnz_out) {
+  std::istringstream fin(std::string(text, (size_t)bytes));
+  int64_t nnz = 0;
+  const bool weighted = fields == 3;
+  for (int64_t l = 0; l < L; l++) {
+    I m, n;
+    fin >> m >> n;
+    V w = V();
+    if (weighted) {
+      if (val) fin >> w;
+      else { std::string skip; fin >> skip; }
+    }
+    if (!fin) return 1;
+    if (zero_index) { n--; m--; }
+    if (symmetry == 0) {                       // :322-366
+      row[nnz] = m; col[nnz] = n;
+      if (val) val[nnz] = w;
+      nnz++;
+    } else if (upper) {                        // :368-384
+      row[nnz] = std::min(m, n); col[nnz] = std::max(m, n);
+      if (val) val[nnz] = w;
+      nnz++;
+    } else {                                   // :403-470
+      row[nnz] = m; col[nnz] = n;
+      if (val) val[nnz] = w;
+      nnz++;
+      const bool check_diagonal = symmetry != 2;
+      if (!check_diagonal || m != n) {
+        row[nnz] = n; col[nnz] = m;
+        if (val) val[nnz] = symmetry == 2 ? (V)(-val[nnz - 1]) : val[nnz - 1];
+        nnz++;
+      }
+    }
+  }
+  *nnz_out = nnz;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -607,6 +654,34 @@ void orc_csr_to_csc(int it, int vt, int64_t n, int64_t m, int64_t nnz, const voi
                                (int32_t *)cp_out, (int32_t *)row_out, val_out),
            csr_to_csc<int64_t>(vt, n, m, nnz, (const int64_t *)rp, (const int64_t *)col, val,
                                (int64_t *)cp_out, (int64_t *)row_out, val_out));
+}
+int orc_mtx_parse(int it, int vt, const char *text, int64_t bytes, int64_t entries, int fields, int symmetry,
+                  int zero_index, int upper, void *row, void *col, void *val, int64_t *nnz) {
+#define MTX_CALL(I, V) \
+  return mtx_parse<I, V>(text, bytes, entries, fields, symmetry, zero_index, upper, (I *)row, (I *)col, (V *)val, nnz)
+  if (it == 0) {
+    switch (vt) {
+      case V_NONE: MTX_CALL(int32_t, int32_t);
+      case V_I32: MTX_CALL(int32_t, int32_t);
+      case V_U32: MTX_CALL(int32_t, uint32_t);
+      case V_F32: MTX_CALL(int32_t, float);
+      case V_I64: MTX_CALL(int32_t, int64_t);
+      case V_U64: MTX_CALL(int32_t, uint64_t);
+      case V_F64: MTX_CALL(int32_t, double);
+    }
+  } else {
+    switch (vt) {
+      case V_NONE: MTX_CALL(int64_t, int32_t);
+      case V_I32: MTX_CALL(int64_t, int32_t);
+      case V_U32: MTX_CALL(int64_t, uint32_t);
+      case V_F32: MTX_CALL(int64_t, float);
+      case V_I64: MTX_CALL(int64_t, int64_t);
+      case V_U64: MTX_CALL(int64_t, uint64_t);
+      case V_F64: MTX_CALL(int64_t, double);
+    }
+  }
+#undef MTX_CALL
+  return 2;
 }
 int64_t orc_csr_bandwidth(int it, int64_t n, const void *rp, const void *col) {
   if (it == 0) return csr_bandwidth<int32_t>(n, (const int32_t *)rp, (const int32_t *)col);

@@ -12,7 +12,8 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define SBX_HD __host__ __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#define SBX_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define SBX_HD inline
 #endif
@@ -38,13 +39,7 @@ static inline void sbx_pow5_table_fill(uint64_t *table) {
 
 namespace sbx_d2b {
 
-SBX_HD int clz64(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __clzll((long long)x);
-#else
-  return __builtin_clzll(x);
-#endif
-}
+SBX_HD int clz64(uint64_t x) { return __builtin_clzll(x); }
 
 // number of significant limbs / bits of a little-endian multi-limb integer
 SBX_HD int limbs_of(const uint64_t *a, int n) {

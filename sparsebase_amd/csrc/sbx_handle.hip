@@ -95,6 +95,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   }
   h->pinned_bytes = kPinnedBytes;
   h->rb_seq = 0;
+  h->pow5 = nullptr;
   h->rs_pool = nullptr;
   h->rs_next = 0;
   {
@@ -113,6 +114,7 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
   for (auto &b : h->blocks) (void)hipFree(b.ptr);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->rs_pool) (void)hipFree(h->rs_pool);
+  if (h->pow5) (void)hipFree(h->pow5);
   for (auto &r : h->prof_pending) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
@@ -331,7 +333,7 @@ extern "C" int sbx_memcpy_peer(sbx_handle_t h, void *dst_dev, int dst_device, co
 const char *const sbx_kernel_names[SBX_K_COUNT] = {
     "scan",          "radix_hist",   "radix_scatter", "coo_to_csr", "csr_to_coo", "permute_tile",
     "permute_long",  "permute_block", "permute_prep", "bfs_expand",    "bfs_heavy",  "bfs_bottom_up", "bfs_small_levels",  "level_order", "cc",
-    "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "csc",  "feature", "misc"};
+    "rcm_small",     "rcm_misc",     "gray",          "degree",     "check",       "csc",  "feature", "mtx", "misc"};
 
 static hipEvent_t prof_event(sbx_handle_t h) {
   if (!h->prof_pool.empty()) {

@@ -193,6 +193,19 @@ int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
   return sbx_widen_i32(h, ro, row_out, nnz);
 }
 
+int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t n_rows,
+                                 int64_t n_cols, int64_t entries, int fields, int symmetry, unsigned flags,
+                                 int64_t capacity, void *row_out, void *col_out, void *val_out, int64_t *nnz_host) {
+  I64_BEGIN();
+  (void)ovf;
+  SCRATCH32(r, capacity, true);
+  SCRATCH32(c, capacity, true);
+  SBX_TRY(sbx_mtx_parse_coordinate(h, SBX_I32, vt, text_dev, bytes, n_rows, n_cols, entries, fields, symmetry, flags,
+                                   capacity, r, c, val_out, nnz_host));
+  SBX_TRY(sbx_widen_i32(h, r, row_out, *nnz_host));
+  return sbx_widen_i32(h, c, col_out, *nnz_host);
+}
+
 int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
   I64_BEGIN();
   NARROW(rp, row_ptr, n + 1);

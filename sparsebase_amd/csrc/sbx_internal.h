@@ -36,6 +36,7 @@ enum sbx_kernel_id {
   SBX_K_CHECK,
   SBX_K_CSC,
   SBX_K_FEATURE,
+  SBX_K_MTX,
   SBX_K_MISC,
   SBX_K_COUNT
 };
@@ -69,6 +70,7 @@ struct sbx_handle_s {
   // SBX_RS_SLOTS sorts instead of one per sort (every memset is a launch on the critical path)
   void *rs_pool;
   int rs_next;
+  void *pow5;       // device table of 5^k for the exact decimal conversion (sbx_mtx.hip), built on first use
   unsigned rb_seq;  // sequence number of the last polled read-back (sbx_readback)
   bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
   int num_cus;
@@ -218,6 +220,9 @@ int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
 int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
+int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t n_rows,
+                                 int64_t n_cols, int64_t entries, int fields, int symmetry, unsigned flags,
+                                 int64_t capacity, void *row_out, void *col_out, void *val_out, int64_t *nnz_host);
 int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out);
 int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
                                     void *dist_out);

@@ -187,6 +187,24 @@ def csr_to_csc(n, m, row_ptr, col, val=None):
     return cp, ro, vo
 
 
+# ----------------------------------------------------------------------------- Matrix Market ingest
+def mtx_parse_coordinate(text, n_rows, n_cols, entries, fields, symmetry=0, zero_index=True, upper_triangle=False,
+                         index_dtype=torch.int32, value_dtype=None):
+    """text: uint8 device tensor with the bytes after the size line.  Returns (row, col, val) trimmed to nnz."""
+    hd = handle_for(_check_dev(text))
+    expand = symmetry != 0 and not upper_triangle
+    cap = max(1, entries * (2 if expand else 1))
+    row = torch.empty(cap, dtype=index_dtype, device=text.device)
+    col = torch.empty(cap, dtype=index_dtype, device=text.device)
+    val = None if (value_dtype is None or fields != 3) else torch.empty(cap, dtype=value_dtype, device=text.device)
+    nnz = C.c_int64(0)
+    flags = (1 if zero_index else 0) | (2 if upper_triangle else 0)
+    hd.check(hd.lib.sbx_mtx_parse_coordinate(hd.h, _it(row), _vt(val), _p(text), text.numel(), n_rows, n_cols, entries,
+                                             fields, symmetry, flags, cap, _p(row), _p(col), _p(val), C.byref(nnz)))
+    k = nnz.value
+    return row[:k], col[:k], (None if val is None else val[:k])
+
+
 # ----------------------------------------------------------------------------- features (SURVEY §8f.2)
 def csr_degrees(row_ptr):
     hd = handle_for(_check_dev(row_ptr))

@@ -93,6 +93,22 @@ class Oracle:
                                 _p(val), _p(ro), _p(co), _p(vo))
         return ro, co, vo
 
+    def mtx_parse(self, text, entries, fields, symmetry=0, zero_index=True, upper=False, index_dtype=np.int32,
+                  value_dtype=None):
+        """Coordinate section (bytes after the size line) -> (row, col, val) in file order; raises on a failed stream."""
+        cap = max(1, entries * 2)
+        row, col = np.empty(cap, index_dtype), np.empty(cap, index_dtype)
+        val = None if value_dtype is None else np.empty(cap, value_dtype)
+        nnz = C.c_int64(0)
+        buf = bytes(text)
+        rc = self.lib.orc_mtx_parse(0 if index_dtype == np.int32 else 1, vt_of(val), buf, C.c_int64(len(buf)),
+                                    C.c_int64(entries), int(fields), int(symmetry), int(zero_index), int(upper),
+                                    _p(row), _p(col), _p(val), C.byref(nnz))
+        if rc != 0:
+            raise ValueError("mtx_parse: stream failed")
+        k = nnz.value
+        return row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
+
     def csr_bandwidth(self, rp, col):
         return int(self.lib.orc_csr_bandwidth(it_of(rp), C.c_int64(len(rp) - 1), _p(rp), _p(col)))
 
@@ -233,6 +249,18 @@ class Ref:
         self._chk(self.lib.ref_csr_to_coo(it_of(rp), vt_of(val), C.c_int64(n), C.c_int64(m),
                                           C.c_int64(nnz), _p(rp), _p(col), _p(val), _p(ro), _p(co), _p(vo)))
         return ro, co, vo
+
+    def mtx_read(self, path, zero_index=True, upper=False, index_dtype=np.int32, value_dtype=None, cap=1 << 22):
+        """The real MTXReader::ReadCOO on a file: (n, m, row, col, val) - already sorted by the COO constructor."""
+        row, col = np.empty(cap, index_dtype), np.empty(cap, index_dtype)
+        val = None if value_dtype is None else np.empty(cap, value_dtype)
+        dims = (C.c_int64 * 3)()
+        rc = self.lib.ref_mtx_read(0 if index_dtype == np.int32 else 1, vt_of(val), str(path).encode(), int(zero_index),
+                                   int(upper), C.c_int64(cap), _p(row), _p(col), _p(val), dims)
+        if rc != 0:
+            raise ValueError(f"ref_mtx_read rc={rc}")
+        k = dims[2]
+        return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
 
     def features(self, rp, col):
         """(bandwidth, profile as IDType, degrees, float distribution, double distribution) of a square CSR."""

@@ -98,6 +98,58 @@ def test_csc_degenerate(ops, oracle):
          oracle.coo_to_csc(3, 3, one, one, np.array([1.5], np.float32)))
 
 
+# ----------------------------------------------------------------------------- Matrix Market ingest
+SYMM = {"general": 0, "symmetric": 1, "skew-symmetric": 2}
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mtx_parse_vs_oracle(ops, oracle, seed):
+    import mtxgen
+    field = ["real", "integer", "pattern", "real"][seed % 4]
+    symmetry = ["general", "symmetric", "skew-symmetric", "symmetric"][(seed // 2) % 4]
+    if field == "pattern" and symmetry == "skew-symmetric":
+        symmetry = "symmetric"
+    head, body, n, m, L = mtxgen.random_mtx(3000 + seed, field, symmetry, messy=seed >= 4,
+                                            n=(5000 if seed == 7 else None), nnz=(400000 if seed == 7 else None))
+    text = torch.frombuffer(bytearray(body.encode() or b" "), dtype=torch.uint8).cuda()
+    fields = 2 if field == "pattern" else 3
+    cases = [(None, None)] if field == "pattern" else \
+        ([(np.int32, torch.int32), (np.int64, torch.int64)] if field == "integer" else
+         [(np.float32, torch.float32), (np.float64, torch.float64)])
+    for vnp, vt in cases:
+        for upper in (False, True) if symmetry != "general" else (False,):
+            for zero in (True, False):
+                for inp, it in ((np.int32, torch.int32), (np.int64, torch.int64)):
+                    want = oracle.mtx_parse(body.encode(), L, fields, SYMM[symmetry], zero, upper, inp, vnp)
+                    got = ops.mtx_parse_coordinate(text, n, m, L, fields, SYMM[symmetry], zero, upper, it, vt)
+                    assert np.array_equal(host(got[0]), want[0]) and np.array_equal(host(got[1]), want[1])
+                    if vnp is not None:
+                        assert np.array_equal(host(got[2]).view(np.uint8), want[2].view(np.uint8))
+    if field != "pattern":   # values present but not wanted
+        got = ops.mtx_parse_coordinate(text, n, m, L, 3, SYMM[symmetry], True, False, torch.int32, None)
+        want = oracle.mtx_parse(body.encode(), L, 3, SYMM[symmetry], True, False, np.int32, None)
+        assert got[2] is None and np.array_equal(host(got[0]), want[0]) and np.array_equal(host(got[1]), want[1])
+
+
+def test_mtx_parse_errors_and_edges(ops):
+    from sparsebase_amd import capi
+    def parse(body, L, fields=3, vt=torch.float64):
+        text = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+        return ops.mtx_parse_coordinate(text, 9, 9, L, fields, 0, True, False, torch.int32, vt)
+    r, c, v = parse(b"  1 2 0.5\n\n\t3   4\t-1e400 \r\n5 6 4.9e-324", 3)
+    assert host(r).tolist() == [0, 2, 4] and host(c).tolist() == [1, 3, 5]
+    assert host(v).tolist() == [0.5, -np.inf, 5e-324]
+    for bad in (b"1 2 0.5\n3 4", b"1 2 0.5\n3 x 1", b"1 2 nan", b"1 2 0x10", b"1 2 1.5.2", b"0 2 1"):
+        with pytest.raises(capi.SbxError):
+            parse(bad, 2 if bad.count(b"\n") else 1)
+    with pytest.raises(capi.SbxError):   # 20 significant digits with a non-zero tail
+        parse(b"1 1 1.2345678901234567891", 1)
+    r, c, v = parse(b"1 1 12345678901234567890000", 1)   # zeros beyond 19 digits are exact
+    assert host(v).tolist() == [1.234567890123456789e22]
+    with pytest.raises(capi.SbxError):   # a '.' in an integer field
+        parse(b"1 1 2.5", 1, 3, torch.int32)
+
+
 # ----------------------------------------------------------------------------- features
 def test_kat_features(ops, kat):
     k = kat["feature_7x7"]  # feature/bandwidth_tests.cc:33-48, feature/profile_tests.cc:33-48
