@@ -4,7 +4,8 @@
 // Usage: degree_order <file.mtx>     (reference input: examples/data/ash958.mtx)
 #include <iostream>
 
-#include "mtx_io.h"
+#include "sparsebase/sparsebase.h"
+
 
 using namespace sparsebase;
 using vertex_type = unsigned int;
@@ -16,7 +17,7 @@ int main(int argc, char *argv[]) {
     return 1;
   }
   context::CPUContext cpu_context;
-  auto *coo = examples::ReadMTXToCOO<vertex_type, edge_type>(argv[1]);
+  auto *coo = bases::IOBase::ReadMTXToCOO<vertex_type, edge_type, void>(argv[1], true);
   auto *csr = coo->Convert<format::CSR>(&cpu_context);
   const vertex_type n = csr->get_dimensions()[0];
   auto *row_ptr = csr->get_row_ptr();

@@ -3,7 +3,8 @@
 // Usage: gray_order <file.mtx>   (column count must be a multiple of 16)
 #include <iostream>
 
-#include "mtx_io.h"
+#include "sparsebase/sparsebase.h"
+
 
 using namespace sparsebase;
 
@@ -13,7 +14,7 @@ int main(int argc, char *argv[]) {
     return 1;
   }
   context::CPUContext cpu_context;
-  auto *coo = examples::ReadMTXToCOO<int, int>(argv[1]);
+  auto *coo = bases::IOBase::ReadMTXToCOO<int, int, void>(argv[1], true);
   auto *csr = coo->Convert<format::CSR>(&cpu_context);
   const int n = csr->get_dimensions()[0];
   const int avg = (int)(csr->get_num_nnz() / (n ? n : 1));

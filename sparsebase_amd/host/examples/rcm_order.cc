@@ -4,7 +4,8 @@
 // Usage: rcm_order <symmetric.mtx>
 #include <iostream>
 
-#include "mtx_io.h"
+#include "sparsebase/sparsebase.h"
+
 
 using namespace sparsebase;
 using vertex_type = unsigned int;
@@ -17,7 +18,7 @@ int main(int argc, char *argv[]) {
   }
   context::CPUContext cpu_context;
   context::HIPContext gpu(0);
-  auto *coo = examples::ReadMTXToCOO<vertex_type, edge_type>(argv[1]);
+  auto *coo = bases::IOBase::ReadMTXToCOO<vertex_type, edge_type, void>(argv[1], true);
   // host COO -> device CSR in one call: the graph search chains COO->HIPCOO->HIPCSR
   auto *dcsr = coo->Convert<format::HIPCSR>(&gpu);
   const vertex_type n = dcsr->get_dimensions()[0];

@@ -16,6 +16,8 @@
 #include "sparsebase/format/csr.h"
 #include "sparsebase/format/hip_formats.h"
 #include "sparsebase/utils/logger.h"
+// last: the reader needs the complete conversion graph
+#include "sparsebase/bases/iobase.h"
 
 namespace sparsebase {
 // pre-0.3 spelling used by north_star / older call sites (SURVEY.md "Naming drift")

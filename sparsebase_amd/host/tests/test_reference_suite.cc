@@ -8,8 +8,13 @@
 //   reorder/{degree,rcm,gray}_reorder_tests.cc, reorder_tests.cc:27-125, bases/reorder_base_tests.cc
 //   converter/converter_order_two_cuda_tests.cu:11-49             host<->device round trips
 //   feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc  reorder-quality features
+//   io/mtx_reader_tests.cc:47-260 (coordinate files of io/reader_data.inc)   Matrix Market ingest
 // Fixtures: functionality_common.inc:6-44, converter/common.inc:5-16, format/common.inc:4-12.
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstdio>
+#include <fstream>
 #include <memory>
 #include <numeric>
 
@@ -236,6 +241,93 @@ TEST(HIPFormats, CSCOnDevice) {
   delete dcoo;
   delete dcsc;
   delete dcsr;
+}
+
+// ------------------------------------------------------------------ io/mtx_reader_tests.cc (coordinate files), reader_data.inc
+static std::string write_tmp(const std::string &name, const std::string &text) {
+  const std::string path = std::string("/tmp/sbx_test_") + std::to_string((long)getpid()) + "_" + name;
+  std::ofstream f(path, std::ios::binary);
+  f << text;
+  return path;
+}
+static int m_row_ptr[6]{0, 0, 1, 2, 3, 5}, m_row[5]{1, 2, 3, 4, 4}, m_col[5]{0, 1, 0, 2, 3};
+static float m_vals[5]{0.1f, 0.3f, 0.2f, 0.4f, 0.5f};
+static int m_row_ptr_symm[6]{0, 3, 5, 7, 9, 11}, m_row_symm[11]{0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4},
+    m_col_symm[11]{0, 1, 3, 0, 2, 1, 4, 0, 4, 2, 3};
+static float m_vals_symm[11]{0.7f, 0.1f, 0.2f, 0.1f, 0.3f, 0.3f, 0.4f, 0.2f, 0.5f, 0.4f, 0.5f};
+static int m_row_skew[10]{0, 0, 1, 1, 2, 2, 3, 3, 4, 4}, m_col_skew[10]{1, 3, 0, 2, 1, 4, 0, 4, 2, 3};
+static float m_vals_skew[10]{-0.1f, -0.2f, 0.1f, -0.3f, 0.3f, -0.4f, 0.2f, -0.5f, 0.4f, 0.5f};
+
+TEST(MTXReader, CoordinateFilesOfTheReferenceSuite) {
+  const std::string general = write_tmp("g.mtx", "%%MatrixMarket matrix coordinate pattern general\n%This is a comment\n5 5 5\n2 1\n4 1\n3 2\n5 3\n5 4\n");
+  const std::string general_v = write_tmp("gv.mtx", "%%MatrixMarket matrix coordinate real general\n%This is a comment\n5 5 5\n2 1 0.1\n4 1 0.2\n3 2 0.3\n5 3 0.4\n5 4 0.5\n");
+  const std::string symm_v = write_tmp("sv.mtx", "%%MatrixMarket matrix coordinate real symmetric\n%This is a comment\n5 5 6\n1 1 0.7\n2 1 0.1\n4 1 0.2\n3 2 0.3\n5 3 0.4\n5 4 0.5\n");
+  const std::string skew_v = write_tmp("kv.mtx", "%%MatrixMarket matrix coordinate real skew-symmetric\n%This is a comment\n5 5 5\n2 1 0.1\n4 1 0.2\n3 2 0.3\n5 3 0.4\n5 4 0.5\n");
+  {  // BasicsGeneral (:58-108)
+    io::MTXReader<int, int, int> reader(general);
+    auto *coo = reader.ReadCOO();
+    EXPECT_EQ((int)coo->get_num_nnz(), 5);
+    EXPECT_TRUE(same(coo->get_row(), m_row, 5));
+    EXPECT_TRUE(same(coo->get_col(), m_col, 5));
+    EXPECT_EQ(coo->get_vals(), (int *)nullptr);
+    delete coo;
+    auto *csr = reader.ReadCSR();
+    EXPECT_TRUE(same(csr->get_row_ptr(), m_row_ptr, 6));
+    EXPECT_TRUE(same(csr->get_col(), m_col, 5));
+    delete csr;
+    io::MTXReader<int, int, float> reader_v(general_v);
+    auto *coo_v = reader_v.ReadCOO();
+    EXPECT_TRUE(same(coo_v->get_row(), m_row, 5));
+    EXPECT_TRUE(same(coo_v->get_vals(), m_vals, 5));
+    delete coo_v;
+    auto *csr_v = bases::IOBase::ReadMTXToCSR<int, int, float>(general_v, true);
+    EXPECT_TRUE(same(csr_v->get_row_ptr(), m_row_ptr, 6));
+    EXPECT_TRUE(same(csr_v->get_vals(), m_vals, 5));
+    delete csr_v;
+    io::MTXReader<int, int, double> one_based(general_v, false);  // convert_to_zero_index = false
+    auto *coo1 = one_based.ReadCOO();
+    EXPECT_EQ(coo1->get_row()[0], 2);
+    EXPECT_EQ(coo1->get_vals()[0], 0.1);
+    delete coo1;
+  }
+  {  // BasicsSymmetric (:162-213)
+    io::MTXReader<int, int, float> reader(symm_v);
+    auto *coo = reader.ReadCOO();
+    EXPECT_EQ((int)coo->get_num_nnz(), 11);
+    EXPECT_TRUE(same(coo->get_row(), m_row_symm, 11));
+    EXPECT_TRUE(same(coo->get_col(), m_col_symm, 11));
+    EXPECT_TRUE(same(coo->get_vals(), m_vals_symm, 11));
+    delete coo;
+    auto *csr = reader.ReadCSR();
+    EXPECT_TRUE(same(csr->get_row_ptr(), m_row_ptr_symm, 6));
+    EXPECT_TRUE(same(csr->get_vals(), m_vals_symm, 11));
+    delete csr;
+    io::MTXReader<int, int, float> upper(symm_v, true, true);  // upper triangle only: 6 entries, (min, max)
+    auto *ut = upper.ReadCOO();
+    EXPECT_EQ((int)ut->get_num_nnz(), 6);
+    for (int i = 0; i < 6; i++) EXPECT_TRUE(ut->get_row()[i] <= ut->get_col()[i]);
+    delete ut;
+    std::unique_ptr<format::HIPCOO<int, int, float>> d(reader.ReadHIPCOO(*hip_context));  // stays in HBM
+    EXPECT_TRUE(same(fetch(d->device(), d->get_col(), 11).data(), m_col_symm, 11));
+  }
+  {  // BasicsSkewSymmetric (:215-260)
+    io::MTXReader<int, int, float> reader(skew_v);
+    auto *coo = reader.ReadCOO();
+    EXPECT_EQ((int)coo->get_num_nnz(), 10);
+    EXPECT_TRUE(same(coo->get_row(), m_row_skew, 10));
+    EXPECT_TRUE(same(coo->get_col(), m_col_skew, 10));
+    EXPECT_TRUE(same(coo->get_vals(), m_vals_skew, 10));
+    delete coo;
+  }
+  // ReadingWeightedIntoVoidValues (:47-56) and the other header errors of ParseHeader
+  EXPECT_THROW((io::MTXReader<int, int, void>(general_v)), utils::ReaderException);
+  EXPECT_THROW((io::MTXReader<int, int, int>("/nonexistent/file.mtx")), utils::ReaderException);
+  const std::string bad = write_tmp("bad.mtx", "%%MatrixMarket matrix coordinate real hermitian\n1 1 1\n1 1 1.0\n");
+  EXPECT_THROW((io::MTXReader<int, int, float>(bad)), utils::ReaderException);
+  const std::string garbage = write_tmp("garbage.mtx", "%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n2 x 3\n");
+  io::MTXReader<int, int, float> greader(garbage);
+  EXPECT_THROW(greader.ReadCOO(), utils::ReaderException);
+  for (const auto &f : {general, general_v, symm_v, skew_v, bad, garbage}) std::remove(f.c_str());
 }
 
 // ------------------------------------------------------------------ feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc

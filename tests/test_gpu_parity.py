@@ -131,6 +131,27 @@ def test_mtx_parse_vs_oracle(ops, oracle, seed):
         assert got[2] is None and np.array_equal(host(got[0]), want[0]) and np.array_equal(host(got[1]), want[1])
 
 
+def test_kat_mtx_reader(ops, kat):
+    # io/mtx_reader_tests.cc:58-260 on the fixtures of io/reader_data.inc, then the COO constructor's sort
+    for name, symm in (("general", 0), ("symmetric", 1), ("skew-symmetric", 2)):
+        k = kat["mtx_reader"][name]
+        for key, fields, vt in (("text", 2, None), ("text_values", 3, torch.float32)):
+            lines = k[key].split("\n")
+            i = 0
+            while lines[i].startswith("%"):
+                i += 1
+            n, m, L = (int(x) for x in lines[i].split())
+            body = "\n".join(lines[i + 1:]).encode()
+            text = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+            row, col, val = ops.mtx_parse_coordinate(text, n, m, L, fields, symm, True, False, torch.int32, vt)
+            row, col = row.clone(), col.clone()
+            val = None if val is None else val.clone()
+            ops.coo_sort_(n, m, row, col, val)
+            assert host(row).tolist() == k["row"] and host(col).tolist() == k["col"]
+            if vt is not None:
+                assert np.array_equal(host(val), np.array(k["vals"], np.float32))
+
+
 def test_mtx_parse_errors_and_edges(ops):
     from sparsebase_amd import capi
     def parse(body, L, fields=3, vt=torch.float64):
