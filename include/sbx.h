@@ -182,6 +182,28 @@ int sbx_mtx_parse_coordinate(sbx_handle_t h, sbx_index_type it, sbx_value_type v
                              int symmetry, unsigned flags, int64_t capacity, void *row_out, void *col_out,
                              void *val_out, int64_t *nnz_host);
 
+/* Number of whitespace-separated tokens in a device text buffer (to size the parsers' outputs). */
+int sbx_text_count_tokens(sbx_handle_t h, const void *text_dev, int64_t bytes, int64_t *tokens_host);
+
+/* ------------------------------------------------------------------ *
+ * Edge-list ingest — io/edge_list_reader.cc:19-158 EdgeListReader::ReadCOO.  text_dev: the whole file on
+ * the device; entries = tokens / (weighted ? 3 : 2) (sbx_text_count_tokens).  Vertices are 0-based (:31).
+ * Every edge "u v [w]" is kept unless SBX_EDGES_REMOVE_SELF and u == v (:35); with SBX_EDGES_UNDIRECTED
+ * its reverse follows it (:38-39); n = max(u) + 1, m = max(v) + 1 over the kept edges, made equal by
+ * SBX_EDGES_SQUARE or SBX_EDGES_UNDIRECTED (:41-49); the edges are sorted by (row, col) (:51-56; stable
+ * here, the reference's std::sort leaves the order of equal coordinates unspecified) and, with
+ * SBX_EDGES_REMOVE_DUPLICATES, reduced to the first of every run of equal coordinates (:58-66).
+ * Outputs need capacity >= entries (2 * entries with SBX_EDGES_UNDIRECTED); dims_nnz_host[3] receives
+ * n, m, nnz.  Synchronous.                                              */
+/* ------------------------------------------------------------------ */
+#define SBX_EDGES_REMOVE_DUPLICATES 1u
+#define SBX_EDGES_REMOVE_SELF 2u
+#define SBX_EDGES_UNDIRECTED 4u
+#define SBX_EDGES_SQUARE 8u
+int sbx_edge_list_parse(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, const void *text_dev,
+                        int64_t bytes, int64_t entries, int weighted, unsigned flags, int64_t capacity,
+                        void *row_out, void *col_out, void *val_out, int64_t *dims_nnz_host);
+
 /* ------------------------------------------------------------------ *
  * Reorder-quality features: single-pass reductions over a device CSR.
  *   sbx_csr_degrees              feature/degrees.cc:93-105      degrees_out[i] = row_ptr[i+1] - row_ptr[i]

@@ -24,6 +24,7 @@
 #include "sparsebase/feature/degrees.h"
 #include "sparsebase/feature/profile.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/io/edge_list_reader.h"
 #include "sparsebase/io/mtx_reader.h"
 #include "sparsebase/format/csc.h"
 #include "sparsebase/format/csr.h"
@@ -191,6 +192,28 @@ void t_permute(int64_t n, int64_t m, I *rp, I *col, V *val, I *row_order, I *col
   if constexpr (!std::is_same_v<V, void>) delete[] c;
 }
 
+// the real EdgeListReader on a file
+template <typename I, typename V>
+int t_edge_list_read(const char *path, int weighted, int dedup, int no_self, int undirected, int square, int64_t cap,
+                     I *row, I *col, V *val, int64_t *dims) {
+  io::EdgeListReader<I, I, V> reader(path, weighted != 0, dedup != 0, no_self != 0, undirected != 0, square != 0);
+  format::COO<I, I, V> *coo = reader.ReadCOO();
+  const int64_t nnz = coo->get_num_nnz();
+  dims[0] = coo->get_dimensions()[0];
+  dims[1] = coo->get_dimensions()[1];
+  dims[2] = nnz;
+  int rc = 0;
+  if (nnz > cap) rc = -3;
+  else {
+    memcpy(row, coo->get_row(), nnz * sizeof(I));
+    memcpy(col, coo->get_col(), nnz * sizeof(I));
+    if constexpr (!std::is_same_v<V, void>)
+      if (val && coo->get_vals()) memcpy(val, coo->get_vals(), nnz * sizeof(V));
+  }
+  delete coo;
+  return rc;
+}
+
 // the real MTXReader on a file: COO arrays as its ReadCOO() returns them (constructor sort applied)
 template <typename I, typename V>
 int t_mtx_read(const char *path, int zero_index, int upper, int64_t cap, I *row, I *col, V *val, int64_t *dims) {
@@ -267,6 +290,18 @@ int ref_csr_to_csc(int it, int vt, int64_t n, int64_t nnz, void *rp, void *col, 
                    void *row_out, void *val_out) {
   TUPLE_SWITCH(it, vt, F_CSR_CSC, 0);
   return 0;
+}
+int ref_edge_list_read(int it, int vt, const char *path, int weighted, int dedup, int no_self, int undirected, int square,
+                       int64_t cap, void *row, void *col, void *val, int64_t *dims) {
+  try {
+    if (it == 0 && vt == 0) return t_edge_list_read<int, void>(path, weighted, dedup, no_self, undirected, square, cap, (int *)row, (int *)col, (void *)nullptr, dims);
+    if (it == 0 && vt == 3) return t_edge_list_read<int, float>(path, weighted, dedup, no_self, undirected, square, cap, (int *)row, (int *)col, (float *)val, dims);
+    if (it == 0 && vt == 6) return t_edge_list_read<int, double>(path, weighted, dedup, no_self, undirected, square, cap, (int *)row, (int *)col, (double *)val, dims);
+    if (it == 1 && vt == 0) return t_edge_list_read<long long, void>(path, weighted, dedup, no_self, undirected, square, cap, (long long *)row, (long long *)col, (void *)nullptr, dims);
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return -2;
 }
 int ref_mtx_read(int it, int vt, const char *path, int zero_index, int upper, int64_t cap, void *row, void *col,
                  void *val, int64_t *dims) {

@@ -25,6 +25,7 @@
 #include <queue>
 #include <sstream>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -249,6 +250,52 @@ int mtx_parse(const char *text, int64_t bytes, int64_t L, int fields, int symmet
     }
   }
   *nnz_out = nnz;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Edge list -> sorted COO   io/edge_list_reader.cc:19-158 (EdgeListReader::ReadCOO), same stream
+// extractions and the same std::sort / std::unique calls.  dims_nnz = {n, m, nnz}.
+// ---------------------------------------------------------------------------
+template <typename I, typename V>
+int edge_list_parse(const char *text, int64_t bytes, int weighted, int remove_duplicates, int remove_self_edges,
+                    int read_undirected, int square, I *row, I *col, V *val, int64_t *dims_nnz) {
+  std::istringstream infile(std::string(text, (size_t)bytes));
+  I u, v;
+  V w = 0;
+  I m = 0, n = 0;
+  std::vector<std::tuple<I, I, V>> edges;
+  while (infile >> u >> v) {
+    if (weighted) infile >> w;
+    if (u != v || !remove_self_edges) {
+      edges.push_back(std::tuple<I, I, V>(u, v, w));
+      if (read_undirected) edges.push_back(std::tuple<I, I, V>(v, u, w));
+      n = std::max(n, (I)(u + 1));
+      m = std::max(m, (I)(v + 1));
+    }
+  }
+  if (square || read_undirected) {
+    n = std::max(n, m);
+    m = n;
+  }
+  std::sort(edges.begin(), edges.end(), [](const std::tuple<I, I, V> &t1, const std::tuple<I, I, V> t2) {
+    if (std::get<0>(t1) == std::get<0>(t2)) return std::get<1>(t1) < std::get<1>(t2);
+    return std::get<0>(t1) < std::get<0>(t2);
+  });
+  if (remove_duplicates) {
+    auto it = std::unique(edges.begin(), edges.end(), [](const std::tuple<I, I, V> &t1, const std::tuple<I, I, V> t2) {
+      return std::get<0>(t1) == std::get<0>(t2) && std::get<1>(t1) == std::get<1>(t2);
+    });
+    edges.erase(it, edges.end());
+  }
+  for (size_t i = 0; i < edges.size(); i++) {
+    row[i] = std::get<0>(edges[i]);
+    col[i] = std::get<1>(edges[i]);
+    if (weighted && val) val[i] = std::get<2>(edges[i]);
+  }
+  dims_nnz[0] = n;
+  dims_nnz[1] = m;
+  dims_nnz[2] = (int64_t)edges.size();
   return 0;
 }
 
@@ -682,6 +729,24 @@ int orc_mtx_parse(int it, int vt, const char *text, int64_t bytes, int64_t entri
   }
 #undef MTX_CALL
   return 2;
+}
+int orc_edge_list_parse(int it, int vt, const char *text, int64_t bytes, int weighted, int remove_duplicates,
+                        int remove_self_edges, int read_undirected, int square, void *row, void *col, void *val,
+                        int64_t *dims_nnz) {
+#define EL_CALL(I, V)                                                                                              \
+  return edge_list_parse<I, V>(text, bytes, weighted, remove_duplicates, remove_self_edges, read_undirected, square, \
+                               (I *)row, (I *)col, (V *)val, dims_nnz)
+  if (it == 0) {
+    if (vt == V_F32) EL_CALL(int32_t, float);
+    if (vt == V_F64) EL_CALL(int32_t, double);
+    if (vt == V_I64) EL_CALL(int32_t, int64_t);
+    EL_CALL(int32_t, int32_t);
+  }
+  if (vt == V_F32) EL_CALL(int64_t, float);
+  if (vt == V_F64) EL_CALL(int64_t, double);
+  if (vt == V_I64) EL_CALL(int64_t, int64_t);
+  EL_CALL(int64_t, int32_t);
+#undef EL_CALL
 }
 int64_t orc_csr_bandwidth(int it, int64_t n, const void *rp, const void *col) {
   if (it == 0) return csr_bandwidth<int32_t>(n, (const int32_t *)rp, (const int32_t *)col);

@@ -68,6 +68,8 @@ PROTOTYPES = {
     "sbx_csr_to_csc": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _int),
     "sbx_mtx_parse_coordinate": ([_H, _int, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, _u, _i64, _vp, _vp, _vp,
                                  C.POINTER(_i64)], _int),
+    "sbx_text_count_tokens": ([_H, _vp, _i64, C.POINTER(_i64)], _int),
+    "sbx_edge_list_parse": ([_H, _int, _int, _vp, _i64, _i64, _int, _u, _i64, _vp, _vp, _vp, C.POINTER(_i64)], _int),
     "sbx_csr_degrees": ([_H, _int, _i64, _vp, _vp], _int),
     "sbx_csr_degree_distribution": ([_H, _int, _i64, _i64, _vp, _int, _vp], _int),
     "sbx_csr_bandwidth": ([_H, _int, _i64, _i64, _vp, _vp, C.POINTER(_i64)], _int),

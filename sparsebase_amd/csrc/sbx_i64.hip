@@ -206,6 +206,19 @@ int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *
   return sbx_widen_i32(h, c, col_out, *nnz_host);
 }
 
+int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t entries,
+                            int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
+                            int64_t *dims_nnz_host) {
+  I64_BEGIN();
+  (void)ovf;
+  SCRATCH32(r, capacity, true);
+  SCRATCH32(c, capacity, true);
+  SBX_TRY(sbx_edge_list_parse(h, SBX_I32, vt, text_dev, bytes, entries, weighted, flags, capacity, r, c, val_out,
+                              dims_nnz_host));
+  SBX_TRY(sbx_widen_i32(h, r, row_out, dims_nnz_host[2]));
+  return sbx_widen_i32(h, c, col_out, dims_nnz_host[2]);
+}
+
 int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
   I64_BEGIN();
   NARROW(rp, row_ptr, n + 1);

@@ -223,6 +223,9 @@ int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, 
 int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t n_rows,
                                  int64_t n_cols, int64_t entries, int fields, int symmetry, unsigned flags,
                                  int64_t capacity, void *row_out, void *col_out, void *val_out, int64_t *nnz_host);
+int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t entries,
+                            int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
+                            int64_t *dims_nnz_host);
 int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out);
 int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
                                     void *dist_out);

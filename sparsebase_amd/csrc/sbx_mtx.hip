@@ -170,6 +170,85 @@ __global__ __launch_bounds__(MX_THREADS) void k_mtx_expand(const int32_t *__rest
   (void)value_signed_or_float;
 }
 
+// ---- edge lists (io/edge_list_reader.cc:19-158): self-edge filter, reverse edges, dimensions, duplicates
+struct EdgeDims {
+  unsigned n, m;  // max(u) + 1, max(v) + 1 over the edges that are kept (:41-42)
+};
+
+__global__ __launch_bounds__(MX_THREADS) void k_edge_flags(const int32_t *__restrict__ u, const int32_t *__restrict__ v,
+                                                           int64_t entries, int remove_self, int undirected,
+                                                           unsigned *__restrict__ outputs, EdgeDims *__restrict__ dims) {
+  __shared__ unsigned s_n[MX_THREADS / 64], s_m[MX_THREADS / 64];
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned mn = 0, mm = 0;
+  if (l < entries) {
+    const bool keep = !(remove_self && u[l] == v[l]);
+    outputs[l] = keep ? (undirected ? 2u : 1u) : 0u;
+    if (keep) {
+      mn = (unsigned)u[l] + 1u;
+      mm = (unsigned)v[l] + 1u;
+    }
+  }
+  mn = sbx_wave_max(mn);
+  mm = sbx_wave_max(mm);
+  if (sbx_lane() == 0) {
+    s_n[threadIdx.x >> 6] = mn;
+    s_m[threadIdx.x >> 6] = mm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < MX_THREADS / 64; w++) {
+      mn = s_n[w] > mn ? s_n[w] : mn;
+      mm = s_m[w] > mm ? s_m[w] : mm;
+    }
+    if (mn) atomicMax(&dims->n, mn);  // one atomic pair per workgroup
+    if (mm) atomicMax(&dims->m, mm);
+  }
+}
+
+template <int VB>
+__global__ __launch_bounds__(MX_THREADS) void k_edge_emit(const int32_t *__restrict__ u, const int32_t *__restrict__ v,
+                                                          const char *__restrict__ w, const unsigned *__restrict__ before,
+                                                          const unsigned *__restrict__ outputs, int64_t entries,
+                                                          int32_t *__restrict__ row, int32_t *__restrict__ col,
+                                                          char *__restrict__ val) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= entries || outputs[l] == 0) return;
+  const int64_t o = before[l];
+  row[o] = u[l];
+  col[o] = v[l];
+  if (VB == 4) ((uint32_t *)val)[o] = ((const uint32_t *)w)[l];
+  if (VB == 8) ((uint64_t *)val)[o] = ((const uint64_t *)w)[l];
+  if (outputs[l] == 2) {  // the reverse edge right behind (:38-39)
+    row[o + 1] = v[l];
+    col[o + 1] = u[l];
+    if (VB == 4) ((uint32_t *)val)[o + 1] = ((const uint32_t *)w)[l];
+    if (VB == 8) ((uint64_t *)val)[o + 1] = ((const uint64_t *)w)[l];
+  }
+}
+
+// first entry of every run of equal (row, col) in the sorted list (std::unique, :58-66)
+__global__ __launch_bounds__(MX_THREADS) void k_edge_first(const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                                           int64_t count, unsigned *__restrict__ first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) first[i] = (i == 0 || row[i] != row[i - 1] || col[i] != col[i - 1]) ? 1u : 0u;
+}
+
+template <int VB>
+__global__ __launch_bounds__(MX_THREADS) void k_edge_compact(const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                                             const char *__restrict__ val, const unsigned *__restrict__ first,
+                                                             const unsigned *__restrict__ before, int64_t count,
+                                                             int32_t *__restrict__ row_out, int32_t *__restrict__ col_out,
+                                                             char *__restrict__ val_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count || !first[i]) return;
+  const int64_t o = before[i];
+  row_out[o] = row[i];
+  col_out[o] = col[i];
+  if (VB == 4) ((uint32_t *)val_out)[o] = ((const uint32_t *)val)[i];
+  if (VB == 8) ((uint64_t *)val_out)[o] = ((const uint64_t *)val)[i];
+}
+
 struct NestGuard {
   sbx_handle_t h;
   explicit NestGuard(sbx_handle_t h) : h(h) { h->nest++; }
@@ -303,5 +382,123 @@ extern "C" int sbx_mtx_parse_coordinate(sbx_handle_t h, sbx_index_type it, sbx_v
              (st[0] & MX_BAD_INDEX) ? "index " : "", (st[0] & MX_INDEX_RANGE) ? "(index out of range) " : "",
              (st[0] & MX_BAD_VALUE) ? "value" : "");
   *nnz_host = nnz;
+  return SBX_OK;
+}
+
+// number of whitespace-separated tokens of a text buffer (sizes the outputs of the parsers)
+extern "C" int sbx_text_count_tokens(sbx_handle_t h, const void *text_dev, int64_t bytes, int64_t *tokens_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, tokens_host && bytes >= 0 && (bytes == 0 || text_dev), "bad argument");
+  SBX_REQUIRE(h, bytes < ((int64_t)1 << 32), "text sections of 4 GiB and more are not supported (32-bit token offsets)");
+  *tokens_host = 0;
+  SBX_TRY(sbx_arena_begin(h));
+  if (bytes == 0) return SBX_OK;
+  NestGuard guard(h);
+  const unsigned tiles = (unsigned)((bytes + MX_TILE - 1) / MX_TILE);
+  unsigned *tile_tokens = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_tokens));
+  SBX_HIP(h, hipMemsetAsync(tile_tokens + tiles, 0, sizeof(unsigned), h->stream));
+  SBX_KLAUNCH(h, SBX_K_MTX, k_mtx_count, dim3(tiles), dim3(MX_THREADS), (const char *)text_dev, bytes, tile_tokens);
+  SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_exclusive_scan_u32(h, tile_tokens, tile_tokens, (int64_t)tiles + 1, nullptr));
+  unsigned total = 0;
+  SBX_TRY(sbx_readback(h, &total, tile_tokens + tiles, sizeof(unsigned)));
+  *tokens_host = total;
+  return SBX_OK;
+}
+
+// Edge list -> sorted COO: io/edge_list_reader.cc:19-158 (EdgeListReader::ReadCOO).
+extern "C" int sbx_edge_list_parse(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, const void *text_dev,
+                                   int64_t bytes, int64_t entries, int weighted, unsigned flags, int64_t capacity,
+                                   void *row_out, void *col_out, void *val_out, int64_t *dims_nnz_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, dims_nnz_host && bytes >= 0 && entries >= 0 && (entries == 0 || (text_dev && row_out && col_out)),
+              "bad argument");
+  const bool undirected = (flags & SBX_EDGES_UNDIRECTED) != 0, remove_self = (flags & SBX_EDGES_REMOVE_SELF) != 0;
+  const bool dedup = (flags & SBX_EDGES_REMOVE_DUPLICATES) != 0, square = (flags & SBX_EDGES_SQUARE) != 0;
+  SBX_REQUIRE(h, capacity >= (undirected ? 2 : 1) * entries, "output capacity: entries (2 * entries for undirected reads)");
+  SBX_REQUIRE(h, 2 * entries < ((int64_t)1 << 31), "too many entries for int32 indices");
+  dims_nnz_host[0] = dims_nnz_host[1] = dims_nnz_host[2] = 0;
+  if (it == SBX_I64)
+    return sbx_i64_edge_list_parse(h, vt, text_dev, bytes, entries, weighted, flags, capacity, row_out, col_out, val_out,
+                                   dims_nnz_host);
+  const int vb = (weighted && val_out) ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  if (entries == 0) return SBX_OK;
+  NestGuard guard(h);
+  // (1) tokens -> (u, v, w) in file order: the coordinate parser, 0-based indices, no expansion
+  int32_t *u = nullptr, *v = nullptr;
+  char *w = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)entries, &u));
+  SBX_TRY(sbx_salloc(h, (size_t)entries, &v));
+  if (vb) SBX_TRY(sbx_salloc(h, (size_t)entries * vb, &w));
+  int64_t parsed = 0;
+  SBX_TRY(sbx_mtx_parse_coordinate(h, SBX_I32, vt, text_dev, bytes, 0, 0, entries, weighted ? 3 : 2, 0, 0u, entries, u, v,
+                                   vb ? w : nullptr, &parsed));
+  // (2) self-edge filter, reverse edges, dimensions
+  unsigned *outputs = nullptr, *before = nullptr;
+  EdgeDims *dims = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)entries + 1, &outputs));
+  SBX_TRY(sbx_salloc(h, (size_t)entries + 1, &before));
+  SBX_TRY(sbx_salloc(h, 1, &dims));
+  SBX_HIP(h, hipMemsetAsync(dims, 0, sizeof(EdgeDims), h->stream));
+  SBX_HIP(h, hipMemsetAsync(outputs + entries, 0, sizeof(unsigned), h->stream));
+  const unsigned grid = (unsigned)((entries + MX_THREADS - 1) / MX_THREADS);
+  SBX_KLAUNCH(h, SBX_K_MTX, k_edge_flags, dim3(grid), dim3(MX_THREADS), (const int32_t *)u, (const int32_t *)v, entries,
+              remove_self ? 1 : 0, undirected ? 1 : 0, outputs, dims);
+  SBX_TRY(sbx_exclusive_scan_u32(h, outputs, before, entries + 1, nullptr));
+  int32_t *r1 = (int32_t *)row_out, *c1 = (int32_t *)col_out;
+  char *v1 = (char *)val_out;
+  if (dedup) {  // stage the sorted list, compact into the outputs
+    SBX_TRY(sbx_salloc(h, (size_t)capacity, &r1));
+    SBX_TRY(sbx_salloc(h, (size_t)capacity, &c1));
+    if (vb) SBX_TRY(sbx_salloc(h, (size_t)capacity * vb, &v1));
+  }
+#define EMIT(VBX)                                                                                                       \
+  SBX_KLAUNCH(h, SBX_K_MTX, k_edge_emit<VBX>, dim3(grid), dim3(MX_THREADS), (const int32_t *)u, (const int32_t *)v,     \
+              (const char *)w, (const unsigned *)before, (const unsigned *)outputs, entries, r1, c1, v1)
+  if (vb == 0) EMIT(0);
+  else if (vb == 4) EMIT(4);
+  else EMIT(8);
+#undef EMIT
+  SBX_LAUNCH_CHECK(h);
+  unsigned count = 0;
+  SBX_TRY(sbx_readback(h, &count, before + entries, sizeof(unsigned)));
+  EdgeDims hd;
+  SBX_TRY(sbx_readback(h, &hd, dims, sizeof(EdgeDims)));
+  int64_t n = hd.n, m = hd.m;
+  if (square || undirected) {  // :46-49
+    n = n > m ? n : m;
+    m = n;
+  }
+  // (3) sort by (row, col) (:51-56; stable here: duplicates keep their file order), (4) std::unique (:58-66)
+  int64_t nnz = count;
+  if (count > 1) SBX_TRY(sbx_coo_sort(h, SBX_I32, vb ? vt : SBX_V_NONE, n, m, count, r1, c1, vb ? v1 : nullptr));
+  if (dedup && count > 0) {
+    unsigned *first = nullptr, *fbefore = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)count + 1, &first));
+    SBX_TRY(sbx_salloc(h, (size_t)count + 1, &fbefore));
+    SBX_HIP(h, hipMemsetAsync(first + count, 0, sizeof(unsigned), h->stream));
+    const unsigned g2 = (unsigned)((count + MX_THREADS - 1) / MX_THREADS);
+    SBX_KLAUNCH(h, SBX_K_MTX, k_edge_first, dim3(g2), dim3(MX_THREADS), (const int32_t *)r1, (const int32_t *)c1,
+                (int64_t)count, first);
+    SBX_TRY(sbx_exclusive_scan_u32(h, first, fbefore, (int64_t)count + 1, nullptr));
+#define COMPACT(VBX)                                                                                                   \
+  SBX_KLAUNCH(h, SBX_K_MTX, k_edge_compact<VBX>, dim3(g2), dim3(MX_THREADS), (const int32_t *)r1, (const int32_t *)c1, \
+              (const char *)v1, (const unsigned *)first, (const unsigned *)fbefore, (int64_t)count, (int32_t *)row_out, \
+              (int32_t *)col_out, (char *)val_out)
+    if (vb == 0) COMPACT(0);
+    else if (vb == 4) COMPACT(4);
+    else COMPACT(8);
+#undef COMPACT
+    SBX_LAUNCH_CHECK(h);
+    unsigned uniq = 0;
+    SBX_TRY(sbx_readback(h, &uniq, fbefore + count, sizeof(unsigned)));
+    nnz = uniq;
+  }
+  dims_nnz_host[0] = n;
+  dims_nnz_host[1] = m;
+  dims_nnz_host[2] = nnz;
   return SBX_OK;
 }

@@ -9,6 +9,7 @@
 //   converter/converter_order_two_cuda_tests.cu:11-49             host<->device round trips
 //   feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc  reorder-quality features
 //   io/mtx_reader_tests.cc:47-260 (coordinate files of io/reader_data.inc)   Matrix Market ingest
+//   io/edge_list_reader_tests.cc:7-80                               edge-list ingest
 // Fixtures: functionality_common.inc:6-44, converter/common.inc:5-16, format/common.inc:4-12.
 #include <unistd.h>
 
@@ -328,6 +329,49 @@ TEST(MTXReader, CoordinateFilesOfTheReferenceSuite) {
   io::MTXReader<int, int, float> greader(garbage);
   EXPECT_THROW(greader.ReadCOO(), utils::ReaderException);
   for (const auto &f : {general, general_v, symm_v, skew_v, bad, garbage}) std::remove(f.c_str());
+}
+
+TEST(EdgeListReader, Basics) {  // io/edge_list_reader_tests.cc:7-80, fixtures reader_data.inc:388-400
+  const std::string edges = write_tmp("e.edges", "1 0\n3 0\n2 1\n4 2\n4 3\n");
+  const std::string edges_v = write_tmp("ev.edges", "1 0 0.1\n3 0 0.2\n2 1 0.3\n4 2 0.4\n4 3 0.5\n");
+  io::EdgeListReader<int, int, int> reader1(edges);  // undirected: every edge twice
+  auto *coo = reader1.ReadCOO();
+  EXPECT_EQ((int)coo->get_num_nnz(), 10);
+  EXPECT_EQ((int)coo->get_dimensions()[0], 5);
+  EXPECT_EQ((int)coo->get_dimensions()[1], 5);
+  for (int i = 0; i < 10; i++) {
+    bool found = false;
+    for (int k = 0; k < 5; k++)
+      found |= (coo->get_row()[i] == m_row[k] && coo->get_col()[i] == m_col[k]) ||
+               (coo->get_row()[i] == m_col[k] && coo->get_col()[i] == m_row[k]);
+    EXPECT_TRUE(found);
+    if (i) EXPECT_TRUE(coo->get_row()[i - 1] < coo->get_row()[i] ||
+                       (coo->get_row()[i - 1] == coo->get_row()[i] && coo->get_col()[i - 1] < coo->get_col()[i]));
+  }
+  delete coo;
+  io::EdgeListReader<int, int, int> reader2(edges, false, false, false, false);  // directed
+  auto *coo2 = reader2.ReadCOO();
+  EXPECT_EQ((int)coo2->get_num_nnz(), 5);
+  EXPECT_EQ((int)coo2->get_dimensions()[1], 4);  // m = max(v) + 1 when neither square nor undirected
+  EXPECT_TRUE(same(coo2->get_row(), m_row, 5));
+  EXPECT_TRUE(same(coo2->get_col(), m_col, 5));
+  delete coo2;
+  io::EdgeListReader<int, int, float> reader3(edges_v, true, false, false, false);  // weighted, directed
+  auto *coo3 = reader3.ReadCOO();
+  EXPECT_EQ((int)coo3->get_num_nnz(), 5);
+  EXPECT_TRUE(same(coo3->get_row(), m_row, 5));
+  EXPECT_TRUE(same(coo3->get_col(), m_col, 5));
+  EXPECT_TRUE(same(coo3->get_vals(), m_vals, 5));
+  delete coo3;
+  auto *csr = bases::IOBase::ReadEdgeListToCSR<int, int, float>(edges_v, true, false, false, true);  // square
+  EXPECT_TRUE(same(csr->get_row_ptr(), m_row_ptr, 6));
+  EXPECT_TRUE(same(csr->get_vals(), m_vals, 5));
+  EXPECT_EQ((int)csr->get_dimensions()[1], 5);
+  delete csr;
+  EXPECT_THROW((io::EdgeListReader<int, int, void>(edges_v, true).ReadCOO()), utils::ReaderException);
+  EXPECT_THROW((io::EdgeListReader<int, int, int>("/nonexistent.edges").ReadCOO()), utils::ReaderException);
+  std::remove(edges.c_str());
+  std::remove(edges_v.c_str());
 }
 
 // ------------------------------------------------------------------ feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc

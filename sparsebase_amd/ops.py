@@ -205,6 +205,35 @@ def mtx_parse_coordinate(text, n_rows, n_cols, entries, fields, symmetry=0, zero
     return row[:k], col[:k], (None if val is None else val[:k])
 
 
+def text_count_tokens(text):
+    hd = handle_for(_check_dev(text))
+    out = C.c_int64(0)
+    hd.check(hd.lib.sbx_text_count_tokens(hd.h, _p(text), text.numel(), C.byref(out)))
+    return out.value
+
+
+def edge_list_parse(text, weighted=False, remove_duplicates=False, remove_self_edges=False, read_undirected=True,
+                    square=False, index_dtype=torch.int32, value_dtype=None):
+    """Edge list text (uint8 device tensor) -> (n, m, row, col, val) sorted by (row, col); EdgeListReader::ReadCOO."""
+    hd = handle_for(_check_dev(text))
+    fields = 3 if weighted else 2
+    tokens = text_count_tokens(text)
+    if tokens % fields:
+        raise ValueError(f"edge list holds {tokens} tokens, not a multiple of {fields}")
+    entries = tokens // fields
+    cap = max(1, entries * (2 if read_undirected else 1))
+    row = torch.empty(cap, dtype=index_dtype, device=text.device)
+    col = torch.empty(cap, dtype=index_dtype, device=text.device)
+    val = None if (value_dtype is None or not weighted) else torch.empty(cap, dtype=value_dtype, device=text.device)
+    dims = (C.c_int64 * 3)()
+    flags = (1 if remove_duplicates else 0) | (2 if remove_self_edges else 0) | (4 if read_undirected else 0) | \
+        (8 if square else 0)
+    hd.check(hd.lib.sbx_edge_list_parse(hd.h, _it(row), _vt(val), _p(text), text.numel(), entries, int(weighted), flags,
+                                        cap, _p(row), _p(col), _p(val), dims))
+    k = dims[2]
+    return dims[0], dims[1], row[:k], col[:k], (None if val is None else val[:k])
+
+
 # ----------------------------------------------------------------------------- features (SURVEY §8f.2)
 def csr_degrees(row_ptr):
     hd = handle_for(_check_dev(row_ptr))

@@ -42,3 +42,26 @@ def random_mtx(seed, field="real", symmetry="general", n=None, nnz=None, messy=F
         body = body.rstrip("\n")     # no newline at the end of the file
     head = f"%%MatrixMarket matrix coordinate {field} {symmetry}\n% a comment line\n{n} {m} {L}\n"
     return head, body, n, m, L
+
+
+def random_edge_list(seed, weighted=False, n=None, edges=None, dup_frac=0.2, self_frac=0.05):
+    """Edge list text with duplicate edges (carrying EQUAL weights, so that which duplicate survives
+    std::unique after the reference's unstable sort does not matter) and self loops."""
+    g = np.random.default_rng(seed)
+    n = int(g.integers(2, 400)) if n is None else n
+    e = int(g.integers(0, 3000)) if edges is None else edges
+    u, v = g.integers(0, n, e), g.integers(0, n, e)
+    loops = g.random(e) < self_frac
+    v[loops] = u[loops]
+    k = int(e * dup_frac)
+    if e and k:
+        src = g.integers(0, e, k)
+        u, v = np.concatenate([u, u[src]]), np.concatenate([v, v[src]])
+    # weight = a function of the undirected pair, so every duplicate (and a reverse edge written by read_undirected) agrees
+    lo, hi = np.minimum(u, v), np.maximum(u, v)
+    w = ((lo * 7919 + hi * 104729) % 1000) / 8.0 - 30.0
+    p = g.permutation(len(u))
+    lines = []
+    for i in p:
+        lines.append(f"{u[i]} {v[i]}" + (f" {float(w[i])!r}" if weighted else ""))
+    return "\n".join(lines) + ("\n" if lines else "")

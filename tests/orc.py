@@ -109,6 +109,19 @@ class Oracle:
         k = nnz.value
         return row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
 
+    def edge_list_parse(self, text, weighted=False, remove_duplicates=False, remove_self_edges=False,
+                        read_undirected=True, square=False, index_dtype=np.int32, value_dtype=None):
+        buf = bytes(text)
+        cap = max(1, 2 * (buf.count(b"\n") + 2) * 2)
+        row, col = np.empty(cap, index_dtype), np.empty(cap, index_dtype)
+        val = None if value_dtype is None else np.empty(cap, value_dtype)
+        dims = (C.c_int64 * 3)()
+        self.lib.orc_edge_list_parse(0 if index_dtype == np.int32 else 1, vt_of(val), buf, C.c_int64(len(buf)),
+                                     int(weighted), int(remove_duplicates), int(remove_self_edges), int(read_undirected),
+                                     int(square), _p(row), _p(col), _p(val), dims)
+        k = dims[2]
+        return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
+
     def csr_bandwidth(self, rp, col):
         return int(self.lib.orc_csr_bandwidth(it_of(rp), C.c_int64(len(rp) - 1), _p(rp), _p(col)))
 
@@ -259,6 +272,19 @@ class Ref:
                                    int(upper), C.c_int64(cap), _p(row), _p(col), _p(val), dims)
         if rc != 0:
             raise ValueError(f"ref_mtx_read rc={rc}")
+        k = dims[2]
+        return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
+
+    def edge_list_read(self, path, weighted=False, remove_duplicates=False, remove_self_edges=False,
+                       read_undirected=True, square=False, index_dtype=np.int32, value_dtype=None, cap=1 << 22):
+        row, col = np.empty(cap, index_dtype), np.empty(cap, index_dtype)
+        val = None if value_dtype is None else np.empty(cap, value_dtype)
+        dims = (C.c_int64 * 3)()
+        rc = self.lib.ref_edge_list_read(0 if index_dtype == np.int32 else 1, vt_of(val), str(path).encode(), int(weighted),
+                                         int(remove_duplicates), int(remove_self_edges), int(read_undirected), int(square),
+                                         C.c_int64(cap), _p(row), _p(col), _p(val), dims)
+        if rc != 0:
+            raise ValueError(f"ref_edge_list_read rc={rc}")
         k = dims[2]
         return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
 

@@ -152,6 +152,26 @@ def test_kat_mtx_reader(ops, kat):
                 assert np.array_equal(host(val), np.array(k["vals"], np.float32))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_edge_list_vs_oracle(ops, oracle, seed):
+    import mtxgen
+    weighted = seed % 2 == 1
+    text = mtxgen.random_edge_list(5000 + seed, weighted, n=(20000 if seed == 5 else None), edges=(300000 if seed == 5 else None))
+    dtext = torch.frombuffer(bytearray(text.encode() or b" "), dtype=torch.uint8).cuda()
+    for vnp, vt in ((np.float32, torch.float32), (np.float64, torch.float64)) if weighted else ((None, None),):
+        for dedup in (False, True):
+            for no_self in (False, True):
+                for undirected in (False, True):
+                    for square in (False, True):
+                        for inp, it in ((np.int32, torch.int32),) if seed else ((np.int32, torch.int32), (np.int64, torch.int64)):
+                            want = oracle.edge_list_parse(text.encode(), weighted, dedup, no_self, undirected, square, inp, vnp)
+                            got = ops.edge_list_parse(dtext, weighted, dedup, no_self, undirected, square, it, vt)
+                            assert (got[0], got[1]) == (want[0], want[1])
+                            assert np.array_equal(host(got[2]), want[2]) and np.array_equal(host(got[3]), want[3])
+                            if weighted:
+                                assert np.array_equal(host(got[4]), want[4])
+
+
 def test_mtx_parse_errors_and_edges(ops):
     from sparsebase_amd import capi
     def parse(body, L, fields=3, vt=torch.float64):
