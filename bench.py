@@ -212,6 +212,42 @@ def main():
             "rowwise": rowwise,
         }
 
+    # ---- the other step that shards (north_star): COO -> CSR by row range, same row_ptr stitch
+    convert_apply = None
+    if not args.no_sharded:
+        from sparsebase_amd import sharded
+        if world > 1:
+            rp_c, col_c = (rp, col) if rank == 0 else synth.rmat_symmetric_torch(args.scale, args.edge_factor, seed=1, device=dev)
+        else:
+            rp_c, col_c = rp, col
+        n_c, nnz_c = rp_c.numel() - 1, col_c.numel()
+        val_c = torch.ones(nnz_c, device=dev, dtype=torch.float32)
+        row_c = ops.csr_to_coo(n_c, n_c, rp_c, col_c, None, move=True)[0]   # replicated row-sorted COO
+
+        def convert_step():
+            if world > 1:
+                return sharded.coo_to_csr_sharded(n_c, n_c, row_c, col_c, val_c)
+            return ops.coo_to_csr(n_c, n_c, row_c, col_c, val_c, rows_sorted=True)
+
+        convert_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            convert_step()
+        barrier()
+        wc = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([wc], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wc = float(t.item())
+        alg_c = 20 * nnz_c + 4 * (n_c + 1)
+        convert_apply = {
+            "workload": (f"COO->CSR of one RMAT scale-{args.scale} COO, row ranges over {world} GPU(s), all-gather of row_ptr"
+                         if world > 1 else f"COO->CSR (copy), RMAT scale-{args.scale}, 1 GPU"),
+            "scaling": "strong", "value": n_c * args.steps / wc / 1e6, "unit": "Mrows/s", "ms_per_step": wc / args.steps * 1e3,
+            "alg_gbs": alg_c * args.steps / wc / 1e9, "frac_of_hbm_peak": alg_c * args.steps / wc / 1e9 / (HBM_PEAK_GBS * world)}
+        del row_c, val_c
+
     # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -228,6 +264,7 @@ def main():
                                    "one instance per GPU",
                        "rows": n, "nnz": nnz, "rcm": stats},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "permute_apply": permute_apply,
+            "convert_apply": convert_apply,
         }
         print(json.dumps(line))
     if world > 1:
