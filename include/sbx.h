@@ -172,7 +172,7 @@ int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t
  * with SBX_MTX_UPPER_TRIANGLE the entry is stored as (min, max) instead (:368-384).  SBX_MTX_ZERO_INDEX
  * subtracts 1 from both indices (:334-337).  Outputs need capacity >= entries (2 * entries when mirrors
  * are produced); *nnz_host receives the number of nonzeros written.  The COO constructor's sort is the
- * caller's next step (sbx_coo_sort).  Malformed tokens -> SBX_ERR_BAD_ARG; values with more than 19
+ * caller's next step (sbx_coo_sort).  Malformed tokens -> SBX_ERR_BAD_ARG; values with more than 38
  * significant digits and a non-zero tail -> SBX_ERR_UNSUPPORTED.  Synchronous.                 */
 /* ------------------------------------------------------------------ */
 #define SBX_MTX_ZERO_INDEX 1u

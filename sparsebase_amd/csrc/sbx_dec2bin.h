@@ -1,6 +1,6 @@
 // sbx_dec2bin.h — exact decimal -> binary floating point for the Matrix Market parser.
 //
-// value = w * 10^q10 with w < 2^64 (at most 19 significant decimal digits) is converted to
+// value = w * 10^q10 with w < 2^128 (up to 38 significant decimal digits) is converted to
 // the nearest double / float, ties to even — the result strtod / strtof (and therefore
 // `istream >> double/float`, which the reference reader uses, io/mtx_reader.cc:331) produce.
 // No floating-point arithmetic is involved: the value is formed exactly in multi-limb
@@ -20,6 +20,7 @@
 
 #define SBX_POW5_MAX 400   /* |q10| up to here is converted exactly; beyond: 0 / inf by magnitude */
 #define SBX_POW5_LIMBS 16  /* 5^400 has 929 bits */
+#define SBX_DECIMAL_MAX_DIGITS 38
 
 // table[k * SBX_POW5_LIMBS + i] = limb i (little endian) of 5^k, k = 0..SBX_POW5_MAX
 static inline void sbx_pow5_table_fill(uint64_t *table) {
@@ -88,23 +89,40 @@ SBX_HD uint64_t round_pack(uint64_t mant, int e2, bool sticky) {
   return ((uint64_t)(exp - EMIN + 1) << (P - 1)) | (kept & ((1ull << (P - 1)) - 1ull));
 }
 
-// exact (mant, e2, sticky) with mant in [2^63, 2^64) for w * 10^q10, w != 0, |q10| <= SBX_POW5_MAX
-SBX_HD void exact_scale(uint64_t w, int q10, const uint64_t *pow5, uint64_t *mant, int *e2, bool *sticky) {
+// dst (nd limbs, zeroed here) = src (ns limbs) << shift
+SBX_HD void shl_multi(uint64_t *dst, int nd, const uint64_t *src, int ns, int shift) {
+  for (int i = 0; i < nd; i++) dst[i] = 0;
+  const int limb = shift >> 6, bit = shift & 63;
+  for (int i = 0; i < ns; i++) {
+    if (i + limb < nd) dst[i + limb] |= src[i] << bit;
+    if (bit && i + limb + 1 < nd) dst[i + limb + 1] |= src[i] >> (64 - bit);
+  }
+}
+
+// exact (mant, e2, sticky) with mant in [2^63, 2^64) for w * 10^q10, w = w_hi * 2^64 + w_lo != 0,
+// |q10| <= SBX_POW5_MAX
+SBX_HD void exact_scale(uint64_t w_hi, uint64_t w_lo, int q10, const uint64_t *pow5, uint64_t *mant, int *e2,
+                        bool *sticky) {
+  constexpr int NL = SBX_POW5_LIMBS + 2;
+  const uint64_t w[2] = {w_lo, w_hi};
+  const int wl = w_hi ? 2 : 1;
   if (q10 >= 0) {
-    // N = w * 5^q (SBX_POW5_LIMBS + 1 limbs), value = N * 2^q
+    // N = w * 5^q, value = N * 2^q
     const uint64_t *p5 = pow5 + (size_t)q10 * SBX_POW5_LIMBS;
-    uint64_t n[SBX_POW5_LIMBS + 1];
-    unsigned __int128 carry = 0;
-    for (int i = 0; i < SBX_POW5_LIMBS; i++) {
-      const unsigned __int128 t = (unsigned __int128)p5[i] * w + carry;
-      n[i] = (uint64_t)t;
-      carry = t >> 64;
+    uint64_t n[NL];
+    for (int i = 0; i < NL; i++) n[i] = 0;
+    for (int j = 0; j < wl; j++) {
+      unsigned __int128 carry = 0;
+      for (int i = 0; i < SBX_POW5_LIMBS; i++) {
+        const unsigned __int128 t = (unsigned __int128)p5[i] * w[j] + n[i + j] + carry;
+        n[i + j] = (uint64_t)t;
+        carry = t >> 64;
+      }
+      n[SBX_POW5_LIMBS + j] += (uint64_t)carry;
     }
-    n[SBX_POW5_LIMBS] = (uint64_t)carry;
-    const int nl = limbs_of(n, SBX_POW5_LIMBS + 1);
+    const int nl = limbs_of(n, NL);
     const int lz = clz64(n[nl - 1]);
-    // top 64 bits of N
-    uint64_t top = n[nl - 1] << lz;
+    uint64_t top = n[nl - 1] << lz;  // top 64 bits of N
     bool st = false;
     if (nl >= 2) {
       if (lz) top |= n[nl - 2] >> (64 - lz);
@@ -121,36 +139,24 @@ SBX_HD void exact_scale(uint64_t w, int q10, const uint64_t *pow5, uint64_t *man
   const uint64_t *d = pow5 + (size_t)k * SBX_POW5_LIMBS;
   const int dl = limbs_of(d, SBX_POW5_LIMBS);
   const int dbits = 64 * dl - clz64(d[dl - 1]);
-  const int wbits = 64 - clz64(w);
-  // rem = w << (dbits - wbits): same bit length as d, so rem / d is in (1/2, 2)
-  uint64_t rem[SBX_POW5_LIMBS + 1];
-  for (int i = 0; i <= SBX_POW5_LIMBS; i++) rem[i] = 0;
-  int sh = dbits - wbits;  // may be negative when 5^k is shorter than w (small k)
-  int s_total;             // value = (quotient stream) * 2^(-s_total - k) with quotient = rem0 * 2^i / d
+  const int wbits = 64 * wl - clz64(w[wl - 1]);
+  // align the two operands to the same bit length, so that rem / dd is in (1/2, 2):
+  // sh >= 0: rem = w << sh, dd = d;  sh < 0 (5^k shorter than w): rem = w, dd = d << -sh
+  const int sh = dbits - wbits;
+  uint64_t rem[NL], dd[NL];
   if (sh >= 0) {
-    rem[sh >> 6] = w << (sh & 63);
-    if ((sh & 63) && (sh >> 6) + 1 <= SBX_POW5_LIMBS) rem[(sh >> 6) + 1] = w >> (64 - (sh & 63));
-    s_total = sh;
+    shl_multi(rem, NL, w, wl, sh);
+    shl_multi(dd, NL, d, dl, 0);
   } else {
-    // d is shorter than w: scale d up instead (compare against d << -sh), i.e. divide w by d * 2^-sh
-    rem[0] = w;
-    s_total = sh;  // negative: quotient is larger by 2^-sh
+    shl_multi(rem, NL, w, wl, 0);
+    shl_multi(dd, NL, d, dl, -sh);
   }
-  const int rl = dl + 1 > 2 ? dl + 1 : 2;  // limbs that can be non-zero in rem / shifted d
-  uint64_t dd[SBX_POW5_LIMBS + 1];
-  for (int i = 0; i <= SBX_POW5_LIMBS; i++) dd[i] = i < dl ? d[i] : 0;
-  if (sh < 0) {  // dd = d << (-sh), still fits: its bit length becomes wbits <= 64
-    const int up = -sh;
-    uint64_t lo = d[0] << up;  // dl == 1 here because dbits < wbits <= 64
-    dd[0] = lo;
-    dd[1] = 0;
-  }
-  // produce quotient bits until the leading 1 has been seen and 63 more follow
+  const int ml = dl > wl ? dl : wl;
+  const int rl = ml + 1;  // limbs that can be non-zero (rem < 2 * dd at every step)
   uint64_t q = 0;
-  int produced = 0;  // quotient bits after the leading one, inclusive
+  int produced = 0;  // quotient bits from the leading one on
   int steps = 0;
   while (produced < 64) {
-    // compare rem >= dd over rl limbs
     bool ge = true;
     for (int i = rl - 1; i >= 0; i--) {
       if (rem[i] != dd[i]) {
@@ -180,30 +186,30 @@ SBX_HD void exact_scale(uint64_t w, int q10, const uint64_t *pow5, uint64_t *man
   for (int i = 0; i < rl; i++) st |= rem[i] != 0;
   *mant = q;
   *sticky = st;
-  // quotient bit j (j = 0 first step) has weight 2^-j relative to rem0/dd; q collects `steps` bits:
-  // rem0 / dd = q * 2^-(steps - 1) (+ remainder), and w / d = (rem0 / dd) * 2^(-s_total)
-  *e2 = -(steps - 1) - s_total - k;
+  // quotient bit j (j = 0 first step) has weight 2^-j relative to rem0 / dd; q collects `steps` bits:
+  // rem0 / dd = q * 2^-(steps - 1) (+ remainder), and w / d = (rem0 / dd) * 2^-sh
+  *e2 = -(steps - 1) - sh - k;
 }
 
 template <int P, int EMIN, int EMAX, int EXP_BITS>
-SBX_HD uint64_t convert(uint64_t w, int q10, const uint64_t *pow5) {
-  if (w == 0) return 0;
+SBX_HD uint64_t convert(uint64_t w_hi, uint64_t w_lo, int q10, const uint64_t *pow5) {
+  if ((w_hi | w_lo) == 0) return 0;
   if (q10 > SBX_POW5_MAX) return (uint64_t)((1u << EXP_BITS) - 1u) << (P - 1);  // >= 10^401: infinity in both formats
-  if (q10 < -SBX_POW5_MAX) return 0;  // < 2^64 * 10^-401: below half the smallest subnormal
+  if (q10 < -SBX_POW5_MAX) return 0;  // < 10^38 * 10^-401: below half the smallest subnormal
   uint64_t mant;
   int e2;
   bool sticky;
-  exact_scale(w, q10, pow5, &mant, &e2, &sticky);
+  exact_scale(w_hi, w_lo, q10, pow5, &mant, &e2, &sticky);
   return round_pack<P, EMIN, EMAX, EXP_BITS>(mant, e2, sticky);
 }
 
 }  // namespace sbx_d2b
 
 // ---- token -> (sign, w, q10): the characters `istream >> double` consumes (libstdc++ num_get: digits, one
-// '.', an exponent) — no hex floats, no inf/nan.  status: 0 ok, 1 malformed, 2 more than 19 significant
-// digits with a non-zero tail (not representable in w; refused rather than rounded twice).
+// '.', an exponent) — no hex floats, no inf/nan.  status: 0 ok, 1 malformed, 2 more than 38 significant
+// digits with a non-zero tail (not representable in the 128-bit w; refused rather than rounded twice).
 struct sbx_decimal {
-  uint64_t w;
+  uint64_t w_lo, w_hi;  // the first (up to) 38 significant digits as an integer
   int q10;
   int neg;
   int status;
@@ -211,7 +217,8 @@ struct sbx_decimal {
 
 SBX_HD sbx_decimal sbx_parse_decimal(const char *s, int64_t len) {
   sbx_decimal r;
-  r.w = 0; r.q10 = 0; r.neg = 0; r.status = 1;
+  r.w_lo = 0; r.w_hi = 0; r.q10 = 0; r.neg = 0; r.status = 1;
+  unsigned __int128 w = 0;
   int64_t i = 0;
   if (i < len && (s[i] == '+' || s[i] == '-')) { r.neg = s[i] == '-'; i++; }
   int digits = 0;       // significant digits taken into w
@@ -223,7 +230,7 @@ SBX_HD sbx_decimal sbx_parse_decimal(const char *s, int64_t len) {
     any = 1;
     const int dgt = s[i] - '0';
     if (digits == 0 && dgt == 0) continue;  // leading zero
-    if (digits < 19) { r.w = r.w * 10u + (uint64_t)dgt; digits++; }
+    if (digits < 38) { w = w * 10u + (unsigned)dgt; digits++; }
     else { dropped++; tail_nonzero |= dgt != 0; }
   }
   if (i < len && s[i] == '.') {
@@ -232,7 +239,7 @@ SBX_HD sbx_decimal sbx_parse_decimal(const char *s, int64_t len) {
       any = 1;
       const int dgt = s[i] - '0';
       if (digits == 0 && dgt == 0) { frac_taken++; continue; }  // 0.000x: scale only
-      if (digits < 19) { r.w = r.w * 10u + (uint64_t)dgt; digits++; frac_taken++; }
+      if (digits < 38) { w = w * 10u + (unsigned)dgt; digits++; frac_taken++; }
       else tail_nonzero |= dgt != 0;
     }
   }
@@ -252,6 +259,8 @@ SBX_HD sbx_decimal sbx_parse_decimal(const char *s, int64_t len) {
   if (q > 200000) q = 200000;
   if (q < -200000) q = -200000;
   r.q10 = (int)q;
+  r.w_lo = (uint64_t)w;
+  r.w_hi = (uint64_t)(w >> 64);
   r.status = tail_nonzero ? 2 : 0;
   return r;
 }
@@ -274,9 +283,9 @@ SBX_HD int sbx_parse_integer(const char *s, int64_t len, long long *out) {
 }
 
 // IEEE bit patterns (sign applied by the caller)
-SBX_HD uint64_t sbx_decimal_to_double_bits(uint64_t w, int q10, const uint64_t *pow5) {
-  return sbx_d2b::convert<53, -1022, 1023, 11>(w, q10, pow5);
+SBX_HD uint64_t sbx_decimal_to_double_bits(const sbx_decimal &d, const uint64_t *pow5) {
+  return sbx_d2b::convert<53, -1022, 1023, 11>(d.w_hi, d.w_lo, d.q10, pow5);
 }
-SBX_HD uint32_t sbx_decimal_to_float_bits(uint64_t w, int q10, const uint64_t *pow5) {
-  return (uint32_t)sbx_d2b::convert<24, -126, 127, 8>(w, q10, pow5);
+SBX_HD uint32_t sbx_decimal_to_float_bits(const sbx_decimal &d, const uint64_t *pow5) {
+  return (uint32_t)sbx_d2b::convert<24, -126, 127, 8>(d.w_hi, d.w_lo, d.q10, pow5);
 }

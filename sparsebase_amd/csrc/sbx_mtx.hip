@@ -11,7 +11,7 @@
 // is placed by an exclusive scan of the mirror flags.  The COO constructor's sort is the
 // caller's next step (sbx_coo_sort).  Tokens the stream extraction would choke on (hex,
 // inf/nan, garbage, a '.' in an integer field) are reported as an error instead of
-// reproducing the stream's fail state; values with more than 19 significant digits and a
+// reproducing the stream's fail state; values with more than 38 significant digits and a
 // non-zero tail are refused (SBX_ERR_UNSUPPORTED).
 #include "sbx_dec2bin.h"
 #include "sbx_device.h"
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(MX_THREADS) void k_mtx_parse(const char *__restrict
       const sbx_decimal d = sbx_parse_decimal(text + s, len);
       if (d.status == 1) bad |= MX_BAD_VALUE;
       if (d.status == 2) bad |= MX_TOO_MANY_DIGITS;
-      if (VKIND == 2) vbits = (uint64_t)(sbx_decimal_to_float_bits(d.w, d.q10, pow5) | ((uint32_t)d.neg << 31));
-      else vbits = sbx_decimal_to_double_bits(d.w, d.q10, pow5) | ((uint64_t)d.neg << 63);
+      if (VKIND == 2) vbits = (uint64_t)(sbx_decimal_to_float_bits(d, pow5) | ((uint32_t)d.neg << 31));
+      else vbits = sbx_decimal_to_double_bits(d, pow5) | ((uint64_t)d.neg << 63);
     }
   }
   if (upper && symmetry != 0) {  // :368-384: keep the entry in the upper triangle, no mirror
@@ -376,7 +376,7 @@ extern "C" int sbx_mtx_parse_coordinate(sbx_handle_t h, sbx_index_type it, sbx_v
   unsigned st[2] = {0, 0};
   SBX_TRY(sbx_readback(h, st, status, sizeof(st)));
   if (st[0] & MX_TOO_MANY_DIGITS)
-    SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_mtx_parse_coordinate: a value has more than 19 significant digits");
+    SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_mtx_parse_coordinate: a value has more than 38 significant digits");
   if (st[0])
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_mtx_parse_coordinate: malformed %s%s%s token in the coordinate section",
              (st[0] & MX_BAD_INDEX) ? "index " : "", (st[0] & MX_INDEX_RANGE) ? "(index out of range) " : "",

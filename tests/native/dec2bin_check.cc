@@ -22,15 +22,15 @@ static int check(const std::string &tok, int *bad) {
     if (full && tok.find_first_of("xXpPnNiI") == std::string::npos) { std::printf("parser rejects %s\n", tok.c_str()); (*bad)++; }
     return 0;
   }
-  if (d.status == 2) return 0;  // > 19 significant digits: refused by design
+  if (d.status == 2) return 0;  // > 38 significant digits with a non-zero tail: refused by design
   const float want_f = strtof(tok.c_str(), nullptr);
-  uint64_t got_d = sbx_decimal_to_double_bits(d.w, d.q10, table.data()) | ((uint64_t)d.neg << 63);
-  uint32_t got_f = sbx_decimal_to_float_bits(d.w, d.q10, table.data()) | ((uint32_t)d.neg << 31);
+  uint64_t got_d = sbx_decimal_to_double_bits(d, table.data()) | ((uint64_t)d.neg << 63);
+  uint32_t got_f = sbx_decimal_to_float_bits(d, table.data()) | ((uint32_t)d.neg << 31);
   uint64_t wd; uint32_t wf;
   memcpy(&wd, &want_d, 8); memcpy(&wf, &want_f, 4);
   if (got_d != wd || got_f != wf) {
-    if (*bad < 10) std::printf("MISMATCH %s: double %016" PRIx64 " want %016" PRIx64 "  float %08x want %08x (w=%" PRIu64 " q=%d)\n",
-                               tok.c_str(), got_d, wd, got_f, wf, d.w, d.q10);
+    if (*bad < 10) std::printf("MISMATCH %s: double %016" PRIx64 " want %016" PRIx64 "  float %08x want %08x (w_hi=%" PRIu64 " w_lo=%" PRIu64 " q=%d)\n",
+                               tok.c_str(), got_d, wd, got_f, wf, d.w_hi, d.w_lo, d.q10);
     (*bad)++;
   }
   return 1;
@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
   for (const char *f : fixed) checked += check(f, &bad);
   for (long i = 0; i < count; i++) {
     std::string tok;
-    const int kind = (int)(g() % 6);
+    const int kind = (int)(g() % 8);
     if (kind == 0) {  // random double printed with 17 significant digits
       uint64_t bits = g();
       double x; memcpy(&x, &bits, 8);
@@ -76,6 +76,18 @@ int main(int argc, char **argv) {
       const uint64_t m = (g() % (1ull << 53)) | (1ull << 52);
       const int e = (int)(g() % 40) - 20;
       char buf[64]; snprintf(buf, sizeof buf, "%.19g", std::ldexp((double)m + 0.5 * (g() & 1), e)); tok = buf;
+    } else if (kind == 6) {  // 20..38 significant digits: exact decimal expansions of halfway points and their neighbours
+      const uint64_t m = (g() % (1ull << 53)) | (1ull << 52);
+      const int e = (int)(g() % 60) - 30;
+      char buf[128]; snprintf(buf, sizeof buf, "%.*e", 19 + (int)(g() % 19), std::ldexp((double)m + 0.5, e) * (1.0 + (double)(int)(g() % 3 - 1) * 1e-17));
+      // printing a double cannot show the halfway point itself; build it from the integer: (2m + 1) * 2^(e-1)
+      if (e >= 1 && e <= 10) { unsigned __int128 v = ((unsigned __int128)(2 * m + 1)) << (e - 1); std::string t; while (v) { t.insert(t.begin(), (char)('0' + (int)(v % 10))); v /= 10; } tok = t; }
+      else tok = buf;
+    } else if (kind == 7) {  // long random digit strings
+      const int nd = 20 + (int)(g() % 30);
+      for (int k = 0; k < nd; k++) tok += (char)('0' + (k == 0 ? 1 + g() % 9 : g() % 10));
+      tok.insert(1 + g() % tok.size(), ".");
+      char buf[16]; snprintf(buf, sizeof buf, "e%d", (int)(g() % 640) - 320); tok += buf;
     } else {  // plain integers and fixed-point
       char buf[64]; snprintf(buf, sizeof buf, "%lld.%03d", (long long)(g() % 2000000000000ll) - 1000000000000ll, (int)(g() % 1000)); tok = buf;
     }

@@ -183,10 +183,12 @@ def test_mtx_parse_errors_and_edges(ops):
     for bad in (b"1 2 0.5\n3 4", b"1 2 0.5\n3 x 1", b"1 2 nan", b"1 2 0x10", b"1 2 1.5.2", b"0 2 1"):
         with pytest.raises(capi.SbxError):
             parse(bad, 2 if bad.count(b"\n") else 1)
-    with pytest.raises(capi.SbxError):   # 20 significant digits with a non-zero tail
-        parse(b"1 1 1.2345678901234567891", 1)
-    r, c, v = parse(b"1 1 12345678901234567890000", 1)   # zeros beyond 19 digits are exact
-    assert host(v).tolist() == [1.234567890123456789e22]
+    r, c, v = parse(b"1 1 1.2345678901234567891\n2 2 9007199254740993.00000000000000000001", 2)   # up to 38 significant digits are exact
+    assert host(v).tolist() == [1.2345678901234567891, 9007199254740994.0]
+    with pytest.raises(capi.SbxError):   # more than 38 significant digits with a non-zero tail
+        parse(b"1 1 1.23456789012345678901234567890123456789012", 1)
+    r, c, v = parse(b"1 1 12345678901234567890000000000000000000000000000000", 1)   # zeros beyond 38 digits are exact
+    assert host(v).tolist() == [1.234567890123456789e49]
     with pytest.raises(capi.SbxError):   # a '.' in an integer field
         parse(b"1 1 2.5", 1, 3, torch.int32)
 
