@@ -442,8 +442,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       const int bits = (remaining + passes_left - 1) / passes_left;
       const unsigned mask = (1u << bits) - 1u;
       const int shift = done;
+      if (tid < 256) {
 #pragma unroll
-      for (int i = 0; i < PT_THREADS / 64; i++) s_whist[i][tid] = 0;
+        for (int i = 0; i < PT_THREADS / 64; i++) s_whist[i][tid] = 0;
+      }
       int kc[PT_ITEMS], kr[PT_ITEMS];
       V kv[HASV ? PT_ITEMS : 1];
       unsigned rank[PT_ITEMS];
@@ -476,17 +478,21 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       {
         unsigned c4[PT_THREADS / 64];
         unsigned tot = 0;
+        if (tid < 256) {  // thread `tid` owns digit `tid`
 #pragma unroll
-        for (int i = 0; i < PT_THREADS / 64; i++) {
-          c4[i] = s_whist[i][tid];
-          tot += c4[i];
+          for (int i = 0; i < PT_THREADS / 64; i++) {
+            c4[i] = s_whist[i][tid];
+            tot += c4[i];
+          }
         }
         unsigned all;
         unsigned ex = sbx_block_exclusive_sum<unsigned, PT_THREADS>(tot, s_scan, &all);
+        if (tid < 256) {
 #pragma unroll
-        for (int i = 0; i < PT_THREADS / 64; i++) {
-          s_whist[i][tid] = ex;
-          ex += c4[i];
+          for (int i = 0; i < PT_THREADS / 64; i++) {
+            s_whist[i][tid] = ex;
+            ex += c4[i];
+          }
         }
       }
       __syncthreads();
