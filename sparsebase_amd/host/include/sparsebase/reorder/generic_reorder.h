@@ -9,6 +9,8 @@ class GenericReorder : public Reorderer<IDType> {
  public:
   typedef utils::Parameters ParamsType;
   GenericReorder() = default;
+  // ReorderBase::Reorder<GenericReorder>(params, ...) constructs the operator from its parameter object
+  explicit GenericReorder(ParamsType) {}
 };
 }  // namespace sparsebase::reorder
 #endif

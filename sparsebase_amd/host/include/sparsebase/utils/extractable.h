@@ -1,5 +1,7 @@
-// sparsebase/utils/extractable.h — interface of feature extractors that can be fused by an
-// Extractor (reference: utils/extractable.h:32-104).
+// sparsebase/utils/extractable.h — what a feature extractor has to offer so that several of them can be
+// fused and driven through one interface (reference: utils/extractable.h:32-104): its identity, the
+// identities and fresh instances of the extractors fused into it, their parameter objects, and the
+// extraction itself, which returns {type_index of the feature class -> std::any holding the result}.
 #ifndef SPARSEBASE_UTILS_EXTRACTABLE_H_
 #define SPARSEBASE_UTILS_EXTRACTABLE_H_
 #include <any>
@@ -16,21 +18,24 @@ namespace sparsebase::utils {
 
 class Extractable {
  public:
-  // features of `format` as {type_index of the feature class -> std::any holding the result}
-  virtual std::unordered_map<std::type_index, std::any> Extract(format::Format *format,
-                                                                std::vector<context::Context *> contexts,
-                                                                bool convert_input) = 0;
-  virtual std::type_index get_id() = 0;
-  virtual std::vector<std::type_index> get_sub_ids() = 0;  // the classes fused into this one
-  virtual std::vector<Extractable *> get_subs() = 0;       // fresh instances of them (caller owns)
-  virtual std::shared_ptr<utils::Parameters> get_params() = 0;
-  virtual std::shared_ptr<utils::Parameters> get_params(std::type_index feature_extractor) = 0;
-  virtual void set_params(std::type_index feature_extractor, std::shared_ptr<utils::Parameters> params) = 0;
+  typedef std::unordered_map<std::type_index, std::any> FeatureMap;
+  typedef std::shared_ptr<utils::Parameters> ParamsPtr;
+
   virtual ~Extractable() = default;
+  // identity
+  virtual std::type_index get_id() = 0;
+  virtual std::vector<std::type_index> get_sub_ids() = 0;
+  virtual std::vector<Extractable *> get_subs() = 0;  // caller owns the instances
+  // parameters: of this object, of one fused extractor
+  virtual ParamsPtr get_params() = 0;
+  virtual ParamsPtr get_params(std::type_index feature_extractor) = 0;
+  virtual void set_params(std::type_index feature_extractor, ParamsPtr params) = 0;
+  // the work
+  virtual FeatureMap Extract(format::Format *format, std::vector<context::Context *> contexts, bool convert_input) = 0;
 
  protected:
-  std::shared_ptr<utils::Parameters> params_;
-  std::unordered_map<std::type_index, std::shared_ptr<utils::Parameters>> pmap_;
+  ParamsPtr params_;
+  std::unordered_map<std::type_index, ParamsPtr> pmap_;
 };
 
 }  // namespace sparsebase::utils
