@@ -74,7 +74,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # SBX_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks
+        # (ranks then share devices); the real runs use nccl = RCCL, one GPU per rank
+        backend = os.environ.get("SBX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+            local_rank = local_rank % torch.cuda.device_count()
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
