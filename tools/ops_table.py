@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sparsebase_amd import ops, synth
 import orc
-ref = orc.Ref() if orc.ref_available() else None
+ref = orc.Ref() if (orc.ref_available() and "--gpu-only" not in sys.argv) else None
 HBM = 8000.0
 
 def gpu_ms(f, reps=7):
