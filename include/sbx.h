@@ -240,7 +240,7 @@ typedef struct sbx_rcm_stats {
   int64_t isolated;         /* vertices with an empty row                   */
   int64_t small_components; /* components ordered by the batched kernel     */
   int64_t large_components; /* components ordered by level-synchronous BFS  */
-  int64_t bfs_sweeps;       /* full BFS sweeps over the largest component   */
+  int64_t bfs_sweeps;       /* full BFS sweeps over the largest component (speculative ones included) */
   int64_t bfs_levels;       /* levels summed over those sweeps              */
   int64_t edges_scanned;    /* adjacency entries visited (all sweeps)       */
   int64_t edges_scanned_bottom_up; /* ... of which by the bottom-up kernel   */

@@ -367,6 +367,12 @@ static double bu_ratio() {
   return r;
 }
 
+// first candidate root of the pseudo-peripheral search whose Cuthill-McKee sweep is run speculatively
+static int64_t rcm_speculate_from() {
+  static const int64_t k = getenv("SBX_DEBUG_RCM_SPECULATE") ? atoll(getenv("SBX_DEBUG_RCM_SPECULATE")) : 2;
+  return k;
+}
+
 struct WaveStage {
   I *buf;                  // this wave's LDS slice
   unsigned cnt;            // wave-uniform fill level
@@ -1300,19 +1306,45 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       }
     for (unsigned c = 0; c < hd.n_large; c++) {
       // pseudo-peripheral search from the component's smallest vertex (:22-81)
+      //
+      // The search ends with the first candidate root whose sweep does not deepen the level
+      // structure, and the Cuthill-McKee sweep that follows starts from that same vertex: the
+      // two sweeps discover identical levels and differ only in the order inside a level.  So
+      // from the third candidate on (the usual place for the search to end) the Cuthill-McKee
+      // sweep is run FIRST.  If the structure did not deepen it already is the final sweep —
+      // one sweep saved; if it did, the plain sweep is still needed (its order inside the last
+      // level breaks the ties for the next candidate) and the speculative one was wasted.
+      // Either way the output is the reference's; only the number of sweeps differs.
       BfsResult r;
-      int64_t prev_ecc = -1, ecc = 0, sweeps = 0, levels = 0;
+      int64_t prev_ecc = -1, ecc = 0, sweeps = 0, levels = 0, candidate = 0;
       I fixed = roots[c];
       bool have_first_sweep = first_is_large && roots[c] == v0;
+      bool cm_done = false;
       while (prev_ecc != ecc) {
         prev_ecc = ecc;
         if (have_first_sweep) {
           r = r0;  // sweep (2) above was exactly this component's first sweep
           have_first_sweep = false;
         } else {
+          if (candidate >= rcm_speculate_from()) {
+            SBX_TRY(run_bfs<true>(h, b, fixed, roots[c], &r));
+            sweeps++;
+            levels += r.levels;
+            const int64_t e = (int64_t)r.levels - 1;
+            const int64_t deepest = e > ecc ? e : ecc;
+            if (deepest == ecc || (int64_t)r.count == deepest + 1) {
+              cm_done = true;  // this candidate is the root and q already holds its Cuthill-McKee order
+              break;
+            }
+            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
+                        (const I *)q, r.count, ppos);
+            SBX_LAUNCH_CHECK(h);
+            fixed = -1;  // k_bfs_start left the root on the device
+          }
           SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
         }
         fixed = -1;  // later sweeps start from the device-resident root
+        candidate++;
         sweeps++;
         levels += r.levels;
         const int64_t e = (int64_t)r.levels - 1;
@@ -1329,9 +1361,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         if (path) break;
       }
       // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
-      SBX_TRY(run_bfs<true>(h, b, -1, roots[c], &r));
-      sweeps++;
-      levels += r.levels;
+      if (!cm_done) {
+        SBX_TRY(run_bfs<true>(h, b, -1, roots[c], &r));
+        sweeps++;
+        levels += r.levels;
+      }
       if ((int64_t)r.count != (int64_t)sizes[c])
         SBX_FAIL(h, SBX_ERR_INTERNAL,
                  "sbx_rcm_reorder: BFS reached %u of %d vertices of a component (pattern not symmetric?)", r.count,
