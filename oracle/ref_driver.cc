@@ -24,6 +24,10 @@
 #include "sparsebase/feature/degrees.h"
 #include "sparsebase/feature/profile.h"
 #include "sparsebase/format/coo.h"
+#include "sparsebase/io/binary_reader_order_one.h"
+#include "sparsebase/io/binary_reader_order_two.h"
+#include "sparsebase/io/binary_writer_order_one.h"
+#include "sparsebase/io/binary_writer_order_two.h"
 #include "sparsebase/io/edge_list_reader.h"
 #include "sparsebase/io/mtx_reader.h"
 #include "sparsebase/format/csc.h"
@@ -352,4 +356,80 @@ int ref_permute_csr(int it, int vt, int64_t n, int64_t m, void *rp, void *col, v
   return 0;
 }
 
+// SbFF binary container, <int,int,float> and Array<float> (io/binary_{reader,writer}_order_{one,two}.cc).
+// The reference's COO reader takes nnz from dimensions[1] and its CSR writer stores dimensions[1]
+// entries of col/vals, so callers keep nnz == column count where the reference must read or write.
+int ref_sbff_write_coo(const char *path, int n, int m, int nnz, int *row, int *col, float *vals) {
+  try {
+    sparsebase::format::COO<int, int, float> coo(n, m, nnz, row, col, vals, sparsebase::format::kNotOwned, true);
+    sparsebase::io::BinaryWriterOrderTwo<int, int, float>(path).WriteCOO(&coo);
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
+int ref_sbff_write_csr(const char *path, int n, int m, int *row_ptr, int *col, float *vals) {
+  try {
+    sparsebase::format::CSR<int, int, float> csr(n, m, row_ptr, col, vals, sparsebase::format::kNotOwned, true);
+    sparsebase::io::BinaryWriterOrderTwo<int, int, float>(path).WriteCSR(&csr);
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
+int ref_sbff_read_coo(const char *path, int64_t cap, int *row, int *col, float *vals, int64_t *dims) {
+  try {
+    auto *coo = sparsebase::io::BinaryReaderOrderTwo<int, int, float>(path).ReadCOO();
+    dims[0] = coo->get_dimensions()[0];
+    dims[1] = coo->get_dimensions()[1];
+    dims[2] = coo->get_num_nnz();
+    dims[3] = coo->get_vals() != nullptr;
+    if (dims[2] > cap) return -3;
+    std::memcpy(row, coo->get_row(), dims[2] * sizeof(int));
+    std::memcpy(col, coo->get_col(), dims[2] * sizeof(int));
+    if (coo->get_vals()) std::memcpy(vals, coo->get_vals(), dims[2] * sizeof(float));
+    delete coo;
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
+int ref_sbff_read_csr(const char *path, int64_t cap_rows, int64_t cap, int *row_ptr, int *col, float *vals, int64_t *dims) {
+  try {
+    auto *csr = sparsebase::io::BinaryReaderOrderTwo<int, int, float>(path).ReadCSR();
+    dims[0] = csr->get_dimensions()[0];
+    dims[1] = csr->get_dimensions()[1];
+    dims[2] = csr->get_num_nnz();
+    dims[3] = csr->get_vals() != nullptr;
+    if (dims[2] > cap || dims[0] > cap_rows) return -3;
+    std::memcpy(row_ptr, csr->get_row_ptr(), (dims[0] + 1) * sizeof(int));
+    std::memcpy(col, csr->get_col(), dims[2] * sizeof(int));
+    if (csr->get_vals()) std::memcpy(vals, csr->get_vals(), dims[2] * sizeof(float));
+    delete csr;
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
+int ref_sbff_write_array(const char *path, int n, float *vals) {
+  try {
+    sparsebase::format::Array<float> arr(n, vals, sparsebase::format::kNotOwned);
+    sparsebase::io::BinaryWriterOrderOne<float>(path).WriteArray(&arr);
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
+int ref_sbff_read_array(const char *path, int64_t cap, float *vals, int64_t *n) {
+  try {
+    auto *arr = sparsebase::io::BinaryReaderOrderOne<float>(path).ReadArray();
+    *n = arr->get_dimensions()[0];
+    if (*n > cap) return -3;
+    std::memcpy(vals, arr->get_vals(), *n * sizeof(float));
+    delete arr;
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
 }  // extern "C"

@@ -10,6 +10,7 @@
 //   feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc  reorder-quality features
 //   io/mtx_reader_tests.cc:47-260 (coordinate files of io/reader_data.inc)   Matrix Market ingest
 //   io/edge_list_reader_tests.cc:7-80                               edge-list ingest
+//   io/binary_{reader,writer}_order_{one,two}_tests.cc                SbFF binary containers
 // Fixtures: functionality_common.inc:6-44, converter/common.inc:5-16, format/common.inc:4-12.
 #include <unistd.h>
 
@@ -372,6 +373,96 @@ TEST(EdgeListReader, Basics) {  // io/edge_list_reader_tests.cc:7-80, fixtures r
   EXPECT_THROW((io::EdgeListReader<int, int, int>("/nonexistent.edges").ReadCOO()), utils::ReaderException);
   std::remove(edges.c_str());
   std::remove(edges_v.c_str());
+}
+
+// ------------------------------------------------------------------ io/binary_{reader,writer}_order_{one,two}_tests.cc
+TEST(BinaryOrderTwo, COO) {  // binary_reader_order_two_tests.cc:7-36, binary_writer_order_two_tests.cc:5-34
+  int row[4]{1, 2, 3, 4}, col[4]{5, 6, 7, 8};
+  float fv[4]{0.1f, 0.2f, 0.3f, 0.4f};
+  format::COO<int, int, float> coo(4, 4, 4, row, col, fv, format::kNotOwned);
+  const std::string path = write_tmp("coo.bin", "");
+  io::BinaryWriterOrderTwo<int, int, float>(path).WriteCOO(&coo);
+  std::unique_ptr<format::COO<int, int, float>> coo2(io::BinaryReaderOrderTwo<int, int, float>(path).ReadCOO());
+  EXPECT_TRUE(coo.get_dimensions() == coo2->get_dimensions());
+  EXPECT_EQ(coo.get_num_nnz(), coo2->get_num_nnz());
+  EXPECT_TRUE(same(coo2->get_row(), row, 4) && same(coo2->get_col(), col, 4) && same(coo2->get_vals(), fv, 4));
+  // straight to the device; nnz is the length of `row`, not the column count
+  int row6[6]{2, 0, 1, 0, 2, 1}, col6[6]{1, 2, 0, 0, 2, 1};
+  float fv6[6]{1, 2, 3, 4, 5, 6};
+  format::COO<int, int, float> wide(3, 3, 6, row6, col6, fv6, format::kNotOwned, true);  // written unsorted
+  bases::IOBase::WriteCOOToBinary(&wide, path);
+  std::unique_ptr<format::HIPCOO<int, int, float>> d(io::BinaryReaderOrderTwo<int, int, float>(path).ReadHIPCOO(*hip_context));
+  EXPECT_EQ((int)d->get_num_nnz(), 6);
+  std::unique_ptr<format::COO<int, int, float>> back(d->Convert<format::COO>(&cpu_context));
+  const int srow[6]{0, 0, 1, 1, 2, 2}, scol[6]{0, 2, 0, 1, 1, 2};  // the constructor sorted it on the device
+  const float sval[6]{4, 2, 3, 6, 1, 5};
+  EXPECT_TRUE(same(back->get_row(), srow, 6) && same(back->get_col(), scol, 6) && same(back->get_vals(), sval, 6));
+  std::unique_ptr<format::COO<int, int, float>> host(bases::IOBase::ReadBinaryToCOO<int, int, float>(path));
+  EXPECT_TRUE(same(host->get_row(), srow, 6) && same(host->get_col(), scol, 6) && same(host->get_vals(), sval, 6));
+  // pattern files; values cannot go into ValueType void (binary_reader_order_two.cc:61-68)
+  format::COO<int, int, void> pattern(3, 3, 6, row6, col6, nullptr, format::kNotOwned, true);
+  io::BinaryWriterOrderTwo<int, int, void>(path).WriteCOO(&pattern);
+  std::unique_ptr<format::COO<int, int, void>> p2(io::BinaryReaderOrderTwo<int, int, void>(path).ReadCOO());
+  EXPECT_TRUE(same(p2->get_row(), srow, 6) && same(p2->get_col(), scol, 6) && p2->get_vals() == nullptr);
+  std::unique_ptr<format::COO<int, int, float>> p3(io::BinaryReaderOrderTwo<int, int, float>(path).ReadCOO());
+  EXPECT_TRUE(p3->get_vals() == nullptr);
+  bases::IOBase::WriteCOOToBinary(&wide, path);
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, void>(path).ReadCOO()), utils::ReaderException);
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, float>(path).ReadCSR()), utils::ReaderException);  // not a CSR file
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, double>(path).ReadCOO()), utils::ReaderException);  // element size
+  EXPECT_THROW((io::BinaryReaderOrderTwo<long long, long long, float>(path).ReadCOO()), utils::ReaderException);
+  std::remove(path.c_str());
+}
+
+TEST(BinaryOrderTwo, CSR) {  // binary_reader_order_two_tests.cc:38-70, binary_writer_order_two_tests.cc:36-70
+  int rp[5]{0, 2, 3, 3, 4}, col[4]{0, 2, 1, 3};
+  float fv[4]{0.1f, 0.2f, 0.3f, 0.4f};
+  format::CSR<int, int, float> csr(4, 4, rp, col, fv, format::kNotOwned);
+  const std::string path = write_tmp("csr.bin", "");
+  io::BinaryWriterOrderTwo<int, int, float>(path).WriteCSR(&csr);
+  std::unique_ptr<format::CSR<int, int, float>> csr2(io::BinaryReaderOrderTwo<int, int, float>(path).ReadCSR());
+  EXPECT_TRUE(csr.get_dimensions() == csr2->get_dimensions());
+  EXPECT_EQ(csr.get_num_nnz(), csr2->get_num_nnz());
+  EXPECT_TRUE(same(csr2->get_row_ptr(), rp, 5) && same(csr2->get_col(), col, 4) && same(csr2->get_vals(), fv, 4));
+  // more nonzeros than columns (outside what the reference's writer can store), rows written unsorted
+  int rp9[4]{0, 3, 5, 9}, col9[9]{2, 0, 1, 2, 0, 3, 1, 0, 2};
+  int iv9[9]{1, 2, 3, 4, 5, 6, 7, 8, 9};
+  format::CSR<int, int, int> wide(3, 4, rp9, col9, iv9, format::kNotOwned, true);
+  bases::IOBase::WriteCSRToBinary(&wide, path);
+  const int scol[9]{0, 1, 2, 0, 2, 0, 1, 2, 3}, sval[9]{2, 3, 1, 5, 4, 8, 7, 9, 6};
+  std::unique_ptr<format::CSR<int, int, int>> host(bases::IOBase::ReadBinaryToCSR<int, int, int>(path));
+  EXPECT_EQ((int)host->get_num_nnz(), 9);
+  EXPECT_TRUE(same(host->get_row_ptr(), rp9, 4) && same(host->get_col(), scol, 9) && same(host->get_vals(), sval, 9));
+  std::unique_ptr<format::HIPCSR<int, int, int>> d(io::BinaryReaderOrderTwo<int, int, int>(path).ReadHIPCSR(*hip_context));
+  std::unique_ptr<CSR3> back(d->Convert<format::CSR>(&cpu_context));
+  EXPECT_TRUE(same(back->get_row_ptr(), rp9, 4) && same(back->get_col(), scol, 9) && same(back->get_vals(), sval, 9));
+  // the file feeds the path directly: read to the device, reorder there
+  reorder::DegreeReorder<int, int, int> by_degree(true);
+  std::unique_ptr<int[]> order(by_degree.GetReorder(d.get(), {hip_context.get()}, false));
+  EXPECT_TRUE(is_permutation_of_iota(order.get(), 3));
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, int>(path).ReadCOO()), utils::ReaderException);
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, void>(path).ReadCSR()), utils::ReaderException);
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, double>(path).ReadCSR()), utils::ReaderException);  // element size
+  std::remove(path.c_str());
+}
+
+TEST(BinaryOrderOne, Array) {  // binary_reader_order_one_tests.cc:6-28
+  int array[5]{1, 2, 3, 4, 5};
+  format::Array<int> sb_array(5, array, format::kNotOwned);
+  const std::string path = write_tmp("arr.bin", "");
+  io::BinaryWriterOrderOne<int>(path).WriteArray(&sb_array);
+  std::unique_ptr<format::Array<int>> a2(io::BinaryReaderOrderOne<int>(path).ReadArray());
+  EXPECT_EQ((int)a2->get_dimensions()[0], 5);
+  EXPECT_TRUE(same(a2->get_vals(), array, 5));
+  std::unique_ptr<format::HIPArray<int>> d(io::BinaryReaderOrderOne<int>(path).ReadHIPArray(*hip_context));
+  std::unique_ptr<format::Array<int>> back(d->Convert<format::Array>(&cpu_context));
+  EXPECT_TRUE(same(back->get_vals(), array, 5));
+  std::unique_ptr<format::Array<int>> a3(bases::IOBase::ReadBinaryToArray<int>(path));
+  EXPECT_TRUE(same(a3->get_vals(), array, 5));
+  EXPECT_THROW((io::BinaryReaderOrderOne<double>(path).ReadArray()), utils::ReaderException);    // element size
+  EXPECT_THROW((io::BinaryReaderOrderOne<unsigned>(path).ReadArray()), utils::ReaderException);  // signed file
+  EXPECT_THROW((io::BinaryReaderOrderTwo<int, int, int>(path).ReadCOO()), utils::ReaderException);
+  std::remove(path.c_str());
 }
 
 // ------------------------------------------------------------------ feature/{bandwidth,profile,degrees,degree_distribution}_tests.cc

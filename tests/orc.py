@@ -288,6 +288,48 @@ class Ref:
         k = dims[2]
         return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (None if val is None else val[:k].copy())
 
+    # ---- SbFF binary containers, <int,int,float> / Array<float>
+    def sbff_write_coo(self, path, n, m, row, col, vals=None):
+        rc = self.lib.ref_sbff_write_coo(str(path).encode(), int(n), int(m), len(row), _p(row), _p(col), _p(vals))
+        if rc != 0:
+            raise ValueError(f"ref_sbff_write_coo rc={rc}")
+
+    def sbff_write_csr(self, path, n, m, row_ptr, col, vals=None):
+        rc = self.lib.ref_sbff_write_csr(str(path).encode(), int(n), int(m), _p(row_ptr), _p(col), _p(vals))
+        if rc != 0:
+            raise ValueError(f"ref_sbff_write_csr rc={rc}")
+
+    def sbff_write_array(self, path, vals):
+        rc = self.lib.ref_sbff_write_array(str(path).encode(), len(vals), _p(vals))
+        if rc != 0:
+            raise ValueError(f"ref_sbff_write_array rc={rc}")
+
+    def sbff_read_coo(self, path, cap=1 << 20):
+        row, col, vals = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32)
+        dims = (C.c_int64 * 4)()
+        rc = self.lib.ref_sbff_read_coo(str(path).encode(), C.c_int64(cap), _p(row), _p(col), _p(vals), dims)
+        if rc != 0:
+            raise ValueError(f"ref_sbff_read_coo rc={rc}")
+        k = dims[2]
+        return dims[0], dims[1], row[:k].copy(), col[:k].copy(), (vals[:k].copy() if dims[3] else None)
+
+    def sbff_read_csr(self, path, cap=1 << 20):
+        rp, col, vals = np.empty(cap + 1, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32)
+        dims = (C.c_int64 * 4)()
+        rc = self.lib.ref_sbff_read_csr(str(path).encode(), C.c_int64(cap), C.c_int64(cap), _p(rp), _p(col), _p(vals), dims)
+        if rc != 0:
+            raise ValueError(f"ref_sbff_read_csr rc={rc}")
+        k = dims[2]
+        return dims[0], dims[1], rp[:dims[0] + 1].copy(), col[:k].copy(), (vals[:k].copy() if dims[3] else None)
+
+    def sbff_read_array(self, path, cap=1 << 20):
+        vals = np.empty(cap, np.float32)
+        n = C.c_int64(0)
+        rc = self.lib.ref_sbff_read_array(str(path).encode(), C.c_int64(cap), _p(vals), C.byref(n))
+        if rc != 0:
+            raise ValueError(f"ref_sbff_read_array rc={rc}")
+        return vals[:n.value].copy()
+
     def features(self, rp, col):
         """(bandwidth, profile as IDType, degrees, float distribution, double distribution) of a square CSR."""
         n = len(rp) - 1
