@@ -767,6 +767,7 @@ constexpr int SL_MAXE = 32768;   // frontier adjacency entries handled in-kernel
 constexpr int SL_CAP = 8192;     // next-level vertices that fit the LDS sort
 constexpr int SL_FPT = SL_MAXF / 1024;  // frontier entries per thread in the degree scan
 constexpr int SL_GROUP = 64;            // children of one parent ordered by counting (longer: bitonic sort)
+constexpr int SL_CH = 8;                // adjacency entries a thread loads together
 static_assert(SL_MAXE <= 32 * 1024, "the plain sweep keeps one winner bit per entry of a thread's run");
 
 template <bool CM>
@@ -833,21 +834,13 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       // in order (a contiguous run per thread), keeps those that won and compacts them.  The
       // Cuthill-McKee sweep gets its children grouped by parent the same way and then only
       // orders each parent's group by degree rank.
-      for (unsigned e = tid; e < etotal; e += 1024) {
-        unsigned lo = 0, hi = fsize - 1;
-        while (lo < hi) {
-          const unsigned mid = (lo + hi + 1) >> 1;
-          if (s_eoff[mid] <= e) lo = mid; else hi = mid - 1;
-        }
-        const I v = col[s_start[lo] + (I)(e - s_eoff[lo])];
-        const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!((word >> (v & 31)) & 1u)) atomicMin(&ppos[v], lo);
-      }
-      __syncthreads();
+      // Every thread owns a contiguous run of <= 32 entries and works through it in chunks of SL_CH with
+      // the loads of a chunk issued together (col, then the bitmap words, then ppos): a level costs a
+      // fixed handful of dependent memory round trips instead of a handful per entry.  The first chunk
+      // (the whole run whenever the frontier has <= 8 K entries) stays in registers across both passes.
       const unsigned per = (etotal + 1023u) / 1024u;  // <= SL_MAXE / 1024 = 32 entries per thread
       const unsigned e0 = (unsigned)tid * per;
       const unsigned e1 = e0 + per < etotal ? e0 + per : etotal;
-      unsigned won = 0, cntw = 0;
       unsigned pfirst = 0;
       if (e0 < etotal) {
         unsigned lo = 0, hi = fsize - 1;
@@ -856,36 +849,136 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
           if (s_eoff[mid] <= e0) lo = mid; else hi = mid - 1;
         }
         pfirst = lo;
-        unsigned pcur = lo;
-        for (unsigned e = e0; e < e1; e++) {
-          while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
-          const I j = s_start[pcur] + (I)(e - s_eoff[pcur]);
-          const I v = col[j];
-          const unsigned word = __hip_atomic_load(&vbits[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bool w1 = !((word >> (v & 31)) & 1u) &&
-                    __hip_atomic_load(&ppos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pcur;
-          if (w1 && e > s_eoff[pcur] && col[j - 1] == v) w1 = false;  // duplicate entry: the first one counts
-          if (w1) {
-            won |= 1u << (e - e0);
-            cntw++;
+      }
+      I v0[SL_CH];          // first chunk: neighbour ids,
+      unsigned p0[SL_CH];   // frontier positions of their parents,
+      unsigned unv0 = 0;    // not-yet-visited mask,
+      I jfirst = 0;         // index in col[] of the run's first entry
+      // (re)builds one chunk: parents by walking the LDS prefix, then col and the bitmap words in two batches
+      auto load_chunk = [&](unsigned eb, unsigned &pcur, I (&v)[SL_CH], unsigned (&pp)[SL_CH], I &j0, unsigned &unv) {
+        I jj[SL_CH];
+#pragma unroll
+        for (int k = 0; k < SL_CH; k++) {
+          const unsigned e = eb + k;
+          jj[k] = -1;
+          pp[k] = 0;
+          if (e < e1) {
+            while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
+            pp[k] = pcur;
+            jj[k] = s_start[pcur] + (I)(e - s_eoff[pcur]);
+          }
+        }
+        j0 = jj[0];
+#pragma unroll
+        for (int k = 0; k < SL_CH; k++) v[k] = jj[k] >= 0 ? col[jj[k]] : (I)0;
+        unsigned word[SL_CH];
+#pragma unroll
+        for (int k = 0; k < SL_CH; k++)
+          word[k] = jj[k] >= 0 ? __hip_atomic_load(&vbits[v[k] >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+        unv = 0;
+#pragma unroll
+        for (int k = 0; k < SL_CH; k++)
+          if (jj[k] >= 0 && !((word[k] >> (v[k] & 31)) & 1u)) unv |= 1u << k;
+      };
+      {  // pass 1: smallest parent position of every unvisited neighbour
+        unsigned pcur = pfirst;
+        for (unsigned eb = e0; eb < e1; eb += SL_CH) {
+          I v[SL_CH];
+          unsigned pp[SL_CH], unv;
+          I j0;
+          load_chunk(eb, pcur, v, pp, j0, unv);
+#pragma unroll
+          for (int k = 0; k < SL_CH; k++)
+            if ((unv >> k) & 1u) atomicMin(&ppos[v[k]], pp[k]);
+          if (eb == e0) {
+#pragma unroll
+            for (int k = 0; k < SL_CH; k++) {
+              v0[k] = v[k];
+              p0[k] = pp[k];
+            }
+            unv0 = unv;
+            jfirst = j0;
+          }
+        }
+      }
+      __syncthreads();
+      unsigned won = 0, cntw = 0;
+      {  // pass 2: the entries that hold the winning (parent, neighbour) pairs, in entry order
+        unsigned pcur = pfirst;
+        for (unsigned eb = e0; eb < e1; eb += SL_CH) {
+          I v[SL_CH];
+          unsigned pp[SL_CH], unv;
+          I j0;
+          if (eb == e0) {
+#pragma unroll
+            for (int k = 0; k < SL_CH; k++) {
+              v[k] = v0[k];
+              pp[k] = p0[k];
+            }
+            unv = unv0;
+            j0 = jfirst;
+            pcur = p0[SL_CH - 1] > pcur ? p0[SL_CH - 1] : pcur;
+          } else {
+            load_chunk(eb, pcur, v, pp, j0, unv);
+          }
+          unsigned cur[SL_CH];
+#pragma unroll
+          for (int k = 0; k < SL_CH; k++)
+            cur[k] = ((unv >> k) & 1u) ? __hip_atomic_load(&ppos[v[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : UNSEEN;
+          // a duplicate entry of a row does not count: its predecessor in the same row holds the same id
+          const bool has_prev = eb > s_eoff[pp[0]];
+          const I prev0 = has_prev ? col[j0 - 1] : (I)-1;
+#pragma unroll
+          for (int k = 0; k < SL_CH; k++) {
+            bool w1 = ((unv >> k) & 1u) && cur[k] == pp[k];
+            if (k == 0) w1 = w1 && !(has_prev && prev0 == v[0]);
+            else w1 = w1 && !(pp[k - 1] == pp[k] && v[k - 1] == v[k]);
+            if (w1) {
+              won |= 1u << (eb - e0 + k);
+              cntw++;
+            }
           }
         }
       }
       unsigned nfw;
       unsigned slot = sbx_block_exclusive_sum<unsigned, 1024>(cntw, s_escan, &nfw);
       if (tid == 0) s_cnt = nfw;
-      unsigned pcur = pfirst;
-      for (unsigned e = e0; won; e++) {
-        while (pcur + 1 < fsize && s_eoff[pcur + 1] <= e) pcur++;
-        if (won & 1u) {
-          const I v = col[s_start[pcur] + (I)(e - s_eoff[pcur])];
-          if (slot < (unsigned)SL_CAP)
-            s_key[slot] = CM ? (((uint64_t)pcur << 32) | (uint64_t)drank[v]) : (uint64_t)(uint32_t)v;
-          nf_list[slot] = v;
-          wdeg += (unsigned long long)(rp[v + 1] - rp[v]);
-          slot++;
+      {  // emission: keys of the winners in entry order, their degrees for the host's bookkeeping
+        unsigned pcur = pfirst;
+        for (unsigned eb = e0; eb < e1 && (won >> (eb - e0)); eb += SL_CH) {
+          const unsigned wm = (won >> (eb - e0)) & ((1u << SL_CH) - 1u);
+          I v[SL_CH];
+          unsigned pp[SL_CH], unv;
+          I j0;
+          if (eb == e0) {
+#pragma unroll
+            for (int k = 0; k < SL_CH; k++) {
+              v[k] = v0[k];
+              pp[k] = p0[k];
+            }
+            pcur = p0[SL_CH - 1] > pcur ? p0[SL_CH - 1] : pcur;
+          } else {
+            load_chunk(eb, pcur, v, pp, j0, unv);
+          }
+          uint32_t dr[SL_CH];
+          I ra[SL_CH], rb[SL_CH];
+#pragma unroll
+          for (int k = 0; k < SL_CH; k++) {
+            const bool on = (wm >> k) & 1u;
+            dr[k] = (CM && on) ? drank[v[k]] : 0u;
+            ra[k] = on ? rp[v[k]] : (I)0;
+            rb[k] = on ? rp[v[k] + 1] : (I)0;
+          }
+#pragma unroll
+          for (int k = 0; k < SL_CH; k++)
+            if ((wm >> k) & 1u) {
+              if (slot < (unsigned)SL_CAP)
+                s_key[slot] = CM ? (((uint64_t)pp[k] << 32) | (uint64_t)dr[k]) : (uint64_t)(uint32_t)v[k];
+              nf_list[slot] = v[k];
+              wdeg += (unsigned long long)(rb[k] - ra[k]);
+              slot++;
+            }
         }
-        won >>= 1;
       }
       __syncthreads();
     }
