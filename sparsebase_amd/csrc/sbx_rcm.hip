@@ -784,6 +784,9 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
   __shared__ unsigned s_eoff[SL_MAXF];    // exclusive prefix of the frontier degrees
   __shared__ unsigned s_escan[1024 / 64 + 1];
   __shared__ uint16_t s_rank[SL_CAP];     // Cuthill-McKee sweep: where an entry moves inside its parent's group
+  __shared__ unsigned s_gfirst[CM ? SL_MAXF : 1];  // Cuthill-McKee sweep: first slot of every parent's group of children
+  unsigned *s_gcnt = reinterpret_cast<unsigned *>(s_front);  // ... and its size (s_front is idle between the degree
+                                                             // scan and the publication of the next frontier)
   __shared__ unsigned s_cnt;
   __shared__ unsigned long long s_deg[1024 / 64 + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -824,6 +827,11 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
     }
     if (dsum > (unsigned long long)SL_MAXE) break;  // SL_STOP_READY
     __syncthreads();
+    if (CM)
+      for (unsigned i = tid; i < fsize; i += 1024) {
+        s_gfirst[i] = ~0u;
+        s_gcnt[i] = 0;
+      }
     // ---- expand, flattened over the frontier's adjacency entries: thread -> entry e, its frontier
     // position by binary search in the LDS prefix (a wave per vertex left 60 of 64 lanes idle on meshes)
     unsigned long long wdeg = 0;
@@ -975,6 +983,10 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
               if (slot < (unsigned)SL_CAP)
                 s_key[slot] = CM ? (((uint64_t)pp[k] << 32) | (uint64_t)dr[k]) : (uint64_t)(uint32_t)v[k];
               nf_list[slot] = v[k];
+              if (CM) {
+                atomicMin(&s_gfirst[pp[k]], slot);
+                atomicAdd(&s_gcnt[pp[k]], 1u);
+              }
               wdeg += (unsigned long long)(rb[k] - ra[k]);
               slot++;
             }
@@ -983,13 +995,13 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       __syncthreads();
     }
     scanned += dsum;
-    wdeg = sbx_block_sum<unsigned long long, 1024>(wdeg, s_deg);
     const unsigned nf = s_cnt;
     if (nf == 0) {
       status = SL_DONE;
       break;
     }
     if (nf > (unsigned)SL_CAP) {  // cannot order it here: leave it to the host path
+      wdeg = sbx_block_sum<unsigned long long, 1024>(wdeg, s_deg);
       if (tid == 0) {
         dv->nf = nf;
         dv->fedges = wdeg;
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       status = SL_STOP_EXPANDED;
       break;
     }
-    ordered_edges += wdeg;  // degrees of the vertices discovered (and ordered) in-kernel
+    ordered_edges += wdeg;  // degrees of the vertices discovered (and ordered) in-kernel: per-thread partial, summed at exit
     // ---- Cuthill-McKee sweep: s_key holds (parent position << 32 | degree rank), grouped by parent.
     // Groups of <= SL_GROUP children (every mesh) are ordered by counting smaller ranks inside the
     // group; a longer group (a hub) falls back to a bitonic sort of the whole level.
@@ -1006,10 +1018,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       for (unsigned j = tid; j < nf; j += 1024) {
         const uint64_t kj = s_key[j];
         const uint32_t pj = (uint32_t)(kj >> 32);
-        unsigned a = j, bnd = j + 1;
-        while (a > 0 && (uint32_t)(s_key[a - 1] >> 32) == pj && j - a < (unsigned)SL_GROUP) a--;
-        while (bnd < nf && (uint32_t)(s_key[bnd] >> 32) == pj && bnd - a <= (unsigned)SL_GROUP) bnd++;
-        const unsigned c = bnd - a;
+        const unsigned a = s_gfirst[pj], c = s_gcnt[pj], bnd = a + c;  // the group's slots, recorded by the emission
         maxc = c > maxc ? c : maxc;
         unsigned r = 0;
         if (c <= (unsigned)SL_GROUP)
@@ -1076,6 +1085,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
     level++;
     __syncthreads();
   }
+  ordered_edges = sbx_block_sum<unsigned long long, 1024>(ordered_edges, s_deg);
   if (tid == 0) {
     dv->sl_off = off;
     dv->sl_fsize = fsize;
