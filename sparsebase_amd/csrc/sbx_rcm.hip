@@ -784,6 +784,8 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
   __shared__ unsigned s_eoff[SL_MAXF];    // exclusive prefix of the frontier degrees
   __shared__ unsigned s_escan[1024 / 64 + 1];
   __shared__ uint16_t s_rank[SL_CAP];     // Cuthill-McKee sweep: where an entry moves inside its parent's group
+  __shared__ I s_nstart[CM ? 1 : SL_MAXF];        // plain sweep: rp[v] and degree of the vertices just discovered, in their
+  __shared__ unsigned s_ndeg[CM ? 1 : SL_MAXF];   // final order - the next level starts without a row-pointer round trip
   __shared__ unsigned s_gfirst[CM ? SL_MAXF : 1];  // Cuthill-McKee sweep: first slot of every parent's group of children
   unsigned *s_gcnt = reinterpret_cast<unsigned *>(s_front);  // ... and its size (s_front is idle between the degree
                                                              // scan and the publication of the next frontier)
@@ -792,6 +794,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   unsigned long long ordered_edges = 0, scanned = 0;
   unsigned status = SL_STOP_READY;
+  bool carried = false;  // s_nstart / s_ndeg describe the current frontier
   if (fsize <= SL_MAXF)
     for (unsigned i = tid; i < fsize; i += 1024) s_front[i] = q[off + i];
   __syncthreads();
@@ -805,10 +808,15 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       const unsigned i = (unsigned)tid * SL_FPT + k;
       dl[k] = 0;
       if (i < fsize) {
-        const I u = s_front[i];
-        const I s0 = rp[u];
-        s_start[i] = s0;
-        dl[k] = (unsigned)(rp[u + 1] - s0);
+        if (!CM && carried) {
+          s_start[i] = s_nstart[i];
+          dl[k] = s_ndeg[i];
+        } else {
+          const I u = s_front[i];
+          const I s0 = rp[u];
+          s_start[i] = s0;
+          dl[k] = (unsigned)(rp[u + 1] - s0);
+        }
       }
       mine += dl[k];
     }
@@ -986,6 +994,9 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
               if (CM) {
                 atomicMin(&s_gfirst[pp[k]], slot);
                 atomicAdd(&s_gcnt[pp[k]], 1u);
+              } else if (slot < (unsigned)SL_MAXF) {
+                s_nstart[slot] = ra[k];
+                s_ndeg[slot] = (unsigned)(rb[k] - ra[k]);
               }
               wdeg += (unsigned long long)(rb[k] - ra[k]);
               slot++;
@@ -1083,6 +1094,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
     fsize = nf;
     total += nf;
     level++;
+    carried = true;
     __syncthreads();
   }
   ordered_edges = sbx_block_sum<unsigned long long, 1024>(ordered_edges, s_deg);
