@@ -32,6 +32,7 @@
 #include "sbx_internal.h"
 
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -41,6 +42,7 @@ constexpr int RCM_SMALL = 64;        // components up to this size: one lane eac
 constexpr int RCM_LIGHT = 256;       // neighbours expanded by the discovering wave itself
 constexpr int RCM_CHUNK = 1024;      // hub neighbours per workgroup chunk
 constexpr int RCM_LDS_SORT = 4096;   // levels up to this size are sorted by one workgroup
+constexpr int RCM_REBUILD_BITS = 32768;  // levels from max(this, n/128) vertices on rebuild the visited bitmap from ppos
 constexpr unsigned UNSEEN = 0xFFFFFFFFu;
 
 struct RcmDev {                 // device-resident scalars
@@ -343,12 +345,14 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
 //          whether this edge can still lower it; only then the atomicMin is issued.
 //          The winner of the UNSEEN -> p transition appends the vertex to the frontier.
 __global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                            unsigned *__restrict__ lpos, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root) {
+                            unsigned *__restrict__ lpos, unsigned *__restrict__ ppos, I *__restrict__ q,
+                            RcmDev *__restrict__ dv, I fixed_root) {
   const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
   dv->root = (unsigned)r;
   vbits[r >> 5] = 1u << (r & 31);  // both bitmaps were cleared by the host for this sweep
   fbits[r >> 5] = 1u << (r & 31);
   lpos[r] = 0;
+  ppos[r] = 0;  // every vertex of the sweep has a parent position: "ppos set" == "visited" (k_visited_from_ppos)
   q[0] = r;
   dv->nf = 0;
   dv->n_heavy = 0;
@@ -675,7 +679,7 @@ template <bool CM>
 __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__ key, unsigned nf,
                                                     const uint32_t *__restrict__ dorder, I *__restrict__ q_level,
                                                     unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                                                    unsigned *__restrict__ lpos, int mark_frontier,
+                                                    unsigned *__restrict__ lpos, int mark_frontier, int set_bits,
                                                     RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -683,9 +687,9 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
     const uint32_t lo = (uint32_t)key[j];
     const I v = (I)(CM ? dorder[lo] : lo);
     q_level[j] = v;
-    atomicOr(&vbits[v >> 5], 1u << (v & 31));  // this level is now ordered
+    if (set_bits) atomicOr(&vbits[v >> 5], 1u << (v & 31));  // this level is now ordered
     if (mark_frontier) {  // only a bottom-up expansion reads the frontier bitmap / positions
-      atomicOr(&fbits[v >> 5], 1u << (v & 31));
+      if (set_bits) atomicOr(&fbits[v >> 5], 1u << (v & 31));
       lpos[v] = (unsigned)j;
     }
   }
@@ -693,6 +697,28 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
     dv->nf = 0;
     dv->n_heavy = 0;
     dv->fedges = 0;
+  }
+}
+
+// Big levels do not set their bits one atomic per vertex (1.4 M single-bit atomics on a 512 KB bitmap take
+// ~150 us): every vertex of the sweep has a parent position and nothing else has, so the visited bitmap IS
+// (ppos != UNSEEN) — one coalesced pass over ppos, a ballot per 64 vertices, no atomics.  The frontier
+// bitmap is what that pass adds to the old one.
+__global__ __launch_bounds__(256) void k_visited_from_ppos(const unsigned *__restrict__ ppos,
+                                                           unsigned long long *__restrict__ vbits64,
+                                                           unsigned long long *__restrict__ fbits64, int64_t n) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int lane = sbx_lane();
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t v = base + lane;
+    const bool seen = v < n && ppos[v] != UNSEEN;
+    const unsigned long long now = __ballot(seen);
+    if (lane == 0) {
+      const unsigned long long before = vbits64[base >> 6];
+      vbits64[base >> 6] = now;
+      if (fbits64) fbits64[base >> 6] = now & ~before;
+    }
   }
 }
 
@@ -1186,7 +1212,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   SBX_HIP(h, hipMemsetAsync(b.vbits, 0, bm_bytes, h->stream));
   SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.q, b.dv, fixed_root);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
@@ -1269,9 +1295,15 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                                     32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       int in_b = 0;
       SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
+      // one pass over ppos (n words) against one single-bit atomic per vertex of the level
+      const int set_bits = (int64_t)nf < std::max<int64_t>(RCM_REBUILD_BITS, b.n / 128) ? 1 : 0;
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256),
                   (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier,
-                  b.dv);
+                  set_bits, b.dv);
+      if (!set_bits)
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_visited_from_ppos, dim3(sbx_grid_for(b.n, 256 * 4, 4096)), dim3(256),
+                    (const unsigned *)b.ppos, (unsigned long long *)b.vbits,
+                    mark_frontier ? (unsigned long long *)b.fbits : (unsigned long long *)nullptr, b.n);
     }
     SBX_LAUNCH_CHECK(h);
     off += fsize;
