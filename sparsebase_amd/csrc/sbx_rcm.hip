@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, c
 // label[v] = root; component sizes.  Equal roots are combined inside the wave, and the
 // workgroup's dominant root (the giant component) is accumulated in LDS and flushed
 // once, so the giant's counter word is not hammered by one atomic per wave.
-__global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ csize, int64_t n,
-                                                     const unsigned *__restrict__ cbits, I first_root,
+__global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I *parent, I *__restrict__ csize,
+                                                     int64_t n, const unsigned *__restrict__ cbits, I first_root,
                                                      I first_size) {
   __shared__ I s_major;
   __shared__ unsigned s_major_cnt;
@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void k_cc_finalize(I *parent, I *__restrict__ 
     if (v < n) {
       if ((cbits[v >> 5] >> (v & 31)) & 1u) {
         parent[v] = first_root;  // labelled by the first sweep; its size is known
+      } else if (rp[v] == rp[v + 1]) {
+        csize[v] = 1;  // isolated: its own root and nobody else's — a plain (coalesced) store, no atomic
       } else {
         root = parent[v];
         while (root != parent[root]) root = parent[root];
@@ -1318,6 +1320,18 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   return SBX_OK;
 }
 
+// parent positions back to UNSEEN after a sweep: per reached vertex, or — when the sweep reached a good part of
+// the graph — by refilling the whole array (16 MB stream at HBM speed against millions of scattered stores)
+static int reset_ppos(sbx_handle_t h, const I *q, unsigned count, unsigned *ppos, int64_t n) {
+  if ((int64_t)count >= n / 16) {
+    SBX_HIP(h, hipMemsetAsync(ppos, 0xFF, (size_t)n * sizeof(unsigned), h->stream));
+  } else {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(count, 256, 4096)), dim3(256), q, count, ppos);
+    SBX_LAUNCH_CHECK(h);
+  }
+  return SBX_OK;
+}
+
 }  // namespace
 
 extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
@@ -1410,7 +1424,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
               (const unsigned *)cbits, dv);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
               (const I *)big_list, (const RcmDev *)dv);
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), label, csize, n, (const unsigned *)cbits,
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), rp, label, csize, n, (const unsigned *)cbits,
               v0 >= 0 ? v0 : (I)0, (I)r0.count);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
@@ -1423,9 +1437,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const bool first_is_large = r0.count > (unsigned)RCM_SMALL;
   if (v0 >= 0 && !first_is_large) {
     // the pre-swept component is handled by the batched kernel: drop the sweep's marks
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r0.count, 256, 4096)), dim3(256), (const I *)q,
-                r0.count, ppos);
-    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(reset_ppos(h, (const I *)q, r0.count, ppos, n));
   }
   // (3) small components: one lane each
   if (hd.n_small) {
@@ -1483,9 +1495,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
               cm_done = true;  // this candidate is the root and q already holds its Cuthill-McKee order
               break;
             }
-            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
-                        (const I *)q, r.count, ppos);
-            SBX_LAUNCH_CHECK(h);
+            SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
             fixed = -1;  // k_bfs_start left the root on the device
           }
           SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
@@ -1502,9 +1512,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
                              (const I *)(q + r.last_offset), r.last_size, dv);
           SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
         }
-        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_reset_visited, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
-                           (const I *)q, r.count, ppos);
-        SBX_LAUNCH_CHECK(h);
+        SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
         if (path) break;
       }
       // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
@@ -1520,6 +1528,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
                          (const I *)q, r.count, bases[c], inv);
       SBX_LAUNCH_CHECK(h);
+      // invariant of the sweeps (k_visited_from_ppos relies on it): ppos is UNSEEN outside the running sweep
+      if (c + 1 < hd.n_large) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
       if (sizes[c] > largest) {
         largest = sizes[c];
         sweeps_max = sweeps;
