@@ -736,6 +736,27 @@ def test_degenerate_shapes(ops, oracle):
     _check_all_ops(ops, oracle, rp, col, 3)
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_rcm_several_wide_components(ops, oracle, seed):
+    # three disjoint power-law graphs with shuffled ids: every component has levels wide enough for the
+    # bitmap-from-parent-positions path, and that path relies on the parent positions being reset between
+    # components (sbx_rcm.hip: k_visited_from_ppos, reset_ppos)
+    g = np.random.default_rng(100 + seed)
+    parts, offset = [], 0
+    for k, scale in enumerate((17, 16, 17)):
+        rp, col = synth.rmat_symmetric(scale, 8, seed=10 * seed + k)
+        r_idx = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        parts.append((r_idx + offset, col.astype(np.int64) + offset))
+        offset += len(rp) - 1
+    relabel = g.permutation(offset)
+    src = relabel[np.concatenate([p[0] for p in parts])]
+    dst = relabel[np.concatenate([p[1] for p in parts])]
+    rp, col = synth.csr_from_edges(offset, src, dst)
+    got, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
+    assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
+    assert stats["large_components"] >= 3
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_rcm_many_midsize_components(ops, oracle, seed):
     # disjoint union of paths, grids, stars and cliques of 65..600 vertices with shuffled ids:
