@@ -724,6 +724,76 @@ __global__ __launch_bounds__(256) void k_visited_from_ppos(const unsigned *__res
   }
 }
 
+// Plain sweeps, big levels: the vertices the level discovered are exactly what the pass above adds to the
+// visited bitmap, and reading them off that bitmap yields them in ascending id order for free.  The sort key
+// (parent position, id) then only needs its parent-position digits sorted (stable): half the radix passes.
+constexpr int RCM_FW_WORDS = 64;     // 64-vertex words per workgroup of the two kernels below (4096 vertices)
+constexpr int RCM_FW_INLINE = 4096;  // up to this many workgroups each one sums its predecessors' totals itself
+
+__global__ __launch_bounds__(256) void k_fresh_words(const unsigned *__restrict__ ppos,
+                                                     unsigned long long *__restrict__ vbits64,
+                                                     unsigned long long *__restrict__ fbits64,
+                                                     unsigned long long *__restrict__ fresh64, int *__restrict__ cnt,
+                                                     int *__restrict__ btot, int64_t n) {
+  __shared__ int s_tot;
+  if (threadIdx.x == 0) s_tot = 0;
+  __syncthreads();
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS;
+  int mine = 0;
+  for (int k = wv; k < RCM_FW_WORDS; k += 4) {
+    const int64_t base = (w0 + k) * 64;
+    if (base >= n) break;
+    const int64_t v = base + lane;
+    const bool seen = v < n && ppos[v] != UNSEEN;
+    const unsigned long long now = __ballot(seen);
+    if (lane == 0) {
+      const unsigned long long fresh = now & ~vbits64[w0 + k];
+      vbits64[w0 + k] = now;
+      if (fbits64) fbits64[w0 + k] = fresh;
+      fresh64[w0 + k] = fresh;
+      const int c = __popcll(fresh);
+      cnt[w0 + k] = c;
+      mine += c;
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(&s_tot, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) btot[blockIdx.x] = s_tot;
+}
+
+// one wave per RCM_FW_WORDS words: lane = word; base of the workgroup = totals of the workgroups before it
+// (summed here when there are few of them, taken from their scan otherwise)
+__global__ __launch_bounds__(64) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
+                                                        const int *__restrict__ cnt, const int *__restrict__ btot,
+                                                        int btot_is_scanned, const unsigned *__restrict__ ppos,
+                                                        uint64_t *__restrict__ key, int64_t words) {
+  const int lane = sbx_lane();
+  int base = 0;
+  if (btot_is_scanned) {
+    base = btot[blockIdx.x];
+  } else {
+    for (int i = lane; i < (int)blockIdx.x; i += 64) base += btot[i];
+    base = sbx_wave_sum(base);
+  }
+  const int64_t w = (int64_t)blockIdx.x * RCM_FW_WORDS + lane;
+  const int c = w < words ? cnt[w] : 0;
+  int inc = c;  // inclusive wave scan
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  int o = base + inc - c;
+  unsigned long long f = w < words ? fresh64[w] : 0ull;
+  while (f) {
+    const int bit = __builtin_ctzll(f);
+    const uint32_t v = (uint32_t)(w * 64 + bit);
+    key[o++] = ((uint64_t)ppos[v] << 32) | (uint64_t)v;
+    f &= f - 1;
+  }
+}
+
 // small level: keys, bitonic sort in LDS and emit in one workgroup
 template <bool CM>
 __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__ nf_list, unsigned nf,
@@ -1192,6 +1262,8 @@ struct BfsBuffers {
   I *nf_list;   // unordered next frontier
   uint64_t *heavy;
   uint64_t *ka, *kb;
+  unsigned long long *fresh64;  // per 64 vertices: the bits the current level added to the visited bitmap
+  int *wcnt, *woff;             // ... their popcounts, and the totals of every RCM_FW_WORDS of them
   const uint32_t *drank, *dorder;
   RcmDev *dv;
   int64_t n;
@@ -1290,19 +1362,35 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                   (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
-      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
-                  (const unsigned *)b.ppos, b.drank, b.ka);
-      sbx_radix_pass passes[16];
-      const int np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32,
-                                    32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
-      int in_b = 0;
-      SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
       // one pass over ppos (n words) against one single-bit atomic per vertex of the level
       const int set_bits = (int64_t)nf < std::max<int64_t>(RCM_REBUILD_BITS, b.n / 128) ? 1 : 0;
+      sbx_radix_pass passes[16];
+      int np;
+      if (!CM && !set_bits) {
+        // keys in ascending id order straight from the bitmap pass: only the parent positions are left to sort
+        const int64_t words = (b.n + 63) / 64;
+        const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_fresh_words, dim3((unsigned)fw_blocks), dim3(256), (const unsigned *)b.ppos,
+                    (unsigned long long *)b.vbits,
+                    mark_frontier ? (unsigned long long *)b.fbits : (unsigned long long *)nullptr, b.fresh64, b.wcnt,
+                    b.woff, b.n);
+        const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
+        if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(64),
+                    (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
+                    (const unsigned *)b.ppos, b.ka, words);
+        np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
+      } else {
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
+                    (const unsigned *)b.ppos, b.drank, b.ka);
+        np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
+      }
+      int in_b = 0;
+      SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256),
                   (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier,
                   set_bits, b.dv);
-      if (!set_bits)
+      if (CM && !set_bits)
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_visited_from_ppos, dim3(sbx_grid_for(b.n, 256 * 4, 4096)), dim3(256),
                     (const unsigned *)b.ppos, (unsigned long long *)b.vbits,
                     mark_frontier ? (unsigned long long *)b.fbits : (unsigned long long *)nullptr, b.n);
@@ -1405,6 +1493,9 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
   b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.fresh64));
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.wcnt));
+  SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 / RCM_FW_WORDS + 2, &b.woff));
   b.max_deg = hd0.max_deg;
   // (2) The smallest non-isolated vertex v0 is the smallest id of its component, i.e. the
   // start of that component's pseudo-peripheral search.  Its first BFS sweep is needed
