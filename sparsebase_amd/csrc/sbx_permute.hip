@@ -70,30 +70,68 @@ __global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ ord
   for (; i < n; i += stride) ((V *)out)[order[i]] = ((const V *)vals)[i];
 }
 
-// row lengths (for the scan; entry nr zeroed) and the lists of rows too long for the tile kernel
+// row lengths (for the scan; entry nr zeroed) and the lists of rows too long for the tile kernel.
+// The lists are appended to through five counter words; a few thousand long rows spread over millions would
+// queue one atomic each on them (~88 atomics/us per word: 100 us for 10 K rows), so every workgroup stages the
+// rows it finds in LDS and reserves list space once per class (the order inside a list does not matter).
+constexpr int RC_STAGE = 512;  // staged rows per class and workgroup before an early flush
 template <typename I>
 __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ rec, I *__restrict__ rpo, int64_t nr,
                                                       I *__restrict__ long_rows, I *__restrict__ block_rows,
                                                       int64_t block_stride, int block_cap,
                                                       PermState *__restrict__ st) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i <= nr; i += stride) {
-    if (i == nr) {
-      if (rpo) rpo[i] = 0;
-      continue;
+  constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
+  __shared__ unsigned s_cnt[NC], s_base[NC];
+  __shared__ unsigned long long s_long_nnz;
+  __shared__ int s_full;
+  __shared__ I s_rows[NC][RC_STAGE];
+  const int tid = threadIdx.x;
+  if (tid < NC) s_cnt[tid] = 0;
+  if (tid == 0) s_long_nnz = 0;
+  __syncthreads();
+  auto flush = [&]() {  // all threads; leaves the stage empty
+    if (tid < NC && s_cnt[tid]) {
+      unsigned *counter = tid < BR_CLASSES ? &st->n_block[tid] : &st->n_long;
+      s_base[tid] = atomicAdd(counter, s_cnt[tid]);
     }
-    const I d = (I)rec[i].x;
-    if (rpo) rpo[i] = d;
-    if (d > block_cap) {
-      const unsigned slot = atomicAdd(&st->n_long, 1u);
-      long_rows[slot] = (I)i;
-      atomicAdd(&st->long_nnz, (unsigned long long)d);
-    } else if (d > PT_TILE) {
-      const int cls = d <= br_cap(0) ? 0 : d <= br_cap(1) ? 1 : d <= br_cap(2) ? 2 : 3;
-      block_rows[cls * block_stride + atomicAdd(&st->n_block[cls], 1u)] = (I)i;
+    if (tid == 0 && s_long_nnz) {
+      atomicAdd(&st->long_nnz, s_long_nnz);
+      s_long_nnz = 0;
     }
+    __syncthreads();
+    for (int c = 0; c < NC; c++) {
+      I *list = c < BR_CLASSES ? block_rows + (int64_t)c * block_stride : long_rows;
+      for (unsigned k = tid; k < s_cnt[c]; k += 256) list[s_base[c] + k] = s_rows[c][k];
+    }
+    __syncthreads();
+    if (tid < NC) s_cnt[tid] = 0;
+    __syncthreads();
+  };
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base <= nr; base += stride) {  // uniform trip count per workgroup
+    const int64_t i = base + tid;
+    if (i == nr && rpo) rpo[i] = 0;
+    if (i < nr) {
+      const I d = (I)rec[i].x;
+      if (rpo) rpo[i] = d;
+      int cls = -1;
+      if (d > block_cap) cls = BR_CLASSES;
+      else if (d > PT_TILE) cls = d <= br_cap(0) ? 0 : d <= br_cap(1) ? 1 : d <= br_cap(2) ? 2 : 3;
+      if (cls >= 0) {
+        s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
+        if (cls == BR_CLASSES) atomicAdd(&s_long_nnz, (unsigned long long)d);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      bool full = false;
+      for (int c = 0; c < NC; c++) full |= s_cnt[c] + 256u > (unsigned)RC_STAGE;
+      s_full = full;
+    }
+    __syncthreads();
+    if (s_full) flush();  // uniform decision
   }
+  flush();
 }
 
 template <typename I>
@@ -913,7 +951,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
                 (const int2 *)rec, rpo, nr, long_rows, block_rows, block_stride, block_cap, st);
   } else {
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_lengths<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
@@ -961,7 +999,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
     SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
                 (const int2 *)rec, (I *)nullptr, nr, long_rows, block_rows, block_stride, block_cap, st);
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
@@ -1015,7 +1053,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)nullptr, n, (int64_t)0, n, rec);
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256),
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(n + 1, 256, 2048)), dim3(256),
               (const int2 *)rec, (I *)nullptr, n, long_rows, block_rows, n, block_cap, st);
   SBX_LAUNCH_CHECK(h);
   PermState hs;
