@@ -487,12 +487,23 @@ constexpr int RCM_GROUP = 16;
 constexpr int RCM_VPW = 64 / RCM_GROUP;  // frontier vertices per wave
 constexpr int RCM_BU_INLINE = 16;        // bottom-up: candidates up to this degree get one lane each
 
+constexpr int RCM_HUB_STAGE = 256;  // hubs a workgroup stages before it reserves their chunk descriptors
+
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
                                                     unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
                                                     RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
+  // hubs found by this workgroup: (frontier position, number of chunks).  A frontier of the RMAT input holds
+  // ~20 K hubs; one returning atomic each on dv->n_heavy is 0.2 ms of queueing on that word.  (The hub kernel
+  // is ~10 % faster when the queue is in position order, as the immediate reservations left it — a parent
+  // position is then rarely lowered twice — but that costs more here than it saves there.)
+  __shared__ unsigned s_hub_p[RCM_HUB_STAGE], s_hub_n[RCM_HUB_STAGE];
+  __shared__ unsigned s_hub_cnt, s_hub_base;
+  __shared__ unsigned s_hub_scan[256 / 64 + 1];
+  if (threadIdx.x == 0) s_hub_cnt = 0;
+  __syncthreads();
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
@@ -508,12 +519,22 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
       e = rp[u + 1];
     }
     if (e - s > RCM_LIGHT) {
-      // hub: queue one descriptor (position, chunk) per 1024-neighbour chunk
+      // hub: one descriptor (position, chunk) per 1024-neighbour chunk, queued at the end of the kernel
       const unsigned nchunks = (unsigned)((e - s + RCM_CHUNK - 1) / RCM_CHUNK);
-      unsigned slot = 0;
-      if (gl == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
-      slot = __shfl(slot, grp * RCM_GROUP, 64);
-      for (unsigned c = gl; c < nchunks; c += RCM_GROUP) heavy[slot + c] = ((uint64_t)p << 32) | c;
+      unsigned hs = 0;
+      if (gl == 0) hs = atomicAdd(&s_hub_cnt, 1u);
+      hs = __shfl(hs, grp * RCM_GROUP, 64);
+      if (hs < (unsigned)RCM_HUB_STAGE) {
+        if (gl == 0) {
+          s_hub_p[hs] = (unsigned)p;
+          s_hub_n[hs] = nchunks;
+        }
+      } else {  // stage full: reserve this hub's descriptors directly
+        unsigned slot = 0;
+        if (gl == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
+        slot = __shfl(slot, grp * RCM_GROUP, 64);
+        for (unsigned c = gl; c < nchunks; c += RCM_GROUP) heavy[slot + c] = ((uint64_t)p << 32) | c;
+      }
       e = s;  // nothing to do inline
     }
     if (gl == 0) scanned += (unsigned)(e - s);
@@ -529,6 +550,23 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
       }
       bfs_visit4(v, act, (unsigned)p, rp, vbits, ppos, st, nf_list, dv);
       j += 4 * RCM_GROUP;
+    }
+  }
+  __syncthreads();
+  {  // the staged hubs: one reservation for the whole workgroup
+    const unsigned nh = s_hub_cnt < (unsigned)RCM_HUB_STAGE ? s_hub_cnt : (unsigned)RCM_HUB_STAGE;
+    const unsigned mine = threadIdx.x < nh ? s_hub_n[threadIdx.x] : 0u;
+    unsigned all;
+    const unsigned ex = sbx_block_exclusive_sum<unsigned, 256>(mine, s_hub_scan, &all);
+    if (threadIdx.x == 0) s_hub_base = all ? atomicAdd(&dv->n_heavy, all) : 0u;
+    if (threadIdx.x < nh) s_hub_n[threadIdx.x] = ex;  // now: first descriptor of the hub (its chunk count is `mine`)
+    __syncthreads();
+    // descriptors of hub h = [base + ex_h, base + ex_{h+1}): all threads share the writing
+    for (unsigned hh = 0; hh < nh; hh++) {
+      const unsigned first = s_hub_n[hh];
+      const unsigned cnt = (hh + 1 < nh ? s_hub_n[hh + 1] : all) - first;
+      const uint64_t hi = (uint64_t)s_hub_p[hh] << 32;
+      for (unsigned c = threadIdx.x; c < cnt; c += 256) heavy[s_hub_base + first + c] = hi | c;
     }
   }
   stage_end_block(st, nf_list, dv, scanned, false);
