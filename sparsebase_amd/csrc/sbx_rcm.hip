@@ -45,20 +45,21 @@ constexpr int RCM_LDS_SORT = 4096;   // levels up to this size are sorted by one
 constexpr int RCM_REBUILD_BITS = 32768;  // levels from max(this, n/128) vertices on rebuild the visited bitmap from ppos
 constexpr unsigned UNSEEN = 0xFFFFFFFFu;
 
-struct RcmDev {                 // device-resident scalars
-  unsigned nf;                  // size of the frontier being built
-  unsigned n_heavy;             // hub vertices queued for the chunked kernel
-  unsigned n_small;             // small components listed
+// Device-resident scalars.  The five counters every expansion workgroup adds to sit in cache lines of their
+// own: atomics on one line queue behind each other whichever word they target.
+struct RcmDev {
+  alignas(128) unsigned nf;                  // size of the frontier being built
+  alignas(128) unsigned n_heavy;             // hub chunk descriptors queued for the chunked kernel
+  alignas(128) unsigned long long fedges;    // sum of degrees of the level being built (direction heuristic)
+  alignas(128) unsigned long long edges;     // adjacency entries scanned (statistics)
+  alignas(128) unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
+  alignas(128) unsigned n_small;             // small components listed
   unsigned n_large;             // large components listed
   unsigned n_cc_big;            // high-degree vertices queued by the CC hook kernel
   unsigned max_deg;
   unsigned root;                // current BFS root of the component being ordered
   unsigned first_vertex;        // smallest vertex id with a non-empty row (UNSEEN if none)
-  unsigned pad;
   unsigned long long best;      // (degree<<32 | position) minimum over the deepest level
-  unsigned long long edges;     // adjacency entries scanned (statistics)
-  unsigned long long fedges;    // sum of degrees of the level being built (direction heuristic)
-  unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
   // hand-off state of the persistent small-level kernel
   unsigned sl_off, sl_fsize, sl_level, sl_total;
   unsigned sl_status;           // SL_DONE / SL_STOP_READY / SL_STOP_EXPANDED
