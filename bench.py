@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", type=int, default=22, help="RMAT scale (2^scale rows)")
     ap.add_argument("--edge-factor", type=int, default=13, help="~100M nnz after symmetrisation at scale 22")
-    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the CPU-baseline sample")
+    ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the CPU-baseline sample (default: the bench matrix itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     return ap.parse_args()
@@ -258,7 +258,7 @@ def main():
     # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args, synth)
+        cpu_baseline = run_cpu_baseline(args, synth, rp, col)
 
     if rank == 0:
         line = {
@@ -278,12 +278,16 @@ def main():
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(args, synth):
+def run_cpu_baseline(args, synth, rp_dev, col_dev):
     """Times the reference pipeline on the host: real reference if oracle/_ref is present
-    ("reference"), else the oracle restatement ("port")."""
+    ("reference"), else the oracle restatement ("port").  Default sample: rank 0's bench matrix itself,
+    one repetition (≈ 10 s of host work); --cpu-scale selects a smaller RMAT instance."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    rp_t, col_t = synth.rmat_symmetric_torch(args.cpu_scale, args.edge_factor, seed=1)
+    if args.cpu_scale == args.scale:
+        rp_t, col_t = rp_dev, col_dev
+    else:
+        rp_t, col_t = synth.rmat_symmetric_torch(args.cpu_scale, args.edge_factor, seed=1)
     rp, col = rp_t.cpu().numpy(), col_t.cpu().numpy()
     n, nnz = len(rp) - 1, len(col)
     val = (np.arange(nnz) % 1021).astype(np.float32)
@@ -305,7 +309,9 @@ def run_cpu_baseline(args, synth):
 
     rcm_s, permute_s = run_once()
     out = {"value": n / (rcm_s + permute_s) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": kind,
-           "sample": f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition",
+           "sample": (f"the bench matrix itself (symmetric RMAT scale {args.cpu_scale}, n={n}, nnz={nnz}), 1 repetition"
+                      if args.cpu_scale == args.scale else
+                      f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition"),
            "rcm_s": rcm_s, "permute_s": permute_s}
     if kind == "reference":
         # only the CSR constructor's two loops are OpenMP-parallel in the reference (format/csr.cc:102,123):
