@@ -50,6 +50,7 @@ constexpr unsigned UNSEEN = 0xFFFFFFFFu;
 struct RcmDev {
   alignas(128) unsigned nf;                  // size of the frontier being built
   alignas(128) unsigned n_heavy;             // hub chunk descriptors queued for the chunked kernel
+  unsigned hub_overflow;                     // some workgroup reserved descriptors outside its directory entry
   alignas(128) unsigned long long fedges;    // sum of degrees of the level being built (direction heuristic)
   alignas(128) unsigned long long edges;     // adjacency entries scanned (statistics)
   alignas(128) unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
@@ -359,6 +360,7 @@ __global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbi
   q[0] = r;
   dv->nf = 0;
   dv->n_heavy = 0;
+  dv->hub_overflow = 0;
   dv->best = ~0ull;
   dv->fedges = (unsigned long long)(rp[r + 1] - rp[r]);  // degree sum of level 0
 }
@@ -489,32 +491,36 @@ constexpr int RCM_VPW = 64 / RCM_GROUP;  // frontier vertices per wave
 constexpr int RCM_BU_INLINE = 16;        // bottom-up: candidates up to this degree get one lane each
 
 constexpr int RCM_HUB_STAGE = 256;  // hubs a workgroup stages before it reserves their chunk descriptors
+constexpr int RCM_DIR_MAX = 2048;    // workgroups of k_bfs_expand the hub kernel can follow through the directory
 
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
                                                     unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
-                                                    RcmDev *__restrict__ dv) {
+                                                    uint2 *__restrict__ hub_dir, RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
   // hubs found by this workgroup: (frontier position, number of chunks).  A frontier of the RMAT input holds
   // ~20 K hubs; one returning atomic each on dv->n_heavy is 0.2 ms of queueing on that word.  (The hub kernel
-  // is ~10 % faster when the queue is in position order, as the immediate reservations left it — a parent
-  // position is then rarely lowered twice — but that costs more here than it saves there.)
+  // is ~10 % faster when it meets the descriptors in position order — a parent position is then rarely
+  // lowered twice.  Workgroups therefore own CONTIGUOUS position ranges and leave (first descriptor, count) in
+  // a directory indexed by workgroup: the hub kernel walks the directory, i.e. the positions, front to back.)
   __shared__ unsigned s_hub_p[RCM_HUB_STAGE], s_hub_n[RCM_HUB_STAGE];
   __shared__ unsigned s_hub_cnt, s_hub_base;
   __shared__ unsigned s_hub_scan[256 / 64 + 1];
   if (threadIdx.x == 0) s_hub_cnt = 0;
   __syncthreads();
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
   WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
   unsigned long long scanned = 0;
-  for (int64_t p0 = wave * RCM_VPW; p0 < fsize; p0 += nwaves * RCM_VPW) {
+  // positions [blockIdx.x * per, +per) belong to this workgroup; its four waves interleave inside the range
+  const int64_t per = (((int64_t)fsize + gridDim.x - 1) / gridDim.x + 4 * RCM_VPW - 1) / (4 * RCM_VPW) * (4 * RCM_VPW);
+  const int64_t pb = (int64_t)blockIdx.x * per;
+  const int64_t pe = pb + per < (int64_t)fsize ? pb + per : (int64_t)fsize;
+  for (int64_t p0 = pb + (int64_t)sbx_wave_in_block() * RCM_VPW; p0 < pe; p0 += 4 * RCM_VPW) {
     const int64_t p = p0 + grp;
     I s = 0, e = 0;
-    if (p < fsize) {
+    if (p < pe) {
       const I u = frontier[p];
       s = rp[u];
       e = rp[u + 1];
@@ -530,9 +536,12 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
           s_hub_p[hs] = (unsigned)p;
           s_hub_n[hs] = nchunks;
         }
-      } else {  // stage full: reserve this hub's descriptors directly
+      } else {  // stage full: reserve this hub's descriptors directly (the hub kernel then ignores the directory)
         unsigned slot = 0;
-        if (gl == 0) slot = atomicAdd(&dv->n_heavy, nchunks);
+        if (gl == 0) {
+          slot = atomicAdd(&dv->n_heavy, nchunks);
+          dv->hub_overflow = 1;
+        }
         slot = __shfl(slot, grp * RCM_GROUP, 64);
         for (unsigned c = gl; c < nchunks; c += RCM_GROUP) heavy[slot + c] = ((uint64_t)p << 32) | c;
       }
@@ -559,7 +568,10 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
     const unsigned mine = threadIdx.x < nh ? s_hub_n[threadIdx.x] : 0u;
     unsigned all;
     const unsigned ex = sbx_block_exclusive_sum<unsigned, 256>(mine, s_hub_scan, &all);
-    if (threadIdx.x == 0) s_hub_base = all ? atomicAdd(&dv->n_heavy, all) : 0u;
+    if (threadIdx.x == 0) {
+      s_hub_base = all ? atomicAdd(&dv->n_heavy, all) : 0u;
+      hub_dir[blockIdx.x] = make_uint2(s_hub_base, all);
+    }
     if (threadIdx.x < nh) s_hub_n[threadIdx.x] = ex;  // now: first descriptor of the hub (its chunk count is `mine`)
     __syncthreads();
     // descriptors of hub h = [base + ex_h, base + ex_{h+1}): all threads share the writing
@@ -578,13 +590,53 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
                                                           const unsigned *__restrict__ vbits, unsigned *ppos,
                                                           I *__restrict__ nf_list,
                                                           const uint64_t *__restrict__ heavy,
+                                                          const uint2 *__restrict__ hub_dir, unsigned ndir,
                                                           RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
+  __shared__ unsigned s_dbase[RCM_DIR_MAX], s_dfirst[RCM_DIR_MAX + 1];  // directory: where a workgroup's
+  __shared__ unsigned s_dscan[256 / 64 + 1];                             // descriptors are / how many came before
   const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
+  // Without overflow the descriptors are visited in directory (= frontier position) order: the d-th one overall
+  // is entry d - first[g] of workgroup g's run.  Otherwise: in queue order.
+  const bool ordered = dv->hub_overflow == 0 && ndir <= (unsigned)RCM_DIR_MAX;
+  if (ordered) {
+    constexpr int PER = RCM_DIR_MAX / 256;
+    unsigned cnt[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const unsigned g = threadIdx.x * PER + k;
+      uint2 e = make_uint2(0u, 0u);
+      if (g < ndir) e = hub_dir[g];
+      if (g < (unsigned)RCM_DIR_MAX) s_dbase[g] = e.x;
+      cnt[k] = e.y;
+      sum += e.y;
+    }
+    unsigned all;
+    unsigned run = sbx_block_exclusive_sum<unsigned, 256>(sum, s_dscan, &all);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      s_dfirst[threadIdx.x * PER + k] = run;
+      run += cnt[k];
+    }
+    if (threadIdx.x == 255) s_dfirst[RCM_DIR_MAX] = run;
+    __syncthreads();
+  }
   WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
   unsigned long long scanned = 0;
+  unsigned g = 0;
   for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
-    const uint64_t desc = heavy[d];
+    unsigned at = d;
+    if (ordered) {
+      // last g with first[g] <= d (first[] is non-decreasing; d only grows, so the search resumes at g)
+      unsigned lo = g, hi = (unsigned)RCM_DIR_MAX;
+      while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (s_dfirst[mid] <= d) lo = mid; else hi = mid - 1;
+      }
+      g = lo;
+      at = s_dbase[g] + (d - s_dfirst[g]);
+    }
+    const uint64_t desc = heavy[at];
     const unsigned p = (unsigned)(desc >> 32), c = (unsigned)desc;
     const I u = frontier[p];
     const I s = rp[u], e = rp[u + 1];
@@ -737,6 +789,8 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     dv->nf = 0;
     dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  dv->hub_overflow = 0;
     dv->fedges = 0;
   }
 }
@@ -883,6 +937,8 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
   if (threadIdx.x == 0) {
     dv->nf = 0;
     dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  dv->hub_overflow = 0;
     dv->fedges = 0;
   }
 }
@@ -1245,6 +1301,9 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
     if (status != SL_STOP_EXPANDED) {
       dv->nf = 0;
       dv->n_heavy = 0;
+      dv->hub_overflow = 0;
+    dv->hub_overflow = 0;
+  dv->hub_overflow = 0;
     }
     atomicAdd(&dv->edges, scanned);
   }
@@ -1300,6 +1359,7 @@ struct BfsBuffers {
   I *q;         // visiting order of the current BFS (levels concatenated)
   I *nf_list;   // unordered next frontier
   uint64_t *heavy;
+  uint2 *hub_dir;  // per workgroup of k_bfs_expand: (first chunk descriptor, count)
   uint64_t *ka, *kb;
   unsigned long long *fresh64;  // per 64 vertices: the bits the current level added to the visited bitmap
   int *wcnt, *woff;             // ... their popcounts, and the totals of every RCM_FW_WORDS of them
@@ -1374,11 +1434,11 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       if (grid > max_grid) grid = max_grid;
       if (grid < 1) grid = 1;
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
-                  level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.dv);
+                  level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv);
       if (b.max_deg > (unsigned)RCM_LIGHT)  // mesh-like inputs have no hubs: one launch less per level
         SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
-                    (const uint64_t *)b.heavy, b.dv);
+                    (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
@@ -1531,6 +1591,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   BfsBuffers b;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
+  SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
   b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.fresh64));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.wcnt));
