@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
                                                           const uint2 *__restrict__ hub_dir, unsigned ndir,
                                                           RcmDev *__restrict__ dv) {
   __shared__ I s_stage[4][RCM_STAGE];
-  __shared__ unsigned s_dbase[RCM_DIR_MAX], s_dfirst[RCM_DIR_MAX + 1];  // directory: where a workgroup's
-  __shared__ unsigned s_dscan[256 / 64 + 1];                             // descriptors are / how many came before
+  __shared__ unsigned s_dfirst[RCM_DIR_MAX + 1];  // directory: how many descriptors came before a workgroup's run
+  __shared__ unsigned s_dscan[256 / 64 + 1];
   const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
   // Without overflow the descriptors are visited in directory (= frontier position) order: the d-th one overall
   // is entry d - first[g] of workgroup g's run.  Otherwise: in queue order.
@@ -607,7 +607,6 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
       const unsigned g = threadIdx.x * PER + k;
       uint2 e = make_uint2(0u, 0u);
       if (g < ndir) e = hub_dir[g];
-      if (g < (unsigned)RCM_DIR_MAX) s_dbase[g] = e.x;
       cnt[k] = e.y;
       sum += e.y;
     }
@@ -634,7 +633,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
         if (s_dfirst[mid] <= d) lo = mid; else hi = mid - 1;
       }
       g = lo;
-      at = s_dbase[g] + (d - s_dfirst[g]);
+      at = hub_dir[g].x + (d - s_dfirst[g]);
     }
     const uint64_t desc = heavy[at];
     const unsigned p = (unsigned)(desc >> 32), c = (unsigned)desc;
@@ -1388,6 +1387,15 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
+  // the hub kernel runs as exactly one resident wave of workgroups: a partial second wave (x8 on a kernel that
+  // fits 5 per CU) left a tail that cost 15 %
+  static int heavy_per_cu = 0;
+  if (heavy_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bfs_expand_heavy, 256, 0) != hipSuccess || nb < 1) nb = 4;
+    heavy_per_cu = nb;
+  }
+  const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
   int64_t remaining = b.nnz;      // adjacency entries owned by vertices not yet in any level
   int64_t frontier_edges = -1;    // degree sum of the current frontier (-1: level 0, read lazily)
   bool try_small = true;  // false right after the small-level kernel declined this very frontier
@@ -1436,7 +1444,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
                   level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv);
       if (b.max_deg > (unsigned)RCM_LIGHT)  // mesh-like inputs have no hubs: one launch less per level
-        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(max_grid), dim3(256), b.rp, b.col,
+        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv);
     }
