@@ -158,7 +158,8 @@ def main():
             "traffic": traffic,
             "avg_launch_ms": ms_step / launches_step, "launches_per_step": launches_step,
             "measured": f"HIP events around every launch over {args.steps} further steps of the same loop "
-                        f"({wall_events / args.steps * 1e3:.2f} ms/step with the events in place)",
+                        f"({wall_events / args.steps * 1e3:.2f} ms/step with the events in place; the permute's "
+                        f"independent paths run back to back there and overlap on side streams in the timed region)",
             "alg_bytes_per_step": alg,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
         }

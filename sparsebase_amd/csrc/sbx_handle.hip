@@ -96,6 +96,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->pinned_bytes = kPinnedBytes;
   h->rb_seq = 0;
   h->pow5 = nullptr;
+  h->aux_ready = false;
   h->rs_pool = nullptr;
   h->rs_next = 0;
   {
@@ -115,12 +116,24 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->rs_pool) (void)hipFree(h->rs_pool);
   if (h->pow5) (void)hipFree(h->pow5);
+  if (h->aux_ready) {
+    for (int i = 0; i < 2; i++) (void)hipStreamDestroy(h->aux_stream[i]);
+    for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->aux_event[i]);
+  }
   for (auto &r : h->prof_pending) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
   for (auto &e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
+  return SBX_OK;
+}
+
+int sbx_aux_streams(sbx_handle_t h) {
+  if (h->aux_ready) return SBX_OK;
+  for (int i = 0; i < 2; i++) SBX_HIP(h, hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+  for (int i = 0; i < 3; i++) SBX_HIP(h, hipEventCreateWithFlags(&h->aux_event[i], hipEventDisableTiming));
+  h->aux_ready = true;
   return SBX_OK;
 }
 

@@ -74,6 +74,11 @@ struct sbx_handle_s {
   unsigned rb_seq;  // sequence number of the last polled read-back (sbx_readback)
   bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
   int num_cus;
+  // side streams for independent stages of one call (permute: tile / block-row / long-row paths), created on
+  // first use; aux_event[0] marks the fork point on `stream`, [1], [2] the ends of the side streams
+  hipStream_t aux_stream[2];
+  hipEvent_t aux_event[3];
+  bool aux_ready;
   // profiler: when on, every kernel launch is bracketed by HIP events on the
   // handle's stream; sbx_profile_query drains them into the accumulators
   bool prof_on;
@@ -85,6 +90,7 @@ struct sbx_handle_s {
   char err[512];
 };
 
+int sbx_aux_streams(sbx_handle_t h);  // creates aux_stream / aux_event if needed
 void sbx_prof_begin(sbx_handle_t h, int kid);
 void sbx_prof_end(sbx_handle_t h);
 

@@ -801,6 +801,74 @@ int launch_fix(sbx_handle_t h, sbx_value_type vt, const I *rpo, const I *col, vo
   return SBX_OK;
 }
 
+static bool permute_overlap() {
+  static const bool on = !(getenv("SBX_PERMUTE_OVERLAP") && atoi(getenv("SBX_PERMUTE_OVERLAP")) == 0);
+  return on;
+}
+
+// rows of PT_TILE < length <= 16 K: one workgroup per row, by capacity class
+template <int VB>
+int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
+                    const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *block_rows,
+                    const unsigned *n_block, int64_t block_stride, PermState *st) {
+  typedef int32_t I;
+  RowPasses rpasses;
+  sbx_radix_pass pl[16];
+  rpasses.n = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, pl);
+  for (int i = 0; i < rpasses.n && i < 4; i++) {
+    rpasses.shift[i] = pl[i].shift;
+    rpasses.bits[i] = pl[i].bits;
+  }
+#define BLOCK_ROWS(CLS, THREADS)                                                                                  \
+  if (n_block[CLS])                                                                                               \
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
+                dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, col_out,     \
+                val_out, rpasses, st)
+  BLOCK_ROWS(0, 256);
+  BLOCK_ROWS(1, 512);
+  BLOCK_ROWS(2, 1024);
+  if constexpr (VB != 8) BLOCK_ROWS(3, 1024);  // 8-byte values: 16384 entries do not fit LDS, those rows are "long"
+#undef BLOCK_ROWS
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+// longer rows: flat gather, device radix sort on (row rank, column), scatter back
+template <int VB>
+int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
+                   const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *long_rows,
+                   unsigned n_long, int64_t long_nnz, PermState *st) {
+  typedef int32_t I;
+  uint32_t *loff = nullptr;
+  uint64_t *ka = nullptr, *kb = nullptr;
+  char *pa = nullptr, *pb = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &loff));
+  SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &kb));
+  if (VB) {
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pa));
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pb));
+  }
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), rpo, long_rows, loff,
+                     (int)n_long);
+  SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), rec,
+                     col_in, val_in, col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz, ka, pa, st);
+  SBX_LAUNCH_CHECK(h);
+  sbx_radix_pass passes[16];
+  const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
+                                32 + sbx_bits_for((uint64_t)(n_long - 1)), passes);
+  int in_b = 0;
+  PermState hs2;  // rows that are already ordered (row-wise permutes) skip the sort
+  SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
+  if (hs2.long_unsorted) SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256),
+                     (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
+                     (const uint32_t *)loff, long_nnz, col_out, val_out, st);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
 // Sort stage shared by permute and csr_sort_rows: rows of `rpo` (nr rows, already
 // on device) are produced from the source CSR through the row/col maps.
 template <int VB>
@@ -809,60 +877,48 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
                int64_t total, const int32_t *long_rows, unsigned n_long, int64_t long_nnz, const int32_t *block_rows,
                const unsigned *n_block, int64_t block_stride, PermState *st) {
   typedef int32_t I;
+  // The three paths write disjoint rows of the output and only read the inputs: with more than one of them
+  // present they run on streams of their own (tile kernel on the caller's stream), so the block-row kernels'
+  // tails and the long-row path's short, latency-bound launches hide behind the tile kernel.  While the
+  // profiler is on they run back to back, so that a kernel's event time is its own.
+  const bool has_block = (n_block[0] | n_block[1] | n_block[2] | n_block[3]) != 0;
+  const bool fork = !h->prof_on && permute_overlap() && total > 0 && (has_block || n_long);
+  hipStream_t main_stream = h->stream;
+  if (fork) {
+    SBX_TRY(sbx_aux_streams(h));
+    SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
+    if (has_block) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[0], h->aux_event[0], 0));
+    if (n_long) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[0], 0));
+  }
   if (total > 0) {
     const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rec, col_in, val_in,
                 col_order, rpo, col_out, val_out, nr, st, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
     SBX_LAUNCH_CHECK(h);
   }
-  if (n_block[0] | n_block[1] | n_block[2] | n_block[3]) {
-    RowPasses rpasses;
-    sbx_radix_pass pl[16];
-    rpasses.n = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, pl);
-    for (int i = 0; i < rpasses.n && i < 4; i++) {
-      rpasses.shift[i] = pl[i].shift;
-      rpasses.bits[i] = pl[i].bits;
+  if (has_block) {
+    if (fork) h->stream = h->aux_stream[0];
+    const int rc = block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
+                                       block_stride, st);
+    if (fork) {
+      if (rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
+      h->stream = main_stream;
     }
-#define BLOCK_ROWS(CLS, THREADS)                                                                                  \
-  if (n_block[CLS])                                                                                               \
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
-                dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, col_out,     \
-                val_out, rpasses, st)
-    BLOCK_ROWS(0, 256);
-    BLOCK_ROWS(1, 512);
-    BLOCK_ROWS(2, 1024);
-    if constexpr (VB != 8) BLOCK_ROWS(3, 1024);  // 8-byte values: 16384 entries do not fit LDS, those rows are "long"
-#undef BLOCK_ROWS
-    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(rc);
   }
   if (n_long) {
-    uint32_t *loff = nullptr;
-    uint64_t *ka = nullptr, *kb = nullptr;
-    char *pa = nullptr, *pb = nullptr;
-    SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &loff));
-    SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &ka));
-    SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &kb));
-    if (VB) {
-      SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pa));
-      SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &pb));
+    if (fork) h->stream = h->aux_stream[1];
+    const int rc = long_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
+                                      long_nnz, st);
+    if (fork) {
+      if (rc == SBX_OK && hipEventRecord(h->aux_event[2], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
+      h->stream = main_stream;
     }
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_lengths<I>, dim3((n_long + 255) / 256), dim3(256), rpo, long_rows, loff,
-                       (int)n_long);
-    SBX_TRY(sbx_exclusive_scan_u32(h, loff, loff, n_long, nullptr));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_gather<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256), rec,
-                       col_in, val_in, col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz, ka, pa, st);
-    SBX_LAUNCH_CHECK(h);
-    sbx_radix_pass passes[16];
-    const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
-                                  32 + sbx_bits_for((uint64_t)(n_long - 1)), passes);
-    int in_b = 0;
-    PermState hs2;  // rows that are already ordered (row-wise permutes) skip the sort
-    SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
-    if (hs2.long_unsorted) SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, long_nnz, passes, np, &in_b));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_scatter<I, VB>), dim3(sbx_grid_for(long_nnz, 256, 8192)), dim3(256),
-                       (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
-                       (const uint32_t *)loff, long_nnz, col_out, val_out, st);
-    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(rc);
+  }
+  if (fork) {  // join
+    if (has_block) SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[1], 0));
+    if (n_long) SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[2], 0));
   }
   if (VB) SBX_TRY(launch_fix<I>(h, vt, rpo, col_out, val_out, nr, st));
   return SBX_OK;
