@@ -97,6 +97,8 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->rb_seq = 0;
   h->pow5 = nullptr;
   h->aux_ready = false;
+  h->aux_dirty = false;
+  h->rs_override = nullptr;
   h->rs_pool = nullptr;
   h->rs_next = 0;
   {
@@ -193,6 +195,11 @@ extern "C" int sbx_reserve(sbx_handle_t h, size_t scratch_bytes) {
 int sbx_arena_begin(sbx_handle_t h) {
   SBX_HIP(h, hipSetDevice(h->device));
   if (h->nest > 0) return SBX_OK;  // nested entry point: keep the caller's scratch alive
+  if (h->aux_dirty) {  // a call gave up between fork and join: its side work still owns scratch
+    for (int i = 0; i < 2; i++) SBX_HIP(h, hipStreamSynchronize(h->aux_stream[i]));
+    h->aux_dirty = false;
+    h->rs_override = nullptr;
+  }
   if (h->blocks.size() > 1) {
     // the previous call overflowed the first block: consolidate to one block
     size_t total = 0;
@@ -233,6 +240,11 @@ int sbx_arena_alloc(sbx_handle_t h, size_t bytes, void **out) {
 }
 
 int sbx_radix_slot(sbx_handle_t h, void **slot) {
+  if (h->rs_override) {
+    *slot = h->rs_override;
+    h->rs_override = nullptr;
+    return SBX_OK;
+  }
   if (!h->rs_pool) {
     SBX_HIP(h, hipMalloc(&h->rs_pool, (size_t)SBX_RS_SLOTS * SBX_RS_SLOT_BYTES));
     h->rs_next = SBX_RS_SLOTS;  // forces the first memset

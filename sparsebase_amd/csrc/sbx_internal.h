@@ -79,6 +79,9 @@ struct sbx_handle_s {
   hipStream_t aux_stream[2];
   hipEvent_t aux_event[3];
   bool aux_ready;
+  bool aux_dirty;     // a side stream may still be running work of a call that returned early (error path)
+  void *rs_override;  // next radix sort takes this zeroed slot instead of one from the pool (sorts on a side stream
+                      // must not share the pool with the main stream: the pool is re-zeroed in stream order)
   // profiler: when on, every kernel launch is bracketed by HIP events on the
   // handle's stream; sbx_profile_query drains them into the accumulators
   bool prof_on;

@@ -887,6 +887,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   if (fork) {
     SBX_TRY(sbx_aux_streams(h));
     SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
+    h->aux_dirty = true;
     if (has_block) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[0], h->aux_event[0], 0));
     if (n_long) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[0], 0));
   }
@@ -919,6 +920,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   if (fork) {  // join
     if (has_block) SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[1], 0));
     if (n_long) SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[2], 0));
+    h->aux_dirty = false;
   }
   if (VB) SBX_TRY(launch_fix<I>(h, vt, rpo, col_out, val_out, nr, st));
   return SBX_OK;

@@ -376,6 +376,11 @@ static double bu_ratio() {
   return r;
 }
 
+static bool rcm_overlap() {
+  static const bool on = !(getenv("SBX_RCM_OVERLAP") && atoi(getenv("SBX_RCM_OVERLAP")) == 0);
+  return on;
+}
+
 // first candidate root of the pseudo-peripheral search whose Cuthill-McKee sweep is run speculatively
 static int64_t rcm_speculate_from() {
   static const int64_t k = getenv("SBX_DEBUG_RCM_SPECULATE") ? atoll(getenv("SBX_DEBUG_RCM_SPECULATE")) : 2;
@@ -1586,16 +1591,49 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_LAUNCH_CHECK(h);
   RcmDev hd0;
   SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
+  // Only the Cuthill-McKee sweep reads the degree ranks: they are built on a side stream while the plain sweeps —
+  // launch- and latency-bound — run on the caller's stream, and joined before the first Cuthill-McKee sweep.
   const uint32_t *dorder;
+  hipStream_t main_stream = h->stream;
+  const bool side = !h->prof_on && rcm_overlap();
   {
+    if (side) {
+      void *slot = nullptr;
+      SBX_TRY(sbx_arena_alloc(h, SBX_RS_SLOT_BYTES, &slot));
+      SBX_TRY(sbx_aux_streams(h));
+      SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
+      SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[0], h->aux_event[0], 0));
+      h->aux_dirty = true;
+      h->stream = h->aux_stream[0];
+      if (hipMemsetAsync(slot, 0, SBX_RS_SLOT_BYTES, h->stream) != hipSuccess) {
+        h->stream = main_stream;
+        SBX_FAIL(h, SBX_ERR_HIP, "sbx_rcm_reorder: hipMemsetAsync failed");
+      }
+      h->rs_override = slot;
+    }
     sbx_radix_pass passes[16];
     const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
     int in_b = 0;
-    SBX_TRY(sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n, passes, np, &in_b));
+    int rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n, passes, np, &in_b);
     dorder = in_b ? did_b : did_a;
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(gn), dim3(256), dorder, drank, n);
-    SBX_LAUNCH_CHECK(h);
+    if (rc == SBX_OK) {
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(gn), dim3(256), dorder, drank, n);
+      if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
+      if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
+    }
+    h->stream = main_stream;
+    h->rs_override = nullptr;
+    SBX_TRY(rc);
   }
+  bool ranks_joined = !side;
+  auto join_ranks = [&]() -> int {
+    if (!ranks_joined) {
+      SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[1], 0));
+      ranks_joined = true;
+      h->aux_dirty = false;
+    }
+    return SBX_OK;
+  };
   BfsBuffers b;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
@@ -1685,6 +1723,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
           have_first_sweep = false;
         } else {
           if (candidate >= rcm_speculate_from()) {
+            SBX_TRY(join_ranks());
             SBX_TRY(run_bfs<true>(h, b, fixed, roots[c], &r));
             sweeps++;
             levels += r.levels;
@@ -1716,6 +1755,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       }
       // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
       if (!cm_done) {
+        SBX_TRY(join_ranks());
         SBX_TRY(run_bfs<true>(h, b, -1, roots[c], &r));
         sweeps++;
         levels += r.levels;
@@ -1736,6 +1776,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       }
     }
   }
+  SBX_TRY(join_ranks());  // inputs without a large component never ran a Cuthill-McKee sweep
   if (stats_host) {
     RcmDev fin;
     SBX_TRY(sbx_readback(h, &fin, dv, sizeof(RcmDev)));

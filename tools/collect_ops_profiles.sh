@@ -9,6 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export SBX_PERMUTE_OVERLAP=0  # clean per-kernel durations (see collect_profiles.sh)
+export SBX_RCM_OVERLAP=0
 rm -rf /tmp/ops_kt /tmp/ops_f /tmp/ops_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ops_kt -o kt -- python3 tools/ops_table.py --gpu-only > "$OUT/${TAG}_ops_kt.log" 2>&1
 cp $(find /tmp/ops_kt -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_ops_kernel_stats.csv"
