@@ -832,28 +832,37 @@ __global__ __launch_bounds__(256) void k_fresh_words(const unsigned *__restrict_
                                                      unsigned long long *__restrict__ fbits64,
                                                      unsigned long long *__restrict__ fresh64, int *__restrict__ cnt,
                                                      int *__restrict__ btot, int64_t n) {
+  constexpr int WPW = RCM_FW_WORDS / 4;  // words per wave: 16 consecutive ones, loaded together
   __shared__ int s_tot;
+  __shared__ unsigned long long s_now[4][WPW];
   if (threadIdx.x == 0) s_tot = 0;
   __syncthreads();
   const int lane = sbx_lane(), wv = threadIdx.x >> 6;
-  const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS;
-  int mine = 0;
-  for (int k = wv; k < RCM_FW_WORDS; k += 4) {
-    const int64_t base = (w0 + k) * 64;
-    if (base >= n) break;
-    const int64_t v = base + lane;
-    const bool seen = v < n && ppos[v] != UNSEEN;
-    const unsigned long long now = __ballot(seen);
-    if (lane == 0) {
-      const unsigned long long fresh = now & ~vbits64[w0 + k];
-      vbits64[w0 + k] = now;
-      if (fbits64) fbits64[w0 + k] = fresh;
-      fresh64[w0 + k] = fresh;
-      const int c = __popcll(fresh);
-      cnt[w0 + k] = c;
-      mine += c;
-    }
+  const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS + (int64_t)wv * WPW;
+  unsigned pv[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int64_t v = (w0 + i) * 64 + lane;
+    pv[i] = v < n ? ppos[v] : UNSEEN;
   }
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const unsigned long long now = __ballot(pv[i] != UNSEEN);
+    if (lane == 0) s_now[wv][i] = now;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int mine = 0;
+  if (lane < WPW && (w0 + lane) * 64 < n) {  // lane = word: the 16 bitmap words of the wave in one go
+    const int64_t w = w0 + lane;
+    const unsigned long long now = s_now[wv][lane];
+    const unsigned long long fresh = now & ~vbits64[w];
+    vbits64[w] = now;
+    if (fbits64) fbits64[w] = fresh;
+    fresh64[w] = fresh;
+    mine = __popcll(fresh);
+    cnt[w] = mine;
+  }
+  mine = sbx_wave_sum(mine);
   if (lane == 0 && mine) atomicAdd(&s_tot, mine);
   __syncthreads();
   if (threadIdx.x == 0) btot[blockIdx.x] = s_tot;
