@@ -868,13 +868,15 @@ __global__ __launch_bounds__(256) void k_fresh_words(const unsigned *__restrict_
   if (threadIdx.x == 0) btot[blockIdx.x] = s_tot;
 }
 
-// one wave per RCM_FW_WORDS words: lane = word; base of the workgroup = totals of the workgroups before it
-// (summed here when there are few of them, taken from their scan otherwise)
-__global__ __launch_bounds__(64) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
-                                                        const int *__restrict__ cnt, const int *__restrict__ btot,
-                                                        int btot_is_scanned, const unsigned *__restrict__ ppos,
-                                                        uint64_t *__restrict__ key, int64_t words) {
-  const int lane = sbx_lane();
+// One workgroup per RCM_FW_WORDS words.  Its base = totals of the workgroups before it (summed here when there
+// are few of them, taken from their scan otherwise); every wave scans the 64 word counts itself (lane = word) and
+// then writes the keys of its 16 words with lane = vertex: parent positions read and keys written in runs.
+__global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
+                                                         const int *__restrict__ cnt, const int *__restrict__ btot,
+                                                         int btot_is_scanned, const unsigned *__restrict__ ppos,
+                                                         uint64_t *__restrict__ key, int64_t words) {
+  constexpr int WPW = RCM_FW_WORDS / 4;
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
   int base = 0;
   if (btot_is_scanned) {
     base = btot[blockIdx.x];
@@ -882,21 +884,25 @@ __global__ __launch_bounds__(64) void k_keys_from_fresh(const unsigned long long
     for (int i = lane; i < (int)blockIdx.x; i += 64) base += btot[i];
     base = sbx_wave_sum(base);
   }
-  const int64_t w = (int64_t)blockIdx.x * RCM_FW_WORDS + lane;
-  const int c = w < words ? cnt[w] : 0;
-  int inc = c;  // inclusive wave scan
+  const int64_t wb = (int64_t)blockIdx.x * RCM_FW_WORDS;
+  const int c = wb + lane < words ? cnt[wb + lane] : 0;
+  int inc = c;  // inclusive wave scan over the workgroup's 64 words
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int t = __shfl_up(inc, d, 64);
     if (lane >= d) inc += t;
   }
-  int o = base + inc - c;
-  unsigned long long f = w < words ? fresh64[w] : 0ull;
-  while (f) {
-    const int bit = __builtin_ctzll(f);
-    const uint32_t v = (uint32_t)(w * 64 + bit);
-    key[o++] = ((uint64_t)ppos[v] << 32) | (uint64_t)v;
-    f &= f - 1;
+  const int excl = base + inc - c;
+  const unsigned long long mine = (lane >= wv * WPW && lane < (wv + 1) * WPW && wb + lane < words) ? fresh64[wb + lane] : 0ull;
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int src = wv * WPW + i;
+    const unsigned long long f = __shfl(mine, src, 64);
+    const int o = __shfl(excl, src, 64);
+    if ((f >> lane) & 1ull) {
+      const uint32_t v = (uint32_t)((wb + src) * 64 + lane);
+      key[o + __popcll(f & sbx_lanemask_lt())] = ((uint64_t)ppos[v] << 32) | (uint64_t)v;
+    }
   }
 }
 
@@ -1497,7 +1503,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                     b.woff, b.n);
         const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
         if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
-        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(64),
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
                     (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
                     (const unsigned *)b.ppos, b.ka, words);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
