@@ -70,7 +70,14 @@ typedef enum sbx_value_type {
  * Handle, memory and device utilities                                  *
  * (replaces the raw cudaMalloc/cudaMemcpy calls of                     *
  *  converter/converter_order_two_cuda.cu:11-105,                       *
- *  context/cuda_context_cuda.cu:9-21, converter/converter_cuda.cu:12-21) */
+ *  context/cuda_context_cuda.cu:9-21, converter/converter_cuda.cu:12-21)  *
+ *                                                                      *
+ * Streams: every entry point enqueues its work on the handle's stream  *
+ * (sbx_set_stream; default: the null stream).  Some entry points run    *
+ * independent stages on up to two private side streams of the handle;  *
+ * those fork from and are joined back into the handle's stream by      *
+ * events before the call returns, so callers order against the         *
+ * handle's stream only.  A handle serves one host thread at a time.    */
 /* ------------------------------------------------------------------ */
 int sbx_version(void);
 const char *sbx_status_string(int status);
