@@ -1402,8 +1402,8 @@ struct BfsResult {
 template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
-  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, bm_bytes, h->stream));
-  SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
+  // vbits and fbits are adjacent pieces of one allocation (sbx_rcm_reorder): one fill clears both
+  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
@@ -1483,14 +1483,16 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     // level positions) are only written when it will be bottom-up
     const bool next_bottom_up = nf >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
     const int mark_frontier = next_bottom_up ? 1 : 0;
-    if (mark_frontier) SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
+    // levels wide enough for the bitmap pass (k_fresh_words / k_visited_from_ppos) get every word of fbits rewritten
+    const bool bitmap_pass = nf > (unsigned)RCM_LDS_SORT && (int64_t)nf >= std::max<int64_t>(RCM_REBUILD_BITS, b.n / 128);
+    if (mark_frontier && !bitmap_pass) SBX_HIP(h, hipMemsetAsync(b.fbits, 0, bm_bytes, h->stream));
     if (nf <= RCM_LDS_SORT) {
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_sort_small<CM>), dim3(1), dim3(1024), (const I *)b.nf_list, nf,
                   (const unsigned *)b.ppos, b.drank, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier, b.dv);
     } else {
       const unsigned g = sbx_grid_for(nf, 256, 4096);
       // one pass over ppos (n words) against one single-bit atomic per vertex of the level
-      const int set_bits = (int64_t)nf < std::max<int64_t>(RCM_REBUILD_BITS, b.n / 128) ? 1 : 0;
+      const int set_bits = bitmap_pass ? 0 : 1;
       sbx_radix_pass passes[16];
       int np;
       if (!CM && !set_bits) {
@@ -1585,9 +1587,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)n, &nf_list));
   SBX_TRY(sbx_salloc(h, (size_t)n, &dist));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ppos));
-  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &vbits));
-  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &fbits));
-  SBX_TRY(sbx_salloc(h, (size_t)(n + 31) / 32 + 1, &cbits));
+  // the three bitmaps share one allocation (64-bit aligned pieces): vbits and fbits are cleared together
+  const size_t bm_words = (((size_t)(n + 31) / 32 + 1) + 1) & ~(size_t)1;
+  SBX_TRY(sbx_salloc(h, 3 * bm_words, &vbits));
+  fbits = vbits + bm_words;
+  cbits = fbits + bm_words;
   SBX_TRY(sbx_salloc(h, (size_t)n, &q_small));
   SBX_TRY(sbx_salloc(h, (size_t)n, &lpos));
   SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
