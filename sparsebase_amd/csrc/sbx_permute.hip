@@ -11,41 +11,55 @@
 //   no column map:  k_permute_copy, a segmented copy (+ in-row order check; unsorted input
 //                   rows redo the call through the sorting kernels below)
 //   column map:
-//   k_permute_tile  one workgroup per 1024 output nonzeros: gathers whole old rows
-//                   (col relabelled through col_order) into LDS and sorts every row
-//                   of <= 1024 entries there: all-pairs ranking when the tile only
-//                   holds rows <= 32, otherwise one tile-wide stable LDS radix sort
-//                   on the composite key (local row, column); streams them out.
-//   k_permute_block_rows  rows of 1K..16K entries: one workgroup per row in four
-//                   capacity classes, LDS radix sort over the column bits.
+//   k_permute_tile  one workgroup per PT_W output nonzeros: gathers whole old rows (col relabelled
+//                   through col_order) and sorts every row of <= PT_LMAX entries in LDS with ONE
+//                   bucket-rank pass (below); streams them out.
+//   k_permute_block_rows  rows of PT_LMAX..8K entries: one workgroup per row in three capacity
+//                   classes, the same bucket-rank sort.
 //   long rows       longer rows: gathered into a compact buffer, sorted by
 //                   (row, col) with the device radix sort, scattered back.
 //   k_fix_dup_runs  only if some row was unsorted AND duplicate columns exist:
 //                   orders equal-column runs by value (std::less<pair<col,val>>).
 // HBM traffic per nonzero in the copy, tile and block paths is the compulsory 2*(I+V) bytes.
+//
+// Bucket-rank sort (what replaces the five LDS radix passes of round 1).  A row of L relabelled
+// columns with smallest / largest value mn / mx gets NB = 2^ceil(log2 L) order-preserving buckets
+// of width 2^shift, shift = bits(mx - mn) - log2 NB: bucket = (col - mn) >> shift.  Rows sit back to
+// back in the tile, so the row whose first entry is at tile position hp owns the counter words
+// [2 hp, 2 hp + NB) and every row is sorted by the same four sweeps over the whole tile: count
+// (one LDS atomic per entry), inclusive scan of the counters, placement (one returning atomic:
+// the entry's word = low `shift` bits of the column | position in the row goes to its bucket's
+// slot range) and ranking (an entry counts the smaller words of its own bucket, ~1 on average).
+// Final position = bucket start + rank; entries move in place through registers.  The word order
+// is (column, original position): the sort is stable.  A bucket of more than BK_MAX entries (a row
+// whose columns cluster far more tightly than its range) sends the tile to the LSD radix sort kept
+// below as the distribution-independent path.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
 namespace {
 
-constexpr int PT_THREADS = 256;
-constexpr int PT_TILE = 1024;        // rows up to this many entries are sorted in LDS
-constexpr int PT_CAP = 2 * PT_TILE;  // LDS capacity of one tile, in entries
-constexpr int PT_ITEMS = PT_CAP / PT_THREADS;
-constexpr int PT_SHORT = 32;         // all-pairs rank sort up to this row length
-constexpr int PT_MAXMED = PT_CAP / (PT_SHORT + 1) + 2;
-// one workgroup sorts one row in LDS; four capacity classes so a 1100-entry row does not pay for 16384 slots
-constexpr int BR_CLASSES = 4;
-__host__ __device__ constexpr int br_cap(int cls) { return 2048 << cls; }  // 2048, 4096, 8192, 16384
-template <int VB> struct BlockRowCap { static constexpr int value = 16384; };
-template <> struct BlockRowCap<8> { static constexpr int value = 8192; };
+constexpr int PT_THREADS = 64;
+constexpr int PT_ITEMS = 8;  // a multiple of 4: the thread-consecutive sweeps move 16 bytes per LDS access
+constexpr int PT_CAP = PT_THREADS * PT_ITEMS;  // LDS capacity of one tile, in entries
+constexpr int PT_W = 384;                      // a tile owns the rows that start in a window of PT_W output positions
+constexpr int PT_LMAX = 128;                   // rows up to this many entries are sorted by the tile kernel
+static_assert(PT_W + PT_LMAX - 1 <= PT_CAP, "a tile must hold its window plus the tail of its last row");
+constexpr int BK_SHORT = 8;   // rows up to this length are one bucket (plain all-pairs ranking)
+constexpr int BK_MAX = 96;    // a larger bucket sends the tile / row to the radix sort
+// one workgroup sorts one row in LDS; capacity classes so a 1100-entry row does not pay for 8192 slots
+constexpr int BR_CLASSES = 6;
+__host__ __device__ constexpr int br_cap(int cls) { return 256 << cls; }  // 256, 512, 1024, 2048, 4096, 8192
+template <int VB> struct BlockRowCap { static constexpr int value = 8192; };
+template <> struct BlockRowCap<8> { static constexpr int value = 4096; };   // 8-byte values: 8192 entries do not fit LDS
 
 struct PermState {            // device-resident flags/counters of one call
   unsigned any_unsorted;      // some row had col[j] < col[j-1] after relabelling (csr.cc:102-116)
   unsigned any_dup;           // some row holds a duplicate column
   unsigned n_long;            // rows longer than the block-row capacity (global radix path)
-  unsigned n_block[BR_CLASSES];  // rows in (PT_TILE, capacity], by capacity class: one workgroup each
+  unsigned n_block[BR_CLASSES];  // rows in (PT_LMAX, capacity], by capacity class: one workgroup each
   unsigned long long long_nnz;
+  unsigned long long block_nnz;  // nonzeros of the one-workgroup-per-row classes
   unsigned long long total;   // nnz of the shard
   unsigned long_unsorted;     // some row of the global-radix class is out of order
   unsigned pad2;
@@ -82,12 +96,12 @@ __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ r
                                                       PermState *__restrict__ st) {
   constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
   __shared__ unsigned s_cnt[NC], s_base[NC];
-  __shared__ unsigned long long s_long_nnz;
+  __shared__ unsigned long long s_long_nnz, s_block_nnz;
   __shared__ int s_full;
   __shared__ I s_rows[NC][RC_STAGE];
   const int tid = threadIdx.x;
   if (tid < NC) s_cnt[tid] = 0;
-  if (tid == 0) s_long_nnz = 0;
+  if (tid == 0) s_long_nnz = s_block_nnz = 0;
   __syncthreads();
   auto flush = [&]() {  // all threads; leaves the stage empty
     if (tid < NC && s_cnt[tid]) {
@@ -97,6 +111,10 @@ __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ r
     if (tid == 0 && s_long_nnz) {
       atomicAdd(&st->long_nnz, s_long_nnz);
       s_long_nnz = 0;
+    }
+    if (tid == 1 && s_block_nnz) {
+      atomicAdd(&st->block_nnz, s_block_nnz);
+      s_block_nnz = 0;
     }
     __syncthreads();
     for (int c = 0; c < NC; c++) {
@@ -116,10 +134,13 @@ __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ r
       if (rpo) rpo[i] = d;
       int cls = -1;
       if (d > block_cap) cls = BR_CLASSES;
-      else if (d > PT_TILE) cls = d <= br_cap(0) ? 0 : d <= br_cap(1) ? 1 : d <= br_cap(2) ? 2 : 3;
+      else if (d > PT_LMAX) {
+        cls = 0;
+        while (d > br_cap(cls)) cls++;
+      }
       if (cls >= 0) {
         s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
-        if (cls == BR_CLASSES) atomicAdd(&s_long_nnz, (unsigned long long)d);
+        atomicAdd(cls == BR_CLASSES ? &s_long_nnz : &s_block_nnz, (unsigned long long)d);
       }
     }
     __syncthreads();
@@ -280,199 +301,23 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
   if (__any(bad) && sbx_lane() == 0) st->any_unsorted = 1;
 }
 
-// ---- the tile kernel ----------------------------------------------------------
-// IDENT: csr_sort_rows mode (no row/col maps, input == output arrays allowed).
-template <typename I, int VB>
-__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
-    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, I *col_out, char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits) {
-  typedef typename ValT<VB>::type V;
-  constexpr bool HASV = VB != 0;
-  __shared__ int s_col[PT_CAP];
-  __shared__ V s_val[HASV ? PT_CAP : 1];
-  __shared__ int s_row[PT_CAP];  // row heads -> source offset of every entry -> row length -> dense row rank (radix key)
-  __shared__ unsigned s_whist[PT_THREADS / 64][256];
-  // first position of the entry's row in the tile; dead before the radix passes start, so it lives in the histogram space
-  unsigned short *s_hp = (unsigned short *)&s_whist[0][0];
-  static_assert(sizeof(unsigned short) * PT_CAP <= sizeof(unsigned) * (PT_THREADS / 64) * 256, "s_hp must fit s_whist");
-  __shared__ unsigned s_scan[PT_THREADS / 64 + 1];
-  __shared__ int s_nmed;
-  __shared__ int s_tile_unsorted;
-  __shared__ int64_t s_span[2];
-  __shared__ int s_wmax[PT_THREADS / 64];
+// ---- shared pieces of the two sorting kernels -----------------------------------
+__device__ __forceinline__ int bits_u32(unsigned x) { return x ? 32 - __clz((int)x) : 0; }  // bits needed for 0..x
+
+// Stable LSD radix sort of `count` (<= THREADS * ITEMS) LDS records by (krow, kcol) — column bits first, then
+// the row bits — with ballot match-any ranking and per-wave digit counters.  The distribution-independent
+// path behind the bucket-rank sort (clustered rows), and the round-1 sort of this file.  Padding records
+// must carry 0x7FFFFFFF keys.  `whist` needs (THREADS / 64) * 256 words.  All threads call it.
+template <typename V, bool HASV, bool HASROW, int THREADS, int ITEMS>
+__device__ void lds_radix_sort(int *s_col, int *s_row, V *s_val, unsigned *whist_base, unsigned *s_scan, int count,
+                               int col_bits, int row_bits) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int CAP = THREADS * ITEMS;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t lo_t = (int64_t)blockIdx.x * PT_TILE, hi_t = lo_t + PT_TILE;
-
-  if (tid < 64) {
-    const int64_t a = sbx_wave_upper_bound<I>(rpo, nr + 1, (I)(lo_t - 1));  // first row starting at >= lo_t
-    if (tid == 0) s_span[0] = a;
-  } else if (tid < 128) {
-    const int64_t total = (int64_t)rpo[nr];
-    int64_t b = nr;
-    if (hi_t - 1 < total) b = sbx_wave_upper_bound<I>(rpo, nr + 1, (I)(hi_t - 1));
-    if (tid == 64) s_span[1] = b > nr ? nr : b;
-  }
-  if (tid == 0) {
-    s_nmed = 0;
-    s_tile_unsorted = 0;
-  }
-#pragma unroll
-  for (int k = 0; k < PT_ITEMS; k++) s_row[k * PT_THREADS + tid] = 0;
-  __syncthreads();
-  const int64_t ra = s_span[0];
-  int64_t rb = s_span[1];
-  if (ra >= rb) return;
-  if ((int64_t)rpo[rb] - (int64_t)rpo[rb - 1] > PT_TILE) rb--;  // a long row can only be the last one
-  if (ra >= rb) return;
-  const int64_t e0 = rpo[ra];
-  const int cnt = (int)((int64_t)rpo[rb] - e0);
-  if (cnt == 0) return;
-
-  // Row heads into LDS (tiles whose row range is dominated by empty rows — e.g. the
-  // isolated vertices RCM packs at the end — would walk millions of heads: they test
-  // each position by binary search instead), then a max-scan of head positions gives every
-  // entry its row; the row's (length, source offset) record is fetched once per row piece.
-  const int64_t nrows_range = rb - ra;
-  if (nrows_range <= 4 * PT_CAP) {
-    for (int64_t r = ra + 1 + tid; r < rb; r += PT_THREADS) {
-      const int p = (int)((int64_t)rpo[r] - e0);
-      if (p < cnt) atomicMax(&s_row[p], (int)(r - ra));
-    }
-  } else {
-    for (int p = tid; p < cnt; p += PT_THREADS) {
-      const int64_t target = e0 + p;  // last row r in [ra, rb) with rpo[r] <= target
-      int64_t lo = ra, hi = rb;       // invariant: rpo[lo] <= target, answer in [lo, hi)
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)rpo[mid] <= target) lo = mid;
-        else hi = mid;
-      }
-      if ((int64_t)rpo[lo] == target) s_row[p] = (int)(lo - ra);
-    }
-  }
-  __syncthreads();
-  {
-    const int p0 = tid * PT_ITEMS;
-    int hd[PT_ITEMS];
-    int last = 0;
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) {
-      hd[k] = s_row[p0 + k];
-      if (hd[k]) last = p0 + k + 1;
-    }
-    const int inc = sbx_wave_inclusive_max(last);
-    int open = __shfl_up(inc, 1, 64);
-    if (lane == 0) open = 0;
-    if (lane == 63) s_wmax[wv] = inc;
-    __syncthreads();
-    for (int w = 0; w < wv; w++) open = s_wmax[w] > open ? s_wmax[w] : open;
-    int hp = open ? open - 1 : 0;
-    int2 rc = rec[ra + (open ? s_row[open - 1] : 0)];
-    __syncthreads();  // every carry-in has been read: s_row can be overwritten
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) {
-      const int p = p0 + k;
-      if (hd[k]) {
-        hp = p;
-        rc = rec[ra + hd[k]];
-      }
-      if (p < cnt) {
-        s_row[p] = (int)((int64_t)rc.y - (e0 + hp));  // source index = e0 + p + this
-        s_hp[p] = (unsigned short)hp;
-      }
-      hd[k] = rc.x;  // row length, stored once the offsets have been consumed
-    }
-    __syncthreads();
-    // gather: whole old rows, columns relabelled (permute_order_two.cc:63-74)
-    for (int p = tid; p < cnt; p += PT_THREADS) {
-      const int64_t src = e0 + p + s_row[p];
-      I c = col_in[src];
-      if (col_order) c = col_order[c];
-      s_col[p] = (int)c;
-      if (HASV) s_val[p] = ((const V *)val_in)[src];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++)
-      if (p0 + k < cnt) s_row[p0 + k] = hd[k];
-  }
-  __syncthreads();
-
-  // classify the tile: rows <= PT_SHORT only -> all-pairs ranking; otherwise one
-  // tile-wide stable LSD radix sort on the composite key (local row, column)
-  bool unsorted = false, dup = false, has_medium = false;
-  for (int p = tid; p < cnt; p += PT_THREADS) {
-    const int s = (int)s_hp[p];
-    if (p > s && s_col[p] < s_col[p - 1]) unsorted = true;
-    if (p == s && s_row[p] > PT_SHORT) has_medium = true;
-  }
-  if (__any(unsorted) && lane == 0) {
-    st->any_unsorted = 1;
-    s_tile_unsorted = 1;
-  }
-  if (__any(has_medium) && lane == 0) s_nmed = 1;
-  __syncthreads();
-  if (s_tile_unsorted == 0) {
-    // every row of the tile is already in column order (row-wise permutes, identity
-    // column maps, orders that preserve locality): a stable sort would not move
-    // anything, so stream the gathered rows out as they are
-    for (int p = tid; p < cnt; p += PT_THREADS) {
-      const int c = s_col[p];
-      if (p && c == s_col[p - 1] && s_hp[p] == s_hp[p - 1]) dup = true;
-      col_out[e0 + p] = (I)c;
-      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
-    }
-    if (__any(dup) && lane == 0) st->any_dup = 1;
-    return;
-  }
-  if (s_nmed == 0) {
-    for (int p = tid; p < cnt; p += PT_THREADS) {
-      const int s = (int)s_hp[p], len = s_row[p];
-      const int c = s_col[p];
-      int rank = 0;
-      for (int j = s; j < s + len; j++) {
-        const int cj = s_col[j];
-        rank += (cj < c) || (cj == c && j < p);
-        dup |= (cj == c) && (j != p);
-      }
-      const int64_t o = e0 + s + rank;
-      col_out[o] = (I)c;
-      if (HASV) ((V *)val_out)[o] = s_val[p];
-    }
-    if (__any(dup) && lane == 0) st->any_dup = 1;
-    return;
-  }
-
-  // ---- tile-wide LDS radix sort: passes over the column bits, then the row bits.
-  // The row part of the key is the DENSE rank of the element's row among the rows
-  // present in the tile (prefix count of row heads), so it never exceeds 11 bits
-  // however many empty rows the range contains.
-  {
-    int flag[PT_ITEMS];
-    int local = 0;
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) {
-      const int p = tid * PT_ITEMS + k;
-      const bool head = p < cnt && (p == 0 || s_hp[p] != s_hp[p - 1]);
-      local += head;
-      flag[k] = local;
-    }
-    int all;
-    const int ex = sbx_block_exclusive_sum<int, PT_THREADS>(local, (int *)s_scan, &all);
-#pragma unroll
-    for (int k = 0; k < PT_ITEMS; k++) {
-      const int p = tid * PT_ITEMS + k;
-      if (p < cnt) s_row[p] = ex + flag[k] - 1;
-    }
-    if (tid == 0) s_nmed = all;  // number of rows present
-  }
-  __syncthreads();
-  int row_bits = 0;
-  for (int t = s_nmed - 1; t > 0; t >>= 1) row_bits++;
-  const int total_bits[2] = {col_bits, row_bits};
-  volatile unsigned *wh = s_whist[wv];
+  volatile unsigned *wh = whist_base + wv * 256;
   const uint64_t lt = sbx_lanemask_lt();
-  for (int part = 0; part < 2; part++) {
+  const int total_bits[2] = {col_bits, HASROW ? row_bits : 0};
+  for (int part = 0; part < (HASROW ? 2 : 1); part++) {
     int done = 0;
     while (done < total_bits[part]) {
       const int remaining = total_bits[part] - done;
@@ -480,25 +325,22 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       const int bits = (remaining + passes_left - 1) / passes_left;
       const unsigned mask = (1u << bits) - 1u;
       const int shift = done;
-      if (tid < 256) {
+      for (int i = tid; i < 256 * WAVES; i += THREADS) whist_base[i] = 0;
+      int kc[ITEMS], kr[HASROW ? ITEMS : 1];
+      V kv[HASV ? ITEMS : 1];
+      unsigned rank[ITEMS];
 #pragma unroll
-        for (int i = 0; i < PT_THREADS / 64; i++) s_whist[i][tid] = 0;
-      }
-      int kc[PT_ITEMS], kr[PT_ITEMS];
-      V kv[HASV ? PT_ITEMS : 1];
-      unsigned rank[PT_ITEMS];
-#pragma unroll
-      for (int i = 0; i < PT_ITEMS; i++) {
-        const int e = wv * 64 * PT_ITEMS + i * 64 + lane;
-        const bool ok = e < cnt;
+      for (int i = 0; i < ITEMS; i++) {
+        const int e = wv * 64 * ITEMS + i * 64 + lane;
+        const bool ok = e < count;
         kc[i] = ok ? s_col[e] : 0x7FFFFFFF;
-        kr[i] = ok ? s_row[e] : 0x7FFFFFFF;
+        if (HASROW) kr[i] = ok ? s_row[e] : 0x7FFFFFFF;
         if (HASV) kv[i] = ok ? s_val[e] : (V)0;
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < PT_ITEMS; i++) {
-        const unsigned d = ((unsigned)(part ? kr[i] : kc[i]) >> shift) & mask;
+      for (int i = 0; i < ITEMS; i++) {
+        const unsigned d = ((unsigned)((HASROW && part) ? kr[i] : kc[i]) >> shift) & mask;
         uint64_t m = ~(uint64_t)0;
         for (int bb = 0; bb < bits; bb++) {
           const bool bit = (d >> bb) & 1u;
@@ -514,33 +356,40 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       }
       __syncthreads();
       {
-        unsigned c4[PT_THREADS / 64];
+        // digit totals over the waves -> exclusive scan over the digits -> per-(wave, digit) bases; a thread owns
+        // DPT consecutive digits (1 when the workgroup has 256 threads or more)
+        constexpr int DPT = THREADS >= 256 ? 1 : 256 / THREADS;
+        unsigned c4[DPT][WAVES];
         unsigned tot = 0;
-        if (tid < 256) {  // thread `tid` owns digit `tid`
+        if (tid * DPT < 256) {
 #pragma unroll
-          for (int i = 0; i < PT_THREADS / 64; i++) {
-            c4[i] = s_whist[i][tid];
-            tot += c4[i];
-          }
+          for (int j = 0; j < DPT; j++)
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) {
+              c4[j][i] = whist_base[i * 256 + tid * DPT + j];
+              tot += c4[j][i];
+            }
         }
         unsigned all;
-        unsigned ex = sbx_block_exclusive_sum<unsigned, PT_THREADS>(tot, s_scan, &all);
-        if (tid < 256) {
+        unsigned ex = sbx_block_exclusive_sum<unsigned, THREADS>(tot, s_scan, &all);
+        if (tid * DPT < 256) {
 #pragma unroll
-          for (int i = 0; i < PT_THREADS / 64; i++) {
-            s_whist[i][tid] = ex;
-            ex += c4[i];
-          }
+          for (int j = 0; j < DPT; j++)
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) {
+              whist_base[i * 256 + tid * DPT + j] = ex;
+              ex += c4[j][i];
+            }
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < PT_ITEMS; i++) {
-        const unsigned d = ((unsigned)(part ? kr[i] : kc[i]) >> shift) & mask;
-        const unsigned pos = s_whist[wv][d] + rank[i];
-        if (pos < (unsigned)PT_CAP) {
+      for (int i = 0; i < ITEMS; i++) {
+        const unsigned d = ((unsigned)((HASROW && part) ? kr[i] : kc[i]) >> shift) & mask;
+        const unsigned pos = whist_base[wv * 256 + d] + rank[i];
+        if (pos < (unsigned)CAP) {
           s_col[pos] = kc[i];
-          s_row[pos] = kr[i];
+          if (HASROW) s_row[pos] = kr[i];
           if (HASV) s_val[pos] = kv[i];
         }
       }
@@ -548,136 +397,636 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       done += bits;
     }
   }
-  for (int p = tid; p < cnt; p += PT_THREADS) {
-    const int c = s_col[p];
-    if (p && c == s_col[p - 1] && s_row[p] == s_row[p - 1]) dup = true;
-    col_out[e0 + p] = (I)c;
-    if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
-  }
-  if (__any(dup) && lane == 0) st->any_dup = 1;
 }
 
-// ---- rows of (PT_TILE, capacity] entries: one workgroup per row, LDS radix sort ----
-// The row is gathered (relabelled) into LDS once, sorted there by a stable LSD radix
-// sort over the significant column bits (ballot match-any ranking, per-wave digit
-// counters; every thread keeps its items in registers across the in-place scatter)
-// and streamed out: HBM sees each nonzero exactly once in and once out.
-struct RowPasses {
-  int n;
-  int shift[4];
-  int bits[4];
-};
+// In-place inclusive scan of the bucket counters c[0, nc) (thread t owns CPT consecutive words, moved 16 bytes at a
+// time; the array must extend to THREADS * CPT words); returns this thread's largest count.  Two barriers inside;
+// the caller adds the one that publishes the result.
+template <int THREADS, int CPT>
+__device__ __forceinline__ unsigned scan_bucket_counts(unsigned *c, int nc, unsigned *s_scan) {
+  static_assert(CPT % 4 == 0, "16-byte LDS accesses");
+  const int base = (int)threadIdx.x * CPT;
+  unsigned v[CPT];
+  unsigned sum = 0, mx = 0;
+  if (base < nc) {
+#pragma unroll
+    for (int i = 0; i < CPT; i += 4) {
+      const uint4 q = *(const uint4 *)(c + base + i);
+      v[i] = q.x, v[i + 1] = q.y, v[i + 2] = q.z, v[i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+      const unsigned y = base + i < nc ? v[i] : 0u;  // words past nc are stale
+      mx = y > mx ? y : mx;
+      sum += y;
+      v[i] = sum;
+    }
+  }
+  unsigned tot;
+  const unsigned ex = sbx_block_exclusive_sum<unsigned, THREADS>(sum, s_scan, &tot);
+  if (base < nc) {
+#pragma unroll
+    for (int i = 0; i < CPT; i += 4)
+      *(uint4 *)(c + base + i) = make_uint4(v[i] + ex, v[i + 1] + ex, v[i + 2] + ex, v[i + 3] + ex);
+  }
+  return mx;
+}
 
+// diagnostic only (SBX_DEBUG_TILE_STOP=9): wall-clock cycles from kernel entry to the end of each phase, summed over
+// the tiles by thread 0; [31] counts the tiles.  Printed and cleared by sort_stage.
+__device__ unsigned long long g_tile_stamps[32];
+#define TILE_STAMP(i)                                                                    \
+  do {                                                                                   \
+    if (dbg_stop == 9 && tid == 0) {                                                     \
+      unsigned long long t_;                                                             \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+      atomicAdd(&g_tile_stamps[i], t_ - t_start);                                        \
+    }                                                                                    \
+  } while (0)
+
+// ---- the tile kernel ----------------------------------------------------------
+// col_order == nullptr: csr_sort_rows mode (no relabel).  tile_first[t] = first row whose output range starts at
+// or after position t * PT_W (k_tile_first).  Entries live in registers (position p = k * THREADS + tid); LDS is one
+// pool of 16 bytes per entry whose regions change hands between the phases (a row longer than PT_LMAX that ends
+// inside the window keeps its positions in the tile as a hole: counted, never gathered or written):
+//   r0  row-head marks -> (source offset - position) -> gathered columns -> placed words -> sorted columns
+//   r1  first position of the entry's row | row length << 16            (radix path: dense row rank)
+//   c   per-head (source offset, length) -> per-row (min, max) -> bucket counters -> sorted values
+template <typename I, int VB>
+__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
+    PermState *__restrict__ st, int col_bits, int force_radix) {
+  typedef typename ValT<VB>::type V;
+  constexpr bool HASV = VB != 0;
+  constexpr int THREADS = PT_THREADS, ITEMS = PT_ITEMS, CAP = PT_CAP, WAVES = THREADS / 64;
+  static_assert(sizeof(V) * CAP <= sizeof(unsigned) * 2 * CAP, "the sorted values are staged in the counter region");
+  __shared__ __attribute__((aligned(16))) unsigned s_pool[4 * CAP + 4];
+  __shared__ unsigned s_whist[WAVES * 256];  // radix path only
+  __shared__ unsigned s_scan[WAVES + 1];
+  __shared__ int s_wmax[WAVES];
+  __shared__ int s_flag[2];  // [0] some row of the tile is out of order, [1] take the radix path
+  int *const s_a = (int *)s_pool;  // r0 under its successive names
+  int *const s_key = (int *)s_pool;
+  unsigned *const s_hl = s_pool + CAP;
+  unsigned *const s_c = s_pool + 2 * CAP;
+  V *const s_val = (V *)(s_pool + 2 * CAP);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dbg_stop = force_radix >> 8;  // timing ablation only (SBX_DEBUG_TILE_STOP): leave after a phase, output junk
+  force_radix &= 0xFF;
+  unsigned long long t_start = 0;
+  if (dbg_stop == 9) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+
+  const int64_t ra = tile_first[blockIdx.x];
+  int64_t rb = tile_first[blockIdx.x + 1];
+  if (ra >= rb) return;
+  const int64_t e0 = rpo[ra];
+  if ((int64_t)rpo[rb] - (int64_t)rpo[rb - 1] > PT_LMAX) rb--;  // a long last row would not fit (it has its own kernel)
+  if (ra >= rb) return;
+  const int cnt = (int)((int64_t)rpo[rb] - e0);
+  if (cnt == 0) return;
+  TILE_STAMP(0);
+  if (dbg_stop == 9 && tid == 0) {
+    atomicAdd(&g_tile_stamps[31], 1ull);
+    atomicAdd(&g_tile_stamps[30], (unsigned long long)cnt);
+  }
+
+  // ---- row map.  Non-empty rows mark their first position and leave (source offset, length) there; a max-scan
+  // of head positions then gives every entry its row.  (Windows dominated by empty rows — the isolated vertices
+  // RCM packs at the end — would walk millions of rows: they search each position instead.)
+#pragma unroll
+  for (int k = 0; k < ITEMS; k += 4) *(int4 *)&s_a[k * THREADS + 4 * tid] = make_int4(0, 0, 0, 0);
+  if (tid < 2) s_flag[tid] = 0;
+  __syncthreads();
+  TILE_STAMP(1);
+  if (rb - ra <= 4 * CAP) {
+    for (int64_t r = ra + tid; r < rb; r += THREADS) {
+      const int2 rc = rec[r];
+      if (rc.x > 0) {
+        const int p = (int)((int64_t)rpo[r] - e0);
+        s_a[p] = 1;
+        *(uint2 *)&s_c[2 * p] = make_uint2((unsigned)rc.y, (unsigned)rc.x);
+      }
+    }
+  } else {
+    for (int p = tid; p < cnt; p += THREADS) {
+      const int64_t target = e0 + p;  // last row r in [ra, rb) with rpo[r] <= target: the row that owns the position
+      int64_t lo = ra, hi = rb;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rpo[mid] <= target) lo = mid;
+        else hi = mid;
+      }
+      if ((int64_t)rpo[lo] == target) {
+        const int2 rc = rec[lo];
+        s_a[p] = 1;
+        *(uint2 *)&s_c[2 * p] = make_uint2((unsigned)rc.y, (unsigned)rc.x);
+      }
+    }
+  }
+  __syncthreads();
+  TILE_STAMP(2);
+  {
+    const int p0 = tid * ITEMS;
+    int hd[ITEMS];
+    int last = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+      const int4 q = *(const int4 *)&s_a[p0 + k];
+      hd[k] = q.x, hd[k + 1] = q.y, hd[k + 2] = q.z, hd[k + 3] = q.w;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (hd[k]) last = p0 + k + 1;
+    const int inc = sbx_wave_inclusive_max(last);
+    int open = __shfl_up(inc, 1, 64);
+    if (lane == 0) open = 0;
+    if (lane == 63) s_wmax[wv] = inc;
+    __syncthreads();
+    for (int w = 0; w < wv; w++) open = s_wmax[w] > open ? s_wmax[w] : open;
+    int hp = open ? open - 1 : 0;  // position 0 is a head
+    uint2 sl = *(const uint2 *)&s_c[2 * hp];  // (source offset, length) of the row open at this thread's first entry
+    unsigned ohl[ITEMS];
+    int oa[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = p0 + k;
+      if (hd[k]) {
+        hp = p;
+        sl = *(const uint2 *)&s_c[2 * p];
+      }
+      ohl[k] = (unsigned)hp | (sl.y << 16);  // entries past cnt inherit the last row: never used
+      oa[k] = (int)sl.x - hp;                // source index of the entry = this + p
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+      *(uint4 *)&s_hl[p0 + k] = make_uint4(ohl[k], ohl[k + 1], ohl[k + 2], ohl[k + 3]);
+      *(int4 *)&s_a[p0 + k] = make_int4(oa[k], oa[k + 1], oa[k + 2], oa[k + 3]);
+    }
+  }
+  __syncthreads();
+  TILE_STAMP(3);
+  if (dbg_stop == 1) {
+    for (int p = tid; p < cnt; p += THREADS) col_out[e0 + p] = (I)(s_a[p] + (int)s_hl[p]);
+    return;
+  }
+
+  // ---- gather: whole old rows, columns relabelled (permute_order_two.cc:63-74); entries stay in registers
+  int kc[ITEMS];
+  V kv[HASV ? ITEMS : 1];
+  unsigned hl[ITEMS];
+  unsigned live = 0, hole = 0;  // bit k: entry k is sorted here / belongs to a row too long for the tile
+  {
+    I c[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      c[k] = 0;
+      hl[k] = 0;
+      if (HASV) kv[k] = (V)0;
+      if (p < cnt) {
+        hl[k] = s_hl[p];
+        if ((hl[k] >> 16) <= (unsigned)PT_LMAX) {
+          live |= 1u << k;
+          const int64_t s = (int64_t)s_a[p] + p;
+          c[k] = __builtin_nontemporal_load(col_in + s);
+          if (HASV) kv[k] = __builtin_nontemporal_load((const V *)val_in + s);
+        } else {
+          hole |= 1u << k;
+        }
+      }
+    }
+    if (dbg_stop == 9) {
+      int acc = 0;
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) acc += (int)c[k];
+      if (acc == 0x12345678) s_flag[1] = 1;  // forces the wait for the column loads in front of the stamp
+      TILE_STAMP(4);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      kc[k] = 0x7FFFFFFF;
+      if (live >> k & 1) {
+        kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
+        s_key[p] = kc[k];  // the word this thread read its source offset from
+      }
+    }
+  }
+  __syncthreads();
+  TILE_STAMP(5);
+  if (dbg_stop == 2) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        col_out[e0 + p] = (I)kc[k];
+        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+      }
+    }
+    return;
+  }
+  {
+    bool unsorted = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        const int hp = (int)(hl[k] & 0xFFFFu);
+        if (p > hp && kc[k] < s_key[p - 1]) unsorted = true;
+        if (p == hp)  // the row's (min, max) accumulators, where its (source, length) record was
+          *(uint2 *)&s_c[2 * p] = make_uint2(0xFFFFFFFFu, 0u);
+      }
+    }
+    if (__any(unsorted) && lane == 0) {
+      st->any_unsorted = 1;
+      s_flag[0] = 1;
+    }
+  }
+  __syncthreads();
+  TILE_STAMP(6);
+  if (s_flag[0] == 0) {
+    // every row of the tile is already in column order (identity column maps, orders that preserve
+    // locality): a stable sort would not move anything, so stream the gathered rows out as they are
+    bool dup = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        if (p > (int)(hl[k] & 0xFFFFu) && kc[k] == s_key[p - 1]) dup = true;
+        col_out[e0 + p] = (I)kc[k];
+        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+      }
+    }
+    if (__any(dup) && lane == 0) st->any_dup = 1;
+    return;
+  }
+
+  // ---- bucket-rank sort.  (min, max) per row: every thread reduces the runs of its own consecutive entries and
+  // adds one LDS atomic pair per run
+  {
+    const int p0 = tid * ITEMS;
+    unsigned cur = 0xFFFFFFFFu, mn = 0, mx = 0;
+    unsigned key[ITEMS], hpv[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+      const int4 q = *(const int4 *)&s_key[p0 + k];
+      const uint4 g = *(const uint4 *)&s_hl[p0 + k];
+      key[k] = (unsigned)q.x, key[k + 1] = (unsigned)q.y, key[k + 2] = (unsigned)q.z, key[k + 3] = (unsigned)q.w;
+      hpv[k] = g.x, hpv[k + 1] = g.y, hpv[k + 2] = g.z, hpv[k + 3] = g.w;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const bool use = p0 + k < cnt && (hpv[k] >> 16) <= (unsigned)PT_LMAX;  // holes hold no columns
+      hpv[k] &= 0xFFFFu;
+      if (use) {
+        if (hpv[k] != cur) {
+          if (cur != 0xFFFFFFFFu) {
+            atomicMin(&s_c[2 * cur], mn);
+            atomicMax(&s_c[2 * cur + 1], mx);
+          }
+          cur = hpv[k];
+          mn = mx = key[k];
+        } else {
+          mn = key[k] < mn ? key[k] : mn;
+          mx = key[k] > mx ? key[k] : mx;
+        }
+      }
+    }
+    if (cur != 0xFFFFFFFFu) {
+      atomicMin(&s_c[2 * cur], mn);
+      atomicMax(&s_c[2 * cur + 1], mx);
+    }
+  }
+  __syncthreads();
+  TILE_STAMP(7);
+  unsigned bk[ITEMS], wd[ITEMS];
+  {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      bk[k] = 2 * (unsigned)p;  // holes are counted at their own position: the prefix sums stay aligned with the tile
+      wd[k] = 0;
+      if (live >> k & 1) {
+        const unsigned hp = hl[k] & 0xFFFFu, len = hl[k] >> 16;
+        const uint2 mm = *(const uint2 *)&s_c[2 * hp];
+        const unsigned mn = mm.x, mx = mm.y;
+        const int rbits = bits_u32(mx - mn);
+        const int ib = bits_u32(len - 1);                 // bits of the position inside the row
+        const int lg = len > (unsigned)BK_SHORT ? ib : 0; // 2^lg buckets, 2^lg < 2 * len
+        const int shift = rbits > lg ? rbits - lg : 0;
+        const unsigned rel = (unsigned)kc[k] - mn;
+        const unsigned bo = shift >= 32 ? 0u : rel >> shift;
+        const unsigned low = shift >= 32 ? rel : rel & ((1u << shift) - 1u);
+        if (shift + ib > 32) bad = true;  // word does not fit (short rows spread over > 2^27 columns)
+        wd[k] = (low << ib) | ((unsigned)p - hp);
+        bk[k] = 2 * hp + bo;
+      }
+    }
+    if ((__any(bad) || force_radix) && lane == 0) s_flag[1] = 1;
+  }
+  __syncthreads();  // the (min, max) words and the column copies in r0 have been read
+  TILE_STAMP(8);
+  if (dbg_stop == 3) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        col_out[e0 + p] = (I)(bk[k] + wd[k]);
+        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+      }
+    }
+    return;
+  }
+  for (int i = 4 * tid; i < 2 * cnt; i += 4 * THREADS) *(uint4 *)&s_c[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  TILE_STAMP(9);
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++)
+    if ((live | hole) >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
+  __syncthreads();
+  TILE_STAMP(10);
+  {
+    const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
+    if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[1] = 1;
+  }
+  __syncthreads();
+  TILE_STAMP(11);
+  if (dbg_stop == 4) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        col_out[e0 + p] = (I)(s_c[bk[k]] + wd[k]);
+        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+      }
+    }
+    return;
+  }
+  if (s_flag[1] == 0) {
+    // placement fills every bucket from its end: afterwards s_c[b] is the bucket's first slot and s_c[b + 1] its end
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (live >> k & 1) s_a[atomicSub(&s_c[bk[k]], 1u) - 1u] = (int)wd[k];
+    __syncthreads();
+    TILE_STAMP(12);
+    int fin[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      fin[k] = 0;
+      if (live >> k & 1) {
+        const unsigned b0 = s_c[bk[k]], b1 = s_c[bk[k] + 1];
+        unsigned r = 0;
+        for (unsigned j = b0; j < b1; j++) r += (unsigned)s_a[j] < wd[k];
+        fin[k] = (int)(b0 + r);
+      }
+    }
+    if (dbg_stop == 5) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const int p = k * THREADS + tid;
+        if (live >> k & 1) {
+          col_out[e0 + p] = (I)(fin[k] + kc[k]);
+          if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        }
+      }
+      return;
+    }
+    __syncthreads();  // the placed words (r0) and the bucket bounds (c) are dead: the sorted entries move in
+    TILE_STAMP(13);
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (live >> k & 1) {
+        s_key[fin[k]] = kc[k];
+        if (HASV) s_val[fin[k]] = kv[k];
+      }
+    __syncthreads();
+    TILE_STAMP(14);
+  } else {
+    // radix path: composite key (dense rank of the row among the rows present, column); r0 still holds the columns
+    int flag[ITEMS];
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = tid * ITEMS + k;
+      const bool head = p < cnt && (s_hl[p] & 0xFFFFu) == (unsigned)p;
+      local += head;
+      flag[k] = local;
+    }
+    int all;
+    const int ex = sbx_block_exclusive_sum<int, THREADS>(local, (int *)s_scan, &all);  // its barriers also retire the reads above
+    int *const s_rank = (int *)s_hl;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = tid * ITEMS + k;
+      if (p < cnt) s_rank[p] = ex + flag[k] - 1;
+    }
+    if (HASV) {  // (holes sort among themselves inside their own row rank: harmless, they are never written out)
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++)
+        if (k * THREADS + tid < cnt) s_val[k * THREADS + tid] = kv[k];
+    }
+    __syncthreads();
+    int row_bits = 0;
+    for (int t = all - 1; t > 0; t >>= 1) row_bits++;
+    lds_radix_sort<V, HASV, true, THREADS, ITEMS>(s_key, s_rank, s_val, s_whist, s_scan, cnt, col_bits, row_bits);
+  }
+  {
+    bool dup = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (live >> k & 1) {
+        const int c = s_key[p];
+        if (p > (int)(hl[k] & 0xFFFFu) && c == s_key[p - 1]) dup = true;  // rows keep their position ranges
+        col_out[e0 + p] = (I)c;
+        if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+      }
+    }
+    if (__any(dup) && lane == 0) st->any_dup = 1;
+  }
+  if (dbg_stop == 9) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TILE_STAMP(15);
+  }
+}
+
+// tile_first[t] = first row r in [0, nr] whose output range starts at or after position t * PT_W
+template <typename I>
+__global__ __launch_bounds__(256) void k_tile_first(const I *__restrict__ rpo, int64_t nr, int64_t ntiles,
+                                                    I *__restrict__ tile_first) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  const int64_t pos = t * PT_W;
+  int64_t lo = 0, hi = nr;  // first r with rpo[r] >= pos, nr if none
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)rpo[mid] >= pos) hi = mid;
+    else lo = mid + 1;
+  }
+  tile_first[t] = (I)lo;
+}
+
+// ---- rows of (PT_LMAX, capacity] entries: one workgroup per row ------------------------
+// The row is gathered (relabelled) once, sorted in LDS by the bucket-rank pass (or, if its columns cluster,
+// by the LSD radix sort over the significant column bits) and streamed out: HBM sees each nonzero once in
+// and once out.
 template <typename I, int VB, int CAP, int BR_THREADS>
 __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out, char *val_out, RowPasses passes,
-    PermState *__restrict__ st) {
+    const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out, char *val_out, int col_bits,
+    PermState *__restrict__ st, int force_radix) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int ITEMS = CAP / BR_THREADS;
   constexpr int WAVES = BR_THREADS / 64;
-  __shared__ int s_key[CAP];
+  static_assert(WAVES * 256 <= CAP, "the radix path keeps its digit counters in the bucket counter array");
+  __shared__ __attribute__((aligned(16))) int s_key[CAP];
   __shared__ V s_val[HASV ? CAP : 1];
-  __shared__ unsigned s_whist[WAVES][256];
+  __shared__ __attribute__((aligned(16))) int s_a[CAP];           // placed words
+  __shared__ __attribute__((aligned(16))) unsigned s_c[CAP + 4];  // bucket counters
   __shared__ unsigned s_scan[WAVES + 1];
+  __shared__ unsigned s_mm[2 * WAVES];
+  __shared__ int s_flag[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t r = block_rows[blockIdx.x];
   const int64_t e0 = rpo[r];
   const int len = (int)((int64_t)rpo[r + 1] - e0);
   const int64_t src0 = rec[r].y;
-  for (int i = tid; i < CAP; i += BR_THREADS) {
-    int c = 0x7FFFFFFF;  // padding: sorts last, never written out
-    if (i < len) {
-      I cc = col_in[src0 + i];
-      if (col_order) cc = col_order[cc];
-      c = (int)cc;
-      if (HASV) s_val[i] = ((const V *)val_in)[src0 + i];
+  if (tid < 2) s_flag[tid] = 0;
+  int kc[ITEMS];
+  V kv[HASV ? ITEMS : 1];
+  {
+    I c[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * BR_THREADS + tid;
+      c[k] = 0;
+      if (HASV) kv[k] = (V)0;
+      if (p < len) {
+        c[k] = __builtin_nontemporal_load(col_in + src0 + p);
+        if (HASV) kv[k] = __builtin_nontemporal_load((const V *)val_in + src0 + p);
+      }
     }
-    s_key[i] = c;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * BR_THREADS + tid;
+      kc[k] = 0x7FFFFFFF;  // padding: sorts last, never written out
+      if (p < len) kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
+      s_key[p] = kc[k];
+    }
   }
   __syncthreads();
-  bool unsorted = false;
-  for (int i = tid + 1; i < len; i += BR_THREADS) unsorted |= s_key[i] < s_key[i - 1];
-  if (tid == 0) s_scan[BR_THREADS / 64] = 0;
-  __syncthreads();
-  if (__any(unsorted) && lane == 0) {
-    st->any_unsorted = 1;
-    s_scan[BR_THREADS / 64] = 1;
+  {
+    bool unsorted = false;
+    unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * BR_THREADS + tid;
+      if (p < len) {
+        if (p > 0 && kc[k] < s_key[p - 1]) unsorted = true;
+        mn = (unsigned)kc[k] < mn ? (unsigned)kc[k] : mn;
+        mx = (unsigned)kc[k] > mx ? (unsigned)kc[k] : mx;
+      }
+    }
+    mn = sbx_wave_min(mn);
+    mx = sbx_wave_max(mx);
+    if (lane == 0) {
+      s_mm[2 * w] = mn;
+      s_mm[2 * w + 1] = mx;
+    }
+    if (__any(unsorted) && lane == 0) {
+      st->any_unsorted = 1;
+      s_flag[0] = 1;
+    }
   }
   __syncthreads();
-  const int npass = s_scan[BR_THREADS / 64] ? passes.n : 0;  // an ordered row needs no sort
+  if (s_flag[0] == 0) {  // an ordered row needs no sort
+    bool dup = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * BR_THREADS + tid;
+      if (p < len) {
+        if (p > 0 && kc[k] == s_key[p - 1]) dup = true;
+        col_out[e0 + p] = (I)kc[k];
+        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+      }
+    }
+    if (__any(dup) && lane == 0) st->any_dup = 1;
+    return;
+  }
+  unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+  for (int i = 0; i < WAVES; i++) {
+    mn = s_mm[2 * i] < mn ? s_mm[2 * i] : mn;
+    mx = s_mm[2 * i + 1] > mx ? s_mm[2 * i + 1] : mx;
+  }
+  const int rbits = bits_u32(mx - mn);
+  const int ib = bits_u32((unsigned)len - 1);  // 2^ib buckets, len <= 2^ib <= CAP
+  const int shift = rbits > ib ? rbits - ib : 0;
+  const unsigned lowmask = shift >= 32 ? 0xFFFFFFFFu : (1u << shift) - 1u;  // shift + ib = max(rbits, ib) <= 32
+  unsigned bk[ITEMS], wd[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const int p = k * BR_THREADS + tid;
+    const unsigned rel = (unsigned)kc[k] - mn;
+    bk[k] = shift >= 32 ? 0u : rel >> shift;
+    wd[k] = ((rel & lowmask) << ib) | (unsigned)p;
+    s_c[p] = 0;
+  }
+  if (tid < 4) s_c[CAP + tid] = (unsigned)len;  // end of the last bucket
   __syncthreads();
-
-  volatile unsigned *wh = s_whist[w];
-  const uint64_t lt = sbx_lanemask_lt();
-  for (int pass = 0; pass < npass; pass++) {
-    const int shift = passes.shift[pass], bits = passes.bits[pass];
-    const unsigned mask = (1u << bits) - 1u;
-    for (int i = tid; i < 256 * WAVES; i += BR_THREADS) (&s_whist[0][0])[i] = 0;
-    int k[ITEMS];
-    V v[HASV ? ITEMS : 1];
-    unsigned rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const int e = w * 64 * ITEMS + i * 64 + lane;
-      k[i] = s_key[e];
-      if (HASV) v[i] = s_val[e];
-    }
+  for (int k = 0; k < ITEMS; k++)
+    if (k * BR_THREADS + tid < len) atomicAdd(&s_c[bk[k]], 1u);
+  __syncthreads();
+  {
+    const unsigned mxc = scan_bucket_counts<BR_THREADS, ITEMS>(s_c, CAP, s_scan);
+    if ((__any(mxc > (unsigned)BK_MAX) || force_radix) && lane == 0) s_flag[1] = 1;
+  }
+  __syncthreads();
+  if (s_flag[1] == 0) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (k * BR_THREADS + tid < len) s_a[atomicSub(&s_c[bk[k]], 1u) - 1u] = (int)wd[k];
     __syncthreads();
+    int fin[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const unsigned d = ((unsigned)k[i] >> shift) & mask;
-      uint64_t m = ~(uint64_t)0;
-      for (int b = 0; b < bits; b++) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
-      }
-      const unsigned prev = wh[d];
-      const unsigned rk = (unsigned)__popcll(m & lt);
-      __builtin_amdgcn_wave_barrier();
-      if (rk == 0) wh[d] = prev + (unsigned)__popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      rank[i] = prev + rk;
-    }
-    __syncthreads();
-    {
-      unsigned c[WAVES];
-      unsigned tot = 0;
-      if (tid < 256) {
-#pragma unroll
-        for (int i = 0; i < WAVES; i++) {
-          c[i] = s_whist[i][tid];
-          tot += c[i];
-        }
-      }
-      unsigned all;
-      unsigned ex = sbx_block_exclusive_sum<unsigned, BR_THREADS>(tot, s_scan, &all);
-      if (tid < 256) {
-#pragma unroll
-        for (int i = 0; i < WAVES; i++) {
-          s_whist[i][tid] = ex;
-          ex += c[i];
-        }
+    for (int k = 0; k < ITEMS; k++) {
+      fin[k] = 0;
+      if (k * BR_THREADS + tid < len) {
+        const unsigned b0 = s_c[bk[k]], b1 = s_c[bk[k] + 1];
+        unsigned rk = 0;
+        for (unsigned j = b0; j < b1; j++) rk += (unsigned)s_a[j] < wd[k];
+        fin[k] = (int)(b0 + rk);
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const unsigned d = ((unsigned)k[i] >> shift) & mask;
-      const unsigned pos = s_whist[w][d] + rank[i];
-      s_key[pos] = k[i];
-      if (HASV) s_val[pos] = v[i];
+    for (int k = 0; k < ITEMS; k++)
+      if (k * BR_THREADS + tid < len) {
+        s_key[fin[k]] = kc[k];
+        if (HASV) s_val[fin[k]] = kv[k];
+      }
+    __syncthreads();
+  } else {
+    if (HASV) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) s_val[k * BR_THREADS + tid] = kv[k];
     }
     __syncthreads();
+    lds_radix_sort<V, HASV, false, BR_THREADS, ITEMS>(s_key, nullptr, s_val, s_c, s_scan, CAP, col_bits, 0);
   }
   bool dup = false;
-  for (int i = tid; i < len; i += BR_THREADS) {
-    const int c = s_key[i];
-    if (i && c == s_key[i - 1]) dup = true;
-    col_out[e0 + i] = (I)c;
-    if (HASV) ((V *)val_out)[e0 + i] = s_val[i];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const int p = k * BR_THREADS + tid;
+    if (p < len) {
+      const int c = s_key[p];
+      if (p > 0 && c == s_key[p - 1]) dup = true;
+      col_out[e0 + p] = (I)c;
+      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+    }
   }
   if (__any(dup) && lane == 0) st->any_dup = 1;
 }
@@ -806,30 +1155,34 @@ static bool permute_overlap() {
   return on;
 }
 
-// rows of PT_TILE < length <= 16 K: one workgroup per row, by capacity class
+static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / row takes the radix path (tests)
+  static const int on = (getenv("SBX_PERMUTE_FORCE_RADIX") ? atoi(getenv("SBX_PERMUTE_FORCE_RADIX")) & 0xFF : 0) |
+                        (getenv("SBX_DEBUG_TILE_STOP") ? atoi(getenv("SBX_DEBUG_TILE_STOP")) << 8 : 0);
+  return on;
+}
+
+// rows of PT_LMAX < length <= 8 K: one workgroup per row, by capacity class
 template <int VB>
 int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
                     const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *block_rows,
-                    const unsigned *n_block, int64_t block_stride, PermState *st) {
+                    const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st) {
   typedef int32_t I;
-  RowPasses rpasses;
-  sbx_radix_pass pl[16];
-  rpasses.n = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, pl);
-  for (int i = 0; i < rpasses.n && i < 4; i++) {
-    rpasses.shift[i] = pl[i].shift;
-    rpasses.bits[i] = pl[i].bits;
-  }
+  const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
+  const int force = permute_force_radix();
 #define BLOCK_ROWS(CLS, THREADS)                                                                                  \
   if (n_block[CLS])                                                                                               \
     SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
                 dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, col_out,     \
-                val_out, rpasses, st)
-  BLOCK_ROWS(0, 256);
-  BLOCK_ROWS(1, 512);
-  BLOCK_ROWS(2, 1024);
-  if constexpr (VB != 8) BLOCK_ROWS(3, 1024);  // 8-byte values: 16384 entries do not fit LDS, those rows are "long"
+                val_out, col_bits, st, force & 0xFF)
+  BLOCK_ROWS(0, 64);
+  BLOCK_ROWS(1, 64);
+  BLOCK_ROWS(2, 128);
+  BLOCK_ROWS(3, 256);
+  BLOCK_ROWS(4, 512);
+  if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
 #undef BLOCK_ROWS
   SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_PERMUTE_BLOCK, block_nnz * (int64_t)(2 * (sizeof(I) + VB)));
   return SBX_OK;
 }
 
@@ -874,14 +1227,18 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
 template <int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t *col_in, const char *val_in,
                const int32_t *col_order, const int32_t *rpo, int32_t *col_out, char *val_out, int64_t nr, int64_t m,
-               int64_t total, const int32_t *long_rows, unsigned n_long, int64_t long_nnz, const int32_t *block_rows,
-               const unsigned *n_block, int64_t block_stride, PermState *st) {
+               int64_t total, const int32_t *long_rows, const int32_t *block_rows, int64_t block_stride,
+               const PermState &hs, PermState *st) {
   typedef int32_t I;
+  const unsigned n_long = hs.n_long;
+  const unsigned *n_block = hs.n_block;
+  const int64_t long_nnz = (int64_t)hs.long_nnz, block_nnz = (int64_t)hs.block_nnz;
   // The three paths write disjoint rows of the output and only read the inputs: with more than one of them
   // present they run on streams of their own (tile kernel on the caller's stream), so the block-row kernels'
   // tails and the long-row path's short, latency-bound launches hide behind the tile kernel.  While the
   // profiler is on they run back to back, so that a kernel's event time is its own.
-  const bool has_block = (n_block[0] | n_block[1] | n_block[2] | n_block[3]) != 0;
+  bool has_block = false;
+  for (int c = 0; c < BR_CLASSES; c++) has_block |= n_block[c] != 0;
   const bool fork = !h->prof_on && permute_overlap() && total > 0 && (has_block || n_long);
   hipStream_t main_stream = h->stream;
   if (fork) {
@@ -892,15 +1249,34 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
     if (n_long) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[0], 0));
   }
   if (total > 0) {
-    const unsigned tiles = (unsigned)((total + PT_TILE - 1) / PT_TILE);
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3(tiles), dim3(PT_THREADS), rec, col_in, val_in,
-                col_order, rpo, col_out, val_out, nr, st, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0));
+    const int64_t tiles = (total + PT_W - 1) / PT_W;
+    I *tile_first = nullptr;
+    SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_first));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), rpo, nr, tiles,
+                tile_first);
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)tiles), dim3(PT_THREADS), rec, col_in,
+                val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st,
+                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), permute_force_radix());
     SBX_LAUNCH_CHECK(h);
+    SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, (total - long_nnz - block_nnz) * (int64_t)(2 * (sizeof(I) + VB)));
+    if ((permute_force_radix() >> 8) == 9) {  // diagnostic: print and clear the phase stamps
+      unsigned long long hs_[32];
+      SBX_HIP(h, hipStreamSynchronize(h->stream));
+      SBX_HIP(h, hipMemcpyFromSymbol(hs_, HIP_SYMBOL(g_tile_stamps), sizeof(hs_)));
+      if (hs_[31]) {
+        fprintf(stderr, "tile stamps: tiles %llu avg entries %.0f | cycles to end of phase:", hs_[31],
+                (double)hs_[30] / (double)hs_[31]);
+        for (int i = 0; i < 16; i++) fprintf(stderr, " [%d] %.0f", i, (double)hs_[i] / (double)hs_[31]);
+        fprintf(stderr, "\n");
+      }
+      memset(hs_, 0, sizeof(hs_));
+      SBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), hs_, sizeof(hs_)));
+    }
   }
   if (has_block) {
     if (fork) h->stream = h->aux_stream[0];
     const int rc = block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
-                                       block_stride, st);
+                                       block_stride, block_nnz, st);
     if (fork) {
       if (rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
       h->stream = main_stream;
@@ -1004,7 +1380,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   int64_t block_stride = 0;
   if (col_order) {  // the sorting pipeline needs the rows that do not fit a tile listed by class
-    int64_t cap_long = nnz / PT_TILE + 1;
+    int64_t cap_long = nnz / PT_LMAX + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
@@ -1051,7 +1427,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     SBX_TRY(sbx_readback(h, &hc, st, sizeof(PermState)));
     if (!hc.any_unsorted) return SBX_OK;
     // some input row is out of order: redo with the sorting pipeline (row_ptr_out is already final)
-    int64_t cap_long = nnz / PT_TILE + 1;
+    int64_t cap_long = nnz / PT_LMAX + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
@@ -1065,8 +1441,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   int rc;
 #define STAGE(VBX)                                                                                                  \
   rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
-                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, hs.n_long, (int64_t)hs.long_nnz,     \
-                       block_rows, hs.n_block, block_stride, st)
+                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
@@ -1119,8 +1494,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   int rc;
 #define STAGE(VBX)                                                                                               \
   rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)nullptr,          \
-                       (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, hs.n_long, (int64_t)hs.long_nnz,    \
-                       block_rows, hs.n_block, (int64_t)n, st)
+                       (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, block_rows, (int64_t)n, hs, st)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);

@@ -419,7 +419,7 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
     # a few very long rows (radix path), medium rows (bitonic path), duplicates with values
     g = np.random.default_rng(3)
     n, m = 64, 50000
-    # one row in every sort class: tile (<= 1024), block rows of 2048 / 4096 / 8192 / 16384 slots, global radix
+    # one row in every sort class: tile (<= 1024), block rows of 2048 / 4096 / 8192 slots, global radix
     lens = np.array([0, 1, 2, 40, 33, 1024, 1025, 2048, 2049, 3000, 4096, 4097, 5000, 8192, 8193, 9000, 16384, 16385,
                      20000] + [int(x) for x in g.integers(0, 300, n - 19)])
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -430,6 +430,64 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
         # identity maps: nothing is unsorted, so duplicates must keep their input order
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
+
+
+def _clustered_case(seed=5):
+    """Rows whose relabelled columns sit in one tight block plus a far outlier: the bucket-rank sort of
+    sbx_permute.hip meets a bucket larger than its limit there and must take the radix path."""
+    g = np.random.default_rng(seed)
+    m = 1 << 20
+    lens = [300, 5, 700, 1024, 64, 1500, 3000, 6000, 2, 130] + [int(x) for x in g.integers(0, 260, 120)]
+    cols = []
+    for i, l in enumerate(lens):
+        if l == 0:
+            cols.append(np.zeros(0, np.int64))
+            continue
+        base = int(g.integers(0, m // 2))
+        block = base + np.arange(max(l - 1, 1))[: max(l - 1, 0)]
+        far = np.array([m - 1 - i]) if l > 1 else np.array([base])
+        cols.append(np.sort(np.concatenate([block, far]))[:l])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols).astype(np.int32)
+    # column map that keeps blocks tight but scrambles inside 64-column groups
+    co = np.arange(m, dtype=np.int64)
+    co = (co & ~63) | g.permutation(64)[co & 63]
+    return len(lens), m, rp, col, co.astype(np.int32)
+
+
+def test_permute_clustered_rows(ops, oracle):
+    n, m, rp, col, co = _clustered_case()
+    g = np.random.default_rng(9)
+    ro = synth.random_permutation(n, 3)
+    for val in (None, g.integers(-5, 5, len(col)).astype(np.int32), g.random(len(col))):
+        same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co)),
+             oracle.permute_csr(rp, col, val, ro, co))
+
+
+def test_permute_forced_radix_path():
+    """SBX_PERMUTE_FORCE_RADIX=1 sends every tile and block row through the LDS radix sort (the
+    distribution-independent path behind the bucket-rank sort); read once per process, hence the child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+        "from orc import Oracle; from sparsebase_amd import ops, synth\n"
+        "orc = Oracle(); d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "g = np.random.default_rng(1)\n"
+        "lens = np.array([0, 1, 40, 1024, 1025, 2048, 3000, 4097, 8192, 9000] + [int(x) for x in g.integers(0, 300, 200)])\n"
+        "n, m = len(lens), 70000\n"
+        "rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)\n"
+        "col = np.concatenate([np.sort(g.integers(0, m, l)) for l in lens]).astype(np.int32)\n"
+        "ro, co = synth.random_permutation(n, 1), synth.random_permutation(m, 2)\n"
+        "for v in (None, g.integers(-3, 3, len(col)).astype(np.int32), g.random(len(col))):\n"
+        "    got = ops.permute_csr(n, m, d(rp), d(col), d(v), d(ro), d(co)); want = orc.permute_csr(rp, col, v, ro, co)\n"
+        "    for a, b in zip(got, want):\n"
+        "        assert (a is None and b is None) or np.array_equal(a.cpu().numpy(), b)\n"
+        "print('forced-radix ok')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, SBX_PERMUTE_FORCE_RADIX="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced-radix ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_permute_rowwise_copy_path(ops, oracle):
