@@ -47,6 +47,7 @@ constexpr int PT_LMAX = 128;                   // rows up to this many entries a
 static_assert(PT_W + PT_LMAX - 1 <= PT_CAP, "a tile must hold its window plus the tail of its last row");
 constexpr int BK_SHORT = 8;   // rows up to this length are one bucket (plain all-pairs ranking)
 constexpr int BK_MAX = 96;    // a larger bucket sends the tile / row to the radix sort
+constexpr int BK_REFINE = 6;  // a larger bucket after the first level: every bucket is split again in proportion to its count
 // one workgroup sorts one row in LDS; capacity classes so a 1100-entry row does not pay for 8192 slots
 constexpr int BR_CLASSES = 6;
 __host__ __device__ constexpr int br_cap(int cls) { return 256 << cls; }  // 256, 512, 1024, 2048, 4096, 8192
@@ -62,6 +63,8 @@ struct PermState {            // device-resident flags/counters of one call
   unsigned long long block_nnz;  // nonzeros of the one-workgroup-per-row classes
   unsigned long long total;   // nnz of the shard
   unsigned long_unsorted;     // some row of the global-radix class is out of order
+  unsigned n_fb_rows;         // rows / tiles whose columns cluster: listed for the radix kernels
+  unsigned n_fb_tiles;
   unsigned pad2;
 };
 
@@ -452,20 +455,21 @@ __device__ unsigned long long g_tile_stamps[32];
 //   r0  row-head marks -> (source offset - position) -> gathered columns -> placed words -> sorted columns
 //   r1  first position of the entry's row | row length << 16            (radix path: dense row rank)
 //   c   per-head (source offset, length) -> per-row (min, max) -> bucket counters -> sorted values
-template <typename I, int VB>
-__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
-    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
-    PermState *__restrict__ st, int col_bits, int force_radix) {
+template <typename I, int VB, bool RADIX>
+__device__ __forceinline__ void permute_tile_body(
+    const int64_t tile, const int2 *__restrict__ rec, const I *col_in, const char *val_in,
+    const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out,
+    char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix,
+    unsigned *__restrict__ fb_tiles) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int THREADS = PT_THREADS, ITEMS = PT_ITEMS, CAP = PT_CAP, WAVES = THREADS / 64;
   static_assert(sizeof(V) * CAP <= sizeof(unsigned) * 2 * CAP, "the sorted values are staged in the counter region");
   __shared__ __attribute__((aligned(16))) unsigned s_pool[4 * CAP + 4];
-  __shared__ unsigned s_whist[WAVES * 256];  // radix path only
+  __shared__ unsigned s_whist[RADIX ? WAVES * 256 : 1];
   __shared__ unsigned s_scan[WAVES + 1];
   __shared__ int s_wmax[WAVES];
-  __shared__ int s_flag[2];  // [0] some row of the tile is out of order, [1] take the radix path
+  __shared__ int s_flag[4];  // [0] some row of the tile is out of order, [1] radix path, [2] refine, [3] overfull level-0 bucket
   int *const s_a = (int *)s_pool;  // r0 under its successive names
   int *const s_key = (int *)s_pool;
   unsigned *const s_hl = s_pool + CAP;
@@ -477,8 +481,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   unsigned long long t_start = 0;
   if (dbg_stop == 9) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
 
-  const int64_t ra = tile_first[blockIdx.x];
-  int64_t rb = tile_first[blockIdx.x + 1];
+  const int64_t ra = tile_first[tile];
+  int64_t rb = tile_first[tile + 1];
   if (ra >= rb) return;
   const int64_t e0 = rpo[ra];
   if ((int64_t)rpo[rb] - (int64_t)rpo[rb - 1] > PT_LMAX) rb--;  // a long last row would not fit (it has its own kernel)
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   // RCM packs at the end — would walk millions of rows: they search each position instead.)
 #pragma unroll
   for (int k = 0; k < ITEMS; k += 4) *(int4 *)&s_a[k * THREADS + 4 * tid] = make_int4(0, 0, 0, 0);
-  if (tid < 2) s_flag[tid] = 0;
+  if (tid < 4) s_flag[tid] = 0;
   __syncthreads();
   TILE_STAMP(1);
   if (rb - ra <= 4 * CAP) {
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   __syncthreads();
   TILE_STAMP(7);
   unsigned bk[ITEMS], wd[ITEMS];
+  unsigned char sh[ITEMS];
   {
     bool bad = false;
 #pragma unroll
@@ -708,6 +713,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       const int p = k * THREADS + tid;
       bk[k] = 2 * (unsigned)p;  // holes are counted at their own position: the prefix sums stay aligned with the tile
       wd[k] = 0;
+      sh[k] = 0;
       if (live >> k & 1) {
         const unsigned hp = hl[k] & 0xFFFFu, len = hl[k] >> 16;
         const uint2 mm = *(const uint2 *)&s_c[2 * hp];
@@ -722,9 +728,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
         if (shift + ib > 32) bad = true;  // word does not fit (short rows spread over > 2^27 columns)
         wd[k] = (low << ib) | ((unsigned)p - hp);
         bk[k] = 2 * hp + bo;
+        sh[k] = (unsigned char)(shift >= 32 ? 32 : shift);
       }
     }
-    if ((__any(bad) || force_radix) && lane == 0) s_flag[1] = 1;
+    if ((__any(bad) || force_radix || RADIX) && lane == 0) s_flag[1] = 1;
   }
   __syncthreads();  // the (min, max) words and the column copies in r0 have been read
   TILE_STAMP(8);
@@ -749,10 +756,40 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   TILE_STAMP(10);
   {
     const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
-    if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[1] = 1;
+    if (__any(mxc > (unsigned)BK_REFINE) && lane == 0) s_flag[2] = 1;
+    if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[3] = 1;
   }
   __syncthreads();
   TILE_STAMP(11);
+  if (s_flag[2] && !s_flag[1]) {
+    // level 1 (clustered columns): every bucket is split into as many sub-buckets as it holds entries, by interpolation
+    // inside the bucket; the sub-buckets of the row that starts at hp take the counter words from 2 hp on
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (live >> k & 1) {
+        const unsigned b = bk[k], hp = hl[k] & 0xFFFFu;
+        const unsigned start = b ? s_c[b - 1] : 0u, cntb = s_c[b] - start;
+        const unsigned ib = bits_u32((hl[k] >> 16) - 1);
+        const unsigned low = wd[k] >> ib;
+        const unsigned sub = (sh[k] && sh[k] < 32) ? (unsigned)(((unsigned long long)low * cntb) >> sh[k]) : 0u;
+        bk[k] = hp + start + sub;  // = 2 hp + (start - hp) + sub, below 2 hp + length
+      }
+    }
+    __syncthreads();  // the level-0 bounds have been read
+    for (int i = 4 * tid; i < 2 * cnt; i += 4 * THREADS) *(uint4 *)&s_c[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if ((live | hole) >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
+    __syncthreads();
+    const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
+    if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[1] = 1;
+    __syncthreads();
+  } else if (s_flag[3]) {
+    __syncthreads();
+    if (tid == 0) s_flag[1] = 1;
+    __syncthreads();
+  }
   if (dbg_stop == 4) {
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
@@ -803,6 +840,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
       }
     __syncthreads();
     TILE_STAMP(14);
+  } else if constexpr (!RADIX) {
+    // the columns of some row cluster: the tile goes on the list of the radix kernel (same kernel body, RADIX = true)
+    if (tid == 0) fb_tiles[atomicAdd(&st->n_fb_tiles, 1u)] = (unsigned)tile;
+    return;
   } else {
     // radix path: composite key (dense rank of the row among the rows present, column); r0 still holds the columns
     int flag[ITEMS];
@@ -852,6 +893,29 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
   }
 }
 
+template <typename I, int VB>
+__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
+    PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles) {
+  permute_tile_body<I, VB, false>((int64_t)blockIdx.x, rec, col_in, val_in, col_order, rpo, tile_first, col_out, val_out,
+                                  nr, st, col_bits, force_radix, fb_tiles);
+}
+
+// the tiles the kernel above listed (clustered columns): same body, LSD radix sort instead of the bucket-rank pass
+template <typename I, int VB>
+__global__ __launch_bounds__(PT_THREADS) void k_permute_tile_radix(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
+    PermState *__restrict__ st, int col_bits, const unsigned *__restrict__ fb_tiles) {
+  const unsigned n = st->n_fb_tiles;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    permute_tile_body<I, VB, true>((int64_t)fb_tiles[i], rec, col_in, val_in, col_order, rpo, tile_first, col_out,
+                                   val_out, nr, st, col_bits, 0, nullptr);
+    __syncthreads();  // the next tile reuses the LDS pool
+  }
+}
+
 // tile_first[t] = first row r in [0, nr] whose output range starts at or after position t * PT_W
 template <typename I>
 __global__ __launch_bounds__(256) void k_tile_first(const I *__restrict__ rpo, int64_t nr, int64_t ntiles,
@@ -869,166 +933,332 @@ __global__ __launch_bounds__(256) void k_tile_first(const I *__restrict__ rpo, i
 }
 
 // ---- rows of (PT_LMAX, capacity] entries: one workgroup per row ------------------------
-// The row is gathered (relabelled) once, sorted in LDS by the bucket-rank pass (or, if its columns cluster,
-// by the LSD radix sort over the significant column bits) and streamed out: HBM sees each nonzero once in
-// and once out.
+// LDS-only barrier: waits for this wave's LDS traffic, not for its global loads — the prefetches of the rows
+// to come stay in flight across it (__syncthreads() would drain them: vmcnt counts loads and stores alike).
+template <int THREADS>
+__device__ __forceinline__ void lds_barrier() {
+  if (THREADS > 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: LDS operations execute in order
+}
+
+// A workgroup walks the rows blockIdx.x, blockIdx.x + gridDim.x, ... of its class list as a software pipeline:
+// while row i is sorted in LDS and streamed out, the relabel gathers of row i + 1, the column / value loads of
+// row i + 2, the row record of row i + 3 and the list entry of row i + 4 are in flight (registers only).  The
+// sort itself is the bucket-rank pass (or, if the row's columns cluster, the LSD radix sort over the significant
+// column bits); HBM sees each nonzero once in and once out.
 template <typename I, int VB, int CAP, int BR_THREADS>
 __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, const I *__restrict__ block_rows, I *col_out, char *val_out, int col_bits,
-    PermState *__restrict__ st, int force_radix) {
+    const I *__restrict__ rpo, const I *__restrict__ block_rows, int n_rows, I *col_out, char *val_out,
+    PermState *__restrict__ st, int force_radix, unsigned *__restrict__ fb_rows) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int ITEMS = CAP / BR_THREADS;
   constexpr int WAVES = BR_THREADS / 64;
-  static_assert(WAVES * 256 <= CAP, "the radix path keeps its digit counters in the bucket counter array");
-  __shared__ __attribute__((aligned(16))) int s_key[CAP];
-  __shared__ V s_val[HASV ? CAP : 1];
-  __shared__ __attribute__((aligned(16))) int s_a[CAP];           // placed words
-  __shared__ __attribute__((aligned(16))) unsigned s_c[CAP + 4];  // bucket counters
+  static_assert(sizeof(V) <= 8, "sorted values are staged in the placed-word + counter regions");
+  __shared__ __attribute__((aligned(16))) unsigned s_pool[3 * CAP + 4];
   __shared__ unsigned s_scan[WAVES + 1];
   __shared__ unsigned s_mm[2 * WAVES];
-  __shared__ int s_flag[2];
+  __shared__ int s_flag[4];  // [0] row out of order, [1] radix list, [2] refine, [3] overfull bucket at level 0
+  int *const s_key = (int *)s_pool;             // gathered columns -> sorted columns
+  int *const s_a = (int *)s_pool + CAP;         // placed words
+  unsigned *const s_c = s_pool + 2 * CAP;       // bucket counters (CAP + 4 words)
+  V *const s_val = (V *)(s_pool + CAP);         // sorted values: over the placed words (and, 8-byte values, the counters)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t r = block_rows[blockIdx.x];
-  const int64_t e0 = rpo[r];
-  const int len = (int)((int64_t)rpo[r + 1] - e0);
-  const int64_t src0 = rec[r].y;
-  if (tid < 2) s_flag[tid] = 0;
-  int kc[ITEMS];
-  V kv[HASV ? ITEMS : 1];
-  {
-    I c[ITEMS];
+  const int G = (int)gridDim.x;
+
+  // pipeline state.  Row-level quantities are the same in every lane but travel in vector registers so that their
+  // loads are vector-memory loads (scalar loads share lgkmcnt with LDS: every LDS wait would wait for them too).
+  // Every load of an iteration is issued unconditionally (clamped addresses) at its top and nothing reads the
+  // results before the rotation that follows the sort: the compiler's waits then sit behind the sort, where the
+  // loads have landed, and the stores of the sorted row are issued after the rotation, behind nothing.
+  int rid_d = 0;                                  // stage D: list entry loaded
+  int e0_c = 0, len_c = -1, src_c = 0, rid_c = 0; // stage C: row record loaded
+  I c_b[ITEMS];                                   // stage B: columns / values loaded
+  V v_b[HASV ? ITEMS : 1];
+  int e0_b = 0, len_b = -1, rid_b = 0;
+  int k_a[ITEMS];                                 // stage A: relabelled columns loaded -> sorted this iteration
+  V v_a[HASV ? ITEMS : 1];
+  int e0_a = 0, len_a = -1, rid_a = 0;
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const int p = k * BR_THREADS + tid;
-      c[k] = 0;
-      if (HASV) kv[k] = (V)0;
-      if (p < len) {
-        c[k] = __builtin_nontemporal_load(col_in + src0 + p);
-        if (HASV) kv[k] = __builtin_nontemporal_load((const V *)val_in + src0 + p);
+  for (int k = 0; k < ITEMS; k++) {
+    c_b[k] = 0;
+    k_a[k] = 0;
+    if (HASV) v_b[k] = (V)0, v_a[k] = (V)0;
+  }
+  int zero = 0;
+  asm volatile("" : "+v"(zero));  // a vector-register zero the compiler cannot fold: keeps the row-level loads on the vector path
+  const int my_rows = ((int)blockIdx.x < n_rows) ? (n_rows - 1 - (int)blockIdx.x) / G + 1 : 0;
+  bool valid_d = false;
+
+  for (int it = 0; it < my_rows + 4; it++) {
+    // E: list entry of row it
+    const bool valid_e = it < my_rows;
+    const int rid_e = (int)block_rows[(int64_t)blockIdx.x + (int64_t)(valid_e ? it : 0) * G + zero];
+    // D: row record of row it - 1
+    const int rid_s = valid_d ? rid_d : 0;
+    const int r0_d = (int)rpo[rid_s], r1_d = (int)rpo[rid_s + 1], src_d = rec[rid_s].y;
+    // C: columns / values of row it - 2
+    I c_c[ITEMS];
+    V v_c[HASV ? ITEMS : 1];
+    {
+      const int64_t base = len_c > 0 ? (int64_t)src_c : 0;
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const int p = k * BR_THREADS + tid;
+        const int64_t o = base + (p < len_c ? p : 0);
+        c_c[k] = __builtin_nontemporal_load(col_in + o);
+        if (HASV) v_c[k] = __builtin_nontemporal_load((const V *)val_in + o);
       }
     }
+    // B: relabel gathers of row it - 3 (permute_order_two.cc:68)
+    int k_b[ITEMS];
+    if (col_order) {
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const int p = k * BR_THREADS + tid;
-      kc[k] = 0x7FFFFFFF;  // padding: sorts last, never written out
-      if (p < len) kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
-      s_key[p] = kc[k];
+      for (int k = 0; k < ITEMS; k++) k_b[k] = (int)col_order[k * BR_THREADS + tid < len_b ? c_b[k] : 0];
+    } else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) k_b[k] = (int)c_b[k];
     }
-  }
-  __syncthreads();
-  {
-    bool unsorted = false;
-    unsigned mn = 0xFFFFFFFFu, mx = 0;
+
+    // A: sort row it - 4 in LDS
+    const int len = __builtin_amdgcn_readfirstlane(len_a);
+    const int64_t e0 = e0_a;
+    int out_mode = 0;  // 1: sorted row in LDS, to be streamed out after the rotation
+    if (len >= 0) {
+      if (tid < 4) s_flag[tid] = 0;
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const int p = k * BR_THREADS + tid;
-      if (p < len) {
-        if (p > 0 && kc[k] < s_key[p - 1]) unsorted = true;
-        mn = (unsigned)kc[k] < mn ? (unsigned)kc[k] : mn;
-        mx = (unsigned)kc[k] > mx ? (unsigned)kc[k] : mx;
+      for (int k = 0; k < ITEMS; k++) {
+        if (k * BR_THREADS + tid >= len) k_a[k] = 0x7FFFFFFF;  // padding: sorts last, never written out
+        s_key[k * BR_THREADS + tid] = k_a[k];
+      }
+      lds_barrier<BR_THREADS>();
+      {
+        bool unsorted = false;
+        unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const int p = k * BR_THREADS + tid;
+          if (p < len) {
+            if (p > 0 && k_a[k] < s_key[p - 1]) unsorted = true;
+            mn = (unsigned)k_a[k] < mn ? (unsigned)k_a[k] : mn;
+            mx = (unsigned)k_a[k] > mx ? (unsigned)k_a[k] : mx;
+          }
+        }
+        mn = sbx_wave_min(mn);
+        mx = sbx_wave_max(mx);
+        if (lane == 0) {
+          s_mm[2 * w] = mn;
+          s_mm[2 * w + 1] = mx;
+        }
+        if (__any(unsorted) && lane == 0 && !(force_radix & 2)) {  // (bit 1: timing ablation, rows stream out unsorted)
+          st->any_unsorted = 1;
+          s_flag[0] = 1;
+        }
+      }
+      lds_barrier<BR_THREADS>();
+      if (__builtin_amdgcn_readfirstlane(s_flag[0]) == 0) {  // an ordered row needs no sort
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const int p = k * BR_THREADS + tid;
+          if (p < len) {
+            if (p > 0 && k_a[k] == s_key[p - 1]) dup = true;
+            col_out[e0 + p] = (I)k_a[k];
+            if (HASV) ((V *)val_out)[e0 + p] = v_a[k];
+          }
+        }
+        if (__any(dup) && lane == 0) st->any_dup = 1;
+      } else {
+        unsigned mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+          mn = s_mm[2 * i] < mn ? s_mm[2 * i] : mn;
+          mx = s_mm[2 * i + 1] > mx ? s_mm[2 * i + 1] : mx;
+        }
+        const int rbits = bits_u32(mx - mn);
+        const int ib = bits_u32((unsigned)len - 1);  // 2^ib buckets, len <= 2^ib <= CAP
+        const int shift = rbits > ib ? rbits - ib : 0;
+        const unsigned lowmask = shift >= 32 ? 0xFFFFFFFFu : (1u << shift) - 1u;  // shift + ib = max(rbits, ib) <= 32
+        unsigned bk[ITEMS], wd[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const int p = k * BR_THREADS + tid;
+          const unsigned rel = (unsigned)k_a[k] - mn;
+          bk[k] = shift >= 32 ? 0u : rel >> shift;
+          wd[k] = ((rel & lowmask) << ib) | (unsigned)p;
+        }
+        // level 0: buckets of equal width.  If one of them holds more than BK_REFINE entries (clustered columns, e.g. a
+        // banded order), level 1 splits every bucket into as many sub-buckets as it has entries, again by interpolation.
+        for (int level = 0;; level++) {
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++) s_c[k * BR_THREADS + tid] = 0;
+          if (tid < 4) s_c[CAP + tid] = (unsigned)len;  // end of the last bucket
+          lds_barrier<BR_THREADS>();
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++)
+            if (k * BR_THREADS + tid < len) atomicAdd(&s_c[bk[k]], 1u);
+          lds_barrier<BR_THREADS>();
+          {
+            // in-place inclusive scan of the counters (as scan_bucket_counts, with LDS-only barriers)
+            const int base = tid * ITEMS;
+            unsigned v[ITEMS];
+            unsigned sum = 0, mxc = 0;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i += 4) {
+              const uint4 q = *(const uint4 *)(s_c + base + i);
+              v[i] = q.x, v[i + 1] = q.y, v[i + 2] = q.z, v[i + 3] = q.w;
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+              mxc = v[i] > mxc ? v[i] : mxc;
+              sum += v[i];
+              v[i] = sum;
+            }
+            const unsigned inc = sbx_wave_inclusive_sum(sum);
+            if (lane == 63) s_scan[w] = inc;
+            if (level == 0 && __any(mxc > (unsigned)BK_REFINE) && lane == 0) s_flag[2] = 1;
+            if ((__any(mxc > (unsigned)BK_MAX) || (force_radix & 1)) && lane == 0) s_flag[1 + 2 * (1 - level)] = 1;
+            lds_barrier<BR_THREADS>();
+            unsigned ex = inc - sum;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++)
+              if (i < w) ex += s_scan[i];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i += 4)
+              *(uint4 *)(s_c + base + i) = make_uint4(v[i] + ex, v[i + 1] + ex, v[i + 2] + ex, v[i + 3] + ex);
+          }
+          lds_barrier<BR_THREADS>();
+          if (level == 1 || __builtin_amdgcn_readfirstlane(s_flag[2]) == 0) {
+            if (level == 0 && __builtin_amdgcn_readfirstlane(s_flag[3])) {  // not refined: an overfull level-0 bucket stands
+              if (tid == 0) s_flag[1] = 1;
+              lds_barrier<BR_THREADS>();
+            }
+            break;
+          }
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++) {
+            if (k * BR_THREADS + tid < len) {
+              const unsigned b = bk[k];
+              const unsigned start = b ? s_c[b - 1] : 0u, cntb = s_c[b] - start;
+              const unsigned low = ((unsigned)k_a[k] - mn) & lowmask;
+              const unsigned sub = shift ? (unsigned)(((unsigned long long)low * cntb) >> shift) : 0u;
+              bk[k] = start + sub;  // < start + cntb: sub-buckets of different buckets do not meet
+            }
+          }
+          lds_barrier<BR_THREADS>();  // the level-0 bounds have been read
+        }
+        if (__builtin_amdgcn_readfirstlane(s_flag[1]) != 0) {  // (rare) the row goes on the list of k_permute_rows_radix
+          if (tid == 0) fb_rows[atomicAdd(&st->n_fb_rows, 1u)] = (unsigned)rid_a;
+        } else {
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++)
+            if (k * BR_THREADS + tid < len) s_a[atomicSub(&s_c[bk[k]], 1u) - 1u] = (int)wd[k];
+          lds_barrier<BR_THREADS>();
+          int fin[ITEMS];
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++) {
+            fin[k] = 0;
+            if (k * BR_THREADS + tid < len) {
+              const unsigned b0 = s_c[bk[k]], b1 = s_c[bk[k] + 1];
+              unsigned rk = 0;
+              for (unsigned j = b0; j < b1; j++) rk += (unsigned)s_a[j] < wd[k];
+              fin[k] = (int)(b0 + rk);
+            }
+          }
+          lds_barrier<BR_THREADS>();  // placed words and bucket bounds are dead: the sorted entries move in
+#pragma unroll
+          for (int k = 0; k < ITEMS; k++)
+            if (k * BR_THREADS + tid < len) {
+              s_key[fin[k]] = k_a[k];
+              if (HASV) s_val[fin[k]] = v_a[k];
+            }
+          out_mode = 1;
+        }
       }
     }
-    mn = sbx_wave_min(mn);
-    mx = sbx_wave_max(mx);
-    if (lane == 0) {
-      s_mm[2 * w] = mn;
-      s_mm[2 * w + 1] = mx;
+
+    // rotate the pipeline (the first reads of this iteration's loads)
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      k_a[k] = k_b[k];
+      if (HASV) v_a[k] = v_b[k];
+      c_b[k] = c_c[k];
+      if (HASV) v_b[k] = v_c[k];
     }
-    if (__any(unsorted) && lane == 0) {
-      st->any_unsorted = 1;
-      s_flag[0] = 1;
+    e0_a = e0_b, len_a = len_b, rid_a = rid_b;
+    e0_b = e0_c, len_b = len_c, rid_b = rid_c;
+    e0_c = r0_d, len_c = valid_d ? r1_d - r0_d : -1, src_c = src_d, rid_c = rid_d;
+    rid_d = rid_e, valid_d = valid_e;
+
+    if (len >= 0) {
+      if (out_mode) {  // stream the sorted row out of LDS
+        lds_barrier<BR_THREADS>();
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const int p = k * BR_THREADS + tid;
+          if (p < len) {
+            const int c = s_key[p];
+            if (p > 0 && c == s_key[p - 1]) dup = true;
+            col_out[e0 + p] = (I)c;
+            if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+          }
+        }
+        if (__any(dup) && lane == 0) st->any_dup = 1;
+      }
+      lds_barrier<BR_THREADS>();  // the next row's columns overwrite s_key
     }
   }
-  __syncthreads();
-  if (s_flag[0] == 0) {  // an ordered row needs no sort
+}
+
+// the rows the kernel above listed (clustered columns): one workgroup per row, LSD radix sort over the column bits
+template <typename I, int VB>
+__global__ __launch_bounds__(1024) void k_permute_rows_radix(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const unsigned *__restrict__ fb_rows, I *col_out, char *val_out, int col_bits,
+    PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  constexpr bool HASV = VB != 0;
+  constexpr int THREADS = 1024, CAP = BlockRowCap<VB>::value, ITEMS = CAP / THREADS, WAVES = THREADS / 64;
+  __shared__ int s_key[CAP];
+  __shared__ V s_val[HASV ? CAP : 1];
+  __shared__ unsigned s_whist[WAVES * 256];
+  __shared__ unsigned s_scan[WAVES + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned n = st->n_fb_rows;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t r = fb_rows[i];
+    const int64_t e0 = rpo[r];
+    const int len = (int)((int64_t)rpo[r + 1] - e0);
+    const int64_t src0 = rec[r].y;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      int c = 0x7FFFFFFF;  // padding: sorts last, never written out
+      if (p < len) {
+        const I cc = col_in[src0 + p];
+        c = (int)(col_order ? col_order[cc] : cc);
+        if (HASV) s_val[p] = ((const V *)val_in)[src0 + p];
+      }
+      s_key[p] = c;
+    }
+    __syncthreads();
+    lds_radix_sort<V, HASV, false, THREADS, ITEMS>(s_key, nullptr, s_val, s_whist, s_scan, CAP, col_bits, 0);
     bool dup = false;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-      const int p = k * BR_THREADS + tid;
+      const int p = k * THREADS + tid;
       if (p < len) {
-        if (p > 0 && kc[k] == s_key[p - 1]) dup = true;
-        col_out[e0 + p] = (I)kc[k];
-        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        const int c = s_key[p];
+        if (p > 0 && c == s_key[p - 1]) dup = true;
+        col_out[e0 + p] = (I)c;
+        if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
       }
     }
     if (__any(dup) && lane == 0) st->any_dup = 1;
-    return;
-  }
-  unsigned mn = 0xFFFFFFFFu, mx = 0;
-#pragma unroll
-  for (int i = 0; i < WAVES; i++) {
-    mn = s_mm[2 * i] < mn ? s_mm[2 * i] : mn;
-    mx = s_mm[2 * i + 1] > mx ? s_mm[2 * i + 1] : mx;
-  }
-  const int rbits = bits_u32(mx - mn);
-  const int ib = bits_u32((unsigned)len - 1);  // 2^ib buckets, len <= 2^ib <= CAP
-  const int shift = rbits > ib ? rbits - ib : 0;
-  const unsigned lowmask = shift >= 32 ? 0xFFFFFFFFu : (1u << shift) - 1u;  // shift + ib = max(rbits, ib) <= 32
-  unsigned bk[ITEMS], wd[ITEMS];
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    const int p = k * BR_THREADS + tid;
-    const unsigned rel = (unsigned)kc[k] - mn;
-    bk[k] = shift >= 32 ? 0u : rel >> shift;
-    wd[k] = ((rel & lowmask) << ib) | (unsigned)p;
-    s_c[p] = 0;
-  }
-  if (tid < 4) s_c[CAP + tid] = (unsigned)len;  // end of the last bucket
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++)
-    if (k * BR_THREADS + tid < len) atomicAdd(&s_c[bk[k]], 1u);
-  __syncthreads();
-  {
-    const unsigned mxc = scan_bucket_counts<BR_THREADS, ITEMS>(s_c, CAP, s_scan);
-    if ((__any(mxc > (unsigned)BK_MAX) || force_radix) && lane == 0) s_flag[1] = 1;
-  }
-  __syncthreads();
-  if (s_flag[1] == 0) {
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++)
-      if (k * BR_THREADS + tid < len) s_a[atomicSub(&s_c[bk[k]], 1u) - 1u] = (int)wd[k];
     __syncthreads();
-    int fin[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      fin[k] = 0;
-      if (k * BR_THREADS + tid < len) {
-        const unsigned b0 = s_c[bk[k]], b1 = s_c[bk[k] + 1];
-        unsigned rk = 0;
-        for (unsigned j = b0; j < b1; j++) rk += (unsigned)s_a[j] < wd[k];
-        fin[k] = (int)(b0 + rk);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++)
-      if (k * BR_THREADS + tid < len) {
-        s_key[fin[k]] = kc[k];
-        if (HASV) s_val[fin[k]] = kv[k];
-      }
-    __syncthreads();
-  } else {
-    if (HASV) {
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) s_val[k * BR_THREADS + tid] = kv[k];
-    }
-    __syncthreads();
-    lds_radix_sort<V, HASV, false, BR_THREADS, ITEMS>(s_key, nullptr, s_val, s_c, s_scan, CAP, col_bits, 0);
   }
-  bool dup = false;
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    const int p = k * BR_THREADS + tid;
-    if (p < len) {
-      const int c = s_key[p];
-      if (p > 0 && c == s_key[p - 1]) dup = true;
-      col_out[e0 + p] = (I)c;
-      if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
-    }
-  }
-  if (__any(dup) && lane == 0) st->any_dup = 1;
 }
 
 // ---- long rows ----------------------------------------------------------------
@@ -1168,19 +1398,30 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
                     const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st) {
   typedef int32_t I;
   const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
-  const int force = permute_force_radix();
+  const int force = permute_force_radix() & 0xFF;
+  size_t n_all = 0;
+  for (int c = 0; c < BR_CLASSES; c++) n_all += n_block[c];
+  unsigned *fb_rows = nullptr;  // rows whose columns cluster (listed by the class kernels, sorted by the radix kernel)
+  SBX_TRY(sbx_salloc(h, n_all + 1, &fb_rows));
+  // persistent grids: enough workgroups to fill the CUs' LDS a few times over, each walking its rows as a pipeline
 #define BLOCK_ROWS(CLS, THREADS)                                                                                  \
-  if (n_block[CLS])                                                                                               \
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(n_block[CLS]),  \
-                dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, col_out,     \
-                val_out, col_bits, st, force & 0xFF)
+  if (n_block[CLS]) {                                                                                             \
+    const unsigned per_cu = (unsigned)(160 * 1024 / (br_cap(CLS) * 12 + 256));                                    \
+    unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu);                         \
+    if (grid > n_block[CLS]) grid = n_block[CLS];                                                                 \
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(grid),          \
+                dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride,              \
+                (int)n_block[CLS], col_out, val_out, st, force, fb_rows);                                         \
+  }
   BLOCK_ROWS(0, 64);
-  BLOCK_ROWS(1, 64);
-  BLOCK_ROWS(2, 128);
-  BLOCK_ROWS(3, 256);
-  BLOCK_ROWS(4, 512);
+  BLOCK_ROWS(1, 128);
+  BLOCK_ROWS(2, 256);
+  BLOCK_ROWS(3, 512);
+  BLOCK_ROWS(4, 1024);
   if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
 #undef BLOCK_ROWS
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_rows_radix<I, VB>), dim3((unsigned)(n_all < 512 ? n_all : 512)),
+              dim3(1024), rec, col_in, val_in, col_order, rpo, (const unsigned *)fb_rows, col_out, val_out, col_bits, st);
   SBX_LAUNCH_CHECK(h);
   SBX_PROF_BYTES(h, SBX_K_PERMUTE_BLOCK, block_nnz * (int64_t)(2 * (sizeof(I) + VB)));
   return SBX_OK;
@@ -1254,9 +1495,15 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
     SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_first));
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), rpo, nr, tiles,
                 tile_first);
+    unsigned *fb_tiles = nullptr;  // tiles whose rows cluster (listed by the tile kernel, sorted by its radix twin)
+    SBX_TRY(sbx_salloc(h, (size_t)tiles, &fb_tiles));
+    const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)tiles), dim3(PT_THREADS), rec, col_in,
-                val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st,
-                sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), permute_force_radix());
+                val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st, col_bits,
+                permute_force_radix(), fb_tiles);
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile_radix<I, VB>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)),
+                dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st,
+                col_bits, (const unsigned *)fb_tiles);
     SBX_LAUNCH_CHECK(h);
     SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, (total - long_nnz - block_nnz) * (int64_t)(2 * (sizeof(I) + VB)));
     if ((permute_force_radix() >> 8) == 9) {  // diagnostic: print and clear the phase stamps
