@@ -113,14 +113,16 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
 extern "C" int sbx_destroy(sbx_handle_t h) {
   if (!h) return SBX_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);  // may be a caller-owned stream that is already gone: the error is ignored
+  if (h->aux_ready)  // side-stream work of a call that failed between fork and join may still use the scratch
+    for (int i = 0; i < SBX_AUX_STREAMS; i++) (void)hipStreamSynchronize(h->aux_stream[i]);
   for (auto &b : h->blocks) (void)hipFree(b.ptr);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->rs_pool) (void)hipFree(h->rs_pool);
   if (h->pow5) (void)hipFree(h->pow5);
   if (h->aux_ready) {
-    for (int i = 0; i < 2; i++) (void)hipStreamDestroy(h->aux_stream[i]);
-    for (int i = 0; i < 3; i++) (void)hipEventDestroy(h->aux_event[i]);
+    for (int i = 0; i < SBX_AUX_STREAMS; i++) (void)hipStreamDestroy(h->aux_stream[i]);
+    for (int i = 0; i < SBX_AUX_STREAMS + 1; i++) (void)hipEventDestroy(h->aux_event[i]);
   }
   for (auto &r : h->prof_pending) {
     (void)hipEventDestroy(r.start);
@@ -133,8 +135,8 @@ extern "C" int sbx_destroy(sbx_handle_t h) {
 
 int sbx_aux_streams(sbx_handle_t h) {
   if (h->aux_ready) return SBX_OK;
-  for (int i = 0; i < 2; i++) SBX_HIP(h, hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
-  for (int i = 0; i < 3; i++) SBX_HIP(h, hipEventCreateWithFlags(&h->aux_event[i], hipEventDisableTiming));
+  for (int i = 0; i < SBX_AUX_STREAMS; i++) SBX_HIP(h, hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+  for (int i = 0; i < SBX_AUX_STREAMS + 1; i++) SBX_HIP(h, hipEventCreateWithFlags(&h->aux_event[i], hipEventDisableTiming));
   h->aux_ready = true;
   return SBX_OK;
 }
@@ -196,7 +198,7 @@ int sbx_arena_begin(sbx_handle_t h) {
   SBX_HIP(h, hipSetDevice(h->device));
   if (h->nest > 0) return SBX_OK;  // nested entry point: keep the caller's scratch alive
   if (h->aux_dirty) {  // a call gave up between fork and join: its side work still owns scratch
-    for (int i = 0; i < 2; i++) SBX_HIP(h, hipStreamSynchronize(h->aux_stream[i]));
+    for (int i = 0; i < SBX_AUX_STREAMS; i++) SBX_HIP(h, hipStreamSynchronize(h->aux_stream[i]));
     h->aux_dirty = false;
     h->rs_override = nullptr;
   }

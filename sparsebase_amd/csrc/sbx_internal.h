@@ -52,6 +52,8 @@ struct sbx_block {
   size_t cap;
 };
 
+#define SBX_AUX_STREAMS 7  /* permute: [0] row classes (serial mode) / class 0, [1] long rows, [2..6] classes 1..5 */
+
 struct sbx_handle_s {
   int device;
   hipStream_t stream;
@@ -75,9 +77,9 @@ struct sbx_handle_s {
   bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
   int num_cus;
   // side streams for independent stages of one call (permute: tile / block-row / long-row paths), created on
-  // first use; aux_event[0] marks the fork point on `stream`, [1], [2] the ends of the side streams
-  hipStream_t aux_stream[2];
-  hipEvent_t aux_event[3];
+  // first use; aux_event[0] marks the fork point on `stream`, [1 + i] the end of side stream i
+  hipStream_t aux_stream[SBX_AUX_STREAMS];
+  hipEvent_t aux_event[SBX_AUX_STREAMS + 1];
   bool aux_ready;
   bool aux_dirty;     // a side stream may still be running work of a call that returned early (error path)
   void *rs_override;  // next radix sort takes this zeroed slot instead of one from the pool (sorts on a side stream

@@ -96,7 +96,7 @@ template <typename I>
 __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ rec, I *__restrict__ rpo, int64_t nr,
                                                       I *__restrict__ long_rows, I *__restrict__ block_rows,
                                                       int64_t block_stride, int block_cap,
-                                                      PermState *__restrict__ st) {
+                                                      PermState *__restrict__ st, I *__restrict__ sp) {
   constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
   __shared__ unsigned s_cnt[NC], s_base[NC];
   __shared__ unsigned long long s_long_nnz, s_block_nnz;
@@ -132,9 +132,11 @@ __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ r
   for (int64_t base = (int64_t)blockIdx.x * 256; base <= nr; base += stride) {  // uniform trip count per workgroup
     const int64_t i = base + tid;
     if (i == nr && rpo) rpo[i] = 0;
+    if (i == nr) sp[i] = 0;
     if (i < nr) {
       const I d = (I)rec[i].x;
       if (rpo) rpo[i] = d;
+      sp[i] = d <= PT_LMAX ? d : (I)0;  // lengths of the rows the tile kernel sorts: their prefix sums lay out its tiles
       int cls = -1;
       if (d > block_cap) cls = BR_CLASSES;
       else if (d > PT_LMAX) {
@@ -458,9 +460,9 @@ __device__ unsigned long long g_tile_stamps[32];
 template <typename I, int VB, bool RADIX>
 __device__ __forceinline__ void permute_tile_body(
     const int64_t tile, const int2 *__restrict__ rec, const I *col_in, const char *val_in,
-    const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out,
-    char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix,
-    unsigned *__restrict__ fb_tiles) {
+    const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ sp,
+    const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits,
+    int force_radix, unsigned *__restrict__ fb_tiles) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int THREADS = PT_THREADS, ITEMS = PT_ITEMS, CAP = PT_CAP, WAVES = THREADS / 64;
@@ -469,25 +471,28 @@ __device__ __forceinline__ void permute_tile_body(
   __shared__ unsigned s_whist[RADIX ? WAVES * 256 : 1];
   __shared__ unsigned s_scan[WAVES + 1];
   __shared__ int s_wmax[WAVES];
+  __shared__ int s_ob[CAP];  // at a row's first position: where the row starts in the output
   __shared__ int s_flag[4];  // [0] some row of the tile is out of order, [1] radix path, [2] refine, [3] overfull level-0 bucket
   int *const s_a = (int *)s_pool;  // r0 under its successive names
   int *const s_key = (int *)s_pool;
   unsigned *const s_hl = s_pool + CAP;
   unsigned *const s_c = s_pool + 2 * CAP;
   V *const s_val = (V *)(s_pool + 2 * CAP);
+  // output index of entry k (position p): the row's start in the output + the entry's position inside the row
+#define OUTPOS(k, p) ((int64_t)s_ob[hl[k] & 0xFFFFu] + ((p) - (int)(hl[k] & 0xFFFFu)))
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dbg_stop = force_radix >> 8;  // timing ablation only (SBX_DEBUG_TILE_STOP): leave after a phase, output junk
   force_radix &= 0xFF;
   unsigned long long t_start = 0;
   if (dbg_stop == 9) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
 
+  // the tile's rows: those of at most PT_LMAX entries whose range in the SHORT-row entry space (prefix sums `sp`
+  // over the lengths of such rows only) starts in the window; longer rows between them belong to other kernels
   const int64_t ra = tile_first[tile];
-  int64_t rb = tile_first[tile + 1];
+  const int64_t rb = tile_first[tile + 1];
   if (ra >= rb) return;
-  const int64_t e0 = rpo[ra];
-  if ((int64_t)rpo[rb] - (int64_t)rpo[rb - 1] > PT_LMAX) rb--;  // a long last row would not fit (it has its own kernel)
-  if (ra >= rb) return;
-  const int cnt = (int)((int64_t)rpo[rb] - e0);
+  const int64_t e0 = sp[ra];
+  const int cnt = (int)((int64_t)sp[rb] - e0);
   if (cnt == 0) return;
   TILE_STAMP(0);
   if (dbg_stop == 9 && tid == 0) {
@@ -506,9 +511,10 @@ __device__ __forceinline__ void permute_tile_body(
   if (rb - ra <= 4 * CAP) {
     for (int64_t r = ra + tid; r < rb; r += THREADS) {
       const int2 rc = rec[r];
-      if (rc.x > 0) {
-        const int p = (int)((int64_t)rpo[r] - e0);
+      if (rc.x > 0 && rc.x <= PT_LMAX) {
+        const int p = (int)((int64_t)sp[r] - e0);
         s_a[p] = 1;
+        s_ob[p] = (int)rpo[r];
         *(uint2 *)&s_c[2 * p] = make_uint2((unsigned)rc.y, (unsigned)rc.x);
       }
     }
@@ -518,12 +524,13 @@ __device__ __forceinline__ void permute_tile_body(
       int64_t lo = ra, hi = rb;
       while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)rpo[mid] <= target) lo = mid;
+        if ((int64_t)sp[mid] <= target) lo = mid;
         else hi = mid;
       }
-      if ((int64_t)rpo[lo] == target) {
+      if ((int64_t)sp[lo] == target) {  // (rows that add nothing to sp share the value of the short row behind them)
         const int2 rc = rec[lo];
         s_a[p] = 1;
+        s_ob[p] = (int)rpo[lo];
         *(uint2 *)&s_c[2 * p] = make_uint2((unsigned)rc.y, (unsigned)rc.x);
       }
     }
@@ -571,7 +578,7 @@ __device__ __forceinline__ void permute_tile_body(
   __syncthreads();
   TILE_STAMP(3);
   if (dbg_stop == 1) {
-    for (int p = tid; p < cnt; p += THREADS) col_out[e0 + p] = (I)(s_a[p] + (int)s_hl[p]);
+    for (int p = tid; p < cnt; p += THREADS) col_out[(int64_t)s_ob[s_hl[p] & 0xFFFFu] + (p - (int)(s_hl[p] & 0xFFFFu))] = (I)(s_a[p] + (int)s_hl[p]);
     return;
   }
 
@@ -579,7 +586,7 @@ __device__ __forceinline__ void permute_tile_body(
   int kc[ITEMS];
   V kv[HASV ? ITEMS : 1];
   unsigned hl[ITEMS];
-  unsigned live = 0, hole = 0;  // bit k: entry k is sorted here / belongs to a row too long for the tile
+  unsigned live = 0;  // bit k: the tile holds an entry at position k * THREADS + tid
   {
     I c[ITEMS];
 #pragma unroll
@@ -590,14 +597,10 @@ __device__ __forceinline__ void permute_tile_body(
       if (HASV) kv[k] = (V)0;
       if (p < cnt) {
         hl[k] = s_hl[p];
-        if ((hl[k] >> 16) <= (unsigned)PT_LMAX) {
-          live |= 1u << k;
-          const int64_t s = (int64_t)s_a[p] + p;
-          c[k] = __builtin_nontemporal_load(col_in + s);
-          if (HASV) kv[k] = __builtin_nontemporal_load((const V *)val_in + s);
-        } else {
-          hole |= 1u << k;
-        }
+        live |= 1u << k;
+        const int64_t s = (int64_t)s_a[p] + p;
+        c[k] = __builtin_nontemporal_load(col_in + s);
+        if (HASV) kv[k] = __builtin_nontemporal_load((const V *)val_in + s);
       }
     }
     if (dbg_stop == 9) {
@@ -624,8 +627,8 @@ __device__ __forceinline__ void permute_tile_body(
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
       if (live >> k & 1) {
-        col_out[e0 + p] = (I)kc[k];
-        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        col_out[OUTPOS(k, p)] = (I)kc[k];
+        if (HASV) ((V *)val_out)[OUTPOS(k, p)] = kv[k];
       }
     }
     return;
@@ -658,8 +661,8 @@ __device__ __forceinline__ void permute_tile_body(
       const int p = k * THREADS + tid;
       if (live >> k & 1) {
         if (p > (int)(hl[k] & 0xFFFFu) && kc[k] == s_key[p - 1]) dup = true;
-        col_out[e0 + p] = (I)kc[k];
-        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        col_out[OUTPOS(k, p)] = (I)kc[k];
+        if (HASV) ((V *)val_out)[OUTPOS(k, p)] = kv[k];
       }
     }
     if (__any(dup) && lane == 0) st->any_dup = 1;
@@ -681,9 +684,8 @@ __device__ __forceinline__ void permute_tile_body(
     }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-      const bool use = p0 + k < cnt && (hpv[k] >> 16) <= (unsigned)PT_LMAX;  // holes hold no columns
       hpv[k] &= 0xFFFFu;
-      if (use) {
+      if (p0 + k < cnt) {
         if (hpv[k] != cur) {
           if (cur != 0xFFFFFFFFu) {
             atomicMin(&s_c[2 * cur], mn);
@@ -711,7 +713,7 @@ __device__ __forceinline__ void permute_tile_body(
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
-      bk[k] = 2 * (unsigned)p;  // holes are counted at their own position: the prefix sums stay aligned with the tile
+      bk[k] = 0;
       wd[k] = 0;
       sh[k] = 0;
       if (live >> k & 1) {
@@ -740,8 +742,8 @@ __device__ __forceinline__ void permute_tile_body(
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
       if (live >> k & 1) {
-        col_out[e0 + p] = (I)(bk[k] + wd[k]);
-        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        col_out[OUTPOS(k, p)] = (I)(bk[k] + wd[k]);
+        if (HASV) ((V *)val_out)[OUTPOS(k, p)] = kv[k];
       }
     }
     return;
@@ -751,7 +753,7 @@ __device__ __forceinline__ void permute_tile_body(
   TILE_STAMP(9);
 #pragma unroll
   for (int k = 0; k < ITEMS; k++)
-    if ((live | hole) >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
+    if (live >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
   __syncthreads();
   TILE_STAMP(10);
   {
@@ -780,7 +782,7 @@ __device__ __forceinline__ void permute_tile_body(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
-      if ((live | hole) >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
+      if (live >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
     __syncthreads();
     const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
     if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[1] = 1;
@@ -795,8 +797,8 @@ __device__ __forceinline__ void permute_tile_body(
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
       if (live >> k & 1) {
-        col_out[e0 + p] = (I)(s_c[bk[k]] + wd[k]);
-        if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+        col_out[OUTPOS(k, p)] = (I)(s_c[bk[k]] + wd[k]);
+        if (HASV) ((V *)val_out)[OUTPOS(k, p)] = kv[k];
       }
     }
     return;
@@ -824,8 +826,8 @@ __device__ __forceinline__ void permute_tile_body(
       for (int k = 0; k < ITEMS; k++) {
         const int p = k * THREADS + tid;
         if (live >> k & 1) {
-          col_out[e0 + p] = (I)(fin[k] + kc[k]);
-          if (HASV) ((V *)val_out)[e0 + p] = kv[k];
+          col_out[OUTPOS(k, p)] = (I)(fin[k] + kc[k]);
+          if (HASV) ((V *)val_out)[OUTPOS(k, p)] = kv[k];
         }
       }
       return;
@@ -863,7 +865,7 @@ __device__ __forceinline__ void permute_tile_body(
       const int p = tid * ITEMS + k;
       if (p < cnt) s_rank[p] = ex + flag[k] - 1;
     }
-    if (HASV) {  // (holes sort among themselves inside their own row rank: harmless, they are never written out)
+    if (HASV) {
 #pragma unroll
       for (int k = 0; k < ITEMS; k++)
         if (k * THREADS + tid < cnt) s_val[k * THREADS + tid] = kv[k];
@@ -881,8 +883,8 @@ __device__ __forceinline__ void permute_tile_body(
       if (live >> k & 1) {
         const int c = s_key[p];
         if (p > (int)(hl[k] & 0xFFFFu) && c == s_key[p - 1]) dup = true;  // rows keep their position ranges
-        col_out[e0 + p] = (I)c;
-        if (HASV) ((V *)val_out)[e0 + p] = s_val[p];
+        col_out[OUTPOS(k, p)] = (I)c;
+        if (HASV) ((V *)val_out)[OUTPOS(k, p)] = s_val[p];
       }
     }
     if (__any(dup) && lane == 0) st->any_dup = 1;
@@ -892,25 +894,26 @@ __device__ __forceinline__ void permute_tile_body(
     TILE_STAMP(15);
   }
 }
+#undef OUTPOS
 
 template <typename I, int VB>
 __global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
-    PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles) {
-  permute_tile_body<I, VB, false>((int64_t)blockIdx.x, rec, col_in, val_in, col_order, rpo, tile_first, col_out, val_out,
-                                  nr, st, col_bits, force_radix, fb_tiles);
+    const I *__restrict__ rpo, const I *__restrict__ sp, const I *__restrict__ tile_first, I *col_out, char *val_out,
+    int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles) {
+  permute_tile_body<I, VB, false>((int64_t)blockIdx.x, rec, col_in, val_in, col_order, rpo, sp, tile_first, col_out,
+                                  val_out, nr, st, col_bits, force_radix, fb_tiles);
 }
 
 // the tiles the kernel above listed (clustered columns): same body, LSD radix sort instead of the bucket-rank pass
 template <typename I, int VB>
 __global__ __launch_bounds__(PT_THREADS) void k_permute_tile_radix(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
-    const I *__restrict__ rpo, const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr,
-    PermState *__restrict__ st, int col_bits, const unsigned *__restrict__ fb_tiles) {
+    const I *__restrict__ rpo, const I *__restrict__ sp, const I *__restrict__ tile_first, I *col_out, char *val_out,
+    int64_t nr, PermState *__restrict__ st, int col_bits, const unsigned *__restrict__ fb_tiles) {
   const unsigned n = st->n_fb_tiles;
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-    permute_tile_body<I, VB, true>((int64_t)fb_tiles[i], rec, col_in, val_in, col_order, rpo, tile_first, col_out,
+    permute_tile_body<I, VB, true>((int64_t)fb_tiles[i], rec, col_in, val_in, col_order, rpo, sp, tile_first, col_out,
                                    val_out, nr, st, col_bits, 0, nullptr);
     __syncthreads();  // the next tile reuses the LDS pool
   }
@@ -1013,7 +1016,7 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
     }
     // B: relabel gathers of row it - 3 (permute_order_two.cc:68)
     int k_b[ITEMS];
-    if (col_order) {
+    if (col_order && !(force_radix & 4)) {  // (bit 2: timing ablation without the relabel gathers)
 #pragma unroll
       for (int k = 0; k < ITEMS; k++) k_b[k] = (int)col_order[k * BR_THREADS + tid < len_b ? c_b[k] : 0];
     } else {
@@ -1385,6 +1388,11 @@ static bool permute_overlap() {
   return on;
 }
 
+static int permute_grid_factor() {  // SBX_PERMUTE_GRID_FACTOR: workgroups launched per resident slot (tuning)
+  static const int f = getenv("SBX_PERMUTE_GRID_FACTOR") ? atoi(getenv("SBX_PERMUTE_GRID_FACTOR")) : 1;
+  return f < 1 ? 1 : f;
+}
+
 static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / row takes the radix path (tests)
   static const int on = (getenv("SBX_PERMUTE_FORCE_RADIX") ? atoi(getenv("SBX_PERMUTE_FORCE_RADIX")) & 0xFF : 0) |
                         (getenv("SBX_DEBUG_TILE_STOP") ? atoi(getenv("SBX_DEBUG_TILE_STOP")) << 8 : 0);
@@ -1395,8 +1403,11 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
 template <int VB>
 int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
                     const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *block_rows,
-                    const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st) {
+                    const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st, bool fork) {
   typedef int32_t I;
+  // fork: h->stream is side stream 0, which already waits for the fork event; the classes spread over side streams
+  // 0, 2, 3, ... (1 belongs to the long rows) and the radix kernel behind them joins them again on stream 0
+  hipStream_t base = h->stream;
   const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
   const int force = permute_force_radix() & 0xFF;
   size_t n_all = 0;
@@ -1406,12 +1417,25 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
   // persistent grids: enough workgroups to fill the CUs' LDS a few times over, each walking its rows as a pipeline
 #define BLOCK_ROWS(CLS, THREADS)                                                                                  \
   if (n_block[CLS]) {                                                                                             \
-    const unsigned per_cu = (unsigned)(160 * 1024 / (br_cap(CLS) * 12 + 256));                                    \
-    unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu);                         \
+    /* resident workgroups per CU: LDS (12 B per slot) and ~24 waves (the kernels need 64..100 VGPRs) */          \
+    const unsigned by_lds = (unsigned)(160 * 1024 / (br_cap(CLS) * 12 + 256)), by_waves = 24u / ((THREADS) / 64); \
+    const unsigned per_cu = by_lds < by_waves ? by_lds : by_waves;                                                \
+    unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu) * (unsigned)permute_grid_factor();           \
     if (grid > n_block[CLS]) grid = n_block[CLS];                                                                 \
+    const int si = (CLS) == 0 ? 0 : (CLS) + 1;                                                                    \
+    if (fork && si) {                                                                                             \
+      h->stream = h->aux_stream[si];                                                                              \
+      SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[0], 0));                                              \
+    }                                                                                                             \
     SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(grid),          \
                 dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride,              \
                 (int)n_block[CLS], col_out, val_out, st, force, fb_rows);                                         \
+    if (fork && si) {                                                                                             \
+      const hipError_t e1_ = hipEventRecord(h->aux_event[1 + si], h->stream);                                     \
+      const hipError_t e2_ = hipStreamWaitEvent(base, h->aux_event[1 + si], 0);                                   \
+      h->stream = base;                                                                                           \
+      if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
+    }                                                                                                             \
   }
   BLOCK_ROWS(0, 64);
   BLOCK_ROWS(1, 128);
@@ -1469,7 +1493,7 @@ template <int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t *col_in, const char *val_in,
                const int32_t *col_order, const int32_t *rpo, int32_t *col_out, char *val_out, int64_t nr, int64_t m,
                int64_t total, const int32_t *long_rows, const int32_t *block_rows, int64_t block_stride,
-               const PermState &hs, PermState *st) {
+               const PermState &hs, PermState *st, const int32_t *sp) {
   typedef int32_t I;
   const unsigned n_long = hs.n_long;
   const unsigned *n_block = hs.n_block;
@@ -1481,6 +1505,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   bool has_block = false;
   for (int c = 0; c < BR_CLASSES; c++) has_block |= n_block[c] != 0;
   const bool fork = !h->prof_on && permute_overlap() && total > 0 && (has_block || n_long);
+  (void)total;
   hipStream_t main_stream = h->stream;
   if (fork) {
     SBX_TRY(sbx_aux_streams(h));
@@ -1489,23 +1514,24 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
     if (has_block) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[0], h->aux_event[0], 0));
     if (n_long) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[0], 0));
   }
-  if (total > 0) {
-    const int64_t tiles = (total + PT_W - 1) / PT_W;
+  const int64_t short_nnz = total - long_nnz - block_nnz;  // entries of the rows the tile kernel sorts
+  if (short_nnz > 0) {
+    const int64_t tiles = (short_nnz + PT_W - 1) / PT_W;
     I *tile_first = nullptr;
     SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_first));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), rpo, nr, tiles,
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), sp, nr, tiles,
                 tile_first);
     unsigned *fb_tiles = nullptr;  // tiles whose rows cluster (listed by the tile kernel, sorted by its radix twin)
     SBX_TRY(sbx_salloc(h, (size_t)tiles, &fb_tiles));
     const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)tiles), dim3(PT_THREADS), rec, col_in,
-                val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st, col_bits,
+                val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr, st, col_bits,
                 permute_force_radix(), fb_tiles);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile_radix<I, VB>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)),
-                dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, (const I *)tile_first, col_out, val_out, nr, st,
-                col_bits, (const unsigned *)fb_tiles);
+                dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
+                st, col_bits, (const unsigned *)fb_tiles);
     SBX_LAUNCH_CHECK(h);
-    SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, (total - long_nnz - block_nnz) * (int64_t)(2 * (sizeof(I) + VB)));
+    SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, short_nnz * (int64_t)(2 * (sizeof(I) + VB)));
     if ((permute_force_radix() >> 8) == 9) {  // diagnostic: print and clear the phase stamps
       unsigned long long hs_[32];
       SBX_HIP(h, hipStreamSynchronize(h->stream));
@@ -1523,7 +1549,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   if (has_block) {
     if (fork) h->stream = h->aux_stream[0];
     const int rc = block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
-                                       block_stride, block_nnz, st);
+                                       block_stride, block_nnz, st, fork);
     if (fork) {
       if (rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
       h->stream = main_stream;
@@ -1623,7 +1649,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)row_order, n, row_begin, nr, rec);
-  I *long_rows = nullptr, *block_rows = nullptr;
+  I *long_rows = nullptr, *block_rows = nullptr, *sp = nullptr;
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   int64_t block_stride = 0;
   if (col_order) {  // the sorting pipeline needs the rows that do not fit a tile listed by class
@@ -1631,9 +1657,11 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
     block_stride = cap_long;
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
-                (const int2 *)rec, rpo, nr, long_rows, block_rows, block_stride, block_cap, st);
+                (const int2 *)rec, rpo, nr, long_rows, block_rows, block_stride, block_cap, st, sp);
+    SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, nr + 1, nullptr));
   } else {
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_lengths<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
                 (const int2 *)rec, nr, rpo);
@@ -1680,15 +1708,18 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
     SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+    SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
-                (const int2 *)rec, (I *)nullptr, nr, long_rows, block_rows, block_stride, block_cap, st);
+                (const int2 *)rec, (I *)nullptr, nr, long_rows, block_rows, block_stride, block_cap, st, sp);
     SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, nr + 1, nullptr));
     SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
+    hs.total = (unsigned long long)total;
   }
   int rc;
 #define STAGE(VBX)                                                                                                  \
   rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
-                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st)
+                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st, sp)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
@@ -1733,15 +1764,18 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)nullptr, n, (int64_t)0, n, rec);
+  I *sp = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)n + 1, &sp));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(n + 1, 256, 2048)), dim3(256),
-              (const int2 *)rec, (I *)nullptr, n, long_rows, block_rows, n, block_cap, st);
+              (const int2 *)rec, (I *)nullptr, n, long_rows, block_rows, n, block_cap, st, sp);
   SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, n + 1, nullptr));
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   int rc;
 #define STAGE(VBX)                                                                                               \
   rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)nullptr,          \
-                       (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, block_rows, (int64_t)n, hs, st)
+                       (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, block_rows, (int64_t)n, hs, st, sp)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
