@@ -51,9 +51,8 @@ def parse():
 
 def kernel_alg_bytes(name, n, nnz, stats, launches):
     """ALGORITHMIC bytes moved by all launches of one kernel group during one step
-    (DESIGN.md "Algorithmic bytes").  I = Z = V = 4 bytes."""
-    if name == "permute_tile":
-        return 16 * nnz + 12 * n + 8          # SURVEY §8d Permute2D figure
+    (DESIGN.md "Algorithmic bytes").  I = Z = V = 4 bytes.  The permute kernels declare the bytes of the
+    nonzeros they themselves process at their launch sites (sbx_profile_query_bytes): None here."""
     if name in ("bfs_expand", "bfs_heavy"):
         # top-down: every scanned adjacency entry once (4 B) and, per frontier vertex,
         # row_ptr (8 B) + parent-position word read+write (8 B)
@@ -62,8 +61,6 @@ def kernel_alg_bytes(name, n, nnz, stats, launches):
     if name == "bfs_bottom_up":
         # bottom-up: scanned adjacency entries (4 B each) + the visited bitmap (n/8 B) per launch
         return 4 * stats["edges_scanned_bottom_up"] + int(launches * n / 8)
-    if name == "permute_block":
-        return None
     return None
 
 
@@ -163,9 +160,12 @@ def main():
             "alg_bytes_per_step": alg,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
         }
+        # whole operations (SURVEY §8d figures), timed un-instrumented below
+        roofline["op"] = op_fractions(ops, n, nnz, rp, col, val, order, out, stats, args.steps)
 
     # ---- the step that shards: row-range permutation apply + RCCL all-gather of row_ptr
     permute_apply = None
+    comm = None
     if not args.no_sharded:
         from sparsebase_amd import sharded
         perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).to(torch.int32)
@@ -182,10 +182,16 @@ def main():
             rp_s, col_s, val_s = rp, col, val
         n_s, nnz_s = rp_s.numel() - 1, col_s.numel()
         ranges = sharded.row_ranges(n_s, world)
+        comm = sharded.make_comm(local_rank) if world > 1 else None   # RCCL behind the C ABI (nccl backend)
+        out_s = None
+        if world > 1:  # the rank's slab, sized by the shard's entries and allocated once, outside the timed loop
+            cap = ops.permute_csr_rows_nnz(n_s, rp_s, perm, *ranges[rank])
+            out_s = (torch.empty(n_s + 1, dtype=rp_s.dtype, device=dev), torch.empty(cap, dtype=col_s.dtype, device=dev),
+                     torch.empty(cap, dtype=val_s.dtype, device=dev))
 
         def sharded_step():
             if world > 1:
-                return sharded.permute_csr_sharded(n_s, n_s, rp_s, col_s, val_s, perm, perm, ranges=ranges)
+                return ops.permute_csr_sharded(comm, n_s, n_s, rp_s, col_s, val_s, perm, perm, ranges=ranges, out=out_s)
             return ops.permute_csr(n_s, n_s, rp_s, col_s, val_s, perm, perm, out=out)
 
         sharded_step()
@@ -231,10 +237,18 @@ def main():
         n_c, nnz_c = rp_c.numel() - 1, col_c.numel()
         val_c = torch.ones(nnz_c, device=dev, dtype=torch.float32)
         row_c = ops.csr_to_coo(n_c, n_c, rp_c, col_c, None, move=True)[0]   # replicated row-sorted COO
+        out_c = None
+        if world > 1:
+            if comm is None:
+                comm = sharded.make_comm(local_rank)
+            lo_c, hi_c = sharded.row_ranges(n_c, world)[rank]
+            cap = int(rp_c[hi_c] - rp_c[lo_c])
+            out_c = (torch.empty(n_c + 1, dtype=rp_c.dtype, device=dev), torch.empty(cap, dtype=col_c.dtype, device=dev),
+                     torch.empty(cap, dtype=val_c.dtype, device=dev))
 
         def convert_step():
             if world > 1:
-                return sharded.coo_to_csr_sharded(n_c, n_c, row_c, col_c, val_c)
+                return ops.coo_to_csr_sharded(comm, n_c, n_c, row_c, col_c, val_c, out=out_c)
             return ops.coo_to_csr(n_c, n_c, row_c, col_c, val_c, rows_sorted=True)
 
         convert_step()
@@ -255,11 +269,15 @@ def main():
             "scaling": "strong", "value": n_c * args.steps / wc / 1e6, "unit": "Mrows/s", "ms_per_step": wc / args.steps * 1e3,
             "alg_gbs": alg_c * args.steps / wc / 1e9, "frac_of_hbm_peak": alg_c * args.steps / wc / 1e9 / (HBM_PEAK_GBS * world)}
         del row_c, val_c
+    if comm is not None:
+        comm.close()
 
     # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args, synth, rp, col)
+        step()
+        torch.cuda.synchronize()
+        cpu_baseline = run_cpu_baseline(args, synth, rp, col, gpu_result=(order, out, val))
 
     if rank == 0:
         line = {
@@ -274,12 +292,42 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "permute_apply": permute_apply,
             "convert_apply": convert_apply,
         }
+        if cpu_baseline and "parity_on_bench_matrix" in cpu_baseline:
+            line["parity_on_bench_matrix"] = cpu_baseline["parity_on_bench_matrix"]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(args, synth, rp_dev, col_dev):
+def op_fractions(ops, n, nnz, rp, col, val, order, out, stats, steps):
+    """Whole-operation roofline fractions on the bench matrix: Permute2D(order, order) with the RCM order
+    (16 N + 12 n + 8 bytes) and RCMReorder (B (4 N + 16 n) bytes, B = the sweeps the reference's algorithm
+    prescribes on this instance: pseudo-peripheral iterations + 1)."""
+    def timed(f):
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    t_perm = timed(lambda: ops.permute_csr(n, n, rp, col, val, order, order, out=out))
+    t_rcm = timed(lambda: ops.rcm_reorder(rp, col, out=torch.empty_like(order)))
+    b_ref = int(stats.get("reference_sweeps") or 0) or None
+    alg_p = 16 * nnz + 12 * n + 8
+    res = {"permute2d": {"ms": t_perm * 1e3, "alg_bytes": alg_p, "alg_gbs": alg_p / t_perm / 1e9,
+                         "frac_of_hbm_peak": alg_p / t_perm / 1e9 / HBM_PEAK_GBS}}
+    if b_ref:
+        alg_r = b_ref * (4 * nnz + 16 * n)
+        res["rcm"] = {"ms": t_rcm * 1e3, "reference_sweeps": b_ref, "executed_sweeps": stats.get("bfs_sweeps"),
+                      "alg_bytes": alg_r, "alg_gbs": alg_r / t_rcm / 1e9,
+                      "frac_of_hbm_peak": alg_r / t_rcm / 1e9 / HBM_PEAK_GBS}
+    else:
+        res["rcm"] = {"ms": t_rcm * 1e3}
+    return res
+
+
+def run_cpu_baseline(args, synth, rp_dev, col_dev, gpu_result=None):
     """Times the reference pipeline on the host: real reference if oracle/_ref is present
     ("reference"), else the oracle restatement ("port").  Default sample: rank 0's bench matrix itself,
     one repetition (≈ 10 s of host work); --cpu-scale selects a smaller RMAT instance."""
@@ -298,22 +346,34 @@ def run_cpu_baseline(args, synth, rp_dev, col_dev):
     else:
         impl, kind = orc.Oracle(), "port"
         cores = 1
+    last = {}
+
     def run_once():
         t0 = time.perf_counter()
         order = impl.rcm_reorder(rp, col)
         t1 = time.perf_counter()
         if kind == "reference":
-            impl.permute_csr(rp, col, val, order, order, m=n)
+            res = impl.permute_csr(rp, col, val, order, order, m=n)
         else:
-            impl.permute_csr(rp, col, val, order, order)
-        return t1 - t0, time.perf_counter() - t1
+            res = impl.permute_csr(rp, col, val, order, order)
+        t2 = time.perf_counter()
+        last["order"], last["csr"] = order, res
+        return t1 - t0, t2 - t1
 
-    rcm_s, permute_s = run_once()
+    cold = run_once()
+    rcm_s, permute_s = run_once()  # the warm repetition is the one reported
     out = {"value": n / (rcm_s + permute_s) / 1e6, "unit": "Mrows/s", "cores": cores, "kind": kind,
-           "sample": (f"the bench matrix itself (symmetric RMAT scale {args.cpu_scale}, n={n}, nnz={nnz}), 1 repetition"
-                      if args.cpu_scale == args.scale else
-                      f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), 1 repetition"),
-           "rcm_s": rcm_s, "permute_s": permute_s}
+           "sample": (f"the bench matrix itself (symmetric RMAT scale {args.cpu_scale}, n={n}, nnz={nnz}), "
+                      "second of 2 repetitions" if args.cpu_scale == args.scale else
+                      f"same pipeline on symmetric RMAT scale {args.cpu_scale} (n={n}, nnz={nnz}), second of 2 repetitions"),
+           "rcm_s": rcm_s, "permute_s": permute_s, "cold": {"rcm_s": cold[0], "permute_s": cold[1]}}
+    if gpu_result is not None and args.cpu_scale == args.scale:
+        # the headline configuration verified end to end: the GPU step's outputs against the CPU leg's, bit for bit
+        g_order, g_out, _ = gpu_result
+        ok = bool(np.array_equal(g_order.cpu().numpy(), last["order"]))
+        for g, w in zip(g_out, last["csr"]):
+            ok = ok and bool(np.array_equal(g.cpu().numpy(), w))
+        out["parity_on_bench_matrix"] = ok
     if kind == "reference":
         # only the CSR constructor's two loops are OpenMP-parallel in the reference (format/csr.cc:102,123):
         # the same run with one thread (SURVEY §8d asks for both)

@@ -301,6 +301,53 @@ int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, i
 int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n,
                       const void *order, const void *vals, void *out);
 
+/* ------------------------------------------------------------------ *
+ * §8e  The steps that shard over the GPUs of one node (one process per GPU): permutation
+ * apply by new-row range and COO -> CSR by row range.  Inputs (CSR / row-sorted COO, order
+ * vectors) are replicated; a rank computes its own slab with no communication, then two
+ * all-gathers (8 bytes per rank of nnz totals; the rebased row_ptr segments in padded equal
+ * chunks, Z * n bytes in total) give every rank the complete row_ptr.  col / val stay
+ * row-sharded.  The reference has no multi-GPU operator; its device-to-device edge is
+ * converter/converter_order_two_cuda.cu:41-76 (predicate converter/converter_cuda.cu:12-21).
+ *
+ * Communicator: RCCL (sbx_comm_create_rccl; rank 0 makes the id with sbx_comm_unique_id and
+ * hands it to the other ranks by any means) or a caller-supplied all-gather hook
+ * (sbx_comm_create) — the hook gets device pointers and must leave `recv` (world * bytes, in
+ * rank order) complete for work enqueued afterwards on `stream` (a hipStream_t).            */
+/* ------------------------------------------------------------------ */
+#define SBX_COMM_ID_BYTES 128
+typedef struct sbx_comm_s *sbx_comm_t;
+typedef int (*sbx_allgather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes,
+                                void *stream);
+int sbx_comm_create(int rank, int world, sbx_allgather_fn allgather, void *user, sbx_comm_t *out);
+int sbx_comm_unique_id(void *id_out /* SBX_COMM_ID_BYTES */);
+int sbx_comm_create_rccl(int device, int rank, int world, const void *unique_id, sbx_comm_t *out);
+int sbx_comm_rank(sbx_comm_t comm, int *rank, int *world);
+int sbx_comm_destroy(sbx_comm_t comm);
+
+/* Entries of the new rows [row_begin,row_end): what a rank's col_out / val_out must hold. */
+int sbx_permute_csr_rows_nnz(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                             const void *row_order, int64_t row_begin, int64_t row_end,
+                             int64_t *nnz_host);
+
+/* A5 sharded.  row_splits: world + 1 new-row boundaries (NULL: equal ranges).  row_ptr_out
+ * (n + 1 entries) is complete on every rank; col_out / val_out receive THIS rank's rows
+ * (out_capacity entries); shard_offsets_host (world + 1, may be NULL) are the positions of the
+ * shards in the global entry space.  Synchronous; the collectives run on the handle's stream. */
+int sbx_permute_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt,
+                            int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                            const void *col, const void *val, const void *row_order,
+                            const void *col_order, const int64_t *row_splits, void *row_ptr_out,
+                            void *col_out, void *val_out, int64_t out_capacity,
+                            int64_t *shard_offsets_host);
+
+/* A2 sharded: row-sorted COO (replicated) -> this rank's rows of the CSR + the whole row_ptr. */
+int sbx_coo_to_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt,
+                           int64_t n, int64_t m, int64_t nnz, const void *row, const void *col,
+                           const void *val, const int64_t *row_splits, void *row_ptr_out,
+                           void *col_out, void *val_out, int64_t out_capacity,
+                           int64_t *shard_offsets_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(lambda so: _compile(so[0], so[1], verbose), jobs))
     if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

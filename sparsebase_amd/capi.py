@@ -35,6 +35,9 @@ class RcmStats(C.Structure):
 # every symbol include/sbx.h declares (tests/test_abi.py checks header <-> library <-> this table)
 _i64, _int, _u, _vp, _sz = C.c_int64, C.c_int, C.c_uint, C.c_void_p, C.c_size_t
 _H = C.c_void_p
+COMM_ID_BYTES = 128
+# int (*sbx_allgather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes, void *stream)
+ALLGATHER_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, _sz, _vp)
 PROTOTYPES = {
     "sbx_version": ([], _int),
     "sbx_status_string": ([_int], C.c_char_p),
@@ -82,6 +85,16 @@ PROTOTYPES = {
     "sbx_permute_csr_rows": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
                               _vp, _i64, C.POINTER(_i64)], _int),
     "sbx_permute_array": ([_H, _int, _int, _i64, _vp, _vp, _vp], _int),
+    "sbx_comm_create": ([_int, _int, ALLGATHER_FN, _vp, C.POINTER(_vp)], _int),
+    "sbx_comm_unique_id": ([_vp], _int),
+    "sbx_comm_create_rccl": ([_int, _int, _int, _vp, C.POINTER(_vp)], _int),
+    "sbx_comm_rank": ([_vp, C.POINTER(_int), C.POINTER(_int)], _int),
+    "sbx_comm_destroy": ([_vp], _int),
+    "sbx_permute_csr_rows_nnz": ([_H, _int, _i64, _vp, _vp, _i64, _i64, C.POINTER(_i64)], _int),
+    "sbx_permute_csr_sharded": ([_H, _vp, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp,
+                                 _vp, _vp, _i64, C.POINTER(_i64)], _int),
+    "sbx_coo_to_csr_sharded": ([_H, _vp, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _vp,
+                                _i64, C.POINTER(_i64)], _int),
 }
 
 _lib = None

@@ -1,0 +1,363 @@
+// sbx_sharded.hip — the steps of the path that shard across the GPUs of a node, one process per GPU.
+//
+//   sbx_comm_*                 communicator: RCCL (ncclAllGather over xGMI; librccl is loaded on first use, the
+//                              library does not link against it) or a caller-supplied all-gather hook
+//   sbx_permute_csr_sharded    A5 by new-row range: this rank's slab with sbx_permute_csr_rows, then the two
+//                              all-gathers that give every rank the whole permuted row_ptr
+//   sbx_coo_to_csr_sharded     A2 by row range of a row-sorted COO: the rank's nonzero slice by binary search, local
+//                              conversion, same stitch
+//   sbx_permute_csr_rows_nnz   entries of a new-row range (sizes the rank's slab before the first call)
+//
+// Reference counterpart of the device-to-device edge: converter/converter_order_two_cuda.cu:41-76 (peer copies between
+// CUDA contexts, predicate converter/converter_cuda.cu:12-21); the reference has no multi-GPU operator — north_star
+// asks for the row-range split with an all-gatherv of row_ptr.  Exchange per call: 8 bytes per rank (nnz totals) and
+// Z * n bytes in total (padded equal row_ptr chunks); col/val stay row-sharded.  No collective touches the nonzeros.
+#include <dlfcn.h>
+
+#include <vector>
+
+#include "sbx_device.h"
+#include "sbx_internal.h"
+
+struct sbx_comm_s {
+  int rank, world;
+  sbx_allgather_fn allgather;
+  void *user;
+  void *nccl_comm;  // RCCL flavour only
+};
+
+namespace {
+
+// ---- RCCL, loaded lazily ----------------------------------------------------------------------------------
+struct Id128 {  // ncclUniqueId
+  char bytes[SBX_COMM_ID_BYTES];
+};
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128 /* by value, as ncclCommInitRank takes it */, int) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+bool rccl_load() {
+  if (g_rccl.lib) return true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *lib = nullptr;
+  for (const char *nm : names) {
+    lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
+  }
+  if (!lib) return false;
+  RcclApi a;
+  a.lib = lib;
+  a.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(lib, "ncclCommInitRank");
+  a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(lib, "ncclAllGather");
+  a.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+  a.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) {
+    dlclose(lib);
+    return false;
+  }
+  g_rccl = a;
+  return true;
+}
+
+int rccl_allgather(void *user, const void *send, void *recv, size_t bytes, void *stream) {
+  sbx_comm_t c = (sbx_comm_t)user;
+  const int rc = g_rccl.AllGather(send, recv, bytes, /* ncclChar */ 0, c->nccl_comm, (hipStream_t)stream);
+  return rc == 0 ? SBX_OK : SBX_ERR_HIP;
+}
+
+// ---- stitch kernels -----------------------------------------------------------------------------------------
+constexpr int MAX_WORLD = 64;
+struct Splits {
+  int64_t lo[MAX_WORLD + 1];
+};
+
+// send[i] = local[i] + offset for the shard's rows, zero padding up to `chunk`
+template <typename I>
+__global__ __launch_bounds__(256) void k_seg_prepare(const I *__restrict__ local, int64_t rows, int64_t offset,
+                                                     I *__restrict__ send, int64_t chunk) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < chunk; i += stride) send[i] = i < rows ? (I)((int64_t)local[i] + offset) : (I)0;
+}
+
+// out[row] = gathered[rank(row) * chunk + row - lo(rank)], out[n] = total
+template <typename I>
+__global__ __launch_bounds__(256) void k_stitch(const I *__restrict__ gathered, int64_t chunk, Splits sp, int world,
+                                                int64_t n, int64_t total, I *__restrict__ out) {
+  int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; row <= n; row += stride) {
+    if (row == n) {
+      out[row] = (I)total;
+      continue;
+    }
+    int r = 0;  // the rank whose range holds the row (world <= 64: a short scan, the same for a whole wave mostly)
+    while (r + 1 < world && sp.lo[r + 1] <= row) r++;
+    out[row] = gathered[(int64_t)r * chunk + (row - sp.lo[r])];
+  }
+}
+
+__global__ void k_set_i64(int64_t *dst, int64_t v) { *dst = v; }
+
+// first positions of rows >= lo and >= hi in a non-decreasing row array
+template <typename I>
+__global__ void k_row_bounds(const I *__restrict__ row, int64_t nnz, int64_t lo, int64_t hi, int64_t *__restrict__ out2) {
+  const int64_t key = threadIdx.x == 0 ? lo : hi;
+  int64_t a = 0, b = nnz;
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if ((int64_t)row[mid] >= key) b = mid;
+    else a = mid + 1;
+  }
+  out2[threadIdx.x] = a;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_rebase(const I *__restrict__ row, int64_t count, int64_t lo, I *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) out[i] = (I)((int64_t)row[i] - lo);
+}
+
+// entries of the old rows that the order maps into [rb0, rb1)
+template <typename I>
+__global__ __launch_bounds__(256) void k_range_nnz(const I *__restrict__ rp, const I *__restrict__ row_order, int64_t n,
+                                                   int64_t rb0, int64_t rb1, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long s_part[4];
+  unsigned long long acc = 0;
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; u < n; u += stride) {
+    const int64_t r = row_order ? (int64_t)row_order[u] : u;
+    if (r >= rb0 && r < rb1) acc += (unsigned long long)(rp[u + 1] - rp[u]);
+  }
+  acc = sbx_block_sum<unsigned long long, 256>(acc, s_part);
+  if (threadIdx.x == 0 && acc) atomicAdd(out, acc);
+}
+
+struct NestGuard {  // the nested entry points must not rewind the caller's scratch
+  sbx_handle_t h;
+  explicit NestGuard(sbx_handle_t h_) : h(h_) { h->nest++; }
+  ~NestGuard() { if (h->nest > 0) h->nest--; }
+};
+
+int resolve_splits(sbx_handle_t h, sbx_comm_t comm, int64_t n, const int64_t *row_splits, Splits *sp, int64_t *chunk) {
+  const int world = comm->world;
+  if (world < 1 || world > MAX_WORLD) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "world size %d (supported: 1..%d)", world, MAX_WORLD);
+  if (row_splits) {
+    for (int r = 0; r <= world; r++) sp->lo[r] = row_splits[r];
+  } else {  // contiguous ranges whose sizes differ by at most one row
+    const int64_t base = n / world, extra = n % world;
+    int64_t lo = 0;
+    for (int r = 0; r < world; r++) {
+      sp->lo[r] = lo;
+      lo += base + (r < extra ? 1 : 0);
+    }
+    sp->lo[world] = n;
+  }
+  if (sp->lo[0] != 0 || sp->lo[world] != n) SBX_FAIL(h, SBX_ERR_BAD_ARG, "row_splits must run from 0 to n");
+  *chunk = 1;
+  for (int r = 0; r < world; r++) {
+    if (sp->lo[r + 1] < sp->lo[r]) SBX_FAIL(h, SBX_ERR_BAD_ARG, "row_splits must be non-decreasing");
+    if (sp->lo[r + 1] - sp->lo[r] > *chunk) *chunk = sp->lo[r + 1] - sp->lo[r];
+  }
+  return SBX_OK;
+}
+
+// the two all-gathers + the stitch: local (rows + 1 entries, rebased to 0) -> row_ptr_out (n + 1 entries)
+template <typename I>
+int stitch(sbx_handle_t h, sbx_comm_t comm, const Splits &sp, int64_t chunk, int64_t n, const I *local, int64_t local_nnz,
+           I *row_ptr_out, int64_t *shard_offsets_host) {
+  const int world = comm->world, rank = comm->rank;
+  const int64_t rows = sp.lo[rank + 1] - sp.lo[rank];
+  int64_t *mine = nullptr, *totals = nullptr;
+  I *send = nullptr, *gathered = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &mine));
+  SBX_TRY(sbx_salloc(h, (size_t)world, &totals));
+  SBX_TRY(sbx_salloc(h, (size_t)chunk, &send));
+  SBX_TRY(sbx_salloc(h, (size_t)chunk * world, &gathered));
+  // (1) nnz totals -> offsets of the shards in the global entry space
+  SBX_KLAUNCH(h, SBX_K_MISC, k_set_i64, dim3(1), dim3(1), mine, local_nnz);
+  SBX_LAUNCH_CHECK(h);
+  if (comm->allgather(comm->user, mine, totals, sizeof(int64_t), (void *)h->stream) != SBX_OK)
+    SBX_FAIL(h, SBX_ERR_HIP, "all-gather of the shard totals failed");
+  std::vector<int64_t> tot(world), off(world + 1, 0);
+  SBX_TRY(sbx_readback(h, tot.data(), totals, sizeof(int64_t) * world));
+  for (int r = 0; r < world; r++) off[r + 1] = off[r] + tot[r];
+  if (sizeof(I) == 4 && off[world] >= ((int64_t)1 << 31)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "row_ptr does not fit 32 bits");
+  if (shard_offsets_host)
+    for (int r = 0; r <= world; r++) shard_offsets_host[r] = off[r];
+  // (2) row_ptr segments in padded equal chunks (the all-gatherv of SURVEY §8e), then every rank assembles the whole
+  SBX_KLAUNCH(h, SBX_K_MISC, k_seg_prepare<I>, dim3(sbx_grid_for(chunk, 256, 4096)), dim3(256), local, rows, off[rank], send,
+              chunk);
+  SBX_LAUNCH_CHECK(h);
+  if (comm->allgather(comm->user, send, gathered, sizeof(I) * (size_t)chunk, (void *)h->stream) != SBX_OK)
+    SBX_FAIL(h, SBX_ERR_HIP, "all-gather of the row_ptr segments failed");
+  SBX_KLAUNCH(h, SBX_K_MISC, k_stitch<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256), (const I *)gathered, chunk, sp,
+              world, n, off[world], row_ptr_out);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+}  // namespace
+
+extern "C" int sbx_comm_create(int rank, int world, sbx_allgather_fn allgather, void *user, sbx_comm_t *out) {
+  if (!out || !allgather || world < 1 || rank < 0 || rank >= world) return SBX_ERR_BAD_ARG;
+  sbx_comm_t c = new sbx_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->allgather = allgather;
+  c->user = user;
+  c->nccl_comm = nullptr;
+  *out = c;
+  return SBX_OK;
+}
+
+extern "C" int sbx_comm_unique_id(void *id_out) {
+  if (!id_out) return SBX_ERR_BAD_ARG;
+  if (!rccl_load()) return SBX_ERR_UNSUPPORTED;
+  return g_rccl.GetUniqueId(id_out) == 0 ? SBX_OK : SBX_ERR_HIP;
+}
+
+extern "C" int sbx_comm_create_rccl(int device, int rank, int world, const void *unique_id, sbx_comm_t *out) {
+  if (!out || !unique_id || world < 1 || rank < 0 || rank >= world) return SBX_ERR_BAD_ARG;
+  if (!rccl_load()) return SBX_ERR_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return SBX_ERR_NO_DEVICE;
+  Id128 id;
+  memcpy(id.bytes, unique_id, SBX_COMM_ID_BYTES);
+  void *nc = nullptr;
+  if (g_rccl.CommInitRank(&nc, world, id, rank) != 0) return SBX_ERR_HIP;
+  sbx_comm_t c = new sbx_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->allgather = rccl_allgather;
+  c->user = c;
+  c->nccl_comm = nc;
+  *out = c;
+  return SBX_OK;
+}
+
+extern "C" int sbx_comm_destroy(sbx_comm_t c) {
+  if (!c) return SBX_OK;
+  if (c->nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl_comm);
+  delete c;
+  return SBX_OK;
+}
+
+extern "C" int sbx_comm_rank(sbx_comm_t c, int *rank, int *world) {
+  if (!c) return SBX_ERR_BAD_ARG;
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  return SBX_OK;
+}
+
+extern "C" int sbx_permute_csr_rows_nnz(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                                        const void *row_order, int64_t row_begin, int64_t row_end, int64_t *nnz_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (!row_ptr || !nnz_host || n < 0 || row_begin < 0 || row_begin > row_end || row_end > n)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows_nnz: bad argument");
+  SBX_TRY(sbx_arena_begin(h));
+  unsigned long long *acc = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &acc));
+  SBX_HIP(h, hipMemsetAsync(acc, 0, sizeof(*acc), h->stream));
+  if (n > 0) {
+    const unsigned grid = sbx_grid_for(n, 256, 2048);
+    if (it == SBX_I32)
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_range_nnz<int32_t>, dim3(grid), dim3(256), (const int32_t *)row_ptr,
+                  (const int32_t *)row_order, n, row_begin, row_end, acc);
+    else
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_range_nnz<int64_t>, dim3(grid), dim3(256), (const int64_t *)row_ptr,
+                  (const int64_t *)row_order, n, row_begin, row_end, acc);
+    SBX_LAUNCH_CHECK(h);
+  }
+  unsigned long long v = 0;
+  SBX_TRY(sbx_readback(h, &v, acc, sizeof(v)));
+  *nnz_host = (int64_t)v;
+  return SBX_OK;
+}
+
+extern "C" int sbx_permute_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt, int64_t n,
+                                       int64_t m, int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                                       const void *row_order, const void *col_order, const int64_t *row_splits,
+                                       void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
+                                       int64_t *shard_offsets_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (!comm || !row_ptr || !row_ptr_out || n < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_sharded: bad argument");
+  Splits sp;
+  int64_t chunk = 1;
+  SBX_TRY(resolve_splits(h, comm, n, row_splits, &sp, &chunk));
+  const int64_t lo = sp.lo[comm->rank], hi = sp.lo[comm->rank + 1];
+  SBX_TRY(sbx_arena_begin(h));
+  NestGuard guard(h);
+  const size_t ib = (size_t)sbx_index_bytes(it);
+  void *local = nullptr;
+  SBX_TRY(sbx_arena_alloc(h, ib * (size_t)(hi - lo + 1), &local));
+  int64_t local_nnz = 0;
+  SBX_TRY(sbx_permute_csr_rows(h, it, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, lo, hi, local, col_out,
+                               val_out, out_capacity, &local_nnz));
+  if (it == SBX_I32)
+    return stitch<int32_t>(h, comm, sp, chunk, n, (const int32_t *)local, local_nnz, (int32_t *)row_ptr_out,
+                           shard_offsets_host);
+  return stitch<int64_t>(h, comm, sp, chunk, n, (const int64_t *)local, local_nnz, (int64_t *)row_ptr_out,
+                         shard_offsets_host);
+}
+
+extern "C" int sbx_coo_to_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt, int64_t n,
+                                      int64_t m, int64_t nnz, const void *row, const void *col, const void *val,
+                                      const int64_t *row_splits, void *row_ptr_out, void *col_out, void *val_out,
+                                      int64_t out_capacity, int64_t *shard_offsets_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (!comm || !row_ptr_out || n < 0 || nnz < 0 || (nnz > 0 && (!row || !col)))
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr_sharded: bad argument");
+  Splits sp;
+  int64_t chunk = 1;
+  SBX_TRY(resolve_splits(h, comm, n, row_splits, &sp, &chunk));
+  const int64_t lo = sp.lo[comm->rank], hi = sp.lo[comm->rank + 1];
+  SBX_TRY(sbx_arena_begin(h));
+  NestGuard guard(h);
+  const size_t ib = (size_t)sbx_index_bytes(it);
+  const int vb = val ? sbx_value_bytes(vt) : 0;
+  if (vb < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "unknown value type");
+  // the rank's nonzeros: the contiguous slice [a, b) of the row-sorted COO
+  int64_t *bounds = nullptr;
+  SBX_TRY(sbx_salloc(h, 2, &bounds));
+  if (it == SBX_I32)
+    SBX_KLAUNCH(h, SBX_K_MISC, k_row_bounds<int32_t>, dim3(1), dim3(2), (const int32_t *)row, nnz, lo, hi, bounds);
+  else
+    SBX_KLAUNCH(h, SBX_K_MISC, k_row_bounds<int64_t>, dim3(1), dim3(2), (const int64_t *)row, nnz, lo, hi, bounds);
+  SBX_LAUNCH_CHECK(h);
+  int64_t ab[2];
+  SBX_TRY(sbx_readback(h, ab, bounds, sizeof(ab)));
+  const int64_t a = ab[0], local_nnz = ab[1] - ab[0];
+  if (local_nnz > out_capacity)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr_sharded: shard needs %lld entries, capacity %lld", (long long)local_nnz,
+             (long long)out_capacity);
+  void *local = nullptr, *rebased = nullptr;
+  SBX_TRY(sbx_arena_alloc(h, ib * (size_t)(hi - lo + 1), &local));
+  SBX_TRY(sbx_arena_alloc(h, ib * (size_t)(local_nnz > 0 ? local_nnz : 1), &rebased));
+  if (local_nnz > 0) {
+    const unsigned grid = sbx_grid_for(local_nnz, 256, 8192);
+    if (it == SBX_I32)
+      SBX_KLAUNCH(h, SBX_K_MISC, k_rebase<int32_t>, dim3(grid), dim3(256), (const int32_t *)row + a, local_nnz, lo,
+                  (int32_t *)rebased);
+    else
+      SBX_KLAUNCH(h, SBX_K_MISC, k_rebase<int64_t>, dim3(grid), dim3(256), (const int64_t *)row + a, local_nnz, lo,
+                  (int64_t *)rebased);
+    SBX_LAUNCH_CHECK(h);
+  }
+  SBX_TRY(sbx_coo_to_csr(h, it, vt, hi - lo, m, local_nnz, rebased, (const char *)col + ib * (size_t)a,
+                         val ? (const char *)val + (size_t)vb * (size_t)a : nullptr, local, col_out, val ? val_out : nullptr,
+                         SBX_FLAG_ROWS_SORTED));
+  if (it == SBX_I32)
+    return stitch<int32_t>(h, comm, sp, chunk, n, (const int32_t *)local, local_nnz, (int32_t *)row_ptr_out,
+                           shard_offsets_host);
+  return stitch<int64_t>(h, comm, sp, chunk, n, (const int64_t *)local, local_nnz, (int64_t *)row_ptr_out,
+                         shard_offsets_host);
+}

@@ -65,7 +65,7 @@ class Handle:
 
     def bind_stream(self):
         s = torch.cuda.current_stream(self.device_index).cuda_stream
-        self.lib.sbx_set_stream(self.h, C.c_void_p(s))
+        self.check(self.lib.sbx_set_stream(self.h, C.c_void_p(s)))
 
     def check(self, rc):
         if rc != capi.SBX_OK:
@@ -320,11 +320,21 @@ def permute_csr(n, m, row_ptr, col, val, row_order, col_order, out=None):
     return rpo, co, vo
 
 
+def permute_csr_rows_nnz(n, row_ptr, row_order, row_begin, row_end):
+    """Entries of the new rows [row_begin, row_end): the size of that shard's col / val slab."""
+    hd = handle_for(_check_dev(row_ptr, row_order))
+    got = C.c_int64(0)
+    hd.check(hd.lib.sbx_permute_csr_rows_nnz(hd.h, _it(row_ptr), n, _p(row_ptr), _p(row_order), row_begin, row_end,
+                                             C.byref(got)))
+    return got.value
+
+
 def permute_csr_rows(n, m, row_ptr, col, val, row_order, col_order, row_begin, row_end, capacity=None):
     """One row-range shard of the permuted matrix (the multi-GPU decomposition)."""
     hd = handle_for(_check_dev(row_ptr, col, val, row_order, col_order))
     nr = row_end - row_begin
-    capacity = col.numel() if capacity is None else capacity
+    if capacity is None:  # exactly the shard's entries, not the whole matrix's
+        capacity = permute_csr_rows_nnz(n, row_ptr, row_order, row_begin, row_end)
     rpo = torch.empty(nr + 1, dtype=row_ptr.dtype, device=row_ptr.device)
     co = torch.empty(capacity, dtype=col.dtype, device=col.device)
     vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
@@ -341,3 +351,130 @@ def permute_array(order, vals):
     out = torch.empty_like(vals)
     hd.check(hd.lib.sbx_permute_array(hd.h, _it(order), _vt(vals), order.numel(), _p(order), _p(vals), _p(out)))
     return out
+
+
+# ----------------------------------------------------------------------------- sharded steps
+class Comm:
+    """An sbx communicator: RCCL (`Comm.rccl`, one GPU per rank, the id travels over torch.distributed) or an
+    all-gather hook over a torch.distributed group of any backend (`Comm.hook`, e.g. gloo with ranks sharing a GPU)."""
+
+    def __init__(self, lib, handle, keep=None):
+        self.lib, self.c, self._keep = lib, handle, keep
+
+    @classmethod
+    def rccl(cls, device_index, group=None):
+        import torch.distributed as dist
+        lib = capi.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(capi.COMM_ID_BYTES)
+            rc = lib.sbx_comm_unique_id(buf)
+            if rc != capi.SBX_OK:
+                raise capi.SbxError(rc, "sbx_comm_unique_id failed (librccl not loadable?)")
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        c = C.c_void_p()
+        rc = lib.sbx_comm_create_rccl(int(device_index), rank, world, C.c_char_p(box[0]), C.byref(c))
+        if rc != capi.SBX_OK:
+            raise capi.SbxError(rc, "sbx_comm_create_rccl failed")
+        return cls(lib, c)
+
+    @classmethod
+    def hook(cls, device_index, group=None):
+        """All-gather through torch.distributed on host buffers (staged with sbx_memcpy_*): for backends without
+        device collectives and for ranks that share one GPU."""
+        import numpy as np
+        import torch.distributed as dist
+        lib = capi.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        hd = handle_for(torch.device("cuda", device_index))
+
+        def allgather(user, send, recv, nbytes, stream):
+            try:
+                mine = np.empty(nbytes, np.uint8)
+                torch.cuda.current_stream(device_index).synchronize()
+                if lib.sbx_memcpy_d2h(hd.h, mine.ctypes.data_as(C.c_void_p), C.c_void_p(send), nbytes) != capi.SBX_OK:
+                    return 3
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(mine), group=group)
+                whole = torch.cat(parts).numpy()
+                if lib.sbx_memcpy_h2d(hd.h, C.c_void_p(recv), whole.ctypes.data_as(C.c_void_p), nbytes * world) != capi.SBX_OK:
+                    return 3
+                return 0
+            except Exception:  # noqa: BLE001  (must not unwind through the C frame)
+                return 6
+
+        cb = capi.ALLGATHER_FN(allgather)
+        c = C.c_void_p()
+        rc = lib.sbx_comm_create(rank, world, cb, None, C.byref(c))
+        if rc != capi.SBX_OK:
+            raise capi.SbxError(rc, "sbx_comm_create failed")
+        return cls(lib, c, keep=cb)
+
+    def close(self):
+        if self.c:
+            self.lib.sbx_comm_destroy(self.c)
+            self.c = None
+
+
+def _splits(ranges):
+    if ranges is None:
+        return None
+    cuts = [ranges[0][0]] + [hi for _, hi in ranges]
+    return (C.c_int64 * len(cuts))(*cuts)
+
+
+def permute_csr_sharded(comm, n, m, row_ptr, col, val, row_order, col_order, ranges=None, out=None, capacity=None):
+    """sbx_permute_csr_sharded: returns (global row_ptr, this rank's col, val slabs, shard offsets list).
+    `out` = (row_ptr_out (n + 1), col_out, val_out) pre-allocated slabs (capacity = col_out.numel())."""
+    hd = handle_for(_check_dev(row_ptr, col, val, row_order, col_order))
+    rank, world = C.c_int(0), C.c_int(0)
+    hd.lib.sbx_comm_rank(comm.c, C.byref(rank), C.byref(world))
+    if out is None:
+        if capacity is None:
+            lo, hi = ranges[rank.value] if ranges is not None else _equal_range(n, world.value, rank.value)
+            capacity = permute_csr_rows_nnz(n, row_ptr, row_order, lo, hi)
+        rpo = torch.empty(n + 1, dtype=row_ptr.dtype, device=row_ptr.device)
+        co = torch.empty(capacity, dtype=col.dtype, device=col.device)
+        vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+    else:
+        rpo, co, vo = out
+        capacity = co.numel()
+    offs = (C.c_int64 * (world.value + 1))()
+    hd.check(hd.lib.sbx_permute_csr_sharded(hd.h, comm.c, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
+                                            _p(val), _p(row_order), _p(col_order), _splits(ranges), _p(rpo), _p(co),
+                                            _p(vo), capacity, offs))
+    offs = list(offs)
+    k = offs[rank.value + 1] - offs[rank.value]
+    return rpo, co[:k], (None if vo is None else vo[:k]), offs
+
+
+def coo_to_csr_sharded(comm, n, m, row, col, val, ranges=None, out=None, capacity=None):
+    """sbx_coo_to_csr_sharded on a replicated row-sorted COO."""
+    hd = handle_for(_check_dev(row, col, val))
+    rank, world = C.c_int(0), C.c_int(0)
+    hd.lib.sbx_comm_rank(comm.c, C.byref(rank), C.byref(world))
+    if out is None:
+        if capacity is None:
+            lo, hi = ranges[rank.value] if ranges is not None else _equal_range(n, world.value, rank.value)
+            b = torch.searchsorted(row, torch.tensor([lo, hi], dtype=row.dtype, device=row.device), right=False)
+            capacity = int(b[1] - b[0])
+        rpo = torch.empty(n + 1, dtype=row.dtype, device=row.device)
+        co = torch.empty(capacity, dtype=col.dtype, device=col.device)
+        vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+    else:
+        rpo, co, vo = out
+        capacity = co.numel()
+    offs = (C.c_int64 * (world.value + 1))()
+    hd.check(hd.lib.sbx_coo_to_csr_sharded(hd.h, comm.c, _it(row), _vt(val), n, m, row.numel(), _p(row), _p(col), _p(val),
+                                           _splits(ranges), _p(rpo), _p(co), _p(vo), capacity, offs))
+    offs = list(offs)
+    k = offs[rank.value + 1] - offs[rank.value]
+    return rpo, co[:k], (None if vo is None else vo[:k]), offs
+
+
+def _equal_range(n, world, rank):
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

@@ -10,10 +10,13 @@ CSR and the order vectors (replicated); it produces its slab of col/val locally
   2. all_gather of the rebased row_ptr segments (Z*n bytes in total)
 
 after which every rank holds the complete permuted row_ptr; col/val stay
-row-sharded (a distributed CSR) unless gather_entries=True.  The collective is
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests that exercise exactly this stitching code with a test double for the
-shard computation).
+row-sharded (a distributed CSR) unless gather_entries=True.  The product path is ONE
+C-ABI call per rank (sbx_permute_csr_sharded / sbx_coo_to_csr_sharded,
+sparsebase_amd/csrc/sbx_sharded.hip): the rank's slab, both all-gathers (RCCL
+ncclAllGather from C++ when the torch.distributed backend is nccl; an all-gather hook
+over the group otherwise) and the stitch kernel.  This module only chooses the row
+ranges and builds the communicator; the CPU gloo tests inject the shard computation and
+run the host-language restatement of the stitch (stitch_row_ptr).
 """
 import torch
 import torch.distributed as dist
@@ -46,56 +49,71 @@ def balanced_row_ranges(new_row_lengths_prefix, world_size):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
-def stitch_row_ptr(local_row_ptr, ranges, group=None):
-    """All-gather the rebased per-shard row_ptr segments into the global row_ptr.
+def make_comm(device_index, group=None):
+    """The sbx communicator for a torch.distributed group: RCCL (ncclAllGather called from the C ABI, one GPU per
+    rank) when the group's backend is nccl, otherwise the all-gather hook over the group (gloo: ranks may share a GPU)."""
+    from . import ops
+    if dist.get_backend(group) == "nccl":
+        return ops.Comm.rccl(device_index, group)
+    return ops.Comm.hook(device_index, group)
 
-    local_row_ptr: (hi-lo+1,) tensor, rebased to 0, on this rank's device.
-    Returns (global_row_ptr (n+1,), shard_offsets (world_size+1,) int64 tensor).
+
+def stitch_row_ptr(local_row_ptr, ranges, group=None):
+    """Host-language restatement of the stitch the C ABI does on the device (sbx_sharded.hip: nnz totals, padded
+    equal chunks, one all-gather each): used with CPU tensors by the gloo tests, which inject the shard computation.
+
+    local_row_ptr: (hi-lo+1,) tensor, rebased to 0.  Returns (global_row_ptr (n+1,), shard_offsets (world+1,) int64).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = ranges[rank]
     assert local_row_ptr.numel() == hi - lo + 1
     dev, dt = local_row_ptr.device, local_row_ptr.dtype
-    # (1) shard nnz totals -> global offsets
-    mine = local_row_ptr[-1:].to(torch.int64)
-    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(totals, mine, group=group)
-    totals = torch.cat(totals)
+    totals = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(totals, local_row_ptr[-1:].to(torch.int64), group=group)
     offsets = torch.zeros(world + 1, dtype=torch.int64, device=dev)
-    offsets[1:] = torch.cumsum(totals, 0)
-    # (2) row_ptr segments, padded to equal length (all-gather-v emulation)
-    max_rows = max(h - l for l, h in ranges)
-    seg = torch.zeros(max_rows, dtype=dt, device=dev)
+    torch.cumsum(totals, 0, out=offsets[1:])
+    starts = torch.tensor([l for l, _ in ranges] + [ranges[-1][1]], dtype=torch.int64, device=dev)
+    chunk = int((starts[1:] - starts[:-1]).max().clamp(min=1))
+    seg = torch.zeros(chunk, dtype=dt, device=dev)
     seg[: hi - lo] = local_row_ptr[:-1] + offsets[rank].to(dt)
-    gathered = [torch.empty(max_rows, dtype=dt, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, seg, group=group)
+    gathered = torch.empty(world * chunk, dtype=dt, device=dev)
+    dist.all_gather_into_tensor(gathered, seg, group=group)
     n = ranges[-1][1]
+    rows = torch.arange(n, dtype=torch.int64, device=dev)
+    owner = torch.searchsorted(starts[1:], rows, right=True).clamp(max=world - 1)
     out = torch.empty(n + 1, dtype=dt, device=dev)
-    for r, (l, h) in enumerate(ranges):
-        out[l:h] = gathered[r][: h - l]
+    out[:n] = gathered[owner * chunk + rows - starts[owner]]
     out[n] = offsets[world].to(dt)
     return out, offsets
 
 
 def permute_csr_sharded(n, m, row_ptr, col, val, row_order, col_order, group=None, ranges=None,
-                        shard_fn=None, gather_entries=False):
+                        shard_fn=None, gather_entries=False, comm=None, out=None):
     """Sharded Permute2D.  Returns (global_row_ptr, local_col, local_val, (lo, hi), offsets).
 
-    shard_fn(lo, hi) -> (rebased_row_ptr, col, val) defaults to the HIP path
-    (ops.permute_csr_rows); tests inject a CPU double to exercise the collectives.
-    """
+    Product path (shard_fn is None): one call of sbx_permute_csr_sharded — the rank's slab and both all-gathers
+    happen behind the C ABI; `comm` is an ops.Comm (make_comm), `out` optional pre-allocated
+    (row_ptr_out, col_out, val_out).  shard_fn(lo, hi) -> (rebased_row_ptr, col, val) is the tests' injection point:
+    then the stitch runs through torch.distributed on whatever tensors the double returns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ranges = row_ranges(n, world) if ranges is None else ranges
     lo, hi = ranges[rank]
     if shard_fn is None:
         from . import ops
-
-        def shard_fn(a, b):
-            return ops.permute_csr_rows(n, m, row_ptr, col, val, row_order, col_order, a, b)
-    lrp, lcol, lval = shard_fn(lo, hi)
-    grp, offsets = stitch_row_ptr(lrp, ranges, group)
+        own = comm is None
+        comm = make_comm(row_ptr.device.index, group) if own else comm
+        try:
+            grp, lcol, lval, offs = ops.permute_csr_sharded(comm, n, m, row_ptr, col, val, row_order, col_order,
+                                                            ranges=ranges, out=out)
+        finally:
+            if own:
+                comm.close()
+        offsets = torch.tensor(offs, dtype=torch.int64, device=row_ptr.device)
+    else:
+        lrp, lcol, lval = shard_fn(lo, hi)
+        grp, offsets = stitch_row_ptr(lrp, ranges, group)
     if gather_entries:
         lcol = _gather_v(lcol, offsets, group)
         lval = None if lval is None else _gather_v(lval, offsets, group)
@@ -115,24 +133,32 @@ def csr_to_coo_shard(m, row_ptr, col, val, lo, hi, a, b):
     return r + lo, c, v
 
 
-def coo_to_csr_sharded(n, m, row, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False):
+def coo_to_csr_sharded(n, m, row, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False, comm=None,
+                       out=None):
     """Sharded COO -> CSR of a row-sorted COO (replicated input, like the permute): rank r owns rows
     [lo_r, hi_r); its nonzeros are the contiguous slice found by binary search on the sorted row array,
-    converted locally (sbx_coo_to_csr on rebased row ids), and the row_ptr segments are stitched with
-    the same two all-gathers.  Returns (global_row_ptr, local_col, local_val, (lo, hi), offsets).
-
-    shard_fn(lo, hi, a, b) -> (rebased_row_ptr, col, val) for rows [lo, hi) = nonzeros [a, b)."""
+    converted locally, and the row_ptr segments are stitched with the same two all-gathers — all behind
+    sbx_coo_to_csr_sharded unless a shard_fn(lo, hi, a, b) -> (rebased_row_ptr, col, val) double is injected.
+    Returns (global_row_ptr, local_col, local_val, (lo, hi), offsets)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ranges = row_ranges(n, world) if ranges is None else ranges
     lo, hi = ranges[rank]
-    bounds = torch.searchsorted(row, torch.tensor([lo, hi], dtype=row.dtype, device=row.device), right=False)
-    a, b = int(bounds[0]), int(bounds[1])
     if shard_fn is None:
-        def shard_fn(lo_, hi_, a_, b_):
-            return coo_to_csr_shard(m, row, col, val, lo_, hi_, a_, b_)
-    lrp, lcol, lval = shard_fn(lo, hi, a, b)
-    grp, offsets = stitch_row_ptr(lrp, ranges, group)
+        from . import ops
+        own = comm is None
+        comm = make_comm(row.device.index, group) if own else comm
+        try:
+            grp, lcol, lval, offs = ops.coo_to_csr_sharded(comm, n, m, row, col, val, ranges=ranges, out=out)
+        finally:
+            if own:
+                comm.close()
+        offsets = torch.tensor(offs, dtype=torch.int64, device=row.device)
+    else:
+        bounds = torch.searchsorted(row, torch.tensor([lo, hi], dtype=row.dtype, device=row.device), right=False)
+        a, b = int(bounds[0]), int(bounds[1])
+        lrp, lcol, lval = shard_fn(lo, hi, a, b)
+        grp, offsets = stitch_row_ptr(lrp, ranges, group)
     if gather_entries:
         lcol = _gather_v(lcol, offsets, group)
         lval = None if lval is None else _gather_v(lval, offsets, group)
@@ -162,11 +188,13 @@ def csr_to_coo_sharded(n, m, row_ptr, col, val, group=None, ranges=None, shard_f
 
 
 def _gather_v(local, offsets, group=None):
+    """All-gather-v of row-sharded entries (only when the caller wants every rank to hold them all)."""
     world = dist.get_world_size(group)
-    sizes = (offsets[1:] - offsets[:-1]).tolist()
-    cap = int(max(sizes)) if sizes else 0
+    sizes = offsets[1:] - offsets[:-1]
+    cap = int(sizes.max().clamp(min=1))
     pad = torch.zeros(cap, dtype=local.dtype, device=local.device)
     pad[: local.numel()] = local
-    parts = [torch.empty(cap, dtype=local.dtype, device=local.device) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[: int(s)] for p, s in zip(parts, sizes)])
+    parts = torch.empty(world * cap, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(parts, pad, group=group)
+    keep = (torch.arange(cap, device=local.device)[None, :] < sizes[:, None]).reshape(-1)
+    return parts[keep]

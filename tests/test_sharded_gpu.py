@@ -1,0 +1,128 @@
+"""The sharded steps END TO END on the GPU: two fresh child processes, both on GPU 0, gloo between them, each calling
+sbx_permute_csr_sharded / sbx_coo_to_csr_sharded (the real HIP shard computation + the device-side stitch of
+sparsebase_amd/csrc/sbx_sharded.hip, all-gathers through the communicator hook) — compared with the oracle's
+whole-matrix result.  (RCCL itself needs one GPU per rank: bench.py --gpus N uses it on the multi-GPU node.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from orc import Oracle
+        from sparsebase_amd import ops, sharded, synth
+        torch.cuda.set_device(0)
+        orc = Oracle()
+        d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        h = lambda t: None if t is None else t.cpu().numpy()
+        rp, col = synth.rmat_symmetric(13, 8, seed=5)   # power-law rows: every sort class, shard boundaries inside hubs
+        n = len(rp) - 1
+        val = (np.arange(len(col)) % 31).astype(np.float32)
+        order = synth.random_permutation(n, 9)
+        want = orc.permute_csr(rp, col, val, order, order)
+        comm = sharded.make_comm(0)
+        ok, notes = True, []
+
+        def check(tag, cond):
+            nonlocal ok
+            if not cond:
+                notes.append(tag)
+                ok = False
+
+        for idt in (np.int32, np.int64):
+            drp, dcol, dord = d(rp.astype(idt)), d(col.astype(idt)), d(order.astype(idt))
+            for balanced in (False, True):
+                ranges = sharded.balanced_row_ranges(torch.from_numpy(want[0].astype(np.int64)), world) if balanced else None
+                grp, lcol, lval, (lo, hi), offs = sharded.permute_csr_sharded(n, n, drp, dcol, d(val), dord, dord,
+                                                                             ranges=ranges, comm=comm)
+                a, b = int(want[0][lo]), int(want[0][hi])
+                check(f"perm rp {idt} {balanced}", np.array_equal(h(grp), want[0].astype(idt)))
+                check(f"perm col {idt} {balanced}", np.array_equal(h(lcol), want[1][a:b].astype(idt)))
+                check(f"perm val {idt} {balanced}", np.array_equal(h(lval), want[2][a:b]))
+                check(f"perm off {idt} {balanced}", int(offs[rank]) == a and int(offs[-1]) == len(col))
+        # every rank ends up with the whole matrix
+        grp, lcol, lval, _, _ = sharded.permute_csr_sharded(n, n, d(rp), d(col), d(val), d(order), d(order), comm=comm,
+                                                            gather_entries=True)
+        check("perm gather", np.array_equal(h(lcol), want[1]) and np.array_equal(h(lval), want[2]))
+        # pattern-only matrix, row order only (the segmented-copy path inside the shard)
+        w2 = orc.permute_csr(rp, col, None, order, None)
+        grp, lcol, lval, (lo, hi), _ = sharded.permute_csr_sharded(n, n, d(rp), d(col), None, d(order), None, comm=comm)
+        check("rowwise", np.array_equal(h(grp), w2[0]) and np.array_equal(h(lcol), w2[1][w2[0][lo]:w2[0][hi]]) and lval is None)
+        # COO -> CSR by row range (ragged ranges: one rank gets most rows, an empty range too)
+        row, col2, val2 = orc.csr_to_coo(rp, col, val)
+        for ranges in (None, [(0, 5), (5, n)], [(0, 0), (0, n)]):
+            grp, lcol, lval, (lo, hi), offs = sharded.coo_to_csr_sharded(n, n, d(row), d(col2), d(val2), ranges=ranges,
+                                                                         comm=comm)
+            a, b = int(rp[lo]), int(rp[hi])
+            check(f"coo rp {ranges}", np.array_equal(h(grp), rp))
+            check(f"coo col {ranges}", np.array_equal(h(lcol), col[a:b]) and np.array_equal(h(lval), val[a:b]))
+        comm.close()
+        q.put((rank, ok, notes))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, False, [repr(e), traceback.format_exc()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_steps_two_ranks_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29800 + os.getpid() % 150
+    ctx = mp.get_context("spawn")  # fresh interpreters: nothing GPU-related is inherited
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_child, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, notes in results:
+        assert ok, f"rank {rank}: {notes}"
+
+
+def test_rccl_communicator_single_rank():
+    """The RCCL flavour of the communicator (librccl loaded by the C ABI, ncclCommInitRank / ncclAllGather called
+    from C++) on the one GPU of this box: a world of one rank, whole-matrix result compared with the oracle."""
+    import ctypes as C
+    from orc import Oracle
+    from sparsebase_amd import capi, ops, synth
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    lib = capi.load()
+    buf = C.create_string_buffer(capi.COMM_ID_BYTES)
+    assert lib.sbx_comm_unique_id(buf) == capi.SBX_OK
+    c = C.c_void_p()
+    assert lib.sbx_comm_create_rccl(0, 0, 1, buf, C.byref(c)) == capi.SBX_OK
+    comm = ops.Comm(lib, c)
+    try:
+        orc = Oracle()
+        rp, col = synth.rmat_symmetric(12, 8, seed=3)
+        n = len(rp) - 1
+        val = (np.arange(len(col)) % 17).astype(np.float32)
+        order = synth.random_permutation(n, 2)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        grp, lcol, lval, offs = ops.permute_csr_sharded(comm, n, n, d(rp), d(col), d(val), d(order), d(order))
+        want = orc.permute_csr(rp, col, val, order, order)
+        assert np.array_equal(grp.cpu().numpy(), want[0]) and np.array_equal(lcol.cpu().numpy(), want[1])
+        assert np.array_equal(lval.cpu().numpy(), want[2]) and offs == [0, len(col)]
+        row, col2, val2 = orc.csr_to_coo(rp, col, val)
+        grp, lcol, lval, offs = ops.coo_to_csr_sharded(comm, n, n, d(row), d(col2), d(val2))
+        assert np.array_equal(grp.cpu().numpy(), rp) and np.array_equal(lcol.cpu().numpy(), col)
+    finally:
+        comm.close()
