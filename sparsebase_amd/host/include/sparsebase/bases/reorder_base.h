@@ -54,6 +54,22 @@ class ReorderBase {
                                  bool convert_input, bool convert_output = false) {
     return Permute2DRowColumnWise<Ret>(ordering, ordering, format, contexts, convert_input, convert_output);
   }
+  // Permute2D over the GPUs of a node, one process per GPU (no reference counterpart): every rank holds
+  // the same HIPCSR and ordering, permutes its own new-row range and gets the whole row_ptr by all-gather.
+  template <typename I, typename N, typename V>
+  static permute::ShardedHIPCSR<I, N, V> *Permute2DSharded(I *ordering, format::HIPCSR<I, N, V> *format,
+                                                           context::HIPCommunicator &comm,
+                                                           const int64_t *row_splits = nullptr) {
+    return Permute2DRowColumnWiseSharded(ordering, ordering, format, comm, row_splits);
+  }
+  template <typename I, typename N, typename V>
+  static permute::ShardedHIPCSR<I, N, V> *Permute2DRowColumnWiseSharded(I *row_ordering, I *col_ordering,
+                                                                        format::HIPCSR<I, N, V> *format,
+                                                                        context::HIPCommunicator &comm,
+                                                                        const int64_t *row_splits = nullptr) {
+    permute::PermuteOrderTwo<I, N, V> perm(row_ordering, col_ordering);
+    return perm.GetPermutationSharded(format, comm, row_splits);
+  }
   template <template <typename, typename, typename> typename Ret = format::FormatOrderTwo, typename I, typename N,
             typename V>
   static std::pair<std::vector<F2<I, N, V> *>, Ret<I, N, V> *> Permute2DCached(

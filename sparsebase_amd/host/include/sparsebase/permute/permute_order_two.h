@@ -6,9 +6,31 @@
 // Unlike the reference (:76-77) the returned format OWNS its arrays.
 #ifndef SPARSEBASE_PERMUTE_PERMUTE_ORDER_TWO_H_
 #define SPARSEBASE_PERMUTE_PERMUTE_ORDER_TWO_H_
+#include <vector>
+
+#include "sparsebase/context/hip_communicator.h"
 #include "sparsebase/permute/permuter.h"
 
 namespace sparsebase::permute {
+
+// One rank's part of a row-sharded permuted CSR: the WHOLE row_ptr (n + 1 entries) plus the col / vals
+// of the rank's own new rows [row_begin, row_end), all in the rank's HBM; entry_offsets[r] is where rank r's entries
+// start in the global entry space (entry_offsets[world] = nnz).
+template <typename IDType, typename NNZType, typename ValueType>
+struct ShardedHIPCSR {
+  IDType n = 0, m = 0;
+  int64_t row_begin = 0, row_end = 0;
+  std::vector<int64_t> entry_offsets;
+  format::HIPArray<NNZType> *row_ptr = nullptr;
+  format::HIPArray<IDType> *col = nullptr;
+  format::HIPArray<typename std::conditional<std::is_same<ValueType, void>::value, char, ValueType>::type> *vals = nullptr;
+  int64_t local_nnz(int rank) const { return entry_offsets[rank + 1] - entry_offsets[rank]; }
+  ~ShardedHIPCSR() {
+    delete row_ptr;
+    delete col;
+    delete vals;
+  }
+};
 
 template <typename IDType>
 struct PermuteOrderTwoParams : utils::Parameters {
@@ -88,6 +110,61 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
     DeviceResult r = Run(v, params);
     return new format::HIPCSR<IDType, NNZType, ValueType>(v.n, v.m, (NNZType)v.nnz, r.row_ptr, r.col, r.vals,
                                                           context::HIPContext(v.dev->id()), format::kOwned, true);
+  }
+
+ public:
+  // The sharded form of GetPermutation (one call per rank, every rank holding the same HIPCSR and order vectors):
+  // this rank permutes its own new-row range and the ranks all-gather row_ptr (sbx_permute_csr_sharded).
+  // row_splits: world + 1 new-row boundaries, or nullptr for equal ranges.  Caller owns the result.
+  ShardedHIPCSR<IDType, NNZType, ValueType> *GetPermutationSharded(format::HIPCSR<IDType, NNZType, ValueType> *csr,
+                                                                    context::HIPCommunicator &comm,
+                                                                    const int64_t *row_splits = nullptr) {
+    static_assert(sizeof(IDType) == sizeof(NNZType), "index and offset types of one width");
+    auto *params = static_cast<PermuteOrderTwoParams<IDType> *>(this->params_.get());
+    auto v = reorder::detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(csr);
+    auto &dev = *v.dev;
+    const int rank = comm.rank(), world = comm.world();
+    std::vector<int64_t> splits(world + 1);
+    for (int r = 0; r <= world; r++)
+      splits[r] = row_splits ? row_splits[r] : (int64_t)v.n / world * r + std::min<int64_t>(r, (int64_t)v.n % world);
+    IDType *d_ro = params->row_order ? dev.Upload(params->row_order, (size_t)v.n) : nullptr;
+    IDType *d_co = nullptr;
+    if (params->col_order) d_co = (params->col_order == params->row_order && v.n == v.m)
+                                      ? d_ro
+                                      : dev.Upload(params->col_order, (size_t)v.m);
+    int64_t cap = 0;
+    int rc = sbx_permute_csr_rows_nnz(dev.handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, d_ro, splits[rank],
+                                      splits[rank + 1], &cap);
+    typedef typename std::conditional<std::is_same<ValueType, void>::value, char, ValueType>::type Stored;
+    NNZType *rp = nullptr;
+    IDType *col = nullptr;
+    Stored *vals = nullptr;
+    auto *out = new ShardedHIPCSR<IDType, NNZType, ValueType>();
+    out->entry_offsets.assign(world + 1, 0);
+    if (rc == SBX_OK) {
+      rp = (NNZType *)dev.Malloc(((size_t)v.n + 1) * sizeof(NNZType));
+      col = (IDType *)dev.Malloc((size_t)(cap ? cap : 1) * sizeof(IDType));
+      if (v.vals) vals = (Stored *)dev.Malloc((size_t)(cap ? cap : 1) * hip::ValueBytes<ValueType>());
+      rc = sbx_permute_csr_sharded(dev.handle(), comm.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), v.n,
+                                   v.m, v.nnz, v.row_ptr, v.col, v.vals, d_ro, d_co, splits.data(), rp, col, vals, cap,
+                                   out->entry_offsets.data());
+    }
+    if (d_co && d_co != d_ro) dev.Free(d_co);
+    if (d_ro) dev.Free(d_ro);
+    if (rc != SBX_OK) {
+      if (rp) dev.Free(rp);
+      if (col) dev.Free(col);
+      if (vals) dev.Free(vals);
+      delete out;
+      dev.Check(rc);
+    }
+    context::HIPContext ctx(dev.id());
+    out->n = v.n, out->m = v.m;
+    out->row_begin = splits[rank], out->row_end = splits[rank + 1];
+    out->row_ptr = new format::HIPArray<NNZType>((size_t)v.n + 1, rp, ctx, format::kOwned);
+    out->col = new format::HIPArray<IDType>((size_t)cap, col, ctx, format::kOwned);
+    if (vals) out->vals = new format::HIPArray<Stored>((size_t)cap, vals, ctx, format::kOwned);
+    return out;
   }
 };
 

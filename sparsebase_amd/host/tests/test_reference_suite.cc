@@ -617,6 +617,71 @@ TEST(PermuteOrderTwo, RowColWiseAndInverse) {
   delete[] inv_c;
 }
 
+// the sharded form through the C++ API: a world of one rank over RCCL, and two "ranks" of this process
+// (on this box's one GPU) whose all-gather hook exchanges through host memory — both against the plain Permute2D
+struct TwoRankHook {  // the two ranks run one after the other: what each contributed to exchange c is recorded in
+  std::vector<char> sent[2][2];  // pass c and replayed from pass c + 1 on (an operator call makes two exchanges)
+  size_t call = 0;
+  int rank = 0, replay = 0;  // exchanges [0, replay) are real in this pass
+};
+static int two_rank_allgather(void *user, const void *send, void *recv, size_t bytes, void *) {
+  auto *hk = static_cast<TwoRankHook *>(user);
+  auto &dev = hip::Device::Get(hip::DefaultDevice());
+  const size_t c = hk->call++;
+  if ((int)c < hk->replay) {
+    for (int r = 0; r < 2; r++) dev.ToDevice((char *)recv + bytes * r, hk->sent[r][c].data(), bytes);
+    return SBX_OK;
+  }
+  hk->sent[hk->rank][c].resize(bytes);
+  dev.ToHost(hk->sent[hk->rank][c].data(), send, bytes);
+  std::vector<char> zeros(bytes, 0);  // the other rank's part is not known yet
+  for (int r = 0; r < 2; r++)
+    dev.ToDevice((char *)recv + bytes * r, r == hk->rank ? hk->sent[r][c].data() : zeros.data(), bytes);
+  return SBX_OK;
+}
+
+TEST(PermuteOrderTwo, ShardedMatchesWhole) {
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  context::HIPContext gpu(hip::DefaultDevice());
+  auto *dcsr = global_csr.Convert<format::HIPCSR>(&gpu);
+  auto check_rows = [&](permute::ShardedHIPCSR<int, int, int> *sh, int rank) {
+    auto &dev = hip::Device::Get(gpu.device_id);
+    int *rp = dev.Download(sh->row_ptr->get_vals(), (size_t)n + 1);
+    EXPECT_TRUE(same(rp, rc_row_ptr, n + 1));
+    const int64_t a = rc_row_ptr[sh->row_begin], k = sh->local_nnz(rank);
+    EXPECT_TRUE(sh->entry_offsets[rank] == a && k == rc_row_ptr[sh->row_end] - a);
+    int *c = dev.Download(sh->col->get_vals(), (size_t)k), *v = dev.Download(sh->vals->get_vals(), (size_t)k);
+    EXPECT_TRUE(same(c, rc_cols + a, (int)k) && same(v, rc_vals + a, (int)k));
+    delete[] rp;
+    delete[] c;
+    delete[] v;
+  };
+  {  // one rank, RCCL
+    context::HIPCommunicator comm(gpu, 0, 1, context::HIPCommunicator::NewId());
+    permute::PermuteOrderTwo<int, int, int> t(r_reorder_vector, c_reorder_vector);
+    auto *sh = t.GetPermutationSharded(dcsr, comm);
+    EXPECT_TRUE(sh->row_begin == 0 && sh->row_end == n);
+    check_rows(sh, 0);
+    delete sh;
+  }
+  {  // two ranks played one after the other; pass 2 sees both exchanges (nnz totals, row_ptr segments) for real
+    TwoRankHook hk;
+    const int64_t splits[3] = {0, n / 3, n};
+    for (int pass = 0; pass < 3; pass++) {
+      hk.replay = pass;
+      for (int rank = 0; rank < 2; rank++) {
+        hk.rank = rank;
+        hk.call = 0;
+        context::HIPCommunicator comm(gpu, rank, 2, two_rank_allgather, &hk);
+        auto *sh = bases::ReorderBase::Permute2DRowColumnWiseSharded(r_reorder_vector, c_reorder_vector, dcsr, comm, splits);
+        if (pass == 2) check_rows(sh, rank);
+        delete sh;
+      }
+    }
+  }
+  delete dcsr;
+}
+
 TEST(PermuteOrderOne, ArrayAndInversePermutation) {
   auto *inv = bases::ReorderBase::InversePermutation(perm_array, 3);
   EXPECT_TRUE(same(inv, inverse_perm_array, 3));
