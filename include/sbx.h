@@ -252,6 +252,8 @@ typedef struct sbx_rcm_stats {
   int64_t edges_scanned;    /* adjacency entries visited (all sweeps)       */
   int64_t edges_scanned_bottom_up; /* ... of which by the bottom-up kernel   */
   int64_t largest_component;
+  int64_t reference_sweeps; /* sweeps the reference's serial algorithm runs over the largest component:
+                               pseudo-peripheral iterations (rcm_reorder.cc:34) + 1 — the B of the roofline figure */
 } sbx_rcm_stats;
 int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,
                     const void *row_ptr, const void *col, void *inv_perm_out,

@@ -406,7 +406,6 @@ extern "C" int sbx_profile_enable(sbx_handle_t h, int on) {
       h->prof_ms[i] = 0.0;
       h->prof_launches[i] = 0;
       h->prof_bytes[i] = 0;
-    h->prof_bytes[i] = 0;
     }
   }
   h->prof_on = on != 0;

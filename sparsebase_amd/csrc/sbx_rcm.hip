@@ -64,8 +64,10 @@ struct RcmDev {
   // hand-off state of the persistent small-level kernel
   unsigned sl_off, sl_fsize, sl_level, sl_total;
   unsigned sl_status;           // SL_DONE / SL_STOP_READY / SL_STOP_EXPANDED
-  unsigned sl_pad;
+  unsigned unsym;               // the pattern is not structurally symmetric (a BFS cannot reach its component)
   unsigned long long sl_edges;  // degree sum of the levels the kernel ordered
+  unsigned n_components;        // statistics: union-find roots (isolated vertices included) / vertices with an empty row
+  unsigned n_empty_rows;
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -198,9 +200,10 @@ __global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, c
 // once, so the giant's counter word is not hammered by one atomic per wave.
 __global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I *parent, I *__restrict__ csize,
                                                      int64_t n, const unsigned *__restrict__ cbits, I first_root,
-                                                     I first_size) {
+                                                     I first_size, int phase, RcmDev *__restrict__ dv) {
   __shared__ I s_major;
   __shared__ unsigned s_major_cnt;
+  __shared__ unsigned s_empty[4];
   int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (threadIdx.x == 0) {
@@ -208,18 +211,37 @@ __global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I
     s_major_cnt = 0;
   }
   __syncthreads();
+  if (phase == 0) {
+    // Phase 0: a vertex with an empty row that is its own root starts its component's count with a plain
+    // (coalesced) store.  On a symmetric pattern it is isolated and that is all; on an unsymmetric one other
+    // vertices may point at it and add themselves in phase 1 — a launch later, so the store cannot race them.
+    unsigned empty = 0;
+    for (int64_t v = v0; v < n; v += stride) {
+      const bool in_first = (cbits[v >> 5] >> (v & 31)) & 1u;
+      if (rp[v] == rp[v + 1]) {
+        empty++;
+        if (!in_first && parent[v] == (I)v) csize[v] = 1;
+      }
+    }
+    empty = sbx_block_sum<unsigned, 256>(empty, s_empty);
+    if (threadIdx.x == 0 && empty) atomicAdd(&dv->n_empty_rows, empty);
+    return;
+  }
+  bool unsym = false;
   for (int64_t vb = v0 - sbx_lane(); vb < n; vb += stride) {
     const int64_t v = vb + sbx_lane();
     I root = -1;
     if (v < n) {
       if ((cbits[v >> 5] >> (v & 31)) & 1u) {
         parent[v] = first_root;  // labelled by the first sweep; its size is known
-      } else if (rp[v] == rp[v + 1]) {
-        csize[v] = 1;  // isolated: its own root and nobody else's — a plain (coalesced) store, no atomic
+      } else if (rp[v] == rp[v + 1] && parent[v] == (I)v) {
+        // counted in phase 0
       } else {
         root = parent[v];
         while (root != parent[root]) root = parent[root];
         parent[v] = root;
+        // a vertex the first sweep did not reach cannot hang under one it did reach unless some edge has no mirror
+        if ((cbits[root >> 5] >> (root & 31)) & 1u) unsym = true;
       }
     }
     uint64_t todo = __ballot(root >= 0);
@@ -240,6 +262,7 @@ __global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I
       todo &= ~same;
     }
   }
+  if (__any(unsym) && sbx_lane() == 0) dv->unsym = 1;
   __syncthreads();
   if (threadIdx.x == 0 && s_major_cnt) atomicAdd(&csize[s_major], (I)s_major_cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0 && first_size > 0) csize[first_root] = first_size;
@@ -250,15 +273,20 @@ __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, c
                                                   const I *__restrict__ cbase, I *__restrict__ inv,
                                                   I *__restrict__ small_list, I *__restrict__ large_list, int64_t n,
                                                   RcmDev *__restrict__ dv) {
+  __shared__ unsigned s_roots[4];
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned roots = 0;
   for (; v < n; v += stride) {
     if (label[v] != (I)v) continue;  // not a root
+    roots++;
     const I sz = csize[v];
     if (sz == 1) inv[v] = cbase[v];
     else if (sz <= RCM_SMALL) small_list[atomicAdd(&dv->n_small, 1u)] = (I)v;
     else large_list[atomicAdd(&dv->n_large, 1u)] = (I)v;
   }
+  roots = sbx_block_sum<unsigned, 256>(roots, s_roots);  // one add per workgroup: the counter word is hot otherwise
+  if (threadIdx.x == 0 && roots) atomicAdd(&dv->n_components, roots);
 }
 
 // ------------------------------------------------------------------ small components
@@ -276,6 +304,7 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
   // --- pseudo-peripheral search (rcm_reorder.cc:22-81)
   I root = start;
   int prev_ecc = -1, ecc = 0;
+  int reached = 0;  // vertices in q after the last sweep (all of them carry a distance until reset)
   while (prev_ecc != ecc) {
     prev_ecc = ecc;
     int head = 0, tail = 0;
@@ -293,8 +322,11 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
         }
       }
     }
+    reached = tail;
+    if (tail != (int)sz) break;  // not the whole (weakly connected) component: the pattern has an edge without a mirror
     if (head == ecc + 1) break;  // one vertex per level
     if (prev_ecc != ecc) {
+      reached = 0;  // the loop below resets every distance
       bool have = false;
       I best = 0;
       for (int i = 0; i < head; i++) {
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
       }
     }
   }
-  for (int i = 0; i < sz; i++) dist[q[i]] = UNSEEN;  // q holds the whole component
+  for (int i = 0; i < reached; i++) dist[q[i]] = UNSEEN;
   // --- Cuthill-McKee BFS (rcm_reorder.cc:118-144); dist doubles as the visited mark
   int head = 0, tail = 0;
   dist[root] = 0;
@@ -333,6 +365,11 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
         q[p] = v;
       }
     }
+  }
+  if (tail != (int)sz) {  // a BFS that cannot reach its component: report, leave inv alone (q beyond tail is stale)
+    dv->unsym = 1;
+    for (int i = 0; i < tail; i++) dist[q[i]] = UNSEEN;
+    return;
   }
   for (int i = 0; i < sz; i++) inv[q[i]] = base + (sz - 1 - i);  // reverse + invert (:146-160)
 }
@@ -794,7 +831,6 @@ __global__ __launch_bounds__(256) void k_level_emit(const uint64_t *__restrict__
     dv->nf = 0;
     dv->n_heavy = 0;
     dv->hub_overflow = 0;
-  dv->hub_overflow = 0;
     dv->fedges = 0;
   }
 }
@@ -957,7 +993,6 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
     dv->nf = 0;
     dv->n_heavy = 0;
     dv->hub_overflow = 0;
-  dv->hub_overflow = 0;
     dv->fedges = 0;
   }
 }
@@ -1321,8 +1356,6 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__
       dv->nf = 0;
       dv->n_heavy = 0;
       dv->hub_overflow = 0;
-    dv->hub_overflow = 0;
-  dv->hub_overflow = 0;
     }
     atomicAdd(&dv->edges, scanned);
   }
@@ -1680,8 +1713,9 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
               (const unsigned *)cbits, dv);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
               (const I *)big_list, (const RcmDev *)dv);
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), rp, label, csize, n, (const unsigned *)cbits,
-              v0 >= 0 ? v0 : (I)0, (I)r0.count);
+  for (int phase = 0; phase < 2; phase++)
+    SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(gn), dim3(256), rp, label, csize, n, (const unsigned *)cbits,
+                v0 >= 0 ? v0 : (I)0, (I)r0.count, phase, dv);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
   SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gn), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
@@ -1689,6 +1723,10 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
+  if (hd.unsym)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG,
+             "sbx_rcm_reorder: the pattern is not structurally symmetric (a vertex hangs under the first component "
+             "without being reachable from it); RCM is defined on symmetric patterns");
   b.label = label;
   const bool first_is_large = r0.count > (unsigned)RCM_SMALL;
   if (v0 >= 0 && !first_is_large) {
@@ -1702,7 +1740,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_LAUNCH_CHECK(h);
   }
   // (4) large components: host-driven level-synchronous BFS
-  int64_t sweeps_max = 0, levels_max = 0, largest = 0;
+  int64_t sweeps_max = 0, levels_max = 0, largest = 0, ref_sweeps_max = 0;
   if (hd.n_large) {
     std::vector<I> roots(hd.n_large), sizes(hd.n_large), bases(hd.n_large);
     SBX_HIP(h, hipMemcpyAsync(roots.data(), large_list, hd.n_large * sizeof(I), hipMemcpyDeviceToHost, h->stream));
@@ -1780,7 +1818,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         levels += r.levels;
       }
       if ((int64_t)r.count != (int64_t)sizes[c])
-        SBX_FAIL(h, SBX_ERR_INTERNAL,
+        SBX_FAIL(h, SBX_ERR_BAD_ARG,
                  "sbx_rcm_reorder: BFS reached %u of %d vertices of a component (pattern not symmetric?)", r.count,
                  sizes[c]);
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
@@ -1792,13 +1830,20 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         largest = sizes[c];
         sweeps_max = sweeps;
         levels_max = levels;
+        // what the reference's serial algorithm runs on this component: its pseudo-peripheral sweeps (a speculative
+        // Cuthill-McKee sweep that ended the search stood in for the last of them) + the Cuthill-McKee sweep
+        ref_sweeps_max = candidate + (cm_done ? 1 : 0) + 1;
       }
     }
   }
   SBX_TRY(join_ranks());  // inputs without a large component never ran a Cuthill-McKee sweep
+  RcmDev fin;  // (also the synchronisation point of the call)
+  SBX_TRY(sbx_readback(h, &fin, dv, sizeof(RcmDev)));
+  if (fin.unsym)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG,
+             "sbx_rcm_reorder: the pattern is not structurally symmetric (a BFS cannot reach its whole component); "
+             "RCM is defined on symmetric patterns");
   if (stats_host) {
-    RcmDev fin;
-    SBX_TRY(sbx_readback(h, &fin, dv, sizeof(RcmDev)));
     stats_host->small_components = hd.n_small;
     stats_host->large_components = hd.n_large;
     stats_host->bfs_sweeps = sweeps_max;
@@ -1806,10 +1851,9 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     stats_host->edges_scanned = (int64_t)fin.edges;
     stats_host->edges_scanned_bottom_up = (int64_t)fin.edges_bu;
     stats_host->largest_component = largest;
-    stats_host->components = -1;  // filled by callers that need it (count of roots); not tracked on device
-    stats_host->isolated = -1;
-  } else {
-    SBX_HIP(h, hipStreamSynchronize(h->stream));
+    stats_host->components = (int64_t)hd.n_components;
+    stats_host->isolated = (int64_t)hd.n_empty_rows;
+    stats_host->reference_sweeps = ref_sweeps_max;
   }
   return SBX_OK;
 }

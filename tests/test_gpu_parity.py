@@ -842,3 +842,37 @@ def test_rcm_many_midsize_components(ops, oracle, seed):
     got, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
     assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
     assert stats["large_components"] >= 10
+
+
+def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
+    """Directed inputs (an edge list read with read_undirected=False): a BFS cannot reach its weakly connected
+    component.  The reference leaks stale distances there; here every such input must end in a clean error —
+    never an out-of-bounds write or a non-permutation returned as success."""
+    from sparsebase_amd import capi
+    g = np.random.default_rng(77)
+    cases = []
+    # (a) small components of directed chains 0 -> 1 -> 2 ...: from the smallest id everything is reachable,
+    #     reversed chains (k -> k-1) are not: the sweep from the smallest vertex reaches nothing else
+    n = 4000
+    src = np.arange(1, n)
+    dst = src - 1
+    keep = (src % 50) != 0
+    cases.append(synth.csr_from_edges(n, src[keep], dst[keep]))
+    # (b) a random directed graph: big weak components, poor directed reachability
+    n = 30000
+    cases.append(synth.csr_from_edges(n, g.integers(0, n, 4 * n), g.integers(0, n, 4 * n)))
+    # (c) a directed star into vertex 0 plus a symmetric rest: vertices hang under the first component
+    n = 2000
+    s1, d1 = synth.symmetrize(np.arange(0, 500), np.arange(1, 501))
+    cases.append(synth.csr_from_edges(n, np.concatenate([s1, np.arange(600, 900)]), np.concatenate([d1, np.zeros(300, int)])))
+    for rp, col in cases:
+        with pytest.raises(capi.SbxError) as e:
+            ops.rcm_reorder(dev(rp), dev(col))
+        assert e.value.status == 1 and "symmetric" in str(e.value)
+    # the library stays usable afterwards, and symmetric inputs are unaffected
+    rp, col = synth.random_symmetric_graph(5000, seed=3)
+    assert np.array_equal(host(ops.rcm_reorder(dev(rp), dev(col))), oracle.rcm_reorder(rp, col))
+    _, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
+    deg = np.diff(rp)
+    assert stats["isolated"] == int((deg == 0).sum()) and stats["components"] >= stats["isolated"] + 1
+    assert stats["reference_sweeps"] >= 2 or stats["large_components"] == 0
