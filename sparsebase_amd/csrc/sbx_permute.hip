@@ -1247,7 +1247,16 @@ __global__ __launch_bounds__(1024) void k_permute_rows_radix(
       s_key[p] = c;
     }
     __syncthreads();
-    lds_radix_sort<V, HASV, false, THREADS, ITEMS>(s_key, nullptr, s_val, s_whist, s_scan, CAP, col_bits, 0);
+    bool unsorted = false;  // an ordered row is left alone
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * THREADS + tid;
+      if (p > 0 && p < len && s_key[p] < s_key[p - 1]) unsorted = true;
+    }
+    if (__syncthreads_or(unsorted)) {
+      if (tid == 0) st->any_unsorted = 1;
+      lds_radix_sort<V, HASV, false, THREADS, ITEMS>(s_key, nullptr, s_val, s_whist, s_scan, CAP, col_bits, 0);
+    }
     bool dup = false;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {

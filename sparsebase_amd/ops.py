@@ -336,8 +336,8 @@ def permute_csr_rows(n, m, row_ptr, col, val, row_order, col_order, row_begin, r
     if capacity is None:  # exactly the shard's entries, not the whole matrix's
         capacity = permute_csr_rows_nnz(n, row_ptr, row_order, row_begin, row_end)
     rpo = torch.empty(nr + 1, dtype=row_ptr.dtype, device=row_ptr.device)
-    co = torch.empty(capacity, dtype=col.dtype, device=col.device)
-    vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+    co = torch.empty(max(capacity, 1), dtype=col.dtype, device=col.device)  # (an empty slab still needs an address)
+    vo = None if val is None else torch.empty(max(capacity, 1), dtype=val.dtype, device=val.device)
     got = C.c_int64(0)
     hd.check(hd.lib.sbx_permute_csr_rows(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
                                          _p(val), _p(row_order), _p(col_order), row_begin, row_end, _p(rpo), _p(co),
@@ -436,8 +436,8 @@ def permute_csr_sharded(comm, n, m, row_ptr, col, val, row_order, col_order, ran
             lo, hi = ranges[rank.value] if ranges is not None else _equal_range(n, world.value, rank.value)
             capacity = permute_csr_rows_nnz(n, row_ptr, row_order, lo, hi)
         rpo = torch.empty(n + 1, dtype=row_ptr.dtype, device=row_ptr.device)
-        co = torch.empty(capacity, dtype=col.dtype, device=col.device)
-        vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+        co = torch.empty(max(capacity, 1), dtype=col.dtype, device=col.device)
+        vo = None if val is None else torch.empty(max(capacity, 1), dtype=val.dtype, device=val.device)
     else:
         rpo, co, vo = out
         capacity = co.numel()
@@ -461,8 +461,8 @@ def coo_to_csr_sharded(comm, n, m, row, col, val, ranges=None, out=None, capacit
             b = torch.searchsorted(row, torch.tensor([lo, hi], dtype=row.dtype, device=row.device), right=False)
             capacity = int(b[1] - b[0])
         rpo = torch.empty(n + 1, dtype=row.dtype, device=row.device)
-        co = torch.empty(capacity, dtype=col.dtype, device=col.device)
-        vo = None if val is None else torch.empty(capacity, dtype=val.dtype, device=val.device)
+        co = torch.empty(max(capacity, 1), dtype=col.dtype, device=col.device)
+        vo = None if val is None else torch.empty(max(capacity, 1), dtype=val.dtype, device=val.device)
     else:
         rpo, co, vo = out
         capacity = co.numel()
