@@ -118,3 +118,73 @@ def test_c5_gray_keys_100m_banded(ops, oracle, half_bandwidth):
         assert np.array_equal(deg.cpu().numpy(), wdeg)
         assert np.array_equal(key.cpu().numpy().view(np.uint64), wkey)
         assert list(counts) == wcounts.tolist()
+
+
+@pytest.mark.parametrize("half_bandwidth", [64, (1 << 22) // 16])
+def test_c5_gray_end_to_end_100m_banded(oracle, tmp_path, half_bandwidth):
+    """BASELINE config 5 END TO END: GrayReorder through the C++ API (device key stage + the host ordering stage over
+    4 M row keys, host/bin/reorder_cli) against the oracle's whole ordering, both half-bandwidths of SURVEY §8d
+    (w = 64 takes the reference's "highly banded" early-out, w = m/16 the full bitmap path) and both parameter sets
+    ((BitSize32, 10, 4) and the example's (BitSize16, 20, (N/n)/16), examples/gray_order/gray_order.cc:52-54)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "sparsebase_amd", "host", "bin", "reorder_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "sparsebase_amd", "host"), "all"])
+    n = 1 << 22
+    rp, col = (t.cpu().numpy() for t in synth.banded_symmetric_torch(n, half_bandwidth, per_row=12, seed=2))
+    a, b, o = (str(tmp_path / x) for x in ("rp.bin", "col.bin", "out.bin"))
+    rp.tofile(a)
+    col.tofile(b)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "sparsebase_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for params in ((32, 10, 4), (16, 20, max(1, (len(col) // n) // 16))):
+        subprocess.run([cli, "gray", a, b, o, str(n), str(n), *map(str, params), "--device"], check=True, env=env,
+                       timeout=900)
+        got = np.fromfile(o, np.int32)
+        want = oracle.gray_reorder(rp, col, n, *params)
+        assert np.array_equal(got, want), (half_bandwidth, params)
+
+
+def test_c4_one_of_eight_shards_of_1b_nnz(ops):
+    """BASELINE config 4's per-rank workload on this one GPU: the scale-25 RMAT instance (~1.18 B nnz, 33.5 M rows),
+    a seeded random permutation, one of the 8 new-row shards through sbx_permute_csr_rows — the properties of
+    test_c3_permute_100m_properties on the shard plus the consistency of the 8 shard sizes / offsets.  (The stitch of
+    row_ptr over the communicator is tests/test_sharded_gpu.py's; RCCL across 8 GPUs is bench.py --gpus 8's.)"""
+    from sparsebase_amd import sharded
+    rp, col = synth.rmat_symmetric_torch(25, 18, seed=1)
+    n, nnz = rp.numel() - 1, col.numel()
+    assert nnz > 1_000_000_000 and n == 1 << 25
+    val = (torch.arange(nnz, device="cuda", dtype=torch.int32) % 1021).to(torch.float32)
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).to(torch.int32)
+    ranges = sharded.row_ranges(n, 8)
+    sizes = [ops.permute_csr_rows_nnz(n, rp, perm, a, b) for a, b in ranges]
+    assert sum(sizes) == nnz
+    deg_old = (rp[1:] - rp[:-1])
+    deg_new = torch.empty_like(deg_old)
+    deg_new[perm.long()] = deg_old                       # length of every new row
+    offsets = torch.zeros(9, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(torch.tensor(sizes), 0)
+    for r in (3,):
+        a, b = ranges[r]
+        assert int(deg_new[a:b].long().sum()) == sizes[r]
+        srp, scol, sval = ops.permute_csr_rows(n, n, rp, col, val, perm, perm, a, b)
+        k = sizes[r]
+        assert scol.numel() == k and int(srp[0]) == 0 and int(srp[-1]) == k
+        assert torch.equal((srp[1:] - srp[:-1]), deg_new[a:b])                 # row lengths moved with the rows
+        assert ops.csr_rows_sorted(srp, scol)                                  # every row of the shard sorted
+        # the shard's entries are exactly the relabelled entries of its old rows: column and payload checksums
+        in_shard = (perm >= a) & (perm < b)                                    # per old row
+        entry_in = torch.repeat_interleave(in_shard, deg_old.long())           # per old entry
+        src_cols = col[entry_in]
+        assert src_cols.numel() == k
+        assert int(scol.long().sum()) == int(perm[src_cols.long()].long().sum())
+        assert float(sval.double().sum()) == float(val[entry_in].double().sum())
+        del entry_in, src_cols
+        # global row_ptr of the shard's rows = rebased row_ptr + the shard's offset
+        want_rp = torch.zeros(b - a + 1, dtype=torch.int64, device="cuda")
+        want_rp[1:] = torch.cumsum(deg_new[a:b].long(), 0)
+        assert torch.equal(srp.long(), want_rp) and int(offsets[r]) == int(deg_new[:a].long().sum())
+        # row-wise only (the segmented copy): same lengths, every row still sorted
+        rrp, rcol, _ = ops.permute_csr_rows(n, n, rp, col, val, perm, None, a, b)
+        assert torch.equal(rrp, srp) and ops.csr_rows_sorted(rrp, rcol)
