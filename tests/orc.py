@@ -45,7 +45,7 @@ def build_oracle():
 
 class Oracle:
     def __init__(self):
-        path = os.path.join(ORACLE_DIR, "libsbx_oracle.so")
+        path = os.environ.get("SBX_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libsbx_oracle.so")  # (make -C oracle asan)
         src = os.path.join(ORACLE_DIR, "sbx_oracle.cc")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build_oracle()
