@@ -19,7 +19,7 @@
 //   components      ECL-CC style union-find (hook larger root under smaller, so the
 //                   root IS the smallest vertex id), sizes by wave-aggregated atomics,
 //                   bases by one device scan;
-//   small comps     (<= RCM_SMALL vertices) one lane per component runs the serial
+//   small comps     (<= RCM_SMALL vertices; <= RCM_MID when many) one lane per component runs the serial
 //                   algorithm in its own slice of the output;
 //   large comps     level-synchronous BFS: wave-per-frontier-vertex expansion with
 //                   ballot-aggregated frontier append, atomicCAS claim + atomicMin of
@@ -39,6 +39,8 @@ namespace {
 
 typedef int32_t I;
 constexpr int RCM_SMALL = 64;        // components up to this size: one lane each
+constexpr int RCM_MID = 2048;        // ... and up to this size too when there are RCM_MID_BATCH or more of them: a mesh
+constexpr int RCM_MID_BATCH = 64;    // collection with 10^5 components would otherwise be ordered one by one from the host
 constexpr int RCM_LIGHT = 256;       // neighbours expanded by the discovering wave itself
 constexpr int RCM_CHUNK = 1024;      // hub neighbours per workgroup chunk
 constexpr int RCM_LDS_SORT = 4096;   // levels up to this size are sorted by one workgroup
@@ -56,6 +58,7 @@ struct RcmDev {
   alignas(128) unsigned long long edges_bu;  // adjacency entries scanned by the bottom-up kernel
   alignas(128) unsigned n_small;             // small components listed
   unsigned n_large;             // large components listed
+  unsigned n_mid;               // components of RCM_SMALL + 1 .. RCM_MID vertices listed
   unsigned n_cc_big;            // high-degree vertices queued by the CC hook kernel
   unsigned max_deg;
   unsigned root;                // current BFS root of the component being ordered
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I
 // classify components: singletons are final here; small / large roots are listed
 __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, const I *__restrict__ csize,
                                                   const I *__restrict__ cbase, I *__restrict__ inv,
-                                                  I *__restrict__ small_list, I *__restrict__ large_list, int64_t n,
-                                                  RcmDev *__restrict__ dv) {
+                                                  I *__restrict__ small_list, I *__restrict__ mid_list,
+                                                  I *__restrict__ large_list, int64_t n, RcmDev *__restrict__ dv) {
   __shared__ unsigned s_roots[4];
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, c
     const I sz = csize[v];
     if (sz == 1) inv[v] = cbase[v];
     else if (sz <= RCM_SMALL) small_list[atomicAdd(&dv->n_small, 1u)] = (I)v;
+    else if (sz <= RCM_MID) mid_list[atomicAdd(&dv->n_mid, 1u)] = (I)v;
     else large_list[atomicAdd(&dv->n_large, 1u)] = (I)v;
   }
   roots = sbx_block_sum<unsigned, 256>(roots, s_roots);  // one add per workgroup: the counter word is hot otherwise
@@ -292,13 +296,42 @@ __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, c
 // ------------------------------------------------------------------ small components
 // One lane runs the reference's serial algorithm for one component.  q = the
 // component's own slice of the order array, dist = BFS distances (UNSEEN = unvisited).
+// (degree, id) order of the children a parent discovered (rcm_reorder.cc:125-144 drains a min-heap of such pairs)
+__device__ __forceinline__ bool rcm_child_less(const I *__restrict__ rp, I a, I b) {
+  const I da = rp[a + 1] - rp[a], db = rp[b + 1] - rp[b];
+  return da < db || (da == db && a < b);
+}
+// in-place heapsort of a parent's children: hubs of mid-size components (a star of 2000 leaves) would cost an
+// insertion sort millions of moves in one lane
+__device__ void rcm_sort_children(const I *__restrict__ rp, I *a, int cnt) {
+  auto sift = [&](int root, int end) {
+    while (2 * root + 1 < end) {
+      int child = 2 * root + 1;
+      if (child + 1 < end && rcm_child_less(rp, a[child], a[child + 1])) child++;
+      if (!rcm_child_less(rp, a[root], a[child])) return;
+      const I t = a[root];
+      a[root] = a[child];
+      a[child] = t;
+      root = child;
+    }
+  };
+  for (int i = cnt / 2 - 1; i >= 0; i--) sift(i, cnt);
+  for (int end = cnt - 1; end > 0; end--) {
+    const I t = a[0];
+    a[0] = a[end];
+    a[end] = t;
+    sift(0, end);
+  }
+}
+
 __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, const I *__restrict__ col,
-                                                  const I *__restrict__ small_list, const I *__restrict__ csize,
-                                                  const I *__restrict__ cbase, unsigned *dist, I *order,
-                                                  I *__restrict__ inv, RcmDev *__restrict__ dv) {
+                                                  const I *__restrict__ list, unsigned count,
+                                                  const I *__restrict__ csize, const I *__restrict__ cbase,
+                                                  unsigned *dist, I *order, I *__restrict__ inv,
+                                                  RcmDev *__restrict__ dv) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= dv->n_small) return;
-  const I start = small_list[k];
+  if (k >= count) return;
+  const I start = list[k];
   const I base = cbase[start], sz = csize[start];
   I *q = order + base;
   // --- pseudo-peripheral search (rcm_reorder.cc:22-81)
@@ -352,14 +385,18 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
       const I v = col[j];
       if (dist[v] == UNSEEN) {
         dist[v] = 1;
-        // insertion into the (degree,id)-sorted run of u's children
-        const I dvv = rp[v + 1] - rp[v];
-        int p = tail++;
-        while (p > first) {
-          const I w = q[p - 1];
-          const I dw = rp[w + 1] - rp[w];
-          if (dw < dvv || (dw == dvv && w < v)) break;
-          q[p] = w;
+        q[tail++] = v;
+      }
+    }
+    const int kids = tail - first;
+    if (kids > 16) {
+      rcm_sort_children(rp, q + first, kids);
+    } else {
+      for (int i = first + 1; i < tail; i++) {  // insertion into the (degree,id)-sorted run of u's children
+        const I v = q[i];
+        int p = i;
+        while (p > first && rcm_child_less(rp, v, q[p - 1])) {
+          q[p] = q[p - 1];
           p--;
         }
         q[p] = v;
@@ -1396,6 +1433,16 @@ __global__ __launch_bounds__(256) void k_reset_visited(const I *__restrict__ q, 
   for (; j < cnt; j += stride) ppos[q[j]] = UNSEEN;
 }
 
+// (size, base) of the listed components, for the host loop
+__global__ __launch_bounds__(256) void k_comp_info(const I *__restrict__ roots, unsigned cnt, const I *__restrict__ csize,
+                                                   const I *__restrict__ cbase, I *__restrict__ sizes,
+                                                   I *__restrict__ bases) {
+  const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cnt) return;
+  sizes[c] = csize[roots[c]];
+  bases[c] = cbase[roots[c]];
+}
+
 __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q, unsigned cnt, I base,
                                                          I *__restrict__ inv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1600,7 +1647,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
 
   RcmDev *dv;
   uint32_t *dkey_a, *dkey_b, *did_a, *did_b, *drank;
-  I *label, *csize, *cbase, *small_list, *large_list, *big_list, *q, *nf_list;
+  I *label, *csize, *cbase, *small_list, *mid_list, *large_list, *big_list, *q, *nf_list;
   unsigned *dist, *ppos, *vbits, *fbits, *cbits, *lpos;
   I *q_small;
   uint64_t *ka, *kb, *heavy;
@@ -1615,6 +1662,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &cbase));
   SBX_TRY(sbx_salloc(h, (size_t)n, &small_list));
   SBX_TRY(sbx_salloc(h, (size_t)n, &large_list));
+  SBX_TRY(sbx_salloc(h, (size_t)n / (RCM_SMALL + 1) + 1, &mid_list));
   SBX_TRY(sbx_salloc(h, (size_t)n, &big_list));
   SBX_TRY(sbx_salloc(h, (size_t)n, &q));
   SBX_TRY(sbx_salloc(h, (size_t)n, &nf_list));
@@ -1719,7 +1767,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
   SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gn), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
-              small_list, large_list, n, dv);
+              small_list, mid_list, large_list, n, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
@@ -1728,36 +1776,53 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
              "sbx_rcm_reorder: the pattern is not structurally symmetric (a vertex hangs under the first component "
              "without being reachable from it); RCM is defined on symmetric patterns");
   b.label = label;
-  const bool first_is_large = r0.count > (unsigned)RCM_SMALL;
+  // Components of RCM_SMALL + 1 .. RCM_MID vertices: a few of them are ordered like the large ones (level-synchronous
+  // sweeps driven from the host: ~60 us per level, fine for a handful); from RCM_MID_BATCH on they join the batched
+  // kernel, one lane each — a collection of 10^5 meshes of a few hundred vertices is then one launch instead of
+  // 10^5 host-driven searches.
+  const bool mid_batched = hd.n_mid >= (unsigned)RCM_MID_BATCH;
+  const unsigned n_host = hd.n_large + (mid_batched ? 0u : hd.n_mid);  // components ordered from the host
+  const bool first_is_large = r0.count > (unsigned)RCM_SMALL && !(mid_batched && r0.count <= (unsigned)RCM_MID);
   if (v0 >= 0 && !first_is_large) {
     // the pre-swept component is handled by the batched kernel: drop the sweep's marks
     SBX_TRY(reset_ppos(h, (const I *)q, r0.count, ppos, n));
   }
-  // (3) small components: one lane each
+  // (3) small (and, batched, mid-size) components: one lane each
   if (hd.n_small) {
     SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_small + 63) / 64), dim3(64), rp, col,
-                       (const I *)small_list, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
+                       (const I *)small_list, hd.n_small, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
+    SBX_LAUNCH_CHECK(h);
+  }
+  if (mid_batched) {
+    SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_mid + 63) / 64), dim3(64), rp, col, (const I *)mid_list,
+                hd.n_mid, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
     SBX_LAUNCH_CHECK(h);
   }
   // (4) large components: host-driven level-synchronous BFS
   int64_t sweeps_max = 0, levels_max = 0, largest = 0, ref_sweeps_max = 0;
-  if (hd.n_large) {
-    std::vector<I> roots(hd.n_large), sizes(hd.n_large), bases(hd.n_large);
-    SBX_HIP(h, hipMemcpyAsync(roots.data(), large_list, hd.n_large * sizeof(I), hipMemcpyDeviceToHost, h->stream));
-    SBX_HIP(h, hipStreamSynchronize(h->stream));
-    for (unsigned c = 0; c < hd.n_large; c++) {
-      SBX_HIP(h, hipMemcpyAsync(&sizes[c], csize + roots[c], sizeof(I), hipMemcpyDeviceToHost, h->stream));
-      SBX_HIP(h, hipMemcpyAsync(&bases[c], cbase + roots[c], sizeof(I), hipMemcpyDeviceToHost, h->stream));
-    }
+  if (n_host) {
+    std::vector<I> roots(n_host), sizes(n_host), bases(n_host);
+    I *info = nullptr;  // roots | sizes | bases, gathered on the device: three copies whatever the component count
+    SBX_TRY(sbx_salloc(h, (size_t)3 * n_host, &info));
+    if (hd.n_large)
+      SBX_HIP(h, hipMemcpyAsync(info, large_list, hd.n_large * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
+    if (!mid_batched && hd.n_mid)
+      SBX_HIP(h, hipMemcpyAsync(info + hd.n_large, mid_list, hd.n_mid * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_comp_info, dim3((n_host + 255) / 256), dim3(256), (const I *)info, n_host,
+                (const I *)csize, (const I *)cbase, info + n_host, info + 2 * (size_t)n_host);
+    SBX_LAUNCH_CHECK(h);
+    SBX_HIP(h, hipMemcpyAsync(roots.data(), info, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
+    SBX_HIP(h, hipMemcpyAsync(sizes.data(), info + n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
+    SBX_HIP(h, hipMemcpyAsync(bases.data(), info + 2 * (size_t)n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
     SBX_HIP(h, hipStreamSynchronize(h->stream));
     // the pre-swept component goes first: its sweep state (q, ppos) is still live
-    for (unsigned c = 1; c < hd.n_large; c++)
+    for (unsigned c = 1; c < n_host; c++)
       if (first_is_large && roots[c] == v0) {
         std::swap(roots[c], roots[0]);
         std::swap(sizes[c], sizes[0]);
         std::swap(bases[c], bases[0]);
       }
-    for (unsigned c = 0; c < hd.n_large; c++) {
+    for (unsigned c = 0; c < n_host; c++) {
       // pseudo-peripheral search from the component's smallest vertex (:22-81)
       //
       // The search ends with the first candidate root whose sweep does not deepen the level
@@ -1825,7 +1890,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
                          (const I *)q, r.count, bases[c], inv);
       SBX_LAUNCH_CHECK(h);
       // invariant of the sweeps (k_visited_from_ppos relies on it): ppos is UNSEEN outside the running sweep
-      if (c + 1 < hd.n_large) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
+      if (c + 1 < n_host) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
       if (sizes[c] > largest) {
         largest = sizes[c];
         sweeps_max = sweeps;
@@ -1844,8 +1909,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
              "sbx_rcm_reorder: the pattern is not structurally symmetric (a BFS cannot reach its whole component); "
              "RCM is defined on symmetric patterns");
   if (stats_host) {
-    stats_host->small_components = hd.n_small;
-    stats_host->large_components = hd.n_large;
+    stats_host->small_components = hd.n_small + (mid_batched ? hd.n_mid : 0u);
+    stats_host->large_components = n_host;
     stats_host->bfs_sweeps = sweeps_max;
     stats_host->bfs_levels = levels_max;
     stats_host->edges_scanned = (int64_t)fin.edges;

@@ -844,6 +844,65 @@ def test_rcm_many_midsize_components(ops, oracle, seed):
     assert stats["large_components"] >= 10
 
 
+def _many_components(count, seed, lo=65, hi=420):
+    """Disjoint union of `count` paths / 2-D grids / stars / random trees of lo..hi vertices, vertex ids shuffled."""
+    g = np.random.default_rng(seed)
+    srcs, dsts, offset = [], [], 0
+    for k in range(count):
+        kind = k % 4
+        sz = int(g.integers(lo, hi))
+        if kind == 0:    # path
+            s, d = np.arange(sz - 1), np.arange(1, sz)
+        elif kind == 1:  # grid
+            r = max(2, int(np.sqrt(sz)))
+            c = max(2, sz // r)
+            sz = r * c
+            ids = np.arange(sz).reshape(r, c)
+            s = np.concatenate([ids[:, :-1].ravel(), ids[:-1, :].ravel()])
+            d = np.concatenate([ids[:, 1:].ravel(), ids[1:, :].ravel()])
+        elif kind == 2:  # star
+            s, d = np.zeros(sz - 1, np.int64), np.arange(1, sz)
+        else:            # random tree
+            s, d = np.arange(1, sz), (g.random(sz - 1) * np.arange(1, sz)).astype(np.int64)
+        srcs.append(s + offset)
+        dsts.append(d + offset)
+        offset += sz
+    n = offset + 11
+    relabel = g.permutation(n)
+    s, d = relabel[np.concatenate(srcs)], relabel[np.concatenate(dsts)]
+    s, d = synth.symmetrize(s, d)
+    return synth.csr_from_edges(n, s, d)
+
+
+def test_rcm_twenty_thousand_midsize_components(ops, oracle):
+    """The many-component cliff: 20 000 components of 65..420 vertices.  Ordered one by one from the host this took tens
+    of seconds; batched (one lane per component, sparsebase_amd/csrc/sbx_rcm.hip k_rcm_small) it must be bit-exact and
+    beat the CPU restatement of the reference's serial loop (rcm_reorder.cc:104-155) on the same graph."""
+    import time
+    rp, col = _many_components(20000, seed=5)
+    drp, dcol = dev(rp), dev(col)
+    got, stats = ops.rcm_reorder(drp, dcol, return_stats=True)
+    t0 = time.perf_counter()
+    want = oracle.rcm_reorder(rp, col)
+    cpu_s = time.perf_counter() - t0
+    assert np.array_equal(host(got), want), stats
+    assert stats["small_components"] >= 20000 and stats["large_components"] == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.rcm_reorder(drp, dcol)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    assert gpu_s < cpu_s, (gpu_s, cpu_s)
+    # a few mid-size components (below the batching threshold) still take the host-driven route, with hubs and all
+    rp2, col2 = _many_components(40, seed=6, lo=65, hi=1500)
+    got2, stats2 = ops.rcm_reorder(dev(rp2), dev(col2), return_stats=True)
+    assert np.array_equal(host(got2), oracle.rcm_reorder(rp2, col2)) and stats2["large_components"] == 40
+    # ... and above it, sizes up to the batch limit (stars with ~2000 leaves: the in-lane heapsort of the children)
+    rp3, col3 = _many_components(300, seed=7, lo=1200, hi=2040)
+    got3, stats3 = ops.rcm_reorder(dev(rp3), dev(col3), return_stats=True)
+    assert np.array_equal(host(got3), oracle.rcm_reorder(rp3, col3)), stats3
+
+
 def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
     """Directed inputs (an edge list read with read_undirected=False): a BFS cannot reach its weakly connected
     component.  The reference leaks stale distances there; here every such input must end in a clean error —
