@@ -12,7 +12,8 @@ import csv, glob, json, sys, collections
 
 GROUPS = [("k_bfs_bottom_up", "bfs_bottom_up"), ("k_bfs_expand_heavy", "bfs_heavy"), ("k_bfs_expand", "bfs_expand"),
           ("k_bfs_small_levels", "bfs_small_levels"), ("k_permute_tile", "permute_tile"), ("k_permute_copy", "permute_tile"),
-          ("k_permute_block_rows", "permute_block"), ("k_long_", "permute_long"),
+          ("k_permute_block_rows", "permute_block"), ("k_permute_rows_radix", "permute_block"), ("k_long_", "permute_long"),
+          ("k_rowwise_prep", "permute_prep"), ("k_rec_classify", "permute_prep"), ("k_tile_first", "permute_prep"),
           ("k_onesweep_pass", "radix_scatter"), ("k_onesweep_hist", "radix_hist"), ("k_onesweep_bins", "radix_hist"),
           ("k_scan_", "scan"), ("k_cc_", "cc"), ("k_classify", "cc"), ("k_level_", "level_order"),
           ("k_coo_to_csr", "coo_to_csr"), ("k_csr_to_coo", "csr_to_coo"), ("k_gray", "gray"), ("k_degree", "degree")]
