@@ -7,7 +7,7 @@
 //
 // Data flow of one permute (new rows [row_begin,row_end) — the multi-GPU shard):
 //   k_rowwise_prep  from the old-row side: rec[row_order[u]] = (length, source offset)   (12n B r, 8n B w)
-//   lengths / k_rec_classify -> scan -> row_ptr_out; rows too long for a tile listed by class
+//   k_classify_scan lengths -> row_ptr_out (single-pass scan), the short rows' prefix sums, long rows listed by class
 //   no column map:  k_permute_copy, a segmented copy (+ in-row order check; unsorted input
 //                   rows redo the call through the sorting kernels below)
 //   column map:
@@ -87,26 +87,143 @@ __global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ ord
   for (; i < n; i += stride) ((V *)out)[order[i]] = ((const V *)vals)[i];
 }
 
-// row lengths (for the scan; entry nr zeroed) and the lists of rows too long for the tile kernel.
-// The lists are appended to through five counter words; a few thousand long rows spread over millions would
-// queue one atomic each on them (~88 atomics/us per word: 100 us for 10 K rows), so every workgroup stages the
-// rows it finds in LDS and reserves list space once per class (the order inside a list does not matter).
+// The lists of rows too long for the tile kernel are appended to through a handful of counter words; a few thousand
+// long rows spread over millions would queue one atomic each on them (~88 atomics/us per word: 100 us for 10 K rows),
+// so every workgroup stages the rows it finds in LDS and reserves list space once per class (the order inside a list
+// does not matter).
 constexpr int RC_STAGE = 512;  // staged rows per class and workgroup before an early flush
+
+// ---- classification + both prefix sums in ONE launch -------------------------------------------------------
+// rpo = exclusive scan of the new rows' lengths, sp = the same over the lengths of the rows the tile kernel sorts
+// (<= PT_LMAX), and the lists of longer rows by class — what used to be k_rec_classify + two three-launch scans +
+// k_store_total, i.e. eight launches ahead of every permute.  Single pass with decoupled look-back: workgroups take
+// a ticket, publish (aggregate, flag) granules per tile and sum the predecessors' (64-bit value | flag words written
+// and read with relaxed agent-scope atomics: self-contained, no fence).  `status` holds one word per tile + the ticket
+// word at index `tiles`, all zero on entry.
+constexpr int CS_ITEMS = 8;
+constexpr int CS_TILE = 256 * CS_ITEMS;
 template <typename I>
-__global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ rec, I *__restrict__ rpo, int64_t nr,
-                                                      I *__restrict__ long_rows, I *__restrict__ block_rows,
-                                                      int64_t block_stride, int block_cap,
-                                                      PermState *__restrict__ st, I *__restrict__ sp) {
+__global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ rec, I *__restrict__ rpo,
+                                                       I *__restrict__ sp, int64_t nr, I *__restrict__ long_rows,
+                                                       I *__restrict__ block_rows, int64_t block_stride, int block_cap,
+                                                       PermState *__restrict__ st, unsigned long long *status,
+                                                       int64_t tiles, int rpo_aligned) {
   constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
   __shared__ unsigned s_cnt[NC], s_base[NC];
   __shared__ unsigned long long s_long_nnz, s_block_nnz;
-  __shared__ int s_full;
   __shared__ I s_rows[NC][RC_STAGE];
-  const int tid = threadIdx.x;
+  __shared__ unsigned long long s_red[2][4];
+  __shared__ unsigned long long s_before[2];
+  __shared__ unsigned s_tile;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd((unsigned *)(status + tiles), 1u);
   if (tid < NC) s_cnt[tid] = 0;
   if (tid == 0) s_long_nnz = s_block_nnz = 0;
   __syncthreads();
+  const int64_t tile = s_tile;
+  const int64_t base = tile * CS_TILE + (int64_t)tid * CS_ITEMS;  // this thread's first row
+  int d[CS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < CS_ITEMS; k += 2) {  // two (length, source) records per 16-byte load
+    int4 q = make_int4(0, 0, 0, 0);
+    if (base + k + 1 < nr) q = *(const int4 *)(rec + base + k);
+    else if (base + k < nr) q.x = rec[base + k].x;
+    d[k] = q.x;
+    d[k + 1] = q.z;
+  }
+  unsigned long long sum_all = 0, sum_short = 0;
+  unsigned long long loc_all[CS_ITEMS], loc_short[CS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < CS_ITEMS; k++) {
+    loc_all[k] = sum_all;
+    loc_short[k] = sum_short;
+    sum_all += (unsigned)d[k];
+    sum_short += d[k] <= PT_LMAX ? (unsigned)d[k] : 0u;
+  }
+  // exclusive prefix of the thread sums inside the tile
+  const unsigned long long inc_a = sbx_wave_inclusive_sum(sum_all), inc_s = sbx_wave_inclusive_sum(sum_short);
+  if (lane == 63) {
+    s_red[0][wv] = inc_a;
+    s_red[1][wv] = inc_s;
+  }
+  __syncthreads();
+  unsigned long long off_a = inc_a - sum_all, off_s = inc_s - sum_short, tot_a = 0, tot_s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i < wv) off_a += s_red[0][i], off_s += s_red[1][i];
+    tot_a += s_red[0][i], tot_s += s_red[1][i];
+  }
+  // decoupled look-back by the first wave, 64 predecessors per step.  One status word per tile:
+  // (sum of lengths << 33) | (sum of short lengths << 2) | flag — both sums stay below 2^31 (32-bit indices) —
+  // flag 1 = the tile's own aggregate, 2 = inclusive prefix.
+  if (wv == 0) {
+    unsigned long long before_a = 0, before_s = 0;
+    if (tile > 0) {
+      if (lane == 0)
+        __hip_atomic_store(status + tile, (tot_a << 33) | (tot_s << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t t0 = tile - 1;
+      while (true) {
+        const int64_t t = t0 - lane;
+        const unsigned long long w =
+            t >= 0 ? __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;  // before tile 0: empty prefix
+        const unsigned flag = (unsigned)(w & 3ull);
+        const uint64_t inc = __ballot(flag == 2u), missing = __ballot(flag == 0u);
+        const int first_inc = inc ? __builtin_ctzll(inc) : 64;  // nearest predecessor that knows its inclusive prefix
+        const uint64_t needed = first_inc < 63 ? (((uint64_t)1 << (first_inc + 1)) - 1) : ~(uint64_t)0;
+        if (missing & needed) {  // someone in between has not published yet: look again
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        const bool take = lane <= first_inc;
+        before_a += sbx_wave_sum(take ? (w >> 33) : 0ull);
+        before_s += sbx_wave_sum(take ? ((w >> 2) & 0x7FFFFFFFull) : 0ull);
+        if (first_inc < 64) break;
+        t0 -= 64;
+      }
+    }
+    if (lane == 0) {
+      __hip_atomic_store(status + tile, ((before_a + tot_a) << 33) | ((before_s + tot_s) << 2) | 2ull, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      s_before[0] = before_a;
+      s_before[1] = before_s;
+      if (tile == tiles - 1) {  // the grand totals close both arrays
+        if (rpo) rpo[nr] = (I)(before_a + tot_a);
+        sp[nr] = (I)(before_s + tot_s);
+        st->total = before_a + tot_a;
+      }
+    }
+  }
+  __syncthreads();
+  off_a += s_before[0];
+  off_s += s_before[1];
+  if (base < nr) {
+    I oa[CS_ITEMS], os[CS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; k++) {
+      oa[k] = (I)(off_a + loc_all[k]);
+      os[k] = (I)(off_s + loc_short[k]);
+    }
+    if (base + CS_ITEMS <= nr) {
+#pragma unroll
+      for (int k = 0; k < CS_ITEMS; k += 4) {
+        if (rpo && rpo_aligned) {
+          *(int4 *)(rpo + base + k) = make_int4((int)oa[k], (int)oa[k + 1], (int)oa[k + 2], (int)oa[k + 3]);
+        } else if (rpo) {  // a caller's row_ptr_out at an odd offset
+          rpo[base + k] = oa[k], rpo[base + k + 1] = oa[k + 1], rpo[base + k + 2] = oa[k + 2], rpo[base + k + 3] = oa[k + 3];
+        }
+        *(int4 *)(sp + base + k) = make_int4((int)os[k], (int)os[k + 1], (int)os[k + 2], (int)os[k + 3]);
+      }
+    } else {
+      for (int k = 0; base + k < nr; k++) {
+        if (rpo) rpo[base + k] = oa[k];
+        sp[base + k] = os[k];
+      }
+    }
+  }
+  // the lists of rows too long for the tile kernel, staged per workgroup (one reservation per class and flush)
+  if (block_rows == nullptr) return;
   auto flush = [&]() {  // all threads; leaves the stage empty
+    __syncthreads();
     if (tid < NC && s_cnt[tid]) {
       unsigned *counter = tid < BR_CLASSES ? &st->n_block[tid] : &st->n_long;
       s_base[tid] = atomicAdd(counter, s_cnt[tid]);
@@ -128,41 +245,25 @@ __global__ __launch_bounds__(256) void k_rec_classify(const int2 *__restrict__ r
     if (tid < NC) s_cnt[tid] = 0;
     __syncthreads();
   };
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t base = (int64_t)blockIdx.x * 256; base <= nr; base += stride) {  // uniform trip count per workgroup
-    const int64_t i = base + tid;
-    if (i == nr && rpo) rpo[i] = 0;
-    if (i == nr) sp[i] = 0;
-    if (i < nr) {
-      const I d = (I)rec[i].x;
-      if (rpo) rpo[i] = d;
-      sp[i] = d <= PT_LMAX ? d : (I)0;  // lengths of the rows the tile kernel sorts: their prefix sums lay out its tiles
-      int cls = -1;
-      if (d > block_cap) cls = BR_CLASSES;
-      else if (d > PT_LMAX) {
+#pragma unroll 1
+  for (int k = 0; k < CS_ITEMS; k++) {  // 256 rows per round: the stage (RC_STAGE per class) cannot overflow inside one
+    const int64_t i = base + k;
+    const int dd = d[k];
+    if (i < nr && dd > PT_LMAX) {
+      int cls = BR_CLASSES;
+      if (dd <= block_cap) {
         cls = 0;
-        while (d > br_cap(cls)) cls++;
+        while (dd > br_cap(cls)) cls++;
       }
-      if (cls >= 0) {
-        s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
-        atomicAdd(cls == BR_CLASSES ? &s_long_nnz : &s_block_nnz, (unsigned long long)d);
-      }
+      s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
+      atomicAdd(cls == BR_CLASSES ? &s_long_nnz : &s_block_nnz, (unsigned long long)dd);
     }
     __syncthreads();
-    if (tid == 0) {
-      bool full = false;
-      for (int c = 0; c < NC; c++) full |= s_cnt[c] + 256u > (unsigned)RC_STAGE;
-      s_full = full;
-    }
-    __syncthreads();
-    if (s_full) flush();  // uniform decision
+    bool full = false;
+    for (int c = 0; c < NC; c++) full |= s_cnt[c] + 256u > (unsigned)RC_STAGE;
+    if (full) flush();  // uniform: every thread reads the same counters behind the barrier
   }
   flush();
-}
-
-template <typename I>
-__global__ void k_store_total(const I *__restrict__ rpo, int64_t nr, PermState *__restrict__ st) {
-  st->total = (unsigned long long)rpo[nr];
 }
 
 // ---- row-wise permute: no column relabel, so rows keep their internal order and the
@@ -182,16 +283,9 @@ __global__ __launch_bounds__(256) void k_rowwise_prep(const I *__restrict__ rp, 
   for (; u < n; u += stride) {
     const int64_t r = (row_order ? (int64_t)row_order[u] : u) - rb0;
     if (r < 0 || r >= nr) continue;
-    const I s = rp[u];
-    rec[r] = make_int2((int)(rp[u + 1] - s), (int)s);
+    const I s = rp[u], e = rp[u + 1];
+    if (e > s) rec[r] = make_int2((int)(e - s), (int)s);  // (rec is zeroed: empty rows — half of a power-law graph's — cost no store)
   }
-}
-
-template <typename I>
-__global__ __launch_bounds__(256) void k_rowwise_lengths(const int2 *__restrict__ rec, int64_t nr, I *__restrict__ deg_out) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; r <= nr; r += stride) deg_out[r] = r < nr ? (I)rec[r].x : (I)0;
 }
 
 // tile_row[t] = last row r with rpo[r] <= min(t * tile, total)
@@ -1584,6 +1678,21 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   return SBX_OK;
 }
 
+// rpo (may be nullptr: lengths already scanned), sp and the class lists (block_rows nullptr: none) in one launch;
+// st must have been zeroed by the caller
+template <typename I>
+int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr, I *long_rows, I *block_rows,
+                      int64_t block_stride, int block_cap, PermState *st) {
+  const int64_t tiles = (nr + CS_TILE - 1) / CS_TILE > 0 ? (nr + CS_TILE - 1) / CS_TILE : 1;
+  unsigned long long *status = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)(tiles + 2), &status));
+  SBX_HIP(h, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 2), h->stream));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_scan<I>, dim3((unsigned)tiles), dim3(256), rec, rpo, sp, nr, long_rows,
+              block_rows, block_stride, block_cap, st, status, tiles, (int)(((uintptr_t)rpo & 15) == 0));
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
 }  // namespace
 
 #define SBX_REQUIRE(h, cond, msg)                                       \
@@ -1656,32 +1765,26 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nr, h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)row_order, n, row_begin, nr, rec);
   I *long_rows = nullptr, *block_rows = nullptr, *sp = nullptr;
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   int64_t block_stride = 0;
+  SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
   if (col_order) {  // the sorting pipeline needs the rows that do not fit a tile listed by class
     int64_t cap_long = nnz / PT_LMAX + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
-    SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
     block_stride = cap_long;
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
-                (const int2 *)rec, rpo, nr, long_rows, block_rows, block_stride, block_cap, st, sp);
-    SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, nr + 1, nullptr));
-  } else {
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_lengths<I>, dim3(sbx_grid_for(nr + 1, 256, 8192)), dim3(256),
-                (const int2 *)rec, nr, rpo);
   }
-  SBX_LAUNCH_CHECK(h);
-  SBX_TRY(sbx_exclusive_scan_i32(h, rpo, rpo, nr + 1, nullptr));
+  // lengths -> row_ptr_out, the short rows' prefix sums and the class lists: one launch
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, long_rows, block_rows, block_stride, block_cap, st));
   int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
   PermState hs;
   memset(&hs, 0, sizeof(hs));
   if (nr != n || col_order) {
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_store_total<I>, dim3(1), dim3(1), (const I *)rpo, nr, st);
     SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
     total = (int64_t)hs.total;
   }
@@ -1717,11 +1820,8 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
     SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
-    SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(nr + 1, 256, 2048)), dim3(256),
-                (const int2 *)rec, (I *)nullptr, nr, long_rows, block_rows, block_stride, block_cap, st, sp);
-    SBX_LAUNCH_CHECK(h);
-    SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, nr + 1, nullptr));
+    SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, nr, long_rows, block_rows, block_stride,
+                                 block_cap, st));
     SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
     hs.total = (unsigned long long)total;
   }
@@ -1771,14 +1871,12 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
+  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)n, h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)nullptr, n, (int64_t)0, n, rec);
   I *sp = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &sp));
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rec_classify<I>, dim3(sbx_grid_for(n + 1, 256, 2048)), dim3(256),
-              (const int2 *)rec, (I *)nullptr, n, long_rows, block_rows, n, block_cap, st, sp);
-  SBX_LAUNCH_CHECK(h);
-  SBX_TRY(sbx_exclusive_scan_i32(h, sp, sp, n + 1, nullptr));
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, n, long_rows, block_rows, (int64_t)n, block_cap, st));
   PermState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(PermState)));
   int rc;
