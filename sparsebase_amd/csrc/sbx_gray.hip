@@ -252,6 +252,220 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
   }
 }
 
+// ---- short-row fast path ---------------------------------------------------------------------------------------
+// When no row is longer than GR_SHORT_MAX (banded / mesh matrices: BASELINE config 5) the LDS machinery above is
+// overhead.  GR_LPR lanes share a row (a wave = 64 / GR_LPR consecutive rows: their nonzeros are one contiguous stretch
+// of col[], so the wave's loads cover whole lines between them), no LDS, no barrier.  Per-block counts are kept BIT-SLICED
+// and saturating: ge[t] has bit b set iff block b was met more than t times; meeting block b again is
+// ge[t+1] |= ge[t] & x from the top down.  The reference's key bit (count_b > thr, thr = 0 for rows below the
+// threshold, deg / resolution above: gray_reorder.cc:249-267,384-395) is then bit b of ge[thr].  Lanes of a row are
+// merged by a saturating add of the sliced counters over log2(GR_LPR) butterfly steps.  LV = levels needed = largest thr + 1.
+constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
+constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight measured 12 % slower)
+constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
+
+template <typename B>
+__device__ __forceinline__ B gr_shfl_xor(B v, int m) {
+  if constexpr (sizeof(B) == 8) {
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((B)hi << 32) | lo;
+  } else {
+    return (B)__shfl_xor((unsigned)v, m, 64);
+  }
+}
+
+// WSHIFT >= 0: the block width is 2^WSHIFT (the usual case: power-of-two dimensions), block = column >> WSHIFT
+template <typename B, int LV, bool POW2>
+__global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                         int64_t n, uint32_t width, uint32_t magic, uint32_t band,
+                                                         int wshift, int bits, int nnz_threshold,
+                                                         int32_t *__restrict__ degree_out,
+                                                         unsigned long long *__restrict__ key_out,
+                                                         GrayCounts *__restrict__ counts) {
+  __shared__ unsigned long long s_red[4][4];
+  const int tid = threadIdx.x, sub = tid & (GR_LPR - 1);
+  const int64_t rows_per_block = 256 / GR_LPR;
+  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
+  const int64_t step = (int64_t)gridDim.x * rows_per_block;
+  int64_t row = (int64_t)blockIdx.x * rows_per_block + tid / GR_LPR;
+  int32_t s_nx = 0, e_nx = 0;  // the row's bounds, fetched one step ahead
+  if (row < n) s_nx = rp[row], e_nx = rp[row + 1];
+  for (; row < n; row += step) {
+    const int32_t s = s_nx;
+    int32_t e = e_nx;
+    if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
+    const bool long_row = e - s > GR_SHORT_MAX;  // k_gray_long_rows' business
+    if (long_row) e = s;
+    const int d = e - s;
+    const bool sparse = d <= nnz_threshold;
+    const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
+    B ge[LV];
+#pragma unroll
+    for (int t = 0; t < LV; t++) ge[t] = 0;
+    unsigned inb = 0;
+    // the row's entries, GR_BATCH loads in flight per lane (a lane's entries are GR_LPR apart); longer rows take a
+    // second batch
+    const unsigned row_lo = (unsigned)row - band, band2 = 2u * band;  // |c - row| <= band  <=>  c - row_lo <= 2 band (mod 2^32)
+    const unsigned far = (unsigned)row ^ 0x40000000u;                  // a column outside every band: stands for "no entry"
+    for (int32_t j0 = s + sub; __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
+      unsigned c[GR_BATCH];
+#pragma unroll
+      for (int u = 0; u < GR_BATCH; u++) {
+        const int32_t j = j0 + u * GR_LPR;
+        c[u] = j < e ? (unsigned)__builtin_nontemporal_load(col + j) : far;
+      }
+#pragma unroll
+      for (int u = 0; u < GR_BATCH; u++) {
+        unsigned bkt;
+        if (POW2) {
+          bkt = c[u] >> wshift;
+        } else {
+          bkt = __umulhi(c[u], magic);  // c / width, one short at most
+          bkt += (c[u] - bkt * width) >= width;
+        }
+        const B x = c[u] != far ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
+#pragma unroll
+        for (int t = LV - 1; t > 0; t--) ge[t] |= ge[t - 1] & x;
+        ge[0] |= x;
+        inb += c[u] - row_lo <= band2;
+      }
+    }
+    // merge the lanes of the row: counts add, saturating at LV
+#pragma unroll
+    for (int m = 1; m < GR_LPR; m <<= 1) {
+      B o[LV], r[LV];
+#pragma unroll
+      for (int t = 0; t < LV; t++) o[t] = gr_shfl_xor(ge[t], m);
+#pragma unroll
+      for (int t = 0; t < LV; t++) {  // more than t in the sum: more than t here, or there, or (i + 1) here and (t - i) there
+        B v = ge[t] | o[t];
+#pragma unroll
+        for (int i = 0; i < t; i++) v |= ge[i] & o[t - 1 - i];
+        r[t] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < LV; t++) ge[t] = r[t];
+      inb += __shfl_xor(inb, m, 64);
+    }
+    if (sub == 0 && !long_row) {
+      B key = ge[0];
+#pragma unroll
+      for (int t = 1; t < LV; t++) key = thr == (unsigned)t ? ge[t] : key;
+      degree_out[row] = d;
+      key_out[row] = gray_decode((unsigned long long)key);
+      if (sparse) {
+        c_ns += (unsigned)d;
+        c_ds += inb;
+      } else {
+        c_nd += (unsigned)d;
+        c_dd += inb;
+      }
+    }
+  }
+  c_ns = sbx_wave_sum(c_ns); c_ds = sbx_wave_sum(c_ds); c_nd = sbx_wave_sum(c_nd); c_dd = sbx_wave_sum(c_dd);
+  if (sbx_lane() == 0) {
+    s_red[tid >> 6][0] = c_ns; s_red[tid >> 6][1] = c_ds; s_red[tid >> 6][2] = c_nd; s_red[tid >> 6][3] = c_dd;
+  }
+  __syncthreads();
+  if (tid < 4) {  // the grid is a few workgroups per CU: one add per counter and workgroup
+    const unsigned long long t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (t) atomicAdd(&counts->nnz_sparse + tid, t);
+  }
+}
+
+// rows above GR_SHORT_MAX entries: how many, and the first GR_LONG_LIST of them (a few boundary / hub rows in an
+// otherwise short-row matrix go to k_gray_long_rows; many of them send the call to the tile kernel)
+constexpr int GR_LONG_LIST = 4096;
+__global__ __launch_bounds__(256) void k_gray_find_long(const int32_t *__restrict__ rp, int64_t n,
+                                                        unsigned *__restrict__ count, int32_t *__restrict__ list) {
+  __shared__ unsigned s_cnt, s_base;
+  __shared__ int32_t s_rows[1024];
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (rp[i + 1] - rp[i] > GR_SHORT_MAX) {
+      const unsigned k = atomicAdd(&s_cnt, 1u);
+      if (k < 1024u) s_rows[k] = (int32_t)i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(count, s_cnt);  // one add per workgroup (512 workgroups)
+  __syncthreads();
+  const unsigned mine = s_cnt < 1024u ? s_cnt : 1024u;  // (more than 1024 in one workgroup: far beyond the list anyway)
+  for (unsigned k = threadIdx.x; k < mine; k += 256)
+    if (s_base + k < (unsigned)GR_LONG_LIST) list[s_base + k] = s_rows[k];
+}
+
+// GR_PARTS workgroups per listed long row (a 200 K-entry boundary row must not be one workgroup's job): per-block counts
+// in LDS — a thread walks a contiguous piece of the (column-sorted) row, so it adds once per run of equal blocks —
+// then into the row's global slot (64 counters + the band count), finished by k_gray_long_finish
+constexpr int GR_PARTS = 32;
+__global__ __launch_bounds__(256) void k_gray_long_rows(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                        const int32_t *__restrict__ list, uint32_t width,
+                                                        uint32_t magic, uint32_t band, unsigned *__restrict__ slots) {
+  __shared__ unsigned s_cnt[64];
+  __shared__ unsigned s_inb[4];
+  const int tid = threadIdx.x;
+  const int64_t li = blockIdx.x / GR_PARTS, part = blockIdx.x % GR_PARTS;
+  const int64_t row = list[li];
+  const int64_t s = rp[row], len = (int64_t)rp[row + 1] - s;
+  const int64_t a = s + len * part / GR_PARTS, b = s + len * (part + 1) / GR_PARTS;  // this workgroup's piece
+  if (a >= b) return;
+  if (tid < 64) s_cnt[tid] = 0;
+  __syncthreads();
+  const int64_t per = (b - a + 255) / 256;
+  int64_t j = a + per * tid;
+  const int64_t jend = j + per < b ? j + per : b;
+  unsigned inb = 0, run = 0, cur = 0xFFFFFFFFu;
+  for (; j < jend; j++) {
+    const int32_t c = col[j];
+    unsigned bkt = __umulhi((unsigned)c, magic);
+    bkt += ((unsigned)c - bkt * width) >= width;
+    if (bkt != cur) {
+      if (run) atomicAdd(&s_cnt[cur], run);
+      cur = bkt;
+      run = 0;
+    }
+    run++;
+    const int diff = c - (int32_t)row;
+    inb += (unsigned)(diff < 0 ? -diff : diff) <= band;
+  }
+  if (run) atomicAdd(&s_cnt[cur], run);
+  inb = sbx_wave_sum(inb);
+  if (sbx_lane() == 0) s_inb[tid >> 6] = inb;
+  __syncthreads();
+  unsigned *slot = slots + li * 65;
+  if (tid < 64 && s_cnt[tid]) atomicAdd(&slot[tid], s_cnt[tid]);
+  if (tid == 64) {
+    const unsigned t = s_inb[0] + s_inb[1] + s_inb[2] + s_inb[3];
+    if (t) atomicAdd(&slot[64], t);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gray_long_finish(const int32_t *__restrict__ rp, const int32_t *__restrict__ list,
+                                                          unsigned n_long, const unsigned *__restrict__ slots, int bits,
+                                                          int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                          unsigned long long *__restrict__ key_out,
+                                                          GrayCounts *__restrict__ counts) {
+  const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n_long) return;
+  const int64_t row = list[li];
+  const int d = rp[row + 1] - rp[row];
+  const unsigned *slot = slots + (size_t)li * 65;
+  const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
+  unsigned long long key = 0;
+  for (int b = 0; b < bits; b++) key |= (unsigned long long)(slot[b] > thr) << b;
+  degree_out[row] = d;
+  key_out[row] = gray_decode(key);
+  if (d <= nnz_threshold) {  // (a long row below the threshold: only with huge thresholds; a handful of adds at most)
+    atomicAdd(&counts->nnz_sparse, (unsigned long long)d);
+    atomicAdd(&counts->diag_sparse, (unsigned long long)slot[64]);
+  } else {
+    atomicAdd(&counts->nnz_dense, (unsigned long long)d);
+    atomicAdd(&counts->diag_dense, (unsigned long long)slot[64]);
+  }
+}
+
 // rows cut by a tile boundary: key from the slot of the tile they start in; band counters summed
 __global__ __launch_bounds__(256) void k_gray_finish(const int32_t *__restrict__ rp, int bits, int nnz_threshold,
                                                      const int32_t *__restrict__ fix_row,
@@ -318,6 +532,67 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   // c / width = umulhi(c, magic) or that + 1 (c < 2^31): magic = floor(2^32 / width), saturated for width 1
   const uint64_t mg = ((uint64_t)1 << 32) / (uint64_t)width;
   const uint32_t magic = mg > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mg;
+  const int32_t *rp = (const int32_t *)row_ptr, *cl = (const int32_t *)col;
+  unsigned long long *keys = (unsigned long long *)key_out;
+  {
+    // short-row fast path: rows above GR_SHORT_MAX entries are counted (and the first few listed) by one small pass;
+    // up to GR_LONG_LIST of them (boundary rows of a clamped band, a few hubs) get a workgroup each
+    unsigned *nlong = nullptr;
+    int32_t *long_list = nullptr;
+    SBX_TRY(sbx_salloc(h, 1, &nlong));
+    SBX_TRY(sbx_salloc(h, (size_t)GR_LONG_LIST, &long_list));
+    SBX_HIP(h, hipMemsetAsync(nlong, 0, sizeof(unsigned), h->stream));
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_find_long, dim3(sbx_grid_for(n, 256 * 16, 512)), dim3(256), rp, n, nlong, long_list);
+    SBX_LAUNCH_CHECK(h);
+    unsigned hlong = 0;
+    SBX_TRY(sbx_readback(h, &hlong, nlong, sizeof(unsigned)));
+    static const bool allow = !(getenv("SBX_GRAY_SHORT_ROWS") && atoi(getenv("SBX_GRAY_SHORT_ROWS")) == 0);
+    if (allow && hlong <= (unsigned)GR_LONG_LIST) {
+      const unsigned hmax = (unsigned)GR_SHORT_MAX;  // bound of the rows the kernel handles
+      const int lv = (int)(hmax >= (unsigned)bits && (int)hmax > nnz_threshold ? hmax / (unsigned)bits : 0u) + 1;  // <= 5
+      const unsigned grid = sbx_grid_for(n, 256 / GR_LPR, (int64_t)h->num_cus * 16);
+      int wshift = -1;
+      if ((width & (width - 1)) == 0)
+        for (wshift = 0; ((int64_t)1 << wshift) < width; wshift++) {}
+#define GRAY_SHORT(B, LV)                                                                                          \
+  do {                                                                                                             \
+    if (wshift >= 0)                                                                                               \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, true>), dim3(grid), dim3(256), rp, cl, n, (uint32_t)width, \
+                  magic, (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt);          \
+    else                                                                                                           \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, false>), dim3(grid), dim3(256), rp, cl, n,              \
+                  (uint32_t)width, magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt); \
+  } while (0)
+      if (bits <= 32) {
+        if (lv <= 1) GRAY_SHORT(uint32_t, 1);
+        else if (lv <= 3) GRAY_SHORT(uint32_t, 3);
+        else GRAY_SHORT(uint32_t, 5);
+      } else {
+        if (lv <= 1) GRAY_SHORT(unsigned long long, 1);
+        else GRAY_SHORT(unsigned long long, 2);  // 64 blocks: thr <= 64 / 64
+      }
+#undef GRAY_SHORT
+      if (hlong) {
+        unsigned *slots = nullptr;
+        SBX_TRY(sbx_salloc(h, (size_t)hlong * 65, &slots));
+        SBX_HIP(h, hipMemsetAsync(slots, 0, sizeof(unsigned) * (size_t)hlong * 65, h->stream));
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_rows, dim3(hlong * GR_PARTS), dim3(256), rp, cl, (const int32_t *)long_list,
+                    (uint32_t)width, magic, (uint32_t)band, slots);
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 255) / 256), dim3(256), rp,
+                    (const int32_t *)long_list, hlong, (const unsigned *)slots, bits, nnz_threshold,
+                    (int32_t *)degree_out, keys, cnt);
+      }
+      SBX_LAUNCH_CHECK(h);
+      SBX_PROF_BYTES(h, SBX_K_GRAY, 4 * nnz + 16 * n + 4);
+      GrayCounts hcs;
+      SBX_TRY(sbx_readback(h, &hcs, cnt, sizeof(GrayCounts)));
+      counts_host[0] = (int64_t)hcs.nnz_sparse;
+      counts_host[1] = (int64_t)hcs.diag_sparse;
+      counts_host[2] = (int64_t)hcs.nnz_dense;
+      counts_host[3] = (int64_t)hcs.diag_dense;
+      return SBX_OK;
+    }
+  }
   const int64_t ntiles = (nnz + GT_TILE - 1) / GT_TILE;
   int32_t *fix_row = nullptr, *tile_row = nullptr;
   unsigned *slot_acc = nullptr;
@@ -328,8 +603,6 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   SBX_TRY(sbx_salloc(h, (ntiles + 1) * 4, &tile_counts));
   SBX_HIP(h, hipMemsetAsync(fix_row, 0xFF, (size_t)(ntiles + 1) * sizeof(int32_t), h->stream));
   SBX_HIP(h, hipMemsetAsync(slot_acc, 0, (size_t)(ntiles + 1) * 64 * sizeof(unsigned), h->stream));
-  const int32_t *rp = (const int32_t *)row_ptr, *cl = (const int32_t *)col;
-  unsigned long long *keys = (unsigned long long *)key_out;
   const int64_t prep_items = n > ntiles + 1 ? n : ntiles + 1;
   SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_prep, dim3(sbx_grid_for(prep_items, 256, (int64_t)h->num_cus * 16)), dim3(256),
               rp, n, nnz, ntiles, (int32_t *)degree_out, keys, tile_row);
