@@ -10,6 +10,8 @@
 // global bucket offsets by decoupled look-back over per-tile status words, and
 // write keys/payloads out through LDS so the stores are coalesced per bucket run.
 // Traffic per pass: one read + one write of (key, payload).
+#include <stdlib.h>
+
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -333,6 +335,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
   }
 }
 
+static int rs_hist_grid_factor() {  // SBX_RADIX_HIST_GRID: workgroups per CU of the histogram kernel (tuning)
+  static const int f = getenv("SBX_RADIX_HIST_GRID") ? atoi(getenv("SBX_RADIX_HIST_GRID")) : 2;
+  return f < 1 ? 1 : f;
+}
+
 template <typename K, typename P, int ITEMS, bool HAS_P>
 static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t count, const sbx_radix_pass *passes,
                            int np, int *result_in_b) {
@@ -358,8 +365,11 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   const size_t state_words = (size_t)np * tiles * 256;
   unsigned long long *state = nullptr;
   SBX_TRY(sbx_salloc(h, state_words, &state));
-  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>), dim3(sbx_grid_for(count, RS_THREADS * 8, (int64_t)h->num_cus * 8)),
-              dim3(RS_THREADS), (const K *)ka, count, plan, ghist, state, state_words);
+  // few, fat workgroups: every workgroup ends with passes x 256 adds on the same histogram words, and one word takes
+  // only ~88 adds per microsecond whoever issues them
+  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>),
+              dim3(sbx_grid_for(count, RS_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RS_THREADS),
+              (const K *)ka, count, plan, ghist, state, state_words);
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
