@@ -979,7 +979,12 @@ __global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long lon
   }
 }
 
-// small level: keys, bitonic sort in LDS and emit in one workgroup
+// small level: keys, sort in LDS and emit in one workgroup.  The sort is a bucket rank: the keys (all different)
+// go to 4096 order-preserving buckets by their leading bits above the smallest key, the bucket counts are scanned,
+// every key is placed in its bucket's range and ranked there among a handful of neighbours — 8 barriers where the
+// bitonic network over 4096 keys takes 78 (77 us -> ~10 us for the bench matrix's 3.4 K-vertex level).  A bucket
+// holding more than RCM_BR_MAX keys (keys clustered at several scales) sends the level to the bitonic network.
+constexpr int RCM_BR_MAX = 48;
 template <bool CM>
 __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__ nf_list, unsigned nf,
                                                            const unsigned *__restrict__ ppos,
@@ -988,32 +993,110 @@ __global__ __launch_bounds__(1024) void k_level_sort_small(const I *__restrict__
                                                            I *__restrict__ q_level, unsigned *__restrict__ vbits,
                                                            unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
                                                            int mark_frontier, RcmDev *__restrict__ dv) {
+  constexpr int IPT = RCM_LDS_SORT / 1024;
   __shared__ uint64_t s_key[RCM_LDS_SORT];
-  unsigned p2 = 1;
-  while (p2 < nf) p2 <<= 1;
-  for (unsigned j = threadIdx.x; j < p2; j += blockDim.x) {
-    uint64_t k = ~0ull;
+  __shared__ uint64_t s_tmp[RCM_LDS_SORT];
+  __shared__ unsigned s_end[RCM_LDS_SORT];
+  __shared__ uint64_t s_mn[16], s_mx[16];
+  __shared__ unsigned s_wsum[16], s_big;
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  uint64_t mk[IPT];
+  uint64_t mn = ~0ull, mx = 0;
+#pragma unroll
+  for (int i = 0; i < IPT; i++) {
+    const unsigned j = threadIdx.x + i * 1024;
+    mk[i] = ~0ull;
     if (j < nf) {
       const I v = nf_list[j];
-      k = ((uint64_t)ppos[v] << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+      mk[i] = ((uint64_t)ppos[v] << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+      mn = mk[i] < mn ? mk[i] : mn;
+      mx = mk[i] > mx ? mk[i] : mx;
     }
-    s_key[j] = k;
+    s_end[j] = 0;
+  }
+  mn = sbx_wave_min(mn);
+  mx = sbx_wave_max(mx);
+  if (lane == 0) {
+    s_mn[wv] = mn;
+    s_mx[wv] = mx;
+  }
+  if (threadIdx.x == 0) s_big = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn = s_mn[i] < mn ? s_mn[i] : mn;
+    mx = s_mx[i] > mx ? s_mx[i] : mx;
+  }
+  const uint64_t range = mx - mn;  // nf >= 1
+  int shift = 0;
+  while (shift < 64 && (range >> shift) >= (uint64_t)RCM_LDS_SORT) shift++;
+  unsigned bk[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; i++) {
+    bk[i] = 0;
+    if (threadIdx.x + i * 1024 < nf) {
+      bk[i] = (unsigned)((mk[i] - mn) >> shift);
+      atomicAdd(&s_end[bk[i]], 1u);
+    }
   }
   __syncthreads();
-  for (unsigned k = 2; k <= p2; k <<= 1) {
-    for (unsigned j = k >> 1; j > 0; j >>= 1) {
-      for (unsigned t = threadIdx.x; t < p2; t += blockDim.x) {
-        const unsigned l = t ^ j;
-        if (l > t) {
-          const uint64_t a = s_key[t], b = s_key[l];
-          const bool up = (t & k) == 0;
-          if ((a > b) == up) {
-            s_key[t] = b;
-            s_key[l] = a;
+  {  // inclusive scan of the bucket counts: thread t owns buckets 4t..4t+3
+    const uint4 c = *(const uint4 *)&s_end[threadIdx.x * IPT];
+    const unsigned big = c.x > c.y ? (c.x > c.z ? (c.x > c.w ? c.x : c.w) : (c.z > c.w ? c.z : c.w))
+                                   : (c.y > c.z ? (c.y > c.w ? c.y : c.w) : (c.z > c.w ? c.z : c.w));
+    if (big > (unsigned)RCM_BR_MAX) s_big = 1;
+    const unsigned tsum = c.x + c.y + c.z + c.w;
+    const unsigned inc = sbx_wave_inclusive_sum(tsum);
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    unsigned base = inc - tsum;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if (i < wv) base += s_wsum[i];
+    uint4 e;
+    e.x = base + c.x;
+    e.y = e.x + c.y;
+    e.z = e.y + c.z;
+    e.w = e.z + c.w;
+    *(uint4 *)&s_end[threadIdx.x * IPT] = e;
+  }
+  __syncthreads();
+  if (!s_big) {
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+      if (threadIdx.x + i * 1024 < nf) s_tmp[atomicSub(&s_end[bk[i]], 1u) - 1u] = mk[i];
+    __syncthreads();  // s_end[b] is now where bucket b starts
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+      if (threadIdx.x + i * 1024 < nf) {
+        const unsigned lo = s_end[bk[i]], hi = bk[i] + 1 < (unsigned)RCM_LDS_SORT ? s_end[bk[i] + 1] : nf;
+        unsigned r = lo;
+        for (unsigned t = lo; t < hi; t++) r += s_tmp[t] < mk[i] ? 1u : 0u;
+        s_key[r] = mk[i];
+      }
+    __syncthreads();
+  } else {
+    unsigned p2 = 1;
+    while (p2 < nf) p2 <<= 1;
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+      if (threadIdx.x + i * 1024 < p2) s_key[threadIdx.x + i * 1024] = mk[i];
+    __syncthreads();
+    for (unsigned k = 2; k <= p2; k <<= 1) {
+      for (unsigned j = k >> 1; j > 0; j >>= 1) {
+        for (unsigned t = threadIdx.x; t < p2; t += blockDim.x) {
+          const unsigned l = t ^ j;
+          if (l > t) {
+            const uint64_t a = s_key[t], b = s_key[l];
+            const bool up = (t & k) == 0;
+            if ((a > b) == up) {
+              s_key[t] = b;
+              s_key[l] = a;
+            }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   for (unsigned j = threadIdx.x; j < nf; j += blockDim.x) {

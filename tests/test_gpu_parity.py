@@ -903,6 +903,47 @@ def test_rcm_twenty_thousand_midsize_components(ops, oracle):
     assert np.array_equal(host(got3), oracle.rcm_reorder(rp3, col3)), stats3
 
 
+def _edges_to_sym_csr(n, u, v):
+    uu = np.concatenate([u, v])
+    vv = np.concatenate([v, u])
+    key = np.unique(uu.astype(np.int64) * n + vv)
+    r, c = (key // n), (key % n)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+    return rp, c.astype(np.int32)
+
+
+@pytest.mark.parametrize("shape", ["clustered", "spread", "one_parent_two_scales"])
+def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
+    """k_level_sort_small (sbx_rcm.hip): a frontier too wide for the single-workgroup level kernel (> 4096 vertices)
+    discovers a level of <= 4096 vertices, which one workgroup orders by bucket rank.  'clustered' / 'one_parent_two_scales'
+    put more than RCM_BR_MAX keys in one bucket (the bitonic fallback), 'spread' stays on the bucket path."""
+    g = np.random.default_rng(5)
+    wide = 6000
+    n = 1 + wide + 4000 + 50000
+    ids = g.permutation(n).astype(np.int64)  # shuffled labels: ids do not follow discovery order
+    root, a = ids[0], ids[1:1 + wide]
+    b = ids[1 + wide:1 + wide + 4000]
+    u = [np.full(wide, root)]
+    v = [a]
+    if shape == "clustered":     # two parents far apart in the wide level; one owns 300 children
+        pa = np.sort(a)
+        u += [np.full(300, pa[0]), np.full(1, pa[-1])]
+        v += [b[:300], b[300:301]]
+    elif shape == "spread":      # 3500 children over 3500 different parents
+        u += [a[:3500]]
+        v += [b[:3500]]
+    else:                        # one parent, children's ids in two tight far-apart clusters
+        bs = np.sort(ids[1 + wide:])
+        u += [np.full(401, a[7])]
+        v += [np.concatenate([bs[:400], bs[-1:]])]
+    # a tail below the small level so that it is not the last one
+    u += [b[:100]]
+    v += [ids[1 + wide + 4000:1 + wide + 4100]]
+    rp, col = _edges_to_sym_csr(n, np.concatenate(u), np.concatenate(v))
+    got, stats = ops.rcm_reorder(dev(rp), dev(col), return_stats=True)
+    assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
+
+
 def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
     """Directed inputs (an edge list read with read_undirected=False): a BFS cannot reach its weakly connected
     component.  The reference leaks stale distances there; here every such input must end in a clean error —
