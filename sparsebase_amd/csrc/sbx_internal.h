@@ -205,6 +205,18 @@ int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_
                    void *vals_a, void *vals_b, int64_t count, const sbx_radix_pass *passes,
                    int num_passes, int *result_in_b);
 
+// Same sort of 64-bit keys without payload (count >= 2, num_passes >= 1) whose final pass, instead of storing the
+// sorted keys, emits per key at sorted position p: value = map ? map[low32(key)] : low32(key); out[p] = value;
+// bit `value` set in bits_a / bits_b (each optional); pos_of[value] = p (optional).
+struct sbx_radix_emit {
+  const uint32_t *map;
+  uint32_t *out;
+  unsigned *bits_a, *bits_b;
+  unsigned *pos_of;
+};
+int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
+                        int num_passes, const sbx_radix_emit *emit);
+
 int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count);
 
 // ---- 64-bit index arrays (sbx_i64.hip): narrowed to the int32 kernels when every value fits

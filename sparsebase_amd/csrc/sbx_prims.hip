@@ -200,12 +200,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
 // written/read with relaxed agent-scope atomics, so no fence is needed.  `ghist` holds the
 // pass's raw digit counts; every tile scans them itself (256 values) instead of paying a
 // separate one-workgroup launch per sort.
-template <typename K, typename P, int ITEMS, bool HAS_P>
+//
+// EMIT (final pass of sbx_radix_sort_emit): the sorted keys are not stored; the pass writes what the caller wanted
+// them for — out[position] = value (the key's low word, optionally mapped), value's bit in up to two bitmaps,
+// pos_of[value] = position — and saves the caller a kernel that re-reads the sorted keys.
+template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const P *__restrict__ vals_in, P *__restrict__ vals_out,
                                                               int64_t count, int shift, int bits,
                                                               const unsigned long long *__restrict__ ghist,
-                                                              unsigned long long *state, unsigned *ticket) {
+                                                              unsigned long long *state, unsigned *ticket,
+                                                              sbx_radix_emit em) {
   constexpr int TILE = RS_THREADS * ITEMS;
   __shared__ K s_keys[TILE];
   __shared__ P s_vals[HAS_P ? TILE : 1];
@@ -329,8 +334,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
       const K kk = s_keys[j];
       const unsigned d = (unsigned)(kk >> shift) & mask;
       const uint32_t o = s_gofs[d] + (uint32_t)j;
-      keys_out[o] = kk;
-      if (HAS_P) vals_out[o] = s_vals[j];
+      if (EMIT) {
+        const uint32_t lo = (uint32_t)kk;
+        const uint32_t v = em.map ? em.map[lo] : lo;
+        em.out[o] = v;
+        if (em.bits_a) atomicOr(&em.bits_a[v >> 5], 1u << (v & 31));
+        if (em.bits_b) atomicOr(&em.bits_b[v >> 5], 1u << (v & 31));
+        if (em.pos_of) em.pos_of[v] = o;
+      } else {
+        keys_out[o] = kk;
+        if (HAS_P) vals_out[o] = s_vals[j];
+      }
     }
   }
 }
@@ -340,9 +354,9 @@ static int rs_hist_grid_factor() {  // SBX_RADIX_HIST_GRID: workgroups per CU of
   return f < 1 ? 1 : f;
 }
 
-template <typename K, typename P, int ITEMS, bool HAS_P>
+template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT = false>
 static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t count, const sbx_radix_pass *passes,
-                           int np, int *result_in_b) {
+                           int np, int *result_in_b, const sbx_radix_emit *emit = nullptr) {
   constexpr int TILE = RS_THREADS * ITEMS;
   *result_in_b = 0;
   if (count <= 1 || np == 0) return SBX_OK;
@@ -373,10 +387,18 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
+  const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int p = 0; p < np; p++) {
-    SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P>), dim3((unsigned)tiles), dim3(RS_THREADS),
-                (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift, passes[p].bits,
-                (const unsigned long long *)(ghist + (size_t)p * 256), state + (size_t)p * tiles * 256, tickets + p);
+    if (EMIT && p == np - 1)
+      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, EMIT>), dim3((unsigned)tiles),
+                  dim3(RS_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
+                  passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
+                  state + (size_t)p * tiles * 256, tickets + p, *emit);
+    else
+      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, false>), dim3((unsigned)tiles),
+                  dim3(RS_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
+                  passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
+                  state + (size_t)p * tiles * 256, tickets + p, no_emit);
     // a pass reads and writes every (key, payload) record once
     SBX_PROF_BYTES(h, SBX_K_RADIX_SCATTER, 2 * count * (int64_t)(sizeof(K) + (HAS_P ? sizeof(P) : 0)));
     SBX_LAUNCH_CHECK(h);
@@ -385,6 +407,15 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
     *result_in_b ^= 1;
   }
   return SBX_OK;
+}
+
+int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
+                        int num_passes, const sbx_radix_emit *emit) {
+  if (!emit || !emit->out || num_passes < 1 || count < 2)
+    SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_emit: needs an output, a pass and two keys");
+  int in_b = 0;
+  return radix_sort_impl<uint64_t, uint32_t, 16, false, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
+                                                              count, passes, num_passes, &in_b, emit);
 }
 
 int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_a, void *keys_b, void *vals_a,

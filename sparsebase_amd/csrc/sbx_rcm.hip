@@ -834,16 +834,26 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
   stage_end_block(st, nf_list, dv, scanned, true);
 }
 
+// the host has read the expansion's counters by the time a level is ordered: the key kernels clear them for the next one
+__device__ __forceinline__ void reset_level_counters(RcmDev *__restrict__ dv) {
+  dv->nf = 0;
+  dv->n_heavy = 0;
+  dv->hub_overflow = 0;
+  dv->fedges = 0;
+}
+
 template <bool CM>
 __global__ __launch_bounds__(256) void k_level_keys(const I *__restrict__ nf_list, unsigned nf,
                                                     const unsigned *__restrict__ ppos,
-                                                    const uint32_t *__restrict__ drank, uint64_t *__restrict__ key) {
+                                                    const uint32_t *__restrict__ drank, uint64_t *__restrict__ key,
+                                                    RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; j < nf; j += stride) {
     const I v = nf_list[j];
     key[j] = ((uint64_t)ppos[v] << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) reset_level_counters(dv);
 }
 
 template <bool CM>
@@ -947,9 +957,11 @@ __global__ __launch_bounds__(256) void k_fresh_words(const unsigned *__restrict_
 __global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
                                                          const int *__restrict__ cnt, const int *__restrict__ btot,
                                                          int btot_is_scanned, const unsigned *__restrict__ ppos,
-                                                         uint64_t *__restrict__ key, int64_t words) {
+                                                         uint64_t *__restrict__ key, int64_t words,
+                                                         RcmDev *__restrict__ dv) {
   constexpr int WPW = RCM_FW_WORDS / 4;
   const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reset_level_counters(dv);
   int base = 0;
   if (btot_is_scanned) {
     base = btot[blockIdx.x];
@@ -1670,18 +1682,22 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
         if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
                     (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
-                    (const unsigned *)b.ppos, b.ka, words);
+                    (const unsigned *)b.ppos, b.ka, words, b.dv);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       } else {
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
-                    (const unsigned *)b.ppos, b.drank, b.ka);
+                    (const unsigned *)b.ppos, b.drank, b.ka, b.dv);
         np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       }
-      int in_b = 0;
-      SBX_TRY(sbx_radix_sort(h, 8, 0, b.ka, b.kb, nullptr, nullptr, nf, passes, np, &in_b));
-      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256),
-                  (const uint64_t *)(in_b ? b.kb : b.ka), nf, b.dorder, q_next, b.vbits, b.fbits, b.lpos, mark_frontier,
-                  set_bits, b.dv);
+      if (np > 0) {
+        // the last digit pass writes the queue, the bits and the level positions itself (no pass over sorted keys)
+        const sbx_radix_emit em = {CM ? b.dorder : nullptr, (uint32_t *)q_next, set_bits ? b.vbits : nullptr,
+                                   (set_bits && mark_frontier) ? b.fbits : nullptr, mark_frontier ? b.lpos : nullptr};
+        SBX_TRY(sbx_radix_sort_emit(h, b.ka, b.kb, nf, passes, np, &em));
+      } else {  // one parent and keys already in id order: nothing to sort
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256), (const uint64_t *)b.ka, nf, b.dorder,
+                    q_next, b.vbits, b.fbits, b.lpos, mark_frontier, set_bits, b.dv);
+      }
       if (CM && !set_bits)
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_visited_from_ppos, dim3(sbx_grid_for(b.n, 256 * 4, 4096)), dim3(256),
                     (const unsigned *)b.ppos, (unsigned long long *)b.vbits,
