@@ -225,8 +225,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__
     h[k] = run;
   }
   const int inc = sbx_wave_inclusive_max(run);
-  int excl = __shfl_up(inc, 1, 64);
-  if (sbx_lane() == 0) excl = 0;
+  int excl = sbx_wave_shift_up1(inc, 0);
   if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
   __syncthreads();
   int woff = 0;

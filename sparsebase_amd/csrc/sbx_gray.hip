@@ -140,8 +140,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
     }
   }
   const int inc = sbx_wave_inclusive_max(last);
-  int open = __shfl_up(inc, 1, 64);
-  if (sbx_lane() == 0) open = 0;
+  int open = sbx_wave_shift_up1(inc, 0);
   if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
   __syncthreads();
   for (int w = 0; w < (tid >> 6); w++) open = s_wmax[w] > open ? s_wmax[w] : open;

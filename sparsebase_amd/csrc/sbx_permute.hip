@@ -362,8 +362,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
       if (hd[k]) last = p0 + k + 1;
     }
     const int inc = sbx_wave_inclusive_max(last);
-    int open = __shfl_up(inc, 1, 64);
-    if (sbx_lane() == 0) open = 0;
+    int open = sbx_wave_shift_up1(inc, 0);
     if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
     __syncthreads();
     for (int w = 0; w < (tid >> 6); w++) open = s_wmax[w] > open ? s_wmax[w] : open;
@@ -644,8 +643,7 @@ __device__ __forceinline__ void permute_tile_body(
     for (int k = 0; k < ITEMS; k++)
       if (hd[k]) last = p0 + k + 1;
     const int inc = sbx_wave_inclusive_max(last);
-    int open = __shfl_up(inc, 1, 64);
-    if (lane == 0) open = 0;
+    int open = sbx_wave_shift_up1(inc, 0);
     if (lane == 63) s_wmax[wv] = inc;
     __syncthreads();
     for (int w = 0; w < wv; w++) open = s_wmax[w] > open ? s_wmax[w] : open;
@@ -1540,10 +1538,12 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
       if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
     }                                                                                                             \
   }
+  // threads per class, measured on the bench matrix: one wave (no s_barrier at all) up to 512 entries, 8 entries per
+  // thread up to 2048, 4 for 4096 (8 per thread there: +5 %)
   BLOCK_ROWS(0, 64);
-  BLOCK_ROWS(1, 128);
-  BLOCK_ROWS(2, 256);
-  BLOCK_ROWS(3, 512);
+  BLOCK_ROWS(1, 64);
+  BLOCK_ROWS(2, 128);
+  BLOCK_ROWS(3, 256);
   BLOCK_ROWS(4, 1024);
   if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
 #undef BLOCK_ROWS
