@@ -64,11 +64,23 @@ __device__ __forceinline__ T sbx_dpp_reduce(T v, Op op) {  // every lane gets th
   // (full permutations of a row: no lane is without a source, so there is no `old` to keep)
   x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
   x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
-  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_MIRROR, 0xF, 0xF, false));  // every row is uniform now
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));  // quads 0<->1, 2<->3
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_MIRROR, 0xF, 0xF, false));  // halves: every row is uniform now
   const T a = (T)__builtin_amdgcn_readlane((int)x, 0), b = (T)__builtin_amdgcn_readlane((int)x, 16);
   const T c = (T)__builtin_amdgcn_readlane((int)x, 32), d = (T)__builtin_amdgcn_readlane((int)x, 48);
   return op(op(a, b), op(c, d));
+}
+
+// reduction inside every 16-lane row (all 16 lanes get their row's result): four DPP steps
+template <typename T, typename Op>
+__device__ __forceinline__ T sbx_row16_reduce(T v, Op op) {
+  static_assert(sbx_is_dpp<T>::value, "32-bit integers only");
+  T x = v;
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false));
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false));
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
+  x = op(x, (T)__builtin_amdgcn_mov_dpp((int)x, SBX_DPP_ROW_MIRROR, 0xF, 0xF, false));
+  return x;
 }
 
 // lane i gets lane i - 1's value, lane 0 gets `first`

@@ -263,13 +263,25 @@ constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
 constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight measured 12 % slower)
 constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
 
+// Exchange with lane ^ m inside a row's 8 lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
+// 4 is row_half_mirror (lane i <-> 7 - i of the 8) — the same partner QUAD, and every value exchanged here is
+// uniform inside a quad by then (both partners of a merge step compute the same symmetric result).  A DPP move is one
+// VALU instruction; __shfl_xor is a ds_bpermute_b32 plus five instructions of address arithmetic.
+__device__ __forceinline__ unsigned gr_xor32(unsigned v, int m) {
+  switch (m) {
+    case 1: return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);
+    case 2: return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false);
+    case 4: return (unsigned)__builtin_amdgcn_mov_dpp((int)v, SBX_DPP_ROW_HALF_MIRROR, 0xF, 0xF, false);
+    default: return __shfl_xor(v, m, 64);
+  }
+}
 template <typename B>
 __device__ __forceinline__ B gr_shfl_xor(B v, int m) {
   if constexpr (sizeof(B) == 8) {
-    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    const unsigned lo = gr_xor32((unsigned)v, m), hi = gr_xor32((unsigned)(v >> 32), m);
     return ((B)hi << 32) | lo;
   } else {
-    return (B)__shfl_xor((unsigned)v, m, 64);
+    return (B)gr_xor32((unsigned)v, m);
   }
 }
 
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
       }
 #pragma unroll
       for (int t = 0; t < LV; t++) ge[t] = r[t];
-      inb += __shfl_xor(inb, m, 64);
+      inb += gr_xor32(inb, m);
     }
     if (sub == 0 && !long_row) {
       B key = ge[0];

@@ -820,11 +820,8 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
         j += 4 * RCM_GROUP;
       }
       if (gl == 0 && pick >= 0) scanned += (unsigned)(ce - cs);
-#pragma unroll
-      for (int d = RCM_GROUP / 2; d >= 1; d >>= 1) {
-        const unsigned o = __shfl_xor(best, d, 64);
-        best = o < best ? o : best;
-      }
+      static_assert(RCM_GROUP == 16, "a group is one DPP row");
+      best = sbx_row16_reduce(best, SbxOpMin());
       const bool found = (gl == 0) && pick >= 0 && best != UNSEEN;
       const I nv = (I)(base + (pick < 0 ? 0 : pick));
       if (found) ppos[nv] = best;
