@@ -65,7 +65,10 @@ struct PermState {            // device-resident flags/counters of one call
   unsigned long_unsorted;     // some row of the global-radix class is out of order
   unsigned n_fb_rows;         // rows / tiles whose columns cluster: listed for the radix kernels
   unsigned n_fb_tiles;
-  unsigned pad2;
+  unsigned n_seg_fb_rows;     // long-row segments whose columns cluster (listed for the radix kernel)
+  unsigned n_seg[2];          // long-row segments of <= 4096 / <= 8192 entries (virtual rows of the one-workgroup classes)
+  unsigned n_long_fb;         // long rows the segment path hands to the global radix sort (already ordered, or a segment too full)
+  unsigned long long long_fb_nnz;
 };
 
 template <int VB> struct ValT { typedef uint32_t type; };
@@ -1045,10 +1048,12 @@ template <typename I, int VB, int CAP, int BR_THREADS>
 __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
     const I *__restrict__ rpo, const I *__restrict__ block_rows, int n_rows, I *col_out, char *val_out,
-    PermState *__restrict__ st, int force_radix, unsigned *__restrict__ fb_rows) {
+    PermState *__restrict__ st, int force_radix, unsigned *__restrict__ fb_rows, unsigned *__restrict__ fb_count,
+    const unsigned *__restrict__ n_rows_dev) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int ITEMS = CAP / BR_THREADS;
+  if (n_rows_dev) n_rows = (int)*n_rows_dev;  // (segments of long rows: the host does not know how many there are)
   constexpr int WAVES = BR_THREADS / 64;
   static_assert(sizeof(V) <= 8, "sorted values are staged in the placed-word + counter regions");
   __shared__ __attribute__((aligned(16))) unsigned s_pool[3 * CAP + 4];
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(BR_THREADS) void k_permute_block_rows(
           lds_barrier<BR_THREADS>();  // the level-0 bounds have been read
         }
         if (__builtin_amdgcn_readfirstlane(s_flag[1]) != 0) {  // (rare) the row goes on the list of k_permute_rows_radix
-          if (tid == 0) fb_rows[atomicAdd(&st->n_fb_rows, 1u)] = (unsigned)rid_a;
+          if (tid == 0) fb_rows[atomicAdd(fb_count, 1u)] = (unsigned)rid_a;
         } else {
 #pragma unroll
           for (int k = 0; k < ITEMS; k++)
@@ -1312,7 +1317,7 @@ template <typename I, int VB>
 __global__ __launch_bounds__(1024) void k_permute_rows_radix(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
     const I *__restrict__ rpo, const unsigned *__restrict__ fb_rows, I *col_out, char *val_out, int col_bits,
-    PermState *__restrict__ st) {
+    PermState *__restrict__ st, const unsigned *__restrict__ fb_count) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int THREADS = 1024, CAP = BlockRowCap<VB>::value, ITEMS = CAP / THREADS, WAVES = THREADS / 64;
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(1024) void k_permute_rows_radix(
   __shared__ unsigned s_whist[WAVES * 256];
   __shared__ unsigned s_scan[WAVES + 1];
   const int tid = threadIdx.x, lane = tid & 63;
-  const unsigned n = st->n_fb_rows;
+  const unsigned n = *fb_count;
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
     const int64_t r = fb_rows[i];
     const int64_t e0 = rpo[r];
@@ -1431,6 +1436,350 @@ __global__ __launch_bounds__(256) void k_long_lengths(const I *__restrict__ rpo,
   if (k < n_long) len[k] = (uint32_t)(rpo[long_rows[k] + 1] - rpo[long_rows[k]]);
 }
 
+// ---- long rows, column-relabelled permutes: split into segments, sort the segments in LDS ------------------
+// A row of L > capacity relabelled columns is cut into column ranges holding about LS_TARGET entries each; its entries
+// are partitioned by range through two compact buffers and every range — a segment — is then a "virtual row" of the
+// one-workgroup-per-row kernel above (bucket-rank sort in LDS), written straight to its place in the output.  The
+// ranges adapt to the row: a histogram over F = 64 .. 1024 equal bins between the row's smallest and largest column,
+// consecutive bins grouped while their running count stays inside a window of T entries (segment <= T + fullest bin).
+// Three passes over the long rows' entries plus one over their columns (gather, histogram, partition, sort) against
+// the ~ 6 of the global radix sort on (row rank, column), which stays for what this does not cover: a row that is
+// already ordered (the constructor leaves such a row alone, so its equal columns must keep their order: the partition
+// is not stable), a row with a bin too full for a segment (columns clustered below 1/F of the row's range), rows of
+// more than 2 M entries, and the row-wise permutes.
+constexpr int LS_MAXLG = 10;      // at most 1024 histogram bins per row
+constexpr int LS_MAXSEG = 2048;   // segment slots per row held in LDS by the partition pass (two rows per chunk)
+constexpr int LS_CHUNK = 4096;    // compact entries per workgroup: spans at most two long rows (every one is longer)
+constexpr int LS_THREADS = 256;
+constexpr int LS_ITEMS = LS_CHUNK / LS_THREADS;
+
+__host__ __device__ __forceinline__ int ls_lg_bins(int64_t len) {  // 2^lg bins: ~ 128 .. 256 entries each, at most 1024
+  int lg = 0;
+  for (int64_t t = (len - 1) / 256; t > 0; t >>= 1) lg++;
+  return lg > LS_MAXLG ? LS_MAXLG : lg;
+}
+__host__ __device__ __forceinline__ unsigned ls_slots(int64_t len, int target) { return (unsigned)(len / target) + 1u; }
+
+// exclusive prefix sums over the long rows of their lengths, bin counts and segment slots: one workgroup walks the
+// list (a few hundred to a few ten thousand rows) instead of three scans of three launches each
+template <typename I>
+__global__ __launch_bounds__(1024) void k_long_seg_offsets(const I *__restrict__ rpo, const I *__restrict__ long_rows,
+                                                           uint32_t *__restrict__ loff, uint32_t *__restrict__ foff,
+                                                           uint32_t *__restrict__ soff, int n_long, int target) {
+  __shared__ unsigned s_scan[1024 / 64 + 1];
+  unsigned run_l = 0, run_f = 0, run_s = 0;
+  for (int k0 = 0; k0 < n_long; k0 += 1024) {
+    const int k = k0 + (int)threadIdx.x;
+    unsigned l = 0, f = 0, sl = 0;
+    if (k < n_long) {
+      const int64_t len = (int64_t)rpo[long_rows[k] + 1] - (int64_t)rpo[long_rows[k]];
+      l = (unsigned)len;
+      f = 1u << ls_lg_bins(len);
+      sl = ls_slots(len, target);
+    }
+    unsigned tl, tf, ts;
+    const unsigned el = sbx_block_exclusive_sum<unsigned, 1024>(l, s_scan, &tl);
+    const unsigned ef = sbx_block_exclusive_sum<unsigned, 1024>(f, s_scan, &tf);
+    const unsigned es = sbx_block_exclusive_sum<unsigned, 1024>(sl, s_scan, &ts);
+    if (k < n_long) {
+      loff[k] = run_l + el;
+      foff[k] = run_f + ef;
+      soff[k] = run_s + es;
+    }
+    run_l += tl, run_f += tf, run_s += ts;
+  }
+}
+
+// the (at most two) long rows a chunk of the compact entry space touches: the row of the chunk's first entry
+__device__ __forceinline__ int ls_first_row(const uint32_t *__restrict__ loff, int n_long, int64_t e) {
+  int lo = 0, hi = n_long - 1;  // last k with loff[k] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)loff[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+struct LsChunk {  // what a workgroup knows about its chunk [base, base + LS_CHUNK) of the compact entry space
+  int k0;                  // row of the first entry; the chunk's other row, if any, is k0 + 1
+  int64_t start0, end0;    // row k0 = compact entries [start0, end0); entries from end0 on belong to row k0 + 1
+  int64_t lenB;
+  bool hasB;
+};
+__device__ __forceinline__ LsChunk ls_chunk(const uint32_t *__restrict__ loff, int n_long, int64_t long_nnz, int64_t base) {
+  LsChunk c;
+  c.k0 = ls_first_row(loff, n_long, base);
+  c.start0 = loff[c.k0];
+  c.end0 = c.k0 + 1 < n_long ? (int64_t)loff[c.k0 + 1] : long_nnz;
+  c.hasB = base + LS_CHUNK > c.end0 && c.k0 + 1 < n_long;
+  c.lenB = c.hasB ? (c.k0 + 2 < n_long ? (int64_t)loff[c.k0 + 2] : long_nnz) - c.end0 : 0;
+  return c;
+}
+// bin of a column inside its row's range [mn, mx]: equal widths 2^shift, fewer than 2^lg of them
+__device__ __forceinline__ int ls_shift(unsigned mn, unsigned mx, int lg) {
+  const int rb = bits_u32(mx - mn);
+  return rb > lg ? rb - lg : 0;
+}
+
+// pass 1: gather + relabel into the first compact buffer; per-row "out of order" flags and column range
+// (rowmm[2 k] = ~min, rowmm[2 k + 1] = max: both grow from the zero fill)
+template <typename I, int VB>
+__global__ __launch_bounds__(LS_THREADS) void k_long_seg_gather(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ long_rows, const uint32_t *__restrict__ loff, int n_long, int64_t long_nnz,
+    I *__restrict__ c1, char *__restrict__ v1, unsigned *__restrict__ rowmm, unsigned *__restrict__ row_unsorted,
+    PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  __shared__ int s_col[LS_CHUNK + 1];  // [0] = the entry in front of the chunk
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * LS_CHUNK;
+  const LsChunk ch = ls_chunk(loff, n_long, long_nnz, base);
+  const int64_t srcA = rec[long_rows[ch.k0]].y, srcB = ch.hasB ? (int64_t)rec[long_rows[ch.k0 + 1]].y : 0;
+  if (tid == 0) {  // the relabelled column in front of the chunk (same row only)
+    int pc = 0;
+    if (base > ch.start0) {
+      const I c = col_in[srcA + (base - 1 - ch.start0)];
+      pc = (int)(col_order ? col_order[c] : c);
+    }
+    s_col[0] = pc;
+  }
+  int cc[LS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int64_t e = base + i * LS_THREADS + tid;
+    cc[i] = 0;
+    if (e < long_nnz) {
+      const bool b = e >= ch.end0;
+      const int64_t s = b ? srcB + (e - ch.end0) : srcA + (e - ch.start0);
+      const I c = __builtin_nontemporal_load(col_in + s);
+      cc[i] = (int)(col_order ? col_order[c] : c);
+      c1[e] = (I)cc[i];
+      if (VB) ((V *)v1)[e] = __builtin_nontemporal_load((const V *)val_in + s);
+    }
+    s_col[1 + i * LS_THREADS + tid] = cc[i];
+  }
+  __syncthreads();
+  bool unsA = false, unsB = false;
+  unsigned nmnA = 0, mxA = 0, nmnB = 0, mxB = 0;
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int p = i * LS_THREADS + tid;
+    const int64_t e = base + p;
+    if (e < long_nnz) {
+      const bool b = e >= ch.end0;
+      const bool first = b ? e == ch.end0 : e == ch.start0;
+      const unsigned c = (unsigned)cc[i];
+      if (!first && cc[i] < s_col[p]) (b ? unsB : unsA) = true;
+      if (b) {
+        nmnB = ~c > nmnB ? ~c : nmnB;
+        mxB = c > mxB ? c : mxB;
+      } else {
+        nmnA = ~c > nmnA ? ~c : nmnA;
+        mxA = c > mxA ? c : mxA;
+      }
+    }
+  }
+  nmnA = sbx_wave_max(nmnA), mxA = sbx_wave_max(mxA);
+  if (sbx_lane() == 0) {
+    if (nmnA) atomicMax(&rowmm[2 * ch.k0], nmnA);
+    if (mxA) atomicMax(&rowmm[2 * ch.k0 + 1], mxA);
+  }
+  if (ch.hasB) {
+    nmnB = sbx_wave_max(nmnB), mxB = sbx_wave_max(mxB);
+    if (sbx_lane() == 0) {
+      if (nmnB) atomicMax(&rowmm[2 * ch.k0 + 2], nmnB);
+      if (mxB) atomicMax(&rowmm[2 * ch.k0 + 3], mxB);
+    }
+  }
+  if (__any(unsA) && sbx_lane() == 0) row_unsorted[ch.k0] = 1;
+  if (__any(unsB) && sbx_lane() == 0) row_unsorted[ch.k0 + 1] = 1;
+  if (__any(unsA || unsB) && sbx_lane() == 0) st->any_unsorted = 1;
+}
+
+// pass 2: per-row histograms of the relabelled columns (one streaming read of the first compact buffer)
+template <typename I>
+__global__ __launch_bounds__(LS_THREADS) void k_long_seg_hist(const I *__restrict__ c1, const uint32_t *__restrict__ loff,
+                                                              const uint32_t *__restrict__ foff, int n_long,
+                                                              int64_t long_nnz, const unsigned *__restrict__ rowmm,
+                                                              unsigned *__restrict__ fine) {
+  __shared__ unsigned s_hist[2][1 << LS_MAXLG];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * LS_CHUNK;
+  const LsChunk ch = ls_chunk(loff, n_long, long_nnz, base);
+  const int lgA = ls_lg_bins(ch.end0 - ch.start0), lgB = ch.hasB ? ls_lg_bins(ch.lenB) : 0;
+  const unsigned mnA = ~rowmm[2 * ch.k0], mnB = ch.hasB ? ~rowmm[2 * ch.k0 + 2] : 0u;
+  const int shA = ls_shift(mnA, rowmm[2 * ch.k0 + 1], lgA);
+  const int shB = ch.hasB ? ls_shift(mnB, rowmm[2 * ch.k0 + 3], lgB) : 0;
+  for (int i = tid; i < 2 * (1 << LS_MAXLG); i += LS_THREADS) (&s_hist[0][0])[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int64_t e = base + i * LS_THREADS + tid;
+    if (e < long_nnz) {
+      const bool b = e >= ch.end0;
+      const unsigned c = (unsigned)c1[e];
+      atomicAdd(&s_hist[b][b ? (c - mnB) >> shB : (c - mnA) >> shA], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (1 << lgA); i += LS_THREADS)
+    if (s_hist[0][i]) atomicAdd(&fine[foff[ch.k0] + i], s_hist[0][i]);
+  if (ch.hasB)
+    for (int i = tid; i < (1 << lgB); i += LS_THREADS)
+      if (s_hist[1][i]) atomicAdd(&fine[foff[ch.k0 + 1] + i], s_hist[1][i]);
+}
+
+// pass 3 (one workgroup per long row): bins -> segments.  Bin b with exclusive prefix P belongs to segment P / T, so a
+// segment holds fewer than T + (its last bin) entries; fine[] becomes the bin -> segment map, segstart[] where a
+// segment starts inside the row.  Virtual row 2 v of the row kernel: vrec = (length, source in the second compact
+// buffer), vrpo[2 v], vrpo[2 v + 1] = its output range.  Or the row is left to the global radix sort.
+template <typename I>
+__global__ __launch_bounds__(256) void k_long_seg_scan(const I *__restrict__ rpo, const I *__restrict__ long_rows,
+                                                       const uint32_t *__restrict__ loff,
+                                                       const uint32_t *__restrict__ foff,
+                                                       const uint32_t *__restrict__ soff, int n_long, int64_t long_nnz,
+                                                       int target, int seg_cap, unsigned *__restrict__ fine,
+                                                       unsigned *__restrict__ segstart,
+                                                       const unsigned *__restrict__ row_unsorted,
+                                                       unsigned *__restrict__ row_skip, int2 *__restrict__ vrec,
+                                                       I *__restrict__ vrpo, I *__restrict__ vlist, int64_t vstride,
+                                                       I *__restrict__ fb_list, PermState *__restrict__ st) {
+  constexpr int PER = (1 << LS_MAXLG) / 256;
+  __shared__ unsigned s_scan[256 / 64 + 1];
+  __shared__ unsigned s_cnt[LS_MAXSEG];
+  __shared__ int s_skip;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int64_t start = loff[k], len = (k + 1 < n_long ? (int64_t)loff[k + 1] : long_nnz) - start;
+  const int F = 1 << ls_lg_bins(len);
+  const unsigned slots = ls_slots(len, target);
+  const unsigned fo = foff[k], so = soff[k];
+  unsigned c[PER], sum = 0, mx = 0;
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int b = tid * PER + i;
+    c[i] = b < F ? fine[fo + b] : 0u;
+    sum += c[i];
+    mx = c[i] > mx ? c[i] : mx;
+  }
+  if (tid == 0) s_skip = (row_unsorted[k] == 0 || slots > (unsigned)LS_MAXSEG) ? 1 : 0;  // (an ordered row: stable path)
+  for (unsigned g = tid; g < slots && g < (unsigned)LS_MAXSEG; g += 256) s_cnt[g] = 0;
+  __syncthreads();
+  if (mx + (unsigned)target > (unsigned)seg_cap) s_skip = 1;  // a segment may reach target - 1 + its last bin
+  unsigned all;
+  unsigned ex = sbx_block_exclusive_sum<unsigned, 256>(sum, s_scan, &all);  // (its barriers publish s_skip)
+  const int skip = s_skip;
+  if (tid == 0) {
+    row_skip[k] = (unsigned)skip;
+    if (skip) {
+      fb_list[atomicAdd(&st->n_long_fb, 1u)] = long_rows[k];
+      atomicAdd(&st->long_fb_nnz, (unsigned long long)len);
+    }
+  }
+  if (skip) return;
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int b = tid * PER + i;
+    if (b < F) {
+      const unsigned g = ex / (unsigned)target;
+      fine[fo + b] = g;
+      if (c[i]) atomicAdd(&s_cnt[g], c[i]);
+    }
+    ex += c[i];
+  }
+  __syncthreads();
+  // segment starts: exclusive prefix of the segment counts
+  const int64_t out0 = rpo[long_rows[k]];
+  unsigned run = 0;
+  for (unsigned g0 = 0; g0 < slots; g0 += 256) {
+    const unsigned g = g0 + tid;
+    const unsigned n = g < slots ? s_cnt[g] : 0u;
+    unsigned tot;
+    const unsigned e = run + sbx_block_exclusive_sum<unsigned, 256>(n, s_scan, &tot);
+    run += tot;
+    const bool emit = n > 0;
+    const int cls = n > 4096u ? 1 : 0;
+    const unsigned s0 = sbx_wave_append(&st->n_seg[0], emit && cls == 0);
+    const unsigned s1 = sbx_wave_append(&st->n_seg[1], emit && cls == 1);
+    if (g < slots) segstart[so + g] = e;
+    if (emit) {
+      const int64_t v = (int64_t)so + g;
+      vrec[2 * v] = make_int2((int)n, (int)(start + e));
+      vrpo[2 * v] = (I)(out0 + e);
+      vrpo[2 * v + 1] = (I)(out0 + e + n);
+      vlist[(int64_t)cls * vstride + (cls ? s1 : s0)] = (I)(2 * v);
+    }
+  }
+}
+
+// pass 4: the first compact buffer partitioned by segment into the second one (the order of the entries inside a
+// segment is whatever the atomics give: the segment is sorted next)
+template <typename I, int VB>
+__global__ __launch_bounds__(LS_THREADS) void k_long_seg_partition(
+    const I *__restrict__ c1, const char *__restrict__ v1, const uint32_t *__restrict__ loff,
+    const uint32_t *__restrict__ foff, const uint32_t *__restrict__ soff, int n_long, int64_t long_nnz, int target,
+    const unsigned *__restrict__ rowmm, const unsigned *__restrict__ fine, const unsigned *__restrict__ segstart,
+    unsigned *__restrict__ cursor, const unsigned *__restrict__ row_skip, I *__restrict__ c2, char *__restrict__ v2) {
+  typedef typename ValT<VB>::type V;
+  __shared__ unsigned short s_map[2][1 << LS_MAXLG];  // bin -> segment
+  __shared__ unsigned s_hist[2][LS_MAXSEG];           // counts, then: where this chunk's entries of the segment go
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * LS_CHUNK;
+  const LsChunk ch = ls_chunk(loff, n_long, long_nnz, base);
+  const bool skipA = row_skip[ch.k0] != 0, skipB = ch.hasB ? row_skip[ch.k0 + 1] != 0 : true;
+  if (skipA && skipB) return;
+  const int lgA = ls_lg_bins(ch.end0 - ch.start0), lgB = ch.hasB ? ls_lg_bins(ch.lenB) : 0;
+  const unsigned slotsA = skipA ? 0u : ls_slots(ch.end0 - ch.start0, target);
+  const unsigned slotsB = skipB ? 0u : ls_slots(ch.lenB, target);
+  const unsigned mnA = ~rowmm[2 * ch.k0], mnB = ch.hasB ? ~rowmm[2 * ch.k0 + 2] : 0u;
+  const int shA = ls_shift(mnA, rowmm[2 * ch.k0 + 1], lgA);
+  const int shB = ch.hasB ? ls_shift(mnB, rowmm[2 * ch.k0 + 3], lgB) : 0;
+  if (!skipA)
+    for (int i = tid; i < (1 << lgA); i += LS_THREADS) s_map[0][i] = (unsigned short)fine[foff[ch.k0] + i];
+  if (!skipB)
+    for (int i = tid; i < (1 << lgB); i += LS_THREADS) s_map[1][i] = (unsigned short)fine[foff[ch.k0 + 1] + i];
+  for (unsigned i = tid; i < slotsA; i += LS_THREADS) s_hist[0][i] = 0;
+  for (unsigned i = tid; i < slotsB; i += LS_THREADS) s_hist[1][i] = 0;
+  __syncthreads();
+  int cc[LS_ITEMS];
+  unsigned sg[LS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int64_t e = base + i * LS_THREADS + tid;
+    sg[i] = 0xFFFFFFFFu;
+    cc[i] = 0;
+    if (e < long_nnz) {
+      const bool b = e >= ch.end0;
+      if (!(b ? skipB : skipA)) {
+        cc[i] = (int)c1[e];
+        const unsigned c = (unsigned)cc[i];
+        const unsigned g = b ? s_map[1][(c - mnB) >> shB] : s_map[0][(c - mnA) >> shA];
+        sg[i] = (b ? (unsigned)LS_MAXSEG : 0u) + g;
+        atomicAdd(&(&s_hist[0][0])[sg[i]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // one reservation per (chunk, segment): where the chunk's entries of the segment start in the second buffer
+  for (unsigned i = tid; i < slotsA; i += LS_THREADS) {
+    const unsigned n = s_hist[0][i];
+    if (n) s_hist[0][i] = (unsigned)ch.start0 + segstart[soff[ch.k0] + i] + atomicAdd(&cursor[soff[ch.k0] + i], n);
+  }
+  for (unsigned i = tid; i < slotsB; i += LS_THREADS) {
+    const unsigned n = s_hist[1][i];
+    if (n) s_hist[1][i] = (unsigned)ch.end0 + segstart[soff[ch.k0 + 1] + i] + atomicAdd(&cursor[soff[ch.k0 + 1] + i], n);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    if (sg[i] != 0xFFFFFFFFu) {
+      const int64_t e = base + i * LS_THREADS + tid;
+      const unsigned d = atomicAdd(&(&s_hist[0][0])[sg[i]], 1u);
+      c2[d] = (I)cc[i];
+      if (VB) ((V *)v2)[d] = ((const V *)v1)[e];
+    }
+  }
+}
+
 // ---- duplicate-column fix-up (format/csr.cc:143-156 pair ordering) -------------
 template <sbx_value_type VT> struct Typed;
 template <> struct Typed<SBX_V_I32> { typedef int32_t T; };
@@ -1530,7 +1879,8 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
     }                                                                                                             \
     SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_block_rows<I, VB, br_cap(CLS), THREADS>), dim3(grid),          \
                 dim3(THREADS), rec, col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride,              \
-                (int)n_block[CLS], col_out, val_out, st, force, fb_rows);                                         \
+                (int)n_block[CLS], col_out, val_out, st, force, fb_rows, &st->n_fb_rows,                          \
+                (const unsigned *)nullptr);                                                                       \
     if (fork && si) {                                                                                             \
       const hipError_t e1_ = hipEventRecord(h->aux_event[1 + si], h->stream);                                     \
       const hipError_t e2_ = hipStreamWaitEvent(base, h->aux_event[1 + si], 0);                                   \
@@ -1548,7 +1898,8 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
   if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
 #undef BLOCK_ROWS
   SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_rows_radix<I, VB>), dim3((unsigned)(n_all < 512 ? n_all : 512)),
-              dim3(1024), rec, col_in, val_in, col_order, rpo, (const unsigned *)fb_rows, col_out, val_out, col_bits, st);
+              dim3(1024), rec, col_in, val_in, col_order, rpo, (const unsigned *)fb_rows, col_out, val_out, col_bits, st,
+              (const unsigned *)&st->n_fb_rows);
   SBX_LAUNCH_CHECK(h);
   SBX_PROF_BYTES(h, SBX_K_PERMUTE_BLOCK, block_nnz * (int64_t)(2 * (sizeof(I) + VB)));
   return SBX_OK;
@@ -1556,7 +1907,7 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
 
 // longer rows: flat gather, device radix sort on (row rank, column), scatter back
 template <int VB>
-int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
+int long_rows_radix_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
                    const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *long_rows,
                    unsigned n_long, int64_t long_nnz, PermState *st) {
   typedef int32_t I;
@@ -1587,6 +1938,95 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
                      (const uint64_t *)(in_b ? kb : ka), (const char *)(in_b ? pb : pa), rpo, long_rows,
                      (const uint32_t *)loff, long_nnz, col_out, val_out, st);
   SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
+
+static bool permute_long_segments() {  // SBX_PERMUTE_LONG_SEGMENTS=0: long rows always take the global radix sort
+  static const bool on = !(getenv("SBX_PERMUTE_LONG_SEGMENTS") && atoi(getenv("SBX_PERMUTE_LONG_SEGMENTS")) == 0);
+  return on;
+}
+
+// longer rows of a permute that relabels columns: segments sorted in LDS (kernels above); what that path declines
+// (rows already in order, overfull segments) and every long row of the other callers goes through the radix path
+template <int VB>
+int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
+                   const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *long_rows,
+                   unsigned n_long, int64_t long_nnz, PermState *st) {
+  typedef int32_t I;
+  if (!col_order || !permute_long_segments() || (permute_force_radix() & 1) || long_nnz >= ((int64_t)1 << 31))
+    return long_rows_radix_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
+                                    long_nnz, st);
+  const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
+  const int seg_cap = BlockRowCap<VB>::value;
+  const int target = seg_cap / 4;  // a segment: fewer than target + (one bin) entries
+  const size_t seg_max = (size_t)(long_nnz / target) + (size_t)n_long + 2;  // sum of the rows' segment slots
+  const size_t bin_max = (size_t)(long_nnz / 128) + (size_t)n_long * 2 + 2;  // sum of the rows' bins (each < L / 128 + 2)
+  uint32_t *loff = nullptr, *foff = nullptr, *soff = nullptr;
+  unsigned *zero = nullptr;
+  I *c1 = nullptr, *c2 = nullptr, *vrpo = nullptr, *vlist = nullptr, *fb_list = nullptr;
+  char *v1 = nullptr, *v2 = nullptr;
+  int2 *vrec = nullptr;
+  unsigned *fb_rows = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &loff));
+  SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &foff));
+  SBX_TRY(sbx_salloc(h, (size_t)n_long + 1, &soff));
+  // fine | cursor | row range | row_unsorted | row_skip: one fill
+  const size_t zero_words = bin_max + seg_max + 4 * (size_t)n_long;
+  SBX_TRY(sbx_salloc(h, zero_words + seg_max, &zero));
+  unsigned *fine = zero, *cursor = fine + bin_max, *rowmm = cursor + seg_max, *row_unsorted = rowmm + 2 * (size_t)n_long;
+  unsigned *row_skip = row_unsorted + n_long, *segstart = row_skip + n_long;
+  SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &c1));
+  SBX_TRY(sbx_salloc(h, (size_t)long_nnz, &c2));
+  if (VB) {
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &v1));
+    SBX_TRY(sbx_salloc(h, (size_t)long_nnz * VB, &v2));
+  }
+  SBX_TRY(sbx_salloc(h, 2 * seg_max, &vrec));
+  SBX_TRY(sbx_salloc(h, 2 * seg_max + 1, &vrpo));
+  SBX_TRY(sbx_salloc(h, 2 * seg_max, &vlist));
+  SBX_TRY(sbx_salloc(h, (size_t)n_long, &fb_list));
+  SBX_TRY(sbx_salloc(h, seg_max, &fb_rows));
+  SBX_HIP(h, hipMemsetAsync(zero, 0, sizeof(unsigned) * zero_words, h->stream));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_seg_offsets<I>, dim3(1), dim3(1024), rpo, long_rows, loff, foff, soff,
+              (int)n_long, target);
+  const unsigned chunks = (unsigned)((long_nnz + LS_CHUNK - 1) / LS_CHUNK);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_seg_gather<I, VB>), dim3(chunks), dim3(LS_THREADS), rec, col_in, val_in,
+              col_order, long_rows, (const uint32_t *)loff, (int)n_long, long_nnz, c1, v1, rowmm, row_unsorted, st);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_seg_hist<I>, dim3(chunks), dim3(LS_THREADS), (const I *)c1,
+              (const uint32_t *)loff, (const uint32_t *)foff, (int)n_long, long_nnz, (const unsigned *)rowmm, fine);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, k_long_seg_scan<I>, dim3(n_long), dim3(256), rpo, long_rows, (const uint32_t *)loff,
+              (const uint32_t *)foff, (const uint32_t *)soff, (int)n_long, long_nnz, target, seg_cap, fine, segstart,
+              (const unsigned *)row_unsorted, row_skip, vrec, vrpo, vlist, (int64_t)seg_max, fb_list, st);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_long_seg_partition<I, VB>), dim3(chunks), dim3(LS_THREADS), (const I *)c1,
+              (const char *)v1, (const uint32_t *)loff, (const uint32_t *)foff, (const uint32_t *)soff, (int)n_long,
+              long_nnz, target, (const unsigned *)rowmm, (const unsigned *)fine, (const unsigned *)segstart, cursor,
+              (const unsigned *)row_skip, c2, v2);
+  // the segments: virtual rows of the one-workgroup-per-row kernel (columns already relabelled: no column map)
+  const int force = permute_force_radix() & 0xFE;
+  // (1024-thread workgroups: one resident per CU, as in block_rows_path)
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
+              (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
+              0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
+  if constexpr (VB != 8) {
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
+                dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
+                (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
+                (const unsigned *)&st->n_seg[1]);
+  }
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_rows_radix<I, VB>), dim3(256), dim3(1024), (const int2 *)vrec,
+              (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const unsigned *)fb_rows, col_out,
+              val_out, col_bits, st, (const unsigned *)&st->n_seg_fb_rows);
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_PERMUTE_LONG, long_nnz * (int64_t)(2 * (sizeof(I) + VB)));
+  PermState hs2;
+  SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
+  if (getenv("SBX_DEBUG_LONG"))
+    fprintf(stderr, "long rows %u (%lld entries): segments %u + %u, clustered segments %u, rows left to the radix sort %u (%llu entries)\n",
+            n_long, (long long)long_nnz, hs2.n_seg[0], hs2.n_seg[1], hs2.n_seg_fb_rows, hs2.n_long_fb, hs2.long_fb_nnz);
+  if (hs2.n_long_fb)
+    SBX_TRY(long_rows_radix_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, (const I *)fb_list,
+                                     hs2.n_long_fb, (int64_t)hs2.long_fb_nnz, st));
   return SBX_OK;
 }
 

@@ -432,6 +432,48 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
 
 
+def test_permute_long_row_segments(ops, oracle):
+    """Rows above the one-workgroup capacity under a column map (sbx_permute.hip, k_long_seg_*): split into column-range
+    segments that are sorted in LDS.  Covers: rows of 8 K .. 300 K entries (8 .. 256 segments; chunks of the compact buffer
+    that straddle two rows), duplicate columns with values, a row whose relabelled columns all fall into one segment (too
+    full: that row takes the global radix sort), a row the map leaves in order (the reference does not touch it: stable
+    path) next to rows it scrambles, and 8-byte values (segments of at most 4096 entries)."""
+    g = np.random.default_rng(11)
+    n, m = 40, 1 << 20
+    lens = [8193, 12000, 4097, 300000, 8200, 70000, 16385, 9000, 0, 5, 30000, 10000] + [int(x) for x in g.integers(0, 200, n - 12)]
+    cols = []
+    for i, l in enumerate(lens):
+        if i == 7:      # tight cluster: one segment gets everything
+            c = 5000 + g.choice(20000, l, replace=False)
+        elif i == 11:   # columns below 2^19: the map below keeps them in order
+            c = g.choice(1 << 19, l, replace=False)
+        elif i == 10:   # duplicates
+            c = g.integers(1 << 19, m, l)
+        else:
+            c = (1 << 19) + g.choice(1 << 19, l, replace=False) if l else np.zeros(0, np.int64)
+        cols.append(np.sort(c))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols).astype(np.int32)
+    co = np.arange(m, dtype=np.int64)
+    co[1 << 19:] = (1 << 19) + g.permutation(1 << 19)   # lower half stays put (monotone), upper half is scrambled
+    co = co.astype(np.int32)
+    ro = synth.random_permutation(n, 4)
+    val = g.integers(-3, 3, len(col)).astype(np.int32)
+    for v in (val.astype(np.float32), None, val.astype(np.float64)):
+        same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
+        same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, dev(co)), oracle.permute_csr(rp, col, v, None, co))
+    # a monotone map over everything: every long row stays in order, duplicates keep their input order
+    mono = np.arange(m, dtype=np.int32)
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(mono)), oracle.permute_csr(rp, col, val, ro, mono))
+    # shards (sbx_permute_csr_rows) go through the same stage
+    whole = oracle.permute_csr(rp, col, val, ro, co)
+    for r0, r1 in ((0, 17), (17, 40)):
+        prp, pcol, pval = ops.permute_csr_rows(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co), r0, r1)
+        a, b = int(whole[0][r0]), int(whole[0][r1])
+        assert np.array_equal(host(prp), whole[0][r0:r1 + 1] - a)
+        assert np.array_equal(host(pcol)[:b - a], whole[1][a:b]) and np.array_equal(host(pval)[:b - a], whole[2][a:b])
+
+
 def _clustered_case(seed=5):
     """Rows whose relabelled columns sit in one tight block plus a far outlier: the bucket-rank sort of
     sbx_permute.hip meets a bucket larger than its limit there and must take the radix path."""
