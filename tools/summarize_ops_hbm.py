@@ -4,8 +4,11 @@ stats, bytes per launch from separate FETCH_SIZE / WRITE_SIZE counter passes (un
 gfx950 as MI355X_MICROARCH.md prescribes — exact for wide streaming reads, an upper bound otherwise).
 usage: summarize_ops_hbm.py <kernel_stats.csv> <fetch_dir> <write_dir> <out.json>"""
 import collections, csv, glob, json, sys
-KERNELS = ["k_coo_to_csr", "k_csr_to_coo", "k_permute_copy", "k_permute_tile", "k_gray_tile", "k_onesweep_pass",
-           "k_csc_pack", "k_csc_unpack", "k_bandwidth", "k_profile_sorted", "k_degrees", "k_rowwise_prep"]
+# (first match wins: longer names in front of their prefixes)
+KERNELS = ["k_coo_to_csr", "k_csr_to_coo", "k_permute_copy", "k_permute_tile_radix", "k_permute_tile",
+           "k_permute_block_rows", "k_permute_rows_radix", "k_long_seg_gather", "k_long_seg_partition", "k_gray_tile",
+           "k_gray_rows_short", "k_onesweep_pass", "k_csc_pack", "k_csc_unpack", "k_bandwidth", "k_profile_sorted",
+           "k_degrees", "k_rowwise_prep", "k_classify_scan"]
 
 def key_of(name):
     for k in KERNELS:
