@@ -262,6 +262,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
 constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
 constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight measured 12 % slower)
 constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
+constexpr int GR_LONG_LIST = 4096;  // rows above GR_SHORT_MAX entries the short-row path lists for k_gray_long_rows
 
 // Exchange with lane ^ m inside a row's 8 lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
 // 4 is row_half_mirror (lane i <-> 7 - i of the 8) — the same partner QUAD, and every value exchanged here is
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
                                                          int wshift, int bits, int nnz_threshold,
                                                          int32_t *__restrict__ degree_out,
                                                          unsigned long long *__restrict__ key_out,
-                                                         GrayCounts *__restrict__ counts) {
+                                                         GrayCounts *__restrict__ counts, unsigned *nlong,
+                                                         int32_t *__restrict__ long_list) {
   __shared__ unsigned long long s_red[4][4];
   const int tid = threadIdx.x, sub = tid & (GR_LPR - 1);
   const int64_t rows_per_block = 256 / GR_LPR;
@@ -305,7 +307,15 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     const int32_t s = s_nx;
     int32_t e = e_nx;
     if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
+    // The kernel runs before anyone knows whether the matrix suits it: rows above GR_SHORT_MAX entries are listed for
+    // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
+    // leaves at its next long row — the host then discards the results and takes the tile kernel.
     const bool long_row = e - s > GR_SHORT_MAX;  // k_gray_long_rows' business
+    if (__any(long_row)) {  // (nothing on the common path: the counter is only touched by waves that meet a long row)
+      const unsigned slot = sbx_wave_append(nlong, long_row && sub == 0);
+      if (long_row && sub == 0 && slot < (unsigned)GR_LONG_LIST) long_list[slot] = (int32_t)row;
+      if (__any(long_row && sub == 0 && slot >= (unsigned)GR_LONG_LIST)) return;  // list full: this wave leaves
+    }
     if (long_row) e = s;
     const int d = e - s;
     const bool sparse = d <= nnz_threshold;
@@ -382,29 +392,6 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     const unsigned long long t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
     if (t) atomicAdd(&counts->nnz_sparse + tid, t);
   }
-}
-
-// rows above GR_SHORT_MAX entries: how many, and the first GR_LONG_LIST of them (a few boundary / hub rows in an
-// otherwise short-row matrix go to k_gray_long_rows; many of them send the call to the tile kernel)
-constexpr int GR_LONG_LIST = 4096;
-__global__ __launch_bounds__(256) void k_gray_find_long(const int32_t *__restrict__ rp, int64_t n,
-                                                        unsigned *__restrict__ count, int32_t *__restrict__ list) {
-  __shared__ unsigned s_cnt, s_base;
-  __shared__ int32_t s_rows[1024];
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (rp[i + 1] - rp[i] > GR_SHORT_MAX) {
-      const unsigned k = atomicAdd(&s_cnt, 1u);
-      if (k < 1024u) s_rows[k] = (int32_t)i;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(count, s_cnt);  // one add per workgroup (512 workgroups)
-  __syncthreads();
-  const unsigned mine = s_cnt < 1024u ? s_cnt : 1024u;  // (more than 1024 in one workgroup: far beyond the list anyway)
-  for (unsigned k = threadIdx.x; k < mine; k += 256)
-    if (s_base + k < (unsigned)GR_LONG_LIST) list[s_base + k] = s_rows[k];
 }
 
 // GR_PARTS workgroups per listed long row (a 200 K-entry boundary row must not be one workgroup's job): per-block counts
@@ -536,9 +523,14 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   SBX_TRY(sbx_arena_begin(h));
   counts_host[0] = counts_host[1] = counts_host[2] = counts_host[3] = 0;
   if (n == 0) return SBX_OK;
-  GrayCounts *cnt = nullptr;
-  SBX_TRY(sbx_salloc(h, 1, &cnt));
-  SBX_HIP(h, hipMemsetAsync(cnt, 0, sizeof(GrayCounts), h->stream));
+  struct GrayBoth {  // band counters and the short-row kernel's long-row count: one fill, one read-back
+    GrayCounts c;
+    unsigned nlong, pad;
+  };
+  GrayBoth *both = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &both));
+  SBX_HIP(h, hipMemsetAsync(both, 0, sizeof(GrayBoth), h->stream));
+  GrayCounts *cnt = &both->c;
   const int64_t band = m / 128;  // :138
   // c / width = umulhi(c, magic) or that + 1 (c < 2^31): magic = floor(2^32 / width), saturated for width 1
   const uint64_t mg = ((uint64_t)1 << 32) / (uint64_t)width;
@@ -546,19 +538,13 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   const int32_t *rp = (const int32_t *)row_ptr, *cl = (const int32_t *)col;
   unsigned long long *keys = (unsigned long long *)key_out;
   {
-    // short-row fast path: rows above GR_SHORT_MAX entries are counted (and the first few listed) by one small pass;
-    // up to GR_LONG_LIST of them (boundary rows of a clamped band, a few hubs) get a workgroup each
-    unsigned *nlong = nullptr;
+    // short-row fast path, tried first: the kernel lists the rows above GR_SHORT_MAX entries it meets; up to
+    // GR_LONG_LIST of them (boundary rows of a clamped band, a few hubs) then get GR_PARTS workgroups each
+    unsigned *nlong = &both->nlong;
     int32_t *long_list = nullptr;
-    SBX_TRY(sbx_salloc(h, 1, &nlong));
     SBX_TRY(sbx_salloc(h, (size_t)GR_LONG_LIST, &long_list));
-    SBX_HIP(h, hipMemsetAsync(nlong, 0, sizeof(unsigned), h->stream));
-    SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_find_long, dim3(sbx_grid_for(n, 256 * 16, 512)), dim3(256), rp, n, nlong, long_list);
-    SBX_LAUNCH_CHECK(h);
-    unsigned hlong = 0;
-    SBX_TRY(sbx_readback(h, &hlong, nlong, sizeof(unsigned)));
     static const bool allow = !(getenv("SBX_GRAY_SHORT_ROWS") && atoi(getenv("SBX_GRAY_SHORT_ROWS")) == 0);
-    if (allow && hlong <= (unsigned)GR_LONG_LIST) {
+    if (allow) {
       const unsigned hmax = (unsigned)GR_SHORT_MAX;  // bound of the rows the kernel handles
       const int lv = (int)(hmax >= (unsigned)bits && (int)hmax > nnz_threshold ? hmax / (unsigned)bits : 0u) + 1;  // <= 5
       const unsigned grid = sbx_grid_for(n, 256 / GR_LPR, (int64_t)h->num_cus * 16);
@@ -569,10 +555,12 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   do {                                                                                                             \
     if (wshift >= 0)                                                                                               \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, true>), dim3(grid), dim3(256), rp, cl, n, (uint32_t)width, \
-                  magic, (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt);          \
+                  magic, (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong,   \
+                  long_list);                                                                                      \
     else                                                                                                           \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, false>), dim3(grid), dim3(256), rp, cl, n,              \
-                  (uint32_t)width, magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt); \
+                  (uint32_t)width, magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, \
+                  nlong, long_list);                                                                               \
   } while (0)
       if (bits <= 32) {
         if (lv <= 1) GRAY_SHORT(uint32_t, 1);
@@ -583,25 +571,33 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         else GRAY_SHORT(unsigned long long, 2);  // 64 blocks: thr <= 64 / 64
       }
 #undef GRAY_SHORT
-      if (hlong) {
-        unsigned *slots = nullptr;
-        SBX_TRY(sbx_salloc(h, (size_t)hlong * 65, &slots));
-        SBX_HIP(h, hipMemsetAsync(slots, 0, sizeof(unsigned) * (size_t)hlong * 65, h->stream));
-        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_rows, dim3(hlong * GR_PARTS), dim3(256), rp, cl, (const int32_t *)long_list,
-                    (uint32_t)width, magic, (uint32_t)band, slots);
-        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 255) / 256), dim3(256), rp,
-                    (const int32_t *)long_list, hlong, (const unsigned *)slots, bits, nnz_threshold,
-                    (int32_t *)degree_out, keys, cnt);
-      }
       SBX_LAUNCH_CHECK(h);
-      SBX_PROF_BYTES(h, SBX_K_GRAY, 4 * nnz + 16 * n + 4);
-      GrayCounts hcs;
-      SBX_TRY(sbx_readback(h, &hcs, cnt, sizeof(GrayCounts)));
-      counts_host[0] = (int64_t)hcs.nnz_sparse;
-      counts_host[1] = (int64_t)hcs.diag_sparse;
-      counts_host[2] = (int64_t)hcs.nnz_dense;
-      counts_host[3] = (int64_t)hcs.diag_dense;
-      return SBX_OK;
+      // one read-back: how many long rows the kernel met and — final if there were none — the band counters
+      GrayBoth hb;
+      SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+      const unsigned hlong = hb.nlong;
+      if (hlong <= (unsigned)GR_LONG_LIST) {
+        if (hlong) {
+          unsigned *slots = nullptr;
+          SBX_TRY(sbx_salloc(h, (size_t)hlong * 65, &slots));
+          SBX_HIP(h, hipMemsetAsync(slots, 0, sizeof(unsigned) * (size_t)hlong * 65, h->stream));
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_rows, dim3(hlong * GR_PARTS), dim3(256), rp, cl,
+                      (const int32_t *)long_list, (uint32_t)width, magic, (uint32_t)band, slots);
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 255) / 256), dim3(256), rp,
+                      (const int32_t *)long_list, hlong, (const unsigned *)slots, bits, nnz_threshold,
+                      (int32_t *)degree_out, keys, cnt);
+          SBX_LAUNCH_CHECK(h);
+          SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+        }
+        SBX_PROF_BYTES(h, SBX_K_GRAY, 4 * nnz + 16 * n + 4);
+        counts_host[0] = (int64_t)hb.c.nnz_sparse;
+        counts_host[1] = (int64_t)hb.c.diag_sparse;
+        counts_host[2] = (int64_t)hb.c.nnz_dense;
+        counts_host[3] = (int64_t)hb.c.diag_dense;
+        return SBX_OK;
+      }
+      // too many long rows: the kernel left early; start over with the tile kernel
+      SBX_HIP(h, hipMemsetAsync(cnt, 0, sizeof(GrayCounts), h->stream));
     }
   }
   const int64_t ntiles = (nnz + GT_TILE - 1) / GT_TILE;
