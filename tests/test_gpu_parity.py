@@ -462,6 +462,15 @@ def test_permute_long_row_segments(ops, oracle):
     for v in (val.astype(np.float32), None, val.astype(np.float64)):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, dev(co)), oracle.permute_csr(rp, col, v, None, co))
+    # one column repeated 300 / 3000 times inside long rows: the segment that holds the run cannot be bucket-ranked
+    # (one bucket gets them all) and goes through the radix kernel for clustered segments; equal columns end in value order
+    for rep in (300, 3000):
+        rows2 = [np.sort(np.concatenate([g.integers(0, m, l - rep), np.full(rep, int(g.integers(0, m)))])) for l in (20000, 9000, 5000)]
+        rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(np.int32)
+        col2 = np.concatenate(rows2).astype(np.int32)
+        ro2 = synth.random_permutation(3, rep)
+        for v2 in (g.integers(-9, 9, len(col2)).astype(np.int32), g.random(len(col2))):
+            same(ops.permute_csr(3, m, dev(rp2), dev(col2), dev(v2), dev(ro2), dev(co)), oracle.permute_csr(rp2, col2, v2, ro2, co))
     # a monotone map over everything: every long row stays in order, duplicates keep their input order
     mono = np.arange(m, dtype=np.int32)
     same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(mono)), oracle.permute_csr(rp, col, val, ro, mono))
@@ -657,6 +666,24 @@ def test_gray_row_keys_long_rows_and_odd_widths(ops, oracle):
     deg, key, counts = ops.gray_row_keys(m, dev(rp.astype(np.int64)), dev(col.astype(np.int64)), 64, 10)
     wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, 64, 10)
     assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+
+
+@pytest.mark.parametrize("res", [1, 2, 3, 5, 8, 12, 15, 16, 17, 31, 33, 64])
+def test_gray_row_keys_every_resolution_on_short_rows(ops, oracle, res):
+    """Short-row matrices at resolutions below 16: a dense row of d <= 64 entries compares its block counts with
+    d / resolution, up to 64 — more counter slices than the 8-lanes-per-row kernel carries, so those calls must take the
+    tile kernel (round 2 shipped the fast path without that bound for a while; tools/fuzz_ops.py found it)."""
+    g = np.random.default_rng(100 + res)
+    n, m = 600, res * 40
+    lens = g.integers(0, min(m, 64) + 1, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(g.choice(m, int(l), replace=False)) for l in lens]).astype(np.int32)
+    for thr in (0, 1, 7, 19, 64):
+        deg, key, counts = ops.gray_row_keys(m, dev(rp), dev(col), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, res, thr)
+        assert np.array_equal(host(deg), wdeg), (res, thr)
+        assert np.array_equal(host(key).view(np.uint64), wkey), (res, thr)
+        assert list(counts) == wcounts.tolist(), (res, thr)
 
 
 # ----------------------------------------------------------------------------- RCM
