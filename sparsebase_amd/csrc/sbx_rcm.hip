@@ -71,6 +71,9 @@ struct RcmDev {
   unsigned long long sl_edges;  // degree sum of the levels the kernel ordered
   unsigned n_components;        // statistics: union-find roots (isolated vertices included) / vertices with an empty row
   unsigned n_empty_rows;
+  // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
+  unsigned tie_deg, tie_count, tie_min_id;
+  unsigned desc[2];             // tie-break walk root -> w_1 -> ... : w_k in desc[k & 1]
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -531,21 +534,62 @@ __device__ __forceinline__ void stage_push(I v, bool won, const I *__restrict__ 
 // Visits up to 4 neighbours per lane in phases (bitmap tests, then coherent ppos
 // pre-checks, then the atomics) so that 4 independent loads per lane are in flight
 // instead of one 3-deep dependent chain per neighbour.
+struct UnorderedSweep {  // state of a sweep that only needs the level SETS (see run_ubfs)
+  unsigned char *claim8;  // MODE 1: one byte per vertex, set when an edge reaches it (plain stores: any parent will do)
+  unsigned *nbits;        // MODE 2: the cone bitmap
+  unsigned *dist;         // level of every reached vertex
+  unsigned level;         // the level being built (MODE 2: the level being marked)
+};
+
+// MODE 0: ordered sweep (smallest parent position wins).  MODE 1: unordered sweep (the first edge to reach a vertex
+// claims its bit in us.nbits).  MODE 2: cone marking of the tie-break (run_ubfs / ubfs_pick_root): the "frontier" is
+// the marked vertices of level us.level + 1, visited are the REACHED vertices of level us.level not marked yet.
+template <int MODE>
 __device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, unsigned p, const I *__restrict__ rp,
                                            const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
-                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
-  unsigned unv = 0;
+                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv, const UnorderedSweep &us) {
+  unsigned seen = 0;  // bit k: v[k] is in the sweep's visited bitmap
 #pragma unroll
   for (int k = 0; k < 4; k++)
-    if (((actmask >> k) & 1u) && !((vbits[v[k] >> 5] >> (v[k] & 31)) & 1u)) unv |= 1u << k;
-  unsigned cur[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    cur[k] = ((unv >> k) & 1u) ? __hip_atomic_load(&ppos[v[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (((actmask >> k) & 1u) && ((vbits[v[k] >> 5] >> (v[k] & 31)) & 1u)) seen |= 1u << k;
+  unsigned unv = MODE == 2 ? seen : (actmask & ~seen & 0xFu);
   unsigned won = 0;
+  if (MODE == 2) {
+    unsigned dk[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (((unv >> k) & 1u) && cur[k] > p && atomicMin(&ppos[v[k]], p) == UNSEEN) won |= 1u << k;
+    for (int k = 0; k < 4; k++) dk[k] = ((unv >> k) & 1u) ? us.dist[v[k]] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (dk[k] != us.level) unv &= ~(1u << k);
+  }
+  if (MODE == 1) {
+    // no atomics and no winner: the level is collected from the bytes afterwards (k_ubfs_collect_*)
+    unsigned char cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = ((unv >> k) & 1u) ? us.claim8[v[k]] : (unsigned char)1;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (!cur[k]) us.claim8[v[k]] = 1;
+    return;
+  } else if (MODE == 2) {
+    // bits only ever get set, so a stale word from the pre-check costs an atomic, not a result
+    unsigned cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = ((unv >> k) & 1u) ? us.nbits[v[k] >> 5] : ~0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned bit = 1u << (v[k] & 31);
+      if (((unv >> k) & 1u) && !(cur[k] & bit) && !(atomicOr(&us.nbits[v[k] >> 5], bit) & bit)) won |= 1u << k;
+    }
+  } else {
+    unsigned cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      cur[k] = ((unv >> k) & 1u) ? __hip_atomic_load(&ppos[v[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (((unv >> k) & 1u) && cur[k] > p && atomicMin(&ppos[v[k]], p) == UNSEEN) won |= 1u << k;
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) stage_push(v[k], (won >> k) & 1u, rp, st, nf_list, dv);
 }
@@ -572,11 +616,13 @@ constexpr int RCM_BU_INLINE = 16;        // bottom-up: candidates up to this deg
 constexpr int RCM_HUB_STAGE = 256;  // hubs a workgroup stages before it reserves their chunk descriptors
 constexpr int RCM_DIR_MAX = 2048;    // workgroups of k_bfs_expand the hub kernel can follow through the directory
 
+template <int U>
 __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
                                                     unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
-                                                    uint2 *__restrict__ hub_dir, RcmDev *__restrict__ dv) {
+                                                    uint2 *__restrict__ hub_dir, RcmDev *__restrict__ dv,
+                                                    UnorderedSweep us) {
   __shared__ I s_stage[4][RCM_STAGE];
   // hubs found by this workgroup: (frontier position, number of chunks).  A frontier of the RMAT input holds
   // ~20 K hubs; one returning atomic each on dv->n_heavy is 0.2 ms of queueing on that word.  (The hub kernel
@@ -637,7 +683,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
         v[k] = jk < e ? col[jk] : 0;
         if (jk < e) act |= 1u << k;
       }
-      bfs_visit4(v, act, (unsigned)p, rp, vbits, ppos, st, nf_list, dv);
+      bfs_visit4<U>(v, act, (unsigned)p, rp, vbits, ppos, st, nf_list, dv, us);
       j += 4 * RCM_GROUP;
     }
   }
@@ -664,13 +710,14 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   stage_end_block(st, nf_list, dv, scanned, false);
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
                                                           const I *__restrict__ frontier, unsigned next_level,
                                                           const unsigned *__restrict__ vbits, unsigned *ppos,
                                                           I *__restrict__ nf_list,
                                                           const uint64_t *__restrict__ heavy,
                                                           const uint2 *__restrict__ hub_dir, unsigned ndir,
-                                                          RcmDev *__restrict__ dv) {
+                                                          RcmDev *__restrict__ dv, UnorderedSweep us) {
   __shared__ I s_stage[4][RCM_STAGE];
   __shared__ unsigned s_dfirst[RCM_DIR_MAX + 1];  // directory: how many descriptors came before a workgroup's run
   __shared__ unsigned s_dscan[256 / 64 + 1];
@@ -729,7 +776,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
         v[k] = j < ce ? col[j] : 0;
         if (j < ce) act |= 1u << k;
       }
-      bfs_visit4(v, act, p, rp, vbits, ppos, st, nf_list, dv);
+      bfs_visit4<U>(v, act, p, rp, vbits, ppos, st, nf_list, dv, us);
     }
     scanned += (unsigned long long)(ce - cs);
   }
@@ -1579,7 +1626,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   static int heavy_per_cu = 0;
   if (heavy_per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bfs_expand_heavy, 256, 0) != hipSuccess || nb < 1) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bfs_expand_heavy<0>, 256, 0) != hipSuccess || nb < 1) nb = 4;
     heavy_per_cu = nb;
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
@@ -1628,12 +1675,13 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       unsigned grid = (waves_needed + 3) / 4;
       if (grid > max_grid) grid = max_grid;
       if (grid < 1) grid = 1;
-      SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off), fsize,
-                  level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv);
+      const UnorderedSweep none = {nullptr, nullptr, nullptr, 0u};
+      SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<0>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
+                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, none);
       if (b.max_deg > (unsigned)RCM_LIGHT)  // mesh-like inputs have no hubs: one launch less per level
-        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy, dim3(heavy_grid), dim3(256), b.rp, b.col,
+        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<0>, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
-                    (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv);
+                    (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, none);
     }
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
@@ -1705,6 +1753,439 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   out->levels = level + 1;
   out->last_offset = off;
   out->last_size = fsize;
+  return SBX_OK;
+}
+
+// ---- unordered sweeps ---------------------------------------------------------------------------------------
+// A sweep of the pseudo-peripheral search is only asked three things: how many levels, how many vertices, and which
+// vertex of the deepest level comes FIRST in queue order among those of smallest degree (rcm_reorder.cc:58-76).  The
+// first two do not depend on the order inside a level at all, so these sweeps run as a plain direction-optimising BFS
+// over level SETS: an edge that reaches an unvisited vertex sets its byte in `claim8` (a plain store: any parent will
+// do, so there is nothing to win and no atomic), the bottom-up kernel stops at the first frontier neighbour, and the
+// level — bitmaps, distances, the list in ascending id order, its size and degree sum — is collected from the bytes
+// by two streaming kernels over n (k_ubfs_collect_words / _list).  Nothing is sorted and no parent position is kept.  The third is settled
+// afterwards, exactly, without knowing any position: let T_L be the candidates (deepest level, smallest degree) and
+// T_{k-1} the level-(k-1) neighbours of T_k.  A vertex's queue position is ordered by (position of its first parent,
+// id), all parents of T_k lie in T_{k-1}, and every member of T_{k-1} is a parent of some member of T_k — so the first
+// member of T_k in queue order is the smallest id among the members of T_k adjacent to the first member of T_{k-1}.
+// Marking the T_k upwards (k_ubfs_cone_up) and walking root -> w_1 -> ... -> w_L downwards (k_ubfs_descend) costs a
+// few adjacency scans where the ordered sweep sorted every level.  Deep, narrow graphs (more than UB_MAX_LEVELS
+// levels) keep the ordered sweep, whose small levels run in one persistent workgroup.
+constexpr unsigned UB_MAX_LEVELS = 64;
+
+static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search keeps the order inside its levels
+  static const bool on = !(getenv("SBX_RCM_UNORDERED") && atoi(getenv("SBX_RCM_UNORDERED")) == 0);
+  return on;
+}
+
+__global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
+                             unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root) {
+  const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
+  dv->root = (unsigned)r;
+  vbits[r >> 5] = 1u << (r & 31);  // the bitmaps were cleared by the host for this sweep
+  fbits[r >> 5] = 1u << (r & 31);
+  dist[r] = 0;
+  q[0] = r;
+  dv->nf = 0;
+  dv->n_heavy = 0;
+  dv->hub_overflow = 0;
+  dv->fedges = (unsigned long long)(rp[r + 1] - rp[r]);
+}
+
+// Level collection, pass 1 (64 bitmap words = 4096 vertices per workgroup, as k_fresh_words): claimed bytes -> the
+// frontier word, visited |= it, bytes cleared, distances written; per-word counts and per-workgroup totals of the
+// level's size and degree sum.
+__global__ __launch_bounds__(256) void k_ubfs_collect_words(unsigned char *__restrict__ claim8,
+                                                            unsigned long long *__restrict__ vbits64,
+                                                            unsigned long long *__restrict__ fbits64,
+                                                            unsigned *__restrict__ dist, unsigned level,
+                                                            const I *__restrict__ rp, int *__restrict__ cnt,
+                                                            int *__restrict__ btot, unsigned long long *__restrict__ dtot,
+                                                            int64_t n) {
+  constexpr int WPW = RCM_FW_WORDS / 4;
+  __shared__ int s_tot;
+  __shared__ unsigned long long s_deg;
+  if (threadIdx.x == 0) s_tot = 0, s_deg = 0;
+  __syncthreads();
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS + (int64_t)wv * WPW;
+  unsigned char cb[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int64_t v = (w0 + i) * 64 + lane;
+    cb[i] = v < n ? claim8[v] : (unsigned char)0;
+  }
+  int mine = 0;
+  unsigned long long deg = 0;
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int64_t v = (w0 + i) * 64 + lane;
+    const unsigned long long now = __ballot(cb[i] != 0);
+    if (cb[i]) {
+      claim8[v] = 0;
+      dist[v] = level;
+      deg += (unsigned long long)(rp[v + 1] - rp[v]);
+    }
+    if ((w0 + i) * 64 < n && lane == 0) {
+      fbits64[w0 + i] = now;
+      if (now) vbits64[w0 + i] |= now;
+      cnt[w0 + i] = __popcll(now);
+    }
+    mine += lane == 0 ? __popcll(now) : 0;
+  }
+  mine = sbx_wave_sum(mine);
+  deg = sbx_wave_sum(deg);
+  if (lane == 0 && mine) {
+    atomicAdd(&s_tot, mine);
+    atomicAdd(&s_deg, deg);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    btot[blockIdx.x] = s_tot;
+    dtot[blockIdx.x] = s_deg;
+  }
+}
+
+// pass 2: the level's vertices in ascending id order into the queue (bases as in k_keys_from_fresh); the last
+// workgroup also leaves the level's size and degree sum where the host reads them
+__global__ __launch_bounds__(256) void k_ubfs_collect_list(const unsigned long long *__restrict__ fbits64,
+                                                           const int *__restrict__ cnt, const int *__restrict__ btot,
+                                                           const unsigned long long *__restrict__ dtot,
+                                                           I *__restrict__ q_next, int64_t words,
+                                                           RcmDev *__restrict__ dv) {
+  constexpr int WPW = RCM_FW_WORDS / 4;
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  int base = 0;
+  for (int i = lane; i < (int)blockIdx.x; i += 64) base += btot[i];
+  base = sbx_wave_sum(base);
+  if (blockIdx.x == gridDim.x - 1 && wv == 0) {
+    unsigned long long d = 0;
+    for (int i = lane; i < (int)gridDim.x; i += 64) d += dtot[i];
+    d = sbx_wave_sum(d);
+    if (lane == 0) {
+      dv->nf = (unsigned)(base + btot[blockIdx.x]);
+      dv->fedges = d;
+      dv->n_heavy = 0;
+      dv->hub_overflow = 0;
+    }
+  }
+  const int64_t wb = (int64_t)blockIdx.x * RCM_FW_WORDS;
+  const int c = wb + lane < words ? cnt[wb + lane] : 0;
+  const int inc = sbx_wave_inclusive_sum(c);
+  const int excl = base + inc - c;
+  const unsigned long long mine = (lane >= wv * WPW && lane < (wv + 1) * WPW && wb + lane < words) ? fbits64[wb + lane] : 0ull;
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int src = wv * WPW + i;
+    const unsigned long long f = __shfl(mine, src, 64);
+    const int o = __shfl(excl, src, 64);
+    if ((f >> lane) & 1ull) q_next[o + __popcll(f & sbx_lanemask_lt())] = (I)((wb + src) * 64 + lane);
+  }
+}
+
+// bottom-up without positions: an unvisited vertex joins the level at its FIRST neighbour in the frontier
+__global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
+                                                        const I *__restrict__ label, I comp_label,
+                                                        const unsigned *__restrict__ vbits,
+                                                        const unsigned *__restrict__ fbits,
+                                                        unsigned char *__restrict__ claim8, I *__restrict__ nf_list,
+                                                        int64_t n, RcmDev *__restrict__ dv) {
+  __shared__ I s_stage[4][RCM_STAGE];
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int lane = sbx_lane();
+  const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  unsigned long long scanned = 0;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t v = base + lane;
+    bool cand = false;
+    I s = 0, e = 0;
+    if (v < n && !((vbits[v >> 5] >> (v & 31)) & 1u)) {
+      s = rp[v];
+      e = rp[v + 1];
+      cand = (e > s) && (label == nullptr || label[v] == comp_label);
+    }
+    const bool small = cand && (e - s) <= RCM_BU_INLINE;
+    bool found = false;
+    if (__any(small)) {
+      const int dg = small ? (int)(e - s) : 0;
+      I us[RCM_BU_INLINE];
+#pragma unroll
+      for (int k = 0; k < RCM_BU_INLINE; k++) us[k] = k < dg ? col[s + k] : (I)-1;
+#pragma unroll
+      for (int k = 0; k < RCM_BU_INLINE; k++)
+        if (us[k] >= 0 && ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u)) found = true;
+      if (small) scanned += (unsigned)dg;
+      found = found && small;
+    }
+    uint64_t todo = __ballot(cand && !small);
+    uint64_t big_found = 0;  // lanes (vertices) of this wave's 64 that a group found a frontier neighbour for
+    while (todo) {
+      uint64_t t = todo;
+      int pick = -1;
+      for (int g = 0; g < RCM_VPW; g++) {
+        const int c = t ? __builtin_ctzll(t) : -1;
+        if (g == grp) pick = c;
+        if (t) t &= t - 1;
+      }
+      todo = t;
+      const I cs = __shfl(s, pick < 0 ? 0 : pick, 64), ce = __shfl(e, pick < 0 ? 0 : pick, 64);
+      bool hit = false;
+      I j = (pick < 0 ? 0 : cs) + gl;
+      const I jend = pick < 0 ? 0 : ce;
+      unsigned seen = 0;
+      while (__any(j < jend)) {
+        I us[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) us[k] = (j + k * RCM_GROUP) < jend ? col[j + k * RCM_GROUP] : (I)-1;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (us[k] >= 0) {
+            seen++;
+            if ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u) hit = true;
+          }
+        // a group whose vertex has been found stops (its 16 lanes agree through the row-wide OR)
+        const unsigned any_hit = sbx_row16_reduce(hit ? 1u : 0u, SbxOpMax());
+        j = any_hit ? jend : j + 4 * RCM_GROUP;
+      }
+      scanned += seen;
+      const unsigned ghit = sbx_row16_reduce(hit ? 1u : 0u, SbxOpMax());
+      // the lane that holds a group's vertex is lane `pick` of the wave: collect the groups' results for their owners
+#pragma unroll
+      for (int g = 0; g < RCM_VPW; g++) {
+        const int pk = __shfl(pick, g * RCM_GROUP, 64);
+        const unsigned gh = __shfl(ghit, g * RCM_GROUP, 64);
+        if (gh && pk >= 0) big_found |= (uint64_t)1 << pk;
+      }
+    }
+    found = found || ((big_found >> lane) & 1ull);
+    if (found) claim8[v] = 1;  // lane = vertex: 64 consecutive bytes per wave
+  }
+  stage_end_block(st, nf_list, dv, scanned, true);
+}
+
+// deepest level: smallest degree, then how many vertices have it (marked in the cone bitmap) and the smallest id
+__global__ __launch_bounds__(256) void k_ubfs_min_degree(const I *__restrict__ rp, const I *__restrict__ level,
+                                                         unsigned count, RcmDev *__restrict__ dv) {
+  unsigned best = 0xFFFFFFFFu;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
+    const I v = level[j];
+    const unsigned d = (unsigned)(rp[v + 1] - rp[v]);
+    best = d < best ? d : best;
+  }
+  best = sbx_wave_min(best);
+  if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->tie_deg, best);
+}
+__global__ __launch_bounds__(256) void k_ubfs_mark_ties(const I *__restrict__ rp, const I *__restrict__ level,
+                                                        unsigned count, unsigned *__restrict__ cone,
+                                                        I *__restrict__ list, RcmDev *__restrict__ dv) {
+  const unsigned dmin = dv->tie_deg;
+  unsigned mid = 0xFFFFFFFFu;
+  const unsigned rounds = (count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  for (unsigned r = 0; r < rounds; r++) {  // (all lanes stay in the loop: the append is wave-wide)
+    const unsigned j = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    I v = 0;
+    bool tie = false;
+    if (j < count) {
+      v = level[j];
+      tie = (unsigned)(rp[v + 1] - rp[v]) == dmin;
+    }
+    if (tie) {
+      atomicOr(&cone[v >> 5], 1u << (v & 31));
+      mid = (unsigned)v < mid ? (unsigned)v : mid;
+    }
+    const unsigned slot = sbx_wave_append(&dv->tie_count, tie);
+    if (tie) list[slot] = v;
+  }
+  mid = sbx_wave_min(mid);
+  if (sbx_lane() == 0 && mid != 0xFFFFFFFFu) atomicMin(&dv->tie_min_id, mid);
+}
+__global__ void k_ubfs_root_from_single_tie(RcmDev *__restrict__ dv) { dv->root = dv->tie_min_id; }
+
+__global__ void k_ubfs_reset_counters(RcmDev *__restrict__ dv) { reset_level_counters(dv); }
+
+// w_0 = root, w_k = smallest id among the marked level-k neighbours of w_{k-1}; w_L is the next root.  One launch per
+// level (w_{k-1} may be a hub with 10^5 neighbours: the whole grid scans them); w_k lives in dv->desc[k & 1].
+__global__ void k_ubfs_descend_start(RcmDev *__restrict__ dv) {
+  dv->desc[0] = dv->root;
+  dv->desc[1] = 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(256) void k_ubfs_descend_step(const I *__restrict__ rp, const I *__restrict__ col,
+                                                           const unsigned *__restrict__ vbits,
+                                                           const unsigned *__restrict__ dist,
+                                                           const unsigned *__restrict__ cone, unsigned k,
+                                                           RcmDev *__restrict__ dv) {
+  const unsigned w = dv->desc[(k - 1) & 1];
+  if (w == 0xFFFFFFFFu) {  // the step before found nothing: cannot happen on a symmetric pattern
+    if (blockIdx.x == 0 && threadIdx.x == 0) dv->unsym = 1;
+    return;
+  }
+  unsigned best = 0xFFFFFFFFu;
+  const I s = rp[w], e = rp[w + 1];
+  for (int64_t a = (int64_t)s + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < e; a += (int64_t)gridDim.x * blockDim.x) {
+    const I c = col[a];
+    if (((cone[c >> 5] >> (c & 31)) & 1u) && ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k)
+      best = (unsigned)c < best ? (unsigned)c : best;
+  }
+  best = sbx_wave_min(best);
+  if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k & 1], best);
+}
+// between two steps: the slot the next step will minimise into
+__global__ void k_ubfs_descend_next(RcmDev *__restrict__ dv, unsigned k, int last) {
+  if (last) {
+    const unsigned w = dv->desc[k & 1];
+    if (w == 0xFFFFFFFFu) dv->unsym = 1;
+    else dv->root = w;
+  } else {
+    dv->desc[(k + 1) & 1] = 0xFFFFFFFFu;
+  }
+}
+
+// One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed
+// UB_MAX_LEVELS levels and was abandoned (the caller runs the ordered sweep instead).  `levels_off` / `levels_size`
+// receive the levels' places in q.
+static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, I fixed_root, I comp_label,
+                    BfsResult *out, std::vector<unsigned> &levels_off, std::vector<unsigned> &levels_size,
+                    bool *too_deep) {
+  const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
+  const int64_t words = (b.n + 63) / 64;
+  const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
+  *too_deep = false;
+  if (fw_blocks > RCM_FW_INLINE) {  // (> 16 M vertices: the collection kernels sum their predecessors' totals inline)
+    *too_deep = true;
+    return SBX_OK;
+  }
+  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
+  SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
+  unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
+  unsigned long long *dtot = (unsigned long long *)b.ka;  // (the sort buffers are free as well)
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root);
+  unsigned off = 0, fsize = 1, level = 0, total = 1;
+  const unsigned max_grid = (unsigned)h->num_cus * 8;
+  static int heavy_per_cu = 0;
+  if (heavy_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bfs_expand_heavy<1>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+    heavy_per_cu = nb;
+  }
+  const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
+  int64_t remaining = b.nnz, frontier_edges = -1;
+  levels_off.assign(1, 0u);
+  levels_size.assign(1, 1u);
+  while (true) {
+    I *q_next = b.q + off + fsize;  // the next level is appended to the queue when it is collected
+    const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
+    const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
+    if (bottom_up) {
+      SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
+                  (const unsigned *)b.vbits, (const unsigned *)b.fbits, claim8, b.nf_list, b.n, b.dv);
+    } else {
+      const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
+      unsigned grid = (waves_needed + 3) / 4;
+      if (grid > max_grid) grid = max_grid;
+      if (grid < 1) grid = 1;
+      SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<1>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
+                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, us);
+      if (b.max_deg > (unsigned)RCM_LIGHT)
+        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<1>, dim3(heavy_grid), dim3(256), b.rp, b.col,
+                    (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
+                    (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, us);
+    }
+    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect_words, dim3((unsigned)fw_blocks), dim3(256), claim8,
+                (unsigned long long *)b.vbits, (unsigned long long *)b.fbits, dist, level + 1, b.rp, b.wcnt, b.woff, dtot,
+                b.n);
+    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect_list, dim3((unsigned)fw_blocks), dim3(256),
+                (const unsigned long long *)b.fbits, (const int *)b.wcnt, (const int *)b.woff,
+                (const unsigned long long *)dtot, q_next, words, b.dv);
+    SBX_LAUNCH_CHECK(h);
+    RcmDev hd;
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    const unsigned nf = hd.nf;
+    if (nf == 0) break;
+    frontier_edges = (int64_t)hd.fedges;
+    remaining -= frontier_edges;
+    if (remaining < 0) remaining = 0;
+    off += fsize;
+    fsize = nf;
+    total += nf;
+    level++;
+    levels_off.push_back(off);
+    levels_size.push_back(fsize);
+    if (level + 1 > UB_MAX_LEVELS) {
+      *too_deep = true;
+      return SBX_OK;
+    }
+  }
+  out->count = total;
+  out->levels = level + 1;
+  out->last_offset = off;
+  out->last_size = fsize;
+  return SBX_OK;
+}
+
+// the next candidate root after an unordered sweep: first vertex in queue order among the deepest level's vertices of
+// smallest degree (see the comment above k_ubfs_start); left in dv->root
+static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r,
+                          const std::vector<unsigned> &levels_off, const std::vector<unsigned> &levels_size) {
+  const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
+  const unsigned *dist = b.lpos;
+  const I *last = b.q + r.last_offset;
+  static const unsigned tie_init[3] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
+  SBX_HIP(h, hipMemcpyAsync(&b.dv->tie_deg, tie_init, sizeof(tie_init), hipMemcpyHostToDevice, h->stream));
+  const unsigned g = sbx_grid_for(r.last_size, 256, 1024);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_min_degree, dim3(g), dim3(256), b.rp, last, r.last_size, b.dv);
+  SBX_HIP(h, hipMemsetAsync(cone, 0, bm_bytes, h->stream));
+  I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level by level from the deepest up
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_ties, dim3(g), dim3(256), b.rp, last, r.last_size, cone, list, b.dv);
+  SBX_LAUNCH_CHECK(h);
+  RcmDev hd;
+  SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+  if (hd.tie_count <= 1) {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
+    SBX_LAUNCH_CHECK(h);
+    return SBX_OK;
+  }
+  // T_{k-1} = the level-(k-1) neighbours of T_k: the expansion kernels in cone mode, hubs split into chunks as ever
+  const unsigned max_grid = (unsigned)h->num_cus * 8;
+  static int heavy_per_cu = 0;
+  if (heavy_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bfs_expand_heavy<2>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+    heavy_per_cu = nb;
+  }
+  const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
+  unsigned cnt = hd.tie_count;
+  for (unsigned k = r.levels - 1; k >= 2; k--) {  // level 0 is the root: every T_1 member hangs under it
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_reset_counters, dim3(1), dim3(1), b.dv);
+    const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
+    const unsigned waves_needed = (cnt + RCM_VPW - 1) / RCM_VPW;
+    unsigned grid = (waves_needed + 3) / 4;
+    if (grid > max_grid) grid = max_grid;
+    if (grid < 1) grid = 1;
+    I *next = list + cnt;
+    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(grid), dim3(256), b.rp, b.col, (const I *)list, cnt, k,
+                (const unsigned *)b.vbits, b.ppos, next, b.heavy, b.hub_dir, b.dv, us);
+    if (b.max_deg > (unsigned)RCM_LIGHT)
+      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col, (const I *)list, k,
+                  (const unsigned *)b.vbits, b.ppos, next, (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid,
+                  b.dv, us);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    list = next;
+    cnt = hd.nf;
+    if (cnt == 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: a level has no path to the level below (pattern not symmetric?)");
+  }
+  (void)levels_off;
+  (void)levels_size;
+  (void)dist;
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_start, dim3(1), dim3(1), b.dv);
+  for (unsigned k = 1; k < r.levels; k++) {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_step, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
+                (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, k, b.dv);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_next, dim3(1), dim3(1), b.dv, k, k + 1 == r.levels ? 1 : 0);
+  }
+  SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
@@ -1842,8 +2323,21 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   BfsResult r0;
   r0.count = 0;
   SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));
+  // sweeps of the pseudo-peripheral search run unordered (level sets only, run_ubfs) unless the component turns out
+  // deep and narrow
+  unsigned char *claim8 = nullptr;
+  unsigned *cone = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)n + 64, &claim8));
+  SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
+  std::vector<unsigned> lv_off, lv_size, lv_off0, lv_size0;
+  bool r0_unordered = false;
   if (v0 >= 0) {
-    SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
+    bool deep = true;
+    if (rcm_unordered()) {
+      SBX_TRY(run_ubfs(h, b, claim8, v0, (I)-1, &r0, lv_off0, lv_size0, &deep));
+      r0_unordered = !deep;
+    }
+    if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
     SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
   }
   // (3) connected components of the rest; the root of each tree is the component's smallest id
@@ -1877,7 +2371,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const bool mid_batched = hd.n_mid >= (unsigned)RCM_MID_BATCH;
   const unsigned n_host = hd.n_large + (mid_batched ? 0u : hd.n_mid);  // components ordered from the host
   const bool first_is_large = r0.count > (unsigned)RCM_SMALL && !(mid_batched && r0.count <= (unsigned)RCM_MID);
-  if (v0 >= 0 && !first_is_large) {
+  if (v0 >= 0 && !first_is_large && !r0_unordered) {
     // the pre-swept component is handled by the batched kernel: drop the sweep's marks
     SBX_TRY(reset_ppos(h, (const I *)q, r0.count, ppos, n));
   }
@@ -1932,11 +2426,16 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       I fixed = roots[c];
       bool have_first_sweep = first_is_large && roots[c] == v0;
       bool cm_done = false;
+      bool deep = !rcm_unordered();  // a sweep of more than UB_MAX_LEVELS levels: this component keeps ordered sweeps
       while (prev_ecc != ecc) {
         prev_ecc = ecc;
+        bool unordered = false;  // the sweep just run kept no order inside its levels
         if (have_first_sweep) {
           r = r0;  // sweep (2) above was exactly this component's first sweep
           have_first_sweep = false;
+          unordered = r0_unordered;
+          if (unordered) lv_off = lv_off0, lv_size = lv_size0;
+          else deep = true;
         } else {
           if (candidate >= rcm_speculate_from()) {
             SBX_TRY(join_ranks());
@@ -1952,7 +2451,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
             SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
             fixed = -1;  // k_bfs_start left the root on the device
           }
-          SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
+          if (!deep) {
+            SBX_TRY(run_ubfs(h, b, claim8, fixed, roots[c], &r, lv_off, lv_size, &deep));
+            unordered = !deep;
+          }
+          if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
         }
         fixed = -1;  // later sweeps start from the device-resident root
         candidate++;
@@ -1962,11 +2465,15 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         if (e > ecc) ecc = e;
         const bool path = (int64_t)r.count == ecc + 1;
         if (!path && prev_ecc != ecc) {
-          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
-                             (const I *)(q + r.last_offset), r.last_size, dv);
-          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
+          if (unordered) {
+            SBX_TRY(ubfs_pick_root(h, b, cone, r, lv_off, lv_size));
+          } else {
+            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
+                               (const I *)(q + r.last_offset), r.last_size, dv);
+            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
+          }
         }
-        SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
+        if (!unordered) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
         if (path) break;
       }
       // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
