@@ -73,7 +73,7 @@ struct RcmDev {
   unsigned n_empty_rows;
   // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
   unsigned tie_deg, tie_count, tie_min_id;
-  unsigned desc[2];             // tie-break walk root -> w_1 -> ... : w_k in desc[k & 1]
+  unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -569,7 +569,7 @@ __device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, un
     for (int k = 0; k < 4; k++) cur[k] = ((unv >> k) & 1u) ? us.claim8[v[k]] : (unsigned char)1;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (!cur[k]) us.claim8[v[k]] = 1;
+      if (!cur[k]) us.claim8[v[k]] = 1;  // (storing without the pre-check load measured 1 % slower)
     return;
   } else if (MODE == 2) {
     // bits only ever get set, so a stale word from the pre-check costs an atomic, not a result
@@ -1763,15 +1763,26 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
 // over level SETS: an edge that reaches an unvisited vertex sets its byte in `claim8` (a plain store: any parent will
 // do, so there is nothing to win and no atomic), the bottom-up kernel stops at the first frontier neighbour, and the
 // level — bitmaps, distances, the list in ascending id order, its size and degree sum — is collected from the bytes
-// by two streaming kernels over n (k_ubfs_collect_words / _list).  Nothing is sorted and no parent position is kept.  The third is settled
-// afterwards, exactly, without knowing any position: let T_L be the candidates (deepest level, smallest degree) and
-// T_{k-1} the level-(k-1) neighbours of T_k.  A vertex's queue position is ordered by (position of its first parent,
-// id), all parents of T_k lie in T_{k-1}, and every member of T_{k-1} is a parent of some member of T_k — so the first
-// member of T_k in queue order is the smallest id among the members of T_k adjacent to the first member of T_{k-1}.
-// Marking the T_k upwards (k_ubfs_cone_up) and walking root -> w_1 -> ... -> w_L downwards (k_ubfs_descend) costs a
-// few adjacency scans where the ordered sweep sorted every level.  Deep, narrow graphs (more than UB_MAX_LEVELS
-// levels) keep the ordered sweep, whose small levels run in one persistent workgroup.
-constexpr unsigned UB_MAX_LEVELS = 64;
+// by two streaming kernels over n (k_ubfs_collect_words / _list).  Nothing is sorted, no parent position is kept.
+// The third is settled afterwards, exactly, without knowing any position: let T_L be the candidates (deepest level,
+// smallest degree) and T_{k-1} the level-(k-1) neighbours of T_k.  A vertex's queue position is ordered by (position
+// of its first parent, id); all parents of T_k lie in T_{k-1}, and every member of T_{k-1} is a parent of some member
+// of T_k — so the first member of T_k in queue order is the smallest id among the members of T_k adjacent to the first
+// member of T_{k-1}.  Marking the T_k upwards (the expansion kernels in their cone mode) and walking root -> w_1 -> ...
+// -> w_L downwards (k_ubfs_descend_step) costs a few adjacency scans where the ordered sweep sorted every level.
+// Deep, narrow graphs (a sweep of more than 64 levels) keep the ordered sweep, whose small levels run in one
+// persistent workgroup.
+static unsigned ub_max_levels() {  // SBX_DEBUG_UB_MAX_LEVELS: deeper sweeps fall back to the ordered kind (tests raise it)
+  static const unsigned v = getenv("SBX_DEBUG_UB_MAX_LEVELS") ? (unsigned)atoll(getenv("SBX_DEBUG_UB_MAX_LEVELS")) : 64u;
+  return v;
+}
+
+// an unordered bottom-up step stops at a vertex's first frontier neighbour, so it pays off much earlier than the ordered
+// one, which must see every neighbour: bottom-up when the frontier owns more than this many times the unvisited edges
+static double ubu_ratio() {
+  static const double r = getenv("SBX_DEBUG_UBU_RATIO") ? atof(getenv("SBX_DEBUG_UBU_RATIO")) : 0.5;
+  return r;
+}
 
 static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search keeps the order inside its levels
   static const bool on = !(getenv("SBX_RCM_UNORDERED") && atoi(getenv("SBX_RCM_UNORDERED")) == 0);
@@ -1965,7 +1976,58 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
   stage_end_block(st, nf_list, dv, scanned, true);
 }
 
-// deepest level: smallest degree, then how many vertices have it (marked in the cone bitmap) and the smallest id
+// deepest level: smallest degree, then the vertices that have it — marked in the cone bitmap, listed (the list counter
+// is dv->nf), their number and smallest id.  A level of up to UB_TIES_SMALL vertices (the usual case: a handful) is one
+// workgroup's job; larger ones take three launches.
+constexpr unsigned UB_TIES_SMALL = 8192;
+__global__ __launch_bounds__(1024) void k_ubfs_ties_small(const I *__restrict__ rp, const I *__restrict__ level,
+                                                          unsigned count, unsigned *__restrict__ cone,
+                                                          I *__restrict__ list, RcmDev *__restrict__ dv) {
+  __shared__ unsigned s_red[16], s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  unsigned best = 0xFFFFFFFFu;
+  for (unsigned j = threadIdx.x; j < count; j += 1024) {
+    const I v = level[j];
+    const unsigned d = (unsigned)(rp[v + 1] - rp[v]);
+    best = d < best ? d : best;
+  }
+  best = sbx_wave_min(best);
+  if (sbx_lane() == 0) s_red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  unsigned dmin = 0xFFFFFFFFu;
+  for (int i = 0; i < 16; i++) dmin = s_red[i] < dmin ? s_red[i] : dmin;
+  __syncthreads();
+  unsigned mid = 0xFFFFFFFFu;
+  for (unsigned j = threadIdx.x; j < count; j += 1024) {
+    const I v = level[j];
+    if ((unsigned)(rp[v + 1] - rp[v]) == dmin) {
+      atomicOr(&cone[v >> 5], 1u << (v & 31));
+      list[atomicAdd(&s_cnt, 1u)] = v;
+      mid = (unsigned)v < mid ? (unsigned)v : mid;
+    }
+  }
+  mid = sbx_wave_min(mid);
+  if (sbx_lane() == 0) s_red[threadIdx.x >> 6] = mid;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned m = 0xFFFFFFFFu;
+    for (int i = 0; i < 16; i++) m = s_red[i] < m ? s_red[i] : m;
+    dv->tie_deg = dmin;
+    dv->tie_min_id = m;
+    dv->tie_count = s_cnt;
+    dv->nf = s_cnt;
+    dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  }
+}
+__global__ void k_ubfs_ties_init(RcmDev *__restrict__ dv) {
+  dv->tie_deg = 0xFFFFFFFFu;
+  dv->tie_min_id = 0xFFFFFFFFu;
+  dv->tie_count = 0;
+  dv->nf = 0;
+  dv->n_heavy = 0;
+  dv->hub_overflow = 0;
+}
 __global__ __launch_bounds__(256) void k_ubfs_min_degree(const I *__restrict__ rp, const I *__restrict__ level,
                                                          unsigned count, RcmDev *__restrict__ dv) {
   unsigned best = 0xFFFFFFFFu;
@@ -1995,18 +2057,21 @@ __global__ __launch_bounds__(256) void k_ubfs_mark_ties(const I *__restrict__ rp
       atomicOr(&cone[v >> 5], 1u << (v & 31));
       mid = (unsigned)v < mid ? (unsigned)v : mid;
     }
-    const unsigned slot = sbx_wave_append(&dv->tie_count, tie);
+    const unsigned slot = sbx_wave_append(&dv->nf, tie);
     if (tie) list[slot] = v;
   }
   mid = sbx_wave_min(mid);
   if (sbx_lane() == 0 && mid != 0xFFFFFFFFu) atomicMin(&dv->tie_min_id, mid);
 }
 __global__ void k_ubfs_root_from_single_tie(RcmDev *__restrict__ dv) { dv->root = dv->tie_min_id; }
-
-__global__ void k_ubfs_reset_counters(RcmDev *__restrict__ dv) { reset_level_counters(dv); }
+__global__ void k_ubfs_reset_hubs(RcmDev *__restrict__ dv) {
+  dv->n_heavy = 0;
+  dv->hub_overflow = 0;
+}
 
 // w_0 = root, w_k = smallest id among the marked level-k neighbours of w_{k-1}; w_L is the next root.  One launch per
-// level (w_{k-1} may be a hub with 10^5 neighbours: the whole grid scans them); w_k lives in dv->desc[k & 1].
+// level (w_{k-1} may be a hub with 10^5 neighbours: the whole grid scans them); w_k lives in dv->desc[k % 3], and the
+// step that fills slot k % 3 also clears slot (k + 1) % 3 for the step after it.
 __global__ void k_ubfs_descend_start(RcmDev *__restrict__ dv) {
   dv->desc[0] = dv->root;
   dv->desc[1] = 0xFFFFFFFFu;
@@ -2016,7 +2081,8 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_step(const I *__restrict__
                                                            const unsigned *__restrict__ dist,
                                                            const unsigned *__restrict__ cone, unsigned k,
                                                            RcmDev *__restrict__ dv) {
-  const unsigned w = dv->desc[(k - 1) & 1];
+  const unsigned w = dv->desc[(k - 1) % 3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) dv->desc[(k + 1) % 3] = 0xFFFFFFFFu;
   if (w == 0xFFFFFFFFu) {  // the step before found nothing: cannot happen on a symmetric pattern
     if (blockIdx.x == 0 && threadIdx.x == 0) dv->unsym = 1;
     return;
@@ -2029,17 +2095,12 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_step(const I *__restrict__
       best = (unsigned)c < best ? (unsigned)c : best;
   }
   best = sbx_wave_min(best);
-  if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k & 1], best);
+  if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k % 3], best);
 }
-// between two steps: the slot the next step will minimise into
-__global__ void k_ubfs_descend_next(RcmDev *__restrict__ dv, unsigned k, int last) {
-  if (last) {
-    const unsigned w = dv->desc[k & 1];
-    if (w == 0xFFFFFFFFu) dv->unsym = 1;
-    else dv->root = w;
-  } else {
-    dv->desc[(k + 1) & 1] = 0xFFFFFFFFu;
-  }
+__global__ void k_ubfs_descend_end(RcmDev *__restrict__ dv, unsigned last_k) {
+  const unsigned w = dv->desc[last_k % 3];
+  if (w == 0xFFFFFFFFu) dv->unsym = 1;
+  else dv->root = w;
 }
 
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed
@@ -2076,7 +2137,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   while (true) {
     I *q_next = b.q + off + fsize;  // the next level is appended to the queue when it is collected
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
-    const bool bottom_up = frontier_edges >= 0 && fsize >= 8192 && (double)frontier_edges > bu_ratio() * (double)remaining;
+    const bool bottom_up = frontier_edges >= 0 && fsize >= 1024 && (double)frontier_edges > ubu_ratio() * (double)remaining;
     if (bottom_up) {
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, claim8, b.nf_list, b.n, b.dv);
@@ -2112,7 +2173,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     level++;
     levels_off.push_back(off);
     levels_size.push_back(fsize);
-    if (level + 1 > UB_MAX_LEVELS) {
+    if (level + 1 > ub_max_levels()) {
       *too_deep = true;
       return SBX_OK;
     }
@@ -2126,27 +2187,29 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
 
 // the next candidate root after an unordered sweep: first vertex in queue order among the deepest level's vertices of
 // smallest degree (see the comment above k_ubfs_start); left in dv->root
-static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r,
-                          const std::vector<unsigned> &levels_off, const std::vector<unsigned> &levels_size) {
+static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
-  const unsigned *dist = b.lpos;
   const I *last = b.q + r.last_offset;
-  static const unsigned tie_init[3] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
-  SBX_HIP(h, hipMemcpyAsync(&b.dv->tie_deg, tie_init, sizeof(tie_init), hipMemcpyHostToDevice, h->stream));
-  const unsigned g = sbx_grid_for(r.last_size, 256, 1024);
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_min_degree, dim3(g), dim3(256), b.rp, last, r.last_size, b.dv);
+  I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level after level, one growing list
   SBX_HIP(h, hipMemsetAsync(cone, 0, bm_bytes, h->stream));
-  I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level by level from the deepest up
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_ties, dim3(g), dim3(256), b.rp, last, r.last_size, cone, list, b.dv);
+  if (r.last_size <= UB_TIES_SMALL) {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_small, dim3(1), dim3(1024), b.rp, last, r.last_size, cone, list, b.dv);
+  } else {
+    const unsigned g = sbx_grid_for(r.last_size, 256, 1024);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_init, dim3(1), dim3(1), b.dv);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_min_degree, dim3(g), dim3(256), b.rp, last, r.last_size, b.dv);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_ties, dim3(g), dim3(256), b.rp, last, r.last_size, cone, list, b.dv);
+  }
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
   SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-  if (hd.tie_count <= 1) {
+  if (hd.nf <= 1) {
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
     SBX_LAUNCH_CHECK(h);
     return SBX_OK;
   }
-  // T_{k-1} = the level-(k-1) neighbours of T_k: the expansion kernels in cone mode, hubs split into chunks as ever
+  // T_{k-1} = the level-(k-1) neighbours of T_k: the expansion kernel in cone mode appends them to the same list (its
+  // counter keeps growing); the hub kernel only runs for a level that queued hub chunks
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   static int heavy_per_cu = 0;
   if (heavy_per_cu == 0) {
@@ -2155,36 +2218,35 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     heavy_per_cu = nb;
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
-  unsigned cnt = hd.tie_count;
+  unsigned begin = 0, end = hd.nf;  // the marked vertices of level k are list[begin, end)
   for (unsigned k = r.levels - 1; k >= 2; k--) {  // level 0 is the root: every T_1 member hangs under it
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_reset_counters, dim3(1), dim3(1), b.dv);
+    const unsigned cnt = end - begin;
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
     const unsigned waves_needed = (cnt + RCM_VPW - 1) / RCM_VPW;
     unsigned grid = (waves_needed + 3) / 4;
     if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;
-    I *next = list + cnt;
-    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(grid), dim3(256), b.rp, b.col, (const I *)list, cnt, k,
-                (const unsigned *)b.vbits, b.ppos, next, b.heavy, b.hub_dir, b.dv, us);
-    if (b.max_deg > (unsigned)RCM_LIGHT)
-      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col, (const I *)list, k,
-                  (const unsigned *)b.vbits, b.ppos, next, (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid,
-                  b.dv, us);
+    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(list + begin), cnt,
+                k, (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us);
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-    list = next;
-    cnt = hd.nf;
-    if (cnt == 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: a level has no path to the level below (pattern not symmetric?)");
+    if (hd.n_heavy) {
+      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col,
+                  (const I *)(list + begin), k, (const unsigned *)b.vbits, b.ppos, list, (const uint64_t *)b.heavy,
+                  (const uint2 *)b.hub_dir, grid, b.dv, us);
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_reset_hubs, dim3(1), dim3(1), b.dv);
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    }
+    begin = end;
+    end = hd.nf;
+    if (end == begin) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: a level has no path to the level below (pattern not symmetric?)");
   }
-  (void)levels_off;
-  (void)levels_size;
-  (void)dist;
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_start, dim3(1), dim3(1), b.dv);
-  for (unsigned k = 1; k < r.levels; k++) {
+  for (unsigned k = 1; k < r.levels; k++)
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_step, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
                 (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, k, b.dv);
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_next, dim3(1), dim3(1), b.dv, k, k + 1 == r.levels ? 1 : 0);
-  }
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_end, dim3(1), dim3(1), b.dv, r.levels - 1);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
@@ -2466,7 +2528,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         const bool path = (int64_t)r.count == ecc + 1;
         if (!path && prev_ecc != ecc) {
           if (unordered) {
-            SBX_TRY(ubfs_pick_root(h, b, cone, r, lv_off, lv_size));
+            SBX_TRY(ubfs_pick_root(h, b, cone, r));
           } else {
             SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
                                (const I *)(q + r.last_offset), r.last_size, dv);
