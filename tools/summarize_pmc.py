@@ -10,7 +10,10 @@ usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json>
 """
 import csv, glob, json, sys, collections
 
-GROUPS = [("k_bfs_bottom_up", "bfs_bottom_up"), ("k_bfs_expand_heavy", "bfs_heavy"), ("k_bfs_expand", "bfs_expand"),
+GROUPS = [("k_bfs_bottom_up", "bfs_bottom_up"), ("k_ubfs_bottom_up", "bfs_bottom_up"), ("k_ubfs_collect", "level_order"),
+          ("k_fresh_words", "level_order"), ("k_keys_from_fresh", "level_order"), ("k_visited_from_ppos", "level_order"),
+          ("k_ubfs_", "rcm_misc"), ("k_classify_scan", "permute_prep"),
+          ("k_bfs_expand_heavy", "bfs_heavy"), ("k_bfs_expand", "bfs_expand"),
           ("k_bfs_small_levels", "bfs_small_levels"), ("k_permute_tile", "permute_tile"), ("k_permute_copy", "permute_tile"),
           ("k_permute_block_rows", "permute_block"), ("k_permute_rows_radix", "permute_block"), ("k_long_", "permute_long"),
           ("k_rowwise_prep", "permute_prep"), ("k_rec_classify", "permute_prep"), ("k_tile_first", "permute_prep"),
