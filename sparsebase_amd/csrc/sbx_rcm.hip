@@ -74,6 +74,9 @@ struct RcmDev {
   // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
   unsigned tie_deg, tie_count, tie_min_id;
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
+  // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
+  alignas(128) unsigned unf[2];
+  alignas(128) unsigned long long ufedges[2];
 };
 
 // ------------------------------------------------------------------ degree rank
@@ -1763,7 +1766,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
 // over level SETS: an edge that reaches an unvisited vertex sets its byte in `claim8` (a plain store: any parent will
 // do, so there is nothing to win and no atomic), the bottom-up kernel stops at the first frontier neighbour, and the
 // level — bitmaps, distances, the list in ascending id order, its size and degree sum — is collected from the bytes
-// by two streaming kernels over n (k_ubfs_collect_words / _list).  Nothing is sorted, no parent position is kept.
+// by one streaming kernel over n (k_ubfs_collect).  Nothing is sorted, no parent position is kept.
 // The third is settled afterwards, exactly, without knowing any position: let T_L be the candidates (deepest level,
 // smallest degree) and T_{k-1} the level-(k-1) neighbours of T_k.  A vertex's queue position is ordered by (position
 // of its first parent, id); all parents of T_k lie in T_{k-1}, and every member of T_{k-1} is a parent of some member
@@ -1801,24 +1804,33 @@ __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vb
   dv->n_heavy = 0;
   dv->hub_overflow = 0;
   dv->fedges = (unsigned long long)(rp[r + 1] - rp[r]);
+  dv->unf[0] = dv->unf[1] = 0;
+  dv->ufedges[0] = dv->ufedges[1] = 0;
 }
 
-// Level collection, pass 1 (64 bitmap words = 4096 vertices per workgroup, as k_fresh_words): claimed bytes -> the
-// frontier word, visited |= it, bytes cleared, distances written; per-word counts and per-workgroup totals of the
-// level's size and degree sum.
-__global__ __launch_bounds__(256) void k_ubfs_collect_words(unsigned char *__restrict__ claim8,
-                                                            unsigned long long *__restrict__ vbits64,
-                                                            unsigned long long *__restrict__ fbits64,
-                                                            unsigned *__restrict__ dist, unsigned level,
-                                                            const I *__restrict__ rp, int *__restrict__ cnt,
-                                                            int *__restrict__ btot, unsigned long long *__restrict__ dtot,
-                                                            int64_t n) {
+// Level collection in one launch (64 bitmap words = 4096 vertices per workgroup): claimed bytes -> the frontier word,
+// visited |= it, bytes cleared, distances written, and the level's vertices appended to the queue — a workgroup that
+// holds any reserves its stretch with one atomic (the order of an unordered level is free; empty workgroups, most of
+// them on a small level, touch nothing).  Size and degree sum of level l accumulate in slot l & 1; the other slot is
+// cleared for level l + 1.  (Two launches — totals, then a list written at bases summed from them — took 19 us per
+// level; a version with 16 K vertices per workgroup to spare the counter word took 24.)
+__global__ __launch_bounds__(256) void k_ubfs_collect(unsigned char *__restrict__ claim8,
+                                                      unsigned long long *__restrict__ vbits64,
+                                                      unsigned long long *__restrict__ fbits64,
+                                                      unsigned *__restrict__ dist, unsigned level,
+                                                      const I *__restrict__ rp, I *__restrict__ q_next, int64_t n,
+                                                      RcmDev *__restrict__ dv) {
   constexpr int WPW = RCM_FW_WORDS / 4;
-  __shared__ int s_tot;
-  __shared__ unsigned long long s_deg;
-  if (threadIdx.x == 0) s_tot = 0, s_deg = 0;
-  __syncthreads();
+  __shared__ unsigned s_wtot[4], s_base;
+  __shared__ unsigned long long s_deg[4];
   const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  const int slot = (int)(level & 1u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dv->unf[slot ^ 1] = 0;
+    dv->ufedges[slot ^ 1] = 0;
+    dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  }
   const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS + (int64_t)wv * WPW;
   unsigned char cb[WPW];
 #pragma unroll
@@ -1826,71 +1838,43 @@ __global__ __launch_bounds__(256) void k_ubfs_collect_words(unsigned char *__res
     const int64_t v = (w0 + i) * 64 + lane;
     cb[i] = v < n ? claim8[v] : (unsigned char)0;
   }
-  int mine = 0;
+  unsigned long long now[WPW];
   unsigned long long deg = 0;
+  unsigned mine = 0;  // wave-uniform: the wave's vertices in this level
 #pragma unroll
   for (int i = 0; i < WPW; i++) {
     const int64_t v = (w0 + i) * 64 + lane;
-    const unsigned long long now = __ballot(cb[i] != 0);
+    now[i] = __ballot(cb[i] != 0);
     if (cb[i]) {
       claim8[v] = 0;
       dist[v] = level;
       deg += (unsigned long long)(rp[v + 1] - rp[v]);
     }
     if ((w0 + i) * 64 < n && lane == 0) {
-      fbits64[w0 + i] = now;
-      if (now) vbits64[w0 + i] |= now;
-      cnt[w0 + i] = __popcll(now);
+      fbits64[w0 + i] = now[i];
+      if (now[i]) vbits64[w0 + i] |= now[i];
     }
-    mine += lane == 0 ? __popcll(now) : 0;
+    mine += (unsigned)__popcll(now[i]);
   }
-  mine = sbx_wave_sum(mine);
   deg = sbx_wave_sum(deg);
-  if (lane == 0 && mine) {
-    atomicAdd(&s_tot, mine);
-    atomicAdd(&s_deg, deg);
+  if (lane == 0) {
+    s_wtot[wv] = mine;
+    s_deg[wv] = deg;
   }
   __syncthreads();
+  const unsigned tot = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+  if (tot == 0) return;
   if (threadIdx.x == 0) {
-    btot[blockIdx.x] = s_tot;
-    dtot[blockIdx.x] = s_deg;
+    s_base = atomicAdd(&dv->unf[slot], tot);
+    atomicAdd(&dv->ufedges[slot], s_deg[0] + s_deg[1] + s_deg[2] + s_deg[3]);
   }
-}
-
-// pass 2: the level's vertices in ascending id order into the queue (bases as in k_keys_from_fresh); the last
-// workgroup also leaves the level's size and degree sum where the host reads them
-__global__ __launch_bounds__(256) void k_ubfs_collect_list(const unsigned long long *__restrict__ fbits64,
-                                                           const int *__restrict__ cnt, const int *__restrict__ btot,
-                                                           const unsigned long long *__restrict__ dtot,
-                                                           I *__restrict__ q_next, int64_t words,
-                                                           RcmDev *__restrict__ dv) {
-  constexpr int WPW = RCM_FW_WORDS / 4;
-  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
-  int base = 0;
-  for (int i = lane; i < (int)blockIdx.x; i += 64) base += btot[i];
-  base = sbx_wave_sum(base);
-  if (blockIdx.x == gridDim.x - 1 && wv == 0) {
-    unsigned long long d = 0;
-    for (int i = lane; i < (int)gridDim.x; i += 64) d += dtot[i];
-    d = sbx_wave_sum(d);
-    if (lane == 0) {
-      dv->nf = (unsigned)(base + btot[blockIdx.x]);
-      dv->fedges = d;
-      dv->n_heavy = 0;
-      dv->hub_overflow = 0;
-    }
-  }
-  const int64_t wb = (int64_t)blockIdx.x * RCM_FW_WORDS;
-  const int c = wb + lane < words ? cnt[wb + lane] : 0;
-  const int inc = sbx_wave_inclusive_sum(c);
-  const int excl = base + inc - c;
-  const unsigned long long mine = (lane >= wv * WPW && lane < (wv + 1) * WPW && wb + lane < words) ? fbits64[wb + lane] : 0ull;
+  __syncthreads();
+  unsigned o = s_base;
+  for (int i = 0; i < wv; i++) o += s_wtot[i];
 #pragma unroll
   for (int i = 0; i < WPW; i++) {
-    const int src = wv * WPW + i;
-    const unsigned long long f = __shfl(mine, src, 64);
-    const int o = __shfl(excl, src, 64);
-    if ((f >> lane) & 1ull) q_next[o + __popcll(f & sbx_lanemask_lt())] = (I)((wb + src) * 64 + lane);
+    if ((now[i] >> lane) & 1ull) q_next[o + (unsigned)__popcll(now[i] & sbx_lanemask_lt())] = (I)((w0 + i) * 64 + lane);
+    o += (unsigned)__popcll(now[i]);
   }
 }
 
@@ -1920,15 +1904,23 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
     const bool small = cand && (e - s) <= RCM_BU_INLINE;
     bool found = false;
     if (__any(small)) {
+      // four entries at a time, every load of a batch in flight together; a wave stops as soon as every one of its small
+      // candidates has either found a frontier neighbour or run out of entries (most have one to four of them)
       const int dg = small ? (int)(e - s) : 0;
-      I us[RCM_BU_INLINE];
+      int done = 0;
+      for (int k0 = 0; k0 < RCM_BU_INLINE; k0 += 4) {
+        if (!__any(small && !found && dg > k0)) break;
+        I us[4];
 #pragma unroll
-      for (int k = 0; k < RCM_BU_INLINE; k++) us[k] = k < dg ? col[s + k] : (I)-1;
+        for (int k = 0; k < 4; k++) us[k] = (small && !found && k0 + k < dg) ? col[s + k0 + k] : (I)-1;
 #pragma unroll
-      for (int k = 0; k < RCM_BU_INLINE; k++)
-        if (us[k] >= 0 && ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u)) found = true;
-      if (small) scanned += (unsigned)dg;
-      found = found && small;
+        for (int k = 0; k < 4; k++)
+          if (us[k] >= 0) {
+            done++;
+            if ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u) found = true;
+          }
+      }
+      scanned += (unsigned)done;
     }
     uint64_t todo = __ballot(cand && !small);
     uint64_t big_found = 0;  // lanes (vertices) of this wave's 64 that a group found a frontier neighbour for
@@ -2113,14 +2105,9 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   const int64_t words = (b.n + 63) / 64;
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
   *too_deep = false;
-  if (fw_blocks > RCM_FW_INLINE) {  // (> 16 M vertices: the collection kernels sum their predecessors' totals inline)
-    *too_deep = true;
-    return SBX_OK;
-  }
   SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
   SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
   unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
-  unsigned long long *dtot = (unsigned long long *)b.ka;  // (the sort buffers are free as well)
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
@@ -2153,18 +2140,14 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, us);
     }
-    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect_words, dim3((unsigned)fw_blocks), dim3(256), claim8,
-                (unsigned long long *)b.vbits, (unsigned long long *)b.fbits, dist, level + 1, b.rp, b.wcnt, b.woff, dtot,
-                b.n);
-    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect_list, dim3((unsigned)fw_blocks), dim3(256),
-                (const unsigned long long *)b.fbits, (const int *)b.wcnt, (const int *)b.woff,
-                (const unsigned long long *)dtot, q_next, words, b.dv);
+    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect, dim3((unsigned)fw_blocks), dim3(256), claim8,
+                (unsigned long long *)b.vbits, (unsigned long long *)b.fbits, dist, level + 1, b.rp, q_next, b.n, b.dv);
     SBX_LAUNCH_CHECK(h);
     RcmDev hd;
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-    const unsigned nf = hd.nf;
+    const unsigned nf = hd.unf[(level + 1) & 1];
     if (nf == 0) break;
-    frontier_edges = (int64_t)hd.fedges;
+    frontier_edges = (int64_t)hd.ufedges[(level + 1) & 1];
     remaining -= frontier_edges;
     if (remaining < 0) remaining = 0;
     off += fsize;
