@@ -74,6 +74,8 @@ struct RcmDev {
   // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
   unsigned tie_deg, tie_count, tie_min_id;
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
+  unsigned cone_begin, cone_end;  // tie-break: the marked vertices of the level being expanded are list[begin, end)
+  unsigned bar;                 // grid barrier of k_ubfs_descend_all
   // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
   alignas(128) unsigned unf[2];
   alignas(128) unsigned long long ufedges[2];
@@ -641,6 +643,10 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
   WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
   unsigned long long scanned = 0;
+  if (U == 2) {  // cone marking: the range of the list to expand is on the device (no host round trip per level)
+    frontier += dv->cone_begin;
+    fsize = dv->cone_end - dv->cone_begin;
+  }
   // positions [blockIdx.x * per, +per) belong to this workgroup; its four waves interleave inside the range
   const int64_t per = (((int64_t)fsize + gridDim.x - 1) / gridDim.x + 4 * RCM_VPW - 1) / (4 * RCM_VPW) * (4 * RCM_VPW);
   const int64_t pb = (int64_t)blockIdx.x * per;
@@ -725,6 +731,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
   __shared__ unsigned s_dfirst[RCM_DIR_MAX + 1];  // directory: how many descriptors came before a workgroup's run
   __shared__ unsigned s_dscan[256 / 64 + 1];
   const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
+  if (U == 2) frontier += dv->cone_begin;
   // Without overflow the descriptors are visited in directory (= frontier position) order: the d-th one overall
   // is entry d - first[g] of workgroup g's run.  Otherwise: in queue order.
   const bool ordered = dv->hub_overflow == 0 && ndir <= (unsigned)RCM_DIR_MAX;
@@ -2010,6 +2017,9 @@ __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const I *__restrict__ 
     dv->nf = s_cnt;
     dv->n_heavy = 0;
     dv->hub_overflow = 0;
+    dv->cone_begin = 0;
+    dv->cone_end = s_cnt;
+    dv->bar = 0;
   }
 }
 __global__ void k_ubfs_ties_init(RcmDev *__restrict__ dv) {
@@ -2056,43 +2066,69 @@ __global__ __launch_bounds__(256) void k_ubfs_mark_ties(const I *__restrict__ rp
   if (sbx_lane() == 0 && mid != 0xFFFFFFFFu) atomicMin(&dv->tie_min_id, mid);
 }
 __global__ void k_ubfs_root_from_single_tie(RcmDev *__restrict__ dv) { dv->root = dv->tie_min_id; }
-__global__ void k_ubfs_reset_hubs(RcmDev *__restrict__ dv) {
+// between two cone levels: what the expansion appended is the next level's range; hub queue cleared
+__global__ void k_ubfs_cone_next(RcmDev *__restrict__ dv, int first) {
+  if (first) {
+    dv->cone_begin = 0;
+    dv->cone_end = dv->nf;
+    dv->bar = 0;
+  } else {
+    dv->cone_begin = dv->cone_end;
+    dv->cone_end = dv->nf;
+    if (dv->cone_end == dv->cone_begin) dv->unsym = 1;  // a level without a path to the level below
+  }
   dv->n_heavy = 0;
   dv->hub_overflow = 0;
 }
 
-// w_0 = root, w_k = smallest id among the marked level-k neighbours of w_{k-1}; w_L is the next root.  One launch per
-// level (w_{k-1} may be a hub with 10^5 neighbours: the whole grid scans them); w_k lives in dv->desc[k % 3], and the
-// step that fills slot k % 3 also clears slot (k + 1) % 3 for the step after it.
-__global__ void k_ubfs_descend_start(RcmDev *__restrict__ dv) {
-  dv->desc[0] = dv->root;
-  dv->desc[1] = 0xFFFFFFFFu;
-}
-__global__ __launch_bounds__(256) void k_ubfs_descend_step(const I *__restrict__ rp, const I *__restrict__ col,
-                                                           const unsigned *__restrict__ vbits,
-                                                           const unsigned *__restrict__ dist,
-                                                           const unsigned *__restrict__ cone, unsigned k,
-                                                           RcmDev *__restrict__ dv) {
-  const unsigned w = dv->desc[(k - 1) % 3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) dv->desc[(k + 1) % 3] = 0xFFFFFFFFu;
-  if (w == 0xFFFFFFFFu) {  // the step before found nothing: cannot happen on a symmetric pattern
-    if (blockIdx.x == 0 && threadIdx.x == 0) dv->unsym = 1;
-    return;
+// w_0 = root, w_k = smallest id among the marked level-k neighbours of w_{k-1}; w_L is the next root.  One launch for
+// the whole walk: UB_DESC_GRID workgroups (all resident: 64 of them on 256 CUs) scan adj(w_{k-1}) together — it may be
+// a hub with 10^5 entries — and meet at a grid barrier (one arrival counter, dv->bar) after every level.  w_k lives in
+// dv->desc[k % 3]; the step that fills slot k % 3 finds it cleared by the step before the previous barrier.
+constexpr unsigned UB_DESC_GRID = 64;
+__device__ __forceinline__ void ub_grid_barrier(RcmDev *dv, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(&dv->bar, 1u);
+    while (__hip_atomic_load(&dv->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __threadfence();
   }
-  unsigned best = 0xFFFFFFFFu;
-  const I s = rp[w], e = rp[w + 1];
-  for (int64_t a = (int64_t)s + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < e; a += (int64_t)gridDim.x * blockDim.x) {
-    const I c = col[a];
-    if (((cone[c >> 5] >> (c & 31)) & 1u) && ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k)
-      best = (unsigned)c < best ? (unsigned)c : best;
-  }
-  best = sbx_wave_min(best);
-  if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k % 3], best);
+  __syncthreads();
 }
-__global__ void k_ubfs_descend_end(RcmDev *__restrict__ dv, unsigned last_k) {
-  const unsigned w = dv->desc[last_k % 3];
-  if (w == 0xFFFFFFFFu) dv->unsym = 1;
-  else dv->root = w;
+__global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ rp, const I *__restrict__ col,
+                                                          const unsigned *__restrict__ vbits,
+                                                          const unsigned *__restrict__ dist,
+                                                          const unsigned *__restrict__ cone, unsigned levels,
+                                                          RcmDev *dv) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dv->desc[0] = dv->root;
+    dv->desc[1] = 0xFFFFFFFFu;
+    dv->desc[2] = 0xFFFFFFFFu;
+  }
+  ub_grid_barrier(dv, gridDim.x);
+  unsigned w = __hip_atomic_load(&dv->desc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned k = 1; k < levels; k++) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) dv->desc[(k + 1) % 3] = 0xFFFFFFFFu;  // idle during this step
+    unsigned best = 0xFFFFFFFFu;
+    if (w != 0xFFFFFFFFu) {
+      const I s = rp[w], e = rp[w + 1];
+      for (int64_t a = (int64_t)s + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < e;
+           a += (int64_t)gridDim.x * blockDim.x) {
+        const I c = col[a];
+        if (((cone[c >> 5] >> (c & 31)) & 1u) && ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k)
+          best = (unsigned)c < best ? (unsigned)c : best;
+      }
+    }
+    best = sbx_wave_min(best);
+    if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k % 3], best);
+    ub_grid_barrier(dv, gridDim.x * (k + 1));
+    w = __hip_atomic_load(&dv->desc[k % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (w == 0xFFFFFFFFu) dv->unsym = 1;  // cannot happen on a symmetric pattern
+    else dv->root = w;
+  }
 }
 
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed
@@ -2201,35 +2237,21 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     heavy_per_cu = nb;
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
-  unsigned begin = 0, end = hd.nf;  // the marked vertices of level k are list[begin, end)
+  // (no host round trip per level: the range of the list a level expands is kept on the device by k_ubfs_cone_next)
+  if (r.last_size > UB_TIES_SMALL) SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_cone_next, dim3(1), dim3(1), b.dv, 1);
+  const unsigned cone_grid = max_grid < 512u ? max_grid : 512u;
   for (unsigned k = r.levels - 1; k >= 2; k--) {  // level 0 is the root: every T_1 member hangs under it
-    const unsigned cnt = end - begin;
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
-    const unsigned waves_needed = (cnt + RCM_VPW - 1) / RCM_VPW;
-    unsigned grid = (waves_needed + 3) / 4;
-    if (grid > max_grid) grid = max_grid;
-    if (grid < 1) grid = 1;
-    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(list + begin), cnt,
-                k, (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us);
-    SBX_LAUNCH_CHECK(h);
-    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-    if (hd.n_heavy) {
-      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col,
-                  (const I *)(list + begin), k, (const unsigned *)b.vbits, b.ppos, list, (const uint64_t *)b.heavy,
-                  (const uint2 *)b.hub_dir, grid, b.dv, us);
-      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_reset_hubs, dim3(1), dim3(1), b.dv);
-      SBX_LAUNCH_CHECK(h);
-      SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-    }
-    begin = end;
-    end = hd.nf;
-    if (end == begin) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: a level has no path to the level below (pattern not symmetric?)");
+    SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(cone_grid), dim3(256), b.rp, b.col, (const I *)list, 0u, k,
+                (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us);
+    if (b.max_deg > (unsigned)RCM_LIGHT)
+      SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col, (const I *)list, k,
+                  (const unsigned *)b.vbits, b.ppos, list, (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, cone_grid,
+                  b.dv, us);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_cone_next, dim3(1), dim3(1), b.dv, 0);
   }
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_start, dim3(1), dim3(1), b.dv);
-  for (unsigned k = 1; k < r.levels; k++)
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_step, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
-                (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, k, b.dv);
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_end, dim3(1), dim3(1), b.dv, r.levels - 1);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
+              (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
