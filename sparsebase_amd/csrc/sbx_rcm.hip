@@ -2131,12 +2131,10 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
   }
 }
 
-// One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed
-// UB_MAX_LEVELS levels and was abandoned (the caller runs the ordered sweep instead).  `levels_off` / `levels_size`
-// receive the levels' places in q.
+// One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
+// depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, I fixed_root, I comp_label,
-                    BfsResult *out, std::vector<unsigned> &levels_off, std::vector<unsigned> &levels_size,
-                    bool *too_deep) {
+                    BfsResult *out, bool *too_deep) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const int64_t words = (b.n + 63) / 64;
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
@@ -2155,8 +2153,6 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
   int64_t remaining = b.nnz, frontier_edges = -1;
-  levels_off.assign(1, 0u);
-  levels_size.assign(1, 1u);
   while (true) {
     I *q_next = b.q + off + fsize;  // the next level is appended to the queue when it is collected
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
@@ -2190,8 +2186,6 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     fsize = nf;
     total += nf;
     level++;
-    levels_off.push_back(off);
-    levels_size.push_back(fsize);
     if (level + 1 > ub_max_levels()) {
       *too_deep = true;
       return SBX_OK;
@@ -2396,12 +2390,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   unsigned *cone = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)n + 64, &claim8));
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
-  std::vector<unsigned> lv_off, lv_size, lv_off0, lv_size0;
   bool r0_unordered = false;
   if (v0 >= 0) {
     bool deep = true;
     if (rcm_unordered()) {
-      SBX_TRY(run_ubfs(h, b, claim8, v0, (I)-1, &r0, lv_off0, lv_size0, &deep));
+      SBX_TRY(run_ubfs(h, b, claim8, v0, (I)-1, &r0, &deep));
       r0_unordered = !deep;
     }
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
@@ -2501,8 +2494,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
           r = r0;  // sweep (2) above was exactly this component's first sweep
           have_first_sweep = false;
           unordered = r0_unordered;
-          if (unordered) lv_off = lv_off0, lv_size = lv_size0;
-          else deep = true;
+          if (!unordered) deep = true;
         } else {
           if (candidate >= rcm_speculate_from()) {
             SBX_TRY(join_ranks());
@@ -2519,7 +2511,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
             fixed = -1;  // k_bfs_start left the root on the device
           }
           if (!deep) {
-            SBX_TRY(run_ubfs(h, b, claim8, fixed, roots[c], &r, lv_off, lv_size, &deep));
+            SBX_TRY(run_ubfs(h, b, claim8, fixed, roots[c], &r, &deep));
             unordered = !deep;
           }
           if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
