@@ -2086,13 +2086,13 @@ __global__ void k_ubfs_cone_next(RcmDev *__restrict__ dv, int first) {
 // a hub with 10^5 entries — and meet at a grid barrier (one arrival counter, dv->bar) after every level.  w_k lives in
 // dv->desc[k % 3]; the step that fills slot k % 3 finds it cleared by the step before the previous barrier.
 constexpr unsigned UB_DESC_GRID = 64;
+// (No __threadfence() around it: on a multi-XCD part an agent-scope fence writes the L2 back — ~5 us a piece — and
+// everything the workgroups exchange between two barriers, dv->desc, moves through agent-scope atomics anyway.)
 __device__ __forceinline__ void ub_grid_barrier(RcmDev *dv, unsigned target) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     atomicAdd(&dv->bar, 1u);
-    while (__hip_atomic_load(&dv->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-    __threadfence();
+    while (__hip_atomic_load(&dv->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
 }
@@ -2102,14 +2102,15 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
                                                           const unsigned *__restrict__ cone, unsigned levels,
                                                           RcmDev *dv) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    dv->desc[0] = dv->root;
-    dv->desc[1] = 0xFFFFFFFFu;
-    dv->desc[2] = 0xFFFFFFFFu;
+    __hip_atomic_store(&dv->desc[0], dv->root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&dv->desc[1], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&dv->desc[2], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ub_grid_barrier(dv, gridDim.x);
   unsigned w = __hip_atomic_load(&dv->desc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned k = 1; k < levels; k++) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) dv->desc[(k + 1) % 3] = 0xFFFFFFFFu;  // idle during this step
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // idle during this step
+      __hip_atomic_store(&dv->desc[(k + 1) % 3], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned best = 0xFFFFFFFFu;
     if (w != 0xFFFFFFFFu) {
       const I s = rp[w], e = rp[w + 1];
