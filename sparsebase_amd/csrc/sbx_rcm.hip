@@ -473,12 +473,14 @@ struct WaveStage {
   I *buf;                  // this wave's LDS slice
   unsigned cnt;            // wave-uniform fill level
   unsigned long long deg;  // per-lane: degrees of the vertices this lane appended
+  unsigned *nf_ctr;             // the list's counter (dv->nf, or a level slot of the unordered sweeps)
+  unsigned long long *fe_ctr;   // the degree-sum counter that goes with it
 };
 
 __device__ __forceinline__ void stage_flush(WaveStage &st, I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
   if (st.cnt == 0) return;
   unsigned base = 0;
-  if (sbx_lane() == 0) base = atomicAdd(&dv->nf, st.cnt);
+  if (sbx_lane() == 0) base = atomicAdd(st.nf_ctr, st.cnt);
   base = __shfl(base, 0, 64);  // (a v_readfirstlane here makes the bottom-up kernel 28 % slower: measured)
   __builtin_amdgcn_wave_barrier();
   for (unsigned i = sbx_lane(); i < st.cnt; i += 64) nf_list[base + i] = st.buf[i];
@@ -508,8 +510,8 @@ __device__ __forceinline__ void stage_end_block(WaveStage &st, I *__restrict__ n
     const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     const unsigned long long dsum = s_deg[0] + s_deg[1] + s_deg[2] + s_deg[3];
     const unsigned long long ssum = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-    s_base = tot ? atomicAdd(&dv->nf, tot) : 0u;
-    if (dsum) atomicAdd(&dv->fedges, dsum);
+    s_base = tot ? atomicAdd(st.nf_ctr, tot) : 0u;
+    if (dsum) atomicAdd(st.fe_ctr, dsum);
     if (ssum) {
       atomicAdd(&dv->edges, ssum);
       if (bottom_up) atomicAdd(&dv->edges_bu, ssum);
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   __syncthreads();
   const int lane = sbx_lane();
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull, &dv->nf, &dv->fedges};
   unsigned long long scanned = 0;
   if (U == 2) {  // cone marking: the range of the list to expand is on the device (no host round trip per level)
     frontier += dv->cone_begin;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
     if (threadIdx.x == 255) s_dfirst[RCM_DIR_MAX] = run;
     __syncthreads();
   }
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull, &dv->nf, &dv->fedges};
   unsigned long long scanned = 0;
   unsigned g = 0;
   for (unsigned d = blockIdx.x; d < nd; d += gridDim.x) {
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull, &dv->nf, &dv->fedges};
   unsigned long long scanned = 0;
   for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
     const int64_t v = base + lane;
@@ -1892,16 +1894,23 @@ __global__ __launch_bounds__(256) void k_ubfs_collect(unsigned char *__restrict_
 constexpr int UB_INLINE = 1024;
 __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
                                                         const I *__restrict__ label, I comp_label,
-                                                        const unsigned *__restrict__ vbits,
-                                                        const unsigned *__restrict__ fbits,
-                                                        unsigned char *__restrict__ claim8, I *__restrict__ nf_list,
-                                                        int64_t n, RcmDev *__restrict__ dv) {
+                                                        unsigned *vbits, const unsigned *__restrict__ fbits,
+                                                        unsigned *__restrict__ nbits, unsigned *__restrict__ dist,
+                                                        unsigned level, I *__restrict__ nf_list, int64_t n,
+                                                        RcmDev *dv) {
   __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int lane = sbx_lane();
   const int grp = lane / RCM_GROUP, gl = lane % RCM_GROUP;
-  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull};
+  const int slot = (int)(level & 1u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (as k_ubfs_collect: the other level slot is cleared for the next level)
+    dv->unf[slot ^ 1] = 0;
+    dv->ufedges[slot ^ 1] = 0;
+    dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  }
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull, &dv->unf[slot], &dv->ufedges[slot]};
   unsigned long long scanned = 0;
   for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
     const int64_t v = base + lane;
@@ -1974,7 +1983,17 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
       }
     }
     found = found || ((big_found >> lane) & 1ull);
-    if (found) claim8[v] = 1;  // lane = vertex: 64 consecutive bytes per wave
+    // lane = vertex and the wave owns the two bitmap words of its 64 vertices: the level is published right here —
+    // visited bit (only this wave ever tests it), next frontier word (every word is written, so the array needs no
+    // clearing), distance, queue — and needs no collection pass
+    const uint64_t fm = __ballot(found);
+    if ((lane & 31) == 0 && base + lane < n) {
+      const unsigned wbits = (unsigned)(fm >> (lane & 32));
+      nbits[(base >> 5) + (lane >> 5)] = wbits;
+      if (wbits) vbits[(base >> 5) + (lane >> 5)] |= wbits;
+    }
+    if (found) dist[v] = level;
+    stage_push((I)v, found, rp, st, nf_list, dv);
   }
   stage_end_block(st, nf_list, dv, scanned, true);
 }
@@ -2138,8 +2157,8 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
 
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
-static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, I fixed_root, I comp_label,
-                    BfsResult *out, bool *too_deep) {
+static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, I fixed_root,
+                    I comp_label, BfsResult *out, bool *too_deep) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const int64_t words = (b.n + 63) / 64;
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
@@ -2158,13 +2177,16 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
   int64_t remaining = b.nnz, frontier_edges = -1;
+  unsigned *cur_f = b.fbits, *cur_n = nbits_buf;  // frontier bitmap / the one a bottom-up level writes (swapped after it)
   while (true) {
-    I *q_next = b.q + off + fsize;  // the next level is appended to the queue when it is collected
+    I *q_next = b.q + off + fsize;  // the next level is appended to the queue
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
     const bool bottom_up = frontier_edges >= 0 && fsize >= 1024 && (double)frontier_edges > ubu_ratio() * (double)remaining;
     if (bottom_up) {
+      // publishes the level itself (bitmaps, distances, queue): no collection pass
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
-                  (const unsigned *)b.vbits, (const unsigned *)b.fbits, claim8, b.nf_list, b.n, b.dv);
+                  b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv);
+      std::swap(cur_f, cur_n);
     } else {
       const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
       unsigned grid = (waves_needed + 3) / 4;
@@ -2176,9 +2198,9 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
         SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<1>, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, us);
+      SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect, dim3((unsigned)fw_blocks), dim3(256), claim8,
+                  (unsigned long long *)b.vbits, (unsigned long long *)cur_f, dist, level + 1, b.rp, q_next, b.n, b.dv);
     }
-    SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect, dim3((unsigned)fw_blocks), dim3(256), claim8,
-                (unsigned long long *)b.vbits, (unsigned long long *)b.fbits, dist, level + 1, b.rp, q_next, b.n, b.dv);
     SBX_LAUNCH_CHECK(h);
     RcmDev hd;
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
@@ -2392,14 +2414,15 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   // sweeps of the pseudo-peripheral search run unordered (level sets only, run_ubfs) unless the component turns out
   // deep and narrow
   unsigned char *claim8 = nullptr;
-  unsigned *cone = nullptr;
+  unsigned *cone = nullptr, *nbits = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)n + 64, &claim8));
+  SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &nbits));
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
   bool r0_unordered = false;
   if (v0 >= 0) {
     bool deep = true;
     if (rcm_unordered()) {
-      SBX_TRY(run_ubfs(h, b, claim8, v0, (I)-1, &r0, &deep));
+      SBX_TRY(run_ubfs(h, b, claim8, nbits, v0, (I)-1, &r0, &deep));
       r0_unordered = !deep;
     }
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
@@ -2516,7 +2539,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
             fixed = -1;  // k_bfs_start left the root on the device
           }
           if (!deep) {
-            SBX_TRY(run_ubfs(h, b, claim8, fixed, roots[c], &r, &deep));
+            SBX_TRY(run_ubfs(h, b, claim8, nbits, fixed, roots[c], &r, &deep));
             unordered = !deep;
           }
           if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
