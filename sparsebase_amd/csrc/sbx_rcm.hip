@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
   __shared__ unsigned s_dfirst[RCM_DIR_MAX + 1];  // directory: how many descriptors came before a workgroup's run
   __shared__ unsigned s_dscan[256 / 64 + 1];
   const unsigned nd = dv->n_heavy;  // chunk descriptors queued by k_bfs_expand
+  if (nd == 0) return;              // a level without hubs: nothing staged, nothing to add to the counters
   if (U == 2) frontier += dv->cone_begin;
   // Without overflow the descriptors are visited in directory (= frontier position) order: the d-th one overall
   // is entry d - first[g] of workgroup g's run.  Otherwise: in queue order.
