@@ -76,6 +76,10 @@ struct RcmDev {
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
   unsigned cone_begin, cone_end;  // tie-break: the marked vertices of the level being expanded are list[begin, end)
   unsigned bar;                 // grid barrier of k_ubfs_descend_all
+  // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
+  unsigned ur_bar, ur_exit;
+  unsigned ur_off, ur_size, ur_level, ur_total, ur_status;
+  unsigned long long ur_fe, ur_esum;
   // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
   alignas(128) unsigned unf[2];
   alignas(128) unsigned long long ufedges[2];
@@ -1816,6 +1820,8 @@ __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vb
   dv->fedges = (unsigned long long)(rp[r + 1] - rp[r]);
   dv->unf[0] = dv->unf[1] = 0;
   dv->ufedges[0] = dv->ufedges[1] = 0;
+  dv->ur_bar = 0;
+  dv->ur_exit = 0;
 }
 
 // Level collection in one launch (64 bitmap words = 4096 vertices per workgroup): claimed bytes -> the frontier word,
@@ -2156,6 +2162,160 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
   }
 }
 
+// ---- unordered sweeps, small levels: one launch for as many consecutive levels as stay small ------------------
+// The first levels of a sweep and its last ones hold a handful of vertices: an expansion + an n-sized collection + a
+// host round trip per level is all overhead there.  UR_GRID workgroups (all resident) run such levels in one launch:
+// vertices are claimed directly in the visited bitmap (atomicOr: nothing contends on a small level), appended to the
+// queue through one wave-aggregated counter, hubs of the frontier are queued and scanned by the whole grid, and the
+// workgroups meet at a grid barrier three times per level.  No fences (an agent-scope fence is an L2 write-back here):
+// everything one workgroup writes for another — queue entries, hub queue, the hand-over state — is stored and loaded
+// with agent-scope atomics, which go past the per-XCD L2s.  The kernel returns when the sweep is over (UR_DONE) or
+// the level it just built is too big for it (UR_STOP: the host continues with the byte-claim / bottom-up kernels; the
+// frontier bitmap is not kept here and is rebuilt if a bottom-up step wants it).
+constexpr unsigned UR_GRID = 64;
+constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
+constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
+constexpr unsigned UR_HEAVY = 2048;       // frontier vertices above this degree are scanned by the whole grid
+constexpr unsigned UR_CONTINUE = 0, UR_DONE = 1, UR_STOP = 2, UR_DEEP = 3;  // DEEP: too many levels in one launch
+
+template <typename T>
+__device__ __forceinline__ T ur_load(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void ur_store(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ur_barrier(RcmDev *dv, unsigned &epoch) {
+  epoch++;
+  __syncthreads();  // (waits for this workgroup's outstanding stores and atomics: vmcnt)
+  if (threadIdx.x == 0) {
+    atomicAdd(&dv->ur_bar, 1u);
+    while (ur_load(&dv->ur_bar) < epoch * gridDim.x) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp, const I *__restrict__ col,
+                                                        unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
+                                                        unsigned off, unsigned size, unsigned level, unsigned total,
+                                                        long long fe_in, unsigned max_levels) {
+  const int lane = sbx_lane();
+  const unsigned level_in = level;
+  const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  unsigned epoch = 0;
+  unsigned long long scanned = 0;
+  {
+    // is the frontier handed in small enough at all?  (level 0: the root's degree is in dv->fedges, k_ubfs_start)
+    const unsigned long long fe = fe_in >= 0 ? (unsigned long long)fe_in : ur_load(&dv->fedges);
+    ur_barrier(dv, epoch);  // (everyone has read dv->fedges before it is cleared below)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ur_store(&dv->nf, 0u);
+      ur_store(&dv->fedges, 0ull);
+      ur_store(&dv->n_heavy, 0u);
+      dv->unf[0] = dv->unf[1] = 0;  // (the level slots of the other kernels: levels may change parity in here)
+      dv->ufedges[0] = dv->ufedges[1] = 0;
+      dv->ur_esum = 0;
+      dv->ur_fe = fe;
+      dv->ur_off = off, dv->ur_size = size, dv->ur_level = level, dv->ur_total = total;
+      ur_store(&dv->ur_status, (fe > (unsigned long long)UR_MAX_E || size > UR_MAX_N) ? UR_STOP : UR_CONTINUE);
+    }
+    ur_barrier(dv, epoch);
+  }
+  unsigned status = ur_load(&dv->ur_status);
+  unsigned long long esum = 0;
+  while (status == UR_CONTINUE) {
+    I *q_next = q + off + size;
+    unsigned long long degacc = 0;
+    auto visit = [&](I c) {
+      bool won = false;
+      if (c >= 0) {
+        const unsigned bit = 1u << (c & 31);
+        if (!(ur_load(&vbits[c >> 5]) & bit)) won = !(atomicOr(&vbits[c >> 5], bit) & bit);
+      }
+      const unsigned pos = sbx_wave_append(&dv->nf, won);
+      if (won) {
+        ur_store(&q_next[pos], c);
+        dist[c] = level + 1;  // (read by later kernels only)
+        degacc += (unsigned long long)(rp[c + 1] - rp[c]);
+      }
+    };
+    // light vertices: one wave each
+    for (unsigned p = gwave; p < size; p += nwaves) {
+      const I u = ur_load(&q[off + p]);
+      const I s = rp[u], e = rp[u + 1];
+      if ((unsigned)(e - s) > UR_HEAVY) {
+        if (lane == 0) ur_store(&hq[atomicAdd(&dv->n_heavy, 1u)], u);
+        continue;
+      }
+      for (I a = s + lane; __any(a < e); a += 64) {
+        visit(a < e ? col[a] : (I)-1);
+        scanned += a < e ? 1u : 0u;
+      }
+    }
+    ur_barrier(dv, epoch);
+    // hubs of the frontier: the whole grid scans each of them
+    const unsigned nh = ur_load(&dv->n_heavy);
+    for (unsigned i = 0; i < nh; i++) {
+      const I u = ur_load(&hq[i]);
+      const I s = rp[u], e = rp[u + 1];
+      for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
+        const int64_t a = a0 + lane;
+        visit(a < e ? col[a] : (I)-1);
+        scanned += a < e ? 1u : 0u;
+      }
+    }
+    degacc = sbx_wave_sum(degacc);
+    if (lane == 0 && degacc) atomicAdd(&dv->fedges, degacc);
+    ur_barrier(dv, epoch);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const unsigned nf = ur_load(&dv->nf);
+      const unsigned long long fe = ur_load(&dv->fedges);
+      unsigned st = UR_DONE;  // nf == 0: the frontier just expanded was the deepest level, off / size stay on it
+      if (nf) {
+        esum += fe;
+        ur_store(&dv->ur_off, off + size);
+        ur_store(&dv->ur_size, nf);
+        ur_store(&dv->ur_level, level + 1);
+        ur_store(&dv->ur_total, total + nf);
+        ur_store(&dv->ur_esum, esum);
+        ur_store(&dv->ur_fe, fe);
+        st = (fe > (unsigned long long)UR_MAX_E || nf > UR_MAX_N) ? UR_STOP : UR_CONTINUE;
+        // a deep, narrow component: the one-workgroup ordered kernel walks such levels at half the cost of this one
+        if (st == UR_CONTINUE && level + 1 - level_in >= max_levels) st = UR_DEEP;
+      }
+      ur_store(&dv->nf, 0u);
+      ur_store(&dv->fedges, 0ull);
+      ur_store(&dv->n_heavy, 0u);
+      ur_store(&dv->ur_status, st);
+    }
+    ur_barrier(dv, epoch);
+    status = ur_load(&dv->ur_status);
+    if (status != UR_DONE) {
+      off = ur_load(&dv->ur_off);
+      size = ur_load(&dv->ur_size);
+      level = ur_load(&dv->ur_level);
+      total = ur_load(&dv->ur_total);
+    }
+  }
+  scanned = sbx_wave_sum(scanned);
+  if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
+  // the last workgroup out clears the barrier words for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&dv->ur_exit, 1u) == gridDim.x - 1) {
+    ur_store(&dv->ur_bar, 0u);
+    ur_store(&dv->ur_exit, 0u);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ubfs_mark_fbits(const I *__restrict__ frontier, unsigned fsize,
+                                                         unsigned *__restrict__ fbits) {
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < fsize; j += gridDim.x * blockDim.x) {
+    const I v = frontier[j];
+    atomicOr(&fbits[v >> 5], 1u << (v & 31));
+  }
+}
+
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, I fixed_root,
@@ -2179,11 +2339,43 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
   int64_t remaining = b.nnz, frontier_edges = -1;
   unsigned *cur_f = b.fbits, *cur_n = nbits_buf;  // frontier bitmap / the one a bottom-up level writes (swapped after it)
+  bool fbits_valid = true;  // cur_f holds exactly the current frontier (the root, or what the level kernels left)
+  unsigned rounds = 0;      // host round trips of this sweep
   while (true) {
+    if (++rounds > ub_max_levels()) {
+      *too_deep = true;
+      return SBX_OK;
+    }
+    if (frontier_edges < 0 || (frontier_edges <= (int64_t)UR_MAX_E && fsize <= UR_MAX_N)) {
+      // small levels: as many as stay small, in one launch
+      SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
+                  (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels());
+      SBX_LAUNCH_CHECK(h);
+      RcmDev hs;
+      SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
+      const bool moved = hs.ur_level != level;
+      off = hs.ur_off, fsize = hs.ur_size, level = hs.ur_level, total = hs.ur_total;
+      remaining -= (int64_t)hs.ur_esum;
+      if (remaining < 0) remaining = 0;
+      frontier_edges = (int64_t)hs.ur_fe;
+      if (moved) fbits_valid = false;
+      if (hs.ur_status == UR_DONE) break;
+      if (hs.ur_status == UR_DEEP) {
+        *too_deep = true;
+        return SBX_OK;
+      }
+      if (moved) continue;  // (UR_STOP with a new frontier: it is looked at again, and is big)
+      // UR_STOP right at the entry: the frontier handed in was too big — expand it with the kernels below
+    }
     I *q_next = b.q + off + fsize;  // the next level is appended to the queue
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
     const bool bottom_up = frontier_edges >= 0 && fsize >= 1024 && (double)frontier_edges > ubu_ratio() * (double)remaining;
     if (bottom_up) {
+      if (!fbits_valid) {
+        SBX_HIP(h, hipMemsetAsync(cur_f, 0, bm_bytes, h->stream));
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_fbits, dim3(sbx_grid_for(fsize, 256, 1024)), dim3(256),
+                    (const I *)(b.q + off), fsize, cur_f);
+      }
       // publishes the level itself (bitmaps, distances, queue): no collection pass
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv);
@@ -2203,6 +2395,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                   (unsigned long long *)b.vbits, (unsigned long long *)cur_f, dist, level + 1, b.rp, q_next, b.n, b.dv);
     }
     SBX_LAUNCH_CHECK(h);
+    fbits_valid = true;
     RcmDev hd;
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     const unsigned nf = hd.unf[(level + 1) & 1];
@@ -2214,10 +2407,6 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     fsize = nf;
     total += nf;
     level++;
-    if (level + 1 > ub_max_levels()) {
-      *too_deep = true;
-      return SBX_OK;
-    }
   }
   out->count = total;
   out->levels = level + 1;
