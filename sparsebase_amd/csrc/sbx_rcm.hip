@@ -80,6 +80,8 @@ struct RcmDev {
   unsigned ur_bar, ur_exit;
   unsigned ur_off, ur_size, ur_level, ur_total, ur_status;
   unsigned long long ur_fe, ur_esum;
+  unsigned ur_nf[3], ur_nh[3];          // per level (slot = level % 3): vertices appended, hubs queued
+  unsigned long long ur_deg[3];         // ... and the degree sum of the level
   // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
   alignas(128) unsigned unf[2];
   alignas(128) unsigned long long ufedges[2];
@@ -1822,6 +1824,7 @@ __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vb
   dv->ufedges[0] = dv->ufedges[1] = 0;
   dv->ur_bar = 0;
   dv->ur_exit = 0;
+  for (int i = 0; i < 3; i++) dv->ur_nf[i] = 0, dv->ur_nh[i] = 0, dv->ur_deg[i] = 0;
 }
 
 // Level collection in one launch (64 bitmap words = 4096 vertices per workgroup): claimed bytes -> the frontier word,
@@ -2200,31 +2203,25 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
                                                         unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
                                                         unsigned off, unsigned size, unsigned level, unsigned total,
                                                         long long fe_in, unsigned max_levels) {
+  // Counters live in three slots used in rotation (slot = level being built % 3): every workgroup reads a level's
+  // totals right after its barrier and derives the next state itself — no broadcast, no reset in between; the slot
+  // the NEXT level will use is cleared during this one (its last readers passed the previous barrier).  One barrier
+  // per level, two when the frontier held hubs.  All slots and the barrier words are zero on entry (k_ubfs_start,
+  // and the last workgroup out leaves them so).
   const int lane = sbx_lane();
-  const unsigned level_in = level;
   const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned level_in = level;
   unsigned epoch = 0;
-  unsigned long long scanned = 0;
-  {
-    // is the frontier handed in small enough at all?  (level 0: the root's degree is in dv->fedges, k_ubfs_start)
-    const unsigned long long fe = fe_in >= 0 ? (unsigned long long)fe_in : ur_load(&dv->fedges);
-    ur_barrier(dv, epoch);  // (everyone has read dv->fedges before it is cleared below)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      ur_store(&dv->nf, 0u);
-      ur_store(&dv->fedges, 0ull);
-      ur_store(&dv->n_heavy, 0u);
-      dv->unf[0] = dv->unf[1] = 0;  // (the level slots of the other kernels: levels may change parity in here)
-      dv->ufedges[0] = dv->ufedges[1] = 0;
-      dv->ur_esum = 0;
-      dv->ur_fe = fe;
-      dv->ur_off = off, dv->ur_size = size, dv->ur_level = level, dv->ur_total = total;
-      ur_store(&dv->ur_status, (fe > (unsigned long long)UR_MAX_E || size > UR_MAX_N) ? UR_STOP : UR_CONTINUE);
-    }
-    ur_barrier(dv, epoch);
-  }
-  unsigned status = ur_load(&dv->ur_status);
-  unsigned long long esum = 0;
+  unsigned long long scanned = 0, esum = 0;
+  unsigned long long fe_cur = fe_in >= 0 ? (unsigned long long)fe_in : ur_load(&dv->fedges);  // level 0: k_ubfs_start left it
+  unsigned status = (fe_cur > (unsigned long long)UR_MAX_E || size > UR_MAX_N) ? UR_STOP : UR_CONTINUE;
   while (status == UR_CONTINUE) {
+    const unsigned slot = (level + 1) % 3, next_slot = (level + 2) % 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ur_store(&dv->ur_nf[next_slot], 0u);
+      ur_store(&dv->ur_nh[next_slot], 0u);
+      ur_store(&dv->ur_deg[next_slot], 0ull);
+    }
     I *q_next = q + off + size;
     unsigned long long degacc = 0;
     auto visit = [&](I c) {
@@ -2233,19 +2230,24 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
         const unsigned bit = 1u << (c & 31);
         if (!(ur_load(&vbits[c >> 5]) & bit)) won = !(atomicOr(&vbits[c >> 5], bit) & bit);
       }
-      const unsigned pos = sbx_wave_append(&dv->nf, won);
+      const unsigned pos = sbx_wave_append(&dv->ur_nf[slot], won);
       if (won) {
         ur_store(&q_next[pos], c);
         dist[c] = level + 1;  // (read by later kernels only)
         degacc += (unsigned long long)(rp[c + 1] - rp[c]);
       }
     };
-    // light vertices: one wave each
+    auto flush_degrees = [&]() {
+      degacc = sbx_wave_sum(degacc);
+      if (lane == 0 && degacc) atomicAdd(&dv->ur_deg[slot], degacc);
+      degacc = 0;
+    };
+    // light vertices: one wave each; hubs of the frontier are queued
     for (unsigned p = gwave; p < size; p += nwaves) {
       const I u = ur_load(&q[off + p]);
       const I s = rp[u], e = rp[u + 1];
       if ((unsigned)(e - s) > UR_HEAVY) {
-        if (lane == 0) ur_store(&hq[atomicAdd(&dv->n_heavy, 1u)], u);
+        if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
         continue;
       }
       for (I a = s + lane; __any(a < e); a += 64) {
@@ -2253,58 +2255,61 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
         scanned += a < e ? 1u : 0u;
       }
     }
+    flush_degrees();
     ur_barrier(dv, epoch);
-    // hubs of the frontier: the whole grid scans each of them
-    const unsigned nh = ur_load(&dv->n_heavy);
-    for (unsigned i = 0; i < nh; i++) {
-      const I u = ur_load(&hq[i]);
-      const I s = rp[u], e = rp[u + 1];
-      for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
-        const int64_t a = a0 + lane;
-        visit(a < e ? col[a] : (I)-1);
-        scanned += a < e ? 1u : 0u;
+    const unsigned nh = ur_load(&dv->ur_nh[slot]);
+    if (nh) {  // the whole grid scans each hub
+      for (unsigned i = 0; i < nh; i++) {
+        const I u = ur_load(&hq[i]);
+        const I s = rp[u], e = rp[u + 1];
+        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
+          const int64_t a = a0 + lane;
+          visit(a < e ? col[a] : (I)-1);
+          scanned += a < e ? 1u : 0u;
+        }
       }
+      flush_degrees();
+      ur_barrier(dv, epoch);
     }
-    degacc = sbx_wave_sum(degacc);
-    if (lane == 0 && degacc) atomicAdd(&dv->fedges, degacc);
-    ur_barrier(dv, epoch);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const unsigned nf = ur_load(&dv->nf);
-      const unsigned long long fe = ur_load(&dv->fedges);
-      unsigned st = UR_DONE;  // nf == 0: the frontier just expanded was the deepest level, off / size stay on it
-      if (nf) {
-        esum += fe;
-        ur_store(&dv->ur_off, off + size);
-        ur_store(&dv->ur_size, nf);
-        ur_store(&dv->ur_level, level + 1);
-        ur_store(&dv->ur_total, total + nf);
-        ur_store(&dv->ur_esum, esum);
-        ur_store(&dv->ur_fe, fe);
-        st = (fe > (unsigned long long)UR_MAX_E || nf > UR_MAX_N) ? UR_STOP : UR_CONTINUE;
-        // a deep, narrow component: the one-workgroup ordered kernel walks such levels at half the cost of this one
-        if (st == UR_CONTINUE && level + 1 - level_in >= max_levels) st = UR_DEEP;
-      }
-      ur_store(&dv->nf, 0u);
-      ur_store(&dv->fedges, 0ull);
-      ur_store(&dv->n_heavy, 0u);
-      ur_store(&dv->ur_status, st);
-    }
-    ur_barrier(dv, epoch);
-    status = ur_load(&dv->ur_status);
-    if (status != UR_DONE) {
-      off = ur_load(&dv->ur_off);
-      size = ur_load(&dv->ur_size);
-      level = ur_load(&dv->ur_level);
-      total = ur_load(&dv->ur_total);
+    // every workgroup derives the same next state from the level's totals
+    const unsigned nf = ur_load(&dv->ur_nf[slot]);
+    const unsigned long long fe = ur_load(&dv->ur_deg[slot]);
+    if (nf == 0) {
+      status = UR_DONE;  // the frontier just expanded was the deepest level: off / size stay on it
+    } else {
+      esum += fe;
+      fe_cur = fe;
+      off += size;
+      size = nf;
+      level++;
+      total += nf;
+      status = (fe > (unsigned long long)UR_MAX_E || nf > UR_MAX_N) ? UR_STOP : UR_CONTINUE;
+      // a deep, narrow component: the one-workgroup ordered kernel walks such levels at half the cost of this one
+      if (status == UR_CONTINUE && level - level_in >= max_levels) status = UR_DEEP;
     }
   }
   scanned = sbx_wave_sum(scanned);
   if (lane == 0 && scanned) atomicAdd(&dv->edges, scanned);
-  // the last workgroup out clears the barrier words for the next launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the hand-over state (plain stores: the host reads after the kernel)
+    dv->ur_off = off, dv->ur_size = size, dv->ur_level = level, dv->ur_total = total;
+    dv->ur_status = status;
+    dv->ur_fe = fe_cur;
+    dv->ur_esum = esum;
+    dv->unf[0] = dv->unf[1] = 0;  // (the level slots of the other kernels: levels may change parity in here)
+    dv->ufedges[0] = dv->ufedges[1] = 0;
+    dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  }
+  // the last workgroup out leaves the barrier words and the slots zero for the next launch
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(&dv->ur_exit, 1u) == gridDim.x - 1) {
     ur_store(&dv->ur_bar, 0u);
     ur_store(&dv->ur_exit, 0u);
+    for (int i = 0; i < 3; i++) {
+      ur_store(&dv->ur_nf[i], 0u);
+      ur_store(&dv->ur_nh[i], 0u);
+      ur_store(&dv->ur_deg[i], 0ull);
+    }
   }
 }
 
