@@ -71,6 +71,7 @@ struct RcmDev {
   unsigned long long sl_edges;  // degree sum of the levels the kernel ordered
   unsigned n_components;        // statistics: union-find roots (isolated vertices included) / vertices with an empty row
   unsigned n_empty_rows;
+  unsigned n_nonempty;          // vertices with a non-empty row: what the degree-rank sort sorts
   // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
   unsigned tie_deg, tie_count, tie_min_id;
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
@@ -88,36 +89,70 @@ struct RcmDev {
 };
 
 // ------------------------------------------------------------------ degree rank
-__global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, uint32_t *__restrict__ key,
-                                                  uint32_t *__restrict__ id, int64_t n, RcmDev *__restrict__ dv) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned mx = 0, fv = UNSEEN;
-  for (; v < n; v += stride) {
+// Only vertices with a non-empty row ever meet a BFS, so only they get a (degree, id) rank: on a power-law graph that
+// halves the sort.  DEG_UNITS waves own contiguous vertex ranges; the first kernel counts each unit's non-empty rows
+// (and finds the largest degree and the first non-empty vertex), the second writes (degree, id) compacted in id
+// order — a unit's base is the sum of the counts before it — which is what the stable sort needs.
+constexpr int DEG_UNITS = 4096;
+__device__ __forceinline__ int64_t deg_unit_len(int64_t n) { return ((n + DEG_UNITS - 1) / DEG_UNITS + 63) / 64 * 64; }
+
+__global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int64_t n, unsigned *__restrict__ ucnt,
+                                                   RcmDev *__restrict__ dv) {
+  const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
+  const int64_t len = deg_unit_len(n), v0 = (int64_t)unit * len;
+  unsigned mx = 0, fv = UNSEEN, cnt = 0;
+  for (int64_t v = v0 + lane; v < v0 + len && v < n; v += 64) {
     const unsigned d = (unsigned)(rp[v + 1] - rp[v]);
-    key[v] = d;
-    id[v] = (uint32_t)v;
     mx = d > mx ? d : mx;
-    if (d) fv = (unsigned)v < fv ? (unsigned)v : fv;
+    if (d) {
+      fv = (unsigned)v < fv ? (unsigned)v : fv;
+      cnt++;
+    }
   }
-  // one pair of atomics per workgroup: the two result words are hot
-  __shared__ unsigned s_mx[4], s_fv[4];
+  cnt = sbx_wave_sum(cnt);
+  if (lane == 0 && unit < DEG_UNITS) ucnt[unit] = cnt;
+  // one set of atomics per workgroup: the result words are hot
+  __shared__ unsigned s_mx[4], s_fv[4], s_cnt[4];
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
-  if (sbx_lane() == 0) {
+  if (lane == 0) {
     s_mx[sbx_wave_in_block()] = mx;
     s_fv[sbx_wave_in_block()] = fv;
+    s_cnt[sbx_wave_in_block()] = cnt;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 4; i++) {
       mx = s_mx[i] > mx ? s_mx[i] : mx;
       fv = s_fv[i] < fv ? s_fv[i] : fv;
+      cnt += s_cnt[i];
     }
     if (mx) {
       atomicMax(&dv->max_deg, mx);
       atomicMin(&dv->first_vertex, fv);
+      atomicAdd(&dv->n_nonempty, cnt);
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
+                                                  uint32_t *__restrict__ key, uint32_t *__restrict__ id) {
+  const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
+  if (unit >= DEG_UNITS) return;
+  unsigned base = 0;
+  for (int j = lane; j < unit; j += 64) base += ucnt[j];
+  base = sbx_wave_sum(base);
+  const int64_t len = deg_unit_len(n), v0 = (int64_t)unit * len;
+  for (int64_t vb = v0; vb < v0 + len && vb < n; vb += 64) {
+    const int64_t v = vb + lane;
+    const unsigned d = v < n ? (unsigned)(rp[v + 1] - rp[v]) : 0u;
+    const uint64_t m = __ballot(d != 0);
+    if (d) {
+      const unsigned o = base + (unsigned)__popcll(m & sbx_lanemask_lt());
+      key[o] = d;
+      id[o] = (uint32_t)v;
+    }
+    base += (unsigned)__popcll(m);
   }
 }
 
@@ -2542,10 +2577,13 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
   // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
   SBX_HIP(h, hipMemsetAsync(&dv->first_vertex, 0xFF, sizeof(unsigned), h->stream));
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(sbx_grid_for(n, 256, 1024)), dim3(256), rp, dkey_a, did_a, n, dv);
+  unsigned *ucnt = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS, &ucnt));
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd0;
   SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
+  const int64_t n_ranked = (int64_t)hd0.n_nonempty;  // vertices that get a degree rank
   // Only the Cuthill-McKee sweep reads the degree ranks: they are built on a side stream while the plain sweeps —
   // launch- and latency-bound — run on the caller's stream, and joined before the first Cuthill-McKee sweep.
   const uint32_t *dorder;
@@ -2569,13 +2607,17 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     sbx_radix_pass passes[16];
     const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
     int in_b = 0;
-    int rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n, passes, np, &in_b);
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(DEG_UNITS / 4), dim3(256), rp, n, (const unsigned *)ucnt, dkey_a,
+                did_a);
+    int rc = hipGetLastError() == hipSuccess ? SBX_OK : SBX_ERR_HIP;
+    if (rc == SBX_OK) rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n_ranked, passes, np, &in_b);
     dorder = in_b ? did_b : did_a;
-    if (rc == SBX_OK) {
-      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(gn), dim3(256), dorder, drank, n);
+    if (rc == SBX_OK && n_ranked > 0) {
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(sbx_grid_for(n_ranked, 256, 8192)), dim3(256), dorder,
+                  drank, n_ranked);
       if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
-      if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
     }
+    if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
     h->stream = main_stream;
     h->rs_override = nullptr;
     SBX_TRY(rc);
