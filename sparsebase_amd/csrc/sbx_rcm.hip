@@ -2724,10 +2724,16 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_comp_info, dim3((n_host + 255) / 256), dim3(256), (const I *)info, n_host,
                 (const I *)csize, (const I *)cbase, info + n_host, info + 2 * (size_t)n_host);
     SBX_LAUNCH_CHECK(h);
-    SBX_HIP(h, hipMemcpyAsync(roots.data(), info, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
-    SBX_HIP(h, hipMemcpyAsync(sizes.data(), info + n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
-    SBX_HIP(h, hipMemcpyAsync(bases.data(), info + 2 * (size_t)n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
-    SBX_HIP(h, hipStreamSynchronize(h->stream));
+    if (n_host <= 64) {  // the usual case, a few components: one polled read-back instead of three copies and a sync
+      I tmp[3 * 64];
+      SBX_TRY(sbx_readback(h, tmp, info, (size_t)3 * n_host * sizeof(I)));
+      for (unsigned c = 0; c < n_host; c++) roots[c] = tmp[c], sizes[c] = tmp[n_host + c], bases[c] = tmp[2 * n_host + c];
+    } else {
+      SBX_HIP(h, hipMemcpyAsync(roots.data(), info, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
+      SBX_HIP(h, hipMemcpyAsync(sizes.data(), info + n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
+      SBX_HIP(h, hipMemcpyAsync(bases.data(), info + 2 * (size_t)n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
+      SBX_HIP(h, hipStreamSynchronize(h->stream));
+    }
     // the pre-swept component goes first: its sweep state (q, ppos) is still live
     for (unsigned c = 1; c < n_host; c++)
       if (first_is_large && roots[c] == v0) {
