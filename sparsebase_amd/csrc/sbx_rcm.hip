@@ -76,6 +76,7 @@ struct RcmDev {
   unsigned tie_deg, tie_count, tie_min_id;
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
   unsigned cone_begin, cone_end;  // tie-break: the marked vertices of the level being expanded are list[begin, end)
+  unsigned cone_k, cone_status;   // k_ubfs_cone_run: the level it stopped at (its list is too long for it) / UR_DONE
   unsigned bar;                 // grid barrier of k_ubfs_descend_all
   // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
   unsigned ur_bar, ur_exit;
@@ -2356,6 +2357,84 @@ __global__ __launch_bounds__(256) void k_ubfs_mark_fbits(const I *__restrict__ f
   }
 }
 
+// Cone marking, small levels: the same persistent scheme as k_ubfs_small_run.  T_{k-1} = the level-(k-1) neighbours of
+// T_k, for k = k_start down to 2, while the list of T_k stays within CONE_SMALL members; a longer list hands the level
+// back to the host (UR_STOP, dv->cone_k = k: the expansion kernels in their cone mode take it), a finished walk returns
+// UR_DONE.  The list is one growing array with one counter (dv->nf); members and hub queue move through agent-scope
+// atomics, the cone bits through atomicOr.
+constexpr unsigned CONE_SMALL = 256;  // (a wave takes a member: 256 waves; 1024 measured 0.3 ms slower per RCM)
+__global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp, const I *__restrict__ col,
+                                                       const unsigned *__restrict__ vbits,
+                                                       const unsigned *__restrict__ dist, unsigned *cone, I *list, I *hq,
+                                                       RcmDev *dv, unsigned k_start) {
+  const int lane = sbx_lane();
+  const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  unsigned epoch = 0;
+  unsigned begin = ur_load(&dv->cone_begin), end = ur_load(&dv->cone_end);
+  unsigned k = k_start, status = UR_DONE;
+  bool broken = false;
+  for (; k >= 2; k--) {
+    if (end - begin > CONE_SMALL) {
+      status = UR_STOP;
+      break;
+    }
+    const unsigned slot = k % 3, next_slot = (k + 2) % 3;  // (k counts down: the next level uses (k - 1) % 3)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ur_store(&dv->ur_nh[next_slot], 0u);
+    auto visit = [&](I c) {
+      bool won = false;
+      if (c >= 0 && ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k - 1) {
+        const unsigned bit = 1u << (c & 31);
+        if (!(ur_load(&cone[c >> 5]) & bit)) won = !(atomicOr(&cone[c >> 5], bit) & bit);
+      }
+      const unsigned pos = sbx_wave_append(&dv->nf, won);
+      if (won) ur_store(&list[pos], c);
+    };
+    for (unsigned p = begin + gwave; p < end; p += nwaves) {
+      const I u = ur_load(&list[p]);
+      const I s = rp[u], e = rp[u + 1];
+      if ((unsigned)(e - s) > UR_HEAVY) {
+        if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
+        continue;
+      }
+      for (I a = s + lane; __any(a < e); a += 64) visit(a < e ? col[a] : (I)-1);
+    }
+    ur_barrier(dv, epoch);
+    const unsigned nh = ur_load(&dv->ur_nh[slot]);
+    if (nh) {
+      for (unsigned i = 0; i < nh; i++) {
+        const I u = ur_load(&hq[i]);
+        const I s = rp[u], e = rp[u + 1];
+        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
+          const int64_t a = a0 + lane;
+          visit(a < e ? col[a] : (I)-1);
+        }
+      }
+      ur_barrier(dv, epoch);
+    }
+    begin = end;
+    end = ur_load(&dv->nf);
+    if (end == begin) {  // a level without a path to the level below: not a symmetric pattern
+      broken = true;
+      break;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dv->cone_begin = begin;
+    dv->cone_end = end;
+    dv->cone_k = k;
+    dv->cone_status = status;
+    if (broken) dv->unsym = 1;
+    dv->n_heavy = 0;
+    dv->hub_overflow = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&dv->ur_exit, 1u) == gridDim.x - 1) {
+    ur_store(&dv->ur_bar, 0u);
+    ur_store(&dv->ur_exit, 0u);
+    for (int i = 0; i < 3; i++) ur_store(&dv->ur_nh[i], 0u);
+  }
+}
+
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, I fixed_root,
@@ -2488,10 +2567,17 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     heavy_per_cu = nb;
   }
   const unsigned heavy_grid = (unsigned)h->num_cus * (unsigned)heavy_per_cu;
-  // (no host round trip per level: the range of the list a level expands is kept on the device by k_ubfs_cone_next)
+  // Small lists — most of them — are walked by the persistent kernel, several levels per launch; a level whose list is
+  // too long for it goes through the expansion kernels in their cone mode (the range of the list stays on the device).
   if (r.last_size > UB_TIES_SMALL) SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_cone_next, dim3(1), dim3(1), b.dv, 1);
   const unsigned cone_grid = max_grid < 512u ? max_grid : 512u;
-  for (unsigned k = r.levels - 1; k >= 2; k--) {  // level 0 is the root: every T_1 member hangs under it
+  for (unsigned k = r.levels - 1; k >= 2;) {  // level 0 is the root: every T_1 member hangs under it
+    SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_cone_run, dim3(UR_GRID), dim3(256), b.rp, b.col, (const unsigned *)b.vbits,
+                (const unsigned *)b.lpos, cone, list, (I *)b.heavy, b.dv, k);
+    SBX_LAUNCH_CHECK(h);
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    if (hd.cone_status == UR_DONE || hd.unsym) break;
+    k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
     SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(cone_grid), dim3(256), b.rp, b.col, (const I *)list, 0u, k,
                 (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us);
@@ -2500,6 +2586,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
                   (const unsigned *)b.vbits, b.ppos, list, (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, cone_grid,
                   b.dv, us);
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_cone_next, dim3(1), dim3(1), b.dv, 0);
+    k--;
   }
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
               (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv);
