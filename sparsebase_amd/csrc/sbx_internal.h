@@ -213,6 +213,7 @@ struct sbx_radix_emit {
   uint32_t *out;
   unsigned *bits_a, *bits_b;
   unsigned *pos_of;
+  uint32_t low_mask;  // low32(key) is ANDed with this first (0: all 32 bits) — keys whose fields are packed tightly
 };
 int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
                         int num_passes, const sbx_radix_emit *emit);

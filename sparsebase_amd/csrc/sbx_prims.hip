@@ -335,7 +335,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restric
       const unsigned d = (unsigned)(kk >> shift) & mask;
       const uint32_t o = s_gofs[d] + (uint32_t)j;
       if (EMIT) {
-        const uint32_t lo = (uint32_t)kk;
+        const uint32_t lo = em.low_mask ? (uint32_t)kk & em.low_mask : (uint32_t)kk;
         const uint32_t v = em.map ? em.map[lo] : lo;
         em.out[o] = v;
         if (em.bits_a) atomicOr(&em.bits_a[v >> 5], 1u << (v & 31));
@@ -387,7 +387,7 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
-  const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   for (int p = 0; p < np; p++) {
     if (EMIT && p == np - 1)
       SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, EMIT>), dim3((unsigned)tiles),

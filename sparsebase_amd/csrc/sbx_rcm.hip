@@ -945,12 +945,12 @@ template <bool CM>
 __global__ __launch_bounds__(256) void k_level_keys(const I *__restrict__ nf_list, unsigned nf,
                                                     const unsigned *__restrict__ ppos,
                                                     const uint32_t *__restrict__ drank, uint64_t *__restrict__ key,
-                                                    RcmDev *__restrict__ dv) {
+                                                    RcmDev *__restrict__ dv, int low_bits) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; j < nf; j += stride) {
+  for (; j < nf; j += stride) {  // the parent position sits right above the low field: no dead digit in between
     const I v = nf_list[j];
-    key[j] = ((uint64_t)ppos[v] << 32) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
+    key[j] = ((uint64_t)ppos[v] << low_bits) | (uint64_t)(CM ? drank[v] : (uint32_t)v);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) reset_level_counters(dv);
 }
@@ -1765,6 +1765,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       const int set_bits = bitmap_pass ? 0 : 1;
       sbx_radix_pass passes[16];
       int np;
+      int low_bits = 32;  // width of the key's low field (vertex id or degree rank); 32: the parent position starts at bit 32
       if (!CM && !set_bits) {
         // keys in ascending id order straight from the bitmap pass: only the parent positions are left to sort
         const int64_t words = (b.n + 63) / 64;
@@ -1780,14 +1781,16 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                     (const unsigned *)b.ppos, b.ka, words, b.dv);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       } else {
+        low_bits = sbx_bits_for((uint64_t)(b.n - 1));
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_keys<CM>), dim3(g), dim3(256), (const I *)b.nf_list, nf,
-                    (const unsigned *)b.ppos, b.drank, b.ka, b.dv);
-        np = sbx_radix_plan(0, sbx_bits_for((uint64_t)(b.n - 1)), 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
+                    (const unsigned *)b.ppos, b.drank, b.ka, b.dv, low_bits);
+        np = sbx_radix_plan(0, low_bits + sbx_bits_for((uint64_t)(fsize - 1)), 0, 0, passes);
       }
       if (np > 0) {
         // the last digit pass writes the queue, the bits and the level positions itself (no pass over sorted keys)
         const sbx_radix_emit em = {CM ? b.dorder : nullptr, (uint32_t *)q_next, set_bits ? b.vbits : nullptr,
-                                   (set_bits && mark_frontier) ? b.fbits : nullptr, mark_frontier ? b.lpos : nullptr};
+                                   (set_bits && mark_frontier) ? b.fbits : nullptr, mark_frontier ? b.lpos : nullptr,
+                                   low_bits < 32 ? (1u << low_bits) - 1u : 0u};
         SBX_TRY(sbx_radix_sort_emit(h, b.ka, b.kb, nf, passes, np, &em));
       } else {  // one parent and keys already in id order: nothing to sort
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, (k_level_emit<CM>), dim3(g), dim3(256), (const uint64_t *)b.ka, nf, b.dorder,
