@@ -301,12 +301,37 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
   const int64_t step = (int64_t)gridDim.x * rows_per_block;
   int64_t row = (int64_t)blockIdx.x * rows_per_block + tid / GR_LPR;
-  int32_t s_nx = 0, e_nx = 0;  // the row's bounds, fetched one step ahead
-  if (row < n) s_nx = rp[row], e_nx = rp[row + 1];
+  // software pipeline: the bounds of the row two steps ahead and the first batch of entries of the row one step ahead
+  // are in flight while this step's row is processed (the kernel is bound by the rp -> col load chain, not by work)
+  int32_t s_cur = 0, e_cur = 0, s_nx = 0, e_nx = 0;
+  if (row < n) s_cur = rp[row], e_cur = rp[row + 1];
+  if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
+  unsigned c_cur[GR_BATCH];
+  {
+    const bool lr = e_cur - s_cur > GR_SHORT_MAX;
+    const unsigned far0 = (unsigned)row ^ 0x40000000u;
+#pragma unroll
+    for (int u = 0; u < GR_BATCH; u++) {
+      const int32_t j = s_cur + sub + u * GR_LPR;
+      c_cur[u] = (!lr && j < e_cur) ? (unsigned)__builtin_nontemporal_load(col + j) : far0;
+    }
+  }
   for (; row < n; row += step) {
-    const int32_t s = s_nx;
-    int32_t e = e_nx;
-    if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
+    const int32_t s = s_cur;
+    int32_t e = e_cur;
+    // next step: its bounds are here (loaded a step ago), its first batch is issued now; the step after: its bounds
+    s_cur = s_nx, e_cur = e_nx;
+    if (row + 2 * step < n) s_nx = rp[row + 2 * step], e_nx = rp[row + 2 * step + 1];
+    unsigned c_nx[GR_BATCH];
+    {
+      const bool lr = e_cur - s_cur > GR_SHORT_MAX;
+      const unsigned far1 = (unsigned)(row + step) ^ 0x40000000u;
+#pragma unroll
+      for (int u = 0; u < GR_BATCH; u++) {
+        const int32_t j = s_cur + sub + u * GR_LPR;
+        c_nx[u] = (row + step < n && !lr && j < e_cur) ? (unsigned)__builtin_nontemporal_load(col + j) : far1;
+      }
+    }
     // The kernel runs before anyone knows whether the matrix suits it: rows above GR_SHORT_MAX entries are listed for
     // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
     // leaves at its next long row — the host then discards the results and takes the tile kernel.
@@ -324,17 +349,19 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
 #pragma unroll
     for (int t = 0; t < LV; t++) ge[t] = 0;
     unsigned inb = 0;
-    // the row's entries, GR_BATCH loads in flight per lane (a lane's entries are GR_LPR apart); longer rows take a
-    // second batch
+    // the row's entries, GR_BATCH per lane and batch (a lane's entries are GR_LPR apart); the first batch was
+    // prefetched, longer rows load further ones here
     const unsigned row_lo = (unsigned)row - band, band2 = 2u * band;  // |c - row| <= band  <=>  c - row_lo <= 2 band (mod 2^32)
     const unsigned far = (unsigned)row ^ 0x40000000u;                  // a column outside every band: stands for "no entry"
-    for (int32_t j0 = s + sub; __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
+    bool first = true;
+    for (int32_t j0 = s + sub; first || __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
       unsigned c[GR_BATCH];
 #pragma unroll
       for (int u = 0; u < GR_BATCH; u++) {
         const int32_t j = j0 + u * GR_LPR;
-        c[u] = j < e ? (unsigned)__builtin_nontemporal_load(col + j) : far;
+        c[u] = first ? c_cur[u] : (j < e ? (unsigned)__builtin_nontemporal_load(col + j) : far);
       }
+      first = false;
 #pragma unroll
       for (int u = 0; u < GR_BATCH; u++) {
         unsigned bkt;
@@ -351,6 +378,8 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
         inb += c[u] - row_lo <= band2;
       }
     }
+#pragma unroll
+    for (int u = 0; u < GR_BATCH; u++) c_cur[u] = c_nx[u];
     // merge the lanes of the row: counts add, saturating at LV
 #pragma unroll
     for (int m = 1; m < GR_LPR; m <<= 1) {
