@@ -78,6 +78,8 @@ struct RcmDev {
   unsigned cone_begin, cone_end;  // tie-break: the marked vertices of the level being expanded are list[begin, end)
   unsigned cone_k, cone_status;   // k_ubfs_cone_run: the level it stopped at (its list is too long for it) / UR_DONE
   unsigned bar;                 // grid barrier of k_ubfs_descend_all
+  unsigned gb_abort;            // a grid barrier gave up waiting (see gb_wait): the host redoes the sweep the safe way
+  unsigned gb_spins;            // how many polls a barrier waits (k_ubfs_start sets it; SBX_DEBUG_GB_SPINS for tests)
   // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
   unsigned ur_bar, ur_exit;
   unsigned ur_off, ur_size, ur_level, ur_total, ur_status;
@@ -1848,7 +1850,8 @@ static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search
 }
 
 __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                             unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root) {
+                             unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
+                             unsigned gb_spins) {
   const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
   dv->root = (unsigned)r;
   vbits[r >> 5] = 1u << (r & 31);  // the bitmaps were cleared by the host for this sweep
@@ -1864,6 +1867,7 @@ __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vb
   dv->ur_bar = 0;
   dv->ur_exit = 0;
   for (int i = 0; i < 3; i++) dv->ur_nf[i] = 0, dv->ur_nh[i] = 0, dv->ur_deg[i] = 0;
+  dv->gb_spins = gb_spins;
 }
 
 // Level collection in one launch (64 bitmap words = 4096 vertices per workgroup): claimed bytes -> the frontier word,
@@ -2158,16 +2162,38 @@ __global__ void k_ubfs_cone_next(RcmDev *__restrict__ dv, int first) {
 // a hub with 10^5 entries — and meet at a grid barrier (one arrival counter, dv->bar) after every level.  w_k lives in
 // dv->desc[k % 3]; the step that fills slot k % 3 finds it cleared by the step before the previous barrier.
 constexpr unsigned UB_DESC_GRID = 64;
-// (No __threadfence() around it: on a multi-XCD part an agent-scope fence writes the L2 back — ~5 us a piece — and
-// everything the workgroups exchange between two barriers, dv->desc, moves through agent-scope atomics anyway.)
-__device__ __forceinline__ void ub_grid_barrier(RcmDev *dv, unsigned target) {
-  __syncthreads();
+// ---- grid barriers that give up --------------------------------------------------------------------------
+// The persistent kernels below synchronise their workgroups through a counter in device memory.  That only works while
+// every workgroup of the grid is running; a plain launch does not promise it, and with a second process on the same GPU
+// one of two such kernels was seen to wait for ever for workgroups that never started (a cooperative launch does
+// promise it, at ~170 us per launch: 1.7 ms per RCM).  So a wait is bounded: after GB_SPINS polls (tens of
+// milliseconds; a barrier normally takes a microsecond or two) the waiter raises dv->gb_abort and leaves, every other
+// waiter sees the flag and leaves too, late workgroups leave at their first barrier, and the host — which finds the flag
+// in its next read-back — throws the sweep away and runs it again with the one-launch-per-level kernels.
+constexpr unsigned GB_SPINS = 1u << 19;
+__device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned target) {
+  __shared__ int s_ok;
+  __syncthreads();  // (also waits for this workgroup's outstanding stores and atomics: vmcnt)
   if (threadIdx.x == 0) {
-    atomicAdd(&dv->bar, 1u);
-    while (__hip_atomic_load(&dv->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    atomicAdd(word, 1u);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(&dv->gb_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > dv->gb_spins) {
+        __hip_atomic_store(&dv->gb_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_ok = ok;
   }
   __syncthreads();
+  return s_ok != 0;
 }
+
+// (No __threadfence() around a barrier: on a multi-XCD part an agent-scope fence writes the L2 back — ~5 us a piece — and
+// everything the workgroups exchange between two barriers moves through agent-scope atomics anyway.)
 __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ rp, const I *__restrict__ col,
                                                           const unsigned *__restrict__ vbits,
                                                           const unsigned *__restrict__ dist,
@@ -2178,7 +2204,7 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
     __hip_atomic_store(&dv->desc[1], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&dv->desc[2], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  ub_grid_barrier(dv, gridDim.x);
+  if (!gb_wait(dv, &dv->bar, gridDim.x)) return;
   unsigned w = __hip_atomic_load(&dv->desc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned k = 1; k < levels; k++) {
     if (blockIdx.x == 0 && threadIdx.x == 0)  // idle during this step
@@ -2195,13 +2221,28 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
     }
     best = sbx_wave_min(best);
     if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->desc[k % 3], best);
-    ub_grid_barrier(dv, gridDim.x * (k + 1));
+    if (!gb_wait(dv, &dv->bar, gridDim.x * (k + 1))) return;
     w = __hip_atomic_load(&dv->desc[k % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (w == 0xFFFFFFFFu) dv->unsym = 1;  // cannot happen on a symmetric pattern
     else dv->root = w;
   }
+}
+
+// after a grid barrier gave up: the words the persistent kernels leave zero when they finish normally
+__global__ void k_gb_reset(RcmDev *__restrict__ dv) {
+  dv->gb_abort = 0;
+  dv->bar = 0;
+  dv->ur_bar = 0;
+  dv->ur_exit = 0;
+  for (int i = 0; i < 3; i++) dv->ur_nf[i] = 0, dv->ur_nh[i] = 0, dv->ur_deg[i] = 0;
+  dv->nf = 0;
+  dv->fedges = 0;
+  dv->n_heavy = 0;
+  dv->hub_overflow = 0;
+  dv->unf[0] = dv->unf[1] = 0;
+  dv->ufedges[0] = dv->ufedges[1] = 0;
 }
 
 // ---- unordered sweeps, small levels: one launch for as many consecutive levels as stay small ------------------
@@ -2228,14 +2269,9 @@ template <typename T>
 __device__ __forceinline__ void ur_store(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ur_barrier(RcmDev *dv, unsigned &epoch) {
+__device__ __forceinline__ bool ur_barrier(RcmDev *dv, unsigned &epoch) {
   epoch++;
-  __syncthreads();  // (waits for this workgroup's outstanding stores and atomics: vmcnt)
-  if (threadIdx.x == 0) {
-    atomicAdd(&dv->ur_bar, 1u);
-    while (ur_load(&dv->ur_bar) < epoch * gridDim.x) __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
+  return gb_wait(dv, &dv->ur_bar, epoch * gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp, const I *__restrict__ col,
@@ -2295,7 +2331,7 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
       }
     }
     flush_degrees();
-    ur_barrier(dv, epoch);
+    if (!ur_barrier(dv, epoch)) return;
     const unsigned nh = ur_load(&dv->ur_nh[slot]);
     if (nh) {  // the whole grid scans each hub
       for (unsigned i = 0; i < nh; i++) {
@@ -2308,7 +2344,7 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
         }
       }
       flush_degrees();
-      ur_barrier(dv, epoch);
+      if (!ur_barrier(dv, epoch)) return;
     }
     // every workgroup derives the same next state from the level's totals
     const unsigned nf = ur_load(&dv->ur_nf[slot]);
@@ -2401,7 +2437,7 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
       }
       for (I a = s + lane; __any(a < e); a += 64) visit(a < e ? col[a] : (I)-1);
     }
-    ur_barrier(dv, epoch);
+    if (!ur_barrier(dv, epoch)) return;
     const unsigned nh = ur_load(&dv->ur_nh[slot]);
     if (nh) {
       for (unsigned i = 0; i < nh; i++) {
@@ -2412,7 +2448,7 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
           visit(a < e ? col[a] : (I)-1);
         }
       }
-      ur_barrier(dv, epoch);
+      if (!ur_barrier(dv, epoch)) return;
     }
     begin = end;
     end = ur_load(&dv->nf);
@@ -2449,7 +2485,9 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
   SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
   unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root);
+  static const unsigned gb_spins = getenv("SBX_DEBUG_GB_SPINS") ? (unsigned)atoll(getenv("SBX_DEBUG_GB_SPINS")) : GB_SPINS;
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root,
+              gb_spins);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   static int heavy_per_cu = 0;
@@ -2475,6 +2513,11 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_LAUNCH_CHECK(h);
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
+      if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+        *too_deep = true;
+        return SBX_OK;
+      }
       const bool moved = hs.ur_level != level;
       off = hs.ur_off, fsize = hs.ur_size, level = hs.ur_level, total = hs.ur_total;
       remaining -= (int64_t)hs.ur_esum;
@@ -2539,7 +2582,8 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
 
 // the next candidate root after an unordered sweep: first vertex in queue order among the deepest level's vertices of
 // smallest degree (see the comment above k_ubfs_start); left in dv->root
-static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r) {
+static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r, bool *aborted) {
+  *aborted = false;
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const I *last = b.q + r.last_offset;
   I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level after level, one growing list
@@ -2579,6 +2623,11 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
                 (const unsigned *)b.lpos, cone, list, (I *)b.heavy, b.dv, k);
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    if (hd.gb_abort) {
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+      *aborted = true;
+      return SBX_OK;
+    }
     if (hd.cone_status == UR_DONE || hd.unsym) break;
     k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
@@ -2594,6 +2643,11 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
               (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv);
   SBX_LAUNCH_CHECK(h);
+  SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
+  if (hd.gb_abort) {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+    *aborted = true;
+  }
   return SBX_OK;
 }
 
@@ -2885,9 +2939,15 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
         if (e > ecc) ecc = e;
         const bool path = (int64_t)r.count == ecc + 1;
         if (!path && prev_ecc != ecc) {
-          if (unordered) {
-            SBX_TRY(ubfs_pick_root(h, b, cone, r));
-          } else {
+          bool tie_aborted = false;
+          if (unordered) SBX_TRY(ubfs_pick_root(h, b, cone, r, &tie_aborted));
+          if (unordered && tie_aborted) {
+            // a grid barrier of the tie-break gave up: the same sweep again, ordered (dv->root still is its root)
+            deep = true;
+            unordered = false;
+            SBX_TRY(run_bfs<false>(h, b, -1, roots[c], &r));
+          }
+          if (!unordered) {
             SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
                                (const I *)(q + r.last_offset), r.last_size, dv);
             SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);

@@ -1013,6 +1013,33 @@ def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
     assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
 
 
+@pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere"])
+def test_rcm_sweep_variants_in_a_child(mode):
+    """The switches of the RCM's pseudo-peripheral sweeps are read once per process, hence the children:
+    SBX_DEBUG_GB_SPINS=0 makes every grid barrier of the persistent kernels give up at once (what a barrier does when its
+    workgroups are not all running, e.g. on a GPU shared with another process) — every sweep and tie-break is then redone
+    by the one-launch-per-level kernels; SBX_RCM_UNORDERED=0 keeps the order inside every level (round 1's sweeps);
+    SBX_DEBUG_UB_MAX_LEVELS lifts the depth limit so that grids and bands take the unordered sweeps too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+        "from orc import Oracle; from sparsebase_amd import ops, synth\n"
+        "orc = Oracle(); d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "cases = [synth.rmat_symmetric(16, 8, seed=3), synth.rmat_symmetric(14, 3, seed=5),\n"
+        "         synth.random_symmetric_graph(30000, avg_deg=3, seed=2, n_blocks=3, isolated_frac=0.1),\n"
+        "         synth.banded_symmetric(40000, 6, per_row=4, seed=1), synth.grid_graph(150, 150, shuffle_seed=4)]\n"
+        "for rp, col in cases:\n"
+        "    assert np.array_equal(ops.rcm_reorder(d(rp), d(col)).cpu().numpy(), orc.rcm_reorder(rp, col))\n"
+        "print('rcm variant ok')\n" % (root, os.path.join(root, "tests")))
+    extra = {"barriers_give_up": {"SBX_DEBUG_GB_SPINS": "0"}, "ordered_sweeps": {"SBX_RCM_UNORDERED": "0"},
+             "unordered_everywhere": {"SBX_DEBUG_UB_MAX_LEVELS": "1000000"}}[mode]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
     """Directed inputs (an edge list read with read_undirected=False): a BFS cannot reach its weakly connected
     component.  The reference leaks stale distances there; here every such input must end in a clean error —
