@@ -74,6 +74,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->nest = 0;
   h->pinned = nullptr;
   h->pinned_bytes = 0;
+  h->rcm_gb_backoff = 0;
   h->err[0] = 0;
   h->prof_on = false;
   for (int i = 0; i < SBX_K_COUNT; i++) {

@@ -2166,11 +2166,11 @@ constexpr unsigned UB_DESC_GRID = 64;
 // The persistent kernels below synchronise their workgroups through a counter in device memory.  That only works while
 // every workgroup of the grid is running; a plain launch does not promise it, and with a second process on the same GPU
 // one of two such kernels was seen to wait for ever for workgroups that never started (a cooperative launch does
-// promise it, at ~170 us per launch: 1.7 ms per RCM).  So a wait is bounded: after GB_SPINS polls (tens of
+// promise it, at ~170 us per launch: 1.7 ms per RCM).  So a wait is bounded: after GB_SPINS polls (a few
 // milliseconds; a barrier normally takes a microsecond or two) the waiter raises dv->gb_abort and leaves, every other
 // waiter sees the flag and leaves too, late workgroups leave at their first barrier, and the host — which finds the flag
 // in its next read-back — throws the sweep away and runs it again with the one-launch-per-level kernels.
-constexpr unsigned GB_SPINS = 1u << 19;
+constexpr unsigned GB_SPINS = 1u << 16;
 __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned target) {
   __shared__ int s_ok;
   __syncthreads();  // (also waits for this workgroup's outstanding stores and atomics: vmcnt)
@@ -2515,6 +2515,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
       if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+        h->rcm_gb_backoff = 16;
         *too_deep = true;
         return SBX_OK;
       }
@@ -2625,6 +2626,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.gb_abort) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+      h->rcm_gb_backoff = 16;
       *aborted = true;
       return SBX_OK;
     }
@@ -2646,6 +2648,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
   if (hd.gb_abort) {
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+    h->rcm_gb_backoff = 16;
     *aborted = true;
   }
   return SBX_OK;
@@ -2800,9 +2803,13 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &nbits));
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
   bool r0_unordered = false;
+  // after a grid barrier gave up (a GPU shared with another process, see gb_wait) the next few calls on this handle do
+  // not try the persistent kernels again
+  const bool unordered_ok = rcm_unordered() && h->rcm_gb_backoff == 0;
+  if (h->rcm_gb_backoff > 0) h->rcm_gb_backoff--;
   if (v0 >= 0) {
     bool deep = true;
-    if (rcm_unordered()) {
+    if (unordered_ok) {
       SBX_TRY(run_ubfs(h, b, claim8, nbits, v0, (I)-1, &r0, &deep));
       r0_unordered = !deep;
     }
@@ -2901,7 +2908,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       I fixed = roots[c];
       bool have_first_sweep = first_is_large && roots[c] == v0;
       bool cm_done = false;
-      bool deep = !rcm_unordered();  // a sweep of more than UB_MAX_LEVELS levels: this component keeps ordered sweeps
+      bool deep = !unordered_ok;  // a sweep of more than UB_MAX_LEVELS levels: this component keeps ordered sweeps
       while (prev_ecc != ecc) {
         prev_ecc = ecc;
         bool unordered = false;  // the sweep just run kept no order inside its levels
