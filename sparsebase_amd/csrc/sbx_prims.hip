@@ -160,6 +160,8 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAX_PASSES = 8;
 constexpr int RS_LOOKBACK = 8;  // predecessor status words fetched per look-back round
 
+typedef unsigned long long rs_word;  // look-back status word: (count << 2) | flag  (32-bit words, count < 2^30: +2 % only)
+
 struct RadixPlan {
   int n;
   int shift[RS_MAX_PASSES];
@@ -170,7 +172,7 @@ struct RadixPlan {
 template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
                                                               unsigned long long *__restrict__ ghist,
-                                                              unsigned long long *__restrict__ state,
+                                                              rs_word *__restrict__ state,
                                                               size_t state_words) {
   __shared__ unsigned lh[RS_MAX_PASSES][256];
   // the look-back status words of all passes are only touched by the pass kernels: clear them here
@@ -178,8 +180,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
     state[j] = 0;
   for (int i = threadIdx.x; i < RS_MAX_PASSES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * RS_THREADS + threadIdx.x;
+  // HU keys per thread and round, all loads issued before the first counter update: one key per round leaves a
+  // thread with one load in flight and the kernel at 1 TB/s
+  constexpr int HU = 8;
   const int64_t stride = (int64_t)gridDim.x * RS_THREADS;
+  int64_t i = (int64_t)blockIdx.x * RS_THREADS + threadIdx.x;
+  for (; i + (HU - 1) * stride < count; i += HU * stride) {
+    K k[HU];
+#pragma unroll
+    for (int u = 0; u < HU; u++) k[u] = keys[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < HU; u++)
+      for (int p = 0; p < plan.n; p++)
+        atomicAdd(&lh[p][(unsigned)(k[u] >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
+  }
   for (; i < count; i += stride) {
     const K k = keys[i];
     for (int p = 0; p < plan.n; p++)
@@ -191,6 +205,31 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
     if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)c);
   }
 }
+
+// diagnostic build only (-DSBX_RADIX_STAMPS, tools/radix_stamps.py): wall-clock cycles from kernel entry to the end of
+// each phase of k_onesweep_pass, summed over the tiles by thread 0; [15] counts the tiles
+#ifdef SBX_RADIX_STAMPS
+__device__ unsigned long long g_rs_stamps[16];
+#define RS_STAMP(i, drain)                                                          \
+  do {                                                                              \
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+    if (tid == 0) {                                                                 \
+      unsigned long long t_;                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+      atomicAdd(&g_rs_stamps[i], (i) == 15 ? 1ull : t_ - t_start);                  \
+    }                                                                               \
+  } while (0)
+extern "C" int sbx_debug_radix_stamps(unsigned long long *out, int clear) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_stamps), sizeof(g_rs_stamps)) != hipSuccess) return 1;
+  if (clear) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define RS_STAMP(i, drain) do { } while (0)
+#endif
 
 // One digit pass in a single kernel.  Tiles take a ticket (so a tile only ever waits
 // for tiles that already run), rank their keys in LDS exactly like a classic scatter
@@ -204,149 +243,271 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
 // EMIT (final pass of sbx_radix_sort_emit): the sorted keys are not stored; the pass writes what the caller wanted
 // them for — out[position] = value (the key's low word, optionally mapped), value's bit in up to two bitmaps,
 // pos_of[value] = position — and saves the caller a kernel that re-reads the sorted keys.
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also drains vmcnt, i.e. the loads
+// of the NEXT tile that the pass kernel keeps in flight while it works on the current one.
+constexpr int RSP_THREADS = 512;  // threads of a pass workgroup (the first 256 own one digit each)
+constexpr int RSP_WAVES = RSP_THREADS / 64;
+__device__ __forceinline__ void rs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t rs_block_exclusive_sum(uint32_t v, uint32_t *lds) {
+  const uint32_t inc = sbx_wave_inclusive_sum(v);
+  const int w = sbx_wave_in_block();
+  if (sbx_lane() == 63) lds[w] = inc;
+  rs_lds_barrier();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int i = 0; i < RSP_WAVES; i++) {
+    const uint32_t t = lds[i];
+    if (i < w) woff += t;
+  }
+  rs_lds_barrier();
+  return woff + inc - v;
+}
+
+// The workgroups are persistent: each takes tickets until the tiles run out, and holds the keys and payloads of its
+// NEXT tile in registers (loads issued before the current tile is touched) — with one tile per workgroup the phases
+// of a tile (load, rank, look-back, store) run one after the other and a CU keeps ~17 KB of loads in flight, a quarter
+// of what the HBM latency asks for (measured with tools/radix_stamps.py: 2.1 TB/s per pass whatever the size).
 template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT>
-__global__ __launch_bounds__(RS_THREADS) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+__global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const P *__restrict__ vals_in, P *__restrict__ vals_out,
                                                               int64_t count, int shift, int bits,
                                                               const unsigned long long *__restrict__ ghist,
-                                                              unsigned long long *state, unsigned *ticket,
+                                                              rs_word *state, unsigned *ticket,
                                                               sbx_radix_emit em) {
-  constexpr int TILE = RS_THREADS * ITEMS;
+  constexpr int TILE = RSP_THREADS * ITEMS;
   __shared__ K s_keys[TILE];
   __shared__ P s_vals[HAS_P ? TILE : 1];
-  __shared__ uint32_t s_whist[RS_WAVES][256];
+  __shared__ uint32_t s_whist[RSP_WAVES][256];
   __shared__ uint32_t s_gofs[256];
-  __shared__ uint32_t s_scan[RS_WAVES + 1];
-  __shared__ unsigned long long s_scan64[RS_WAVES + 1];
-  __shared__ unsigned s_tile;
+  __shared__ uint32_t s_cnt[256];
+  __shared__ uint32_t s_scan[RSP_WAVES + 1];
+  __shared__ unsigned s_tile[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int i = 0; i < RS_WAVES; i++) s_whist[i][tid] = 0;
-  __syncthreads();
-  const unsigned tile = s_tile;
-  const int64_t base = (int64_t)tile * TILE;
-  const int valid = (int)((count - base) < TILE ? (count - base) : TILE);
   const unsigned mask = (1u << bits) - 1u;
-
-  K k[ITEMS];
-  P v[HAS_P ? ITEMS : 1];
-  uint32_t rank[ITEMS];
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const int e = w * 64 * ITEMS + i * 64 + lane;
-    k[i] = e < valid ? keys_in[base + e] : (K) ~(K)0;
-    if (HAS_P) v[i] = e < valid ? vals_in[base + e] : (P)0;
-  }
-  volatile uint32_t *wh = s_whist[w];
+  const unsigned tiles = (unsigned)((count + TILE - 1) / TILE);
+  const bool owner = tid < 256;                  // thread `tid` owns digit `tid`
+  const bool live = owner && (unsigned)tid <= mask;  // digits the pass cannot produce take no part in the look-back
   const uint64_t lt = sbx_lanemask_lt();
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const unsigned d = (unsigned)(k[i] >> shift) & mask;
-    uint64_t m = ~(uint64_t)0;
-    for (int b = 0; b < bits; b++) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
-    }
-    const uint32_t prev = wh[d];
-    const uint32_t r = (uint32_t)__popcll(m & lt);
-    __builtin_amdgcn_wave_barrier();
-    if (r == 0) wh[d] = prev + (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    rank[i] = prev + r;
+  const int e0 = w * 64 * ITEMS + lane;     // this thread's items of a tile: e0 + i * 64
+#ifdef SBX_RADIX_STAMPS
+  unsigned long long t_start;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+#endif
+  // tickets are taken two tiles ahead: the returning atomic takes ~3 us, the tile after the current one must be known
+  // when the current one starts (its loads are issued then)
+  // (a launch with a workgroup per tile takes one ticket per workgroup: the ticket word serves ~88 atomics per
+  // microsecond, and the small sorts of the RCM are all of that kind)
+  const bool single = tiles <= gridDim.x;
+  if (tid == 0) {
+    s_tile[0] = atomicAdd(ticket, 1u);
+    s_tile[1] = single ? 0xffffffffu : atomicAdd(ticket, 1u);
   }
   __syncthreads();
-  {
+  unsigned tile = s_tile[0], next = s_tile[1];
+  // first output position of digit `tid` = exclusive scan of the global counts (count < 2^32: 32 bits do)
+  const uint32_t gbase = rs_block_exclusive_sum(owner ? (uint32_t)ghist[tid] : 0u, s_scan);
+
+  K kn[ITEMS];
+  P vn[HAS_P ? ITEMS : 1];
+  // every load is issued whatever the tile (clamped address): a load under a condition makes the compiler wait for
+  // it at the join
+#define RS_PREFETCH(t_)                                                                \
+  do {                                                                                 \
+    const int64_t last_ = count - 1, b_ = (int64_t)(t_) * TILE + e0;                   \
+    _Pragma("unroll") for (int i = 0; i < ITEMS; i++) {                                \
+      const int64_t a_ = b_ + i * 64 < last_ ? b_ + i * 64 : last_;                    \
+      kn[i] = keys_in[a_];                                                             \
+      if (HAS_P) vn[i] = vals_in[a_];                                                  \
+    }                                                                                  \
+  } while (0)
+  RS_PREFETCH(tile);
+  unsigned after_next = 0;  // thread 0 only
+  // A tile's digit counts are published as soon as its keys are here — for the first tile now, for every other one
+  // while the workgroup still works on the tile before it: the tiles behind wait for these words, and the slowest
+  // workgroup in flight sets for how long.
+#define RS_COUNT_PUBLISH(t_, out_)                                                                              \
+  do {                                                                                                          \
+    const int64_t left_ = count - (int64_t)(t_) * TILE;                                                         \
+    const int valid_ = (int)(left_ < TILE ? (left_ > 0 ? left_ : 0) : TILE);                                    \
+    _Pragma("unroll") for (int i = 0; i < ITEMS; i++)                                                           \
+      if (e0 + i * 64 < valid_) atomicAdd(&s_cnt[(unsigned)(kn[i] >> shift) & mask], 1u);                       \
+    rs_lds_barrier();                                                                                           \
+    out_ = owner ? s_cnt[tid] : 0u;                                                                             \
+    if (live && (t_) < tiles)                                                                                   \
+      __hip_atomic_store(state + (size_t)(t_) * 256 + tid, ((rs_word)out_ << 2) | (rs_word)((t_) == 0 ? 2u : 1u), \
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                           \
+  } while (0)
+  if (owner) s_cnt[tid] = 0;
+  rs_lds_barrier();
+  uint32_t tot_next;
+  RS_COUNT_PUBLISH(tile, tot_next);
+  while (tile < tiles) {
+#ifdef SBX_RADIX_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+#endif
+    const int64_t base = (int64_t)tile * TILE;
+    const int valid = (int)((count - base) < TILE ? (count - base) : TILE);
+    K k[ITEMS];
+    P v[HAS_P ? ITEMS : 1];
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      k[i] = e0 + i * 64 < valid ? kn[i] : (K) ~(K)0;
+      if (HAS_P) v[i] = vn[i];
+    }
+    if (tid == 0) after_next = single ? 0xffffffffu : atomicAdd(ticket, 1u);  // needed at the end of this tile
+    if (owner) {
+#pragma unroll
+      for (int i = 0; i < RSP_WAVES; i++) s_whist[i][tid] = 0;
+      s_cnt[tid] = 0;
+    }
+    rs_lds_barrier();
+    RS_STAMP(0, false);
+    RS_PREFETCH(next);
+    RS_STAMP(1, false);
+    rs_word *mine = state + (size_t)tile * 256 + tid;
+    const uint32_t tot_valid = tot_next;  // counted and published one tile ago
+    volatile uint32_t *wh = s_whist[w];
+    // the lanes holding the same digit as this one, for every item first (independent ballots), then the chain of
+    // counter updates (one LDS round trip per item, nothing else left in it)
+    uint64_t same[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const unsigned d = (unsigned)(k[i] >> shift) & mask;
+      uint64_t m = ~(uint64_t)0;
+      for (int b = 0; b < bits; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      same[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const unsigned d = (unsigned)(k[i] >> shift) & mask;
+      const uint32_t prev = wh[d];
+      const uint32_t r = (uint32_t)__popcll(same[i] & lt);
+      __builtin_amdgcn_wave_barrier();
+      if (r == 0) wh[d] = prev + (uint32_t)__popcll(same[i]);
+      __builtin_amdgcn_wave_barrier();
+      rank[i] = prev + r;
+    }
+    rs_lds_barrier();
+    RS_STAMP(2, false);
     // thread `tid` owns digit `tid`
-    uint32_t c[RS_WAVES];
-    uint32_t tot = 0;
+    uint32_t ex0;
+    {
+      uint32_t c[RSP_WAVES];
+      uint32_t tot = 0;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) {
-      c[i] = s_whist[i][tid];
-      tot += c[i];
-    }
-    // keys past `valid` were given the all-ones key: do not count them globally
-    uint32_t tot_valid = tot;
-    if ((unsigned)tid == mask) tot_valid -= (uint32_t)(TILE - valid);
-    uint32_t all;
-    uint32_t ex = sbx_block_exclusive_sum<uint32_t, RS_THREADS>(tot, s_scan, &all);
-    unsigned long long gall;  // first output position of digit `tid` = exclusive scan of the global counts
-    const unsigned long long gbase =
-        sbx_block_exclusive_sum<unsigned long long, RS_THREADS>(ghist[tid], s_scan64, &gall);
-    // ---- decoupled look-back for digit `tid`
-    unsigned long long *mine = state + (size_t)tile * 256 + tid;
-    unsigned long long before = 0;
-    if (tile == 0) {
-      __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(mine, ((unsigned long long)tot_valid << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // windowed look-back: fetch up to RS_LOOKBACK predecessor words at once (independent
-      // loads), consume them nearest-first; a word that is not published yet is re-polled
-      int64_t t = (int64_t)tile - 1;
-      bool done = false;
-      while (!done) {
-        unsigned long long wv[RS_LOOKBACK];
+      for (int i = 0; i < RSP_WAVES; i++) {
+        c[i] = owner ? s_whist[i][tid] : 0u;
+        tot += c[i];
+      }
+      uint32_t ex = rs_block_exclusive_sum(tot, s_scan);
+      ex0 = ex;
+      if (owner) {
 #pragma unroll
-        for (int i = 0; i < RS_LOOKBACK; i++)
-          wv[i] = (t - i >= 0) ? __hip_atomic_load(state + (size_t)(t - i) * 256 + tid, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT)
-                               : 2ull;  // before tile 0: an empty inclusive prefix
-        int consumed = 0;
-        bool stall = false;
-#pragma unroll
-        for (int i = 0; i < RS_LOOKBACK; i++) {
-          const bool active = !done && !stall;
-          const unsigned flag = (unsigned)(wv[i] & 3ull);
-          if (active && flag == 0u) {
-            stall = true;  // not published yet: resume the walk at this tile
-          } else if (active) {
-            before += wv[i] >> 2;
-            consumed++;
-            if (flag == 2u) done = true;
-          }
+        for (int i = 0; i < RSP_WAVES; i++) {
+          s_whist[i][tid] = ex;
+          ex += c[i];
         }
-        t -= consumed;
-        if (stall) __builtin_amdgcn_s_sleep(1);
-      }
-      __hip_atomic_store(mine, ((before + tot_valid) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    s_gofs[tid] = (uint32_t)(gbase + before) - ex;
-#pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) {
-      s_whist[i][tid] = ex;
-      ex += c[i];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const unsigned d = (unsigned)(k[i] >> shift) & mask;
-    const uint32_t pos = s_whist[w][d] + rank[i];
-    s_keys[pos] = k[i];
-    if (HAS_P) s_vals[pos] = v[i];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const int j = i * RS_THREADS + tid;
-    if (j < valid) {
-      const K kk = s_keys[j];
-      const unsigned d = (unsigned)(kk >> shift) & mask;
-      const uint32_t o = s_gofs[d] + (uint32_t)j;
-      if (EMIT) {
-        const uint32_t lo = em.low_mask ? (uint32_t)kk & em.low_mask : (uint32_t)kk;
-        const uint32_t v = em.map ? em.map[lo] : lo;
-        em.out[o] = v;
-        if (em.bits_a) atomicOr(&em.bits_a[v >> 5], 1u << (v & 31));
-        if (em.bits_b) atomicOr(&em.bits_b[v >> 5], 1u << (v & 31));
-        if (em.pos_of) em.pos_of[v] = o;
-      } else {
-        keys_out[o] = kk;
-        if (HAS_P) vals_out[o] = s_vals[j];
       }
     }
+    rs_lds_barrier();
+    RS_STAMP(3, false);
+    // sorted by digit inside the tile (LDS) while the predecessors' counts arrive
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const unsigned d = (unsigned)(k[i] >> shift) & mask;
+      const uint32_t pos = s_whist[w][d] + rank[i];
+      s_keys[pos] = k[i];
+      if (HAS_P) s_vals[pos] = v[i];
+    }
+    if (next < tiles) RS_COUNT_PUBLISH(next, tot_next);  // (the same for the whole workgroup)
+    {
+      // ---- decoupled look-back for digit `tid`
+      uint32_t before = 0;
+      if (tile != 0 && live) {
+        // windowed look-back: fetch up to RS_LOOKBACK predecessor words at once (independent
+        // loads), consume them nearest-first; a word that is not published yet is re-polled
+        int64_t t = (int64_t)tile - 1;
+        bool done = false;
+#ifdef SBX_RADIX_STAMPS
+        unsigned n_rounds = 0, n_stalls = 0, n_words = 0;
+#endif
+        while (!done) {
+          rs_word wv[RS_LOOKBACK];
+#pragma unroll
+          for (int i = 0; i < RS_LOOKBACK; i++)
+            wv[i] = (t - i >= 0) ? __hip_atomic_load(state + (size_t)(t - i) * 256 + tid, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)
+                                 : (rs_word)2;  // before tile 0: an empty inclusive prefix
+          int consumed = 0;
+          bool stall = false;
+#pragma unroll
+          for (int i = 0; i < RS_LOOKBACK; i++) {
+            const bool active = !done && !stall;
+            const unsigned flag = (unsigned)(wv[i] & 3u);
+            if (active && flag == 0u) {
+              stall = true;  // not published yet: resume the walk at this tile
+            } else if (active) {
+              before += (uint32_t)(wv[i] >> 2);
+              consumed++;
+              if (flag == 2u) done = true;
+            }
+          }
+          t -= consumed;
+          if (stall) __builtin_amdgcn_s_sleep(1);
+#ifdef SBX_RADIX_STAMPS
+          n_rounds++; n_stalls += stall; n_words += consumed;
+#endif
+        }
+#ifdef SBX_RADIX_STAMPS
+        if (tid == 0) {
+          atomicAdd(&g_rs_stamps[8], (unsigned long long)n_rounds);
+          atomicAdd(&g_rs_stamps[9], (unsigned long long)n_stalls);
+          atomicAdd(&g_rs_stamps[10], (unsigned long long)n_words);
+        }
+#endif
+        __hip_atomic_store(mine, ((rs_word)(before + tot_valid) << 2) | (rs_word)2, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      RS_STAMP(4, false);
+      if (owner) s_gofs[tid] = gbase + before - ex0;
+    }
+    rs_lds_barrier();
+    RS_STAMP(5, false);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const int j = i * RSP_THREADS + tid;
+      if (j < valid) {
+        const K kk = s_keys[j];
+        const unsigned d = (unsigned)(kk >> shift) & mask;
+        const uint32_t o = s_gofs[d] + (uint32_t)j;
+        if (EMIT) {
+          const uint32_t lo = em.low_mask ? (uint32_t)kk & em.low_mask : (uint32_t)kk;
+          const uint32_t ev = em.map ? em.map[lo] : lo;
+          em.out[o] = ev;
+          if (em.bits_a) atomicOr(&em.bits_a[ev >> 5], 1u << (ev & 31));
+          if (em.bits_b) atomicOr(&em.bits_b[ev >> 5], 1u << (ev & 31));
+          if (em.pos_of) em.pos_of[ev] = o;
+        } else {
+          keys_out[o] = kk;
+          if (HAS_P) vals_out[o] = s_vals[j];
+        }
+      }
+    }
+    RS_STAMP(6, false);
+    RS_STAMP(15, false);
+    if (tid == 0) s_tile[0] = after_next;
+    rs_lds_barrier();  // the LDS of this tile has been read: the next one may clear and fill it
+    tile = next;
+    next = s_tile[0];
   }
+#undef RS_PREFETCH
+#undef RS_COUNT_PUBLISH
 }
 
 static int rs_hist_grid_factor() {  // SBX_RADIX_HIST_GRID: workgroups per CU of the histogram kernel (tuning)
@@ -357,7 +518,7 @@ static int rs_hist_grid_factor() {  // SBX_RADIX_HIST_GRID: workgroups per CU of
 template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT = false>
 static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t count, const sbx_radix_pass *passes,
                            int np, int *result_in_b, const sbx_radix_emit *emit = nullptr) {
-  constexpr int TILE = RS_THREADS * ITEMS;
+  constexpr int TILE = RSP_THREADS * ITEMS;
   *result_in_b = 0;
   if (count <= 1 || np == 0) return SBX_OK;
   if (np > RS_MAX_PASSES) SBX_FAIL(h, SBX_ERR_INTERNAL, "radix sort: %d passes requested", np);
@@ -377,7 +538,7 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   unsigned long long *ghist = (unsigned long long *)slot;
   unsigned *tickets = (unsigned *)((char *)slot + (size_t)RS_MAX_PASSES * 256 * 8);
   const size_t state_words = (size_t)np * tiles * 256;
-  unsigned long long *state = nullptr;
+  rs_word *state = nullptr;
   SBX_TRY(sbx_salloc(h, state_words, &state));
   // few, fat workgroups: every workgroup ends with passes x 256 adds on the same histogram words, and one word takes
   // only ~88 adds per microsecond whoever issues them
@@ -387,16 +548,20 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
   P *src_v = va, *dst_v = vb;
+  // persistent workgroups: as many as are resident at once (the LDS of a tile allows 160 KB / footprint per CU)
+  constexpr size_t lds_bytes = sizeof(K) * TILE + (HAS_P ? sizeof(P) * TILE : 0) + (RSP_WAVES + 2) * 256 * 4 + 64;
+  const int per_cu = (int)((160 * 1024) / lds_bytes) < 8 ? (int)((160 * 1024) / lds_bytes) : 8;
+  const unsigned pass_grid = (unsigned)(tiles < (int64_t)h->num_cus * per_cu ? tiles : (int64_t)h->num_cus * per_cu);
   const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   for (int p = 0; p < np; p++) {
     if (EMIT && p == np - 1)
-      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, EMIT>), dim3((unsigned)tiles),
-                  dim3(RS_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
+      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, EMIT>), dim3(pass_grid),
+                  dim3(RSP_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
                   passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
                   state + (size_t)p * tiles * 256, tickets + p, *emit);
     else
-      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, false>), dim3((unsigned)tiles),
-                  dim3(RS_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
+      SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, false>), dim3(pass_grid),
+                  dim3(RSP_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
                   passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
                   state + (size_t)p * tiles * 256, tickets + p, no_emit);
     // a pass reads and writes every (key, payload) record once
@@ -414,7 +579,7 @@ int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t coun
   if (!emit || !emit->out || num_passes < 1 || count < 2)
     SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_emit: needs an output, a pass and two keys");
   int in_b = 0;
-  return radix_sort_impl<uint64_t, uint32_t, 16, false, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
+  return radix_sort_impl<uint64_t, uint32_t, 8, false, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
                                                               count, passes, num_passes, &in_b, emit);
 }
 
@@ -422,26 +587,26 @@ int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_
                    void *vals_b, int64_t count, const sbx_radix_pass *passes, int num_passes, int *result_in_b) {
   if (key_bytes == 4) {
     if (payload_bytes == 0)
-      return radix_sort_impl<uint32_t, uint32_t, 16, false>(h, (uint32_t *)keys_a, (uint32_t *)keys_b, nullptr, nullptr,
+      return radix_sort_impl<uint32_t, uint32_t, 8, false>(h, (uint32_t *)keys_a, (uint32_t *)keys_b, nullptr, nullptr,
                                                             count, passes, num_passes, result_in_b);
     if (payload_bytes == 4)
-      return radix_sort_impl<uint32_t, uint32_t, 16, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
+      return radix_sort_impl<uint32_t, uint32_t, 8, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
                                                            (uint32_t *)vals_a, (uint32_t *)vals_b, count, passes,
                                                            num_passes, result_in_b);
     if (payload_bytes == 8)
-      return radix_sort_impl<uint32_t, uint64_t, 16, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
+      return radix_sort_impl<uint32_t, uint64_t, 8, true>(h, (uint32_t *)keys_a, (uint32_t *)keys_b,
                                                            (uint64_t *)vals_a, (uint64_t *)vals_b, count, passes,
                                                            num_passes, result_in_b);
   } else if (key_bytes == 8) {
     if (payload_bytes == 0)
-      return radix_sort_impl<uint64_t, uint32_t, 16, false>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
+      return radix_sort_impl<uint64_t, uint32_t, 8, false>(h, (uint64_t *)keys_a, (uint64_t *)keys_b, nullptr, nullptr,
                                                             count, passes, num_passes, result_in_b);
     if (payload_bytes == 4)
-      return radix_sort_impl<uint64_t, uint32_t, 16, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
+      return radix_sort_impl<uint64_t, uint32_t, 8, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
                                                            (uint32_t *)vals_a, (uint32_t *)vals_b, count, passes,
                                                            num_passes, result_in_b);
     if (payload_bytes == 8)
-      return radix_sort_impl<uint64_t, uint64_t, 8, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
+      return radix_sort_impl<uint64_t, uint64_t, 4, true>(h, (uint64_t *)keys_a, (uint64_t *)keys_b,
                                                           (uint64_t *)vals_a, (uint64_t *)vals_b, count, passes,
                                                           num_passes, result_in_b);
   }
