@@ -483,7 +483,8 @@ __global__ __launch_bounds__(CV_THREADS) void k_csc_unpack(const void *__restric
 
 // col_ptr_out[m+1], row_out[nnz], val_out[nnz] from COO arrays (arena already begun, nesting on)
 int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const int32_t *row,
-                    const int32_t *col, const char *val, int32_t *col_ptr_out, int32_t *row_out, char *val_out) {
+                    const int32_t *col, const char *val, int32_t *col_ptr_out, int32_t *row_out, char *val_out,
+                    bool rows_ascend = false) {
   if (nnz == 0) return sbx_fill_i32(h, col_ptr_out, 0, m + 1);
   const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
   const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
@@ -527,7 +528,10 @@ int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int
   // col_ptr = exclusive scan of the column histogram = row-pointer construction over the sorted columns
   SBX_TRY(sbx_coo_to_csr(h, SBX_I32, SBX_V_NONE, m, n, nnz, skey, nullptr, nullptr, col_ptr_out, nullptr, nullptr,
                          SBX_FLAG_MOVE));
-  // the CSC constructor (format/csc.cc:99-157) then sorts every column's (row, value) pairs if any is out of order
+  // the CSC constructor (format/csc.cc:99-157) then sorts every column's (row, value) pairs if any is out of order —
+  // which none is when the entries came in ascending row order (a CSR source): the stable sort kept that order inside
+  // every column, and the check (a read of the rows and a host round trip) would find nothing
+  if (rows_ascend) return SBX_OK;
   return sbx_csr_sort_rows(h, SBX_I32, vb ? vt : SBX_V_NONE, m, n, nnz, col_ptr_out, row_out, vb ? val_out : nullptr);
 }
 
@@ -648,5 +652,5 @@ extern "C" int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type 
                            SBX_FLAG_MOVE));
   }
   return coo_to_csc_core(h, vt, n, m, nnz, rows, (const int32_t *)col, (const char *)val, (int32_t *)col_ptr_out,
-                         (int32_t *)row_out, (char *)val_out);
+                         (int32_t *)row_out, (char *)val_out, /*rows_ascend=*/true);
 }

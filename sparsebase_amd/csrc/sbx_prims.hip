@@ -159,6 +159,9 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAX_PASSES = 8;
 constexpr int RS_LOOKBACK = 8;  // predecessor status words fetched per look-back round
+#ifndef RS_STALL_SLEEP
+#define RS_STALL_SLEEP 1
+#endif
 
 typedef unsigned long long rs_word;  // look-back status word: (count << 2) | flag  (32-bit words, count < 2^30: +2 % only)
 
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__res
             }
           }
           t -= consumed;
-          if (stall) __builtin_amdgcn_s_sleep(1);
+          if (stall) __builtin_amdgcn_s_sleep(RS_STALL_SLEEP);
 #ifdef SBX_RADIX_STAMPS
           n_rounds++; n_stalls += stall; n_words += consumed;
 #endif

@@ -6,6 +6,9 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from sparsebase_amd import capi
+if os.environ.get("SBX_PROBE_LIB"):  # a variant built by tools/build_variant.py
+    capi.LIB_PATH = os.path.join(ROOT, "sparsebase_amd", "lib", f"libsbx_{os.environ['SBX_PROBE_LIB']}.so")
 from sparsebase_amd import ops
 
 dev = torch.device("cuda", 0)
