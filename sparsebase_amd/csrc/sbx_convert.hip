@@ -362,12 +362,20 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
-  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
-  SBX_KLAUNCH(h, SBX_K_MISC, k_pack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), (const int32_t *)row,
-                     (const int32_t *)col, ka, nnz);
   sbx_radix_pass passes[16];
   const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 32,
                                 32 + sbx_bits_for(n > 0 ? (uint64_t)(n - 1) : 0), passes);
+  if (np >= 2) {
+    // the first digit pass reads (row, col, val) where they are — the key is (row << 32) | col — and the last one
+    // writes them back there: no pack kernel before and no unpack kernel behind the sort
+    char *vtmp2 = nullptr;
+    if (vb && np >= 3) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp2));
+    const sbx_radix_side side = {{col, row}, {val, nullptr}, true, false};
+    return sbx_radix_sort_io(h, 8, vb, &side, ka, kb, vtmp, vtmp2, &side, nnz, passes, np);
+  }
+  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
+  SBX_KLAUNCH(h, SBX_K_MISC, k_pack_rc<int32_t>, dim3(grid), dim3(CV_THREADS), (const int32_t *)row,
+                     (const int32_t *)col, ka, nnz);
   int in_b = 0;
   SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, passes, np, &in_b));
   if (in_b && vb) SBX_HIP(h, hipMemcpyAsync(val, vtmp, (size_t)nnz * vb, hipMemcpyDeviceToDevice, h->stream));
@@ -497,7 +505,19 @@ int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
   const uint32_t *skey = nullptr;
   int in_b = 0;
-  if (vb != 8) {
+  if (vb != 8 && np >= 1 && nnz >= 2) {
+    // the first digit pass reads (col; row, val) from the caller's arrays and the last one writes (row_out, val_out)
+    // and the sorted column keys: payload = row | value << 32 in between, no pack / unpack kernels around the sort
+    const int pb = vb == 4 ? 8 : 4;
+    char *pa = nullptr, *pbuf = nullptr;
+    if (np >= 2) SBX_TRY(sbx_salloc(h, (size_t)nnz * pb, &pa));
+    if (np >= 3) SBX_TRY(sbx_salloc(h, (size_t)nnz * pb, &pbuf));
+    uint32_t *kd = ((np - 1) & 1) ? kb : ka;  // the buffer the last pass does not read
+    const sbx_radix_side src = {{(void *)col, nullptr}, {(void *)row, vb == 4 ? (void *)val : nullptr}, false, vb == 4};
+    const sbx_radix_side dst = {{kd, nullptr}, {row_out, vb == 4 ? (void *)val_out : nullptr}, false, vb == 4};
+    SBX_TRY(sbx_radix_sort_io(h, 4, pb, &src, ka, kb, pa, pbuf, &dst, nnz, passes, np));
+    in_b = kd == kb;
+  } else if (vb != 8) {
     const int pb = vb == 4 ? 8 : 4;
     char *pa = nullptr, *pbuf = nullptr;
     SBX_TRY(sbx_salloc(h, (size_t)nnz * pb, &pa));

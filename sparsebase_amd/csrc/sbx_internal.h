@@ -206,6 +206,21 @@ int sbx_radix_sort(sbx_handle_t h, int key_bytes, int payload_bytes, void *keys_
                    void *vals_a, void *vals_b, int64_t count, const sbx_radix_pass *passes,
                    int num_passes, int *result_in_b);
 
+// The same sort reading its records from, and leaving them in, the caller's own arrays: the first pass loads from
+// `src`, the last one stores to `dst` (which may be the arrays of `src`: needs num_passes >= 2), the passes between
+// use (keys_a, vals_a) / (keys_b, vals_b) — no pack kernel before and no unpack kernel behind the sort.  A side is
+//   k_split: a 64-bit key kept as two 32-bit arrays, k[0] = low word, k[1] = high word (else k[0] = the key array)
+//   p_split: a 64-bit payload kept as two 32-bit arrays, p[0] = low, p[1] = high    (else p[0] = the payload array)
+// Supported: k_split with 8-byte keys (payload 0 / 4 / 8 bytes, not split), p_split with 4-byte keys and 8-byte payloads.
+struct sbx_radix_side {
+  void *k[2];
+  void *p[2];
+  bool k_split, p_split;
+};
+int sbx_radix_sort_io(sbx_handle_t h, int key_bytes, int payload_bytes, const sbx_radix_side *src, void *keys_a,
+                      void *keys_b, void *vals_a, void *vals_b, const sbx_radix_side *dst, int64_t count,
+                      const sbx_radix_pass *passes, int num_passes);
+
 // Same sort of 64-bit keys without payload (count >= 2, num_passes >= 1) whose final pass, instead of storing the
 // sorted keys, emits per key at sorted position p: value = map ? map[low32(key)] : low32(key); out[p] = value;
 // bit `value` set in bits_a / bits_b (each optional); pos_of[value] = p (optional).

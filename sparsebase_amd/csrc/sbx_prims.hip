@@ -156,7 +156,6 @@ int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes) {
 }
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAX_PASSES = 8;
 constexpr int RS_LOOKBACK = 8;  // predecessor status words fetched per look-back round
 #ifndef RS_STALL_SLEEP
@@ -172,11 +171,17 @@ struct RadixPlan {
 };
 
 // Upfront digit histograms of every pass in one read of the keys.
-template <typename K>
+// KS: the 64-bit keys are two 32-bit arrays (keys = low words, keys_hi = high words).
+template <typename K, bool KS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
                                                               unsigned long long *__restrict__ ghist,
                                                               rs_word *__restrict__ state,
-                                                              size_t state_words) {
+                                                              size_t state_words,
+                                                              const uint32_t *__restrict__ keys_hi = nullptr) {
+  auto key_at = [&](int64_t j) -> K {
+    if constexpr (KS) return (K)(((uint64_t)keys_hi[j] << 32) | ((const uint32_t *)keys)[j]);
+    else return keys[j];
+  };
   __shared__ unsigned lh[RS_MAX_PASSES][256];
   // the look-back status words of all passes are only touched by the pass kernels: clear them here
   for (size_t j = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; j < state_words; j += (size_t)gridDim.x * RS_THREADS)
@@ -191,14 +196,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
   for (; i + (HU - 1) * stride < count; i += HU * stride) {
     K k[HU];
 #pragma unroll
-    for (int u = 0; u < HU; u++) k[u] = keys[i + u * stride];
+    for (int u = 0; u < HU; u++) k[u] = key_at(i + u * stride);
 #pragma unroll
     for (int u = 0; u < HU; u++)
       for (int p = 0; p < plan.n; p++)
         atomicAdd(&lh[p][(unsigned)(k[u] >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
   }
   for (; i < count; i += stride) {
-    const K k = keys[i];
+    const K k = key_at(i);
     for (int p = 0; p < plan.n; p++)
       atomicAdd(&lh[p][(unsigned)(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
   }
@@ -271,13 +276,20 @@ __device__ __forceinline__ uint32_t rs_block_exclusive_sum(uint32_t v, uint32_t 
 // NEXT tile in registers (loads issued before the current tile is touched) — with one tile per workgroup the phases
 // of a tile (load, rank, look-back, store) run one after the other and a CU keeps ~17 KB of loads in flight, a quarter
 // of what the HBM latency asks for (measured with tools/radix_stamps.py: 2.1 TB/s per pass whatever the size).
-template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT>
+//
+// IOM (sbx_radix_sort_io): bit 0 / 1 — the pass LOADS 64-bit keys / payloads from two 32-bit arrays (keys_in = low words,
+// io.k_hi_in = high words; vals_in = low, io.p_hi_in = high); bit 2 / 3 — it STORES them that way.
+struct RsSplit {
+  const uint32_t *k_hi_in, *p_hi_in;
+  uint32_t *k_hi_out, *p_hi_out;
+};
+template <typename K, typename P, int ITEMS, bool HAS_P, bool EMIT, int IOM = 0>
 __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const P *__restrict__ vals_in, P *__restrict__ vals_out,
                                                               int64_t count, int shift, int bits,
                                                               const unsigned long long *__restrict__ ghist,
                                                               rs_word *state, unsigned *ticket,
-                                                              sbx_radix_emit em) {
+                                                              sbx_radix_emit em, RsSplit io) {
   constexpr int TILE = RSP_THREADS * ITEMS;
   __shared__ K s_keys[TILE];
   __shared__ P s_vals[HAS_P ? TILE : 1];
@@ -320,8 +332,12 @@ __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__res
     const int64_t last_ = count - 1, b_ = (int64_t)(t_) * TILE + e0;                   \
     _Pragma("unroll") for (int i = 0; i < ITEMS; i++) {                                \
       const int64_t a_ = b_ + i * 64 < last_ ? b_ + i * 64 : last_;                    \
-      kn[i] = keys_in[a_];                                                             \
-      if (HAS_P) vn[i] = vals_in[a_];                                                  \
+      if constexpr ((IOM & 1) != 0)                                                    \
+        kn[i] = (K)(((uint64_t)io.k_hi_in[a_] << 32) | ((const uint32_t *)keys_in)[a_]); \
+      else kn[i] = keys_in[a_];                                                        \
+      if constexpr (HAS_P && (IOM & 2) != 0)                                           \
+        vn[i] = (P)(((uint64_t)io.p_hi_in[a_] << 32) | ((const uint32_t *)vals_in)[a_]); \
+      else if (HAS_P) vn[i] = vals_in[a_];                                             \
     }                                                                                  \
   } while (0)
   RS_PREFETCH(tile);
@@ -497,8 +513,19 @@ __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__res
           if (em.bits_b) atomicOr(&em.bits_b[ev >> 5], 1u << (ev & 31));
           if (em.pos_of) em.pos_of[ev] = o;
         } else {
-          keys_out[o] = kk;
-          if (HAS_P) vals_out[o] = s_vals[j];
+          if constexpr ((IOM & 4) != 0) {
+            ((uint32_t *)keys_out)[o] = (uint32_t)kk;
+            io.k_hi_out[o] = (uint32_t)((uint64_t)kk >> 32);
+          } else {
+            keys_out[o] = kk;
+          }
+          if constexpr (HAS_P && (IOM & 8) != 0) {
+            const P pv = s_vals[j];
+            ((uint32_t *)vals_out)[o] = (uint32_t)pv;
+            io.p_hi_out[o] = (uint32_t)((uint64_t)pv >> 32);
+          } else if (HAS_P) {
+            vals_out[o] = s_vals[j];
+          }
         }
       }
     }
@@ -553,7 +580,8 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   P *src_v = va, *dst_v = vb;
   // persistent workgroups: as many as are resident at once (the LDS of a tile allows 160 KB / footprint per CU)
   constexpr size_t lds_bytes = sizeof(K) * TILE + (HAS_P ? sizeof(P) * TILE : 0) + (RSP_WAVES + 2) * 256 * 4 + 64;
-  const int per_cu = (int)((160 * 1024) / lds_bytes) < 8 ? (int)((160 * 1024) / lds_bytes) : 8;
+  // (two at most: 8 waves of up to 128 VGPRs each)
+  const int per_cu = (int)((160 * 1024) / lds_bytes) < 2 ? (int)((160 * 1024) / lds_bytes) : 2;
   const unsigned pass_grid = (unsigned)(tiles < (int64_t)h->num_cus * per_cu ? tiles : (int64_t)h->num_cus * per_cu);
   const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   for (int p = 0; p < np; p++) {
@@ -561,12 +589,12 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
       SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, EMIT>), dim3(pass_grid),
                   dim3(RSP_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
                   passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
-                  state + (size_t)p * tiles * 256, tickets + p, *emit);
+                  state + (size_t)p * tiles * 256, tickets + p, *emit, RsSplit{});
     else
       SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, false>), dim3(pass_grid),
                   dim3(RSP_THREADS), (const K *)src_k, dst_k, (const P *)src_v, dst_v, count, passes[p].shift,
                   passes[p].bits, (const unsigned long long *)(ghist + (size_t)p * 256),
-                  state + (size_t)p * tiles * 256, tickets + p, no_emit);
+                  state + (size_t)p * tiles * 256, tickets + p, no_emit, RsSplit{});
     // a pass reads and writes every (key, payload) record once
     SBX_PROF_BYTES(h, SBX_K_RADIX_SCATTER, 2 * count * (int64_t)(sizeof(K) + (HAS_P ? sizeof(P) : 0)));
     SBX_LAUNCH_CHECK(h);
@@ -575,6 +603,92 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
     *result_in_b ^= 1;
   }
   return SBX_OK;
+}
+
+// sbx_radix_sort_io: KSPLIT — 64-bit keys split on the caller's sides; PSPLIT — 64-bit payloads split there
+template <typename K, typename P, int ITEMS, bool HAS_P, bool KSPLIT, bool PSPLIT>
+static int radix_sort_io_impl(sbx_handle_t h, const sbx_radix_side *src, K *ka, K *kb, P *va, P *vb,
+                              const sbx_radix_side *dst, int64_t count, const sbx_radix_pass *passes, int np) {
+  constexpr int TILE = RSP_THREADS * ITEMS;
+  constexpr int IN = (KSPLIT ? 1 : 0) | (PSPLIT ? 2 : 0), OUT = (KSPLIT ? 4 : 0) | (PSPLIT ? 8 : 0);
+  if (np > RS_MAX_PASSES) SBX_FAIL(h, SBX_ERR_INTERNAL, "radix sort: %d passes requested", np);
+  if (count >= ((int64_t)1 << 32)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "radix sort: count %lld >= 2^32", (long long)count);
+  const int64_t tiles = (count + TILE - 1) / TILE;
+  RadixPlan plan;
+  plan.n = np;
+  for (int p = 0; p < np; p++) {
+    plan.shift[p] = passes[p].shift;
+    plan.bits[p] = passes[p].bits;
+  }
+  void *slot = nullptr;
+  SBX_TRY(sbx_radix_slot(h, &slot));
+  unsigned long long *ghist = (unsigned long long *)slot;
+  unsigned *tickets = (unsigned *)((char *)slot + (size_t)RS_MAX_PASSES * 256 * 8);
+  const size_t state_words = (size_t)np * tiles * 256;
+  rs_word *state = nullptr;
+  SBX_TRY(sbx_salloc(h, state_words, &state));
+  SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K, KSPLIT>),
+              dim3(sbx_grid_for(count, RS_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RS_THREADS),
+              (const K *)src->k[0], count, plan, ghist, state, state_words, (const uint32_t *)src->k[1]);
+  SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));
+  constexpr size_t lds_bytes = sizeof(K) * TILE + (HAS_P ? sizeof(P) * TILE : 0) + (RSP_WAVES + 2) * 256 * 4 + 64;
+  const int per_cu = (int)((160 * 1024) / lds_bytes) < 2 ? (int)((160 * 1024) / lds_bytes) : 2;
+  const unsigned pass_grid = (unsigned)(tiles < (int64_t)h->num_cus * per_cu ? tiles : (int64_t)h->num_cus * per_cu);
+  const sbx_radix_emit no_emit = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+  K *bk[2] = {ka, kb};
+  P *bv[2] = {va, vb};
+  for (int p = 0; p < np; p++) {
+    const bool first = p == 0, last = p == np - 1;
+    const K *ik = first ? (const K *)src->k[0] : bk[(p - 1) & 1];
+    const P *iv = first ? (const P *)src->p[0] : bv[(p - 1) & 1];
+    K *ok = last ? (K *)dst->k[0] : bk[p & 1];
+    P *ov = last ? (P *)dst->p[0] : bv[p & 1];
+    const RsSplit io = {first ? (const uint32_t *)src->k[1] : nullptr, first ? (const uint32_t *)src->p[1] : nullptr,
+                        last ? (uint32_t *)dst->k[1] : nullptr, last ? (uint32_t *)dst->p[1] : nullptr};
+#define RS_IO_LAUNCH(M)                                                                                            \
+  SBX_KLAUNCH(h, SBX_K_RADIX_SCATTER, (k_onesweep_pass<K, P, ITEMS, HAS_P, false, M>), dim3(pass_grid),            \
+              dim3(RSP_THREADS), ik, ok, iv, ov, count, passes[p].shift, passes[p].bits,                           \
+              (const unsigned long long *)(ghist + (size_t)p * 256), state + (size_t)p * tiles * 256, tickets + p, \
+              no_emit, io)
+    if (first && last) RS_IO_LAUNCH(IN | OUT);
+    else if (first) RS_IO_LAUNCH(IN);
+    else if (last) RS_IO_LAUNCH(OUT);
+    else RS_IO_LAUNCH(0);
+#undef RS_IO_LAUNCH
+    SBX_PROF_BYTES(h, SBX_K_RADIX_SCATTER, 2 * count * (int64_t)(sizeof(K) + (HAS_P ? sizeof(P) : 0)));
+    SBX_LAUNCH_CHECK(h);
+  }
+  return SBX_OK;
+}
+
+int sbx_radix_sort_io(sbx_handle_t h, int key_bytes, int payload_bytes, const sbx_radix_side *src, void *keys_a,
+                      void *keys_b, void *vals_a, void *vals_b, const sbx_radix_side *dst, int64_t count,
+                      const sbx_radix_pass *passes, int num_passes) {
+  if (!src || !dst || num_passes < 1 || count < 2 || src->k_split != dst->k_split || src->p_split != dst->p_split)
+    SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_io: bad sides");
+  if (key_bytes == 8 && src->k_split && !src->p_split) {
+    if (payload_bytes == 0)
+      return radix_sort_io_impl<uint64_t, uint32_t, 8, false, true, false>(h, src, (uint64_t *)keys_a, (uint64_t *)keys_b,
+                                                                          nullptr, nullptr, dst, count, passes, num_passes);
+    if (payload_bytes == 4)
+      return radix_sort_io_impl<uint64_t, uint32_t, 8, true, true, false>(h, src, (uint64_t *)keys_a, (uint64_t *)keys_b,
+                                                                         (uint32_t *)vals_a, (uint32_t *)vals_b, dst, count,
+                                                                         passes, num_passes);
+    if (payload_bytes == 8)
+      return radix_sort_io_impl<uint64_t, uint64_t, 4, true, true, false>(h, src, (uint64_t *)keys_a, (uint64_t *)keys_b,
+                                                                         (uint64_t *)vals_a, (uint64_t *)vals_b, dst, count,
+                                                                         passes, num_passes);
+  } else if (key_bytes == 4 && !src->k_split && payload_bytes == 8 && src->p_split) {
+    return radix_sort_io_impl<uint32_t, uint64_t, 8, true, false, true>(h, src, (uint32_t *)keys_a, (uint32_t *)keys_b,
+                                                                       (uint64_t *)vals_a, (uint64_t *)vals_b, dst, count,
+                                                                       passes, num_passes);
+  } else if (key_bytes == 4 && !src->k_split && payload_bytes == 4 && !src->p_split) {
+    return radix_sort_io_impl<uint32_t, uint32_t, 8, true, false, false>(h, src, (uint32_t *)keys_a, (uint32_t *)keys_b,
+                                                                        (uint32_t *)vals_a, (uint32_t *)vals_b, dst, count,
+                                                                        passes, num_passes);
+  }
+  SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_radix_sort_io: key_bytes=%d payload_bytes=%d split=%d/%d", key_bytes,
+           payload_bytes, (int)src->k_split, (int)src->p_split);
 }
 
 int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
