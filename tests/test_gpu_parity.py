@@ -371,6 +371,26 @@ def test_convert_vs_oracle(ops, oracle, seed):
         same((r_d, c_d, v_d), oracle.coo_sort(rr, cc, vv))
 
 
+@pytest.mark.parametrize("n,m", [(1, 7), (7, 1), (3, 200), (300, 70000), (70000, 300), (70000, 70000), (2, 2)])
+def test_sorts_that_read_and_write_the_callers_arrays(ops, oracle, n, m):
+    # COO constructor sort and COO / CSR -> CSC let the first digit pass of their radix sort load the source arrays and
+    # the last one store the destination arrays (sbx_radix_sort_io); the dimensions choose 1 ... 6 digit passes, the
+    # one-pass cases keep the pack / unpack form
+    g = np.random.default_rng(n * 131 + m)
+    key = np.unique(g.integers(0, n * m, min(n * m, 150000)))
+    key = key[g.permutation(len(key))]
+    row, col = (key // m).astype(np.int32), (key % m).astype(np.int32)
+    nnz = len(key)
+    for val in (None, g.integers(-99, 99, nnz).astype(np.int32), g.random(nnz).astype(np.float32), g.random(nnz)):
+        r_d, c_d, v_d = dev(row.copy()), dev(col.copy()), dev(None if val is None else val.copy())
+        ops.coo_sort_(n, m, r_d, c_d, v_d)
+        want = oracle.coo_sort(row, col, val)
+        same((r_d, c_d, v_d), want)
+        same(ops.coo_to_csc(n, m, dev(row), dev(col), dev(val)), oracle.coo_to_csc(n, m, row, col, val))
+        rp, cc, vv = oracle.coo_to_csr(n, *want)
+        same(ops.csr_to_csc(n, m, dev(rp), dev(cc), dev(vv)), oracle.csr_to_csc(m, rp, cc, vv))
+
+
 def test_coo_to_csr_unsorted_rows(ops, oracle):
     # ignore_sort=true input: row_ptr is still exclusive_scan(histogram(row))
     g = np.random.default_rng(5)
