@@ -7,8 +7,8 @@
 //   feature/profile.cc:91-105               sbx_csr_profile
 //
 // All four are single-pass reductions.  Bandwidth and profile are nonzero-parallel so
-// power-law rows stay balanced: the row of every nonzero comes from the CSR->COO
-// expansion kernel (row ids into scratch), never from a per-row loop.
+// power-law rows stay balanced: the row of every nonzero is derived per tile from row_ptr
+// (tile_rows), never from a per-row loop.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -38,24 +38,167 @@ struct FeatureAcc {
   unsigned long long profile;   // sum over rows of (row - min(row, smallest column))
 };
 
-__global__ __launch_bounds__(FT_THREADS) void k_bandwidth(const int32_t *__restrict__ row,
-                                                          const int32_t *__restrict__ col, int64_t nnz,
-                                                          unsigned *__restrict__ partial) {
+// ---- one pass over the CSR itself, nonzero-parallel -------------------------------------------------------------
+// A workgroup takes FT_TILE consecutive nonzeros: the rows the tile touches come from two wave-wide binary searches
+// in row_ptr, their first positions are marked in LDS (an empty row shares its position with the next non-empty one,
+// which wins the atomicMax) and a max-scan gives every nonzero its row — the CSR -> COO expansion without the 4 bytes
+// per nonzero written and read again.
+constexpr int FT_TILE = FT_THREADS * FT_ITEMS;
+constexpr int FT_SLOTS = 1024;  // result words of the tile kernels (zeroed by the caller, reduced by k_feature_finish)
+
+struct TileRows {
+  int64_t r_lo;         // row of the tile's first nonzero
+  int h[FT_ITEMS];      // row - r_lo of this thread's FT_ITEMS consecutive nonzeros
+  bool head[FT_ITEMS];  // the nonzero is the first one of its row
+};
+
+// first and last row of every tile, one thread per tile: the two searches in row_ptr are four dependent rounds of
+// loads when a workgroup does them for itself, and 25 waves of workgroups per CU then spend half their lives in them
+__global__ __launch_bounds__(FT_THREADS) void k_tile_spans(const int32_t *__restrict__ rp, int64_t n, int64_t nnz,
+                                                           int64_t tiles, int2 *__restrict__ span) {
+  const int64_t t = (int64_t)blockIdx.x * FT_THREADS + threadIdx.x;
+  if (t >= tiles) return;
+  const int64_t t0 = t * FT_TILE, t1 = (t0 + FT_TILE < nnz) ? t0 + FT_TILE : nnz;
+  auto last_le = [&](int64_t v) {  // last row r with rp[r] <= v
+    int64_t lo = 0, hi = n + 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)rp[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    return lo - 1;
+  };
+  span[t] = make_int2((int)last_le(t0), (int)last_le(t1 - 1));
+}
+
+__device__ __forceinline__ TileRows tile_rows(const int32_t *__restrict__ rp, const int2 *__restrict__ span, int64_t tile,
+                                              int64_t t0, int *s_head, int *s_wmax) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < FT_ITEMS; k++) s_head[k * FT_THREADS + tid] = 0;
+  const int2 sp = span[tile];
+  __syncthreads();
+  TileRows t;
+  t.r_lo = sp.x;
+  const int64_t r_hi = sp.y;
+  for (int64_t r = t.r_lo + 1 + tid; r <= r_hi; r += FT_THREADS) atomicMax(&s_head[(int)((int64_t)rp[r] - t0)], (int)(r - t.r_lo));
+  __syncthreads();
+  const bool first_is_head = (int64_t)rp[t.r_lo] == t0;
+  int run = 0;
+#pragma unroll
+  for (int k = 0; k < FT_ITEMS; k++) {
+    const int v = s_head[tid * FT_ITEMS + k];
+    t.head[k] = v != 0 || (first_is_head && tid == 0 && k == 0);
+    run = v > run ? v : run;
+    t.h[k] = run;
+  }
+  const int inc = sbx_wave_inclusive_max(run);
+  const int excl = sbx_wave_shift_up1(inc, 0);
+  if (sbx_lane() == 63) s_wmax[tid >> 6] = inc;
+  __syncthreads();
+  int before = excl;
+  for (int w = 0; w < (tid >> 6); w++) before = s_wmax[w] > before ? s_wmax[w] : before;
+#pragma unroll
+  for (int k = 0; k < FT_ITEMS; k++) t.h[k] = t.h[k] > before ? t.h[k] : before;
+  return t;
+}
+
+// this thread's FT_ITEMS consecutive columns: two 16-byte loads where the array allows it (eight 4-byte loads at a
+// stride of 32 bytes across the lanes make eight times the requests)
+__device__ __forceinline__ void load_items(const int32_t *__restrict__ col, int64_t base, int64_t t1, bool vec_ok,
+                                           int32_t *c) {
+  static_assert(FT_ITEMS == 8, "two 16-byte loads per thread");
+  if (vec_ok && base + FT_ITEMS <= t1) {
+    const int4 a = *(const int4 *)(col + base), b = *(const int4 *)(col + base + 4);
+    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+    c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < FT_ITEMS; k++) c[k] = col[base + k < t1 ? base + k : t1 - 1];
+  }
+}
+
+// bandwidth.cc:100-107: max |row - col| over the nonzeros
+__global__ __launch_bounds__(FT_THREADS) void k_bandwidth_csr(const int32_t *__restrict__ rp,
+                                                              const int32_t *__restrict__ col, int64_t n, int64_t nnz,
+                                                              unsigned *__restrict__ partial, bool vec_ok,
+                                                              const int2 *__restrict__ span) {
+  __shared__ int s_head[FT_TILE];
+  __shared__ int s_wmax[FT_THREADS / 64];
   __shared__ unsigned s_mx[FT_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t tiles = (nnz + FT_TILE - 1) / FT_TILE;
   unsigned mx = 0;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < nnz; i += stride) {
-    const int d = row[i] - col[i];
-    const unsigned a = (unsigned)(d < 0 ? -d : d);
-    mx = a > mx ? a : mx;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {  // (one tile per workgroup as launched)
+    const int64_t t0 = tile * FT_TILE;
+    const int64_t t1 = (t0 + FT_TILE < nnz) ? t0 + FT_TILE : nnz;
+    const int64_t base = t0 + (int64_t)tid * FT_ITEMS;
+    int32_t c[FT_ITEMS];  // in flight during the row search
+    load_items(col, base, t1, vec_ok, c);
+    const TileRows t = tile_rows(rp, span, tile, t0, s_head, s_wmax);
+#pragma unroll
+    for (int k = 0; k < FT_ITEMS; k++) {
+      if (base + k < t1) {
+        const int64_t d = t.r_lo + t.h[k] - (int64_t)c[k];
+        const unsigned a = (unsigned)(d < 0 ? -d : d);
+        mx = a > mx ? a : mx;
+      }
+    }
+    __syncthreads();  // the LDS of tile_rows is reused
   }
   mx = sbx_wave_max(mx);
   if (sbx_lane() == 0) s_mx[sbx_wave_in_block()] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     for (int w = 1; w < FT_THREADS / 64; w++) mx = s_mx[w] > mx ? s_mx[w] : mx;
-    partial[blockIdx.x] = mx;  // one word per workgroup, reduced by k_feature_finish (no hot atomic)
+    // FT_SLOTS result words shared by all workgroups: a word per workgroup leaves the single finishing workgroup with
+    // 51 K loads on the bench matrix (0.14 ms), one word for all would take 88 atomics per microsecond
+    if (mx) atomicMax(&partial[blockIdx.x & (FT_SLOTS - 1)], mx);
+  }
+}
+
+// profile.cc:95-104 for column-sorted rows, and the check that they are (format/csr.cc:102-116) in the same read of
+// the columns: the smallest column of a row is its first one; `*unsorted` is raised if some row is out of order and
+// the caller then takes the general path.
+__global__ __launch_bounds__(FT_THREADS) void k_profile_csr(const int32_t *__restrict__ rp,
+                                                            const int32_t *__restrict__ col, int64_t n, int64_t nnz,
+                                                            unsigned long long *__restrict__ partial,
+                                                            int *__restrict__ unsorted, bool vec_ok,
+                                                            const int2 *__restrict__ span) {
+  __shared__ int s_head[FT_TILE];
+  __shared__ int s_wmax[FT_THREADS / 64];
+  __shared__ unsigned long long s_sum[FT_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t tiles = (nnz + FT_TILE - 1) / FT_TILE;
+  unsigned long long sum = 0;
+  bool bad = false;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t t0 = tile * FT_TILE;
+    const int64_t t1 = (t0 + FT_TILE < nnz) ? t0 + FT_TILE : nnz;
+    const int64_t base = t0 + (int64_t)tid * FT_ITEMS;
+    int32_t c[FT_ITEMS + 1];  // c[0]: the nonzero before this thread's first one
+    c[0] = base > 0 ? col[base - 1 < t1 ? base - 1 : t1 - 1] : 0;
+    load_items(col, base, t1, vec_ok, c + 1);
+    const TileRows t = tile_rows(rp, span, tile, t0, s_head, s_wmax);
+#pragma unroll
+    for (int k = 0; k < FT_ITEMS; k++) {
+      if (base + k < t1) {
+        if (t.head[k]) {
+          const int64_t row = t.r_lo + t.h[k];
+          if ((int64_t)c[k + 1] < row) sum += (unsigned long long)(row - (int64_t)c[k + 1]);
+        } else {
+          bad |= c[k + 1] < c[k];
+        }
+      }
+    }
+    __syncthreads();  // the LDS of tile_rows is reused
+  }
+  if (__any(bad) && sbx_lane() == 0) *unsorted = 1;
+  sum = sbx_wave_sum(sum);
+  if (sbx_lane() == 0) s_sum[sbx_wave_in_block()] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < FT_THREADS / 64; w++) sum += s_sum[w];
+    if (sum) atomicAdd(&partial[blockIdx.x & (FT_SLOTS - 1)], sum);
   }
 }
 
@@ -95,30 +238,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_profile(const int32_t *__restric
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) sum += (unsigned long long)(i - (int64_t)rowmin[i]);  // rowmin <= i by construction
-  sum = sbx_wave_sum(sum);
-  if (sbx_lane() == 0) s_sum[sbx_wave_in_block()] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < FT_THREADS / 64; w++) sum += s_sum[w];
-    partial[blockIdx.x] = sum;
-  }
-}
-
-// column-sorted rows (every CSR that went through a constructor): the smallest column is the first one
-__global__ __launch_bounds__(FT_THREADS) void k_profile_sorted(const int32_t *__restrict__ rp,
-                                                               const int32_t *__restrict__ col, int64_t n,
-                                                               unsigned long long *__restrict__ partial) {
-  __shared__ unsigned long long s_sum[FT_THREADS / 64];
-  unsigned long long sum = 0;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const int32_t s0 = rp[i];
-    if (rp[i + 1] > s0) {
-      const int64_t c = col[s0];
-      if (c < i) sum += (unsigned long long)(i - c);
-    }
-  }
   sum = sbx_wave_sum(sum);
   if (sbx_lane() == 0) s_sum[sbx_wave_in_block()] = sum;
   __syncthreads();
@@ -216,16 +335,19 @@ extern "C" int sbx_csr_bandwidth(sbx_handle_t h, sbx_index_type it, int64_t n, i
   if (it == SBX_I64) return sbx_i64_csr_bandwidth(h, n, nnz, row_ptr, col, bandwidth_host);
   SBX_TRY(sbx_arena_begin(h));
   if (nnz == 0) return SBX_OK;  // bandwidth.cc:100: stays 0 without nonzeros
-  NestGuard guard(h);
-  int32_t *rows = nullptr;
-  SBX_TRY(expand_rows(h, n, nnz, (const int32_t *)row_ptr, &rows));
-  const unsigned grid = sbx_grid_for(nnz, FT_THREADS * 8, (int64_t)h->num_cus * 8);
+  const unsigned tiles = (unsigned)((nnz + FT_TILE - 1) / FT_TILE);
+  const unsigned grid = FT_SLOTS;  // result words for k_feature_finish
   unsigned *partial = nullptr;
   FeatureAcc *acc = nullptr;
   SBX_TRY(sbx_salloc(h, grid, &partial));
   SBX_TRY(sbx_salloc(h, 1, &acc));
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_bandwidth, dim3(grid), dim3(FT_THREADS), (const int32_t *)rows, (const int32_t *)col,
-              nnz, partial);
+  SBX_HIP(h, hipMemsetAsync(partial, 0, grid * sizeof(unsigned), h->stream));
+  int2 *span = nullptr;
+  SBX_TRY(sbx_salloc(h, tiles, &span));
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans, dim3((tiles + FT_THREADS - 1) / FT_THREADS), dim3(FT_THREADS),
+              (const int32_t *)row_ptr, n, nnz, (int64_t)tiles, span);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_bandwidth_csr, dim3(tiles), dim3(FT_THREADS), (const int32_t *)row_ptr,
+              (const int32_t *)col, n, nnz, partial, ((uintptr_t)col & 15) == 0, (const int2 *)span);
   SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)partial,
               (const unsigned long long *)nullptr, (int)grid, acc);
   SBX_LAUNCH_CHECK(h);
@@ -251,19 +373,31 @@ extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int
   FeatureAcc *acc = nullptr;
   SBX_TRY(sbx_salloc(h, grid_n, &partial));
   SBX_TRY(sbx_salloc(h, 1, &acc));
-  int sorted = 0;  // one streaming pass over col; unsorted rows only exist for ignore_sort CSRs
-  SBX_TRY(sbx_csr_rows_sorted(h, SBX_I32, n, row_ptr, col, &sorted));
-  if (sorted) {
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile_sorted, dim3(grid_n), dim3(FT_THREADS), (const int32_t *)row_ptr,
-                (const int32_t *)col, n, partial);
+  {
+    // column-sorted rows (every CSR that went through a constructor): checked and summed in ONE read of the columns;
+    // unsorted rows only exist for ignore_sort CSRs and take the general path below
+    struct { FeatureAcc a; int unsorted; int pad; } hs;
+    const unsigned tiles = (unsigned)((nnz + FT_TILE - 1) / FT_TILE);
+    const unsigned grid = FT_SLOTS;
+    unsigned long long *psum = nullptr, *res = nullptr;
+    SBX_TRY(sbx_salloc(h, grid + 3, &psum));
+    res = psum + grid;
+    SBX_HIP(h, hipMemsetAsync(psum, 0, (grid + 3) * sizeof(unsigned long long), h->stream));
+    int2 *span = nullptr;
+    SBX_TRY(sbx_salloc(h, tiles, &span));
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans, dim3((tiles + FT_THREADS - 1) / FT_THREADS), dim3(FT_THREADS),
+                (const int32_t *)row_ptr, n, nnz, (int64_t)tiles, span);
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile_csr, dim3(tiles), dim3(FT_THREADS), (const int32_t *)row_ptr,
+                (const int32_t *)col, n, nnz, psum, (int *)(res + 2), ((uintptr_t)col & 15) == 0, (const int2 *)span);
     SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
-                (const unsigned long long *)partial, (int)grid_n, acc);
+                (const unsigned long long *)psum, (int)grid, (FeatureAcc *)res);
     SBX_LAUNCH_CHECK(h);
     SBX_PROF_BYTES(h, SBX_K_FEATURE, 4 * nnz + 4 * (n + 1));
-    FeatureAcc hs;
-    SBX_TRY(sbx_readback(h, &hs, acc, sizeof(FeatureAcc)));
-    *profile_host = (int64_t)hs.profile;
-    return SBX_OK;
+    SBX_TRY(sbx_readback(h, &hs, res, sizeof(hs)));
+    if (!hs.unsorted) {
+      *profile_host = (int64_t)hs.a.profile;
+      return SBX_OK;
+    }
   }
   int32_t *rows = nullptr, *rowmin = nullptr;
   SBX_TRY(expand_rows(h, n, nnz, (const int32_t *)row_ptr, &rows));
