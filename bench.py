@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the CPU-baseline sample (default: the bench matrix itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--leg-timeout", type=float, default=300.0,
+                    help="multi-rank runs: seconds the sharded legs may take before the headline is printed without them")
     return ap.parse_args()
 
 
@@ -163,16 +165,65 @@ def main():
         # whole operations (SURVEY §8d figures), timed un-instrumented below
         roofline["op"] = op_fractions(ops, n, nnz, rp, col, val, order, out, stats, args.steps)
 
+    extra = {"permute_apply": None, "convert_apply": None, "cpu_baseline": None}
+
+    def emit():
+        if rank != 0:
+            return
+        line = {
+            "metric": "Mrows/s, RCM reorder + CSR permute, 100M-nnz power-law (RMAT) CSR",
+            "value": value, "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"RCMReorder + Permute2D(order,order) on symmetric RMAT scale {args.scale} "
+                                   f"(a,b,c=.57,.19,.19, edge factor {args.edge_factor}) CSR <int32,int32,float32>, "
+                                   "one instance per GPU",
+                       "rows": n, "nnz": nnz, "rcm": stats},
+            "roofline": roofline, "cpu_baseline": extra["cpu_baseline"], "permute_apply": extra["permute_apply"],
+            "convert_apply": extra["convert_apply"],
+        }
+        cb = extra["cpu_baseline"]
+        if cb and "parity_on_bench_matrix" in cb:
+            line["parity_on_bench_matrix"] = cb["parity_on_bench_matrix"]
+        print(json.dumps(line), flush=True)
+
+    # The two legs below are extras next to the headline (measured above) and, with several ranks, the only part of
+    # this program that depends on a collective: a leg that raises is reported as {"error": ...}, and one that hangs
+    # (a rank lost inside RCCL) ends the program from a watchdog thread after the headline line has been printed —
+    # the main thread may be inside a C call that no Python signal handler interrupts.
+    watchdog = None
+    if world > 1 and not args.no_sharded:
+        import threading
+
+        def give_up():
+            for k in ("permute_apply", "convert_apply"):
+                if extra[k] is None:
+                    extra[k] = {"error": f"no result after {args.leg_timeout} s (watchdog)"}
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
+    def guarded(name, leg):
+        try:
+            extra[name] = leg()
+        except Exception as e:  # noqa: BLE001
+            extra[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            print(f"[bench] rank {rank}: {name} failed: {extra[name]['error']}", file=sys.stderr, flush=True)
+
     # ---- the step that shards: row-range permutation apply + RCCL all-gather of row_ptr
-    permute_apply = None
-    comm = None
-    if not args.no_sharded:
+    comms = []
+
+    def leg_permute():
         from sparsebase_amd import sharded
         perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7)).to(torch.int32)
         if world > 1:
             dist.broadcast(perm, 0)
-            # every rank permutes rank 0's matrix layout-wise identical? No: each rank holds its own
-            # instance; for the sharded apply all ranks must hold the SAME matrix -> regenerate seed 1.
+            # each rank holds its own instance for the headline; for the sharded apply all ranks must hold the SAME
+            # matrix -> the other ranks regenerate seed 1
             if rank != 0:
                 rp_s, col_s = synth.rmat_symmetric_torch(args.scale, args.edge_factor, seed=1, device=dev)
             else:
@@ -182,7 +233,10 @@ def main():
             rp_s, col_s, val_s = rp, col, val
         n_s, nnz_s = rp_s.numel() - 1, col_s.numel()
         ranges = sharded.row_ranges(n_s, world)
-        comm = sharded.make_comm(local_rank) if world > 1 else None   # RCCL behind the C ABI (nccl backend)
+        comm = None
+        if world > 1:  # RCCL behind the C ABI (nccl backend)
+            comm = sharded.make_comm(local_rank)
+            comms.append(comm)
         out_s = None
         if world > 1:  # the rank's slab, sized by the shard's entries and allocated once, outside the timed loop
             cap = ops.permute_csr_rows_nnz(n_s, rp_s, perm, *ranges[rank])
@@ -218,7 +272,7 @@ def main():
             rowwise = {"workload": "Permute2DRowWise(random order), same matrix", "value": n_s * args.steps / w1 / 1e6,
                        "unit": "Mrows/s", "ms_per_step": w1 / args.steps * 1e3, "alg_gbs": alg * args.steps / w1 / 1e9,
                        "frac_of_hbm_peak": alg * args.steps / w1 / 1e9 / HBM_PEAK_GBS}
-        permute_apply = {
+        return {
             "workload": f"Permute2D(random order) of one RMAT scale-{args.scale} CSR, new-row ranges over {world} GPU(s), "
                         "all-gather of row_ptr" if world > 1 else f"Permute2D(random order), RMAT scale-{args.scale}, 1 GPU",
             "scaling": "strong", "value": n_s * args.steps / w / 1e6, "unit": "Mrows/s", "ms_per_step": w / args.steps * 1e3,
@@ -227,8 +281,7 @@ def main():
         }
 
     # ---- the other step that shards (north_star): COO -> CSR by row range, same row_ptr stitch
-    convert_apply = None
-    if not args.no_sharded:
+    def leg_convert():
         from sparsebase_amd import sharded
         if world > 1:
             rp_c, col_c = (rp, col) if rank == 0 else synth.rmat_symmetric_torch(args.scale, args.edge_factor, seed=1, device=dev)
@@ -238,9 +291,11 @@ def main():
         val_c = torch.ones(nnz_c, device=dev, dtype=torch.float32)
         row_c = ops.csr_to_coo(n_c, n_c, rp_c, col_c, None, move=True)[0]   # replicated row-sorted COO
         out_c = None
+        comm = None
         if world > 1:
-            if comm is None:
-                comm = sharded.make_comm(local_rank)
+            if not comms:
+                comms.append(sharded.make_comm(local_rank))
+            comm = comms[0]
             lo_c, hi_c = sharded.row_ranges(n_c, world)[rank]
             cap = int(rp_c[hi_c] - rp_c[lo_c])
             out_c = (torch.empty(n_c + 1, dtype=rp_c.dtype, device=dev), torch.empty(cap, dtype=col_c.dtype, device=dev),
@@ -263,38 +318,30 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wc = float(t.item())
         alg_c = 20 * nnz_c + 4 * (n_c + 1)
-        convert_apply = {
+        return {
             "workload": (f"COO->CSR of one RMAT scale-{args.scale} COO, row ranges over {world} GPU(s), all-gather of row_ptr"
                          if world > 1 else f"COO->CSR (copy), RMAT scale-{args.scale}, 1 GPU"),
             "scaling": "strong", "value": n_c * args.steps / wc / 1e6, "unit": "Mrows/s", "ms_per_step": wc / args.steps * 1e3,
             "alg_gbs": alg_c * args.steps / wc / 1e9, "frac_of_hbm_peak": alg_c * args.steps / wc / 1e9 / (HBM_PEAK_GBS * world)}
-        del row_c, val_c
-    if comm is not None:
-        comm.close()
+
+    if not args.no_sharded:
+        guarded("permute_apply", leg_permute)
+        guarded("convert_apply", leg_convert)
+    if watchdog is not None:
+        watchdog.cancel()
+    for c in comms:
+        try:
+            c.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     # ---- CPU baseline: rank 0, N=1 only, bounded sample of the same workload
-    cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         step()
         torch.cuda.synchronize()
-        cpu_baseline = run_cpu_baseline(args, synth, rp, col, gpu_result=(order, out, val))
+        extra["cpu_baseline"] = run_cpu_baseline(args, synth, rp, col, gpu_result=(order, out, val))
 
-    if rank == 0:
-        line = {
-            "metric": "Mrows/s, RCM reorder + CSR permute, 100M-nnz power-law (RMAT) CSR",
-            "value": value, "unit": "Mrows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"RCMReorder + Permute2D(order,order) on symmetric RMAT scale {args.scale} "
-                                   f"(a,b,c=.57,.19,.19, edge factor {args.edge_factor}) CSR <int32,int32,float32>, "
-                                   "one instance per GPU",
-                       "rows": n, "nnz": nnz, "rcm": stats},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "permute_apply": permute_apply,
-            "convert_apply": convert_apply,
-        }
-        if cpu_baseline and "parity_on_bench_matrix" in cpu_baseline:
-            line["parity_on_bench_matrix"] = cpu_baseline["parity_on_bench_matrix"]
-        print(json.dumps(line))
+    emit()
     if world > 1:
         dist.destroy_process_group()
 
