@@ -38,3 +38,13 @@ t = time.perf_counter(); out = ops.permute_csr_rows(n, n, rp, col, val, perm, No
 dt = time.perf_counter() - t
 res["rowwise_shard3"] = dict(shard_nnz=out[1].numel(), ms=round(dt * 1e3, 3), alg_gbs=round(16 * out[1].numel() / dt / 1e9, 1))
 print(json.dumps(res, indent=1))
+# where a shard's time goes: every launch bracketed by HIP events, the paths back to back (SBX_PERMUTE_OVERLAP=0 style)
+if os.environ.get("C4_PROFILE"):
+    a, b = sharded.row_ranges(n, world)[3]
+    ops.profile_enable(True)
+    for _ in range(3):
+        ops.permute_csr_rows(n, n, rp, col, val, perm, perm, a, b, capacity=nnz // 4)
+    torch.cuda.synchronize()
+    rep = ops.profile_report()
+    ops.profile_enable(False)
+    print(json.dumps({k: [round(v[0] / 3, 3), v[1] // 3] for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}))

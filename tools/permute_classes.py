@@ -12,3 +12,8 @@ names = ["tile(<=128)", "c256", "c512", "c1024", "c2048", "c4096", "c8192", "lon
 for lo, hi, nm in zip(edges[:-1], edges[1:], names):
     m = (ln > lo) & (ln <= hi)
     print(f"{nm:12s} rows {int(m.sum()):9d} entries {int(ln[m].sum()):11d}")
+# slot utilisation of the capacity classes: entries / (rows x capacity)
+for lo, hi, nm in zip(edges[1:-2], edges[2:-1], names[1:-1]):
+    m = (ln > lo) & (ln <= hi)
+    r, e = int(m.sum()), int(ln[m].sum())
+    print(f"{nm:12s} utilisation {e / max(1, r * hi):.2f}  mean length {e / max(1, r):.0f}")
