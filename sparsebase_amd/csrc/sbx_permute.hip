@@ -43,6 +43,9 @@ constexpr int PT_THREADS = 64;
 constexpr int PT_ITEMS = 8;  // a multiple of 4: the thread-consecutive sweeps move 16 bytes per LDS access
 constexpr int PT_CAP = PT_THREADS * PT_ITEMS;  // LDS capacity of one tile, in entries
 constexpr int PT_W = 384;                      // a tile owns the rows that start in a window of PT_W output positions
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4
+#endif
 constexpr int PT_LMAX = 128;                   // rows up to this many entries are sorted by the tile kernel
 static_assert(PT_W + PT_LMAX - 1 <= PT_CAP, "a tile must hold its window plus the tail of its last row");
 constexpr int BK_SHORT = 8;   // rows up to this length are one bucket (plain all-pairs ranking)
@@ -553,11 +556,26 @@ __device__ unsigned long long g_tile_stamps[32];
 //   r0  row-head marks -> (source offset - position) -> gathered columns -> placed words -> sorted columns
 //   r1  first position of the entry's row | row length << 16            (radix path: dense row rank)
 //   c   per-head (source offset, length) -> per-row (min, max) -> bucket counters -> sorted values
+// What a tile needs before it can touch its entries, three dependent rounds of loads deep: its row range
+// (tile_first), the range's bounds in the short-row entry space (sp) and, per lane, the record of the lane's first row.
+// k_permute_tile keeps these in flight for the tiles behind the one it works on.
+template <typename I>
+struct TileIn {
+  I ra, rb;      // rows [ra, rb)
+  I e0, e1;      // sp[ra], sp[rb]
+  int2 rc;       // rec[ra + lane] (length, source offset)
+  I sp_r, rpo_r; // sp / rpo of that row
+};
+// The tile kernels are one wave per workgroup: LDS operations of a wave execute in order, so the points where the
+// phases hand LDS regions over need no barrier — and must not wait for vector memory (__syncthreads() would: the
+// loads of the next tiles are in flight across them).
+#define TILE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 template <typename I, int VB, bool RADIX>
 __device__ __forceinline__ void permute_tile_body(
-    const int64_t tile, const int2 *__restrict__ rec, const I *col_in, const char *val_in,
+    const int64_t tile, const TileIn<I> in, const int2 *__restrict__ rec, const I *col_in, const char *val_in,
     const I *__restrict__ col_order, const I *__restrict__ rpo, const I *__restrict__ sp,
-    const I *__restrict__ tile_first, I *col_out, char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits,
+    I *col_out, char *val_out, int64_t nr, PermState *__restrict__ st, int col_bits,
     int force_radix, unsigned *__restrict__ fb_tiles) {
   typedef typename ValT<VB>::type V;
   constexpr bool HASV = VB != 0;
@@ -584,11 +602,11 @@ __device__ __forceinline__ void permute_tile_body(
 
   // the tile's rows: those of at most PT_LMAX entries whose range in the SHORT-row entry space (prefix sums `sp`
   // over the lengths of such rows only) starts in the window; longer rows between them belong to other kernels
-  const int64_t ra = tile_first[tile];
-  const int64_t rb = tile_first[tile + 1];
+  const int64_t ra = in.ra;
+  const int64_t rb = in.rb;
   if (ra >= rb) return;
-  const int64_t e0 = sp[ra];
-  const int cnt = (int)((int64_t)sp[rb] - e0);
+  const int64_t e0 = in.e0;
+  const int cnt = (int)((int64_t)in.e1 - e0);
   if (cnt == 0) return;
   TILE_STAMP(0);
   if (dbg_stop == 9 && tid == 0) {
@@ -602,10 +620,21 @@ __device__ __forceinline__ void permute_tile_body(
 #pragma unroll
   for (int k = 0; k < ITEMS; k += 4) *(int4 *)&s_a[k * THREADS + 4 * tid] = make_int4(0, 0, 0, 0);
   if (tid < 4) s_flag[tid] = 0;
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(1);
   if (rb - ra <= 4 * CAP) {
-    for (int64_t r = ra + tid; r < rb; r += THREADS) {
+    int64_t r = ra + tid;
+    if (r < rb) {  // the first row of every lane arrived with the tile's bounds (TileIn)
+      const int2 rc = in.rc;
+      if (rc.x > 0 && rc.x <= PT_LMAX) {
+        const int p = (int)((int64_t)in.sp_r - e0);
+        s_a[p] = 1;
+        s_ob[p] = (int)in.rpo_r;
+        *(uint2 *)&s_c[2 * p] = make_uint2((unsigned)rc.y, (unsigned)rc.x);
+      }
+      r += THREADS;
+    }
+    for (; r < rb; r += THREADS) {
       const int2 rc = rec[r];
       if (rc.x > 0 && rc.x <= PT_LMAX) {
         const int p = (int)((int64_t)sp[r] - e0);
@@ -631,7 +660,7 @@ __device__ __forceinline__ void permute_tile_body(
       }
     }
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(2);
   {
     const int p0 = tid * ITEMS;
@@ -648,7 +677,7 @@ __device__ __forceinline__ void permute_tile_body(
     const int inc = sbx_wave_inclusive_max(last);
     int open = sbx_wave_shift_up1(inc, 0);
     if (lane == 63) s_wmax[wv] = inc;
-    __syncthreads();
+    TILE_SYNC();
     for (int w = 0; w < wv; w++) open = s_wmax[w] > open ? s_wmax[w] : open;
     int hp = open ? open - 1 : 0;  // position 0 is a head
     uint2 sl = *(const uint2 *)&s_c[2 * hp];  // (source offset, length) of the row open at this thread's first entry
@@ -670,7 +699,7 @@ __device__ __forceinline__ void permute_tile_body(
       *(int4 *)&s_a[p0 + k] = make_int4(oa[k], oa[k + 1], oa[k + 2], oa[k + 3]);
     }
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(3);
   if (dbg_stop == 1) {
     for (int p = tid; p < cnt; p += THREADS) col_out[(int64_t)s_ob[s_hl[p] & 0xFFFFu] + (p - (int)(s_hl[p] & 0xFFFFu))] = (I)(s_a[p] + (int)s_hl[p]);
@@ -715,7 +744,7 @@ __device__ __forceinline__ void permute_tile_body(
       }
     }
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(5);
   if (dbg_stop == 2) {
 #pragma unroll
@@ -745,7 +774,7 @@ __device__ __forceinline__ void permute_tile_body(
       s_flag[0] = 1;
     }
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(6);
   if (s_flag[0] == 0) {
     // every row of the tile is already in column order (identity column maps, orders that preserve
@@ -799,7 +828,7 @@ __device__ __forceinline__ void permute_tile_body(
       atomicMax(&s_c[2 * cur + 1], mx);
     }
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(7);
   unsigned bk[ITEMS], wd[ITEMS];
   unsigned char sh[ITEMS];
@@ -830,7 +859,7 @@ __device__ __forceinline__ void permute_tile_body(
     }
     if ((__any(bad) || force_radix || RADIX) && lane == 0) s_flag[1] = 1;
   }
-  __syncthreads();  // the (min, max) words and the column copies in r0 have been read
+  TILE_SYNC();  // the (min, max) words and the column copies in r0 have been read
   TILE_STAMP(8);
   if (dbg_stop == 3) {
 #pragma unroll
@@ -844,19 +873,19 @@ __device__ __forceinline__ void permute_tile_body(
     return;
   }
   for (int i = 4 * tid; i < 2 * cnt; i += 4 * THREADS) *(uint4 *)&s_c[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(9);
 #pragma unroll
   for (int k = 0; k < ITEMS; k++)
     if (live >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(10);
   {
     const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
     if (__any(mxc > (unsigned)BK_REFINE) && lane == 0) s_flag[2] = 1;
     if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[3] = 1;
   }
-  __syncthreads();
+  TILE_SYNC();
   TILE_STAMP(11);
   if (s_flag[2] && !s_flag[1]) {
     // level 1 (clustered columns): every bucket is split into as many sub-buckets as it holds entries, by interpolation
@@ -872,20 +901,20 @@ __device__ __forceinline__ void permute_tile_body(
         bk[k] = hp + start + sub;  // = 2 hp + (start - hp) + sub, below 2 hp + length
       }
     }
-    __syncthreads();  // the level-0 bounds have been read
+    TILE_SYNC();  // the level-0 bounds have been read
     for (int i = 4 * tid; i < 2 * cnt; i += 4 * THREADS) *(uint4 *)&s_c[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    TILE_SYNC();
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
       if (live >> k & 1) atomicAdd(&s_c[bk[k]], 1u);
-    __syncthreads();
+    TILE_SYNC();
     const unsigned mxc = scan_bucket_counts<THREADS, 2 * ITEMS>(s_c, 2 * cnt, s_scan);
     if (__any(mxc > (unsigned)BK_MAX) && lane == 0) s_flag[1] = 1;
-    __syncthreads();
+    TILE_SYNC();
   } else if (s_flag[3]) {
-    __syncthreads();
+    TILE_SYNC();
     if (tid == 0) s_flag[1] = 1;
-    __syncthreads();
+    TILE_SYNC();
   }
   if (dbg_stop == 4) {
 #pragma unroll
@@ -903,7 +932,7 @@ __device__ __forceinline__ void permute_tile_body(
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
       if (live >> k & 1) s_a[atomicSub(&s_c[bk[k]], 1u) - 1u] = (int)wd[k];
-    __syncthreads();
+    TILE_SYNC();
     TILE_STAMP(12);
     int fin[ITEMS];
 #pragma unroll
@@ -927,7 +956,7 @@ __device__ __forceinline__ void permute_tile_body(
       }
       return;
     }
-    __syncthreads();  // the placed words (r0) and the bucket bounds (c) are dead: the sorted entries move in
+    TILE_SYNC();  // the placed words (r0) and the bucket bounds (c) are dead: the sorted entries move in
     TILE_STAMP(13);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
@@ -935,7 +964,7 @@ __device__ __forceinline__ void permute_tile_body(
         s_key[fin[k]] = kc[k];
         if (HASV) s_val[fin[k]] = kv[k];
       }
-    __syncthreads();
+    TILE_SYNC();
     TILE_STAMP(14);
   } else if constexpr (!RADIX) {
     // the columns of some row cluster: the tile goes on the list of the radix kernel (same kernel body, RADIX = true)
@@ -965,7 +994,7 @@ __device__ __forceinline__ void permute_tile_body(
       for (int k = 0; k < ITEMS; k++)
         if (k * THREADS + tid < cnt) s_val[k * THREADS + tid] = kv[k];
     }
-    __syncthreads();
+    TILE_SYNC();
     int row_bits = 0;
     for (int t = all - 1; t > 0; t >>= 1) row_bits++;
     lds_radix_sort<V, HASV, true, THREADS, ITEMS>(s_key, s_rank, s_val, s_whist, s_scan, cnt, col_bits, row_bits);
@@ -991,13 +1020,55 @@ __device__ __forceinline__ void permute_tile_body(
 }
 #undef OUTPOS
 
+#undef TILE_SYNC
+
+template <typename I>
+__device__ __forceinline__ TileIn<I> tile_in_now(int64_t tile, const int2 *__restrict__ rec, const I *__restrict__ rpo,
+                                                const I *__restrict__ sp, const I *__restrict__ tile_first, int64_t nr) {
+  TileIn<I> in;
+  in.ra = tile_first[tile];
+  in.rb = tile_first[tile + 1];
+  in.e0 = sp[in.ra];
+  in.e1 = sp[in.rb];
+  const int64_t r = (int64_t)in.ra + threadIdx.x < nr ? (int64_t)in.ra + threadIdx.x : nr - 1;
+  in.rc = rec[r];
+  in.sp_r = sp[r];
+  in.rpo_r = rpo[r];
+  return in;
+}
+
+// Persistent waves: a wave walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps the inputs of the tiles
+// behind the current one in flight — the row range of the tile after next, the bounds and the lanes' first row records
+// of the next one — so that a tile starts from registers instead of three dependent rounds of loads (18 % of a tile's
+// life, tools/tile_stamps.py).  Every load is issued unconditionally with a clamped index.
 template <typename I, int VB>
-__global__ __launch_bounds__(PT_THREADS) void k_permute_tile(
+__global__ __launch_bounds__(PT_THREADS, PT_MIN_WAVES) void k_permute_tile(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
     const I *__restrict__ rpo, const I *__restrict__ sp, const I *__restrict__ tile_first, I *col_out, char *val_out,
-    int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles) {
-  permute_tile_body<I, VB, false>((int64_t)blockIdx.x, rec, col_in, val_in, col_order, rpo, sp, tile_first, col_out,
-                                  val_out, nr, st, col_bits, force_radix, fb_tiles);
+    int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles,
+    int64_t tiles) {
+  const int64_t G = gridDim.x, last = tiles - 1;
+  int64_t t = blockIdx.x;
+  auto clampt = [&](int64_t x) { return x < last ? x : last; };
+  auto clampr = [&](int64_t x) { return x < nr - 1 ? x : nr - 1; };
+  TileIn<I> cur = tile_in_now<I>(clampt(t), rec, rpo, sp, tile_first, nr);
+  I ra1 = tile_first[clampt(t + G)], rb1 = tile_first[clampt(t + G) + 1];  // row range of the next tile
+  for (; t < tiles; t += G) {
+    // issued now, read after the current tile: range of the tile after next, bounds and row records of the next one
+    const I ra2 = tile_first[clampt(t + 2 * G)], rb2 = tile_first[clampt(t + 2 * G) + 1];
+    TileIn<I> nx;
+    nx.ra = ra1, nx.rb = rb1;
+    nx.e0 = sp[ra1];
+    nx.e1 = sp[rb1];
+    const int64_t r1 = clampr((int64_t)ra1 + threadIdx.x);
+    nx.rc = rec[r1];
+    nx.sp_r = sp[r1];
+    nx.rpo_r = rpo[r1];
+    permute_tile_body<I, VB, false>(t, cur, rec, col_in, val_in, col_order, rpo, sp, col_out, val_out, nr, st, col_bits,
+                                    force_radix, fb_tiles);
+    cur = nx;
+    ra1 = ra2, rb1 = rb2;
+  }
 }
 
 // the tiles the kernel above listed (clustered columns): same body, LSD radix sort instead of the bucket-rank pass
@@ -1008,8 +1079,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile_radix(
     int64_t nr, PermState *__restrict__ st, int col_bits, const unsigned *__restrict__ fb_tiles) {
   const unsigned n = st->n_fb_tiles;
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-    permute_tile_body<I, VB, true>((int64_t)fb_tiles[i], rec, col_in, val_in, col_order, rpo, sp, tile_first, col_out,
-                                   val_out, nr, st, col_bits, 0, nullptr);
+    const int64_t tile = (int64_t)fb_tiles[i];
+    permute_tile_body<I, VB, true>(tile, tile_in_now<I>(tile, rec, rpo, sp, tile_first, nr), rec, col_in, val_in,
+                                   col_order, rpo, sp, col_out, val_out, nr, st, col_bits, 0, nullptr);
     __syncthreads();  // the next tile reuses the LDS pool
   }
 }
@@ -1849,6 +1921,11 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
   return on;
 }
 
+static int tile_grid_factor() {  // SBX_PERMUTE_TILE_GRID: persistent tile waves per resident slot (tuning)
+  static const int f = getenv("SBX_PERMUTE_TILE_GRID") ? atoi(getenv("SBX_PERMUTE_TILE_GRID")) : 12;
+  return f < 1 ? 1 : f;
+}
+
 // rows of PT_LMAX < length <= 8 K: one workgroup per row, by capacity class
 template <int VB>
 int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
@@ -2067,9 +2144,12 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
     unsigned *fb_tiles = nullptr;  // tiles whose rows cluster (listed by the tile kernel, sorted by its radix twin)
     SBX_TRY(sbx_salloc(h, (size_t)tiles, &fb_tiles));
     const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)tiles), dim3(PT_THREADS), rec, col_in,
-                val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr, st, col_bits,
-                permute_force_radix(), fb_tiles);
+    // persistent waves, 15 per CU (the LDS of a tile) times 12 (measured: 1 ... 2 per slot lose 10 % to imbalance — a
+    // tile is 30 ... 512 entries —, 8 ... 16 are level, one wave per tile is 7 % slower): each walks its tiles as a pipeline
+    const int64_t tile_grid = (int64_t)h->num_cus * 15 * tile_grid_factor();
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)(tiles < tile_grid ? tiles : tile_grid)),
+                dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
+                st, col_bits, permute_force_radix(), fb_tiles, (int64_t)tiles);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile_radix<I, VB>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)),
                 dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
                 st, col_bits, (const unsigned *)fb_tiles);
