@@ -260,8 +260,12 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
 // threshold, deg / resolution above: gray_reorder.cc:249-267,384-395) is then bit b of ge[thr].  Lanes of a row are
 // merged by a saturating add of the sliced counters over log2(GR_LPR) butterfly steps.  LV = levels needed = largest thr + 1.
 constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
-constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight measured 12 % slower)
-constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
+#ifndef GR_LPR_V
+#define GR_LPR_V 8
+#define GR_BATCH_V 4
+#endif
+constexpr int GR_LPR = GR_LPR_V;         // lanes per row (4 lanes x 8 loads in flight: 12 % slower in round 1 and 15 - 20 % slower on the final kernel; -DGR_LPR_V / -DGR_BATCH_V build the variants)
+constexpr int GR_BATCH = GR_BATCH_V;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
 constexpr int GR_LONG_LIST = 4096;  // rows above GR_SHORT_MAX entries the short-row path lists for k_gray_long_rows
 
 // Exchange with lane ^ m inside a row's 8 lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;

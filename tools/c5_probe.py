@@ -3,11 +3,16 @@
 import json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from sparsebase_amd import capi
+if os.environ.get("SBX_PROBE_LIB"):  # a variant built by tools/build_variant.py
+    capi.LIB_PATH = os.path.join(ROOT, "sparsebase_amd", "lib", f"libsbx_{os.environ['SBX_PROBE_LIB']}.so")
 from sparsebase_amd import ops, synth
 n = 1 << 22
 cases = {"banded_w64": lambda: synth.banded_symmetric_torch(n, 64, per_row=12, seed=2),
          "banded_w_m16": lambda: synth.banded_symmetric_torch(n, n // 16, per_row=12, seed=2),
          "rmat22": lambda: synth.rmat_symmetric_torch(22, 13, seed=1)}
+if os.environ.get("C5_ONLY_BANDED"):
+    cases.pop("rmat22")
 out = {}
 for name, make in cases.items():
     rp, col = make()
