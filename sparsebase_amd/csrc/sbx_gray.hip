@@ -260,12 +260,8 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
 // threshold, deg / resolution above: gray_reorder.cc:249-267,384-395) is then bit b of ge[thr].  Lanes of a row are
 // merged by a saturating add of the sliced counters over log2(GR_LPR) butterfly steps.  LV = levels needed = largest thr + 1.
 constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
-#ifndef GR_LPR_V
-#define GR_LPR_V 8
-#define GR_BATCH_V 4
-#endif
-constexpr int GR_LPR = GR_LPR_V;         // lanes per row (4 lanes x 8 loads in flight: 12 % slower in round 1 and 15 - 20 % slower on the final kernel; -DGR_LPR_V / -DGR_BATCH_V build the variants)
-constexpr int GR_BATCH = GR_BATCH_V;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
+constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight: 12 % slower in round 1 and 15 - 20 % slower on the final kernel)
+constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
 constexpr int GR_LONG_LIST = 4096;  // rows above GR_SHORT_MAX entries the short-row path lists for k_gray_long_rows
 
 // Exchange with lane ^ m inside a row's 8 lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
@@ -291,6 +287,34 @@ __device__ __forceinline__ B gr_shfl_xor(B v, int m) {
 }
 
 // WSHIFT >= 0: the block width is 2^WSHIFT (the usual case: power-of-two dimensions), block = column >> WSHIFT
+// A lane's GR_BATCH = 4 CONSECUTIVE entries [j, j + 4) of its row in one 16-byte load (the address is only 4-byte
+// aligned: gfx950 loads unaligned vectors): the 8 lanes of a row fetch one contiguous 128-byte stretch per batch, where
+// 4-byte loads at a stride of 8 entries made every load instruction of a wave touch 8 separate 32-byte pieces.  The
+// per-row results are sums and ORs over the entries, so which lane sees which entry does not matter.  Entries at or
+// past `e` read as `far`; the vector form is not used where it would run past the end of the array.
+struct __attribute__((packed, aligned(4))) GrU4 {
+  unsigned x, y, z, w;
+};
+__device__ __forceinline__ void gr_load4(const int32_t *__restrict__ col, int32_t j, int32_t e, int32_t nnz, unsigned far,
+                                         bool on, unsigned *c) {
+  static_assert(GR_BATCH == 4, "one 16-byte load per lane and batch");
+  // issued whatever the lane holds (a load under a condition makes the compiler wait for it at the join, which would
+  // serialise the prefetch): the address is clamped into the array and the vector shifted back where that moved it
+  // (only the last three entries of the whole array); nnz >= 4 (the caller's business)
+  int32_t jc = j < nnz - 4 ? j : nnz - 4;
+  jc = jc < 0 ? 0 : jc;
+  const GrU4 v = *(const GrU4 *)(col + jc);
+  const int sh = j - jc;
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int u = 0; u < GR_BATCH; u++) {
+    unsigned x = far;
+#pragma unroll
+    for (int k = u; k < 4; k++) x = (sh == k - u) ? w[k] : x;
+    c[u] = (on && j + u < e) ? x : far;
+  }
+}
+
 template <typename B, int LV, bool POW2>
 __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
                                                          int64_t n, uint32_t width, uint32_t magic, uint32_t band,
@@ -310,16 +334,9 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   int32_t s_cur = 0, e_cur = 0, s_nx = 0, e_nx = 0;
   if (row < n) s_cur = rp[row], e_cur = rp[row + 1];
   if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
+  const int32_t nnz = rp[n];
   unsigned c_cur[GR_BATCH];
-  {
-    const bool lr = e_cur - s_cur > GR_SHORT_MAX;
-    const unsigned far0 = (unsigned)row ^ 0x40000000u;
-#pragma unroll
-    for (int u = 0; u < GR_BATCH; u++) {
-      const int32_t j = s_cur + sub + u * GR_LPR;
-      c_cur[u] = (!lr && j < e_cur) ? (unsigned)__builtin_nontemporal_load(col + j) : far0;
-    }
-  }
+  gr_load4(col, s_cur + GR_BATCH * sub, e_cur, nnz, (unsigned)row ^ 0x40000000u, e_cur - s_cur <= GR_SHORT_MAX, c_cur);
   for (; row < n; row += step) {
     const int32_t s = s_cur;
     int32_t e = e_cur;
@@ -327,15 +344,8 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     s_cur = s_nx, e_cur = e_nx;
     if (row + 2 * step < n) s_nx = rp[row + 2 * step], e_nx = rp[row + 2 * step + 1];
     unsigned c_nx[GR_BATCH];
-    {
-      const bool lr = e_cur - s_cur > GR_SHORT_MAX;
-      const unsigned far1 = (unsigned)(row + step) ^ 0x40000000u;
-#pragma unroll
-      for (int u = 0; u < GR_BATCH; u++) {
-        const int32_t j = s_cur + sub + u * GR_LPR;
-        c_nx[u] = (row + step < n && !lr && j < e_cur) ? (unsigned)__builtin_nontemporal_load(col + j) : far1;
-      }
-    }
+    gr_load4(col, s_cur + GR_BATCH * sub, e_cur, nnz, (unsigned)(row + step) ^ 0x40000000u,
+             row + step < n && e_cur - s_cur <= GR_SHORT_MAX, c_nx);
     // The kernel runs before anyone knows whether the matrix suits it: rows above GR_SHORT_MAX entries are listed for
     // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
     // leaves at its next long row — the host then discards the results and takes the tile kernel.
@@ -358,12 +368,13 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     const unsigned row_lo = (unsigned)row - band, band2 = 2u * band;  // |c - row| <= band  <=>  c - row_lo <= 2 band (mod 2^32)
     const unsigned far = (unsigned)row ^ 0x40000000u;                  // a column outside every band: stands for "no entry"
     bool first = true;
-    for (int32_t j0 = s + sub; first || __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
+    for (int32_t j0 = s; first || __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
       unsigned c[GR_BATCH];
+      if (first) {
 #pragma unroll
-      for (int u = 0; u < GR_BATCH; u++) {
-        const int32_t j = j0 + u * GR_LPR;
-        c[u] = first ? c_cur[u] : (j < e ? (unsigned)__builtin_nontemporal_load(col + j) : far);
+        for (int u = 0; u < GR_BATCH; u++) c[u] = c_cur[u];
+      } else {
+        gr_load4(col, j0 + GR_BATCH * sub, e, nnz, far, true, c);
       }
       first = false;
 #pragma unroll
@@ -376,8 +387,10 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
           bkt += (c[u] - bkt * width) >= width;
         }
         const B x = c[u] != far ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
+#if !defined(GR_ABLATE) || GR_ABLATE != 2  // (timing ablation builds only: tools/build_variant.py)
 #pragma unroll
         for (int t = LV - 1; t > 0; t--) ge[t] |= ge[t - 1] & x;
+#endif
         ge[0] |= x;
         inb += c[u] - row_lo <= band2;
       }
@@ -385,6 +398,9 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
 #pragma unroll
     for (int u = 0; u < GR_BATCH; u++) c_cur[u] = c_nx[u];
     // merge the lanes of the row: counts add, saturating at LV
+#if defined(GR_ABLATE) && GR_ABLATE == 1
+    if (row < 0)
+#endif
 #pragma unroll
     for (int m = 1; m < GR_LPR; m <<= 1) {
       B o[LV], r[LV];
@@ -582,7 +598,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     // saturating counter slices + 1.  The kernel is built for up to 5 (resolution >= 16) — what the tests of round 2
     // missed and tools/fuzz_ops.py found: below that the tile kernel does the work
     const int lv = (int)(hmax >= (unsigned)bits && (int)hmax > nnz_threshold ? hmax / (unsigned)bits : 0u) + 1;
-    if (allow && lv <= (bits <= 32 ? 5 : 2)) {
+    if (allow && lv <= (bits <= 32 ? 5 : 2) && nnz >= 4) {  // (gr_load4 reads 16 bytes at a clamped address)
       const unsigned grid = sbx_grid_for(n, 256 / GR_LPR, (int64_t)h->num_cus * 16);
       int wshift = -1;
       if ((width & (width - 1)) == 0)
