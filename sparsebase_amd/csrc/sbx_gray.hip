@@ -295,24 +295,39 @@ __device__ __forceinline__ B gr_shfl_xor(B v, int m) {
 struct __attribute__((packed, aligned(4))) GrU4 {
   unsigned x, y, z, w;
 };
-__device__ __forceinline__ void gr_load4(const int32_t *__restrict__ col, int32_t j, int32_t e, int32_t nnz, unsigned far,
-                                         bool on, unsigned *c) {
+__device__ __forceinline__ int32_t gr_clamp4(int32_t j, int32_t nnz) {  // where the 16 bytes for entry j are read
+  const int32_t jc = j < nnz - 4 ? j : nnz - 4;  // nnz >= 4 (the caller's business)
+  return jc < 0 ? 0 : jc;
+}
+// Issued whatever the lane holds (a load under a condition makes the compiler wait for it at the join, which would
+// serialise the prefetch): the address is clamped into the array; which of the four words are entries of the lane's
+// row, and the shift the clamp caused for the last three entries of the whole array, are sorted out where the words
+// are used (gr_take4).
+__device__ __forceinline__ void gr_load4(const int32_t *__restrict__ col, int32_t j, int32_t nnz, unsigned *c) {
   static_assert(GR_BATCH == 4, "one 16-byte load per lane and batch");
-  // issued whatever the lane holds (a load under a condition makes the compiler wait for it at the join, which would
-  // serialise the prefetch): the address is clamped into the array and the vector shifted back where that moved it
-  // (only the last three entries of the whole array); nnz >= 4 (the caller's business)
-  int32_t jc = j < nnz - 4 ? j : nnz - 4;
-  jc = jc < 0 ? 0 : jc;
-  const GrU4 v = *(const GrU4 *)(col + jc);
-  const int sh = j - jc;
-  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#if defined(GR_ABLATE) && GR_ABLATE == 4
+  const GrU4 v = {(unsigned)j, (unsigned)j + 1u, (unsigned)j + 2u, (unsigned)j + 3u};
+#else
+  const GrU4 v = *(const GrU4 *)(col + gr_clamp4(j, nnz));
+#endif
+  c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w;
+}
+// c[u] := entry j + u of the array for u < cnt (the lane's share of its row); returns cnt = min(4, e - j) clamped at 0
+__device__ __forceinline__ int gr_take4(int32_t j, int32_t e, int32_t nnz, unsigned *c) {
+  const int left = e - j;
+  const int cnt = left < 0 ? 0 : (left > GR_BATCH ? GR_BATCH : left);
+  const int sh = j - gr_clamp4(j, nnz);
+  if (__any(sh > 0 && cnt > 0)) {  // the end of the array: the vector was read up to 3 entries early
+    const unsigned w[4] = {c[0], c[1], c[2], c[3]};
 #pragma unroll
-  for (int u = 0; u < GR_BATCH; u++) {
-    unsigned x = far;
+    for (int u = 0; u < GR_BATCH; u++) {
+      unsigned x = w[u];
 #pragma unroll
-    for (int k = u; k < 4; k++) x = (sh == k - u) ? w[k] : x;
-    c[u] = (on && j + u < e) ? x : far;
+      for (int k = u + 1; k < 4; k++) x = (sh == k - u) ? w[k] : x;
+      c[u] = x;
+    }
   }
+  return cnt;
 }
 
 template <typename B, int LV, bool POW2>
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   if (row + step < n) s_nx = rp[row + step], e_nx = rp[row + step + 1];
   const int32_t nnz = rp[n];
   unsigned c_cur[GR_BATCH];
-  gr_load4(col, s_cur + GR_BATCH * sub, e_cur, nnz, (unsigned)row ^ 0x40000000u, e_cur - s_cur <= GR_SHORT_MAX, c_cur);
+  gr_load4(col, s_cur + GR_BATCH * sub, nnz, c_cur);
   for (; row < n; row += step) {
     const int32_t s = s_cur;
     int32_t e = e_cur;
@@ -344,8 +359,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     s_cur = s_nx, e_cur = e_nx;
     if (row + 2 * step < n) s_nx = rp[row + 2 * step], e_nx = rp[row + 2 * step + 1];
     unsigned c_nx[GR_BATCH];
-    gr_load4(col, s_cur + GR_BATCH * sub, e_cur, nnz, (unsigned)(row + step) ^ 0x40000000u,
-             row + step < n && e_cur - s_cur <= GR_SHORT_MAX, c_nx);
+    gr_load4(col, s_cur + GR_BATCH * sub, nnz, c_nx);
     // The kernel runs before anyone knows whether the matrix suits it: rows above GR_SHORT_MAX entries are listed for
     // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
     // leaves at its next long row — the host then discards the results and takes the tile kernel.
@@ -358,25 +372,31 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     if (long_row) e = s;
     const int d = e - s;
     const bool sparse = d <= nnz_threshold;
-    const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
+    // d / bits without the division (~35 VALU operations for a runtime divisor; the kernel is VALU-bound): a row of
+    // this kernel has at most GR_SHORT_MAX entries and LV - 1 >= GR_SHORT_MAX / bits
+    unsigned thr = 0;
+#pragma unroll
+    for (int t = 1; t < LV; t++) thr += d >= t * bits;
+    thr = d > nnz_threshold ? thr : 0u;
     B ge[LV];
 #pragma unroll
     for (int t = 0; t < LV; t++) ge[t] = 0;
     unsigned inb = 0;
-    // the row's entries, GR_BATCH per lane and batch (a lane's entries are GR_LPR apart); the first batch was
-    // prefetched, longer rows load further ones here
+    // the row's entries, GR_BATCH consecutive ones per lane and batch; the first batch was prefetched, longer rows
+    // load further ones here
     const unsigned row_lo = (unsigned)row - band, band2 = 2u * band;  // |c - row| <= band  <=>  c - row_lo <= 2 band (mod 2^32)
-    const unsigned far = (unsigned)row ^ 0x40000000u;                  // a column outside every band: stands for "no entry"
     bool first = true;
     for (int32_t j0 = s; first || __any(j0 < e); j0 += GR_BATCH * GR_LPR) {
       unsigned c[GR_BATCH];
+      const int32_t j = j0 + GR_BATCH * sub;
       if (first) {
 #pragma unroll
         for (int u = 0; u < GR_BATCH; u++) c[u] = c_cur[u];
       } else {
-        gr_load4(col, j0 + GR_BATCH * sub, e, nnz, far, true, c);
+        gr_load4(col, j, nnz, c);
       }
       first = false;
+      const int cnt = gr_take4(j, e, nnz, c);
 #pragma unroll
       for (int u = 0; u < GR_BATCH; u++) {
         unsigned bkt;
@@ -386,13 +406,14 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
           bkt = __umulhi(c[u], magic);  // c / width, one short at most
           bkt += (c[u] - bkt * width) >= width;
         }
-        const B x = c[u] != far ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
+        const bool have = u < cnt;
+        const B x = have ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
 #if !defined(GR_ABLATE) || GR_ABLATE != 2  // (timing ablation builds only: tools/build_variant.py)
 #pragma unroll
         for (int t = LV - 1; t > 0; t--) ge[t] |= ge[t - 1] & x;
 #endif
         ge[0] |= x;
-        inb += c[u] - row_lo <= band2;
+        inb += have && c[u] - row_lo <= band2;
       }
     }
 #pragma unroll
@@ -421,8 +442,13 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
       B key = ge[0];
 #pragma unroll
       for (int t = 1; t < LV; t++) key = thr == (unsigned)t ? ge[t] : key;
-      degree_out[row] = d;
-      key_out[row] = gray_decode((unsigned long long)key);
+#if defined(GR_ABLATE) && GR_ABLATE == 3
+      if (key == (B)0x12345678)
+#endif
+      {
+        degree_out[row] = d;
+        key_out[row] = gray_decode((unsigned long long)key);
+      }
       if (sparse) {
         c_ns += (unsigned)d;
         c_ds += inb;
