@@ -260,11 +260,20 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
 // threshold, deg / resolution above: gray_reorder.cc:249-267,384-395) is then bit b of ge[thr].  Lanes of a row are
 // merged by a saturating add of the sliced counters over log2(GR_LPR) butterfly steps.  LV = levels needed = largest thr + 1.
 constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
-constexpr int GR_LPR = 8;         // lanes per row (4 lanes x 8 loads in flight: 12 % slower in round 1 and 15 - 20 % slower on the final kernel)
-constexpr int GR_BATCH = 4;       // loads in flight per lane: rows of up to GR_LPR * GR_BATCH entries take one batch
+#ifndef GR_LPR_V
+#define GR_LPR_V 4
+#define GR_VEC_V 2
+#endif
+// The kernel is VALU-bound (87 % VALU busy, tools/pmc_gray.sh): what is done once per wave step — key selection, Gray
+// decode, thresholds, stores, loop control — is shared by 64 / GR_LPR rows, and a row's lanes merge in log2(GR_LPR)
+// steps.  Measured at C5 (kernel only): 8 lanes x 1 vector 0.139 ms, 4 x 2 0.107, 2 x 4 0.105, 1 x 8 0.137 (64 VGPRs of
+// prefetched entries).  -DGR_LPR_V / -DGR_VEC_V build the variants.
+constexpr int GR_LPR = GR_LPR_V;      // lanes per row
+constexpr int GR_VEC = GR_VEC_V;      // 16-byte loads in flight per lane and batch
+constexpr int GR_BATCH = 4 * GR_VEC;  // entries per lane and batch: rows of up to GR_LPR * GR_BATCH entries take one batch
 constexpr int GR_LONG_LIST = 4096;  // rows above GR_SHORT_MAX entries the short-row path lists for k_gray_long_rows
 
-// Exchange with lane ^ m inside a row's 8 lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
+// Exchange with lane ^ m inside a row's GR_LPR lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
 // 4 is row_half_mirror (lane i <-> 7 - i of the 8) — the same partner QUAD, and every value exchanged here is
 // uniform inside a quad by then (both partners of a merge step compute the same symmetric result).  A DPP move is one
 // VALU instruction; __shfl_xor is a ds_bpermute_b32 plus five instructions of address arithmetic.
@@ -296,35 +305,41 @@ struct __attribute__((packed, aligned(4))) GrU4 {
   unsigned x, y, z, w;
 };
 __device__ __forceinline__ int32_t gr_clamp4(int32_t j, int32_t nnz) {  // where the 16 bytes for entry j are read
-  const int32_t jc = j < nnz - 4 ? j : nnz - 4;  // nnz >= 4 (the caller's business)
-  return jc < 0 ? 0 : jc;
+  return j < nnz - 4 ? j : nnz - 4;  // nnz >= 4 (the caller's business) and j >= 0: never negative
 }
 // Issued whatever the lane holds (a load under a condition makes the compiler wait for it at the join, which would
 // serialise the prefetch): the address is clamped into the array; which of the four words are entries of the lane's
 // row, and the shift the clamp caused for the last three entries of the whole array, are sorted out where the words
 // are used (gr_take4).
 __device__ __forceinline__ void gr_load4(const int32_t *__restrict__ col, int32_t j, int32_t nnz, unsigned *c) {
-  static_assert(GR_BATCH == 4, "one 16-byte load per lane and batch");
+#pragma unroll
+  for (int v4 = 0; v4 < GR_VEC; v4++) {
 #if defined(GR_ABLATE) && GR_ABLATE == 4
-  const GrU4 v = {(unsigned)j, (unsigned)j + 1u, (unsigned)j + 2u, (unsigned)j + 3u};
+    const GrU4 v = {(unsigned)j, (unsigned)j + 1u, (unsigned)j + 2u, (unsigned)j + 3u};
 #else
-  const GrU4 v = *(const GrU4 *)(col + gr_clamp4(j, nnz));
+    const GrU4 v = *(const GrU4 *)(col + gr_clamp4(j + 4 * v4, nnz));
 #endif
-  c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w;
+    c[4 * v4] = v.x, c[4 * v4 + 1] = v.y, c[4 * v4 + 2] = v.z, c[4 * v4 + 3] = v.w;
+  }
 }
-// c[u] := entry j + u of the array for u < cnt (the lane's share of its row); returns cnt = min(4, e - j) clamped at 0
+// c[u] := entry j + u of the array for u < cnt (the lane's share of its row); returns cnt = min(GR_BATCH, e - j)
+// clamped at 0
 __device__ __forceinline__ int gr_take4(int32_t j, int32_t e, int32_t nnz, unsigned *c) {
   const int left = e - j;
   const int cnt = left < 0 ? 0 : (left > GR_BATCH ? GR_BATCH : left);
-  const int sh = j - gr_clamp4(j, nnz);
-  if (__any(sh > 0 && cnt > 0)) {  // the end of the array: the vector was read up to 3 entries early
-    const unsigned w[4] = {c[0], c[1], c[2], c[3]};
+  if (__any(j + GR_BATCH - 4 > nnz - 4 && cnt > 0)) {  // the end of the array: a vector was read up to 3 entries early
 #pragma unroll
-    for (int u = 0; u < GR_BATCH; u++) {
-      unsigned x = w[u];
+    for (int v4 = 0; v4 < GR_VEC; v4++) {
+      const int32_t jv = j + 4 * v4;
+      const int sh = jv - gr_clamp4(jv, nnz);  // (a vector wholly past the end holds no entry of the row: any value)
+      const unsigned w[4] = {c[4 * v4], c[4 * v4 + 1], c[4 * v4 + 2], c[4 * v4 + 3]};
 #pragma unroll
-      for (int k = u + 1; k < 4; k++) x = (sh == k - u) ? w[k] : x;
-      c[u] = x;
+      for (int u = 0; u < 4; u++) {
+        unsigned x = w[u];
+#pragma unroll
+        for (int k = u + 1; k < 4; k++) x = (sh == k - u) ? w[k] : x;
+        c[4 * v4 + u] = x;
+      }
     }
   }
   return cnt;
