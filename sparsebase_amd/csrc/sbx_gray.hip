@@ -297,7 +297,7 @@ __device__ __forceinline__ B gr_shfl_xor(B v, int m) {
 
 // WSHIFT >= 0: the block width is 2^WSHIFT (the usual case: power-of-two dimensions), block = column >> WSHIFT
 // A lane's GR_BATCH = 4 CONSECUTIVE entries [j, j + 4) of its row in one 16-byte load (the address is only 4-byte
-// aligned: gfx950 loads unaligned vectors): the 8 lanes of a row fetch one contiguous 128-byte stretch per batch, where
+// aligned: gfx950 loads unaligned vectors): the lanes of a row fetch one contiguous 128-byte stretch per batch, where
 // 4-byte loads at a stride of 8 entries made every load instruction of a wave touch 8 separate 32-byte pieces.  The
 // per-row results are sums and ORs over the entries, so which lane sees which entry does not matter.  Entries at or
 // past `e` read as `far`; the vector form is not used where it would run past the end of the array.
