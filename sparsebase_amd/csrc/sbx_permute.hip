@@ -43,6 +43,9 @@ constexpr int PT_THREADS = 64;
 constexpr int PT_ITEMS = 8;  // a multiple of 4: the thread-consecutive sweeps move 16 bytes per LDS access
 constexpr int PT_CAP = PT_THREADS * PT_ITEMS;  // LDS capacity of one tile, in entries
 constexpr int PT_W = 384;                      // a tile owns the rows that start in a window of PT_W output positions
+// waves per SIMD the persistent tile kernel is compiled for: 4 = at most 128 VGPRs, where the kernels that carry values
+// do not spill (uncapped they take 169 and lose occupancy: Permute2D 1.56 vs 1.49 ms); the pattern-only kernel spills 9
+// registers under the cap and is 7 % faster without it
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
 #endif
@@ -1042,7 +1045,7 @@ __device__ __forceinline__ TileIn<I> tile_in_now(int64_t tile, const int2 *__res
 // of the next one — so that a tile starts from registers instead of three dependent rounds of loads (18 % of a tile's
 // life, tools/tile_stamps.py).  Every load is issued unconditionally with a clamped index.
 template <typename I, int VB>
-__global__ __launch_bounds__(PT_THREADS, PT_MIN_WAVES) void k_permute_tile(
+__global__ __launch_bounds__(PT_THREADS, VB == 0 ? 1 : PT_MIN_WAVES) void k_permute_tile(
     const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
     const I *__restrict__ rpo, const I *__restrict__ sp, const I *__restrict__ tile_first, I *col_out, char *val_out,
     int64_t nr, PermState *__restrict__ st, int col_bits, int force_radix, unsigned *__restrict__ fb_tiles,
