@@ -737,14 +737,21 @@ __device__ __forceinline__ void permute_tile_body(
       if (acc == 0x12345678) s_flag[1] = 1;  // forces the wait for the column loads in front of the stamp
       TILE_STAMP(4);
     }
+    // the relabel gathers, all ITEMS of them in flight together: issued for every position (a dead one gathers entry 0
+    // of the table) — under `if (live...)` each gather sat in a block of its own with the LDS store of its result,
+    // and the compiler's wait at every join made them eight dependent round trips (37 % of a tile's life)
+    // (one opaque use of all the columns: the compiler waits for their loads HERE, once — they were issued under
+    // `p < cnt`, and without this it waits before every gather for all but the latest outstanding operation, i.e. for
+    // the gather before the last one)
+    static_assert(ITEMS == 8, "operand list below");
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
-      kc[k] = 0x7FFFFFFF;
-      if (live >> k & 1) {
-        kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
-        s_key[p] = kc[k];  // the word this thread read its source offset from
-      }
+      if (live >> k & 1) s_key[p] = kc[k];  // the word this thread read its source offset from
+      else kc[k] = 0x7FFFFFFF;
     }
   }
   TILE_SYNC();
