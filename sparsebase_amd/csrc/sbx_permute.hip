@@ -383,15 +383,32 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
     }
   }
   __syncthreads();
+  // all loads of a thread first, then its stores.  Written as "load, store, next position" under `p < cnt`, the
+  // compiler waited for every load before the store behind it and the copy was 16 dependent round trips per tile
+  // (tools/isa_waits.py); positions past the tile's end read the entry of position 0 (the loads are unconditional).
   int c[PC_ITEMS];
+  V v[VB ? PC_ITEMS : 1];
+  {
+    int64_t src[PC_ITEMS];
+    const int64_t src0 = t0 + s_delta[0];
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++) {
+      const int p = k * PC_THREADS + tid;
+      src[k] = p < cnt ? t0 + p + s_delta[p < cnt ? p : 0] : src0;
+    }
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++) c[k] = col_in[src[k]];
+    if (VB) {
+#pragma unroll
+      for (int k = 0; k < PC_ITEMS; k++) v[k] = ((const V *)val_in)[src[k]];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PC_ITEMS; k++) {
     const int p = k * PC_THREADS + tid;
     if (p < cnt) {
-      const int64_t src = t0 + p + s_delta[p];
-      c[k] = col_in[src];
       col_out[t0 + p] = c[k];
-      if (VB) ((V *)val_out)[t0 + p] = ((const V *)val_in)[src];
+      if (VB) ((V *)val_out)[t0 + p] = v[k];
       s_col[p] = c[k];
     }
   }
