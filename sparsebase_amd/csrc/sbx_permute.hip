@@ -1711,12 +1711,18 @@ __global__ __launch_bounds__(LS_THREADS) void k_long_seg_hist(const I *__restric
   const int shB = ch.hasB ? ls_shift(mnB, rowmm[2 * ch.k0 + 3], lgB) : 0;
   for (int i = tid; i < 2 * (1 << LS_MAXLG); i += LS_THREADS) (&s_hist[0][0])[i] = 0;
   __syncthreads();
+  unsigned cc[LS_ITEMS];  // all loads first (clamped index): under `e < long_nnz` each waited for the one before it
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int64_t e = base + i * LS_THREADS + tid;
+    cc[i] = (unsigned)c1[e < long_nnz ? e : long_nnz - 1];
+  }
 #pragma unroll
   for (int i = 0; i < LS_ITEMS; i++) {
     const int64_t e = base + i * LS_THREADS + tid;
     if (e < long_nnz) {
       const bool b = e >= ch.end0;
-      const unsigned c = (unsigned)c1[e];
+      const unsigned c = cc[i];
       atomicAdd(&s_hist[b][b ? (c - mnB) >> shB : (c - mnA) >> shA], 1u);
     }
   }
@@ -1841,15 +1847,20 @@ __global__ __launch_bounds__(LS_THREADS) void k_long_seg_partition(
   __syncthreads();
   int cc[LS_ITEMS];
   unsigned sg[LS_ITEMS];
+  // (all loads of a thread before anything uses them, at clamped indices: issued one by one under the conditions
+  // below, each waited for the one before it)
+#pragma unroll
+  for (int i = 0; i < LS_ITEMS; i++) {
+    const int64_t e = base + i * LS_THREADS + tid;
+    cc[i] = (int)c1[e < long_nnz ? e : long_nnz - 1];
+  }
 #pragma unroll
   for (int i = 0; i < LS_ITEMS; i++) {
     const int64_t e = base + i * LS_THREADS + tid;
     sg[i] = 0xFFFFFFFFu;
-    cc[i] = 0;
     if (e < long_nnz) {
       const bool b = e >= ch.end0;
       if (!(b ? skipB : skipA)) {
-        cc[i] = (int)c1[e];
         const unsigned c = (unsigned)cc[i];
         const unsigned g = b ? s_map[1][(c - mnB) >> shB] : s_map[0][(c - mnA) >> shA];
         sg[i] = (b ? (unsigned)LS_MAXSEG : 0u) + g;
@@ -1868,13 +1879,20 @@ __global__ __launch_bounds__(LS_THREADS) void k_long_seg_partition(
     if (n) s_hist[1][i] = (unsigned)ch.end0 + segstart[soff[ch.k0 + 1] + i] + atomicAdd(&cursor[soff[ch.k0 + 1] + i], n);
   }
   __syncthreads();
+  V vv[VB ? LS_ITEMS : 1];
+  if (VB) {
+#pragma unroll
+    for (int i = 0; i < LS_ITEMS; i++) {
+      const int64_t e = base + i * LS_THREADS + tid;
+      vv[i] = ((const V *)v1)[e < long_nnz ? e : long_nnz - 1];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < LS_ITEMS; i++) {
     if (sg[i] != 0xFFFFFFFFu) {
-      const int64_t e = base + i * LS_THREADS + tid;
       const unsigned d = atomicAdd(&(&s_hist[0][0])[sg[i]], 1u);
       c2[d] = (I)cc[i];
-      if (VB) ((V *)v2)[d] = ((const V *)v1)[e];
+      if (VB) ((V *)v2)[d] = vv[i];
     }
   }
 }
