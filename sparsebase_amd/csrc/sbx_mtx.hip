@@ -31,8 +31,24 @@ __device__ __forceinline__ bool mx_space(char c) {
 
 // token starts of this thread's MX_BPT bytes as a bit mask
 __device__ __forceinline__ unsigned mx_starts(const char *__restrict__ text, int64_t bytes, int64_t p0) {
+  static_assert(MX_BPT == 16, "one 16-byte load per thread");
   unsigned mask = 0;
-  bool prev_space = p0 == 0 ? true : mx_space(text[p0 - 1]);
+  const char before = p0 == 0 ? ' ' : text[p0 - 1];
+  if (p0 + MX_BPT <= bytes && (((uintptr_t)text + (uintptr_t)p0) & 15) == 0) {
+    // the thread's 16 bytes in one load (byte by byte, under the end-of-text test, the compiler made them 17 loads
+    // that wait for one another: tools/isa_waits.py)
+    const uint4 v = *(const uint4 *)(text + p0);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    bool prev_space = mx_space(before);
+#pragma unroll
+    for (int k = 0; k < MX_BPT; k++) {
+      const bool sp = mx_space((char)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu));
+      if (!sp && prev_space) mask |= 1u << k;
+      prev_space = sp;
+    }
+    return mask;
+  }
+  bool prev_space = mx_space(before);
 #pragma unroll
   for (int k = 0; k < MX_BPT; k++) {
     if (p0 + k >= bytes) break;

@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
   for (const char *f : fixed) checked += check(f, &bad);
   for (long i = 0; i < count; i++) {
     std::string tok;
-    const int kind = (int)(g() % 8);
+    const int kind = (int)(g() % 9);
     if (kind == 0) {  // random double printed with 17 significant digits
       uint64_t bits = g();
       double x; memcpy(&x, &bits, 8);
@@ -88,6 +88,13 @@ int main(int argc, char **argv) {
       for (int k = 0; k < nd; k++) tok += (char)('0' + (k == 0 ? 1 + g() % 9 : g() % 10));
       tok.insert(1 + g() % tok.size(), ".");
       char buf[16]; snprintf(buf, sizeof buf, "e%d", (int)(g() % 640) - 320); tok += buf;
+    } else if (kind == 8) {  // around the limits of the one-operation fast path: digits below / at / above 2^53 and 2^24,
+                             // powers of ten up to and beyond 10^22 / 10^10
+      const int which = (int)(g() % 4);
+      uint64_t w = which == 0 ? g() % (1ull << 53) : which == 1 ? (1ull << 53) - 2 + g() % 5 : which == 2 ? g() % (1ull << 24)
+                                                                                          : (1ull << 24) - 2 + g() % 5;
+      char buf[64]; snprintf(buf, sizeof buf, "%llue%d", (unsigned long long)w, (int)(g() % 53) - 26); tok = buf;
+      if (g() & 1) tok = "-" + tok;
     } else {  // plain integers and fixed-point
       char buf[64]; snprintf(buf, sizeof buf, "%lld.%03d", (long long)(g() % 2000000000000ll) - 1000000000000ll, (int)(g() % 1000)); tok = buf;
     }

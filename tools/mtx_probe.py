@@ -13,7 +13,7 @@ key = np.unique(g.integers(0, n * n, int(L * 1.01)))[:L]
 key = key[g.permutation(len(key))]
 df = pd.DataFrame({"r": key // n + 1, "c": key % n + 1, "v": g.standard_normal(len(key))})
 buf = io.StringIO()
-df.to_csv(buf, sep=" ", header=False, index=False, float_format="%.17g")
+df.to_csv(buf, sep=" ", header=False, index=False, float_format=os.environ.get("MTX_FLOAT_FORMAT", "%.17g"))  # e.g. MTX_FLOAT_FORMAT=%.8g: values the one-operation fast path converts
 body = buf.getvalue().encode()
 L = len(key)
 text = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
