@@ -180,11 +180,32 @@ __global__ __launch_bounds__(CV_THREADS) void k_fill_gaps(I *__restrict__ rp, co
 constexpr int EX_ITEMS = 8;
 constexpr int EX_TILE = CV_THREADS * EX_ITEMS;  // 2048 nonzeros per workgroup
 
+// first and last row of every EX_TILE-wide tile of the nonzeros, one thread per tile (large inputs: the two searches in
+// row_ptr are four dependent rounds of loads when a workgroup does them itself, and with tens of waves of workgroups
+// per CU that is most of a tile's life)
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_ex_tile_spans(const I *__restrict__ rp, int64_t n, int64_t nnz,
+                                                              int64_t tiles, int2 *__restrict__ span) {
+  const int64_t t = (int64_t)blockIdx.x * CV_THREADS + threadIdx.x;
+  if (t >= tiles) return;
+  const int64_t t0 = t * EX_TILE, t1 = (t0 + EX_TILE < nnz) ? t0 + EX_TILE : nnz;
+  auto last_le = [&](int64_t v) {  // last row r with rp[r] <= v
+    int64_t lo = 0, hi = n + 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)rp[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    return lo - 1;
+  };
+  span[t] = make_int2((int)last_le(t0), (int)last_le(t1 - 1));
+}
+constexpr int64_t EX_SPAN_MIN_TILES = 8192;  // from 16 M nonzeros on
+
 template <typename I, int VB, bool MOVE, bool ALIGNED16>
 __global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__ rp, const I *__restrict__ col,
                                                            const char *__restrict__ val, I *__restrict__ row_out,
                                                            I *__restrict__ col_out, char *__restrict__ val_out,
-                                                           int64_t n, int64_t nnz) {
+                                                           int64_t n, int64_t nnz, const int2 *__restrict__ span) {
   __shared__ int s_head[EX_TILE];
   __shared__ int64_t s_span[2];
   __shared__ int s_wmax[CV_THREADS / 64];
@@ -194,8 +215,14 @@ __global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__
   const int cnt = (int)(t1 - t0);
 #pragma unroll
   for (int k = 0; k < EX_ITEMS; k++) s_head[k * CV_THREADS + tid] = 0;
-  // row span of the tile: r_lo = last row with rp[r] <= t0, r_hi likewise for t1-1
-  if (tid < 64) {
+  // row span of the tile: r_lo = last row with rp[r] <= t0, r_hi likewise for t1-1 (precomputed for large inputs)
+  if (span) {
+    if (tid == 0) {
+      const int2 sp = span[blockIdx.x];
+      s_span[0] = sp.x;
+      s_span[1] = sp.y;
+    }
+  } else if (tid < 64) {
     const int64_t lo = sbx_wave_upper_bound<I>(rp, n + 1, (I)t0) - 1;
     if (tid == 0) s_span[0] = lo;
   } else if (tid < 128) {
@@ -409,12 +436,18 @@ int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp,
                       int32_t *row_out, int32_t *col_out, char *val_out) {
   const bool al = aligned16(row_out) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const unsigned grid = (unsigned)((nnz + EX_TILE - 1) / EX_TILE);
+  int2 *span = nullptr;
+  if ((int64_t)grid >= EX_SPAN_MIN_TILES) {
+    SBX_TRY(sbx_salloc(h, (size_t)grid, &span));
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, k_ex_tile_spans<int32_t>, dim3((grid + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS),
+                rp, n, nnz, (int64_t)grid, span);
+  }
   if (al)
     SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
-                       val, row_out, col_out, val_out, n, nnz);
+                       val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   else
     SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
-                       val, row_out, col_out, val_out, n, nnz);
+                       val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
