@@ -23,7 +23,19 @@
 #define SBX_POW5_LIMBS 16  /* 5^400 has 929 bits */
 #define SBX_DECIMAL_MAX_DIGITS 38
 
-// table[k * SBX_POW5_LIMBS + i] = limb i (little endian) of 5^k, k = 0..SBX_POW5_MAX
+// Behind the 5^k limbs the table holds, for q = SBX_EL_QMIN .. SBX_EL_QMAX, the 128-bit truncated significand of 5^q
+// (high word, low word) that the Eisel-Lemire fast path multiplies by (Lemire, "Number parsing at a gigabyte per
+// second", 2021; the construction is the one of its reference implementation): for q >= 0 the top 128 bits of 5^q,
+// for q < 0 those of 2^b / 5^-q + 1.
+#define SBX_EL_QMIN (-342)
+#define SBX_EL_QMAX 308
+#define SBX_EL_ENTRIES (SBX_EL_QMAX - SBX_EL_QMIN + 1)
+#define SBX_POW5_WORDS ((SBX_POW5_MAX + 1) * SBX_POW5_LIMBS)
+#define SBX_TABLE_WORDS (SBX_POW5_WORDS + 2 * SBX_EL_ENTRIES)
+
+static inline void sbx_el_table_fill(const uint64_t *pow5, uint64_t *el);
+
+// table[k * SBX_POW5_LIMBS + i] = limb i (little endian) of 5^k, k = 0..SBX_POW5_MAX; SBX_TABLE_WORDS words in all
 static inline void sbx_pow5_table_fill(uint64_t *table) {
   for (int i = 0; i < SBX_POW5_LIMBS; i++) table[i] = 0;
   table[0] = 1;
@@ -36,6 +48,65 @@ static inline void sbx_pow5_table_fill(uint64_t *table) {
       cur[i] = (uint64_t)t;
       carry = t >> 64;
     }
+  }
+  sbx_el_table_fill(table, table + SBX_POW5_WORDS);
+}
+
+// (host only, once per handle: plain multi-limb shifts and a restoring division)
+static inline void sbx_el_table_fill(const uint64_t *pow5, uint64_t *el) {
+  enum { NL = 30 };  // 2^b has up to 2 * 795 + 128 + 1 bits
+  auto bitlen = [](const uint64_t *a, int n) {
+    while (n > 0 && a[n - 1] == 0) n--;
+    return n == 0 ? 0 : 64 * n - __builtin_clzll(a[n - 1]);
+  };
+  auto top128 = [&](const uint64_t *a, int bits, uint64_t *hi, uint64_t *lo) {  // bits [bits-128, bits) of a, zero-filled below 0
+    auto bit = [&](int i) -> uint64_t { return i < 0 ? 0 : (a[i >> 6] >> (i & 63)) & 1u; };
+    uint64_t h = 0, l = 0;
+    for (int i = 0; i < 64; i++) h = (h << 1) | bit(bits - 1 - i);
+    for (int i = 0; i < 64; i++) l = (l << 1) | bit(bits - 65 - i);
+    *hi = h;
+    *lo = l;
+  };
+  for (int q = SBX_EL_QMIN; q <= SBX_EL_QMAX; q++) {
+    uint64_t *out = el + 2 * (size_t)(q - SBX_EL_QMIN);
+    if (q >= 0) {
+      uint64_t a[NL] = {0};
+      for (int i = 0; i < SBX_POW5_LIMBS; i++) a[i] = pow5[(size_t)q * SBX_POW5_LIMBS + i];
+      top128(a, bitlen(a, NL), &out[0], &out[1]);  // normalised so that bit 127 is set, truncated
+      continue;
+    }
+    const uint64_t *p = pow5 + (size_t)(-q) * SBX_POW5_LIMBS;
+    const int z = bitlen(p, SBX_POW5_LIMBS);  // smallest z with 2^z >= 5^-q (5^k is no power of two)
+    const int b = q >= -27 ? z + 127 : 2 * z + 128;
+    // quo = floor(2^b / p) by restoring division, then + 1
+    uint64_t quo[NL] = {0}, rem[SBX_POW5_LIMBS + 1] = {0};
+    for (int i = b; i >= 0; i--) {
+      uint64_t carry = i == b ? 1u : 0u;  // rem = rem * 2 + bit i of 2^b
+      for (int j = 0; j <= SBX_POW5_LIMBS; j++) {
+        const uint64_t nc = rem[j] >> 63;
+        rem[j] = (rem[j] << 1) | carry;
+        carry = nc;
+      }
+      bool ge = rem[SBX_POW5_LIMBS] != 0;
+      if (!ge) {
+        ge = true;
+        for (int j = SBX_POW5_LIMBS - 1; j >= 0; j--)
+          if (rem[j] != p[j]) { ge = rem[j] > p[j]; break; }
+      }
+      if (ge) {
+        uint64_t borrow = 0;
+        for (int j = 0; j <= SBX_POW5_LIMBS; j++) {
+          const uint64_t pj = j < SBX_POW5_LIMBS ? p[j] : 0;
+          const uint64_t d = rem[j] - pj - borrow;
+          borrow = (rem[j] < pj || (rem[j] == pj && borrow)) ? 1u : 0u;
+          rem[j] = d;
+        }
+        quo[i >> 6] |= (uint64_t)1 << (i & 63);
+      }
+    }
+    for (int j = 0; j < NL; j++)
+      if (++quo[j] != 0) break;  // + 1
+    top128(quo, bitlen(quo, NL), &out[0], &out[1]);  // (q >= -27: exactly 128 bits; below: halved until it fits)
   }
 }
 
@@ -283,6 +354,66 @@ SBX_HD int sbx_parse_integer(const char *s, int64_t len, long long *out) {
   return 0;
 }
 
+namespace sbx_d2b {
+SBX_HD void mul64(uint64_t a, uint64_t b, uint64_t *hi, uint64_t *lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *lo = a * b;
+  *hi = __umul64hi(a, b);
+#else
+  const unsigned __int128 t = (unsigned __int128)a * b;
+  *lo = (uint64_t)t;
+  *hi = (uint64_t)(t >> 64);
+#endif
+}
+// Eisel-Lemire: w * 10^q (w != 0, at most 64 bits) to the nearest double / float with one or two 64 x 64 multiplications
+// by the tabulated significand of 5^q; returns false in the rare cases it cannot decide (the exact path then does).
+// MB explicit significand bits, BIAS the exponent bias + 1 - 1 (1023 / 127), INFP the all-ones exponent, [RLO, RHI] the
+// powers of ten where w * 10^q can fall exactly half way between two values.
+template <int MB, int BIAS, int INFP, int RLO, int RHI, int QLO, int QHI>
+SBX_HD bool eisel_lemire(uint64_t w, int q, const uint64_t *el, uint64_t *bits) {
+  if (q < QLO || q > QHI) return false;
+  const int lz = clz64(w);
+  w <<= lz;
+  const uint64_t *t = el + 2 * (size_t)(q - SBX_EL_QMIN);
+  const uint64_t pmask = 0xFFFFFFFFFFFFFFFFull >> (MB + 3);
+  uint64_t hi, lo;
+  mul64(w, t[0], &hi, &lo);
+  if ((hi & pmask) == pmask) {  // the MB + 3 bits wanted are not settled by the high word of the table entry alone
+    uint64_t hi2, lo2;
+    mul64(w, t[1], &hi2, &lo2);
+    lo += hi2;
+    if (hi2 > lo) hi++;
+  }
+  if (lo == 0xFFFFFFFFFFFFFFFFull && !(q >= -27 && q <= 55)) return false;
+  const int upperbit = (int)(hi >> 63);
+  const int sh = upperbit + 64 - MB - 3;
+  uint64_t mant = hi >> sh;
+  int power2 = (int)((((int64_t)(152170 + 65536) * q) >> 16) + 63) + upperbit - lz + BIAS;
+  if (power2 <= 0) {  // subnormal
+    if (-power2 + 1 >= 64) { *bits = 0; return true; }
+    mant >>= -power2 + 1;
+    mant += mant & 1u;
+    mant >>= 1;
+    power2 = mant < (1ull << MB) ? 0 : 1;
+    *bits = ((uint64_t)power2 << MB) | (mant & ~(1ull << MB));
+    return true;
+  }
+  if (lo <= 1 && q >= RLO && q <= RHI && (mant & 3u) == 1u) {  // exactly half way: to even
+    if ((mant << sh) == hi) mant &= ~1ull;
+  }
+  mant += mant & 1u;
+  mant >>= 1;
+  if (mant >= (2ull << MB)) {
+    mant = 1ull << MB;
+    power2++;
+  }
+  mant &= ~(1ull << MB);
+  if (power2 >= INFP) { *bits = (uint64_t)INFP << MB; return true; }
+  *bits = ((uint64_t)power2 << MB) | mant;
+  return true;
+}
+}  // namespace sbx_d2b
+
 // IEEE bit patterns (sign applied by the caller).
 // Fast path (Clinger 1990): when the digits w and the power of ten are both exactly representable in the target
 // format, ONE correctly rounded IEEE multiplication or division gives the correctly rounded value of w * 10^q — the
@@ -298,6 +429,11 @@ SBX_HD uint64_t sbx_decimal_to_double_bits(const sbx_decimal &d, const uint64_t 
     memcpy(&bits, &r, sizeof bits);
     return bits;
   }
+  if (d.w_hi == 0 && d.w_lo != 0) {  // up to 19 digits: Eisel-Lemire, exact path only where it cannot decide
+    uint64_t bits;
+    if (sbx_d2b::eisel_lemire<52, 1023, 0x7FF, -4, 23, SBX_EL_QMIN, SBX_EL_QMAX>(d.w_lo, d.q10, pow5 + SBX_POW5_WORDS, &bits))
+      return bits;
+  }
   return sbx_d2b::convert<53, -1022, 1023, 11>(d.w_hi, d.w_lo, d.q10, pow5);
 }
 SBX_HD uint32_t sbx_decimal_to_float_bits(const sbx_decimal &d, const uint64_t *pow5) {
@@ -308,6 +444,11 @@ SBX_HD uint32_t sbx_decimal_to_float_bits(const sbx_decimal &d, const uint64_t *
     uint32_t bits;
     memcpy(&bits, &r, sizeof bits);
     return bits;
+  }
+  if (d.w_hi == 0 && d.w_lo != 0) {
+    uint64_t bits;
+    if (sbx_d2b::eisel_lemire<23, 127, 0xFF, -17, 10, -64, 38>(d.w_lo, d.q10, pow5 + SBX_POW5_WORDS, &bits))
+      return (uint32_t)bits;
   }
   return (uint32_t)sbx_d2b::convert<24, -126, 127, 8>(d.w_hi, d.w_lo, d.q10, pow5);
 }

@@ -278,10 +278,10 @@ struct NestGuard {
     if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
   } while (0)
 
-// 5^k table for the exact decimal conversion, built on first use (51 KB per handle)
+// tables for the decimal conversion, built on first use (62 KB per handle)
 static int mx_pow5(sbx_handle_t h, const uint64_t **out) {
   if (!h->pow5) {
-    const size_t words = (size_t)(SBX_POW5_MAX + 1) * SBX_POW5_LIMBS;
+    const size_t words = (size_t)SBX_TABLE_WORDS;  // 5^k limbs + the Eisel-Lemire significands
     uint64_t *host = new uint64_t[words];
     sbx_pow5_table_fill(host);
     void *dev = nullptr;

@@ -11,7 +11,7 @@
 
 #include "sbx_dec2bin.h"
 
-static std::vector<uint64_t> table((size_t)(SBX_POW5_MAX + 1) * SBX_POW5_LIMBS);
+static std::vector<uint64_t> table((size_t)SBX_TABLE_WORDS);
 
 static int check(const std::string &tok, int *bad) {
   const sbx_decimal d = sbx_parse_decimal(tok.data(), (int64_t)tok.size());
