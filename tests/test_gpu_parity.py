@@ -131,6 +131,58 @@ def test_mtx_parse_vs_oracle(ops, oracle, seed):
         assert got[2] is None and np.array_equal(host(got[0]), want[0]) and np.array_equal(host(got[1]), want[1])
 
 
+def test_mtx_values_through_every_conversion_path(ops, oracle):
+    """Decimal -> binary on the DEVICE (sbx_dec2bin.h): values for the one-operation fast path (few digits, small powers
+    of ten) and around its limits, 16 - 19 digit values for Eisel-Lemire incl. subnormals, the largest finite values,
+    halfway cases and overflow, and 20+ digit strings for the exact path — against the oracle's stream extraction."""
+    g = np.random.default_rng(77)
+    toks = ["5e-324", "4.9406564584124654e-324", "2.4703282292062327e-324", "2.4703282292062328e-324",
+            "2.2250738585072014e-308", "2.2250738585072011e-308", "1.7976931348623157e308", "1.7976931348623158e308",
+            "9007199254740993", "9007199254740992", "9007199254740991", "1e23", "8.5e22", "1e22", "1e-22", "1.4e-45", "7e-46",
+            "3.4028235e38", "3.4028236e38", "1.17549435e-38", "16777217", "16777216", "16777215", "0.1", "0.3", "4.35",
+            "1.0000000000000002", "1.0000000000000001110223024625156540424", "123456789012345678",
+            "1234567890123456789", "12345678901234567890", "0.000001", "6.02214076e23", "1e-320", "9.5e-324"]
+    for _ in range(30000):
+        k = int(g.integers(0, 6))
+        if k == 0:    # a double printed with 17 digits
+            x = np.frombuffer(g.bytes(8), np.float64)[0]
+            if not np.isfinite(x): continue
+            toks.append("%.17g" % x)
+        elif k == 1:  # a float printed with 9 digits
+            x = np.frombuffer(g.bytes(4), np.float32)[0]
+            if not np.isfinite(x): continue
+            toks.append("%.9g" % float(x))
+        elif k == 2:  # few digits, small exponents
+            toks.append("%de%d" % (int(g.integers(0, 1 << 53)) >> int(g.integers(0, 53)), int(g.integers(-26, 27))))
+        elif k == 3:  # digits and exponent over the whole range
+            nd = int(g.integers(1, 20))
+            toks.append("".join(str(int(g.integers(1 if i == 0 else 0, 10))) for i in range(nd)) + "e%d" % int(g.integers(-345, 310)))
+        elif k == 4:  # halfway between adjacent doubles, printed with 19 digits
+            mnt = (int(g.integers(0, 1 << 53)) | (1 << 52)) * 2 + 1
+            toks.append("%.19g" % np.ldexp(float(mnt), int(g.integers(-20, 20)) - 1))
+        else:         # long digit strings (exact path)
+            nd = int(g.integers(20, 38))
+            toks.append("".join(str(int(g.integers(1 if i == 0 else 0, 10))) for i in range(nd)) + "e%d" % int(g.integers(-330, 290)))
+    toks = [t.lstrip("-") for t in toks]  # (the sign is added per line below)
+
+    def parse(tk, vt):
+        body = "".join("%d %d %s%s\n" % (i % 97 + 1, i % 89 + 1, "-" if i % 3 == 0 else "", t) for i, t in enumerate(tk))
+        text = torch.frombuffer(bytearray(body.encode()), dtype=torch.uint8).cuda()
+        return body, host(ops.mtx_parse_coordinate(text, 100, 100, len(tk), 3, 0, True, False, torch.int32, vt)[2])
+    # doubles: Python's float() is strtod (correctly rounded; the stream extraction of the oracle refuses the values
+    # that overflow or underflow, which the device converts to inf / 0 like strtod)
+    _, got = parse(toks, torch.float64)
+    want = np.array([(-1.0 if i % 3 == 0 else 1.0) * float(t) for i, t in enumerate(toks)], np.float64)
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    assert len(bad) == 0, [toks[i] for i in bad[:5]]
+    # floats: the tokens a stream reads into a float without failing, against the oracle's extraction
+    ftoks = [t for t in toks if float(t) == 0.0 or 1.2e-38 < abs(float(t)) < 3.4e38]
+    body, got = parse(ftoks, torch.float32)
+    want = oracle.mtx_parse(body.encode(), len(ftoks), 3, 0, True, False, np.int32, np.float32)[2]
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert len(bad) == 0, [ftoks[i] for i in bad[:5]]
+
+
 def test_kat_mtx_reader(ops, kat):
     # io/mtx_reader_tests.cc:58-260 on the fixtures of io/reader_data.inc, then the COO constructor's sort
     for name, symm in (("general", 0), ("symmetric", 1), ("skew-symmetric", 2)):
