@@ -167,7 +167,16 @@ def main():
 
     extra = {"permute_apply": None, "convert_apply": None, "cpu_baseline": None}
 
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
+
     def emit():
+        # (the watchdog thread and the main thread may both get here: the line is printed once)
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
         if rank != 0:
             return
         line = {
@@ -193,15 +202,13 @@ def main():
     # the main thread may be inside a C call that no Python signal handler interrupts.
     watchdog = None
     if world > 1 and not args.no_sharded:
-        import threading
-
         def give_up():
             for k in ("permute_apply", "convert_apply"):
                 if extra[k] is None:
                     extra[k] = {"error": f"no result after {args.leg_timeout} s (watchdog)"}
             emit()
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)  # a rank lost in a collective is a failed run: the launcher must see it
 
         watchdog = threading.Timer(args.leg_timeout, give_up)
         watchdog.daemon = True
@@ -232,7 +239,9 @@ def main():
         else:
             rp_s, col_s, val_s = rp, col, val
         n_s, nnz_s = rp_s.numel() - 1, col_s.numel()
-        ranges = sharded.row_ranges(n_s, world)
+        # new-row ranges of equal ENTRY counts (a power-law matrix in equal row ranges leaves one rank with several
+        # times the work): computed on the device, the same on every rank (replicated input)
+        ranges = sharded.balanced_row_ranges_device(n_s, rp_s, perm, world) if world > 1 else sharded.row_ranges(n_s, world)
         comm = None
         if world > 1:  # RCCL behind the C ABI (nccl backend)
             comm = sharded.make_comm(local_rank)
@@ -277,7 +286,7 @@ def main():
                         "all-gather of row_ptr" if world > 1 else f"Permute2D(random order), RMAT scale-{args.scale}, 1 GPU",
             "scaling": "strong", "value": n_s * args.steps / w / 1e6, "unit": "Mrows/s", "ms_per_step": w / args.steps * 1e3,
             "alg_gbs": alg * args.steps / w / 1e9, "frac_of_hbm_peak": alg * args.steps / w / 1e9 / (HBM_PEAK_GBS * world),
-            "rowwise": rowwise,
+            "rowwise": rowwise, "ranges": "nnz-balanced" if world > 1 else "whole matrix",
         }
 
     # ---- the other step that shards (north_star): COO -> CSR by row range, same row_ptr stitch
@@ -296,14 +305,15 @@ def main():
             if not comms:
                 comms.append(sharded.make_comm(local_rank))
             comm = comms[0]
-            lo_c, hi_c = sharded.row_ranges(n_c, world)[rank]
+            ranges_c = sharded.balanced_row_ranges_device(n_c, rp_c, None, world)
+            lo_c, hi_c = ranges_c[rank]
             cap = int(rp_c[hi_c] - rp_c[lo_c])
             out_c = (torch.empty(n_c + 1, dtype=rp_c.dtype, device=dev), torch.empty(cap, dtype=col_c.dtype, device=dev),
                      torch.empty(cap, dtype=val_c.dtype, device=dev))
 
         def convert_step():
             if world > 1:
-                return ops.coo_to_csr_sharded(comm, n_c, n_c, row_c, col_c, val_c, out=out_c)
+                return ops.coo_to_csr_sharded(comm, n_c, n_c, row_c, col_c, val_c, ranges=ranges_c, out=out_c)
             return ops.coo_to_csr(n_c, n_c, row_c, col_c, val_c, rows_sorted=True)
 
         convert_step()

@@ -335,7 +335,11 @@ int sbx_permute_csr_rows_nnz(sbx_handle_t h, sbx_index_type it, int64_t n, const
 /* A5 sharded.  row_splits: world + 1 new-row boundaries (NULL: equal ranges).  row_ptr_out
  * (n + 1 entries) is complete on every rank; col_out / val_out receive THIS rank's rows
  * (out_capacity entries); shard_offsets_host (world + 1, may be NULL) are the positions of the
- * shards in the global entry space.  Synchronous; the collectives run on the handle's stream. */
+ * shards in the global entry space.  Synchronous; the collectives run on the handle's stream and
+ * the host waits once, behind them (the shards' offsets are computed on the device from the
+ * gathered totals).  A rank whose own part fails (a slab beyond out_capacity, ...) still takes
+ * part in both collectives with a status word, so every rank of the call returns an error
+ * instead of waiting for ever (SBX_ERR_INTERNAL "rank r reported a failure" on the others). */
 int sbx_permute_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt,
                             int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                             const void *col, const void *val, const void *row_order,
@@ -349,6 +353,23 @@ int sbx_coo_to_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, s
                            const void *val, const int64_t *row_splits, void *row_ptr_out,
                            void *col_out, void *val_out, int64_t out_capacity,
                            int64_t *shard_offsets_host);
+
+/* A3 sharded (converter/converter_order_two.cc:72-160 by row range; the reference's
+ * device-to-device edge: converter/converter_order_two_cuda.cu:41-76): CSR (replicated) -> this
+ * rank's slab of the COO, rows [row_splits[rank], row_splits[rank + 1]) with their global row
+ * ids.  No collective: shard_offsets_host (world + 1, may be NULL) = row_ptr at the split
+ * points.  Synchronous. */
+int sbx_csr_to_coo_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt,
+                           int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                           const void *val, const int64_t *row_splits, void *row_out, void *col_out,
+                           void *val_out, int64_t out_capacity, int64_t *shard_offsets_host);
+
+/* Row ranges of (nearly) equal entry counts for the sharded permute (balance by
+ * nnz, not rows): splits_host[0 .. world] over the NEW rows of sbx_permute_csr (row_order may be
+ * NULL: the rows as they are).  Every rank computes the same splits from the replicated input.
+ * world <= 64.  Synchronous. */
+int sbx_balanced_row_splits(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
+                            const void *row_order, int world, int64_t *splits_host);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,9 @@ PROTOTYPES = {
                                  _vp, _vp, _i64, C.POINTER(_i64)], _int),
     "sbx_coo_to_csr_sharded": ([_H, _vp, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _vp,
                                 _i64, C.POINTER(_i64)], _int),
+    "sbx_csr_to_coo_sharded": ([_H, _vp, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _vp,
+                                _i64, C.POINTER(_i64)], _int),
+    "sbx_balanced_row_splits": ([_H, _int, _i64, _vp, _vp, _int, C.POINTER(_i64)], _int),
 }
 
 _lib = None

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     if (__any(long_row)) {  // (nothing on the common path: the counter is only touched by waves that meet a long row)
       const unsigned slot = sbx_wave_append(nlong, long_row && sub == 0);
       if (long_row && sub == 0 && slot < (unsigned)GR_LONG_LIST) long_list[slot] = (int32_t)row;
-      if (__any(long_row && sub == 0 && slot >= (unsigned)GR_LONG_LIST)) return;  // list full: this wave leaves
+      if (__any(long_row && sub == 0 && slot >= (unsigned)GR_LONG_LIST)) break;  // list full: this wave stops (it still meets
+                                                                                 // the workgroup's barrier below; the host discards the results)
     }
     if (long_row) e = s;
     const int d = e - s;

@@ -55,13 +55,8 @@ constexpr int BK_SHORT = 8;   // rows up to this length are one bucket (plain al
 constexpr int BK_MAX = 96;    // a larger bucket sends the tile / row to the radix sort
 constexpr int BK_REFINE = 6;  // a larger bucket after the first level: every bucket is split again in proportion to its count
 // one workgroup sorts one row in LDS; capacity classes so a 1100-entry row does not pay for 8192 slots
-constexpr int BR_CLASSES = 6;   // round-2 kernels (k_permute_block_rows): 256, 512, 1024, 2048, 4096, 8192
-__host__ __device__ constexpr int br_cap(int cls) { return 256 << cls; }
-constexpr int BR_MAXC = 12;     // room for the class table of either set of row kernels
-struct ClassCaps {              // rows of (PT_LMAX, cap[n - 1]] entries go on list c = the first with length <= cap[c]
-  int n;
-  int cap[BR_MAXC];
-};
+constexpr int BR_CLASSES = 6;
+__host__ __device__ constexpr int br_cap(int cls) { return 256 << cls; }  // 256, 512, 1024, 2048, 4096, 8192
 template <int VB> struct BlockRowCap { static constexpr int value = 8192; };
 template <> struct BlockRowCap<8> { static constexpr int value = 4096; };   // 8-byte values: 8192 entries do not fit LDS
 
@@ -69,7 +64,7 @@ struct PermState {            // device-resident flags/counters of one call
   unsigned any_unsorted;      // some row had col[j] < col[j-1] after relabelling (csr.cc:102-116)
   unsigned any_dup;           // some row holds a duplicate column
   unsigned n_long;            // rows longer than the block-row capacity (global radix path)
-  unsigned n_block[BR_MAXC];  // rows in (PT_LMAX, capacity], by capacity class: one workgroup each
+  unsigned n_block[BR_CLASSES];  // rows in (PT_LMAX, capacity], by capacity class: one workgroup each
   unsigned long long long_nnz;
   unsigned long long block_nnz;  // nonzeros of the one-workgroup-per-row classes
   unsigned long long total;   // nnz of the shard
@@ -119,11 +114,10 @@ constexpr int CS_TILE = 256 * CS_ITEMS;
 template <typename I>
 __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ rec, I *__restrict__ rpo,
                                                        I *__restrict__ sp, int64_t nr, I *__restrict__ long_rows,
-                                                       I *__restrict__ block_rows, int64_t block_stride,
-                                                       const ClassCaps caps, PermState *__restrict__ st,
-                                                       unsigned long long *status, int64_t tiles, int rpo_aligned) {
-  constexpr int NC = BR_MAXC + 1;  // class BR_MAXC = rows for the long-row path
-  const int block_cap = caps.cap[caps.n - 1];
+                                                       I *__restrict__ block_rows, int64_t block_stride, int block_cap,
+                                                       PermState *__restrict__ st, unsigned long long *status,
+                                                       int64_t tiles, int rpo_aligned) {
+  constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
   __shared__ unsigned s_cnt[NC], s_base[NC];
   __shared__ unsigned long long s_long_nnz, s_block_nnz;
   __shared__ I s_rows[NC][RC_STAGE];
@@ -240,7 +234,7 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
   auto flush = [&]() {  // all threads; leaves the stage empty
     __syncthreads();
     if (tid < NC && s_cnt[tid]) {
-      unsigned *counter = tid < BR_MAXC ? &st->n_block[tid] : &st->n_long;
+      unsigned *counter = tid < BR_CLASSES ? &st->n_block[tid] : &st->n_long;
       s_base[tid] = atomicAdd(counter, s_cnt[tid]);
     }
     if (tid == 0 && s_long_nnz) {
@@ -253,7 +247,7 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
     }
     __syncthreads();
     for (int c = 0; c < NC; c++) {
-      I *list = c < BR_MAXC ? block_rows + (int64_t)c * block_stride : long_rows;
+      I *list = c < BR_CLASSES ? block_rows + (int64_t)c * block_stride : long_rows;
       for (unsigned k = tid; k < s_cnt[c]; k += 256) list[s_base[c] + k] = s_rows[c][k];
     }
     __syncthreads();
@@ -265,13 +259,13 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
     const int64_t i = base + k;
     const int dd = d[k];
     if (i < nr && dd > PT_LMAX) {
-      int cls = BR_MAXC;
+      int cls = BR_CLASSES;
       if (dd <= block_cap) {
         cls = 0;
-        while (dd > caps.cap[cls]) cls++;
+        while (dd > br_cap(cls)) cls++;
       }
       s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
-      atomicAdd(cls == BR_MAXC ? &s_long_nnz : &s_block_nnz, (unsigned long long)dd);
+      atomicAdd(cls == BR_CLASSES ? &s_long_nnz : &s_block_nnz, (unsigned long long)dd);
     }
     __syncthreads();
     bool full = false;
@@ -1475,8 +1469,6 @@ __global__ __launch_bounds__(1024) void k_permute_rows_radix(
   }
 }
 
-#include "sbx_permute_rows5.h"
-
 // ---- long rows ----------------------------------------------------------------
 // flat over the nonzeros of all long rows (a workgroup per row would leave the longest row as a straggler)
 template <typename I, int VB>
@@ -2072,151 +2064,6 @@ int long_rows_radix_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in,
 }
 
 
-
-// capacity classes of k_rows3: slots = threads x items, in steps of about 1.5 (a row fills 67 - 100 % of its slots)
-// capacity classes of k_rows5: slots = 64 lanes x items x waves, in steps of about 1.5 (a row fills 67 - 100 % of its
-// slots); the classes whose LDS fits (r5_deep) run two rows ahead of the sort
-struct R5Class { int cap, threads, items; };
-static const R5Class r5_classes[] = {{256, 64, 4},   {512, 128, 4},  {768, 192, 4},   {1024, 256, 4},  {1536, 384, 4},
-                                     {2048, 512, 4}, {3072, 768, 4}, {4096, 1024, 4}, {6144, 768, 8},  {8192, 1024, 8}};
-constexpr int R5_NCLASSES = (int)(sizeof(r5_classes) / sizeof(r5_classes[0]));
-static_assert(R5_NCLASSES <= BR_MAXC, "class lists");
-static bool permute_rows5() {  // SBX_PERMUTE_ROWS5=0: round 2's row kernels (k_permute_block_rows)
-  static const bool on = !(getenv("SBX_PERMUTE_ROWS5") && atoi(getenv("SBX_PERMUTE_ROWS5")) == 0);
-  return on;
-}
-
-static ClassCaps permute_class_caps(int vb) {
-  ClassCaps c;
-  memset(&c, 0, sizeof(c));
-  if (permute_rows5()) {
-    c.n = vb == 8 ? R5_NCLASSES - 2 : R5_NCLASSES;  // 8-byte values: at most 4096 entries (the capacity of the radix kernel behind)
-    for (int i = 0; i < c.n; i++) c.cap[i] = r5_classes[i].cap;
-  } else {
-    c.n = vb == 8 ? BR_CLASSES - 1 : BR_CLASSES;
-    for (int i = 0; i < c.n; i++) c.cap[i] = br_cap(i);
-  }
-  return c;
-}
-
-template <typename K>
-static int r5_allow_lds(sbx_handle_t h, K kernel, bool *done) {
-  if (!*done) {
-    SBX_HIP(h, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    *done = true;
-  }
-  return SBX_OK;
-}
-
-#ifndef R5_MINW4
-#define R5_MINW4 5
-#endif
-static int r5_nbw(const R5Class &cls) {  // counter words of a class: the power of two at or above its slots
-  int nbw = 256;
-  while (nbw < cls.cap) nbw <<= 1;
-  return nbw;
-}
-static int r5_deep_cap() {  // SBX_PERMUTE_DEEP_CAP: largest class that runs two rows ahead (tuning)
-  static const int v = getenv("SBX_PERMUTE_DEEP_CAP") ? atoi(getenv("SBX_PERMUTE_DEEP_CAP")) : 4096;
-  return v;
-}
-static bool r5_deep(const R5Class &cls, int vb) {
-  return cls.items == 4 && cls.cap <= r5_deep_cap() &&
-         r5_lds_bytes(cls.threads, cls.items, vb, r5_nbw(cls), true) <= 159 * 1024;
-}
-// one launch of k_rows5 for the rows (or long-row segments) of one capacity class
-template <int VB>
-int launch_rows5(sbx_handle_t h, int kid, const R5Class &cls, unsigned grid, const int2 *rec, const int32_t *col_in,
-                 const char *val_in, const int32_t *col_order, const int32_t *rpo, const int32_t *list, int n_rows,
-                 int32_t *col_out, char *val_out, PermState *st, int force, unsigned *fb_rows, unsigned *fb_count,
-                 const unsigned *n_rows_dev) {
-  const int nbw = r5_nbw(cls);
-  const bool deep = r5_deep(cls, VB);
-  const size_t lds = r5_lds_bytes(cls.threads, cls.items, VB, nbw, deep);
-  static bool allowed[3] = {false, false, false};
-#define R5_GO(ITEMS, MINW, DEEPX, SLOT)                                                                              \
-  {                                                                                                                  \
-    SBX_TRY(r5_allow_lds(h, k_rows5<VB, ITEMS, MINW, DEEPX>, &allowed[SLOT]));                                       \
-    if (h->prof_on) sbx_prof_begin(h, kid);                                                                          \
-    hipLaunchKernelGGL((k_rows5<VB, ITEMS, MINW, DEEPX>), dim3(grid), dim3((unsigned)cls.threads), lds, h->stream,   \
-                       rec, col_in, val_in, col_order, rpo, list, n_rows, col_out, val_out, st, force, fb_rows,      \
-                       fb_count, n_rows_dev, nbw);                                                                   \
-    if (h->prof_on) sbx_prof_end(h);                                                                                 \
-  }
-  if (cls.items == 4 && deep) R5_GO(4, R5_MINW4, true, 0)
-  else if (cls.items == 4) R5_GO(4, R5_MINW4, false, 1)
-  else R5_GO(8, 4, false, 2)
-#undef R5_GO
-  return SBX_OK;
-}
-// resident workgroups of a class per CU: LDS and the waves its registers allow
-static unsigned r5_per_cu(const R5Class &cls, int vb) {
-  const unsigned waves = (unsigned)cls.threads / 64u;
-  const unsigned by_lds = (unsigned)(159 * 1024 / (r5_lds_bytes(cls.threads, cls.items, vb, r5_nbw(cls), r5_deep(cls, vb)) + 64));
-  const unsigned by_waves = (cls.items == 4 ? 4u * R5_MINW4 : 16u) / waves;
-  const unsigned r = by_lds < by_waves ? by_lds : by_waves;
-  return r < 1 ? 1 : r;
-}
-
-// rows of PT_LMAX < length <= 8 K, k_rows5: one workgroup per row, by capacity class
-template <int VB>
-int rows5_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
-               const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *block_rows,
-               const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st, bool fork) {
-  typedef int32_t I;
-  hipStream_t base = h->stream;  // (fork: side stream 0, which already waits for the fork event)
-  const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
-  const int force = permute_force_radix() & 0xFF;
-  const ClassCaps caps = permute_class_caps(VB);
-  size_t n_all = 0;
-  for (int c = 0; c < caps.n; c++) n_all += n_block[c];
-  unsigned *fb_rows = nullptr;  // rows with clustered or duplicate columns (listed by the class kernels, sorted by the radix kernel)
-  SBX_TRY(sbx_salloc(h, n_all + 1, &fb_rows));
-  static const int side[6] = {0, 2, 3, 4, 5, 6};  // side streams of the classes (1 belongs to the long rows)
-  int used = 0;
-  for (int c = caps.n - 1; c >= 0; c--) {  // the classes with the fattest workgroups first
-    if (!n_block[c]) continue;
-    const R5Class &cls = r5_classes[c];
-    unsigned grid = (unsigned)h->num_cus * r5_per_cu(cls, VB) * (unsigned)permute_grid_factor();
-    if (grid > n_block[c]) grid = n_block[c];
-    const int si = side[used++ % 6];
-    if (fork && si) {
-      h->stream = h->aux_stream[si];
-      SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[0], 0));
-    }
-    const int rc = launch_rows5<VB>(h, SBX_K_PERMUTE_BLOCK, cls, grid, rec, col_in, val_in, col_order, rpo,
-                                    block_rows + (int64_t)c * block_stride, (int)n_block[c], col_out, val_out, st, force,
-                                    fb_rows, &st->n_fb_rows, (const unsigned *)nullptr);
-    if (fork && si) {
-      const hipError_t e1_ = hipEventRecord(h->aux_event[1 + si], h->stream);
-      const hipError_t e2_ = hipStreamWaitEvent(base, h->aux_event[1 + si], 0);
-      h->stream = base;
-      if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");
-    }
-    SBX_TRY(rc);
-#ifdef R5_STAMPS
-    {
-      unsigned long long hs_[32];
-      SBX_HIP(h, hipDeviceSynchronize());
-      SBX_HIP(h, hipMemcpyFromSymbol(hs_, HIP_SYMBOL(g_r5_stamps), sizeof(hs_)));
-      if (hs_[31]) {
-        fprintf(stderr, "r5 stamps class %d (%d threads): rows %llu | cycles per phase:", cls.cap, cls.threads, hs_[31]);
-        for (int i = 0; i < 13; i++) fprintf(stderr, " [%d] %.0f", i, (double)hs_[i] / (double)hs_[31]);
-        fprintf(stderr, "\n");
-      }
-      memset(hs_, 0, sizeof(hs_));
-      SBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_r5_stamps), hs_, sizeof(hs_)));
-    }
-#endif
-  }
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_rows_radix<I, VB>), dim3((unsigned)(n_all < 512 ? n_all : 512)),
-              dim3(1024), rec, col_in, val_in, col_order, rpo, (const unsigned *)fb_rows, col_out, val_out, col_bits, st,
-              (const unsigned *)&st->n_fb_rows);
-  SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_PERMUTE_BLOCK, block_nnz * (int64_t)(2 * (sizeof(I) + VB)));
-  return SBX_OK;
-}
-
 static bool permute_long_segments() {  // SBX_PERMUTE_LONG_SEGMENTS=0: long rows always take the global radix sort
   static const bool on = !(getenv("SBX_PERMUTE_LONG_SEGMENTS") && atoi(getenv("SBX_PERMUTE_LONG_SEGMENTS")) == 0);
   return on;
@@ -2279,27 +2126,15 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
               (const unsigned *)row_skip, c2, v2);
   // the segments: virtual rows of the one-workgroup-per-row kernel (columns already relabelled: no column map)
   const int force = permute_force_radix() & 0xFE;
-  if (permute_rows5()) {
-    const R5Class c4 = {4096, 1024, 4}, c8 = {8192, 1024, 8};
-    SBX_TRY(launch_rows5<VB>(h, SBX_K_PERMUTE_LONG, c4, (unsigned)h->num_cus * r5_per_cu(c4, VB), (const int2 *)vrec,
-                             (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist, 0,
-                             col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]));
-    if constexpr (VB != 8)
-      SBX_TRY(launch_rows5<VB>(h, SBX_K_PERMUTE_LONG, c8, (unsigned)h->num_cus * r5_per_cu(c8, VB), (const int2 *)vrec,
-                               (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
-                               (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
-                               (const unsigned *)&st->n_seg[1]));
-  } else {
-    // (1024-thread workgroups: one resident per CU, as in block_rows_path)
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
-                (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
-                0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
-    if constexpr (VB != 8) {
-      SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
-                  dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
-                  (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
-                  (const unsigned *)&st->n_seg[1]);
-    }
+  // (1024-thread workgroups: one resident per CU, as in block_rows_path)
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
+              (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
+              0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
+  if constexpr (VB != 8) {
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
+                dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
+                (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
+                (const unsigned *)&st->n_seg[1]);
   }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_rows_radix<I, VB>), dim3(256), dim3(1024), (const int2 *)vrec,
               (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const unsigned *)fb_rows, col_out,
@@ -2333,7 +2168,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   // tails and the long-row path's short, latency-bound launches hide behind the tile kernel.  While the
   // profiler is on they run back to back, so that a kernel's event time is its own.
   bool has_block = false;
-  for (int c = 0; c < BR_MAXC; c++) has_block |= n_block[c] != 0;
+  for (int c = 0; c < BR_CLASSES; c++) has_block |= n_block[c] != 0;
   const bool fork = !h->prof_on && permute_overlap() && total > 0 && (has_block || n_long);
   (void)total;
   hipStream_t main_stream = h->stream;
@@ -2381,11 +2216,8 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   }
   if (has_block) {
     if (fork) h->stream = h->aux_stream[0];
-    const int rc = permute_rows5()
-                       ? rows5_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
-                                        block_stride, block_nnz, st, fork)
-                       : block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows,
-                                             n_block, block_stride, block_nnz, st, fork);
+    const int rc = block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
+                                       block_stride, block_nnz, st, fork);
     if (fork) {
       if (rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
       h->stream = main_stream;
@@ -2415,13 +2247,13 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
 // st must have been zeroed by the caller
 template <typename I>
 int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr, I *long_rows, I *block_rows,
-                      int64_t block_stride, const ClassCaps &caps, PermState *st) {
+                      int64_t block_stride, int block_cap, PermState *st) {
   const int64_t tiles = (nr + CS_TILE - 1) / CS_TILE > 0 ? (nr + CS_TILE - 1) / CS_TILE : 1;
   unsigned long long *status = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)(tiles + 2), &status));
   SBX_HIP(h, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 2), h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_scan<I>, dim3((unsigned)tiles), dim3(256), rec, rpo, sp, nr, long_rows,
-              block_rows, block_stride, caps, st, status, tiles, (int)(((uintptr_t)rpo & 15) == 0));
+              block_rows, block_stride, block_cap, st, status, tiles, (int)(((uintptr_t)rpo & 15) == 0));
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
@@ -2502,14 +2334,14 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256), (const I *)row_ptr,
               (const I *)row_order, n, row_begin, nr, rec);
   I *long_rows = nullptr, *block_rows = nullptr, *sp = nullptr;
-  const ClassCaps block_cap = permute_class_caps(vb);
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   int64_t block_stride = 0;
   SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
   if (col_order) {  // the sorting pipeline needs the rows that do not fit a tile listed by class
     int64_t cap_long = nnz / PT_LMAX + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
-    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_MAXC, &block_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
   }
   // lengths -> row_ptr_out, the short rows' prefix sums and the class lists: one launch
@@ -2550,7 +2382,7 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
     int64_t cap_long = nnz / PT_LMAX + 1;
     if (cap_long > nr) cap_long = nr;
     SBX_TRY(sbx_salloc(h, (size_t)cap_long, &long_rows));
-    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_MAXC, &block_rows));
+    SBX_TRY(sbx_salloc(h, (size_t)cap_long * BR_CLASSES, &block_rows));
     block_stride = cap_long;
     SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));
     SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, nr, long_rows, block_rows, block_stride,
@@ -2595,12 +2427,12 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   PermState *st = nullptr;
   I *long_rows = nullptr, *block_rows = nullptr, *ctmp = nullptr;
   int2 *rec = nullptr;
-  const ClassCaps block_cap = permute_class_caps(vb);
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   char *vtmp = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_TRY(sbx_salloc(h, (size_t)n, &rec));
   SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
-  SBX_TRY(sbx_salloc(h, (size_t)n * BR_MAXC, &block_rows));
+  SBX_TRY(sbx_salloc(h, (size_t)n * BR_CLASSES, &block_rows));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(PermState), h->stream));

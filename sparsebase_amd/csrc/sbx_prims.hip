@@ -666,8 +666,15 @@ int sbx_radix_sort_io(sbx_handle_t h, int key_bytes, int payload_bytes, const sb
                       const sbx_radix_pass *passes, int num_passes) {
   if (!src || !dst || num_passes < 1 || count < 2 || src->k_split != dst->k_split || src->p_split != dst->p_split)
     SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_io: bad sides");
-  if (num_passes == 1 && (src->k[0] == dst->k[0] || (payload_bytes && src->p[0] == dst->p[0])))
-    SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_io: a single pass cannot sort in place");
+  if (num_passes == 1) {  // one pass reads the source side and writes the destination side: no array may be on both
+    const void *ins[4] = {src->k[0], src->k_split ? src->k[1] : nullptr, payload_bytes ? src->p[0] : nullptr,
+                          (payload_bytes && src->p_split) ? src->p[1] : nullptr};
+    const void *outs[4] = {dst->k[0], dst->k_split ? dst->k[1] : nullptr, payload_bytes ? dst->p[0] : nullptr,
+                           (payload_bytes && dst->p_split) ? dst->p[1] : nullptr};
+    for (const void *a : ins)
+      for (const void *b : outs)
+        if (a && a == b) SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_radix_sort_io: a single pass cannot sort in place");
+  }
   if (key_bytes == 8 && src->k_split && !src->p_split) {
     if (payload_bytes == 0)
       return radix_sort_io_impl<uint64_t, uint32_t, 8, false, true, false>(h, src, (uint64_t *)keys_a, (uint64_t *)keys_b,

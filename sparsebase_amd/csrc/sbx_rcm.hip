@@ -79,6 +79,7 @@ struct RcmDev {
   unsigned cone_k, cone_status;   // k_ubfs_cone_run: the level it stopped at (its list is too long for it) / UR_DONE
   unsigned bar;                 // grid barrier of k_ubfs_descend_all
   unsigned gb_abort;            // a grid barrier gave up waiting (see gb_wait): the host redoes the sweep the safe way
+  unsigned root_next;           // what k_ubfs_descend_all found: committed to `root` by the host once the walk is known to have finished
   unsigned gb_spins;            // how many polls a barrier waits (k_ubfs_start sets it; SBX_DEBUG_GB_SPINS for tests)
   // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
   unsigned ur_bar, ur_exit;
@@ -2225,10 +2226,13 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
     w = __hip_atomic_load(&dv->desc[k % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (not dv->root: if the LAST barrier gave up on the other workgroups while this one passed it, the host redoes the
+    // sweep from the root it still expects there)
     if (w == 0xFFFFFFFFu) dv->unsym = 1;  // cannot happen on a symmetric pattern
-    else dv->root = w;
+    else dv->root_next = w;
   }
 }
+__global__ void k_ubfs_commit_root(RcmDev *__restrict__ dv) { dv->root = dv->root_next; }
 
 // after a grid barrier gave up: the words the persistent kernels leave zero when they finish normally
 __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
@@ -2650,7 +2654,10 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
     h->rcm_gb_backoff = 16;
     *aborted = true;
+  } else if (!hd.unsym) {
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_commit_root, dim3(1), dim3(1), b.dv);
   }
+  SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 

@@ -115,7 +115,8 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
  public:
   // The sharded form of GetPermutation (one call per rank, every rank holding the same HIPCSR and order vectors):
   // this rank permutes its own new-row range and the ranks all-gather row_ptr (sbx_permute_csr_sharded).
-  // row_splits: world + 1 new-row boundaries, or nullptr for equal ranges.  Caller owns the result.
+  // row_splits: world + 1 new-row boundaries, or nullptr: ranges of equal ENTRY counts, computed on the device
+  // (sbx_balanced_row_splits; SURVEY §8e: balance by nnz, not rows).  Caller owns the result.
   ShardedHIPCSR<IDType, NNZType, ValueType> *GetPermutationSharded(format::HIPCSR<IDType, NNZType, ValueType> *csr,
                                                                     context::HIPCommunicator &comm,
                                                                     const int64_t *row_splits = nullptr) {
@@ -125,9 +126,16 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
     auto &dev = *v.dev;
     const int rank = comm.rank(), world = comm.world();
     std::vector<int64_t> splits(world + 1);
-    for (int r = 0; r <= world; r++)
-      splits[r] = row_splits ? row_splits[r] : (int64_t)v.n / world * r + std::min<int64_t>(r, (int64_t)v.n % world);
     IDType *d_ro = params->row_order ? dev.Upload(params->row_order, (size_t)v.n) : nullptr;
+    if (row_splits) {
+      for (int r = 0; r <= world; r++) splits[r] = row_splits[r];
+    } else {
+      const int rs = sbx_balanced_row_splits(dev.handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, d_ro, world, splits.data());
+      if (rs != SBX_OK) {
+        if (d_ro) dev.Free(d_ro);
+        dev.Check(rs);
+      }
+    }
     IDType *d_co = nullptr;
     if (params->col_order) d_co = (params->col_order == params->row_order && v.n == v.m)
                                       ? d_ro

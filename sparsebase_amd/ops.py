@@ -474,6 +474,39 @@ def coo_to_csr_sharded(comm, n, m, row, col, val, ranges=None, out=None, capacit
     return rpo, co[:k], (None if vo is None else vo[:k]), offs
 
 
+def csr_to_coo_sharded(comm, n, m, row_ptr, col, val, ranges=None, out=None, capacity=None):
+    """sbx_csr_to_coo_sharded on a replicated CSR: this rank's slab of the COO (global row ids).
+    Returns (row, col, val slabs, shard offsets list)."""
+    hd = handle_for(_check_dev(row_ptr, col, val))
+    rank, world = C.c_int(0), C.c_int(0)
+    hd.lib.sbx_comm_rank(comm.c, C.byref(rank), C.byref(world))
+    if out is None:
+        if capacity is None:
+            lo, hi = ranges[rank.value] if ranges is not None else _equal_range(n, world.value, rank.value)
+            capacity = int(row_ptr[hi] - row_ptr[lo])
+        ro = torch.empty(max(capacity, 1), dtype=row_ptr.dtype, device=row_ptr.device)
+        co = torch.empty(max(capacity, 1), dtype=col.dtype, device=col.device)
+        vo = None if val is None else torch.empty(max(capacity, 1), dtype=val.dtype, device=val.device)
+    else:
+        ro, co, vo = out
+        capacity = co.numel()
+    offs = (C.c_int64 * (world.value + 1))()
+    hd.check(hd.lib.sbx_csr_to_coo_sharded(hd.h, comm.c, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
+                                           _p(val), _splits(ranges), _p(ro), _p(co), _p(vo), capacity, offs))
+    offs = list(offs)
+    k = offs[rank.value + 1] - offs[rank.value]
+    return ro[:k], co[:k], (None if vo is None else vo[:k]), offs
+
+
+def balanced_row_splits(n, row_ptr, row_order, world):
+    """sbx_balanced_row_splits: new-row ranges of (nearly) equal entry counts, as a list of (lo, hi)."""
+    hd = handle_for(_check_dev(row_ptr, row_order))
+    cuts = (C.c_int64 * (world + 1))()
+    hd.check(hd.lib.sbx_balanced_row_splits(hd.h, _it(row_ptr), n, _p(row_ptr), _p(row_order), world, cuts))
+    cuts = list(cuts)
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
 def _equal_range(n, world, rank):
     base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)

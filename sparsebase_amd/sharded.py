@@ -33,9 +33,16 @@ def row_ranges(n, world_size):
     return out
 
 
+def balanced_row_ranges_device(n, row_ptr, row_order, world_size):
+    """Ranges balanced by nnz instead of rows (power-law inputs), computed behind the C ABI
+    (sbx_balanced_row_splits: scatter of the new rows' lengths, scan, one search per split — all on the device)."""
+    from . import ops
+    return ops.balanced_row_splits(n, row_ptr, row_order, world_size)
+
+
 def balanced_row_ranges(new_row_lengths_prefix, world_size):
-    """Ranges balanced by nnz instead of rows (power-law inputs): split points are
-    found on the host from the scanned new-row lengths (a length n+1 CPU tensor)."""
+    """Host-language restatement of sbx_balanced_row_splits for the CPU gloo tests: split points
+    from the scanned new-row lengths (a length n+1 CPU tensor)."""
     total = int(new_row_lengths_prefix[-1])
     n = new_row_lengths_prefix.numel() - 1
     cuts = [0]
@@ -165,19 +172,29 @@ def coo_to_csr_sharded(n, m, row, col, val, group=None, ranges=None, shard_fn=No
     return grp, lcol, lval, (lo, hi), offsets
 
 
-def csr_to_coo_sharded(n, m, row_ptr, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False):
+def csr_to_coo_sharded(n, m, row_ptr, col, val, group=None, ranges=None, shard_fn=None, gather_entries=False, comm=None,
+                       out=None):
     """Sharded CSR -> COO: rank r expands the row ids of rows [lo_r, hi_r) (nonzeros
     [row_ptr[lo], row_ptr[hi])); no collective is needed unless the caller wants every rank to hold the
-    whole COO (gather_entries).  Returns (local_row, local_col, local_val, (lo, hi), (a, b))."""
+    whole COO (gather_entries).  Product path (shard_fn is None): one call of sbx_csr_to_coo_sharded.
+    Returns (local_row, local_col, local_val, (lo, hi), (a, b))."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ranges = row_ranges(n, world) if ranges is None else ranges
     lo, hi = ranges[rank]
-    a, b = int(row_ptr[lo]), int(row_ptr[hi])
     if shard_fn is None:
-        def shard_fn(lo_, hi_, a_, b_):
-            return csr_to_coo_shard(m, row_ptr, col, val, lo_, hi_, a_, b_)
-    lrow, lcol, lval = shard_fn(lo, hi, a, b)
+        from . import ops
+        own = comm is None
+        comm = make_comm(row_ptr.device.index, group) if own else comm
+        try:
+            lrow, lcol, lval, offs = ops.csr_to_coo_sharded(comm, n, m, row_ptr, col, val, ranges=ranges, out=out)
+        finally:
+            if own:
+                comm.close()
+        a, b = offs[rank], offs[rank + 1]
+    else:
+        a, b = int(row_ptr[lo]), int(row_ptr[hi])
+        lrow, lcol, lval = shard_fn(lo, hi, a, b)
     if gather_entries:
         cuts = torch.tensor([int(row_ptr[l]) for l, _ in ranges] + [int(row_ptr[ranges[-1][1]])], dtype=torch.int64,
                             device=row_ptr.device)

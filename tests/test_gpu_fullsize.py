@@ -146,7 +146,7 @@ def test_c5_gray_end_to_end_100m_banded(oracle, tmp_path, half_bandwidth):
         assert np.array_equal(got, want), (half_bandwidth, params)
 
 
-def test_c4_one_of_eight_shards_of_1b_nnz(ops):
+def test_c4_one_of_eight_shards_of_1b_nnz(ops, oracle):
     """BASELINE config 4's per-rank workload on this one GPU: the scale-25 RMAT instance (~1.18 B nnz, 33.5 M rows),
     a seeded random permutation, one of the 8 new-row shards through sbx_permute_csr_rows — the properties of
     test_c3_permute_100m_properties on the shard plus the consistency of the 8 shard sizes / offsets.  (The stitch of
@@ -165,9 +165,16 @@ def test_c4_one_of_eight_shards_of_1b_nnz(ops):
     deg_new[perm.long()] = deg_old                       # length of every new row
     offsets = torch.zeros(9, dtype=torch.int64)
     offsets[1:] = torch.cumsum(torch.tensor(sizes), 0)
-    for r in (3,):
+    for r in range(8):  # every rank's slab size = the entries of its new rows
         a, b = ranges[r]
         assert int(deg_new[a:b].long().sum()) == sizes[r]
+    # the nnz-balanced ranges of the device (what bench.py --gpus 8 and Permute2DSharded use): within one hub row of 1/8
+    bal = sharded.balanced_row_ranges_device(n, rp, perm, 8)
+    bal_sizes = [ops.permute_csr_rows_nnz(n, rp, perm, a, b) for a, b in bal]
+    assert sum(bal_sizes) == nnz and bal[0][0] == 0 and bal[-1][1] == n
+    assert max(bal_sizes) - min(bal_sizes) <= 2 * int(deg_old.max())
+    for r in (3,):
+        a, b = ranges[r]
         srp, scol, sval = ops.permute_csr_rows(n, n, rp, col, val, perm, perm, a, b)
         k = sizes[r]
         assert scol.numel() == k and int(srp[0]) == 0 and int(srp[-1]) == k
@@ -188,3 +195,17 @@ def test_c4_one_of_eight_shards_of_1b_nnz(ops):
         # row-wise only (the segmented copy): same lengths, every row still sorted
         rrp, rcol, _ = ops.permute_csr_rows(n, n, rp, col, val, perm, None, a, b)
         assert torch.equal(rrp, srp) and ops.csr_rows_sorted(rrp, rcol)
+        del rrp, rcol
+        # BIT-EXACT: the old rows that map into the shard as a CSR of their own, permuted by the oracle
+        in_shard = (perm >= a) & (perm < b)
+        sub_deg = deg_old[in_shard].long()
+        sub_rp = np.zeros(b - a + 1, np.int32)
+        sub_rp[1:] = torch.cumsum(sub_deg, 0).cpu().numpy()
+        entry_in = torch.repeat_interleave(in_shard, deg_old.long())
+        sub_col, sub_val = col[entry_in].cpu().numpy(), val[entry_in].cpu().numpy()
+        sub_order = (perm[in_shard] - a).cpu().numpy()
+        del entry_in
+        want = oracle.permute_csr(sub_rp, sub_col, sub_val, sub_order, perm.cpu().numpy())
+        assert np.array_equal(srp.cpu().numpy(), want[0])
+        assert np.array_equal(scol.cpu().numpy(), want[1])
+        assert np.array_equal(sval.cpu().numpy(), want[2])

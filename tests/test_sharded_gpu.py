@@ -35,6 +35,7 @@ def _child(rank, world, port, q):
         want = orc.permute_csr(rp, col, val, order, order)
         comm = sharded.make_comm(0)
         ok, notes = True, []
+        capi_bad_arg, capi_internal = 1, 6
 
         def check(tag, cond):
             nonlocal ok
@@ -69,6 +70,33 @@ def _child(rank, world, port, q):
             a, b = int(rp[lo]), int(rp[hi])
             check(f"coo rp {ranges}", np.array_equal(h(grp), rp))
             check(f"coo col {ranges}", np.array_equal(h(lcol), col[a:b]) and np.array_equal(h(lval), val[a:b]))
+        # CSR -> COO by row range behind the C ABI (sbx_csr_to_coo_sharded), 32- and 64-bit indices, ragged ranges
+        for idt in (np.int32, np.int64):
+            for ranges in (None, [(0, 7), (7, n)], [(0, n), (n, n)]):
+                lrow, lcol, lval, (lo, hi), (a, b) = sharded.csr_to_coo_sharded(n, n, d(rp.astype(idt)), d(col.astype(idt)),
+                                                                                d(val), ranges=ranges, comm=comm)
+                check(f"csr->coo bounds {idt} {ranges}", (a, b) == (int(rp[lo]), int(rp[hi])))
+                check(f"csr->coo row {idt} {ranges}", np.array_equal(h(lrow), row[a:b].astype(idt)))
+                check(f"csr->coo col {idt} {ranges}", np.array_equal(h(lcol), col2[a:b].astype(idt)) and np.array_equal(h(lval), val2[a:b]))
+        # nnz-balanced ranges from the device (sbx_balanced_row_splits) = the host restatement on the oracle's row_ptr
+        for idt in (np.int32, np.int64):
+            for w in (2, 3, 8):
+                got = sharded.balanced_row_ranges_device(n, d(rp.astype(idt)), d(order.astype(idt)), w)
+                ref = sharded.balanced_row_ranges(torch.from_numpy(want[0].astype(np.int64)), w)
+                check(f"balanced splits {idt} {w}: {got} vs {ref}", got == ref)
+        # a rank whose slab does not fit: EVERY rank returns an error (nobody is left inside a collective)
+        from sparsebase_amd import capi
+        cap = ops.permute_csr_rows_nnz(n, d(rp), d(order), *sharded.row_ranges(n, world)[rank])
+        small = (torch.empty(n + 1, dtype=torch.int32).cuda(), torch.empty(max(cap - (5 if rank == 1 else 0), 1), dtype=torch.int32).cuda(),
+                 torch.empty(max(cap, 1), dtype=torch.float32).cuda())
+        try:
+            sharded.permute_csr_sharded(n, n, d(rp), d(col), d(val), d(order), d(order), comm=comm, out=small)
+            check("a failing rank must fail every rank", False)
+        except capi.SbxError as e:
+            check(f"status of rank {rank}: {e}", e.status == (capi_bad_arg if rank == 1 else capi_internal))
+        # ... and the communicator is still usable afterwards
+        grp, lcol, lval, (lo, hi), offs = sharded.permute_csr_sharded(n, n, d(rp), d(col), d(val), d(order), d(order), comm=comm)
+        check("after the failure", np.array_equal(h(grp), want[0]))
         comm.close()
         q.put((rank, ok, notes))
     except Exception as e:  # noqa: BLE001
@@ -126,3 +154,28 @@ def test_rccl_communicator_single_rank():
         assert np.array_equal(grp.cpu().numpy(), rp) and np.array_equal(lcol.cpu().numpy(), col)
     finally:
         comm.close()
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """bench.py --gpus 8 as the driver launches it (torch.distributed.run, 8 fresh processes), but over gloo with all
+    ranks on GPU 0 and a small matrix: the perm broadcast, the per-rank regeneration, the nnz-balanced ranges, slab
+    sizing, both sharded legs through the C ABI and the watchdog all run with 8 ranks; the line must carry both legs
+    without an error."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    env = dict(os.environ, SBX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scale", "16", "--steps", "2",
+           "--warmup", "1", "--leg-timeout", "240"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["value"] > 0
+    for leg in ("permute_apply", "convert_apply"):
+        assert line[leg] is not None and "error" not in line[leg], line[leg]
+    assert line["permute_apply"]["ranges"] == "nnz-balanced"

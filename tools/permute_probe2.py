@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Permute2D on the bench matrix, random and RCM order: whole-call time, per-kernel-group times (library profiler) and
-bit-for-bit comparison of the result against the round-2 row kernels (SBX_PERMUTE_V3=0 in a child process dumps the
-reference digests first).  SBX_PROBE_LIB=<name> picks a variant library (tools/build_variant.py)."""
+"""Permute2D on the bench matrix, random and RCM order: whole-call time, per-kernel-group times (library profiler) and a
+digest of the result (equal digests = bit-identical outputs across builds).  SBX_PROBE_LIB=<name> picks a variant
+library (tools/build_variant.py)."""
 import hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +23,7 @@ n, nnz = rp.numel() - 1, col.numel()
 val = torch.rand(nnz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
 rnd = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).to(torch.int32)
 rcm = ops.rcm_reorder(rp, col)
-tag = os.environ.get("SBX_PROBE_LIB", "product") + " rows5=" + os.environ.get("SBX_PERMUTE_ROWS5", "1")
+tag = os.environ.get("SBX_PROBE_LIB", "product")
 res = {"tag": tag}
 for name, perm in (("random", rnd), ("rcm", rcm)):
     out = (torch.empty_like(rp), torch.empty_like(col), torch.empty_like(val))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the permute row / tile kernels (diagnostic). usage: tools/pmc_rows3.sh <tag> [--rcm] -> gpurun_out/pmc_rows3_<tag>.txt
+# SQ counters of the permute row / tile kernels (diagnostic). usage: tools/pmc_sq.sh <tag> [--rcm] -> gpurun_out/pmc_sq_<tag>.txt
 set -u
 TAG=$1; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
@@ -10,9 +10,9 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
   i=$((i+1)); rm -rf /tmp/pmcr_$i
-  timeout 200 rocprofv3 --kernel-include-regex "k_rows3|k_permute_tile|k_permute_block|k_tile3" --pmc $set --output-format csv -d /tmp/pmcr_$i -o p -- python3 tools/permute_only.py "$@" > "$OUT/pmc_rows3_$i.log" 2>&1
+  timeout 200 rocprofv3 --kernel-include-regex "k_permute_tile|k_permute_block" --pmc $set --output-format csv -d /tmp/pmcr_$i -o p -- python3 tools/permute_only.py "$@" > "$OUT/pmc_sq_$i.log" 2>&1
 done
-python3 - > "$OUT/pmc_rows3_$TAG.txt" <<'PY'
+python3 - > "$OUT/pmc_sq_$TAG.txt" <<'PY'
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob("/tmp/pmcr_*/**/*counter_collection.csv", recursive=True):
@@ -25,4 +25,4 @@ for k in sorted(acc):
     print(k)
     print("   ", {c: round(v) for c, v in sorted(d.items())})
 PY
-cat "$OUT/pmc_rows3_$TAG.txt"
+cat "$OUT/pmc_sq_$TAG.txt"
