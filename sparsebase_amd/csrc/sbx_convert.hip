@@ -126,7 +126,20 @@ __global__ __launch_bounds__(CV_THREADS) void k_coo_to_csr(const I *__restrict__
     const int64_t i0 = q << 2;
     I r[4];
     const bool full = (i0 + 4 <= nnz);
-    if (full && ALIGNED16 && sizeof(I) == 4) {
+    if (full && ALIGNED16 && sizeof(I) == 8) {
+      const vec16 v0 = *(const vec16 *)(row + i0), v1 = *(const vec16 *)(row + i0 + 2);
+      r[0] = (I)(((uint64_t)v0.y << 32) | v0.x), r[1] = (I)(((uint64_t)v0.w << 32) | v0.z);
+      r[2] = (I)(((uint64_t)v1.y << 32) | v1.x), r[3] = (I)(((uint64_t)v1.w << 32) | v1.z);
+      if (!MOVE) {
+        *(vec16 *)(col_out + i0) = *(const vec16 *)(col + i0);
+        *(vec16 *)(col_out + i0 + 2) = *(const vec16 *)(col + i0 + 2);
+        if (VB == 4) *(vec16 *)(val_out + i0 * 4) = *(const vec16 *)(val + i0 * 4);
+        if (VB == 8) {
+          *(vec16 *)(val_out + i0 * 8) = *(const vec16 *)(val + i0 * 8);
+          *(vec16 *)(val_out + i0 * 8 + 16) = *(const vec16 *)(val + i0 * 8 + 16);
+        }
+      }
+    } else if (full && ALIGNED16 && sizeof(I) == 4) {
       const vec16 v = *(const vec16 *)(row + i0);
       r[0] = (I)v.x; r[1] = (I)v.y; r[2] = (I)v.z; r[3] = (I)v.w;
       if (!MOVE) {
@@ -330,18 +343,45 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
     if ((it) != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "%s: 64-bit indices not built yet", __func__); \
   } while (0)
 
-extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz, const void *row, const void *col,
-                                 int *sorted_host) {
-  if (!h) return SBX_ERR_BAD_ARG;
-  SBX_REQUIRE(h, sorted_host && nnz >= 0 && (nnz == 0 || (row && col)), "bad argument");
-  if (it == SBX_I64) return sbx_i64_coo_is_sorted(h, nnz, row, col, sorted_host);
+template <typename I>
+static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host) {
   SBX_TRY(sbx_arena_begin(h));
   *sorted_host = 1;
   if (nnz == 0) return SBX_OK;
   int *flag = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &flag));
   SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-  SBX_KLAUNCH(h, SBX_K_CHECK, k_coo_is_sorted<int32_t>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), (const int32_t *)row, (const int32_t *)col, nnz, flag);
+  SBX_KLAUNCH(h, SBX_K_CHECK, k_coo_is_sorted<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS),
+              (const I *)row, (const I *)col, nnz, flag);
+  SBX_LAUNCH_CHECK(h);
+  int f = 0;
+  SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
+  *sorted_host = !f;
+  return SBX_OK;
+}
+
+extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz, const void *row, const void *col,
+                                 int *sorted_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, sorted_host && nnz >= 0 && (nnz == 0 || (row && col)), "bad argument");
+  if (it == SBX_I64) return coo_is_sorted_typed<int64_t>(h, nnz, row, col, sorted_host);
+  return coo_is_sorted_typed<int32_t>(h, nnz, row, col, sorted_host);
+}
+
+template <typename I>
+static int csr_rows_sorted_typed(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host) {
+  SBX_TRY(sbx_arena_begin(h));
+  *sorted_host = 1;
+  if (n == 0) return SBX_OK;
+  I nnz_i = 0;
+  SBX_TRY(sbx_readback(h, &nnz_i, (const I *)row_ptr + n, sizeof(I)));  // nnz_ = row_ptr[n], csr.cc:86
+  const int64_t nnz = (int64_t)nnz_i;
+  if (nnz <= 0) return SBX_OK;
+  int *flag = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &flag));
+  SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  SBX_KLAUNCH(h, SBX_K_CHECK, k_csr_rows_sorted<I>, dim3((unsigned)((nnz + EX_TILE - 1) / EX_TILE)), dim3(CV_THREADS),
+              (const I *)row_ptr, (const I *)col, n, nnz, flag);
   SBX_LAUNCH_CHECK(h);
   int f = 0;
   SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
@@ -353,23 +393,9 @@ extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n,
                                    const void *col, int *sorted_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, sorted_host && n >= 0 && row_ptr, "bad argument");
-  if (it == SBX_I64) return sbx_i64_csr_rows_sorted(h, n, row_ptr, col, sorted_host);
-  SBX_TRY(sbx_arena_begin(h));
-  *sorted_host = 1;
-  if (n == 0) return SBX_OK;
-  int32_t nnz32 = 0;
-  SBX_TRY(sbx_readback(h, &nnz32, (const int32_t *)row_ptr + n, sizeof(int32_t)));  // nnz_ = row_ptr[n], csr.cc:86
-  const int64_t nnz = nnz32;
-  if (nnz == 0) return SBX_OK;
-  int *flag = nullptr;
-  SBX_TRY(sbx_salloc(h, 1, &flag));
-  SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-  SBX_KLAUNCH(h, SBX_K_CHECK, k_csr_rows_sorted<int32_t>, dim3((unsigned)((nnz + EX_TILE - 1) / EX_TILE)), dim3(CV_THREADS), (const int32_t *)row_ptr, (const int32_t *)col, n, nnz, flag);
-  SBX_LAUNCH_CHECK(h);
-  int f = 0;
-  SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
-  *sorted_host = !f;
-  return SBX_OK;
+  SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
+  if (it == SBX_I64) return csr_rows_sorted_typed<int64_t>(h, n, row_ptr, col, sorted_host);
+  return csr_rows_sorted_typed<int32_t>(h, n, row_ptr, col, sorted_host);
 }
 
 extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
@@ -414,49 +440,147 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
 
 namespace {
 
-template <int VB, bool MOVE>
-int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *row, const int32_t *col, const char *val,
-                      int32_t *rp, int32_t *col_out, char *val_out, GapEntry *gaps, unsigned *ngaps, unsigned gap_cap,
-                      int *unsorted) {
+template <typename I, int VB, bool MOVE>
+int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const I *row, const I *col, const char *val, I *rp,
+                      I *col_out, char *val_out, GapEntry *gaps, unsigned *ngaps, unsigned gap_cap, int *unsorted) {
   const bool al = aligned16(row) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const int64_t nquads = (nnz + 3) >> 2;
   const unsigned grid = sbx_grid_for(nquads, CV_THREADS, (int64_t)h->num_cus * 32);
   if (al)
-    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   else
-    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
-template <int VB, bool MOVE>
-int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *col, const char *val,
-                      int32_t *row_out, int32_t *col_out, char *val_out) {
+template <typename I, int VB, bool MOVE>
+int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const I *rp, const I *col, const char *val, I *row_out,
+                      I *col_out, char *val_out) {
   const bool al = aligned16(row_out) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const unsigned grid = (unsigned)((nnz + EX_TILE - 1) / EX_TILE);
   int2 *span = nullptr;
   if ((int64_t)grid >= EX_SPAN_MIN_TILES) {
     SBX_TRY(sbx_salloc(h, (size_t)grid, &span));
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, k_ex_tile_spans<int32_t>, dim3((grid + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS),
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, k_ex_tile_spans<I>, dim3((grid + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS),
                 rp, n, nnz, (int64_t)grid, span);
   }
   if (al)
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   else
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<int32_t, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
-__global__ __launch_bounds__(CV_THREADS) void k_row_hist_i32(const int32_t *__restrict__ row,
-                                                             int32_t *__restrict__ cnt, int64_t nnz) {
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_row_hist(const I *__restrict__ row, I *__restrict__ cnt, int64_t nnz) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < nnz; i += stride) atomicAdd(&cnt[row[i]], 1);
+  for (; i < nnz; i += stride) {
+    if constexpr (sizeof(I) == 4) atomicAdd((int *)&cnt[row[i]], 1);
+    else atomicAdd((unsigned long long *)&cnt[row[i]], 1ull);
+  }
+}
+
+// a largest-value reduction over an index array (the 64-bit entry points check row ids against n this way)
+template <typename I>
+__global__ __launch_bounds__(CV_THREADS) void k_any_outside(const I *__restrict__ a, int64_t count, int64_t limit,
+                                                            int *__restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < count; i += stride) bad |= (int64_t)a[i] < 0 || (int64_t)a[i] >= limit;
+  if (__any(bad) && sbx_lane() == 0) *flag = 1;
+}
+
+template <typename I>
+int fill_index(sbx_handle_t h, I *dst, int64_t value, int64_t count) {
+  if constexpr (sizeof(I) == 4) return sbx_fill_i32(h, (int32_t *)dst, (int32_t)value, count);
+  else return sbx_fill_i64(h, (int64_t *)dst, value, count);
+}
+template <typename I>
+int scan_index(sbx_handle_t h, I *a, int64_t count) {
+  if constexpr (sizeof(I) == 4) return sbx_exclusive_scan_i32(h, (const int32_t *)a, (int32_t *)a, count, nullptr);
+  else return sbx_exclusive_scan_i64(h, (const int64_t *)a, (int64_t *)a, count, nullptr);
+}
+
+// A2 for either index width (64-bit indices run natively: values of any size, no narrowed copies)
+template <typename I>
+int coo_to_csr_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row, const void *col,
+                     const void *val, void *row_ptr_out, void *col_out, void *val_out, unsigned flags) {
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
+  if (vb < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr: unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  I *rp = (I *)row_ptr_out;
+  if (nnz == 0) return fill_index<I>(h, rp, 0, n + 1);
+  const unsigned gap_cap = (unsigned)((n + 1) / GAP_INLINE + 2);
+  GapEntry *gaps = nullptr;
+  unsigned *ngaps = nullptr;
+  int *unsorted = nullptr;
+  SBX_TRY(sbx_salloc(h, gap_cap, &gaps));
+  SBX_TRY(sbx_salloc(h, 3, &ngaps));
+  unsorted = (int *)(ngaps + 1);
+  int *outside = (int *)(ngaps + 2);
+  SBX_HIP(h, hipMemsetAsync(ngaps, 0, 3 * sizeof(unsigned), h->stream));
+  const I *r = (const I *)row, *c = (const I *)col;
+  const char *v = (const char *)val;
+  I *co = (I *)col_out;
+  char *vo = (char *)val_out;
+  if (sizeof(I) == 8) {  // row ids index row_ptr: a 64-bit id outside [0, n) must not get that far
+    SBX_KLAUNCH(h, SBX_K_CHECK, k_any_outside<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r, nnz, n,
+                outside);
+    SBX_LAUNCH_CHECK(h);
+    int f = 0;
+    SBX_TRY(sbx_readback(h, &f, outside, sizeof(int)));
+    if (f) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr: a row id lies outside [0, n)");
+  }
+  int rc;
+  if (move) rc = launch_coo_to_csr<I, 0, true>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 0) rc = launch_coo_to_csr<I, 0, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 4) rc = launch_coo_to_csr<I, 4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else rc = launch_coo_to_csr<I, 8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  SBX_TRY(rc);
+  SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_fill_gaps<I>, dim3(256), dim3(CV_THREADS), rp, (const GapEntry *)gaps,
+              (const unsigned *)ngaps, gap_cap);
+  SBX_LAUNCH_CHECK(h);
+  if (!(flags & SBX_FLAG_ROWS_SORTED)) {
+    // unsorted row[] is only reachable with ignore_sort=true; the reference then
+    // still produces exclusive_scan(histogram(row)) (converter_order_two.cc:180-192)
+    int f = 0;
+    SBX_TRY(sbx_readback(h, &f, unsorted, sizeof(int)));
+    if (f) {
+      SBX_TRY(fill_index<I>(h, rp, 0, n + 1));
+      SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_row_hist<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r, rp,
+                  nnz);
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(scan_index<I>(h, rp, n + 1));
+    }
+  }
+  return SBX_OK;
+}
+
+template <typename I>
+int csr_to_coo_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                     const void *val, void *row_out, void *col_out, void *val_out, unsigned flags) {
+  const bool move = (flags & SBX_FLAG_MOVE) != 0;
+  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
+  if (vb < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_csr_to_coo: unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  if (nnz == 0) return SBX_OK;
+  const I *rp = (const I *)row_ptr, *c = (const I *)col;
+  const char *v = (const char *)val;
+  I *ro = (I *)row_out, *co = (I *)col_out;
+  char *vo = (char *)val_out;
+  if (move) return launch_csr_to_coo<I, 0, true>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 0) return launch_csr_to_coo<I, 0, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 4) return launch_csr_to_coo<I, 4, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  return launch_csr_to_coo<I, 8, false>(h, n, nnz, rp, c, v, ro, co, vo);
 }
 
 // ---------------------------------------------------------------- A14 COO -> CSC helpers
@@ -598,49 +722,11 @@ extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr_out && (nnz == 0 || row), "bad argument");
   SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
-  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
-  if (it == SBX_I64)
-    return sbx_i64_coo_to_csr(h, vt, n, m, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
-  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
-  SBX_REQUIRE(h, vb >= 0, "unknown value type");
-  SBX_TRY(sbx_arena_begin(h));
-  int32_t *rp = (int32_t *)row_ptr_out;
-  if (nnz == 0) return sbx_fill_i32(h, rp, 0, n + 1);
-  const unsigned gap_cap = (unsigned)((n + 1) / GAP_INLINE + 2);
-  GapEntry *gaps = nullptr;
-  unsigned *ngaps = nullptr;
-  int *unsorted = nullptr;
-  SBX_TRY(sbx_salloc(h, gap_cap, &gaps));
-  SBX_TRY(sbx_salloc(h, 2, &ngaps));
-  unsorted = (int *)(ngaps + 1);
-  SBX_HIP(h, hipMemsetAsync(ngaps, 0, 2 * sizeof(unsigned), h->stream));
-  const int32_t *r = (const int32_t *)row, *c = (const int32_t *)col;
-  const char *v = (const char *)val;
-  int32_t *co = (int32_t *)col_out;
-  char *vo = (char *)val_out;
-  int rc;
-  if (move) rc = launch_coo_to_csr<0, true>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else if (vb == 0) rc = launch_coo_to_csr<0, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else if (vb == 4) rc = launch_coo_to_csr<4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else rc = launch_coo_to_csr<8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  SBX_TRY(rc);
-  SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_fill_gaps<int32_t>, dim3(256), dim3(CV_THREADS), rp, (const GapEntry *)gaps,
-                     (const unsigned *)ngaps, gap_cap);
-  SBX_LAUNCH_CHECK(h);
-  if (!(flags & SBX_FLAG_ROWS_SORTED)) {
-    // unsorted row[] is only reachable with ignore_sort=true; the reference then
-    // still produces exclusive_scan(histogram(row)) (converter_order_two.cc:180-192)
-    int f = 0;
-    SBX_TRY(sbx_readback(h, &f, unsorted, sizeof(int)));
-    if (f) {
-      SBX_TRY(sbx_fill_i32(h, rp, 0, n + 1));
-      SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_row_hist_i32, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r,
-                         rp, nnz);
-      SBX_LAUNCH_CHECK(h);
-      SBX_TRY(sbx_exclusive_scan_i32(h, rp, rp, n + 1, nullptr));
-    }
-  }
-  return SBX_OK;
+  SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
+  if (it == SBX_I64)  // native 64-bit kernels: column ids and nnz of any size
+    return coo_to_csr_typed<int64_t>(h, vt, n, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31), "nnz exceeds int32");
+  return coo_to_csr_typed<int32_t>(h, vt, n, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
 }
 
 extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
@@ -651,21 +737,11 @@ extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || row_out), "bad argument");
   SBX_REQUIRE(h, move || nnz == 0 || (col && col_out), "col/col_out required for a copy conversion");
-  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
   if (it == SBX_I64)
-    return sbx_i64_csr_to_coo(h, vt, n, m, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
-  const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
-  SBX_REQUIRE(h, vb >= 0, "unknown value type");
-  SBX_TRY(sbx_arena_begin(h));
-  if (nnz == 0) return SBX_OK;
-  const int32_t *rp = (const int32_t *)row_ptr, *c = (const int32_t *)col;
-  const char *v = (const char *)val;
-  int32_t *ro = (int32_t *)row_out, *co = (int32_t *)col_out;
-  char *vo = (char *)val_out;
-  if (move) return launch_csr_to_coo<0, true>(h, n, nnz, rp, c, v, ro, co, vo);
-  if (vb == 0) return launch_csr_to_coo<0, false>(h, n, nnz, rp, c, v, ro, co, vo);
-  if (vb == 4) return launch_csr_to_coo<4, false>(h, n, nnz, rp, c, v, ro, co, vo);
-  return launch_csr_to_coo<8, false>(h, n, nnz, rp, c, v, ro, co, vo);
+    return csr_to_coo_typed<int64_t>(h, vt, n, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31), "nnz exceeds int32");
+  return csr_to_coo_typed<int32_t>(h, vt, n, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
 }
 
 // A14: COO -> CSC.  The reference sizes col_ptr by the ROW count (converter_order_two.cc:32-33) and so

@@ -1,9 +1,9 @@
 // sbx_i64.hip — SBX_I64 support: 64-bit IDType/NNZType arrays (the reference's
-// <int64,int64,double> tuple).  Every BASELINE configuration has n, m, nnz < 2^31, so
-// the 64-bit entry points narrow their index arrays to int32 scratch copies (with an
-// overflow check), run the int32 kernels and widen the index outputs back; values are
-// opaque payload and pass through untouched.  Arrays with entries >= 2^31 return
-// SBX_ERR_UNSUPPORTED (native 64-bit kernels: DESIGN.md "Next").
+// <int64,int64,double> tuple).  The conversions COO <-> CSR and the two sortedness checks run
+// NATIVE 64-bit kernels (sbx_convert.hip: index values and nnz of any size).  The other
+// entry points narrow their index arrays to int32 scratch copies (with an overflow check),
+// run the int32 kernels and widen the index outputs back; values are opaque payload and pass
+// through untouched; arrays with entries >= 2^31 return SBX_ERR_UNSUPPORTED there.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -94,14 +94,6 @@ struct Scope {  // leaves nesting mode on every return path
   int32_t *name = nullptr;           \
   if (want) SBX_TRY(sbx_salloc(h, (size_t)((count) > 0 ? (count) : 1), &name))
 
-int sbx_i64_coo_is_sorted(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host) {
-  I64_BEGIN();
-  NARROW(r, row, nnz);
-  NARROW(c, col, nnz);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_coo_is_sorted(h, SBX_I32, nnz, r, c, sorted_host);
-}
-
 int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
                      void *val) {
   I64_BEGIN();
@@ -117,16 +109,6 @@ static int read_nnz_i64(sbx_handle_t h, const void *row_ptr, int64_t n, int64_t 
   return sbx_readback(h, nnz, (const int64_t *)row_ptr + n, sizeof(int64_t));
 }
 
-int sbx_i64_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host) {
-  I64_BEGIN();
-  int64_t nnz = 0;
-  SBX_TRY(read_nnz_i64(h, row_ptr, n, &nnz));
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_csr_rows_sorted(h, SBX_I32, n, rp, c, sorted_host);
-}
-
 int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                           void *col, void *val) {
   I64_BEGIN();
@@ -135,36 +117,6 @@ int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t 
   SBX_TRY(sbx_i64_check(h, ovf));
   SBX_TRY(sbx_csr_sort_rows(h, SBX_I32, vt, n, m, nnz, rp, c, val));
   return sbx_widen_i32(h, c, col, nnz);
-}
-
-int sbx_i64_coo_to_csr(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
-                       const void *col, const void *val, void *row_ptr_out, void *col_out, void *val_out,
-                       unsigned flags) {
-  I64_BEGIN();
-  const bool move = (flags & SBX_FLAG_MOVE) != 0;
-  NARROW(r, row, nnz);
-  NARROW(c, move ? nullptr : col, nnz);
-  SCRATCH32(rp, n + 1, true);
-  SCRATCH32(co, nnz, !move && col_out);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_coo_to_csr(h, SBX_I32, vt, n, m, nnz, r, c, val, rp, co, val_out, flags));
-  SBX_TRY(sbx_widen_i32(h, rp, row_ptr_out, n + 1));
-  return sbx_widen_i32(h, co, col_out, nnz);
-}
-
-int sbx_i64_csr_to_coo(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                       const void *col, const void *val, void *row_out, void *col_out, void *val_out,
-                       unsigned flags) {
-  I64_BEGIN();
-  const bool move = (flags & SBX_FLAG_MOVE) != 0;
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, move ? nullptr : col, nnz);
-  SCRATCH32(ro, nnz, true);
-  SCRATCH32(co, nnz, !move && col_out);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_csr_to_coo(h, SBX_I32, vt, n, m, nnz, rp, c, val, ro, co, val_out, flags));
-  SBX_TRY(sbx_widen_i32(h, ro, row_out, nnz));
-  return sbx_widen_i32(h, co, col_out, nnz);
 }
 
 int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,

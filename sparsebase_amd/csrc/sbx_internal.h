@@ -230,6 +230,7 @@ struct sbx_radix_emit {
   unsigned *bits_a, *bits_b;
   unsigned *pos_of;
   uint32_t low_mask;  // low32(key) is ANDed with this first (0: all 32 bits) — keys whose fields are packed tightly
+  uint32_t pos_flip;  // non-zero: pos_of[value] = pos_flip - 1 - p (positions counted from the other end)
 };
 int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
                         int num_passes, const sbx_radix_emit *emit);
@@ -245,17 +246,10 @@ int sbx_widen_i32(sbx_handle_t h, const int32_t *src, void *dst_i64, int64_t cou
 int sbx_i64_begin(sbx_handle_t h, int **overflow_flag_dev);          // arena_begin + nesting on
 int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev);     // synchronous overflow check
 void sbx_i64_end(sbx_handle_t h);
-int sbx_i64_coo_is_sorted(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host);
 int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
                      void *val);
-int sbx_i64_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host);
 int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                           void *col, void *val);
-int sbx_i64_coo_to_csr(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
-                       const void *col, const void *val, void *row_ptr_out, void *col_out, void *val_out,
-                       unsigned flags);
-int sbx_i64_csr_to_coo(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                       const void *col, const void *val, void *row_out, void *col_out, void *val_out, unsigned flags);
 int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
 int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,

@@ -883,13 +883,43 @@ def test_int64_tuple_all_ops(ops, oracle):
     assert np.array_equal(host(srp), want[0][n // 4:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
 
 
-def test_int64_values_beyond_int32_are_refused(ops):
+def test_int64_values_beyond_int32(ops, oracle):
+    """64-bit indices with values >= 2^31.  The conversions COO <-> CSR and the two sortedness checks run native 64-bit
+    kernels: column ids of any size are accepted and the results are the oracle's, bit for bit.  The entry points that
+    still narrow to the int32 kernels refuse such arrays loudly (SBX_ERR_UNSUPPORTED), never silently truncate."""
     from sparsebase_amd import capi
-    rp = np.array([0, 1, 2], np.int64)
-    col = np.array([0, 1 << 33], np.int64)
+    g = np.random.default_rng(5)
+    n, m = 300, 1 << 40
+    lens = g.integers(0, 40, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([np.sort(g.choice(1 << 20, l, replace=False)) for l in lens]).astype(np.int64)
+    col = col * (1 << 19) + (1 << 33)                       # every column id beyond 2^33, sorted inside the rows
+    val = g.random(len(col))
+    assert ops.csr_rows_sorted(dev(rp), dev(col)) and oracle.csr_rows_sorted(rp, col)
+    coo = ops.csr_to_coo(n, m, dev(rp), dev(col), dev(val))
+    same(coo, oracle.csr_to_coo(rp, col, val))
+    assert ops.coo_is_sorted(coo[0], coo[1])
+    same(ops.coo_to_csr(n, m, *coo), (rp, col, val))
+    same(ops.coo_to_csr(n, m, *coo, rows_sorted=True), (rp, col, val))
+    # an unsorted row array (ignore_sort inputs): histogram + scan, columns and values verbatim (converter_order_two.cc:180-192)
+    p = g.permutation(len(col))
+    r_u, c_u, v_u = host(coo[0])[p], col[p], val[p]
+    same(ops.coo_to_csr(n, m, dev(r_u), dev(c_u), dev(v_u)), oracle.coo_to_csr(n, r_u, c_u, v_u))
+    assert not ops.coo_is_sorted(dev(r_u), dev(c_u))
+    ucol = col.copy()
+    ucol[rp[5]:rp[6]] = ucol[rp[5]:rp[6]][::-1] if lens[5] > 1 else ucol[rp[5]:rp[6]]
+    assert ops.csr_rows_sorted(dev(rp), dev(ucol)) == oracle.csr_rows_sorted(rp, ucol)
+    # a 64-bit row id outside [0, n) must not index row_ptr
+    bad_row = host(coo[0]).copy()
+    bad_row[-1] = 1 << 35
     with pytest.raises(capi.SbxError) as e:
-        ops.csr_rows_sorted(dev(rp), dev(col))
-    assert e.value.status == 5  # SBX_ERR_UNSUPPORTED, loudly
+        ops.coo_to_csr(n, m, dev(bad_row), dev(col), dev(val), rows_sorted=True)
+    assert e.value.status == 1  # SBX_ERR_BAD_ARG
+    # the operations that still run on narrowed copies refuse what does not fit, loudly
+    order = synth.random_permutation(n, 3, np.int64)
+    with pytest.raises(capi.SbxError) as e:
+        ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(order), None)
+    assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
 
 
 # ----------------------------------------------------------------------------- degenerate / ragged shapes
