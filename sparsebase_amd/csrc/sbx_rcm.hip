@@ -79,7 +79,9 @@ struct RcmDev {
   unsigned cone_k, cone_status;   // k_ubfs_cone_run: the level it stopped at (its list is too long for it) / UR_DONE
   unsigned bar;                 // grid barrier of k_ubfs_descend_all
   unsigned gb_abort;            // a grid barrier gave up waiting (see gb_wait): the host redoes the sweep the safe way
-  unsigned root_next;           // what k_ubfs_descend_all found: committed to `root` by the host once the walk is known to have finished
+  unsigned root_next;           // what the tie-break found; becomes `root` when the next sweep starts (root_pending) —
+  unsigned root_pending;        //   unless a grid barrier gave up on the way: k_gb_reset drops it and the old root stands
+  unsigned tie_done;            // the last level held one candidate: the cone / descend kernels have nothing to do
   unsigned gb_spins;            // how many polls a barrier waits (k_ubfs_start sets it; SBX_DEBUG_GB_SPINS for tests)
   // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
   unsigned ur_bar, ur_exit;
@@ -155,6 +157,31 @@ __global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, int6
       const unsigned o = base + (unsigned)__popcll(m & sbx_lanemask_lt());
       key[o] = d;
       id[o] = (uint32_t)v;
+    }
+    base += (unsigned)__popcll(m);
+  }
+}
+
+// One non-trivial component (the usual power-law input: a giant component and isolated vertices): every vertex with an
+// empty row is a component of its own, placed by the count of components in front of it — the empty rows with a smaller
+// id, plus the whole first component if its root v0 lies in front (format of k_classify / cbase: rcm_reorder.cc visits
+// the components in the order of their smallest vertex).  Same unit walk as k_deg_keys; replaces the union-find, its
+// size scan and the classification when the first sweep already reached every non-empty row.
+__global__ __launch_bounds__(256) void k_iso_positions(const I *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
+                                                       I v0, I comp_size, I *__restrict__ inv) {
+  const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
+  if (unit >= DEG_UNITS) return;
+  unsigned base = 0;  // non-empty rows in front of the unit
+  for (int j = lane; j < unit; j += 64) base += ucnt[j];
+  base = sbx_wave_sum(base);
+  const int64_t len = deg_unit_len(n), u0 = (int64_t)unit * len;
+  for (int64_t vb = u0; vb < u0 + len && vb < n; vb += 64) {
+    const int64_t v = vb + lane;
+    const bool full = v < n && rp[v + 1] != rp[v];
+    const uint64_t m = __ballot(full);
+    if (v < n && !full) {
+      const int64_t nonempty_before = (int64_t)base + __popcll(m & sbx_lanemask_lt());
+      inv[v] = (I)(v - nonempty_before + (v > (int64_t)v0 ? (int64_t)comp_size : 0));
     }
     base += (unsigned)__popcll(m);
   }
@@ -478,7 +505,8 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
 __global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
                             unsigned *__restrict__ lpos, unsigned *__restrict__ ppos, I *__restrict__ q,
                             RcmDev *__restrict__ dv, I fixed_root) {
-  const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
+  const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
+  dv->root_pending = 0;
   dv->root = (unsigned)r;
   vbits[r >> 5] = 1u << (r & 31);  // both bitmaps were cleared by the host for this sweep
   fbits[r >> 5] = 1u << (r & 31);
@@ -1643,6 +1671,7 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
 }
 
 struct BfsBuffers {
+  bool *claim_clean;  // the claim bytes of the unordered sweeps are all zero (a finished sweep leaves them that way)
   const I *rp, *col;
   unsigned *vbits, *fbits, *lpos, *ppos;
   const I *label;
@@ -1853,7 +1882,8 @@ static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search
 __global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
                              unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
                              unsigned gb_spins) {
-  const I r = fixed_root >= 0 ? fixed_root : (I)dv->root;
+  const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
+  dv->root_pending = 0;
   dv->root = (unsigned)r;
   vbits[r >> 5] = 1u << (r & 31);  // the bitmaps were cleared by the host for this sweep
   fbits[r >> 5] = 1u << (r & 31);
@@ -2097,9 +2127,15 @@ __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const I *__restrict__ 
     dv->cone_begin = 0;
     dv->cone_end = s_cnt;
     dv->bar = 0;
+    dv->tie_done = s_cnt <= 1 ? 1u : 0u;  // one candidate: it is the next root, nothing to walk
+    if (s_cnt <= 1) {
+      dv->root_next = m;
+      dv->root_pending = 1;
+    }
   }
 }
 __global__ void k_ubfs_ties_init(RcmDev *__restrict__ dv) {
+  dv->tie_done = 0;
   dv->tie_deg = 0xFFFFFFFFu;
   dv->tie_min_id = 0xFFFFFFFFu;
   dv->tie_count = 0;
@@ -2200,6 +2236,7 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
                                                           const unsigned *__restrict__ dist,
                                                           const unsigned *__restrict__ cone, unsigned levels,
                                                           RcmDev *dv) {
+  if (dv->tie_done) return;  // (one candidate: k_ubfs_ties_small has named the next root)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     __hip_atomic_store(&dv->desc[0], dv->root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&dv->desc[1], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2227,16 +2264,21 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (not dv->root: if the LAST barrier gave up on the other workgroups while this one passed it, the host redoes the
-    // sweep from the root it still expects there)
-    if (w == 0xFFFFFFFFu) dv->unsym = 1;  // cannot happen on a symmetric pattern
-    else dv->root_next = w;
+    // sweep from the root it still expects there — k_gb_reset drops the pending one)
+    if (w == 0xFFFFFFFFu) {
+      dv->unsym = 1;  // cannot happen on a symmetric pattern
+    } else {
+      dv->root_next = w;
+      dv->root_pending = 1;
+    }
   }
 }
-__global__ void k_ubfs_commit_root(RcmDev *__restrict__ dv) { dv->root = dv->root_next; }
 
 // after a grid barrier gave up: the words the persistent kernels leave zero when they finish normally
 __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
   dv->gb_abort = 0;
+  dv->root_pending = 0;
+  dv->tie_done = 0;
   dv->bar = 0;
   dv->ur_bar = 0;
   dv->ur_exit = 0;
@@ -2412,6 +2454,10 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
                                                        RcmDev *dv, unsigned k_start) {
   const int lane = sbx_lane();
   const unsigned gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  if (dv->tie_done) {  // (written by the kernel in front: the same for every workgroup)
+    if (blockIdx.x == 0 && threadIdx.x == 0) dv->cone_status = UR_DONE;
+    return;
+  }
   unsigned epoch = 0;
   unsigned begin = ur_load(&dv->cone_begin), end = ur_load(&dv->cone_end);
   unsigned k = k_start, status = UR_DONE;
@@ -2487,7 +2533,8 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
   *too_deep = false;
   SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
-  SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
+  if (!*b.claim_clean) SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
+  *b.claim_clean = false;  // (until this sweep has run to its end: every level's collection pass clears what it read)
   unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
   static const unsigned gb_spins = getenv("SBX_DEBUG_GB_SPINS") ? (unsigned)atoll(getenv("SBX_DEBUG_GB_SPINS")) : GB_SPINS;
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root,
@@ -2578,6 +2625,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     total += nf;
     level++;
   }
+  *b.claim_clean = true;
   out->count = total;
   out->levels = level + 1;
   out->last_offset = off;
@@ -2603,11 +2651,14 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   }
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
-  SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
-  if (hd.nf <= 1) {
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
-    SBX_LAUNCH_CHECK(h);
-    return SBX_OK;
+  if (r.last_size > UB_TIES_SMALL) {
+    // (the one-workgroup kernel of the small case names a single candidate itself: no round trip for the count)
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    if (hd.nf <= 1) {
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
+      SBX_LAUNCH_CHECK(h);
+      return SBX_OK;
+    }
   }
   // T_{k-1} = the level-(k-1) neighbours of T_k: the expansion kernel in cone mode appends them to the same list (its
   // counter keeps growing); the hub kernel only runs for a level that queued hub chunks
@@ -2654,10 +2705,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
     h->rcm_gb_backoff = 16;
     *aborted = true;
-  } else if (!hd.unsym) {
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_commit_root, dim3(1), dim3(1), b.dv);
   }
-  SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
@@ -2786,6 +2834,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     return SBX_OK;
   };
   BfsBuffers b;
+  bool claim_clean = false;
+  b.claim_clean = &claim_clean;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
@@ -2823,7 +2873,25 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
     SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
   }
-  // (3) connected components of the rest; the root of each tree is the component's smallest id
+  // (3) connected components of the rest; the root of each tree is the component's smallest id.  When the first sweep
+  // reached every non-empty row there is no rest: one kernel places the empty rows and the stage ends (a power-law
+  // input: ~0.2 ms of union-find, size scan, classification and two round trips saved)
+  const bool single_component = v0 >= 0 && (int64_t)r0.count == n_ranked && r0.count > (unsigned)RCM_MID;
+  RcmDev hd;
+  memset(&hd, 0, sizeof(hd));
+  bool mid_batched = false;
+  unsigned n_host = 0;
+  bool first_is_large = false;
+  if (single_component) {
+    SBX_KLAUNCH(h, SBX_K_CC, k_iso_positions, dim3(DEG_UNITS / 4), dim3(256), rp, n, (const unsigned *)ucnt, v0, (I)r0.count,
+                inv);
+    SBX_LAUNCH_CHECK(h);
+    hd.n_large = 1;
+    hd.n_components = (unsigned)(n - n_ranked) + 1u;
+    hd.n_empty_rows = (unsigned)(n - n_ranked);
+    n_host = 1;
+    first_is_large = true;
+  } else {
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list,
               (const unsigned *)cbits, dv);
@@ -2840,7 +2908,6 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gcount), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
               small_list, mid_list, large_list, n, dv);
   SBX_LAUNCH_CHECK(h);
-  RcmDev hd;
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
   if (hd.unsym)
     SBX_FAIL(h, SBX_ERR_BAD_ARG,
@@ -2851,9 +2918,9 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   // sweeps driven from the host: ~60 us per level, fine for a handful); from RCM_MID_BATCH on they join the batched
   // kernel, one lane each — a collection of 10^5 meshes of a few hundred vertices is then one launch instead of
   // 10^5 host-driven searches.
-  const bool mid_batched = hd.n_mid >= (unsigned)RCM_MID_BATCH;
-  const unsigned n_host = hd.n_large + (mid_batched ? 0u : hd.n_mid);  // components ordered from the host
-  const bool first_is_large = r0.count > (unsigned)RCM_SMALL && !(mid_batched && r0.count <= (unsigned)RCM_MID);
+  mid_batched = hd.n_mid >= (unsigned)RCM_MID_BATCH;
+  n_host = hd.n_large + (mid_batched ? 0u : hd.n_mid);  // components ordered from the host
+  first_is_large = r0.count > (unsigned)RCM_SMALL && !(mid_batched && r0.count <= (unsigned)RCM_MID);
   if (v0 >= 0 && !first_is_large && !r0_unordered) {
     // the pre-swept component is handled by the batched kernel: drop the sweep's marks
     SBX_TRY(reset_ppos(h, (const I *)q, r0.count, ppos, n));
@@ -2869,12 +2936,16 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
                 hd.n_mid, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
     SBX_LAUNCH_CHECK(h);
   }
+  }
   // (4) large components: host-driven level-synchronous BFS
   int64_t sweeps_max = 0, levels_max = 0, largest = 0, ref_sweeps_max = 0;
   if (n_host) {
     std::vector<I> roots(n_host), sizes(n_host), bases(n_host);
     I *info = nullptr;  // roots | sizes | bases, gathered on the device: three copies whatever the component count
     SBX_TRY(sbx_salloc(h, (size_t)3 * n_host, &info));
+    if (single_component) {  // root v0; every vertex in front of it has an empty row, i.e. is a component of its own
+      roots[0] = v0, sizes[0] = (I)r0.count, bases[0] = v0;
+    } else {
     if (hd.n_large)
       SBX_HIP(h, hipMemcpyAsync(info, large_list, hd.n_large * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
     if (!mid_batched && hd.n_mid)
@@ -2891,6 +2962,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       SBX_HIP(h, hipMemcpyAsync(sizes.data(), info + n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
       SBX_HIP(h, hipMemcpyAsync(bases.data(), info + 2 * (size_t)n_host, n_host * sizeof(I), hipMemcpyDeviceToHost, h->stream));
       SBX_HIP(h, hipStreamSynchronize(h->stream));
+    }
     }
     // the pre-swept component goes first: its sweep state (q, ppos) is still live
     for (unsigned c = 1; c < n_host; c++)
