@@ -26,6 +26,12 @@ struct GrayCounts {
   unsigned long long nnz_sparse, diag_sparse, nnz_dense, diag_dense;
 };
 
+// The lanes of a wave talk through LDS without a barrier in the kernels below (the LDS operations of one wave execute
+// in order).  For the language that is a data race, and the compiler does move such accesses past each other
+// (k_gray_rows_balanced with its group loop unrolled gave wrong keys): it is told with a wavefront-scope fence, which
+// costs no instruction.
+#define GR_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
 // The whole stage is nonzero-parallel, so it is balanced under any degree distribution and
 // every col load is a coalesced 32 B/lane read: a workgroup owns GT_TILE consecutive
 // nonzeros, finds the rows under them (row heads scattered into LDS from a per-tile row
@@ -271,7 +277,12 @@ constexpr int GR_SHORT_MAX = 64;  // thr <= 64 / 16 = 4: five levels at most
 constexpr int GR_LPR = GR_LPR_V;      // lanes per row
 constexpr int GR_VEC = GR_VEC_V;      // 16-byte loads in flight per lane and batch
 constexpr int GR_BATCH = 4 * GR_VEC;  // entries per lane and batch: rows of up to GR_LPR * GR_BATCH entries take one batch
-constexpr int GR_LONG_LIST = 4096;  // rows above GR_SHORT_MAX entries the short-row path lists for k_gray_long_rows
+constexpr int GR_MED_MAX = 8192;    // rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries: one wave each (k_gray_rows_medium)
+constexpr int GR_LONG_LIST = 4096;  // rows above GR_MED_MAX entries the short-row path lists for k_gray_long_rows
+constexpr int GR_FLAGS = 64;     // copies of the stop flag the waves of k_gray_rows_short poll, one per 128-byte line
+constexpr int GR_FLAG_OFF = 24;  // ... starting this many words after the long-row counter (GrayBoth below)
+constexpr int GR_SPREAD = 64;    // copies of the band counters the power-law kernels add to (4 GrayCounts = a 128-byte line each)
+constexpr unsigned GR_POWER_LAW = 2u;  // nlong[1]: 0 no row above GR_SHORT_MAX .. GR_MED_MAX met, 1 some, 2 many (start over)
 
 // Exchange with lane ^ m inside a row's GR_LPR lanes.  m is a constant after unrolling: 1 and 2 are DPP quad permutations;
 // 4 is row_half_mirror (lane i <-> 7 - i of the 8) — the same partner QUAD, and every value exchanged here is
@@ -367,6 +378,8 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   const int32_t nnz = rp[n];
   unsigned c_cur[GR_BATCH];
   gr_load4(col, s_cur + GR_BATCH * sub, nnz, c_cur);
+  bool saw_medium = false, stopped = false;
+  unsigned abort_seen = 0;
   for (; row < n; row += step) {
     const int32_t s = s_cur;
     int32_t e = e_cur;
@@ -378,12 +391,42 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     // The kernel runs before anyone knows whether the matrix suits it: rows above GR_SHORT_MAX entries are listed for
     // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
     // leaves at its next long row — the host then discards the results and takes the tile kernel.
-    const bool long_row = e - s > GR_SHORT_MAX;  // k_gray_long_rows' business
-    if (__any(long_row)) {  // (nothing on the common path: the counter is only touched by waves that meet a long row)
-      const unsigned slot = sbx_wave_append(nlong, long_row && sub == 0);
-      if (long_row && sub == 0 && slot < (unsigned)GR_LONG_LIST) long_list[slot] = (int32_t)row;
-      if (__any(long_row && sub == 0 && slot >= (unsigned)GR_LONG_LIST)) break;  // list full: this wave stops (it still meets
-                                                                                 // the workgroup's barrier below; the host discards the results)
+    const bool long_row = e - s > GR_SHORT_MAX;  // another kernel's business
+    if (abort_seen == GR_POWER_LAW) {  // (some wave found the matrix to be a power-law one: see below)
+      stopped = true;
+      break;
+    }
+    // (tested a step later: the load is not waited for here.  One of GR_FLAGS copies, each on a line of its own: 16 K
+    // waves polling ONE word every step queue on its L2 channel — that alone took the kernel from 0.12 to 0.44 ms)
+    abort_seen = __atomic_load_n(nlong + GR_FLAG_OFF + (blockIdx.x % GR_FLAGS) * 32, __ATOMIC_RELAXED);
+    if (__any(long_row)) {  // (nothing on the common path: the counter is only touched by waves that meet such a row)
+      // rows above GR_MED_MAX entries are listed for k_gray_long_rows (a handful of hubs, boundary rows of a clamped
+      // band); the rows between only raise a flag: k_gray_list_medium finds them again — a power-law matrix has
+      // hundreds of thousands of them, and appending each to a list would queue on one counter word
+      const bool heavy = e - s > GR_MED_MAX;
+      saw_medium |= long_row && !heavy;  // (published once per workgroup at the end: one word, thousands of waves)
+      // two such rows among the 64 / GR_LPR of one wave step: not a banded matrix with a few boundary rows but the body
+      // of a power-law degree distribution, where this kernel pays a full batch for rows of four entries.  Every wave
+      // stops at its next step, the host discards the results and runs k_gray_rows_balanced.
+      if (__popcll(__ballot(long_row && !heavy && sub == 0)) >= 2) {
+        // (thousands of waves get here in the kernel's first microseconds: each swaps its OWN flag copy, and only the
+        // first one on a copy tells the others and the host — at most GR_FLAGS waves write the shared words)
+        unsigned was = 0;
+        if (sbx_lane() == 0) was = atomicExch(nlong + GR_FLAG_OFF + (blockIdx.x % GR_FLAGS) * 32, GR_POWER_LAW);
+        if (__builtin_amdgcn_readfirstlane((int)was) != (int)GR_POWER_LAW) {
+          static_assert(GR_FLAGS == 64, "one flag copy per lane");
+          __atomic_store_n(nlong + GR_FLAG_OFF + sbx_lane() * 32, GR_POWER_LAW, __ATOMIC_RELAXED);
+          if (sbx_lane() == 0) atomicMax(nlong + 1, GR_POWER_LAW);
+        }
+        stopped = true;
+        break;
+      }
+      if (__any(heavy)) {
+        const unsigned slot = sbx_wave_append(nlong, heavy && sub == 0);
+        if (heavy && sub == 0 && slot < (unsigned)GR_LONG_LIST) long_list[slot] = (int32_t)row;
+        if (__any(heavy && sub == 0 && slot >= (unsigned)GR_LONG_LIST)) break;  // list full: this wave stops (it still meets
+                                                                                // the workgroup's barrier below; the host discards the results)
+      }
     }
     if (long_row) e = s;
     const int d = e - s;
@@ -479,79 +522,559 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     s_red[tid >> 6][0] = c_ns; s_red[tid >> 6][1] = c_ds; s_red[tid >> 6][2] = c_nd; s_red[tid >> 6][3] = c_dd;
   }
   __syncthreads();
+  // (a stopped kernel's results are discarded: nothing to add.  The workgroups of a stopped kernel all end within
+  // microseconds of each other, and their 16 K adds to one 128-byte line took 130 us)
+  if (__syncthreads_or(stopped)) return;
+  if (__syncthreads_or(saw_medium) && tid == 0 && __atomic_load_n(nlong + 1, __ATOMIC_RELAXED) == 0) atomicMax(nlong + 1, 1u);
   if (tid < 4) {  // the grid is a few workgroups per CU: one add per counter and workgroup
     const unsigned long long t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
     if (t) atomicAdd(&counts->nnz_sparse + tid, t);
   }
 }
 
+// ---- power-law matrices ----------------------------------------------------------------------------------------
+// On the RMAT bench matrix 41 % of the rows are empty, 45 % hold 1..16 entries, 3.5 % hold 65..8192 entries and 72 % of
+// the nonzeros, 0.02 % hold the rest.  k_gray_rows_short pays 32 entry slots for a row of four entries there (270 us
+// for a fifth of the nonzeros); it notices (GR_POWER_LAW above) and the host starts over with three kernels that cost
+// per ENTRY:
+//   k_gray_rows_balanced  rows of up to GR_SHORT_MAX entries, a wave per 64 consecutive rows, a lane per entry;
+//                         lists the rows above for the other two
+//   k_gray_rows_medium    a wave per listed row of up to GR_MED_MAX entries, 256 entries per step, the next step's
+//                         loads in flight across row ends
+//   k_gray_long_rows      GR_PARTS workgroups per listed row above GR_MED_MAX entries (as on the banded path)
+
+// The rows above GR_SHORT_MAX entries are cut into UNITS of up to GU_SIZE entries, and k_gray_rows_medium gives every
+// wave the same NUMBER of units (one wave per row was built first: rows of 65 and of 8000 entries in one list, the
+// average wave was done after 65 us and the last one after 155).  A row of one unit is finished by the wave that
+// counts it; the units of a longer row each leave their 64 block counts + band count in a partial slot, and
+// k_gray_units_finish adds a row's slots up — plain stores, no atomics, no ordering between units.
+//   units[i] = (row, offset of the unit in the row, partial slot or -1, -)
+//   mrows[k] = (row, first partial slot, number of units, -)      rows of more than one unit
+constexpr int GU_SIZE = 1024;
+struct GrayLists {  // (units and slots are reserved together: ONE add per workgroup; the mrows counter on a line of its own)
+  alignas(128) unsigned long long units_slots;  // low word: units listed, high word: partial slots handed out
+  alignas(128) unsigned n_mrows;
+};
+// d[i] = length of row row_of(i) + lane if the row is to be listed, 0 otherwise (i < G).  Positions from wave scans and
+// one reservation per workgroup on the counters — every thread of the workgroup calls this, once: a workgroup's adds
+// to one line take ~7 ns each whatever else it does (4 K workgroups x 3 counters were most of a 109 us kernel).
+template <int G, typename RowOf>
+__device__ __forceinline__ void gray_emit_units(const int (&d)[G], RowOf row_of, int4 *__restrict__ units,
+                                                int4 *__restrict__ mrows, GrayLists *__restrict__ lc,
+                                                unsigned (*s_w)[3], unsigned *s_b) {
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  unsigned nu = 0, ns = 0, nm = 0;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const unsigned ng = d[g] > 0 ? (unsigned)(d[g] + GU_SIZE - 1) / GU_SIZE : 0u;
+    nu += ng;
+    ns += ng > 1 ? ng : 0u;
+    nm += ng > 1;
+  }
+  const unsigned iu = sbx_wave_inclusive_sum(nu), is = sbx_wave_inclusive_sum(ns), im = sbx_wave_inclusive_sum(nm);
+  if (lane == 63) s_w[wv][0] = iu, s_w[wv][1] = is, s_w[wv][2] = im;
+  __syncthreads();
+  const unsigned tu = s_w[0][0] + s_w[1][0] + s_w[2][0] + s_w[3][0];
+  if (tu == 0) return;  // (workgroup-uniform)
+  if (threadIdx.x == 0) {
+    const unsigned ts = s_w[0][1] + s_w[1][1] + s_w[2][1] + s_w[3][1];
+    const unsigned long long was = atomicAdd(&lc->units_slots, (unsigned long long)tu | ((unsigned long long)ts << 32));
+    s_b[0] = (unsigned)was, s_b[1] = (unsigned)(was >> 32);
+  }
+  if (threadIdx.x == 64) {
+    const unsigned tm = s_w[0][2] + s_w[1][2] + s_w[2][2] + s_w[3][2];
+    s_b[2] = tm ? atomicAdd(&lc->n_mrows, tm) : 0u;
+  }
+  __syncthreads();
+  unsigned bu = s_b[0] + iu - nu, bs = s_b[1] + is - ns, bm = s_b[2] + im - nm;
+  for (int w = 0; w < wv; w++) bu += s_w[w][0], bs += s_w[w][1], bm += s_w[w][2];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const unsigned ng = d[g] > 0 ? (unsigned)(d[g] + GU_SIZE - 1) / GU_SIZE : 0u;
+    const int32_t row = (int32_t)(row_of(g) + lane);
+    for (unsigned k = 0; k < ng; k++) units[bu + k] = make_int4(row, (int)(k * GU_SIZE), ng > 1 ? (int)(bs + k) : -1, 0);
+    if (ng > 1) mrows[bm++] = make_int4(row, (int)bs, (int)ng, 0), bs += ng;
+    bu += ng;
+  }
+}
+
+// Listing for the banded path (k_gray_rows_short met a few rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries; the ones
+// above are on its own list for k_gray_long_rows): 4096 rows per workgroup.
+constexpr int GL_ROWS = 4096;
+__global__ __launch_bounds__(256) void k_gray_list_medium(const int32_t *__restrict__ rp, int64_t n,
+                                                          int4 *__restrict__ units, int4 *__restrict__ mrows,
+                                                          GrayLists *__restrict__ lc) {
+  __shared__ unsigned s_w[4][3], s_b[3];
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  const int64_t r00 = (int64_t)blockIdx.x * GL_ROWS + (int64_t)wv * (GL_ROWS / 4);  // this wave's 1024 rows
+  int d[GL_ROWS / 256];
+#pragma unroll
+  for (int i = 0; i < GL_ROWS / 256; i++) {
+    const int64_t r = r00 + i * 64 + lane;
+    int32_t len = 0;
+    if (r < n) len = rp[r + 1] - rp[r];
+    d[i] = len > GR_SHORT_MAX && len <= GR_MED_MAX ? len : 0;
+  }
+  gray_emit_units(d, [&](int i) { return r00 + i * 64; }, units, mrows, lc, s_w, s_b);
+}
+
+// A wave owns GB_GROUPS x 64 consecutive rows.  Per group of 64: lane = row reads the bounds, a wave scan of the short
+// rows' lengths numbers their entries 0 .. T-1, and the entries are walked 64 per step with lane = ENTRY: the row of
+// an entry is the last row starting at or before it — the rows whose first entry lies in the step's window drop their
+// lane number at that slot of a 64-word LDS window, a max-scan spreads it to the right (and a carry brings in the row
+// running in from the previous step).  The entry then ORs its block bit into its row's LDS word; rows that compare
+// counts with a threshold of 1 .. LV-1 (rows of at least `resolution` entries) keep the same saturating bit-sliced
+// counters as k_gray_rows_short, filled by a cascade of returning ORs: the entry that finds its bit already set at
+// level t carries it to level t + 1, so level t ends up set iff the block was met more than t times, in any order.
+// Cost: a step of ~45 VALU instructions per 64 ENTRIES + ~100 per 64 rows, against ~400 per 16 rows in
+// k_gray_rows_short.  (gray_reorder.cc:138-170, :249-267, :384-395)
+constexpr int GB_GROUPS = 4;
+constexpr int GB_ITERS = 4;      // blocks of 4 x GB_GROUPS x 64 rows per workgroup: one list reservation for all of them
+constexpr int GB_WINDOW = 256;  // entries per pass: their row lookups, then their loads, then their ORs
+template <typename B, int LV, bool POW2>
+__global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                            int64_t n, uint32_t width, uint32_t magic, uint32_t band,
+                                                            int wshift, int bits, int nnz_threshold,
+                                                            int32_t *__restrict__ degree_out,
+                                                            unsigned long long *__restrict__ key_out,
+                                                            GrayCounts *__restrict__ counts, unsigned *nlong,
+                                                            int32_t *__restrict__ long_list, int4 *__restrict__ units,
+                                                            int4 *__restrict__ mrows, GrayLists *__restrict__ lc) {
+  __shared__ int s_head[4][GB_WINDOW];
+  __shared__ int s_base[4][64];       // row_ptr[row] - (number of the row's first entry): entry q is col[s_base + q]
+  __shared__ unsigned s_cls[4][64];   // bit 0: row above the threshold ("dense"), bit 1: row counts (thr > 0)
+  __shared__ B s_ge[4][LV][64];
+  __shared__ unsigned s_w[4][3], s_b[3];
+  __shared__ unsigned long long s_red[4][4];
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  unsigned long long c_ns = 0, c_nd = 0;
+  unsigned c_ds = 0, c_dd = 0;
+  int listed[GB_ITERS * GB_GROUPS];  // lengths of the rows above GR_SHORT_MAX entries: k_gray_rows_medium's
+#pragma unroll
+  for (int i = 0; i < GB_ITERS * GB_GROUPS; i++) listed[i] = 0;
+#pragma unroll
+  for (int u = 0; u < GB_WINDOW / 64; u++) s_head[wv][u * 64 + lane] = -1;
+  // the workgroup's GB_ITERS blocks of 4 x GB_GROUPS x 64 rows lie a grid apart (hubs and leaves in every workgroup)
+  auto block_row = [&](int it) { return (((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * 4 + wv) * (GB_GROUPS * 64); };
+#pragma unroll 1
+  for (int it = 0; it < GB_ITERS; it++) {
+  const int64_t r00 = block_row(it);
+  int32_t rs_nx = 0, re_nx = 0;
+  if (r00 + lane < n) rs_nx = rp[r00 + lane], re_nx = rp[r00 + lane + 1];
+  int cur[GB_GROUPS];
+#pragma unroll
+  for (int g = 0; g < GB_GROUPS; g++) {
+    const int64_t r0 = r00 + (int64_t)g * 64, r = r0 + lane;
+    const int32_t rs = rs_nx, re = re_nx;
+    if (g + 1 < GB_GROUPS && r + 64 < n) rs_nx = rp[r + 64], re_nx = rp[r + 65];
+    else rs_nx = re_nx = 0;
+    const int d = re - rs;
+    cur[g] = d > GR_SHORT_MAX ? d : 0;
+    const int ds = d <= GR_SHORT_MAX ? d : 0;
+    const int incl = sbx_wave_inclusive_sum(ds);
+    const int off = incl - ds;
+    const int T = __builtin_amdgcn_readlane(incl, 63);
+    unsigned thr = 0;
+#pragma unroll
+    for (int t = 1; t < LV; t++) thr += ds >= t * bits;
+    const bool dense = ds > nnz_threshold;
+    thr = dense ? thr : 0u;
+    s_base[wv][lane] = rs - off;
+    s_cls[wv][lane] = (dense ? 1u : 0u) | (thr ? 2u : 0u);
+#pragma unroll
+    for (int t = 0; t < LV; t++) s_ge[wv][t][lane] = 0;
+    GR_WAVE_FENCE();
+    int carry = 0;
+    for (int k0 = 0; k0 < T; k0 += GB_WINDOW) {
+      // (the LDS operations of one wave execute in order: no barrier between the head writes and the reads)
+      if (ds > 0 && off >= k0 && off < k0 + GB_WINDOW) s_head[wv][off - k0] = lane;
+      GR_WAVE_FENCE();
+      int rl[GB_WINDOW / 64] = {};
+      unsigned c[GB_WINDOW / 64] = {};
+#pragma unroll
+      for (int u = 0; u < GB_WINDOW / 64; u++) {
+        if (k0 + u * 64 < T) {  // (wave-uniform.  Guards, not breaks: see k_gray_rows_medium)
+          const int hd = s_head[wv][u * 64 + lane];
+          s_head[wv][u * 64 + lane] = -1;
+          int m = sbx_wave_inclusive_max(hd);
+          m = m > carry ? m : carry;
+          carry = __builtin_amdgcn_readlane(m, 63);
+          rl[u] = m;
+        }
+      }
+      // the window's loads go out together (a step at a time, each step's load was waited for before the next
+      // step's address existed: 120 us for the bench matrix's 21 M short-row entries)
+#pragma unroll
+      for (int u = 0; u < GB_WINDOW / 64; u++) {
+        const int q = k0 + u * 64 + lane;
+        const int at = q < T ? s_base[wv][rl[u]] + q : 0;  // (unconditional: a load under a condition is waited for at the join)
+        c[u] = (unsigned)col[at];
+      }
+#pragma unroll
+      for (int u = 0; u < GB_WINDOW / 64; u++) {
+        if (k0 + u * 64 >= T) continue;
+        const bool valid = k0 + u * 64 + lane < T;
+        const unsigned cls = s_cls[wv][rl[u]];
+        unsigned bkt;
+        if (POW2) {
+          bkt = c[u] >> wshift;
+        } else {
+          bkt = __umulhi(c[u], magic);  // c / width, one short at most
+          bkt += (c[u] - bkt * width) >= width;
+        }
+        const B x = (B)1 << (bkt & (sizeof(B) * 8 - 1));
+        if (valid) {
+          if (LV == 1 || !(cls & 2u)) {
+            atomicOr(&s_ge[wv][0][rl[u]], x);
+          } else {
+#pragma unroll
+            for (int t = 0; t < LV; t++) {
+              const B old = atomicOr(&s_ge[wv][t][rl[u]], x);
+              if (!(old & x)) break;
+            }
+          }
+          const bool inb = c[u] - ((unsigned)(r0 + rl[u]) - band) <= 2u * band;  // |c - row| <= band
+          c_dd += inb && (cls & 1u);
+          c_ds += inb && !(cls & 1u);
+        }
+      }
+    }
+    GR_WAVE_FENCE();
+    if (r < n && d <= GR_SHORT_MAX) {
+      B key = s_ge[wv][0][lane];
+#pragma unroll
+      for (int t = 1; t < LV; t++) {
+        const B v = s_ge[wv][t][lane];
+        key = thr == (unsigned)t ? v : key;
+      }
+      degree_out[r] = d;
+      key_out[r] = gray_decode((unsigned long long)key);
+      if (dense) c_nd += (unsigned)d;
+      else c_ns += (unsigned)d;
+    }
+    GR_WAVE_FENCE();
+  }
+  // (registers are indexed by constants: the block's lengths go to their place under a uniform branch per block)
+#pragma unroll
+  for (int i = 0; i < GB_ITERS; i++)
+    if (it == i) {
+#pragma unroll
+      for (int g = 0; g < GB_GROUPS; g++) listed[i * GB_GROUPS + g] = cur[g];
+    }
+  }
+  c_ns = sbx_wave_sum(c_ns); c_nd = sbx_wave_sum(c_nd);
+  const unsigned long long w_ds = sbx_wave_sum((unsigned long long)c_ds), w_dd = sbx_wave_sum((unsigned long long)c_dd);
+  if (lane == 0) {
+    s_red[wv][0] = c_ns; s_red[wv][1] = w_ds; s_red[wv][2] = c_nd; s_red[wv][3] = w_dd;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {  // (one of GR_SPREAD copies of the counters, a line each; k_gray_units_finish sums them)
+    const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (t) atomicAdd(&counts[(blockIdx.x % GR_SPREAD) * 4].nnz_sparse + threadIdx.x, t);
+  }
+  gray_emit_units(listed, [&](int i) { return block_row(i / GB_GROUPS) + (i % GB_GROUPS) * 64; }, units, mrows, lc, s_w, s_b);
+}
+
+// One wave per listed unit, round-robin over the list.  (Finding the rows where they are — a wave per 64 consecutive
+// rows, or per 64 rows a fixed stride apart — was built first: 8.8 and 9.0 ms on the RMAT bench matrix, whose
+// generator puts the hubs next to each other AND at ids with many trailing zero bits: whatever regular map from row
+// id to wave is used, some wave gets a few hundred of them.)
+// A wave's units are one stream of GM_STEP-entry steps — four consecutive entries per lane, one 16-byte load — with
+// GM_DEPTH of them in flight: a step is counted, then the step GM_DEPTH further on, of this unit or of a later one, is
+// loaded into its registers.  (The kernel is bound by instruction issue, not by memory: with a 4-byte load per lane and
+// step, 41 VALU + 44 scalar instructions per 64 entries kept every SIMD busy, tools/pmc_gray.sh, at 1.3 TB/s; and with
+// one load per wave outstanding the list -> row_ptr -> col chain limited the first version to 0.95 TB/s.)  Block
+// counts sit in the wave's own 64 LDS words; at the end of a unit lane b holds block b's count: compared with the
+// row's threshold, a ballot is the key — or, for a unit of a longer row, stored to the unit's partial slot.
+// (gray_reorder.cc:249-267, :384-395)
+constexpr int GM_DEPTH = 4;   // steps in flight per wave
+constexpr int GM_STEP = 256;  // entries per step
+constexpr int GU_SLOT = 65;   // words of a partial slot: 64 block counts, the band count
+__global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                          const int4 *__restrict__ units,
+                                                          const GrayLists *__restrict__ lc, uint32_t width,
+                                                          uint32_t magic, int wshift, uint32_t band, int bits,
+                                                          int nnz_threshold, int32_t nnz,
+                                                          int32_t *__restrict__ degree_out,
+                                                          unsigned long long *__restrict__ key_out,
+                                                          unsigned *__restrict__ partial,
+                                                          GrayCounts *__restrict__ counts, unsigned spread) {
+  __shared__ unsigned s_cnt[4][64];
+  __shared__ unsigned long long s_red[4][4];
+  __shared__ int32_t s_tab[4][5][64];  // row, first entry, end, row length, partial slot
+  const int lane = sbx_lane();
+  // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; with it the
+  // cursors below are scalars and their branches scalar branches)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned gwave = blockIdx.x * 4u + (unsigned)wv, nwaves = gridDim.x * 4u;
+  const unsigned total = (unsigned)lc->units_slots;
+  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;  // (wave-uniform)
+  const int mine = gwave < total ? (int)((total - gwave + nwaves - 1) / nwaves) : 0;  // this wave's units: units[gwave + k nwaves]
+  // the bounds of 64 of the wave's units at a time, in LDS (list -> row_ptr: two dependent loads, paid once per 64
+  // units instead of once per unit); the pipeline drains between such blocks
+  for (int kb = 0; kb < mine; kb += 64) {
+    const int blk = mine - kb < 64 ? mine - kb : 64;
+    {
+      int32_t t_row = 0, t_a = 0, t_b = 0, t_dd = 0, t_slot = -1;
+      if (lane < blk) {
+        const int4 un = units[gwave + (unsigned)(kb + lane) * nwaves];
+        const int32_t rs = rp[un.x], re = rp[un.x + 1];
+        t_row = un.x, t_a = rs + un.y, t_dd = re - rs, t_slot = un.z;
+        t_b = re - t_a < GU_SIZE ? re : t_a + GU_SIZE;
+      }
+      s_tab[wv][0][lane] = t_row, s_tab[wv][1][lane] = t_a, s_tab[wv][2][lane] = t_b, s_tab[wv][3][lane] = t_dd,
+      s_tab[wv][4][lane] = t_slot;      GR_WAVE_FENCE();
+    }
+    auto table = [&](int what, int k) { return __builtin_amdgcn_readfirstlane(s_tab[wv][what][k]); };
+    // the fetch cursor: the next step to load.  A load on EVERY call, past the end of the stream too: with a path that
+    // skips one the compiler cannot count the loads behind the one it waits for, and waits for all of them
+    int f_k = 0;
+    int32_t f_row = table(0, 0), f_j = table(1, 0), f_b = table(2, 0), f_dd = table(3, 0), f_slot = table(4, 0);
+    GrU4 R[GM_DEPTH];
+    int32_t m_row[GM_DEPTH], m_b[GM_DEPTH], m_j[GM_DEPTH], m_dd[GM_DEPTH], m_slot[GM_DEPTH];  // (compile-time indices: scalars)
+    auto fetch = [&](int u) {
+      m_row[u] = f_row, m_b[u] = f_b, m_j[u] = f_j, m_dd[u] = f_dd, m_slot[u] = f_slot;
+      const int32_t jj = f_row >= 0 ? f_j + 4 * lane : 0;
+      R[u] = *(const GrU4 *)(col + gr_clamp4(jj, nnz));  // (only 4-byte aligned: gfx950 loads unaligned vectors)
+      if (f_row < 0) return;
+      f_j += GM_STEP;
+      if (f_j >= f_b) {  // next unit
+        f_k++;
+        if (f_k >= blk) {
+          f_row = -1;
+        } else {
+          f_row = table(0, f_k), f_j = table(1, f_k), f_b = table(2, f_k), f_dd = table(3, f_k), f_slot = table(4, f_k);
+        }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < GM_DEPTH; u++) fetch(u);
+    s_cnt[wv][lane] = 0;  // (the LDS operations of one wave execute in order: no barrier around the counters)
+    GR_WAVE_FENCE();
+    unsigned inb = 0;
+    bool more = true;
+    while (more) {
+#pragma unroll
+      for (int u = 0; u < GM_DEPTH; u++) {
+        const int32_t row = m_row[u], ue = m_b[u], j0 = m_j[u];
+        // (no break here: with an exit from the middle of the ring the compiler gives up counting the loads in flight
+        // and waits for all of them before every step; past the end of the stream the remaining steps are skipped)
+        if (row < 0) more = false;
+        if (row >= 0) {
+          const int32_t j = j0 + 4 * lane;
+          const int left = ue - j;
+          const int cnt = left < 0 ? 0 : (left > 4 ? 4 : left);
+          unsigned c[4] = {R[u].x, R[u].y, R[u].z, R[u].w};
+          if (__any(j > nnz - 4 && cnt > 0)) {  // the end of the array: the vector was read up to 3 entries early
+            const int sh = j - gr_clamp4(j, nnz);
+            const unsigned w[4] = {c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              unsigned x = w[t];
+#pragma unroll
+              for (int k = t + 1; k < 4; k++) x = (sh == k - t) ? w[k] : x;
+              c[t] = x;
+            }
+          }
+          unsigned bkt[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            if (wshift >= 0) {
+              bkt[t] = c[t] >> wshift;
+            } else {
+              bkt[t] = __umulhi(c[t], magic);
+              bkt[t] += (c[t] - bkt[t] * width) >= width;
+            }
+            inb += t < cnt && c[t] - ((unsigned)row - band) <= 2u * band;  // |c - row| <= band
+          }
+          // a lane whose entries fall into one block adds their number once (neighbouring columns share a block
+          // unless the row is spread over the whole width; then there are few equal ones to queue on a word)
+          const bool uni = (cnt < 2 || bkt[1] == bkt[0]) && (cnt < 3 || bkt[2] == bkt[0]) && (cnt < 4 || bkt[3] == bkt[0]);
+          if (cnt > 0) {
+            if (uni) {
+              atomicAdd(&s_cnt[wv][bkt[0]], (unsigned)cnt);
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; t++)
+                if (t < cnt) atomicAdd(&s_cnt[wv][bkt[t]], 1u);
+            }
+          }
+          if (j0 + GM_STEP >= ue) {  // the unit's last step
+            const int32_t dd = m_dd[u], slot = m_slot[u];
+            inb = sbx_wave_sum(inb);
+            GR_WAVE_FENCE();
+            const unsigned cb = s_cnt[wv][lane];
+            s_cnt[wv][lane] = 0;
+            GR_WAVE_FENCE();
+            if (slot >= 0) {  // one of several units of its row: k_gray_units_finish adds them up
+              unsigned *ps = partial + (size_t)slot * GU_SLOT;
+              ps[lane] = cb;
+              if (lane == 0) ps[64] = inb;
+            } else {
+              const unsigned thr = (dd > nnz_threshold && dd >= bits) ? (unsigned)(dd / bits) : 0u;
+              const uint64_t key = __ballot(lane < bits && cb > thr);
+              if (lane == 0) {
+                degree_out[row] = dd;
+                key_out[row] = gray_decode(key);
+              }
+              if (dd <= nnz_threshold) c_ns += (unsigned)dd, c_ds += inb;
+              else c_nd += (unsigned)dd, c_dd += inb;
+            }
+            inb = 0;
+          }
+        }
+        fetch(u);
+      }
+    }
+  }
+  if (lane == 0) {
+    s_red[wv][0] = c_ns; s_red[wv][1] = c_ds; s_red[wv][2] = c_nd; s_red[wv][3] = c_dd;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (t) atomicAdd(&counts[(blockIdx.x % spread) * 4].nnz_sparse + threadIdx.x, t);  // (`spread` copies, a line each)
+  }
+}
+
+// The rows of more than one unit, a wave each: lane b adds block b's count over the row's partial slots.  Workgroup 0
+// also folds the counter copies of the kernels before into the counters the host reads.
+__global__ __launch_bounds__(256) void k_gray_units_finish(const int32_t *__restrict__ rp, const int4 *__restrict__ mrows,
+                                                           const GrayLists *__restrict__ lc,
+                                                           const unsigned *__restrict__ partial, int bits,
+                                                           int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                           unsigned long long *__restrict__ key_out,
+                                                           GrayCounts *__restrict__ counts,
+                                                           const GrayCounts *__restrict__ spread, unsigned n_spread) {
+  if (blockIdx.x == 0 && threadIdx.x < 4 && n_spread > 1) {
+    unsigned long long t = 0;
+    for (unsigned i = 0; i < n_spread; i++) t += (&spread[i * 4].nnz_sparse)[threadIdx.x];
+    if (t) atomicAdd(&counts->nnz_sparse + threadIdx.x, t);
+  }
+  __shared__ unsigned long long s_red[4][4];
+  const unsigned nm = lc->n_mrows;
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  unsigned long long c[4] = {0, 0, 0, 0};  // nnz / band count of the rows below the threshold, of the rows above (lane 0's)
+  for (unsigned k = blockIdx.x * 4u + (unsigned)wv; k < nm; k += gridDim.x * 4u) {
+    const int4 mr = mrows[k];
+    const int32_t row = mr.x;
+    const int d = rp[row + 1] - rp[row];
+    unsigned cb = 0, inb = 0;
+    int u = 0;
+    for (; u + 8 <= mr.z; u += 8) {  // (eight loads in flight: a 300 K-entry hub is 300 slots)
+      unsigned v[8], w[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const unsigned *ps = partial + (size_t)(mr.y + u + i) * GU_SLOT;
+        v[i] = ps[lane], w[i] = ps[64];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) cb += v[i], inb += w[i];
+    }
+    for (; u < mr.z; u++) {
+      const unsigned *ps = partial + (size_t)(mr.y + u) * GU_SLOT;
+      cb += ps[lane], inb += ps[64];
+    }
+    const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
+    const unsigned long long key = __ballot(lane < bits && cb > thr);
+    if (lane == 0) {
+      degree_out[row] = d;
+      key_out[row] = gray_decode(key);
+    }
+    const int cls = d <= nnz_threshold ? 0 : 2;
+    c[cls] += (unsigned)d, c[cls + 1] += inb;
+  }
+  // (one add per counter and workgroup: 23 K rows x 2 adds to one line were 220 us)
+  if (lane == 0) s_red[wv][0] = c[0], s_red[wv][1] = c[1], s_red[wv][2] = c[2], s_red[wv][3] = c[3];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (t) atomicAdd(&counts->nnz_sparse + threadIdx.x, t);
+  }
+}
+
 // GR_PARTS workgroups per listed long row (a 200 K-entry boundary row must not be one workgroup's job): per-block counts
 // in LDS — a thread walks a contiguous piece of the (column-sorted) row, so it adds once per run of equal blocks —
-// then into the row's global slot (64 counters + the band count), finished by k_gray_long_finish
+// then into the row's global slot (64 counters + the band count), finished by k_gray_long_finish.  The number of listed
+// rows is read from the device (the power-law path launches this without a read-back in between): the workgroups loop.
 constexpr int GR_PARTS = 32;
 __global__ __launch_bounds__(256) void k_gray_long_rows(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
-                                                        const int32_t *__restrict__ list, uint32_t width,
+                                                        const int32_t *__restrict__ list,
+                                                        const unsigned *__restrict__ n_long, uint32_t width,
                                                         uint32_t magic, uint32_t band, unsigned *__restrict__ slots) {
   __shared__ unsigned s_cnt[64];
   __shared__ unsigned s_inb[4];
   const int tid = threadIdx.x;
-  const int64_t li = blockIdx.x / GR_PARTS, part = blockIdx.x % GR_PARTS;
-  const int64_t row = list[li];
-  const int64_t s = rp[row], len = (int64_t)rp[row + 1] - s;
-  const int64_t a = s + len * part / GR_PARTS, b = s + len * (part + 1) / GR_PARTS;  // this workgroup's piece
-  if (a >= b) return;
-  if (tid < 64) s_cnt[tid] = 0;
-  __syncthreads();
-  const int64_t per = (b - a + 255) / 256;
-  int64_t j = a + per * tid;
-  const int64_t jend = j + per < b ? j + per : b;
-  unsigned inb = 0, run = 0, cur = 0xFFFFFFFFu;
-  for (; j < jend; j++) {
-    const int32_t c = col[j];
-    unsigned bkt = __umulhi((unsigned)c, magic);
-    bkt += ((unsigned)c - bkt * width) >= width;
-    if (bkt != cur) {
-      if (run) atomicAdd(&s_cnt[cur], run);
-      cur = bkt;
-      run = 0;
+  unsigned nl = *n_long;
+  if (nl > (unsigned)GR_LONG_LIST) return;  // (the host takes the tile kernel)
+  for (unsigned w = blockIdx.x; w < nl * GR_PARTS; w += gridDim.x) {
+    const int64_t li = w / GR_PARTS, part = w % GR_PARTS;
+    const int64_t row = list[li];
+    const int64_t s = rp[row], len = (int64_t)rp[row + 1] - s;
+    const int64_t a = s + len * part / GR_PARTS, b = s + len * (part + 1) / GR_PARTS;  // this workgroup's piece
+    if (a >= b) continue;
+    __syncthreads();  // (the previous piece's counters have been read)
+    if (tid < 64) s_cnt[tid] = 0;
+    __syncthreads();
+    const int64_t per = (b - a + 255) / 256;
+    int64_t j = a + per * tid;
+    const int64_t jend = j + per < b ? j + per : b;
+    unsigned inb = 0, run = 0, cur = 0xFFFFFFFFu;
+    for (; j < jend; j++) {
+      const int32_t c = col[j];
+      unsigned bkt = __umulhi((unsigned)c, magic);
+      bkt += ((unsigned)c - bkt * width) >= width;
+      if (bkt != cur) {
+        if (run) atomicAdd(&s_cnt[cur], run);
+        cur = bkt;
+        run = 0;
+      }
+      run++;
+      const int diff = c - (int32_t)row;
+      inb += (unsigned)(diff < 0 ? -diff : diff) <= band;
     }
-    run++;
-    const int diff = c - (int32_t)row;
-    inb += (unsigned)(diff < 0 ? -diff : diff) <= band;
-  }
-  if (run) atomicAdd(&s_cnt[cur], run);
-  inb = sbx_wave_sum(inb);
-  if (sbx_lane() == 0) s_inb[tid >> 6] = inb;
-  __syncthreads();
-  unsigned *slot = slots + li * 65;
-  if (tid < 64 && s_cnt[tid]) atomicAdd(&slot[tid], s_cnt[tid]);
-  if (tid == 64) {
-    const unsigned t = s_inb[0] + s_inb[1] + s_inb[2] + s_inb[3];
-    if (t) atomicAdd(&slot[64], t);
+    if (run) atomicAdd(&s_cnt[cur], run);
+    inb = sbx_wave_sum(inb);
+    if (sbx_lane() == 0) s_inb[tid >> 6] = inb;
+    __syncthreads();
+    unsigned *slot = slots + li * 65;
+    if (tid < 64 && s_cnt[tid]) atomicAdd(&slot[tid], s_cnt[tid]);
+    if (tid == 64) {
+      const unsigned t = s_inb[0] + s_inb[1] + s_inb[2] + s_inb[3];
+      if (t) atomicAdd(&slot[64], t);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_gray_long_finish(const int32_t *__restrict__ rp, const int32_t *__restrict__ list,
-                                                          unsigned n_long, const unsigned *__restrict__ slots, int bits,
+                                                          const unsigned *__restrict__ n_long,
+                                                          const unsigned *__restrict__ slots, int bits,
                                                           int nnz_threshold, int32_t *__restrict__ degree_out,
                                                           unsigned long long *__restrict__ key_out,
                                                           GrayCounts *__restrict__ counts) {
-  const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= n_long) return;
-  const int64_t row = list[li];
-  const int d = rp[row + 1] - rp[row];
-  const unsigned *slot = slots + (size_t)li * 65;
-  const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
-  unsigned long long key = 0;
-  for (int b = 0; b < bits; b++) key |= (unsigned long long)(slot[b] > thr) << b;
-  degree_out[row] = d;
-  key_out[row] = gray_decode(key);
-  if (d <= nnz_threshold) {  // (a long row below the threshold: only with huge thresholds; a handful of adds at most)
-    atomicAdd(&counts->nnz_sparse, (unsigned long long)d);
-    atomicAdd(&counts->diag_sparse, (unsigned long long)slot[64]);
-  } else {
-    atomicAdd(&counts->nnz_dense, (unsigned long long)d);
-    atomicAdd(&counts->diag_dense, (unsigned long long)slot[64]);
+  const unsigned nl = *n_long;
+  if (nl > (unsigned)GR_LONG_LIST) return;
+  const int lane = sbx_lane();
+  // a wave per row, lane b compares block b's count (a thread per row read its 64 counters one after the other:
+  // 24 us for 800 rows)
+  for (unsigned li = blockIdx.x * 4u + (threadIdx.x >> 6); li < nl; li += gridDim.x * 4u) {
+    const int64_t row = list[li];
+    const int d = rp[row + 1] - rp[row];
+    const unsigned *slot = slots + (size_t)li * 65;
+    const unsigned thr = (d > nnz_threshold && d >= bits) ? (unsigned)(d / bits) : 0u;
+    const unsigned cb = slot[lane];
+    const unsigned long long key = __ballot(lane < bits && cb > thr);
+    if (lane == 0) {
+      degree_out[row] = d;
+      key_out[row] = gray_decode(key);
+      if (d <= nnz_threshold) {  // (a long row below the threshold: only with huge thresholds; a handful of adds at most)
+        atomicAdd(&counts->nnz_sparse, (unsigned long long)d);
+        atomicAdd(&counts->diag_sparse, (unsigned long long)slot[64]);
+      } else {
+        atomicAdd(&counts->nnz_dense, (unsigned long long)d);
+        atomicAdd(&counts->diag_dense, (unsigned long long)slot[64]);
+      }
+    }
   }
 }
 
@@ -616,11 +1139,18 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   if (n == 0) return SBX_OK;
   struct GrayBoth {  // band counters and the short-row kernel's long-row count: one fill, one read-back
     GrayCounts c;
-    unsigned nlong, pad;
+    unsigned nlong, pad;  // pad: 0 / 1 / GR_POWER_LAW
   };
-  GrayBoth *both = nullptr;
-  SBX_TRY(sbx_salloc(h, 1, &both));
-  SBX_HIP(h, hipMemsetAsync(both, 0, sizeof(GrayBoth), h->stream));
+  struct GrayAll {
+    GrayBoth b;
+    unsigned fill[GR_FLAG_OFF - 2];
+    unsigned flags[GR_FLAGS * 32];
+  };
+  static_assert(offsetof(GrayAll, flags) == offsetof(GrayBoth, nlong) + GR_FLAG_OFF * 4 && offsetof(GrayAll, flags) % 128 == 0, "flag lines");
+  GrayAll *all = nullptr;
+  SBX_TRY(sbx_salloc(h, 1, &all));
+  SBX_HIP(h, hipMemsetAsync(all, 0, sizeof(GrayAll), h->stream));
+  GrayBoth *both = &all->b;
   GrayCounts *cnt = &both->c;
   const int64_t band = m / 128;  // :138
   // c / width = umulhi(c, magic) or that + 1 (c < 2^31): magic = floor(2^32 / width), saturated for width 1
@@ -645,44 +1175,105 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
       int wshift = -1;
       if ((width & (width - 1)) == 0)
         for (wshift = 0; ((int64_t)1 << wshift) < width; wshift++) {}
-#define GRAY_SHORT(B, LV)                                                                                          \
+#define GRAY_ROWS(K, GRID, B, LV, ...)                                                                              \
   do {                                                                                                             \
     if (wshift >= 0)                                                                                               \
-      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, true>), dim3(grid), dim3(256), rp, cl, n, (uint32_t)width, \
-                  magic, (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong,   \
-                  long_list);                                                                                      \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (K<B, LV, true>), dim3(GRID), dim3(256), rp, cl, n, (uint32_t)width, magic,        \
+                  (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong, long_list,  \
+                  ##__VA_ARGS__);                                                                                  \
     else                                                                                                           \
-      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_short<B, LV, false>), dim3(grid), dim3(256), rp, cl, n,              \
-                  (uint32_t)width, magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, \
-                  nlong, long_list);                                                                               \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (K<B, LV, false>), dim3(GRID), dim3(256), rp, cl, n, (uint32_t)width, magic,       \
+                  (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong, long_list,       \
+                  ##__VA_ARGS__);                                                                                  \
   } while (0)
-      if (bits <= 32) {
-        if (lv <= 1) GRAY_SHORT(uint32_t, 1);
-        else if (lv <= 3) GRAY_SHORT(uint32_t, 3);
-        else GRAY_SHORT(uint32_t, 5);
-      } else {
-        if (lv <= 1) GRAY_SHORT(unsigned long long, 1);
-        else GRAY_SHORT(unsigned long long, 2);  // 64 blocks: thr <= 64 / 64
-      }
-#undef GRAY_SHORT
-      SBX_LAUNCH_CHECK(h);
-      // one read-back: how many long rows the kernel met and — final if there were none — the band counters
+#define GRAY_ROWS_BY_LEVELS(K, GRID, ...)                                                                           \
+  do {                                                                                                             \
+    if (bits <= 32) {                                                                                              \
+      if (lv <= 1) GRAY_ROWS(K, GRID, uint32_t, 1, ##__VA_ARGS__);                                                 \
+      else if (lv <= 3) GRAY_ROWS(K, GRID, uint32_t, 3, ##__VA_ARGS__);                                            \
+      else GRAY_ROWS(K, GRID, uint32_t, 5, ##__VA_ARGS__);                                                         \
+    } else {                                                                                                       \
+      if (lv <= 1) GRAY_ROWS(K, GRID, unsigned long long, 1, ##__VA_ARGS__);                                       \
+      else GRAY_ROWS(K, GRID, unsigned long long, 2, ##__VA_ARGS__); /* 64 blocks: thr <= 64 / 64 */               \
+    }                                                                                                              \
+  } while (0)
+      static const bool try_banded = !(getenv("SBX_GRAY_BANDED_FIRST") && atoi(getenv("SBX_GRAY_BANDED_FIRST")) == 0);
       GrayBoth hb;
-      SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
-      const unsigned hlong = hb.nlong;
-      if (hlong <= (unsigned)GR_LONG_LIST) {
+      hb.nlong = 0, hb.pad = GR_POWER_LAW;
+      if (try_banded) {
+        GRAY_ROWS_BY_LEVELS(k_gray_rows_short, grid);
+        SBX_LAUNCH_CHECK(h);
+        // one read-back: how many long rows the kernel met and — final if there were none — the band counters
+        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+      }
+      const int wsh = wshift >= 0 ? wshift : -1;
+      // the lists of k_gray_rows_medium: a row above GR_SHORT_MAX entries is at least one unit, every further unit is
+      // GU_SIZE entries of it; a row of k > 1 units has more than (k - 1) GU_SIZE entries, and k <= 2 (k - 1)
+      const size_t max_units = (size_t)(nnz / (GR_SHORT_MAX + 1) < n ? nnz / (GR_SHORT_MAX + 1) : n) + (size_t)(nnz / GU_SIZE) + 1;
+      const size_t max_slots = 2 * (size_t)(nnz / GU_SIZE) + 2, max_mrows = (size_t)(nnz / GU_SIZE) + 1;
+      int4 *units = nullptr, *mrows = nullptr;
+      GrayLists *lc = nullptr;
+      unsigned *partial = nullptr;
+      auto alloc_lists = [&]() -> int {
+        SBX_TRY(sbx_salloc(h, max_units, &units));
+        SBX_TRY(sbx_salloc(h, max_mrows, &mrows));
+        SBX_TRY(sbx_salloc(h, max_slots * GU_SLOT, &partial));
+        SBX_TRY(sbx_salloc(h, 1, &lc));
+        SBX_HIP(h, hipMemsetAsync(lc, 0, sizeof(GrayLists), h->stream));
+        return SBX_OK;
+      };
+      if (hb.pad == GR_POWER_LAW) {
+        // the kernel found the body of a power-law degree distribution and stopped (or was not tried): start over
+        // with the kernels that cost per entry; no read-back until the end
+        SBX_TRY(alloc_lists());
+        SBX_HIP(h, hipMemsetAsync(both, 0, sizeof(GrayBoth), h->stream));
+        GrayCounts *spread = nullptr;
+        SBX_TRY(sbx_salloc(h, (size_t)GR_SPREAD * 4, &spread));
+        SBX_HIP(h, hipMemsetAsync(spread, 0, sizeof(GrayCounts) * GR_SPREAD * 4, h->stream));
+        const int64_t brows = (int64_t)GB_ITERS * 4 * GB_GROUPS * 64;  // rows per workgroup
+        const unsigned bgrid = (unsigned)((n + brows - 1) / brows);
+        {
+          GrayCounts *cnt = spread;  // (what the launch macro passes as the counters)
+          GRAY_ROWS_BY_LEVELS(k_gray_rows_balanced, bgrid, units, mrows, lc);
+        }
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,
+                    (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,
+                    nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, spread, (unsigned)GR_SPREAD);
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus), dim3(256), rp, (const int4 *)mrows,
+                    (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
+                    cnt, (const GrayCounts *)spread, (unsigned)GR_SPREAD);
+        SBX_LAUNCH_CHECK(h);
+        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+        hb.pad = 0;
+      } else if (hb.nlong <= (unsigned)GR_LONG_LIST && (hb.nlong || hb.pad)) {
+        const unsigned hlong = hb.nlong;
+        if (hb.pad) {  // a few rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries: listed, then a wave per unit
+          SBX_TRY(alloc_lists());
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_list_medium, dim3((unsigned)((n + GL_ROWS - 1) / GL_ROWS)), dim3(256), rp, n,
+                      units, mrows, lc);
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,
+                      (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,
+                      nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, cnt, 1u);
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3(64), dim3(256), rp, (const int4 *)mrows,
+                      (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
+                      cnt, (const GrayCounts *)cnt, 1u);
+        }
         if (hlong) {
           unsigned *slots = nullptr;
           SBX_TRY(sbx_salloc(h, (size_t)hlong * 65, &slots));
           SBX_HIP(h, hipMemsetAsync(slots, 0, sizeof(unsigned) * (size_t)hlong * 65, h->stream));
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_rows, dim3(hlong * GR_PARTS), dim3(256), rp, cl,
-                      (const int32_t *)long_list, (uint32_t)width, magic, (uint32_t)band, slots);
-          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 255) / 256), dim3(256), rp,
-                      (const int32_t *)long_list, hlong, (const unsigned *)slots, bits, nnz_threshold,
+                      (const int32_t *)long_list, (const unsigned *)nlong, (uint32_t)width, magic, (uint32_t)band, slots);
+          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 3) / 4), dim3(256), rp,
+                      (const int32_t *)long_list, (const unsigned *)nlong, (const unsigned *)slots, bits, nnz_threshold,
                       (int32_t *)degree_out, keys, cnt);
-          SBX_LAUNCH_CHECK(h);
-          SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
         }
+        SBX_LAUNCH_CHECK(h);
+        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+      }
+#undef GRAY_ROWS_BY_LEVELS
+#undef GRAY_ROWS
+      if (hb.nlong <= (unsigned)GR_LONG_LIST) {  // (the power-law path lists nothing there)
         SBX_PROF_BYTES(h, SBX_K_GRAY, 4 * nnz + 16 * n + 4);
         counts_host[0] = (int64_t)hb.c.nnz_sparse;
         counts_host[1] = (int64_t)hb.c.diag_sparse;
@@ -690,7 +1281,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         counts_host[3] = (int64_t)hb.c.diag_dense;
         return SBX_OK;
       }
-      // too many long rows: the kernel left early; start over with the tile kernel
+      // more rows above GR_MED_MAX entries than the list holds: start over with the tile kernel
       SBX_HIP(h, hipMemsetAsync(cnt, 0, sizeof(GrayCounts), h->stream));
     }
   }

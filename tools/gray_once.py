@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Two Gray key stages on the power-law bench matrix: the target of rocprofv3 --kernel-trace."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sparsebase_amd import ops, synth
+rp, col = synth.rmat_symmetric_torch(22, 13, seed=1)
+n = rp.numel() - 1
+for _ in range(2):
+    ops.gray_row_keys(n, rp, col, 32, 10)
+torch.cuda.synchronize()
