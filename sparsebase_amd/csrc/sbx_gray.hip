@@ -628,9 +628,15 @@ __global__ __launch_bounds__(256) void k_gray_list_medium(const int32_t *__restr
 // level t carries it to level t + 1, so level t ends up set iff the block was met more than t times, in any order.
 // Cost: a step of ~45 VALU instructions per 64 ENTRIES + ~100 per 64 rows, against ~400 per 16 rows in
 // k_gray_rows_short.  (gray_reorder.cc:138-170, :249-267, :384-395)
+#ifndef GB_ITERS_V
+#define GB_ITERS_V 4
+#endif
+#ifndef GB_WINDOW_V
+#define GB_WINDOW_V 256
+#endif
 constexpr int GB_GROUPS = 4;
-constexpr int GB_ITERS = 4;      // blocks of 4 x GB_GROUPS x 64 rows per workgroup: one list reservation for all of them
-constexpr int GB_WINDOW = 256;  // entries per pass: their row lookups, then their loads, then their ORs
+constexpr int GB_ITERS = GB_ITERS_V;      // blocks of 4 x GB_GROUPS x 64 rows per workgroup: one list reservation for all of them
+constexpr int GB_WINDOW = GB_WINDOW_V;  // entries per pass: their row lookups, then their loads, then their ORs
 template <typename B, int LV, bool POW2>
 __global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
                                                             int64_t n, uint32_t width, uint32_t magic, uint32_t band,
@@ -685,31 +691,51 @@ __global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__res
     for (int t = 0; t < LV; t++) s_ge[wv][t][lane] = 0;
     GR_WAVE_FENCE();
     int carry = 0;
-    for (int k0 = 0; k0 < T; k0 += GB_WINDOW) {
-      // (the LDS operations of one wave execute in order: no barrier between the head writes and the reads)
-      if (ds > 0 && off >= k0 && off < k0 + GB_WINDOW) s_head[wv][off - k0] = lane;
-      GR_WAVE_FENCE();
-      int rl[GB_WINDOW / 64] = {};
-      unsigned c[GB_WINDOW / 64] = {};
+    int rl_nx[GB_WINDOW / 64] = {};
+    unsigned c_nx[GB_WINDOW / 64] = {};
+    // the row lookups of the window at k0 and its loads — always GB_WINDOW / 64 loads, past the end of the group too
+    // (dummies): with a path that issues fewer the compiler cannot count the loads behind the ones it waits for
+    auto prepare = [&](int k0) {
+      if (k0 < T) {  // (wave-uniform)
+        // (the LDS operations of one wave execute in order: no barrier between the head writes and the reads)
+        if (ds > 0 && off >= k0 && off < k0 + GB_WINDOW) s_head[wv][off - k0] = lane;
+        GR_WAVE_FENCE();
 #pragma unroll
-      for (int u = 0; u < GB_WINDOW / 64; u++) {
-        if (k0 + u * 64 < T) {  // (wave-uniform.  Guards, not breaks: see k_gray_rows_medium)
-          const int hd = s_head[wv][u * 64 + lane];
-          s_head[wv][u * 64 + lane] = -1;
-          int m = sbx_wave_inclusive_max(hd);
-          m = m > carry ? m : carry;
-          carry = __builtin_amdgcn_readlane(m, 63);
-          rl[u] = m;
+        for (int u = 0; u < GB_WINDOW / 64; u++) {
+          if (k0 + u * 64 < T) {  // (wave-uniform.  Guards, not breaks: see k_gray_rows_medium)
+            const int hd = s_head[wv][u * 64 + lane];
+            s_head[wv][u * 64 + lane] = -1;
+            int m = sbx_wave_inclusive_max(hd);
+            m = m > carry ? m : carry;
+            carry = __builtin_amdgcn_readlane(m, 63);
+            rl_nx[u] = m;
+          }
         }
       }
-      // the window's loads go out together (a step at a time, each step's load was waited for before the next
-      // step's address existed: 120 us for the bench matrix's 21 M short-row entries)
 #pragma unroll
       for (int u = 0; u < GB_WINDOW / 64; u++) {
         const int q = k0 + u * 64 + lane;
-        const int at = q < T ? s_base[wv][rl[u]] + q : 0;  // (unconditional: a load under a condition is waited for at the join)
-        c[u] = (unsigned)col[at];
+        const int at = q < T ? s_base[wv][rl_nx[u]] + q : 0;
+        c_nx[u] = (unsigned)col[at];
       }
+    };
+    // the next window's loads are in flight while this one is ORed into its rows' words (a window at a time, a group
+    // of 64 rows of 64 entries is 16 load latencies one after the other, and the rows of a power-law matrix with
+    // 33..64 entries sit next to each other: those waves were the kernel's last 60 us)
+#if defined(GB_ABL) && GB_ABL == 2
+    if (r00 < 0)
+#endif
+    prepare(0);
+#if defined(GB_ABL) && GB_ABL == 2
+    for (int k0 = 0; k0 < T && r00 < 0; k0 += GB_WINDOW) {
+#else
+    for (int k0 = 0; k0 < T; k0 += GB_WINDOW) {
+#endif
+      int rl[GB_WINDOW / 64];
+      unsigned c[GB_WINDOW / 64];
+#pragma unroll
+      for (int u = 0; u < GB_WINDOW / 64; u++) rl[u] = rl_nx[u], c[u] = c_nx[u];
+      prepare(k0 + GB_WINDOW);
 #pragma unroll
       for (int u = 0; u < GB_WINDOW / 64; u++) {
         if (k0 + u * 64 >= T) continue;
@@ -772,7 +798,9 @@ __global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__res
     const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
     if (t) atomicAdd(&counts[(blockIdx.x % GR_SPREAD) * 4].nnz_sparse + threadIdx.x, t);
   }
+#if !defined(GB_ABL) || GB_ABL != 1  // (timing ablation builds only: tools/build_variant.py)
   gray_emit_units(listed, [&](int i) { return block_row(i / GB_GROUPS) + (i % GB_GROUPS) * 64; }, units, mrows, lc, s_w, s_b);
+#endif
 }
 
 // One wave per listed unit, round-robin over the list.  (Finding the rows where they are — a wave per 64 consecutive
@@ -790,6 +818,11 @@ __global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__res
 constexpr int GM_DEPTH = 4;   // steps in flight per wave
 constexpr int GM_STEP = 256;  // entries per step
 constexpr int GU_SLOT = 65;   // words of a partial slot: 64 block counts, the band count
+// (The scalar unit is shared by the four SIMDs of a CU and was the busiest part of the first versions — 86 scalar
+// instructions per step, most of them copies of per-step bookkeeping and exec-mask handling: the fetch and the count
+// side now each walk the unit table with a cursor of their own, and the adds are unconditional with a value of 0
+// where a lane has nothing to add.)
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
                                                           const int4 *__restrict__ units,
                                                           const GrayLists *__restrict__ lc, uint32_t width,
@@ -801,68 +834,66 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
                                                           GrayCounts *__restrict__ counts, unsigned spread) {
   __shared__ unsigned s_cnt[4][64];
   __shared__ unsigned long long s_red[4][4];
-  __shared__ int32_t s_tab[4][5][64];  // row, first entry, end, row length, partial slot
+  __shared__ int32_t s_tab[4][6][64];  // row, first entry, end, row length, partial slot, threshold
+  __shared__ unsigned s_idle[4][64];   // where lanes with nothing to count add
   const int lane = sbx_lane();
   // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes of a wave; with it the
   // cursors below are scalars and their branches scalar branches)
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned gwave = blockIdx.x * 4u + (unsigned)wv, nwaves = gridDim.x * 4u;
   const unsigned total = (unsigned)lc->units_slots;
-  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;  // (wave-uniform)
+  unsigned long long v_ns = 0, v_ds = 0, v_nd = 0, v_dd = 0;  // (the same in every lane)
   const int mine = gwave < total ? (int)((total - gwave + nwaves - 1) / nwaves) : 0;  // this wave's units: units[gwave + k nwaves]
   // the bounds of 64 of the wave's units at a time, in LDS (list -> row_ptr: two dependent loads, paid once per 64
   // units instead of once per unit); the pipeline drains between such blocks
   for (int kb = 0; kb < mine; kb += 64) {
     const int blk = mine - kb < 64 ? mine - kb : 64;
     {
-      int32_t t_row = 0, t_a = 0, t_b = 0, t_dd = 0, t_slot = -1;
+      int32_t t_row = 0, t_a = 0, t_b = 0, t_dd = 0, t_slot = -1, t_thr = 0;
       if (lane < blk) {
         const int4 un = units[gwave + (unsigned)(kb + lane) * nwaves];
         const int32_t rs = rp[un.x], re = rp[un.x + 1];
         t_row = un.x, t_a = rs + un.y, t_dd = re - rs, t_slot = un.z;
         t_b = re - t_a < GU_SIZE ? re : t_a + GU_SIZE;
+        t_thr = (t_dd > nnz_threshold && t_dd >= bits) ? t_dd / bits : 0;
       }
       s_tab[wv][0][lane] = t_row, s_tab[wv][1][lane] = t_a, s_tab[wv][2][lane] = t_b, s_tab[wv][3][lane] = t_dd,
-      s_tab[wv][4][lane] = t_slot;      GR_WAVE_FENCE();
+      s_tab[wv][4][lane] = t_slot, s_tab[wv][5][lane] = t_thr;
+      GR_WAVE_FENCE();
     }
     auto table = [&](int what, int k) { return __builtin_amdgcn_readfirstlane(s_tab[wv][what][k]); };
     // the fetch cursor: the next step to load.  A load on EVERY call, past the end of the stream too: with a path that
     // skips one the compiler cannot count the loads behind the one it waits for, and waits for all of them
     int f_k = 0;
-    int32_t f_row = table(0, 0), f_j = table(1, 0), f_b = table(2, 0), f_dd = table(3, 0), f_slot = table(4, 0);
+    int32_t f_j = table(1, 0), f_b = table(2, 0);
     GrU4 R[GM_DEPTH];
-    int32_t m_row[GM_DEPTH], m_b[GM_DEPTH], m_j[GM_DEPTH], m_dd[GM_DEPTH], m_slot[GM_DEPTH];  // (compile-time indices: scalars)
     auto fetch = [&](int u) {
-      m_row[u] = f_row, m_b[u] = f_b, m_j[u] = f_j, m_dd[u] = f_dd, m_slot[u] = f_slot;
-      const int32_t jj = f_row >= 0 ? f_j + 4 * lane : 0;
+      const int32_t jj = f_k < blk ? f_j + 4 * lane : 0;
       R[u] = *(const GrU4 *)(col + gr_clamp4(jj, nnz));  // (only 4-byte aligned: gfx950 loads unaligned vectors)
-      if (f_row < 0) return;
-      f_j += GM_STEP;
-      if (f_j >= f_b) {  // next unit
-        f_k++;
-        if (f_k >= blk) {
-          f_row = -1;
-        } else {
-          f_row = table(0, f_k), f_j = table(1, f_k), f_b = table(2, f_k), f_dd = table(3, f_k), f_slot = table(4, f_k);
+      if (f_k < blk) {
+        f_j += GM_STEP;
+        if (f_j >= f_b) {  // next unit
+          f_k++;
+          if (f_k < blk) f_j = table(1, f_k), f_b = table(2, f_k);
         }
       }
     };
 #pragma unroll
     for (int u = 0; u < GM_DEPTH; u++) fetch(u);
+    // the count cursor: the same walk, GM_DEPTH steps behind
+    int c_k = 0;
+    int32_t c_row = table(0, 0), c_j = table(1, 0), c_b = table(2, 0);
     s_cnt[wv][lane] = 0;  // (the LDS operations of one wave execute in order: no barrier around the counters)
     GR_WAVE_FENCE();
     unsigned inb = 0;
-    bool more = true;
-    while (more) {
+    while (c_k < blk) {
 #pragma unroll
       for (int u = 0; u < GM_DEPTH; u++) {
-        const int32_t row = m_row[u], ue = m_b[u], j0 = m_j[u];
         // (no break here: with an exit from the middle of the ring the compiler gives up counting the loads in flight
         // and waits for all of them before every step; past the end of the stream the remaining steps are skipped)
-        if (row < 0) more = false;
-        if (row >= 0) {
-          const int32_t j = j0 + 4 * lane;
-          const int left = ue - j;
+        if (c_k < blk) {
+          const int32_t j = c_j + 4 * lane;
+          const int left = c_b - j;
           const int cnt = left < 0 ? 0 : (left > 4 ? 4 : left);
           unsigned c[4] = {R[u].x, R[u].y, R[u].z, R[u].w};
           if (__any(j > nnz - 4 && cnt > 0)) {  // the end of the array: the vector was read up to 3 entries early
@@ -877,50 +908,74 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
             }
           }
           unsigned bkt[4];
+          const unsigned row_lo = (unsigned)c_row - band, band2 = 2u * band;  // |c - row| <= band  <=>  c - row_lo <= 2 band (mod 2^32)
 #pragma unroll
           for (int t = 0; t < 4; t++) {
-            if (wshift >= 0) {
+            if (POW2) {
               bkt[t] = c[t] >> wshift;
             } else {
               bkt[t] = __umulhi(c[t], magic);
               bkt[t] += (c[t] - bkt[t] * width) >= width;
             }
-            inb += t < cnt && c[t] - ((unsigned)row - band) <= 2u * band;  // |c - row| <= band
+            inb += t < cnt && c[t] - row_lo <= band2;
           }
-          // a lane whose entries fall into one block adds their number once (neighbouring columns share a block
-          // unless the row is spread over the whole width; then there are few equal ones to queue on a word)
+          // The columns of a row ascend, so its entries come in RUNS of equal blocks: the first lane of a run of lanes
+          // whose four entries all fall into one block adds the run's length, in one add; only the lanes a block
+          // boundary passes through add their entries one by one.  (Every lane adding its own entries to 64 words
+          // kept the LDS busy with bank conflicts for 84 % of its cycles, tools/pmc_gray.sh, and the waves waiting on
+          // it for half of theirs.)  Rows whose columns do NOT ascend are counted correctly too, just with more adds.
+          const bool active = cnt > 0;
           const bool uni = (cnt < 2 || bkt[1] == bkt[0]) && (cnt < 3 || bkt[2] == bkt[0]) && (cnt < 4 || bkt[3] == bkt[0]);
-          if (cnt > 0) {
-            if (uni) {
-              atomicAdd(&s_cnt[wv][bkt[0]], (unsigned)cnt);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 4; t++)
-                if (t < cnt) atomicAdd(&s_cnt[wv][bkt[t]], 1u);
-            }
+          const unsigned rk = active && uni ? bkt[0] : 0xFFFFFFFFu;
+          const unsigned prev = sbx_wave_shift_up1(rk, 0xFFFFFFFEu);
+          const bool head = active && uni && rk != prev;
+          const uint64_t stops = __ballot(head || !(active && uni));  // where a run ends: the next run, a mixed lane, the end
+          {
+            const int left_u = c_b - c_j;  // entries of this step
+            const int nvalid = left_u < GM_STEP ? left_u : GM_STEP;
+            const uint64_t above = lane < 63 ? stops & ~(((uint64_t)2 << lane) - 1) : 0;
+            const int next = above ? __builtin_ctzll(above) : 64;
+            const int upto = 4 * next < nvalid ? 4 * next : nvalid;
+            // (no add under a condition — a branch on the exec mask is three scalar instructions, and the scalar unit
+            // is the busy one: a lane with nothing to add adds to a word of its own)
+            atomicAdd(head ? &s_cnt[wv][rk] : &s_idle[wv][lane], (unsigned)(upto - 4 * lane));
           }
-          if (j0 + GM_STEP >= ue) {  // the unit's last step
-            const int32_t dd = m_dd[u], slot = m_slot[u];
+          if (__any(active && !uni)) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) atomicAdd(active && !uni && t < cnt ? &s_cnt[wv][bkt[t]] : &s_idle[wv][lane], 1u);
+          }
+          if (c_j + GM_STEP >= c_b) {  // the unit's last step
+            const int32_t dd = table(3, c_k), slot = table(4, c_k);
+            const unsigned thr = (unsigned)table(5, c_k);
             inb = sbx_wave_sum(inb);
             GR_WAVE_FENCE();
             const unsigned cb = s_cnt[wv][lane];
             s_cnt[wv][lane] = 0;
             GR_WAVE_FENCE();
+            // (from here on in vector registers although the values are the same in every lane: the scalar unit is
+            // shared by four SIMDs and busy with the cursors)
+            int row_v = c_row, dd_v = dd;
+            asm volatile("" : "+v"(row_v), "+v"(dd_v));
             if (slot >= 0) {  // one of several units of its row: k_gray_units_finish adds them up
               unsigned *ps = partial + (size_t)slot * GU_SLOT;
               ps[lane] = cb;
               if (lane == 0) ps[64] = inb;
             } else {
-              const unsigned thr = (dd > nnz_threshold && dd >= bits) ? (unsigned)(dd / bits) : 0u;
-              const uint64_t key = __ballot(lane < bits && cb > thr);
+              unsigned long long key = __ballot(lane < bits && cb > thr);
+              asm volatile("" : "+v"(key));
               if (lane == 0) {
-                degree_out[row] = dd;
-                key_out[row] = gray_decode(key);
+                degree_out[row_v] = dd_v;
+                key_out[row_v] = gray_decode(key);
               }
-              if (dd <= nnz_threshold) c_ns += (unsigned)dd, c_ds += inb;
-              else c_nd += (unsigned)dd, c_dd += inb;
+              const bool sparse_v = dd_v <= nnz_threshold;
+              v_ns += sparse_v ? (unsigned)dd_v : 0u, v_ds += sparse_v ? inb : 0u;
+              v_nd += sparse_v ? 0u : (unsigned)dd_v, v_dd += sparse_v ? 0u : inb;
             }
             inb = 0;
+            c_k++;
+            if (c_k < blk) c_row = table(0, c_k), c_j = table(1, c_k), c_b = table(2, c_k);
+          } else {
+            c_j += GM_STEP;
           }
         }
         fetch(u);
@@ -928,7 +983,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
     }
   }
   if (lane == 0) {
-    s_red[wv][0] = c_ns; s_red[wv][1] = c_ds; s_red[wv][2] = c_nd; s_red[wv][3] = c_dd;
+    s_red[wv][0] = v_ns; s_red[wv][1] = v_ds; s_red[wv][2] = v_nd; s_red[wv][3] = v_dd;
   }
   __syncthreads();
   if (threadIdx.x < 4) {
@@ -1214,6 +1269,17 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
       int4 *units = nullptr, *mrows = nullptr;
       GrayLists *lc = nullptr;
       unsigned *partial = nullptr;
+#define GRAY_MEDIUM(COUNTS, NSPREAD)                                                                                 \
+  do {                                                                                                             \
+    if (wshift >= 0)                                                                                               \
+      SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium<true>, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,       \
+                  (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,     \
+                  nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, COUNTS, NSPREAD);              \
+    else                                                                                                           \
+      SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium<false>, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,      \
+                  (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,     \
+                  nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, COUNTS, NSPREAD);              \
+  } while (0)
       auto alloc_lists = [&]() -> int {
         SBX_TRY(sbx_salloc(h, max_units, &units));
         SBX_TRY(sbx_salloc(h, max_mrows, &mrows));
@@ -1236,9 +1302,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
           GrayCounts *cnt = spread;  // (what the launch macro passes as the counters)
           GRAY_ROWS_BY_LEVELS(k_gray_rows_balanced, bgrid, units, mrows, lc);
         }
-        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,
-                    (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,
-                    nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, spread, (unsigned)GR_SPREAD);
+        GRAY_MEDIUM(spread, (unsigned)GR_SPREAD);
         SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus), dim3(256), rp, (const int4 *)mrows,
                     (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
                     cnt, (const GrayCounts *)spread, (unsigned)GR_SPREAD);
@@ -1251,9 +1315,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
           SBX_TRY(alloc_lists());
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_list_medium, dim3((unsigned)((n + GL_ROWS - 1) / GL_ROWS)), dim3(256), rp, n,
                       units, mrows, lc);
-          SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,
-                      (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,
-                      nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, cnt, 1u);
+          GRAY_MEDIUM(cnt, 1u);
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3(64), dim3(256), rp, (const int4 *)mrows,
                       (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
                       cnt, (const GrayCounts *)cnt, 1u);
@@ -1271,6 +1333,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         SBX_LAUNCH_CHECK(h);
         SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
       }
+#undef GRAY_MEDIUM
 #undef GRAY_ROWS_BY_LEVELS
 #undef GRAY_ROWS
       if (hb.nlong <= (unsigned)GR_LONG_LIST) {  // (the power-law path lists nothing there)

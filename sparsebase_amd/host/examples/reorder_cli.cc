@@ -3,7 +3,8 @@
 // C++ API end to end (Gray's device keys + host ordering stage in particular) against
 // fixtures produced by the real reference.
 // Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time]
-// --time repeats the call once and prints the second (warm) call's wall time in seconds on stdout
+// --time repeats the call twice and prints the third (warm) call's wall time in seconds on stdout (gray: and, on a
+// second line, the ms of its device key stage, of the copy of the keys to the host and of the host ordering stage)
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -66,9 +67,15 @@ int main(int argc, char **argv) {
   if (!order) return 1;
   if (timed) {
     delete[] order;
+    order = run();  // (the library settles its scratch arena into one block at the start of the second call)
+    delete[] order;
     const auto t0 = std::chrono::steady_clock::now();
     order = run();
     std::printf("%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (kind == "gray") {  // the stages of that call: device key stage, keys to the host, host ordering (ms)
+      const double *st = reorder::GrayReorder<int, int, void>::last_stage_ms();
+      std::printf("%.4f %.4f %.4f\n", st[0], st[1], st[2]);
+    }
   }
   std::ofstream out(argv[4], std::ios::binary);
   out.write((const char *)order, (size_t)n * sizeof(int));

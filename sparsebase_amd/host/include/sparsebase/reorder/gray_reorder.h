@@ -12,6 +12,7 @@
 //           device-computed keys (O(n log n) on rows, nothing touches the nonzeros).
 #ifndef SPARSEBASE_REORDER_GRAY_REORDER_H_
 #define SPARSEBASE_REORDER_GRAY_REORDER_H_
+#include <chrono>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -44,6 +45,13 @@ class GrayReorder : public Reorderer<IDType> {
   }
   explicit GrayReorder(GrayReorderParams p)
       : GrayReorder(p.resolution, p.nnz_threshold, p.sparse_density_group_size) {}
+  /// Wall time of the last call's stages in this process, in ms: the device key stage (sbx_gray_row_keys, which ends
+  /// with a blocking read-back), the copy of degrees and keys to the host, the host ordering stage.  (Not in the
+  /// reference: what bench.py reports as Gray end to end.)
+  static double *last_stage_ms() {
+    static double ms[3] = {0, 0, 0};
+    return ms;
+  }
 
  protected:
   static bool desc_comparator(const row_grey_pair &l, const row_grey_pair &r) { return l.second > r.second; }
@@ -52,6 +60,8 @@ class GrayReorder : public Reorderer<IDType> {
   static IDType *Run(detail::DeviceCsrView<IDType, NNZType, ValueType> v, utils::Parameters *poly) {
     auto *params = static_cast<GrayReorderParams *>(poly);
     const int64_t n = v.n;
+    using clock = std::chrono::steady_clock;
+    auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
     // ---- device stage
     std::vector<IDType> deg((size_t)n);
     std::vector<uint64_t> key((size_t)n);
@@ -59,16 +69,25 @@ class GrayReorder : public Reorderer<IDType> {
     {
       hip::Staged<IDType> d_deg(*v.dev, (size_t)n);
       hip::Staged<uint64_t> d_key(*v.dev, (size_t)n);
+      auto t0 = clock::now();
       const int rc = sbx_gray_row_keys(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
                                        (int)params->resolution, params->nnz_threshold, d_deg.get(), d_key.get(),
-                                       counts);
+                                       counts);  // (returns after its last read-back: the stage is complete)
+      last_stage_ms()[0] = ms_since(t0);
+      t0 = clock::now();
       if (rc == SBX_OK && n > 0) {
         d_deg.ToHost(deg.data());
         d_key.ToHost(key.data());
       }
+      last_stage_ms()[1] = ms_since(t0);
       v.Release();
       v.dev->Check(rc);
     }
+    const auto t_host = clock::now();
+    struct HostStageTimer {  // (the ordering stage below returns from several places)
+      clock::time_point t;
+      ~HostStageTimer() { last_stage_ms()[2] = std::chrono::duration<double, std::milli>(clock::now() - t).count(); }
+    } host_stage_timer{t_host};
     // ---- host ordering stage (see header comment)
     const int group_size = params->sparse_density_group_size;
     std::vector<IDType> sparse_rows, dense_rows;

@@ -4,7 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from sparsebase_amd import ops, synth
+from sparsebase_amd import capi, ops, synth
+if os.environ.get("SBX_PROBE_LIB"):  # a variant built by tools/build_variant.py
+    capi.LIB_PATH = os.path.join(ROOT, "sparsebase_amd", "lib", f"libsbx_{os.environ['SBX_PROBE_LIB']}.so")
 def bench(name, n, rp, col, res, thr):
     for _ in range(3): ops.gray_row_keys(n, rp, col, res, thr)
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -9,7 +9,9 @@ export TMPDIR=/tmp C5_ONLY_BANDED=1
 RE=${1:-k_gray_rows_short}; PROBE=${2:-tools/c5_probe.py}
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
-           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; do
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC" \
+           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL SQ_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_LEVEL_WAVES"; do
   i=$((i+1)); rm -rf /tmp/pmcg_$i
   timeout 150 rocprofv3 --kernel-include-regex "$RE" --pmc $set --output-format csv -d /tmp/pmcg_$i -o p -- python3 $PROBE > "$OUT/pmc_gray_$i.log" 2>&1
 done
