@@ -1196,10 +1196,13 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     GrayCounts c;
     unsigned nlong, pad;  // pad: 0 / 1 / GR_POWER_LAW
   };
-  struct GrayAll {
+  struct GrayAll {  // everything the kernels count in: one fill at the start of the call
     GrayBoth b;
     unsigned fill[GR_FLAG_OFF - 2];
     unsigned flags[GR_FLAGS * 32];
+    alignas(128) GrayCounts total2;  // the power-law path's counters (b.c holds what the stopped kernel left)
+    GrayLists lists;
+    alignas(128) GrayCounts spread[GR_SPREAD * 4];
   };
   static_assert(offsetof(GrayAll, flags) == offsetof(GrayBoth, nlong) + GR_FLAG_OFF * 4 && offsetof(GrayAll, flags) % 128 == 0, "flag lines");
   GrayAll *all = nullptr;
@@ -1284,18 +1287,14 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         SBX_TRY(sbx_salloc(h, max_units, &units));
         SBX_TRY(sbx_salloc(h, max_mrows, &mrows));
         SBX_TRY(sbx_salloc(h, max_slots * GU_SLOT, &partial));
-        SBX_TRY(sbx_salloc(h, 1, &lc));
-        SBX_HIP(h, hipMemsetAsync(lc, 0, sizeof(GrayLists), h->stream));
+        lc = &all->lists;  // (zeroed with the rest at the start of the call)
         return SBX_OK;
       };
       if (hb.pad == GR_POWER_LAW) {
         // the kernel found the body of a power-law degree distribution and stopped (or was not tried): start over
         // with the kernels that cost per entry; no read-back until the end
         SBX_TRY(alloc_lists());
-        SBX_HIP(h, hipMemsetAsync(both, 0, sizeof(GrayBoth), h->stream));
-        GrayCounts *spread = nullptr;
-        SBX_TRY(sbx_salloc(h, (size_t)GR_SPREAD * 4, &spread));
-        SBX_HIP(h, hipMemsetAsync(spread, 0, sizeof(GrayCounts) * GR_SPREAD * 4, h->stream));
+        GrayCounts *spread = all->spread;
         const int64_t brows = (int64_t)GB_ITERS * 4 * GB_GROUPS * 64;  // rows per workgroup
         const unsigned bgrid = (unsigned)((n + brows - 1) / brows);
         {
@@ -1303,12 +1302,12 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
           GRAY_ROWS_BY_LEVELS(k_gray_rows_balanced, bgrid, units, mrows, lc);
         }
         GRAY_MEDIUM(spread, (unsigned)GR_SPREAD);
-        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus), dim3(256), rp, (const int4 *)mrows,
-                    (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
-                    cnt, (const GrayCounts *)spread, (unsigned)GR_SPREAD);
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus * 4), dim3(256), rp,
+                    (const int4 *)mrows, (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold,
+                    (int32_t *)degree_out, keys, &all->total2, (const GrayCounts *)spread, (unsigned)GR_SPREAD);
         SBX_LAUNCH_CHECK(h);
-        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
-        hb.pad = 0;
+        SBX_TRY(sbx_readback(h, &hb.c, &all->total2, sizeof(GrayCounts)));
+        hb.nlong = 0, hb.pad = 0;
       } else if (hb.nlong <= (unsigned)GR_LONG_LIST && (hb.nlong || hb.pad)) {
         const unsigned hlong = hb.nlong;
         if (hb.pad) {  // a few rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries: listed, then a wave per unit
