@@ -240,7 +240,29 @@ int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void 
 /* ------------------------------------------------------------------ *
  * A7  RCMReorder::GetReorderCSR — reorder/rcm_reorder.cc:83-166 (+ :22-81)
  * Parity is defined for structurally symmetric patterns with column-sorted
- * rows (what the CSR constructor guarantees).  Synchronous.              */
+ * rows (what the CSR constructor guarantees).  Synchronous.
+ *
+ * Grid barriers.  Three of the call's kernels (the small-level runs of the
+ * pseudo-peripheral sweeps and the two tie-break walks, sbx_rcm.hip: gb_wait)
+ * are persistent grids of 64 workgroups that meet at counter barriers in
+ * global memory instead of returning to the host after every BFS level.  A
+ * counter barrier only completes while every workgroup of the grid is
+ * resident, which a plain launch does not promise when ANOTHER process or
+ * stream keeps the GPU's CUs busy.  Every wait is therefore bounded (2^16
+ * polls, a few milliseconds; SBX_DEBUG_GB_SPINS overrides the bound for
+ * tests): a workgroup that runs out of polls raises a flag and leaves, the
+ * others follow, nothing such a kernel computed is committed, and the host —
+ * which finds the flag in its next read-back — redoes that sweep with the
+ * one-launch-per-level kernels.  What the caller sees:
+ *   - the RESULT is the same bit-exact ordering either way, and the call still
+ *     returns SBX_OK: a given-up barrier is not an error;
+ *   - that call takes a few milliseconds longer (the bound), and the next 16
+ *     sbx_rcm_reorder calls on the same handle stay away from the persistent
+ *     kernels (one launch + one read-back per level: about 2x the time on a
+ *     power-law graph), after which they are tried again;
+ *   - nothing is reported through stats_host; sbx_last_error() is untouched.
+ * Sharing one GPU between processes that all run RCM is therefore safe but
+ * slow (plain time slicing); one handle per process and GPU is the intended use. */
 /* ------------------------------------------------------------------ */
 typedef struct sbx_rcm_stats {
   int64_t components;       /* connected components incl. isolated vertices */
@@ -265,7 +287,12 @@ int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,
  * key_out[i] (uint64) = decoded bitmap of row i computed with the row's  *
  * class threshold (sparse rows: 0; dense rows: deg/resolution).          *
  * counts_host[4] = {nnz_sparse, diag_sparse, nnz_dense, diag_dense}.     *
- * Synchronous.  The ordering stage lives above the ABI.  */
+ * Synchronous.  The ordering stage lives above the ABI.
+ * Three families of kernels serve the call, chosen by what the matrix turns
+ * out to be: banded / mesh matrices one sweep of 4 lanes per
+ * row; power-law matrices (the first kernel notices and stops within ~30 us)
+ * per-entry kernels over rows cut into 1024-entry units; resolutions below 16
+ * a nonzero-parallel tile kernel.  The results are identical.              */
 /* ------------------------------------------------------------------ */
 int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, int64_t nnz,
                       const void *row_ptr, const void *col, int resolution, int nnz_threshold,
