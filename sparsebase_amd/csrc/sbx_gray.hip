@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   unsigned c_cur[GR_BATCH];
   gr_load4(col, s_cur + GR_BATCH * sub, nnz, c_cur);
   bool saw_medium = false, stopped = false;
-  unsigned abort_seen = 0;
+  int steps_done = 0;
   for (; row < n; row += step) {
     const int32_t s = s_cur;
     int32_t e = e_cur;
@@ -392,13 +392,18 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
     // k_gray_long_rows as they are met, and once there are more of them than the list holds (a power-law matrix) a wave
     // leaves at its next long row — the host then discards the results and takes the tile kernel.
     const bool long_row = e - s > GR_SHORT_MAX;  // another kernel's business
-    if (abort_seen == GR_POWER_LAW) {  // (some wave found the matrix to be a power-law one: see below)
-      stopped = true;
-      break;
+    // Has some wave found the matrix to be a power-law one (below)?  Looked up in a wave's first three steps — the
+    // flag is raised within microseconds of the kernel's start if it is raised at all, and workgroups that start
+    // later leave at once — and afterwards only by waves that meet a long row themselves: polling at every step cost
+    // the banded matrices 5 – 10 %.  One of GR_FLAGS copies, each on a line of its own (16 K waves polling ONE word
+    // queue on its L2 channel: that alone took the kernel from 0.12 to 0.44 ms).
+    if (steps_done < 3 || __any(long_row)) {
+      if (__atomic_load_n(nlong + GR_FLAG_OFF + (blockIdx.x % GR_FLAGS) * 32, __ATOMIC_RELAXED) == GR_POWER_LAW) {
+        stopped = true;
+        break;
+      }
     }
-    // (tested a step later: the load is not waited for here.  One of GR_FLAGS copies, each on a line of its own: 16 K
-    // waves polling ONE word every step queue on its L2 channel — that alone took the kernel from 0.12 to 0.44 ms)
-    abort_seen = __atomic_load_n(nlong + GR_FLAG_OFF + (blockIdx.x % GR_FLAGS) * 32, __ATOMIC_RELAXED);
+    steps_done++;
     if (__any(long_row)) {  // (nothing on the common path: the counter is only touched by waves that meet such a row)
       // rows above GR_MED_MAX entries are listed for k_gray_long_rows (a handful of hubs, boundary rows of a clamped
       // band); the rows between only raise a flag: k_gray_list_medium finds them again — a power-law matrix has
