@@ -740,6 +740,73 @@ def test_gray_row_keys_long_rows_and_odd_widths(ops, oracle):
     assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
 
 
+def _mixed_rows(g, n, m, lens, sort=True):
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = [g.choice(m, int(l), replace=False) for l in lens]
+    col = np.concatenate([np.sort(r) if sort else r for r in rows]).astype(np.int32) if len(rows) else np.zeros(0, np.int32)
+    return rp, col
+
+
+@pytest.mark.parametrize("res,thr", [(32, 10), (16, 20), (64, 2), (64, 40), (48, 10), (16, 0), (32, 100000)])
+def test_gray_row_keys_power_law_path(ops, oracle, res, thr):
+    """The kernels a power-law matrix gets (sbx_gray.hip: k_gray_rows_short notices and stops, then k_gray_rows_balanced /
+    k_gray_rows_medium / k_gray_units_finish): rows of every class next to each other — empty, 1 .. 64 entries (lane
+    per entry, counted rows among them: 33 .. 64 entries at resolution 32), 65 .. 1024 (one unit), 1025 .. 8192 and
+    above (several units: partial slots), a hub of 40 K entries (40 units) — at power-of-two and other block widths, 32-
+    and 64-bit bitmaps, thresholds on either side of the row lengths, and a last row that ends the array in the middle
+    of a 16-byte load."""
+    g = np.random.default_rng(1000 + res + thr)
+    n = 3000
+    m = res * 1024 if res != 48 else 48 * 1000   # 48: a width that is not a power of two (umulhi division)
+    lens = g.integers(0, 65, n)
+    lens[g.integers(0, n, 400)] = g.integers(65, 1025, 400)          # one-unit rows, two and more per 16 rows in places
+    lens[g.integers(0, n, 60)] = g.integers(1025, 9000, 60)          # rows of several units, on both sides of 8192
+    lens[[5, 6, 7]] = (40000, 1024, 1025)
+    lens[[100, 101, 102, 103]] = (64, 65, 0, 33)
+    lens[n - 1] = 1027                                                # the array ends inside a unit's last vector
+    lens = np.minimum(lens, m)
+    rp, col = _mixed_rows(g, n, m, lens)
+    deg, key, counts = ops.gray_row_keys(m, dev(rp), dev(col), res, thr)
+    wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, res, thr)
+    assert np.array_equal(host(deg), wdeg)
+    bad = np.nonzero(host(key).view(np.uint64) != wkey)[0]
+    assert len(bad) == 0, (bad[:10], lens[bad[:10]])
+    assert list(counts) == wcounts.tolist()
+
+
+def test_gray_row_keys_power_law_path_unsorted_columns(ops, oracle):
+    """The unit kernel adds one count per RUN of equal blocks, which is an optimisation for ascending columns, not an
+    assumption: rows whose columns come in random order (arrays that never went through a CSR constructor) give the
+    same keys."""
+    g = np.random.default_rng(77)
+    n, m = 2000, 32 * 512
+    lens = g.integers(0, 65, n)
+    lens[g.integers(0, n, 300)] = g.integers(65, 3000, 300)
+    rp, col = _mixed_rows(g, n, m, lens, sort=False)
+    for res, thr in ((32, 10), (64, 5)):
+        deg, key, counts = ops.gray_row_keys(m, dev(rp), dev(col), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, res, thr)
+        assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+        assert list(counts) == wcounts.tolist()
+
+
+def test_gray_row_keys_banded_with_a_few_medium_rows(ops, oracle):
+    """A banded matrix with a handful of rows of 65 .. 8192 entries, never two of them among 16 consecutive rows, and two
+    rows above 8192: the banded kernel keeps going, lists the long rows for k_gray_long_rows and raises the flag that
+    sends the medium ones through k_gray_list_medium + the unit kernels."""
+    g = np.random.default_rng(5)
+    n, m = 6000, 32 * 4096
+    lens = g.integers(1, 40, n)
+    for r, l in ((50, 100), (900, 65), (1700, 1024), (2500, 1025), (3300, 5000), (4100, 8192), (4900, 8193), (5700, 30000)):
+        lens[r] = l
+    rp, col = _mixed_rows(g, n, m, lens)
+    for res, thr in ((32, 10), (16, 20)):
+        deg, key, counts = ops.gray_row_keys(m, dev(rp), dev(col), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, m, res, thr)
+        assert np.array_equal(host(deg), wdeg) and np.array_equal(host(key).view(np.uint64), wkey)
+        assert list(counts) == wcounts.tolist()
+
+
 @pytest.mark.parametrize("res", [1, 2, 3, 5, 8, 12, 15, 16, 17, 31, 33, 64])
 def test_gray_row_keys_every_resolution_on_short_rows(ops, oracle, res):
     """Short-row matrices at resolutions below 16: a dense row of d <= 64 entries compares its block counts with
