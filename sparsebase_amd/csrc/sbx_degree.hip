@@ -74,20 +74,16 @@ __global__ void k_degree_one(I *inv) { inv[0] = 0; }
 
 }  // namespace
 
-extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, int ascending,
-                                  void *inv_perm_out) {
-  if (!h) return SBX_ERR_BAD_ARG;
-  if (n < 0 || !row_ptr || (n > 0 && !inv_perm_out)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_degree_reorder: bad argument");
-  if (it == SBX_I64) return sbx_i64_degree_reorder(h, n, row_ptr, ascending, inv_perm_out);
-  if (n >= ((int64_t)1 << 31)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_degree_reorder: dimension exceeds int32");
+template <typename I>
+static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
   if (n == 1) {  // (the radix sort wants two keys)
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_one<int32_t>, dim3(1), dim3(1), (int32_t *)inv_perm_out);
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_one<I>, dim3(1), dim3(1), (I *)inv_perm_out);
     SBX_LAUNCH_CHECK(h);
     return SBX_OK;
   }
-  const int32_t *rp = (const int32_t *)row_ptr;
+  const I *rp = (const I *)row_ptr;
   uint64_t *ka, *kb;
   uint32_t *sorted_id;
   DegState *st;
@@ -97,14 +93,16 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(DegState), h->stream));
   const unsigned grid = sbx_grid_for(n, 256, 2048);
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<int32_t>, dim3(grid), dim3(256), rp, ka, n, st);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<I>, dim3(grid), dim3(256), rp, ka, n, st);
   SBX_LAUNCH_CHECK(h);
-  // one pass over the digit in bits [32, 40); its scatter leaves the ids in order and inv[id] = position
+  // one pass over the digit in bits [32, 40); its scatter leaves the ids in order and inv[id] = position (in the
+  // caller's index width: no 32-bit copy of a 64-bit row_ptr, no widening pass over the result)
   const sbx_radix_pass pass = {32, 8};
   sbx_radix_emit em;
   memset(&em, 0, sizeof(em));
   em.out = sorted_id;
-  em.pos_of = (unsigned *)inv_perm_out;
+  if (sizeof(I) == 4) em.pos_of = (unsigned *)inv_perm_out;
+  else em.pos_of64 = (unsigned long long *)inv_perm_out;
   em.pos_flip = ascending ? 0u : (uint32_t)n;
   SBX_TRY(sbx_radix_sort_emit(h, ka, kb, n, &pass, 1, &em));
   DegState hs;
@@ -118,15 +116,26 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   SBX_TRY(sbx_salloc(h, (size_t)top, &ia));
   SBX_TRY(sbx_salloc(h, (size_t)top, &ib));
   const unsigned tgrid = sbx_grid_for(top, 256, 2048);
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_keys<int32_t>, dim3(tgrid), dim3(256), rp,
-              (const uint32_t *)(sorted_id + (n - top)), top, ta, ia);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_keys<I>, dim3(tgrid), dim3(256), rp, (const uint32_t *)(sorted_id + (n - top)),
+              top, ta, ia);
   SBX_LAUNCH_CHECK(h);
   sbx_radix_pass passes[16];
   const int np = sbx_radix_plan(0, sbx_bits_for(hs.max_deg), 0, 0, passes);
   int in_b = 0;
   SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, top, passes, np, &in_b));
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<int32_t>, dim3(tgrid), dim3(256), (const uint32_t *)(in_b ? ib : ia),
-              (int32_t *)inv_perm_out, top, n - top, n, ascending);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<I>, dim3(tgrid), dim3(256), (const uint32_t *)(in_b ? ib : ia),
+              (I *)inv_perm_out, top, n - top, n, ascending);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
+}
+
+extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, int ascending,
+                                  void *inv_perm_out) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (n < 0 || !row_ptr || (n > 0 && !inv_perm_out)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_degree_reorder: bad argument");
+  // (vertex ids travel in the low word of the sort keys and degrees in 32 bits: n and every row length below 2^32;
+  // row_ptr VALUES — nnz — are not limited for 64-bit indices)
+  if (n >= ((int64_t)1 << 31)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_degree_reorder: dimension exceeds int32");
+  return it == SBX_I64 ? degree_reorder_typed<int64_t>(h, n, row_ptr, ascending, inv_perm_out)
+                       : degree_reorder_typed<int32_t>(h, n, row_ptr, ascending, inv_perm_out);
 }

@@ -9,6 +9,8 @@
 // All four are single-pass reductions.  Bandwidth and profile are nonzero-parallel so
 // power-law rows stay balanced: the row of every nonzero is derived per tile from row_ptr
 // (tile_rows), never from a per-row loop.
+#include <type_traits>
+
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -17,16 +19,16 @@ namespace {
 constexpr int FT_THREADS = 256;
 constexpr int FT_ITEMS = 8;
 
-__global__ __launch_bounds__(FT_THREADS) void k_degrees(const int32_t *__restrict__ rp, int32_t *__restrict__ out,
-                                                        int64_t n) {
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_degrees(const I *__restrict__ rp, I *__restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) out[i] = rp[i + 1] - rp[i];
 }
 
 // dist[i] = degree / (FeatureType)num_edges, one IEEE division per row (degree_distribution.cc:163)
-template <typename F>
-__global__ __launch_bounds__(FT_THREADS) void k_degree_distribution(const int32_t *__restrict__ rp, F *__restrict__ out,
+template <typename I, typename F>
+__global__ __launch_bounds__(FT_THREADS) void k_degree_distribution(const I *__restrict__ rp, F *__restrict__ out,
                                                                     int64_t n, F nnz) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -54,7 +56,8 @@ struct TileRows {
 
 // first and last row of every tile, one thread per tile: the two searches in row_ptr are four dependent rounds of
 // loads when a workgroup does them for itself, and 25 waves of workgroups per CU then spend half their lives in them
-__global__ __launch_bounds__(FT_THREADS) void k_tile_spans(const int32_t *__restrict__ rp, int64_t n, int64_t nnz,
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_tile_spans(const I *__restrict__ rp, int64_t n, int64_t nnz,
                                                            int64_t tiles, int2 *__restrict__ span) {
   const int64_t t = (int64_t)blockIdx.x * FT_THREADS + threadIdx.x;
   if (t >= tiles) return;
@@ -70,7 +73,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_tile_spans(const int32_t *__rest
   span[t] = make_int2((int)last_le(t0), (int)last_le(t1 - 1));
 }
 
-__device__ __forceinline__ TileRows tile_rows(const int32_t *__restrict__ rp, const int2 *__restrict__ span, int64_t tile,
+template <typename I>
+__device__ __forceinline__ TileRows tile_rows(const I *__restrict__ rp, const int2 *__restrict__ span, int64_t tile,
                                               int64_t t0, int *s_head, int *s_wmax) {
   const int tid = threadIdx.x;
 #pragma unroll
@@ -104,13 +108,21 @@ __device__ __forceinline__ TileRows tile_rows(const int32_t *__restrict__ rp, co
 
 // this thread's FT_ITEMS consecutive columns: two 16-byte loads where the array allows it (eight 4-byte loads at a
 // stride of 32 bytes across the lanes make eight times the requests)
-__device__ __forceinline__ void load_items(const int32_t *__restrict__ col, int64_t base, int64_t t1, bool vec_ok,
-                                           int32_t *c) {
-  static_assert(FT_ITEMS == 8, "two 16-byte loads per thread");
+template <typename I>
+__device__ __forceinline__ void load_items(const I *__restrict__ col, int64_t base, int64_t t1, bool vec_ok, I *c) {
+  static_assert(FT_ITEMS == 8, "two 16-byte loads per thread (four for 64-bit columns)");
   if (vec_ok && base + FT_ITEMS <= t1) {
-    const int4 a = *(const int4 *)(col + base), b = *(const int4 *)(col + base + 4);
-    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
-    c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    if (sizeof(I) == 4) {
+      const int4 a = *(const int4 *)(col + base), b = *(const int4 *)(col + base + 4);
+      c[0] = (I)a.x; c[1] = (I)a.y; c[2] = (I)a.z; c[3] = (I)a.w;
+      c[4] = (I)b.x; c[5] = (I)b.y; c[6] = (I)b.z; c[7] = (I)b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < FT_ITEMS; k += 2) {
+        const longlong2 a = *(const longlong2 *)(col + base + k);
+        c[k] = (I)a.x; c[k + 1] = (I)a.y;
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < FT_ITEMS; k++) c[k] = col[base + k < t1 ? base + k : t1 - 1];
@@ -118,28 +130,28 @@ __device__ __forceinline__ void load_items(const int32_t *__restrict__ col, int6
 }
 
 // bandwidth.cc:100-107: max |row - col| over the nonzeros
-__global__ __launch_bounds__(FT_THREADS) void k_bandwidth_csr(const int32_t *__restrict__ rp,
-                                                              const int32_t *__restrict__ col, int64_t n, int64_t nnz,
-                                                              unsigned *__restrict__ partial, bool vec_ok,
+template <typename I, typename P>  // P: unsigned for 32-bit columns, unsigned long long for 64-bit ones
+__global__ __launch_bounds__(FT_THREADS) void k_bandwidth_csr(const I *__restrict__ rp, const I *__restrict__ col, int64_t n,
+                                                              int64_t nnz, P *__restrict__ partial, bool vec_ok,
                                                               const int2 *__restrict__ span) {
   __shared__ int s_head[FT_TILE];
   __shared__ int s_wmax[FT_THREADS / 64];
-  __shared__ unsigned s_mx[FT_THREADS / 64];
+  __shared__ P s_mx[FT_THREADS / 64];
   const int tid = threadIdx.x;
   const int64_t tiles = (nnz + FT_TILE - 1) / FT_TILE;
-  unsigned mx = 0;
+  P mx = 0;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {  // (one tile per workgroup as launched)
     const int64_t t0 = tile * FT_TILE;
     const int64_t t1 = (t0 + FT_TILE < nnz) ? t0 + FT_TILE : nnz;
     const int64_t base = t0 + (int64_t)tid * FT_ITEMS;
-    int32_t c[FT_ITEMS];  // in flight during the row search
+    I c[FT_ITEMS];  // in flight during the row search
     load_items(col, base, t1, vec_ok, c);
     const TileRows t = tile_rows(rp, span, tile, t0, s_head, s_wmax);
 #pragma unroll
     for (int k = 0; k < FT_ITEMS; k++) {
       if (base + k < t1) {
         const int64_t d = t.r_lo + t.h[k] - (int64_t)c[k];
-        const unsigned a = (unsigned)(d < 0 ? -d : d);
+        const P a = (P)(d < 0 ? -d : d);
         mx = a > mx ? a : mx;
       }
     }
@@ -159,8 +171,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_bandwidth_csr(const int32_t *__r
 // profile.cc:95-104 for column-sorted rows, and the check that they are (format/csr.cc:102-116) in the same read of
 // the columns: the smallest column of a row is its first one; `*unsorted` is raised if some row is out of order and
 // the caller then takes the general path.
-__global__ __launch_bounds__(FT_THREADS) void k_profile_csr(const int32_t *__restrict__ rp,
-                                                            const int32_t *__restrict__ col, int64_t n, int64_t nnz,
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_profile_csr(const I *__restrict__ rp, const I *__restrict__ col, int64_t n,
+                                                            int64_t nnz,
                                                             unsigned long long *__restrict__ partial,
                                                             int *__restrict__ unsorted, bool vec_ok,
                                                             const int2 *__restrict__ span) {
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_profile_csr(const int32_t *__res
     const int64_t t0 = tile * FT_TILE;
     const int64_t t1 = (t0 + FT_TILE < nnz) ? t0 + FT_TILE : nnz;
     const int64_t base = t0 + (int64_t)tid * FT_ITEMS;
-    int32_t c[FT_ITEMS + 1];  // c[0]: the nonzero before this thread's first one
+    I c[FT_ITEMS + 1];  // c[0]: the nonzero before this thread's first one
     c[0] = base > 0 ? col[base - 1 < t1 ? base - 1 : t1 - 1] : 0;
     load_items(col, base, t1, vec_ok, c + 1);
     const TileRows t = tile_rows(rp, span, tile, t0, s_head, s_wmax);
@@ -202,36 +215,41 @@ __global__ __launch_bounds__(FT_THREADS) void k_profile_csr(const int32_t *__res
   }
 }
 
+__device__ __forceinline__ void ft_atomic_min(int32_t *p, int32_t v) { atomicMin(p, v); }
+__device__ __forceinline__ void ft_atomic_min(int64_t *p, int64_t v) { atomicMin((long long *)p, (long long)v); }
+
 // smallest column of every row: each thread owns FT_ITEMS consecutive nonzeros and issues one
 // atomicMin per run of equal rows (rows are contiguous, so ~nnz/FT_ITEMS + n atomics in total)
-__global__ __launch_bounds__(FT_THREADS) void k_row_min_col(const int32_t *__restrict__ row,
-                                                            const int32_t *__restrict__ col, int64_t nnz,
-                                                            int32_t *__restrict__ rowmin) {
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_row_min_col(const I *__restrict__ row, const I *__restrict__ col, int64_t nnz,
+                                                            I *__restrict__ rowmin) {
   const int64_t p0 = ((int64_t)blockIdx.x * FT_THREADS + threadIdx.x) * FT_ITEMS;
   if (p0 >= nnz) return;
-  int32_t cur = row[p0], m = col[p0];
+  I cur = row[p0], m = col[p0];
 #pragma unroll
   for (int k = 1; k < FT_ITEMS; k++) {
     if (p0 + k >= nnz) break;
-    const int32_t r = row[p0 + k], c = col[p0 + k];
+    const I r = row[p0 + k], c = col[p0 + k];
     if (r != cur) {
-      atomicMin(&rowmin[cur], m);
+      ft_atomic_min(&rowmin[cur], m);
       cur = r;
       m = c;
     } else {
       m = c < m ? c : m;
     }
   }
-  atomicMin(&rowmin[cur], m);
+  ft_atomic_min(&rowmin[cur], m);
 }
 
-__global__ __launch_bounds__(FT_THREADS) void k_iota(int32_t *__restrict__ out, int64_t n) {
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_iota(I *__restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = (int32_t)i;
+  for (; i < n; i += stride) out[i] = (I)i;
 }
 
-__global__ __launch_bounds__(FT_THREADS) void k_profile(const int32_t *__restrict__ rowmin, int64_t n,
+template <typename I>
+__global__ __launch_bounds__(FT_THREADS) void k_profile(const I *__restrict__ rowmin, int64_t n,
                                                         unsigned long long *__restrict__ partial) {
   __shared__ unsigned long long s_sum[FT_THREADS / 64];
   unsigned long long sum = 0;
@@ -248,13 +266,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_profile(const int32_t *__restric
 }
 
 // single workgroup: reduce the per-workgroup partials
-__global__ __launch_bounds__(FT_THREADS) void k_feature_finish(const unsigned *__restrict__ pmax,
+template <typename P>
+__global__ __launch_bounds__(FT_THREADS) void k_feature_finish(const P *__restrict__ pmax,
                                                                const unsigned long long *__restrict__ psum, int count,
                                                                FeatureAcc *__restrict__ acc) {
   __shared__ unsigned long long s_a[FT_THREADS / 64], s_b[FT_THREADS / 64];
   unsigned long long mx = 0, sum = 0;
   for (int i = threadIdx.x; i < count; i += FT_THREADS) {
-    if (pmax) mx = pmax[i] > mx ? pmax[i] : mx;
+    if (pmax) mx = (unsigned long long)pmax[i] > mx ? (unsigned long long)pmax[i] : mx;
     if (psum) sum += psum[i];
   }
   mx = sbx_wave_max(mx);
@@ -281,9 +300,11 @@ struct NestGuard {
 };
 
 // row ids of every nonzero into scratch (the CSR -> COO move conversion)
-int expand_rows(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp, int32_t **rows) {
+template <typename I>
+int expand_rows(sbx_handle_t h, int64_t n, int64_t nnz, const I *rp, I **rows) {
   SBX_TRY(sbx_salloc(h, (size_t)nnz, rows));
-  return sbx_csr_to_coo(h, SBX_I32, SBX_V_NONE, n, n, nnz, rp, nullptr, nullptr, *rows, nullptr, nullptr, SBX_FLAG_MOVE);
+  return sbx_csr_to_coo(h, sizeof(I) == 4 ? SBX_I32 : SBX_I64, SBX_V_NONE, n, n, nnz, rp, nullptr, nullptr, *rows, nullptr,
+                        nullptr, SBX_FLAG_MOVE);
 }
 
 }  // namespace
@@ -293,16 +314,38 @@ int expand_rows(sbx_handle_t h, int64_t n, int64_t nnz, const int32_t *rp, int32
     if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
   } while (0)
 
+template <typename I>
+static int csr_degrees_typed(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
+  SBX_TRY(sbx_arena_begin(h));
+  if (n == 0) return SBX_OK;
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_degrees<I>, dim3(sbx_grid_for(n, FT_THREADS, 8192)), dim3(FT_THREADS), (const I *)row_ptr,
+              (I *)degrees_out, n);
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_FEATURE, 2 * (int64_t)sizeof(I) * n + (int64_t)sizeof(I));
+  return SBX_OK;
+}
+
 extern "C" int sbx_csr_degrees(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, void *degrees_out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && row_ptr && (n == 0 || degrees_out), "bad argument");
-  if (it == SBX_I64) return sbx_i64_csr_degrees(h, n, row_ptr, degrees_out);
+  return it == SBX_I64 ? csr_degrees_typed<int64_t>(h, n, row_ptr, degrees_out)
+                       : csr_degrees_typed<int32_t>(h, n, row_ptr, degrees_out);
+}
+
+template <typename I>
+static int csr_degree_distribution_typed(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
+                                         void *dist_out) {
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_degrees, dim3(sbx_grid_for(n, FT_THREADS, 8192)), dim3(FT_THREADS),
-              (const int32_t *)row_ptr, (int32_t *)degrees_out, n);
+  const unsigned grid = sbx_grid_for(n, FT_THREADS, 8192);
+  if (feature_bytes == 4)
+    SBX_KLAUNCH(h, SBX_K_FEATURE, (k_degree_distribution<I, float>), dim3(grid), dim3(FT_THREADS), (const I *)row_ptr,
+                (float *)dist_out, n, (float)nnz);
+  else
+    SBX_KLAUNCH(h, SBX_K_FEATURE, (k_degree_distribution<I, double>), dim3(grid), dim3(FT_THREADS), (const I *)row_ptr,
+                (double *)dist_out, n, (double)nnz);
   SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_FEATURE, 8 * n + 4);
+  SBX_PROF_BYTES(h, SBX_K_FEATURE, ((int64_t)sizeof(I) + feature_bytes) * n + (int64_t)sizeof(I));
   return SBX_OK;
 }
 
@@ -311,18 +354,38 @@ extern "C" int sbx_csr_degree_distribution(sbx_handle_t h, sbx_index_type it, in
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (n == 0 || dist_out), "bad argument");
   SBX_REQUIRE(h, feature_bytes == 4 || feature_bytes == 8, "feature type must be float or double");
-  if (it == SBX_I64) return sbx_i64_csr_degree_distribution(h, n, nnz, row_ptr, feature_bytes, dist_out);
+  return it == SBX_I64 ? csr_degree_distribution_typed<int64_t>(h, n, nnz, row_ptr, feature_bytes, dist_out)
+                       : csr_degree_distribution_typed<int32_t>(h, n, nnz, row_ptr, feature_bytes, dist_out);
+}
+
+// (rows are numbered in 32 bits inside a tile: n < 2^31 for either index type; 64-bit columns and row_ptr values —
+// nnz >= 2^31, column ids >= 2^31 — are read as they are)
+template <typename I>
+static int csr_bandwidth_typed(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                               int64_t *bandwidth_host) {
+  typedef typename std::conditional<sizeof(I) == 4, unsigned, unsigned long long>::type P;
   SBX_TRY(sbx_arena_begin(h));
-  if (n == 0) return SBX_OK;
-  const unsigned grid = sbx_grid_for(n, FT_THREADS, 8192);
-  if (feature_bytes == 4)
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_degree_distribution<float>, dim3(grid), dim3(FT_THREADS), (const int32_t *)row_ptr,
-                (float *)dist_out, n, (float)nnz);
-  else
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_degree_distribution<double>, dim3(grid), dim3(FT_THREADS),
-                (const int32_t *)row_ptr, (double *)dist_out, n, (double)nnz);
+  if (nnz == 0) return SBX_OK;  // bandwidth.cc:100: stays 0 without nonzeros
+  const int64_t tiles = (nnz + FT_TILE - 1) / FT_TILE;
+  const unsigned grid = FT_SLOTS;  // result words for k_feature_finish
+  P *partial = nullptr;
+  FeatureAcc *acc = nullptr;
+  SBX_TRY(sbx_salloc(h, grid, &partial));
+  SBX_TRY(sbx_salloc(h, 1, &acc));
+  SBX_HIP(h, hipMemsetAsync(partial, 0, grid * sizeof(P), h->stream));
+  int2 *span = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)tiles, &span));
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans<I>, dim3((unsigned)((tiles + FT_THREADS - 1) / FT_THREADS)), dim3(FT_THREADS),
+              (const I *)row_ptr, n, nnz, tiles, span);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, (k_bandwidth_csr<I, P>), dim3((unsigned)tiles), dim3(FT_THREADS), (const I *)row_ptr,
+              (const I *)col, n, nnz, partial, ((uintptr_t)col & 15) == 0, (const int2 *)span);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish<P>, dim3(1), dim3(FT_THREADS), (const P *)partial,
+              (const unsigned long long *)nullptr, (int)grid, acc);
   SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_FEATURE, (4 + feature_bytes) * n + 4);
+  SBX_PROF_BYTES(h, SBX_K_FEATURE, (int64_t)sizeof(I) * (nnz + n + 1));
+  FeatureAcc ha;
+  SBX_TRY(sbx_readback(h, &ha, acc, sizeof(FeatureAcc)));
+  *bandwidth_host = (int64_t)ha.max_dist + 1;  // |i - j| + 1 (:104-107)
   return SBX_OK;
 }
 
@@ -330,41 +393,16 @@ extern "C" int sbx_csr_bandwidth(sbx_handle_t h, sbx_index_type it, int64_t n, i
                                  const void *col, int64_t *bandwidth_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && bandwidth_host && (nnz == 0 || col), "bad argument");
-  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1 && (it == SBX_I64 || nnz < ((int64_t)1 << 31)) &&
+                     nnz / FT_TILE < ((int64_t)1 << 31), "dimension exceeds what the index type holds");
   *bandwidth_host = 0;
-  if (it == SBX_I64) return sbx_i64_csr_bandwidth(h, n, nnz, row_ptr, col, bandwidth_host);
-  SBX_TRY(sbx_arena_begin(h));
-  if (nnz == 0) return SBX_OK;  // bandwidth.cc:100: stays 0 without nonzeros
-  const unsigned tiles = (unsigned)((nnz + FT_TILE - 1) / FT_TILE);
-  const unsigned grid = FT_SLOTS;  // result words for k_feature_finish
-  unsigned *partial = nullptr;
-  FeatureAcc *acc = nullptr;
-  SBX_TRY(sbx_salloc(h, grid, &partial));
-  SBX_TRY(sbx_salloc(h, 1, &acc));
-  SBX_HIP(h, hipMemsetAsync(partial, 0, grid * sizeof(unsigned), h->stream));
-  int2 *span = nullptr;
-  SBX_TRY(sbx_salloc(h, tiles, &span));
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans, dim3((tiles + FT_THREADS - 1) / FT_THREADS), dim3(FT_THREADS),
-              (const int32_t *)row_ptr, n, nnz, (int64_t)tiles, span);
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_bandwidth_csr, dim3(tiles), dim3(FT_THREADS), (const int32_t *)row_ptr,
-              (const int32_t *)col, n, nnz, partial, ((uintptr_t)col & 15) == 0, (const int2 *)span);
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)partial,
-              (const unsigned long long *)nullptr, (int)grid, acc);
-  SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_FEATURE, 4 * nnz + 4 * (n + 1));
-  FeatureAcc ha;
-  SBX_TRY(sbx_readback(h, &ha, acc, sizeof(FeatureAcc)));
-  *bandwidth_host = (int64_t)ha.max_dist + 1;  // |i - j| + 1 (:104-107)
-  return SBX_OK;
+  return it == SBX_I64 ? csr_bandwidth_typed<int64_t>(h, n, nnz, row_ptr, col, bandwidth_host)
+                       : csr_bandwidth_typed<int32_t>(h, n, nnz, row_ptr, col, bandwidth_host);
 }
 
-extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
-                               const void *col, int64_t *profile_host) {
-  if (!h) return SBX_ERR_BAD_ARG;
-  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && profile_host && (nnz == 0 || col), "bad argument");
-  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
-  *profile_host = 0;
-  if (it == SBX_I64) return sbx_i64_csr_profile(h, n, nnz, row_ptr, col, profile_host);
+template <typename I>
+static int csr_profile_typed(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                             int64_t *profile_host) {
   SBX_TRY(sbx_arena_begin(h));
   if (nnz == 0 || n == 0) return SBX_OK;
   NestGuard guard(h);
@@ -377,41 +415,52 @@ extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int
     // column-sorted rows (every CSR that went through a constructor): checked and summed in ONE read of the columns;
     // unsorted rows only exist for ignore_sort CSRs and take the general path below
     struct { FeatureAcc a; int unsorted; int pad; } hs;
-    const unsigned tiles = (unsigned)((nnz + FT_TILE - 1) / FT_TILE);
+    const int64_t tiles = (nnz + FT_TILE - 1) / FT_TILE;
     const unsigned grid = FT_SLOTS;
     unsigned long long *psum = nullptr, *res = nullptr;
     SBX_TRY(sbx_salloc(h, grid + 3, &psum));
     res = psum + grid;
     SBX_HIP(h, hipMemsetAsync(psum, 0, (grid + 3) * sizeof(unsigned long long), h->stream));
     int2 *span = nullptr;
-    SBX_TRY(sbx_salloc(h, tiles, &span));
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans, dim3((tiles + FT_THREADS - 1) / FT_THREADS), dim3(FT_THREADS),
-                (const int32_t *)row_ptr, n, nnz, (int64_t)tiles, span);
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile_csr, dim3(tiles), dim3(FT_THREADS), (const int32_t *)row_ptr,
-                (const int32_t *)col, n, nnz, psum, (int *)(res + 2), ((uintptr_t)col & 15) == 0, (const int2 *)span);
-    SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
+    SBX_TRY(sbx_salloc(h, (size_t)tiles, &span));
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_tile_spans<I>, dim3((unsigned)((tiles + FT_THREADS - 1) / FT_THREADS)), dim3(FT_THREADS),
+                (const I *)row_ptr, n, nnz, tiles, span);
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile_csr<I>, dim3((unsigned)tiles), dim3(FT_THREADS), (const I *)row_ptr,
+                (const I *)col, n, nnz, psum, (int *)(res + 2), ((uintptr_t)col & 15) == 0, (const int2 *)span);
+    SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish<unsigned>, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
                 (const unsigned long long *)psum, (int)grid, (FeatureAcc *)res);
     SBX_LAUNCH_CHECK(h);
-    SBX_PROF_BYTES(h, SBX_K_FEATURE, 4 * nnz + 4 * (n + 1));
+    SBX_PROF_BYTES(h, SBX_K_FEATURE, (int64_t)sizeof(I) * (nnz + n + 1));
     SBX_TRY(sbx_readback(h, &hs, res, sizeof(hs)));
     if (!hs.unsorted) {
       *profile_host = (int64_t)hs.a.profile;
       return SBX_OK;
     }
   }
-  int32_t *rows = nullptr, *rowmin = nullptr;
-  SBX_TRY(expand_rows(h, n, nnz, (const int32_t *)row_ptr, &rows));
+  I *rows = nullptr, *rowmin = nullptr;
+  SBX_TRY(expand_rows<I>(h, n, nnz, (const I *)row_ptr, &rows));
   SBX_TRY(sbx_salloc(h, (size_t)n, &rowmin));
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_iota, dim3(grid_n), dim3(FT_THREADS), rowmin, n);  // j starts at i (:99)
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_row_min_col, dim3((unsigned)((nnz + FT_THREADS * FT_ITEMS - 1) / (FT_THREADS * FT_ITEMS))),
-              dim3(FT_THREADS), (const int32_t *)rows, (const int32_t *)col, nnz, rowmin);
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile, dim3(grid_n), dim3(FT_THREADS), (const int32_t *)rowmin, n, partial);
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_iota<I>, dim3(grid_n), dim3(FT_THREADS), rowmin, n);  // j starts at i (:99)
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_row_min_col<I>, dim3((unsigned)((nnz + FT_THREADS * FT_ITEMS - 1) / (FT_THREADS * FT_ITEMS))),
+              dim3(FT_THREADS), (const I *)rows, (const I *)col, nnz, rowmin);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_profile<I>, dim3(grid_n), dim3(FT_THREADS), (const I *)rowmin, n, partial);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, k_feature_finish<unsigned>, dim3(1), dim3(FT_THREADS), (const unsigned *)nullptr,
               (const unsigned long long *)partial, (int)grid_n, acc);
   SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_FEATURE, 4 * nnz + 4 * (n + 1));
+  SBX_PROF_BYTES(h, SBX_K_FEATURE, (int64_t)sizeof(I) * (nnz + n + 1));
   FeatureAcc ha;
   SBX_TRY(sbx_readback(h, &ha, acc, sizeof(FeatureAcc)));
   *profile_host = (int64_t)ha.profile;
   return SBX_OK;
+}
+
+extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
+                               const void *col, int64_t *profile_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && profile_host && (nnz == 0 || col), "bad argument");
+  SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1 && (it == SBX_I64 || nnz < ((int64_t)1 << 31)) &&
+                     nnz / FT_TILE < ((int64_t)1 << 31), "dimension exceeds what the index type holds");
+  *profile_host = 0;
+  return it == SBX_I64 ? csr_profile_typed<int64_t>(h, n, nnz, row_ptr, col, profile_host)
+                       : csr_profile_typed<int32_t>(h, n, nnz, row_ptr, col, profile_host);
 }

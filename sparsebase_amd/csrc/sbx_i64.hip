@@ -1,8 +1,9 @@
 // sbx_i64.hip — SBX_I64 support: 64-bit IDType/NNZType arrays (the reference's
-// <int64,int64,double> tuple).  The conversions COO <-> CSR and the two sortedness checks run
-// NATIVE 64-bit kernels (sbx_convert.hip: index values and nnz of any size).  The other
-// entry points narrow their index arrays to int32 scratch copies (with an overflow check),
-// run the int32 kernels and widen the index outputs back; values are opaque payload and pass
+// <int64,int64,double> tuple).  NATIVE 64-bit kernels (index values and nnz of any size, no copies): the conversions
+// COO <-> CSR and the two sortedness checks (sbx_convert.hip), the four features (sbx_features.hip), DegreeReorder
+// (sbx_degree.hip), InversePermutation and PermuteArray (sbx_permute.hip).  The entry points in THIS file — the sorts,
+// CSC, RCM, Gray keys, the CSR permute, the text parsers — narrow their index arrays to int32 scratch copies (with an
+// overflow check), run the int32 kernels and widen the index outputs back; values are opaque payload and pass
 // through untouched; arrays with entries >= 2^31 return SBX_ERR_UNSUPPORTED there.
 #include "sbx_device.h"
 #include "sbx_internal.h"
@@ -171,50 +172,6 @@ int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_
   return sbx_widen_i32(h, c, col_out, dims_nnz_host[2]);
 }
 
-int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  SCRATCH32(deg, n, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_csr_degrees(h, SBX_I32, n, rp, deg));
-  return sbx_widen_i32(h, deg, degrees_out, n);
-}
-
-int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
-                                    void *dist_out) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_csr_degree_distribution(h, SBX_I32, n, nnz, rp, feature_bytes, dist_out);
-}
-
-int sbx_i64_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
-                          int64_t *bandwidth_host) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_csr_bandwidth(h, SBX_I32, n, nnz, rp, c, bandwidth_host);
-}
-
-int sbx_i64_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
-                        int64_t *profile_host) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_csr_profile(h, SBX_I32, n, nnz, rp, c, profile_host);
-}
-
-int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  SCRATCH32(inv, n, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_degree_reorder(h, SBX_I32, n, rp, ascending, inv));
-  return sbx_widen_i32(h, inv, inv_perm_out, n);
-}
-
 int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
                         void *inv_perm_out, sbx_rcm_stats *stats_host) {
   I64_BEGIN();
@@ -236,15 +193,6 @@ int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, con
   SBX_TRY(sbx_i64_check(h, ovf));
   SBX_TRY(sbx_gray_row_keys(h, SBX_I32, n, m, nnz, rp, c, resolution, nnz_threshold, deg, key_out, counts_host));
   return sbx_widen_i32(h, deg, degree_out, n);
-}
-
-int sbx_i64_inverse_permutation(sbx_handle_t h, int64_t n, const void *perm, void *inv_out) {
-  I64_BEGIN();
-  NARROW(p, perm, n);
-  SCRATCH32(inv, n, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_inverse_permutation(h, SBX_I32, n, p, inv));
-  return sbx_widen_i32(h, inv, inv_out, n);
 }
 
 int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
@@ -270,10 +218,3 @@ int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64
   return sbx_widen_i32(h, colo, col_out, got);
 }
 
-int sbx_i64_permute_array(sbx_handle_t h, sbx_value_type vt, int64_t n, const void *order, const void *vals,
-                          void *out) {
-  I64_BEGIN();
-  NARROW(o, order, n);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  return sbx_permute_array(h, SBX_I32, vt, n, o, vals, out);
-}

@@ -231,6 +231,7 @@ struct sbx_radix_emit {
   unsigned *pos_of;
   uint32_t low_mask;  // low32(key) is ANDed with this first (0: all 32 bits) — keys whose fields are packed tightly
   uint32_t pos_flip;  // non-zero: pos_of[value] = pos_flip - 1 - p (positions counted from the other end)
+  unsigned long long *pos_of64;  // the same table in 64-bit words (an int64 inverse permutation), optional
 };
 int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
                         int num_passes, const sbx_radix_emit *emit);
@@ -260,24 +261,13 @@ int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *
 int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t entries,
                             int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
                             int64_t *dims_nnz_host);
-int sbx_i64_csr_degrees(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out);
-int sbx_i64_csr_degree_distribution(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, int feature_bytes,
-                                    void *dist_out);
-int sbx_i64_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
-                          int64_t *bandwidth_host);
-int sbx_i64_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
-                        int64_t *profile_host);
-int sbx_i64_degree_reorder(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out);
 int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
                         void *inv_perm_out, sbx_rcm_stats *stats_host);
 int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
                           int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
                           int64_t *counts_host);
-int sbx_i64_inverse_permutation(sbx_handle_t h, int64_t n, const void *perm, void *inv_out);
 int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                              const void *col, const void *val, const void *row_order, const void *col_order,
                              int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
                              int64_t out_capacity, int64_t *shard_nnz_host);
-int sbx_i64_permute_array(sbx_handle_t h, sbx_value_type vt, int64_t n, const void *order, const void *vals,
-                          void *out);
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);

@@ -2331,11 +2331,14 @@ extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_
                                        void *inv_out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (perm && inv_out)), "bad argument");
-  if (it == SBX_I64) return sbx_i64_inverse_permutation(h, n, perm, inv_out);
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
-                     (const int32_t *)perm, (int32_t *)inv_out, n);
+  if (it == SBX_I64)  // (native: no narrowed copies)
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<int64_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
+                (const int64_t *)perm, (int64_t *)inv_out, n);
+  else
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_invert<int32_t>, dim3(sbx_grid_for(n, 256, 8192)), dim3(256),
+                (const int32_t *)perm, (int32_t *)inv_out, n);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
@@ -2344,13 +2347,19 @@ extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_ty
                                  const void *vals, void *out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (order && vals && out)), "bad argument");
-  if (it == SBX_I64) return sbx_i64_permute_array(h, vt, n, order, vals, out);
   const int vb = sbx_value_bytes(vt);
   SBX_REQUIRE(h, vb == 4 || vb == 8, "value type must be 4 or 8 bytes");
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
   const unsigned grid = sbx_grid_for(n, 256, 8192);
-  if (vb == 4)
+  if (it == SBX_I64) {  // (native: no narrowed copy of the order)
+    if (vb == 4)
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, (k_permute_array<int64_t, 4>), dim3(grid), dim3(256), (const int64_t *)order,
+                  (const char *)vals, (char *)out, n);
+    else
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, (k_permute_array<int64_t, 8>), dim3(grid), dim3(256), (const int64_t *)order,
+                  (const char *)vals, (char *)out, n);
+  } else if (vb == 4)
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, (k_permute_array<int32_t, 4>), dim3(grid), dim3(256), (const int32_t *)order,
                        (const char *)vals, (char *)out, n);
   else

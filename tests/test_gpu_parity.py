@@ -982,6 +982,21 @@ def test_int64_values_beyond_int32(ops, oracle):
     with pytest.raises(capi.SbxError) as e:
         ops.coo_to_csr(n, m, dev(bad_row), dev(col), dev(val), rows_sorted=True)
     assert e.value.status == 1  # SBX_ERR_BAD_ARG
+    # the features and the degree order read 64-bit arrays natively too: column ids beyond 2^33 (bandwidth, profile —
+    # what the reference computes for such a pattern, |row - col| in 64 bits), row_ptr values beyond 2^40 (nnz of any
+    # size: only differences matter)
+    assert ops.csr_bandwidth(dev(rp), dev(col)) == oracle.csr_bandwidth(rp, col)
+    assert ops.csr_profile(dev(rp), dev(col)) == oracle.csr_profile(rp, col)
+    assert ops.csr_profile(dev(rp), dev(ucol)) == oracle.csr_profile(rp, ucol)       # a row out of order: general path
+    big = rp + (1 << 40)
+    assert np.array_equal(host(ops.csr_degrees(dev(big))), oracle.csr_degrees(rp))
+    assert np.array_equal(host(ops.csr_degree_distribution(dev(big), len(col), torch.float64)),
+                          oracle.csr_degree_distribution(rp, len(col), np.float64))
+    lens2 = lens.copy()
+    lens2[[7, 90, 200]] = (300, 256, 70000)                                          # rows on both sides of the 255 cap
+    rp2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
+    for asc in (True, False):
+        assert np.array_equal(host(ops.degree_reorder(dev(rp2 + (1 << 40)), asc)), oracle.degree_reorder(rp2, asc))
     # the operations that still run on narrowed copies refuse what does not fit, loudly
     order = synth.random_permutation(n, 3, np.int64)
     with pytest.raises(capi.SbxError) as e:
