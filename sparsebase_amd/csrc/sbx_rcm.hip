@@ -1081,12 +1081,58 @@ __global__ __launch_bounds__(256) void k_fresh_words(const unsigned *__restrict_
   if (threadIdx.x == 0) btot[blockIdx.x] = s_tot;
 }
 
+// The Cuthill-McKee sweep's big levels, the same idea in RANK space: bit k of the words written here says that the
+// vertex of (degree, id) rank k — dorder[k] — was discovered by the current level (it has a parent position and is not
+// in the visited bitmap yet, which k_visited_from_ppos only updates after the level is ordered).  Read off in bit order
+// the level's vertices come out in ascending degree rank — the low field of their sort keys — so only the
+// parent-position digits are left for the (stable) radix sort: 2 digit passes instead of 5 for the bench matrix's
+// 1.4 M-vertex level.  The price is two 4-byte gathers per ranked vertex (ppos, the visited word) instead of a
+// coalesced pass: worth it from a level of n_ranked / 3 vertices on.
+__global__ __launch_bounds__(256) void k_fresh_words_ranked(const unsigned *__restrict__ ppos,
+                                                            const unsigned *__restrict__ vbits,
+                                                            const uint32_t *__restrict__ dorder,
+                                                            unsigned long long *__restrict__ fresh64,
+                                                            int *__restrict__ cnt, int *__restrict__ btot,
+                                                            int64_t n_ranked) {
+  constexpr int WPW = RCM_FW_WORDS / 4;  // words per wave: 16 consecutive ones
+  __shared__ int s_tot;
+  if (threadIdx.x == 0) s_tot = 0;
+  __syncthreads();
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  const int64_t w0 = (int64_t)blockIdx.x * RCM_FW_WORDS + (int64_t)wv * WPW;
+  uint32_t vv[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {  // (all loads of a round together, at clamped indices: none waits for another)
+    const int64_t k = (w0 + i) * 64 + lane;
+    vv[i] = dorder[k < n_ranked ? k : n_ranked - 1];
+  }
+  unsigned pv[WPW], vw[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; i++) pv[i] = ppos[vv[i]], vw[i] = vbits[vv[i] >> 5];
+  int mine = 0;
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    const int64_t k = (w0 + i) * 64 + lane;
+    const bool fresh = k < n_ranked && pv[i] != UNSEEN && !((vw[i] >> (vv[i] & 31)) & 1u);
+    const unsigned long long f = __ballot(fresh);
+    if (lane == 0 && (w0 + i) * 64 < n_ranked) {
+      fresh64[w0 + i] = f;
+      cnt[w0 + i] = __popcll(f);
+      mine += __popcll(f);
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(&s_tot, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) btot[blockIdx.x] = s_tot;
+}
+
 // One workgroup per RCM_FW_WORDS words.  Its base = totals of the workgroups before it (summed here when there
 // are few of them, taken from their scan otherwise); every wave scans the 64 word counts itself (lane = word) and
 // then writes the keys of its 16 words with lane = vertex: parent positions read and keys written in runs.
 __global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
                                                          const int *__restrict__ cnt, const int *__restrict__ btot,
                                                          int btot_is_scanned, const unsigned *__restrict__ ppos,
+                                                         const uint32_t *__restrict__ dorder,  // ranked form: bit k = rank k
                                                          uint64_t *__restrict__ key, int64_t words,
                                                          RcmDev *__restrict__ dv) {
   constexpr int WPW = RCM_FW_WORDS / 4;
@@ -1110,8 +1156,8 @@ __global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long lon
     const unsigned long long f = __shfl(mine, src, 64);
     const int o = __shfl(excl, src, 64);
     if ((f >> lane) & 1ull) {
-      const uint32_t v = (uint32_t)((wb + src) * 64 + lane);
-      key[o + __popcll(f & sbx_lanemask_lt())] = ((uint64_t)ppos[v] << 32) | (uint64_t)v;
+      const uint32_t v = (uint32_t)((wb + src) * 64 + lane);  // vertex id, or degree rank in the ranked form
+      key[o + __popcll(f & sbx_lanemask_lt())] = ((uint64_t)ppos[dorder ? dorder[v] : v] << 32) | (uint64_t)v;
     }
   }
 }
@@ -1670,6 +1716,16 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
   for (; j < cnt; j += stride) inv[q[j]] = base + (I)(cnt - 1 - j);
 }
 
+static bool rcm_ranked_keys() {  // SBX_RCM_RANKED_KEYS=0: big Cuthill-McKee levels sort their full (parent position, rank) keys
+  static const bool on = !(getenv("SBX_RCM_RANKED_KEYS") && atoi(getenv("SBX_RCM_RANKED_KEYS")) == 0);
+  return on;
+}
+
+static int rcm_ranked_div() {  // ... for levels of at least n_ranked / this many vertices (SBX_DEBUG_RCM_RANKED_DIV)
+  static const int v = getenv("SBX_DEBUG_RCM_RANKED_DIV") ? atoi(getenv("SBX_DEBUG_RCM_RANKED_DIV")) : 3;
+  return v > 0 ? v : 1;
+}
+
 struct BfsBuffers {
   bool *claim_clean;  // the claim bytes of the unordered sweeps are all zero (a finished sweep leaves them that way)
   const I *rp, *col;
@@ -1684,6 +1740,7 @@ struct BfsBuffers {
   unsigned long long *fresh64;  // per 64 vertices: the bits the current level added to the visited bitmap
   int *wcnt, *woff;             // ... their popcounts, and the totals of every RCM_FW_WORDS of them
   const uint32_t *drank, *dorder;
+  int64_t n_ranked;  // entries of dorder (vertices with a non-empty row)
   RcmDev *dv;
   int64_t n;
   unsigned max_deg;  // largest degree of the graph: no hub kernel launches when nothing exceeds RCM_LIGHT
@@ -1810,7 +1867,19 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
         if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
                     (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
-                    (const unsigned *)b.ppos, b.ka, words, b.dv);
+                    (const unsigned *)b.ppos, (const uint32_t *)nullptr, b.ka, words, b.dv);
+        np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
+      } else if (CM && !set_bits && rcm_ranked_keys() && (int64_t)nf * rcm_ranked_div() >= b.n_ranked) {
+        // keys in ascending degree-rank order from a bitmap in rank space: only the parent positions are left to sort
+        const int64_t words = (b.n_ranked + 63) / 64;
+        const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_fresh_words_ranked, dim3((unsigned)fw_blocks), dim3(256),
+                    (const unsigned *)b.ppos, (const unsigned *)b.vbits, b.dorder, b.fresh64, b.wcnt, b.woff, b.n_ranked);
+        const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
+        if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
+                    (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
+                    (const unsigned *)b.ppos, b.dorder, b.ka, words, b.dv);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       } else {
         low_bits = sbx_bits_for((uint64_t)(b.n - 1));
@@ -2839,7 +2908,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
-  b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.dv = dv; b.n = n;
+  b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.n_ranked = n_ranked; b.dv = dv; b.n = n;
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.fresh64));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.wcnt));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 / RCM_FW_WORDS + 2, &b.woff));

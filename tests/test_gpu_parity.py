@@ -1224,6 +1224,32 @@ def test_rcm_sweep_variants_in_a_child(mode):
     assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("mode", ["ranked_keys", "full_keys"])
+def test_rcm_cuthill_mckee_level_keys_in_a_child(mode):
+    """The Cuthill-McKee sweep orders a big level either by full (parent position, degree rank) keys or — from a third
+    of the ranked vertices on — by keys read off a bitmap in RANK space, already in degree-rank order, of which only the
+    parent-position digits are sorted (sbx_rcm.hip: k_fresh_words_ranked).  Graphs with levels of 10^5 .. 10^6 vertices;
+    SBX_DEBUG_RCM_RANKED_DIV=100000 sends every level that takes the bitmap pass that way, SBX_RCM_RANKED_KEYS=0 none.
+    (Read once per process, hence the children.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
+        "from orc import Oracle; from sparsebase_amd import ops, synth\n"
+        "orc = Oracle(); d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "cases = [synth.rmat_symmetric(19, 8, seed=3), synth.rmat_symmetric(18, 16, seed=9),\n"
+        "         synth.random_symmetric_graph(400000, avg_deg=6, seed=2, n_blocks=1, isolated_frac=0.05),\n"
+        "         synth.random_symmetric_graph(300000, avg_deg=12, seed=7, n_blocks=2, isolated_frac=0.3)]\n"
+        "for rp, col in cases:\n"
+        "    assert np.array_equal(ops.rcm_reorder(d(rp), d(col)).cpu().numpy(), orc.rcm_reorder(rp, col))\n"
+        "print('rcm variant ok')\n" % (root, os.path.join(root, "tests")))
+    extra = {"ranked_keys": {"SBX_DEBUG_RCM_RANKED_DIV": "100000"}, "full_keys": {"SBX_RCM_RANKED_KEYS": "0"}}[mode]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
     """Directed inputs (an edge list read with read_undirected=False): a BFS cannot reach its weakly connected
     component.  The reference leaks stale distances there; here every such input must end in a clean error —
