@@ -191,6 +191,11 @@ int sbx_exclusive_scan_i64(sbx_handle_t h, const int64_t *in, int64_t *out, int6
 int sbx_exclusive_scan_u32(sbx_handle_t h, const uint32_t *in, uint32_t *out, int64_t count,
                            uint32_t *total_out);
 
+// stable sort of every segment [seg_ptr[i], seg_ptr[i+1]) of (32-bit key < key_limit, vb-byte value) pairs by key, out
+// of place (sbx_permute.hip: the permute's LDS sort stage with identity maps); the caller has begun the arena
+int sbx_sort_segments(sbx_handle_t h, int vb, int64_t nseg, int64_t key_limit, int64_t nnz, const int32_t *seg_ptr,
+                      const int32_t *key_in, const char *val_in, int32_t *key_out, char *val_out);
+
 // A radix pass covers key bits [shift, shift+bits), bits <= 8.
 struct sbx_radix_pass {
   int shift;

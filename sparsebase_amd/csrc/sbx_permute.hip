@@ -2476,6 +2476,42 @@ extern "C" int sbx_permute_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type
 }
 
 // A4: the CSR constructor's "if any row is unsorted, sort every row" in place.
+// Stable sort of every segment of (key, value) pairs by its 32-bit key, out of place: the sort stage of the permute
+// with identity maps — segments are "rows", keys "columns" below `key_limit` — and without the reference's value
+// ordering of duplicate columns (a CSR-constructor rule): equal keys keep their input order (tiles and row classes
+// order (key, original position); long segments take the stable radix path).  The hybrid COO sort's second half
+// (sbx_convert.hip).  The caller has begun the arena.
+int sbx_sort_segments(sbx_handle_t h, int vb, int64_t nseg, int64_t key_limit, int64_t nnz, const int32_t *seg_ptr,
+                      const int32_t *key_in, const char *val_in, int32_t *key_out, char *val_out) {
+  typedef int32_t I;
+  PermState *st = nullptr;
+  I *long_rows = nullptr, *block_rows = nullptr;
+  int2 *rec = nullptr;
+  const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
+  SBX_TRY(perm_state_alloc(h, &st));
+  SBX_TRY(sbx_salloc(h, (size_t)nseg, &rec));
+  SBX_TRY(sbx_salloc(h, (size_t)nseg, &long_rows));
+  SBX_TRY(sbx_salloc(h, (size_t)nseg * BR_CLASSES, &block_rows));
+  SBX_TRY(perm_state_zero(h, st));
+  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nseg, h->stream));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((nseg + 3) / 4, 256, 8192)), dim3(256), seg_ptr,
+              (const I *)nullptr, nseg, (int64_t)0, nseg, rec);
+  I *sp = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nseg + 1, &sp));
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, nseg, long_rows, block_rows, nseg, block_cap, st));
+  PermState hs;
+  SBX_TRY(perm_fetch(h, &hs, st));
+  // (SBX_V_NONE: no value ordering of equal keys behind the sort)
+  if (vb == 0)
+    return sort_stage<0>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+                         nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
+  if (vb == 4)
+    return sort_stage<4>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+                         nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
+  return sort_stage<8>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+                       nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
+}
+
 extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
                                  int64_t nnz, const void *row_ptr, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;

@@ -423,6 +423,26 @@ def test_convert_vs_oracle(ops, oracle, seed):
         same((r_d, c_d, v_d), oracle.coo_sort(rr, cc, vv))
 
 
+@pytest.mark.parametrize("n,m,nnz", [(1 << 17, 1 << 17, 600000), (1 << 20, 1 << 12, 900000), (5000, 1 << 20, 400000),
+                                     (1 << 22, 1 << 9, 700000)])
+def test_coo_sort_hybrid_groups(ops, oracle, n, m, nnz):
+    """The hybrid COO constructor sort (sbx_convert.hip: two or three digit passes group the records by the row's
+    leading bits, the permute's LDS sort stage orders row-low-bits | column inside every group): DUPLICATE coordinates
+    keep their input order (the oracle's stable rule), hub rows put single groups beyond the LDS classes (long-group
+    path), empty groups in between, every value width, and dimensions that give 0 .. 6 low row bits per group."""
+    g = np.random.default_rng(n + m)
+    row = g.integers(0, n, nnz).astype(np.int32)
+    row[: nnz // 5] = g.integers(0, 3, nnz // 5)                 # three hub rows: one group far above 8192 records
+    row[nnz // 5: nnz // 4] = n - 1                                # ... and the last row of the last group
+    col = g.integers(0, m, nnz).astype(np.int32)
+    col[:5000] = col[5000:10000]                                   # duplicate (row, col) pairs with different values
+    row[:5000] = row[5000:10000]
+    for val in (None, g.integers(-99, 99, nnz).astype(np.int32), g.random(nnz)):
+        r_d, c_d, v_d = dev(row.copy()), dev(col.copy()), dev(None if val is None else val.copy())
+        ops.coo_sort_(n, m, r_d, c_d, v_d)
+        same((r_d, c_d, v_d), oracle.coo_sort(row, col, val))
+
+
 @pytest.mark.parametrize("n,m", [(1, 7), (7, 1), (3, 200), (300, 70000), (70000, 300), (70000, 70000), (2, 2)])
 def test_sorts_that_read_and_write_the_callers_arrays(ops, oracle, n, m):
     # COO constructor sort and COO / CSR -> CSC let the first digit pass of their radix sort load the source arrays and
