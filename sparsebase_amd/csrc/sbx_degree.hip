@@ -22,19 +22,47 @@ struct DegState {
   unsigned max_deg;
 };
 
-// key[j] = min(degree, DG_TOP) << 32 | id for id = n - 1 - j (descending id order)
+// key[j] = min(degree, DG_TOP) << 32 | id for id = n - 1 - j (descending id order).  Four consecutive keys per thread:
+// the five row_ptr words behind them in one 16-byte load (4-byte aligned only: gfx950 loads unaligned vectors) and a
+// 4-byte one, the keys out in two 16-byte stores (one key per thread and iteration, two dependent 4-byte loads each:
+// 36 us for 4.2 M rows; this form 15).
+template <typename I>
+struct __attribute__((packed, aligned(4))) DgQuad {
+  I a, b, c, d;
+};
 template <typename I>
 __global__ __launch_bounds__(256) void k_degree_keys(const I *__restrict__ rp, uint64_t *__restrict__ key, int64_t n,
                                                      DegState *__restrict__ st) {
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // keys 4 q .. 4 q + 3
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned mx = 0, top = 0;
-  for (; j < n; j += stride) {
-    const int64_t u = n - 1 - j;
-    const unsigned d = (unsigned)(rp[u + 1] - rp[u]);
-    key[j] = ((uint64_t)(d < DG_TOP ? d : DG_TOP) << 32) | (uint64_t)(uint32_t)u;
-    mx = d > mx ? d : mx;
-    top += d >= DG_TOP;
+  for (; 4 * q < n; q += stride) {
+    const int64_t j0 = 4 * q, u0 = n - 1 - j0;  // ids u0, u0 - 1, u0 - 2, u0 - 3
+    unsigned d[4];
+    const int cnt = n - j0 < 4 ? (int)(n - j0) : 4;
+    if (cnt == 4) {
+      const DgQuad<I> w = *(const DgQuad<I> *)(rp + u0 - 3);  // rp[u0 - 3 .. u0]
+      const I hi = rp[u0 + 1];
+      d[0] = (unsigned)(hi - w.d), d[1] = (unsigned)(w.d - w.c), d[2] = (unsigned)(w.c - w.b), d[3] = (unsigned)(w.b - w.a);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = k < cnt ? (unsigned)(rp[u0 - k + 1] - rp[u0 - k]) : 0u;
+    }
+    uint64_t kk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      kk[k] = ((uint64_t)(d[k] < DG_TOP ? d[k] : DG_TOP) << 32) | (uint64_t)(uint32_t)(u0 - k);
+      if (k < cnt) {
+        mx = d[k] > mx ? d[k] : mx;
+        top += d[k] >= DG_TOP;
+      }
+    }
+    if (cnt == 4) {  // (key is 256-byte aligned scratch: 32-byte aligned stores)
+      *(ulonglong2 *)(key + j0) = make_ulonglong2(kk[0], kk[1]);
+      *(ulonglong2 *)(key + j0 + 2) = make_ulonglong2(kk[2], kk[3]);
+    } else {
+      for (int k = 0; k < cnt; k++) key[j0 + k] = kk[k];
+    }
   }
   __shared__ unsigned s_mx[4], s_top[4];  // one atomic per workgroup: the result words are hot
   mx = sbx_wave_max(mx);
@@ -92,7 +120,9 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   SBX_TRY(sbx_salloc(h, (size_t)n, &sorted_id));
   SBX_TRY(sbx_salloc(h, 1, &st));
   SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(DegState), h->stream));
-  const unsigned grid = sbx_grid_for(n, 256, 2048);
+  // (few workgroups: each ends with two adds on one line of DegState, ~7 ns apiece whoever issues them — with 4096
+  // workgroups those adds, not the 64 MB the kernel moves, were its 52 us)
+  const unsigned grid = sbx_grid_for((n + 3) / 4, 256, 512);
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<I>, dim3(grid), dim3(256), rp, ka, n, st);
   SBX_LAUNCH_CHECK(h);
   // one pass over the digit in bits [32, 40); its scatter leaves the ids in order and inv[id] = position (in the
