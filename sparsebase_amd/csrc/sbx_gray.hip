@@ -280,7 +280,11 @@ constexpr int GR_BATCH = 4 * GR_VEC;  // entries per lane and batch: rows of up 
 constexpr int GR_MED_MAX = 8192;    // rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries: one wave each (k_gray_rows_medium)
 constexpr int GR_LONG_LIST = 4096;  // rows above GR_MED_MAX entries the short-row path lists for k_gray_long_rows
 constexpr int GR_FLAGS = 64;     // copies of the stop flag the waves of k_gray_rows_short poll, one per 128-byte line
-constexpr int GR_FLAG_OFF = 24;  // ... starting this many words after the long-row counter (GrayBoth below)
+#ifndef GR_EARLY_V
+#define GR_EARLY_V 8
+#endif
+constexpr int GR_EARLY = GR_EARLY_V;      // copies of the band counters k_gray_rows_short adds to, a line each, right behind GrayBoth's line
+constexpr int GR_FLAG_OFF = 24 + GR_EARLY * 32;  // ... starting this many words after the long-row counter (GrayAll below)
 constexpr int GR_SPREAD = 64;    // copies of the band counters the power-law kernels add to (4 GrayCounts = a 128-byte line each)
 constexpr unsigned GR_POWER_LAW = 2u;  // nlong[1]: 0 no row above GR_SHORT_MAX .. GR_MED_MAX met, 1 some, 2 many (start over)
 
@@ -531,9 +535,11 @@ __global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restri
   // microseconds of each other, and their 16 K adds to one 128-byte line took 130 us)
   if (__syncthreads_or(stopped)) return;
   if (__syncthreads_or(saw_medium) && tid == 0 && __atomic_load_n(nlong + 1, __ATOMIC_RELAXED) == 0) atomicMax(nlong + 1, 1u);
-  if (tid < 4) {  // the grid is a few workgroups per CU: one add per counter and workgroup
+  if (tid < 4) {
+    // one add per counter and workgroup, to one of GR_EARLY copies of the counters, a line each (the host adds them
+    // up): the workgroups end together, and their 16 K adds to ONE line were the last 13 us of the kernel
     const unsigned long long t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-    if (t) atomicAdd(&counts->nnz_sparse + tid, t);
+    if (t) atomicAdd(&counts[4 + (blockIdx.x % GR_EARLY) * 4].nnz_sparse + tid, t);
   }
 }
 
@@ -1203,13 +1209,15 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   };
   struct GrayAll {  // everything the kernels count in: one fill at the start of the call
     GrayBoth b;
-    unsigned fill[GR_FLAG_OFF - 2];
+    unsigned fill[24 - 2];
+    GrayCounts early[GR_EARLY * 4];  // k_gray_rows_short's counter copies (line i at &b.c + 4 + 4 i)
     unsigned flags[GR_FLAGS * 32];
     alignas(128) GrayCounts total2;  // the power-law path's counters (b.c holds what the stopped kernel left)
     GrayLists lists;
     alignas(128) GrayCounts spread[GR_SPREAD * 4];
   };
   static_assert(offsetof(GrayAll, flags) == offsetof(GrayBoth, nlong) + GR_FLAG_OFF * 4 && offsetof(GrayAll, flags) % 128 == 0, "flag lines");
+  static_assert(offsetof(GrayAll, early) == 4 * sizeof(GrayCounts), "the first counter copy sits one line behind the counters");
   GrayAll *all = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &all));
   SBX_HIP(h, hipMemsetAsync(all, 0, sizeof(GrayAll), h->stream));
@@ -1263,11 +1271,23 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
       static const bool try_banded = !(getenv("SBX_GRAY_BANDED_FIRST") && atoi(getenv("SBX_GRAY_BANDED_FIRST")) == 0);
       GrayBoth hb;
       hb.nlong = 0, hb.pad = GR_POWER_LAW;
+      // the counters (what the later kernels of the banded path added) + k_gray_rows_short's GR_EARLY copies, summed here
+      auto fetch_both = [&]() -> int {
+        struct { GrayBoth b; unsigned fill[24 - 2]; GrayCounts early[GR_EARLY * 4]; } head;
+        static_assert(sizeof(head) == offsetof(GrayAll, flags), "the head of GrayAll");
+        SBX_TRY(sbx_readback(h, &head, all, sizeof(head)));
+        hb = head.b;
+        for (int i = 0; i < GR_EARLY; i++) {
+          hb.c.nnz_sparse += head.early[4 * i].nnz_sparse, hb.c.diag_sparse += head.early[4 * i].diag_sparse;
+          hb.c.nnz_dense += head.early[4 * i].nnz_dense, hb.c.diag_dense += head.early[4 * i].diag_dense;
+        }
+        return SBX_OK;
+      };
       if (try_banded) {
         GRAY_ROWS_BY_LEVELS(k_gray_rows_short, grid);
         SBX_LAUNCH_CHECK(h);
         // one read-back: how many long rows the kernel met and — final if there were none — the band counters
-        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+        SBX_TRY(fetch_both());
       }
       const int wsh = wshift >= 0 ? wshift : -1;
       // the lists of k_gray_rows_medium: a row above GR_SHORT_MAX entries is at least one unit, every further unit is
@@ -1335,7 +1355,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
                       (int32_t *)degree_out, keys, cnt);
         }
         SBX_LAUNCH_CHECK(h);
-        SBX_TRY(sbx_readback(h, &hb, both, sizeof(GrayBoth)));
+        SBX_TRY(fetch_both());
       }
 #undef GRAY_MEDIUM
 #undef GRAY_ROWS_BY_LEVELS

@@ -116,28 +116,35 @@ __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int
     }
   }
   cnt = sbx_wave_sum(cnt);
-  if (lane == 0 && unit < DEG_UNITS) ucnt[unit] = cnt;
-  // one set of atomics per workgroup: the result words are hot
-  __shared__ unsigned s_mx[4], s_fv[4], s_cnt[4];
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
-  if (lane == 0) {
-    s_mx[sbx_wave_in_block()] = mx;
-    s_fv[sbx_wave_in_block()] = fv;
-    s_cnt[sbx_wave_in_block()] = cnt;
+  // per-unit partials, reduced by k_deg_reduce: three adds per workgroup on one line of RcmDev — 3 K adds at ~7 ns
+  // apiece whoever issues them — were 20 of this kernel's 31 us, at the head of every RCM call
+  if (lane == 0 && unit < DEG_UNITS) ucnt[unit] = cnt, ucnt[DEG_UNITS + unit] = mx, ucnt[2 * DEG_UNITS + unit] = fv;
+}
+
+__global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict__ ucnt, RcmDev *__restrict__ dv) {
+  __shared__ unsigned s_mx[16], s_fv[16], s_cnt[16];
+  unsigned mx = 0, fv = UNSEEN, cnt = 0;
+  for (int u = threadIdx.x; u < DEG_UNITS; u += 1024) {
+    cnt += ucnt[u];
+    mx = ucnt[DEG_UNITS + u] > mx ? ucnt[DEG_UNITS + u] : mx;
+    fv = ucnt[2 * DEG_UNITS + u] < fv ? ucnt[2 * DEG_UNITS + u] : fv;
   }
+  cnt = sbx_wave_sum(cnt);
+  mx = sbx_wave_max(mx);
+  fv = sbx_wave_min(fv);
+  if (sbx_lane() == 0) s_mx[threadIdx.x >> 6] = mx, s_fv[threadIdx.x >> 6] = fv, s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 4; i++) {
+    for (int i = 1; i < 16; i++) {
       mx = s_mx[i] > mx ? s_mx[i] : mx;
       fv = s_fv[i] < fv ? s_fv[i] : fv;
       cnt += s_cnt[i];
     }
-    if (mx) {
-      atomicMax(&dv->max_deg, mx);
-      atomicMin(&dv->first_vertex, fv);
-      atomicAdd(&dv->n_nonempty, cnt);
-    }
+    dv->max_deg = mx;
+    dv->first_vertex = fv;
+    dv->n_nonempty = cnt;
   }
 }
 
@@ -2847,10 +2854,10 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const unsigned gn = sbx_grid_for(n, 256, 8192);
   const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
   // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
-  SBX_HIP(h, hipMemsetAsync(&dv->first_vertex, 0xFF, sizeof(unsigned), h->stream));
   unsigned *ucnt = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS, &ucnt));
+  SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS * 3, &ucnt));  // per unit: non-empty rows, largest degree, first non-empty vertex
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, dv);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_reduce, dim3(1), dim3(1024), (const unsigned *)ucnt, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd0;
   SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
