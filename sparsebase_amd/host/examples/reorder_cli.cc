@@ -3,7 +3,7 @@
 // C++ API end to end (Gray's device keys + host ordering stage in particular) against
 // fixtures produced by the real reference.
 // Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time]
-// --time repeats the call twice and prints the third (warm) call's wall time in seconds on stdout (gray: and, on a
+// --time repeats the call five times and prints the last (warm) call's wall time in seconds on stdout (gray: and, on a
 // second line, the ms of its device key stage, of the copy of the keys to the host and of the host ordering stage)
 #include <chrono>
 #include <cstdio>
@@ -67,8 +67,10 @@ int main(int argc, char **argv) {
   if (!order) return 1;
   if (timed) {
     delete[] order;
-    order = run();  // (the library settles its scratch arena into one block at the start of the second call)
-    delete[] order;
+    for (int warm = 0; warm < 4; warm++) {  // (the library's scratch arena settles into one block over the first calls)
+      order = run();
+      delete[] order;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     order = run();
     std::printf("%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
