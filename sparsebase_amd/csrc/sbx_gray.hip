@@ -1003,20 +1003,13 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
   }
 }
 
-// The rows of more than one unit, a wave each: lane b adds block b's count over the row's partial slots.  Workgroup 0
-// also folds the counter copies of the kernels before into the counters the host reads.
+// The rows of more than one unit, a wave each: lane b adds block b's count over the row's partial slots.
 __global__ __launch_bounds__(256) void k_gray_units_finish(const int32_t *__restrict__ rp, const int4 *__restrict__ mrows,
                                                            const GrayLists *__restrict__ lc,
                                                            const unsigned *__restrict__ partial, int bits,
                                                            int nnz_threshold, int32_t *__restrict__ degree_out,
                                                            unsigned long long *__restrict__ key_out,
-                                                           GrayCounts *__restrict__ counts,
-                                                           const GrayCounts *__restrict__ spread, unsigned n_spread) {
-  if (blockIdx.x == 0 && threadIdx.x < 4 && n_spread > 1) {
-    unsigned long long t = 0;
-    for (unsigned i = 0; i < n_spread; i++) t += (&spread[i * 4].nnz_sparse)[threadIdx.x];
-    if (t) atomicAdd(&counts->nnz_sparse + threadIdx.x, t);
-  }
+                                                           GrayCounts *__restrict__ counts, unsigned n_spread) {
   __shared__ unsigned long long s_red[4][4];
   const unsigned nm = lc->n_mrows;
   const int lane = sbx_lane(), wv = threadIdx.x >> 6;
@@ -1053,10 +1046,20 @@ __global__ __launch_bounds__(256) void k_gray_units_finish(const int32_t *__rest
   // (one add per counter and workgroup: 23 K rows x 2 adds to one line were 220 us)
   if (lane == 0) s_red[wv][0] = c[0], s_red[wv][1] = c[1], s_red[wv][2] = c[2], s_red[wv][3] = c[3];
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 4) {  // (to one of the counter copies, as the kernels before: 4 K adds to one line were this kernel's 28 us)
     const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    if (t) atomicAdd(&counts->nnz_sparse + threadIdx.x, t);
+    if (t) atomicAdd(&counts[(blockIdx.x % n_spread) * 4].nnz_sparse + threadIdx.x, t);
   }
+}
+
+// the counter copies of the power-law kernels, summed into the words the host reads
+__global__ __launch_bounds__(64) void k_gray_fold(const GrayCounts *__restrict__ spread, GrayCounts *__restrict__ total) {
+  const int lane = sbx_lane();
+  unsigned long long t[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) t[q] = sbx_wave_sum(lane < GR_SPREAD ? (&spread[lane * 4].nnz_sparse)[q] : 0ull);
+  static_assert(GR_SPREAD <= 64, "one copy per lane");
+  if (lane == 0) total->nnz_sparse = t[0], total->diag_sparse = t[1], total->nnz_dense = t[2], total->diag_dense = t[3];
 }
 
 // GR_PARTS workgroups per listed long row (a 200 K-entry boundary row must not be one workgroup's job): per-block counts
@@ -1329,7 +1332,8 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         GRAY_MEDIUM(spread, (unsigned)GR_SPREAD);
         SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus * 4), dim3(256), rp,
                     (const int4 *)mrows, (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold,
-                    (int32_t *)degree_out, keys, &all->total2, (const GrayCounts *)spread, (unsigned)GR_SPREAD);
+                    (int32_t *)degree_out, keys, spread, (unsigned)GR_SPREAD);
+        SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_fold, dim3(1), dim3(64), (const GrayCounts *)spread, &all->total2);
         SBX_LAUNCH_CHECK(h);
         SBX_TRY(sbx_readback(h, &hb.c, &all->total2, sizeof(GrayCounts)));
         hb.nlong = 0, hb.pad = 0;
@@ -1342,7 +1346,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
           GRAY_MEDIUM(cnt, 1u);
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3(64), dim3(256), rp, (const int4 *)mrows,
                       (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
-                      cnt, (const GrayCounts *)cnt, 1u);
+                      cnt, 1u);
         }
         if (hlong) {
           unsigned *slots = nullptr;
