@@ -1,7 +1,7 @@
 // sbx_i64.hip — SBX_I64 support: 64-bit IDType/NNZType arrays (the reference's
 // <int64,int64,double> tuple).  NATIVE 64-bit kernels (index values and nnz of any size, no copies): the conversions
 // COO <-> CSR and the two sortedness checks (sbx_convert.hip), the four features (sbx_features.hip), DegreeReorder
-// (sbx_degree.hip), InversePermutation and PermuteArray (sbx_permute.hip).  The entry points in THIS file — the sorts,
+// (sbx_degree.hip), InversePermutation, PermuteArray and the row-wise CSR permute (sbx_permute.hip).  The entry points in THIS file — the sorts,
 // CSC, RCM, Gray keys, the CSR permute, the text parsers — narrow their index arrays to int32 scratch copies (with an
 // overflow check), run the int32 kernels and widen the index outputs back; values are opaque payload and pass
 // through untouched; arrays with entries >= 2^31 return SBX_ERR_UNSUPPORTED there.

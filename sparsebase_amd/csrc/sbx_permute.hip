@@ -228,12 +228,15 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
     if (base + CS_ITEMS <= nr) {
 #pragma unroll
       for (int k = 0; k < CS_ITEMS; k += 4) {
-        if (rpo && rpo_aligned) {
-          *(int4 *)(rpo + base + k) = make_int4((int)oa[k], (int)oa[k + 1], (int)oa[k + 2], (int)oa[k + 3]);
-        } else if (rpo) {  // a caller's row_ptr_out at an odd offset
+        if (sizeof(I) == 4 && rpo && rpo_aligned) {
+          *(int4 *)(void *)(rpo + base + k) = make_int4((int)oa[k], (int)oa[k + 1], (int)oa[k + 2], (int)oa[k + 3]);
+        } else if (rpo) {  // a caller's row_ptr_out at an odd offset, or 64-bit indices
           rpo[base + k] = oa[k], rpo[base + k + 1] = oa[k + 1], rpo[base + k + 2] = oa[k + 2], rpo[base + k + 3] = oa[k + 3];
         }
-        *(int4 *)(sp + base + k) = make_int4((int)os[k], (int)os[k + 1], (int)os[k + 2], (int)os[k + 3]);
+        if (sizeof(I) == 4)
+          *(int4 *)(void *)(sp + base + k) = make_int4((int)os[k], (int)os[k + 1], (int)os[k + 2], (int)os[k + 3]);
+        else
+          sp[base + k] = os[k], sp[base + k + 1] = os[k + 1], sp[base + k + 2] = os[k + 2], sp[base + k + 3] = os[k + 3];
       }
     } else {
       for (int k = 0; base + k < nr; k++) {
@@ -305,15 +308,15 @@ __global__ __launch_bounds__(256) void k_rowwise_prep(const I *__restrict__ rp, 
   // waiting for its own loads (65 us for 4 M rows; the traffic is 80 MB)
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, nq = (n + 3) >> 2;
-  const bool al = (((uintptr_t)rp | (uintptr_t)row_order) & 15) == 0;
+  const bool al = sizeof(I) == 4 && (((uintptr_t)rp | (uintptr_t)row_order) & 15) == 0;  // (64-bit indices: the scalar form)
   for (; q < nq; q += stride) {
     const int64_t u0 = q << 2;
     int64_t b[5], r[4];
     if (u0 + 4 <= n && al) {
-      const int4 p4 = *(const int4 *)(rp + u0);
+      const int4 p4 = *(const int4 *)(const void *)(rp + u0);
       b[0] = p4.x, b[1] = p4.y, b[2] = p4.z, b[3] = p4.w, b[4] = rp[u0 + 4];
       if (row_order) {
-        const int4 o4 = *(const int4 *)(row_order + u0);
+        const int4 o4 = *(const int4 *)(const void *)(row_order + u0);
         r[0] = o4.x, r[1] = o4.y, r[2] = o4.z, r[3] = o4.w;
       } else {
         r[0] = u0, r[1] = u0 + 1, r[2] = u0 + 2, r[3] = u0 + 3;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
   typedef typename ValT<VB>::type V;
   __shared__ unsigned long long s_head[PC_TILE];  // (row - r_lo) << 32 | (source - destination) at the row's first nonzero
   __shared__ int s_delta[PC_TILE];
-  __shared__ int s_col[PC_TILE];
+  __shared__ I s_col[PC_TILE];
   __shared__ int s_wmax[PC_THREADS / 64];
   const int tid = threadIdx.x;
   const int64_t t0 = (int64_t)blockIdx.x * PC_TILE;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_permute_copy(const int2 *__restr
   // all loads of a thread first, then its stores.  Written as "load, store, next position" under `p < cnt`, the
   // compiler waited for every load before the store behind it and the copy was 16 dependent round trips per tile
   // (tools/isa_waits.py); positions past the tile's end read the entry of position 0 (the loads are unconditional).
-  int c[PC_ITEMS];
+  I c[PC_ITEMS];
   V v[VB ? PC_ITEMS : 1];
   {
     int64_t src[PC_ITEMS];
@@ -2369,6 +2372,65 @@ extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   return SBX_OK;
 }
 
+// Row-wise permute (no column map) of a CSR with 64-bit indices, native: the records (length, source offset) stay
+// 32-bit — nnz < 2^31, checked by the caller — while row_ptr, the row order and the columns are read and written as
+// they are: no narrowed copies, column ids of any size.  Returns SBX_ROWWISE_NEEDS_SORT when some input row turns out
+// unsorted (arrays that never went through a CSR constructor): the caller then takes the sorting pipeline.
+constexpr int SBX_ROWWISE_NEEDS_SORT = -1000;
+static int permute_rows_rowwise_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row_ptr,
+                                    const void *col, const void *val, const void *row_order, int64_t row_begin,
+                                    int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                                    int64_t out_capacity, int64_t *shard_nnz_host) {
+  typedef int64_t I;
+  const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  SBX_TRY(sbx_arena_begin(h));
+  const int64_t nr = row_end - row_begin;
+  I *rpo = (I *)row_ptr_out;
+  if (shard_nnz_host) *shard_nnz_host = 0;
+  if (nr == 0) return sbx_fill_i64(h, rpo, 0, 1);
+  PermState *st = nullptr;
+  int2 *rec = nullptr;
+  I *sp = nullptr;
+  SBX_TRY(perm_state_alloc(h, &st));
+  SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
+  SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
+  SBX_TRY(perm_state_zero(h, st));
+  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nr, h->stream));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((n + 3) / 4, 256, 8192)), dim3(256),
+              (const I *)row_ptr, (const I *)row_order, n, row_begin, nr, rec);
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, (I *)nullptr, (I *)nullptr, 0, 0, st));
+  int64_t total = nnz;
+  if (nr != n) {
+    PermState hs;
+    SBX_TRY(perm_fetch(h, &hs, st));
+    total = (int64_t)hs.total;
+  }
+  if (shard_nnz_host) *shard_nnz_host = total;
+  if (total > out_capacity)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
+             (long long)out_capacity);
+  if (total == 0) return SBX_OK;
+  const unsigned tiles = (unsigned)((total + PC_TILE - 1) / PC_TILE);
+  I *tile_row = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_row));
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_rows<I>, dim3(tiles / 256 + 1), dim3(256), (const I *)rpo, nr, total, PC_TILE,
+              (int64_t)tiles, tile_row);
+#define COPY(VBX)                                                                                              \
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_copy<I, VBX>), dim3(tiles), dim3(PC_THREADS), (const int2 *)rec, \
+              (const I *)tile_row, (const I *)col, (const char *)val, (const I *)rpo, (I *)col_out, (char *)val_out, \
+              nr, total, st)
+  if (vb == 0) COPY(0);
+  else if (vb == 4) COPY(4);
+  else COPY(8);
+#undef COPY
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, total * (int64_t)(2 * (sizeof(I) + vb)));
+  PermState hc;
+  SBX_TRY(sbx_readback(h, &hc, st, sizeof(PermState)));
+  return hc.any_unsorted ? SBX_ROWWISE_NEEDS_SORT : SBX_OK;
+}
+
 extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
                                     int64_t nnz, const void *row_ptr, const void *col, const void *val,
                                     const void *row_order, const void *col_order, int64_t row_begin, int64_t row_end,
@@ -2379,9 +2441,15 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
   SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
-  if (it == SBX_I64)
+  if (it == SBX_I64) {
+    if (!col_order) {  // row-wise: native 64-bit kernels (no copies; column ids of any size); falls through when a row is unsorted
+      const int rc = permute_rows_rowwise_i64(h, vt, n, nnz, row_ptr, col, val, row_order, row_begin, row_end, row_ptr_out,
+                                              col_out, val_out, out_capacity, shard_nnz_host);
+      if (rc != SBX_ROWWISE_NEEDS_SORT) return rc;
+    }
     return sbx_i64_permute_csr_rows(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
                                     row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
+  }
   const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));

@@ -1017,10 +1017,19 @@ def test_int64_values_beyond_int32(ops, oracle):
     rp2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
     for asc in (True, False):
         assert np.array_equal(host(ops.degree_reorder(dev(rp2 + (1 << 40)), asc)), oracle.degree_reorder(rp2, asc))
-    # the operations that still run on narrowed copies refuse what does not fit, loudly
+    # the row-wise permute (no column map) is native too: the columns travel as they are
     order = synth.random_permutation(n, 3, np.int64)
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(order), None), oracle.permute_csr(rp, col, val, order, None, m=m))
+    same(ops.permute_csr(n, m, dev(rp), dev(col), None, dev(order), None), oracle.permute_csr(rp, col, None, order, None, m=m))
+    srp, scol, sval = ops.permute_csr_rows(n, m, dev(rp), dev(col), dev(val), dev(order), None, n // 3, n // 2)
+    want = oracle.permute_csr(rp, col, val, order, None, m=m)
+    lo, hi = want[0][n // 3], want[0][n // 2]
+    assert np.array_equal(host(srp), want[0][n // 3:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
+    assert np.array_equal(host(sval), want[2][lo:hi])
+    # the operations that still run on narrowed copies refuse what does not fit, loudly
+    r_big, c_big, v_big = dev(r_u.copy()), dev(c_u.copy()), dev(v_u.copy())
     with pytest.raises(capi.SbxError) as e:
-        ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(order), None)
+        ops.coo_sort_(n, m, r_big, c_big, v_big)
     assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
 
 
