@@ -9,7 +9,8 @@
 // (inv[id] = position, sbx_radix_sort_emit) instead of a sorted array.  The rows of the last bucket — in id order
 // after the stable pass — are then sorted among themselves by their full degree (a few ten thousand rows: a small
 // radix sort) and get their positions from a second scatter.  One read-back (rows in the last bucket, largest degree)
-// sits behind the big pass, where the host would wait anyway.  8n + 4 algorithmic bytes; n = 4 M: ~0.1 ms.
+// sits behind the big pass, where the host would wait anyway.  8n + 4 algorithmic bytes; n = 4.2 M: 0.157 ms.  Templated on
+// the index type: 64-bit row_ptr arrays are read as they are and the inverse permutation is written in 64 bits.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 

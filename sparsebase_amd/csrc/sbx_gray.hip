@@ -9,6 +9,11 @@
 //                   deg/resolution for dense rows (:384-395)
 // and the four band counters of :138-170 (nonzeros within m/128 of the diagonal,
 // split by sparse/dense class).  One O(nnz) pass, 4 B/nonzero + 16 B/row of traffic.
+// Three kernel families, chosen by what the matrix turns out to be (sbx_gray_row_keys below):
+//   k_gray_rows_short (+ k_gray_long_rows/finish, k_gray_list_medium)   banded / mesh matrices: 4 lanes per row
+//   k_gray_rows_balanced, k_gray_rows_medium, k_gray_units_finish       power-law matrices: a lane per entry, rows cut
+//                                                                      into 1024-entry units
+//   k_gray_prep, k_gray_tile, k_gray_finish                             resolutions below 16: nonzero-parallel tiles
 // The ordering stage (std::sort calls whose tie order is libstdc++-specific) stays
 // above the ABI in the host layer — see DESIGN.md "Gray".
 #include "sbx_device.h"
