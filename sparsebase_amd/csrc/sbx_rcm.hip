@@ -233,12 +233,15 @@ __device__ __forceinline__ void cc_hook(I *parent, I a, I b) {
 }
 
 __global__ __launch_bounds__(256) void k_cc_init(const I *__restrict__ rp, const I *__restrict__ col,
-                                                 I *__restrict__ parent, int64_t n) {
+                                                 I *__restrict__ parent, int64_t n,
+                                                 const unsigned *__restrict__ cbits) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; v < n; v += stride) {
     I p = (I)v;
-    if (rp[v] < rp[v + 1]) {
+    // (the members of the component the first sweep covered — nearly every non-empty row of a power-law graph — are
+    // labelled by k_cc_finalize whatever stands here: no gather of their first neighbour)
+    if (rp[v] < rp[v + 1] && !((cbits[v >> 5] >> (v & 31)) & 1u)) {
       const I first = col[rp[v]];  // smallest neighbour (rows are column-sorted)
       if (first < p) p = first;
     }
@@ -2968,7 +2971,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     n_host = 1;
     first_is_large = true;
   } else {
-  SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n);
+  SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n, (const unsigned *)cbits);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list,
               (const unsigned *)cbits, dv);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_big, dim3((unsigned)h->num_cus * 8), dim3(256), rp, col, label,
