@@ -110,6 +110,45 @@ def test_c3_csc_and_features_100m(ops, oracle, c3):
     assert ops.csr_profile(prp, pcol) < before
 
 
+def test_c3_gray_keys_degree_and_coo_sort_100m_bit_exact(ops, oracle, c3):
+    """The power-law kernels of round 3 at full size, bit for bit against the oracle: the Gray key stage on the bench
+    matrix (the banded kernel stops, k_gray_rows_balanced / k_gray_rows_medium / k_gray_units_finish take over; hubs of
+    hundreds of 1024-entry units) at three parameter sets, DegreeReorder in both directions (one digit pass + the
+    re-sorted tail of 76 K vertices), and the hybrid COO constructor sort on the matrix's 105 M entries shuffled
+    (three digit passes, groups = rows, the hubs on the long-group path)."""
+    rp, col, val = c3
+    n, nnz = rp.numel() - 1, col.numel()
+    hrp, hcol = rp.cpu().numpy(), col.cpu().numpy()
+    for res, thr in ((32, 10), (16, 20), (64, 2)):
+        deg, key, counts = ops.gray_row_keys(n, rp, col, res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(hrp, hcol, n, res, thr)
+        assert np.array_equal(deg.cpu().numpy(), wdeg), (res, thr)
+        assert np.array_equal(key.cpu().numpy().view(np.uint64), wkey), (res, thr)
+        assert list(counts) == wcounts.tolist(), (res, thr)
+    for asc in (True, False):
+        assert np.array_equal(ops.degree_reorder(rp, asc).cpu().numpy(), oracle.degree_reorder(hrp, asc))
+    row = ops.csr_to_coo(n, n, rp, col, None, move=True)[0]
+    p = torch.randperm(nnz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+    r, c, v = row[p].contiguous(), col[p].contiguous(), val[p].contiguous()
+    ops.coo_sort_(n, n, r, c, v)          # distinct coordinates: the sorted COO is the CSR's own expansion
+    assert torch.equal(r, row) and torch.equal(c, col) and torch.equal(v, val)
+
+
+def test_c2b_coo_sort_10m_with_duplicates(ops, oracle):
+    """C2B: 10 M uniform entries over 2^20 x 2^20, shuffled, a tenth of them duplicated coordinates with different
+    values: the hybrid sort (two digit passes, 65 536 groups of ~150 records sorted in LDS) keeps duplicates in input
+    order like the oracle's stable sort."""
+    n = m = 1 << 20
+    row, col, val = synth.uniform_random_coo_torch(n, m, 10_000_000, seed=3, shuffled=True)
+    k = row.numel() // 10
+    row[:k], col[:k] = row[k:2 * k].clone(), col[k:2 * k].clone()
+    hr, hc, hv = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    r, c, v = row.clone(), col.clone(), val.clone()
+    ops.coo_sort_(n, m, r, c, v)
+    wr, wc, wv = oracle.coo_sort(hr, hc, hv)
+    assert np.array_equal(r.cpu().numpy(), wr) and np.array_equal(c.cpu().numpy(), wc) and np.array_equal(v.cpu().numpy(), wv)
+
+
 @pytest.mark.parametrize("half_bandwidth", [64, (1 << 22) // 16])
 def test_c5_gray_keys_100m_banded(ops, oracle, half_bandwidth):
     n = 1 << 22
