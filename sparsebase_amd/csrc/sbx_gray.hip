@@ -11,7 +11,8 @@
 // split by sparse/dense class).  One O(nnz) pass, 4 B/nonzero + 16 B/row of traffic.
 // Three kernel families, chosen by what the matrix turns out to be (sbx_gray_row_keys below):
 //   k_gray_rows_short (+ k_gray_long_rows/finish, k_gray_list_medium)   banded / mesh matrices: 4 lanes per row
-//   k_gray_rows_balanced, k_gray_rows_medium, k_gray_units_finish       power-law matrices: a lane per entry, rows cut
+//   k_gray_rows_tiny, k_gray_rows_listed (or k_gray_rows_balanced),    power-law matrices: a lane per row of up to 15
+//   k_gray_rows_medium, k_gray_units_finish                            entries, four per row of up to 64, longer rows cut
 //                                                                      into 1024-entry units
 //   k_gray_prep, k_gray_tile, k_gray_finish                             resolutions below 16: nonzero-parallel tiles
 // The ordering stage (std::sort calls whose tie order is libstdc++-specific) stays
@@ -819,6 +820,245 @@ __global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__res
 #endif
 }
 
+// ---- power-law matrices, rows of up to GR_SHORT_MAX entries, second form -------------------------------------------
+// k_gray_rows_balanced (above) costs ~45 instructions per 64 entries + ~150 per 64 rows and a chain of dependent LDS /
+// scan / load steps per group: 123 us on the bench matrix whatever its shape.  Two kernels without LDS do the same work:
+//   k_gray_rows_tiny    ONE lane per row for rows of up to GR_TINY entries (87 % of the bench matrix's rows, empty ones
+//                       included): four 16-byte loads per lane, the row's block bits ORed in registers.  Such a row is
+//                       shorter than `resolution` (>= 16 on this path), so its threshold is 0 and nothing is counted.
+//                       Lists the rows of GR_TINY + 1 .. GR_SHORT_MAX entries for the kernel below and cuts the longer
+//                       ones into units for k_gray_rows_medium — one reservation per list and workgroup.
+//   k_gray_rows_listed  FOUR lanes per listed row, 16 entries each in four 16-byte loads, the bit-sliced saturating
+//                       counters and DPP merges of k_gray_rows_short.
+constexpr int GR_TINY = 15;
+__device__ __forceinline__ void gr_fix4(int32_t j, int cnt, int32_t nnz, unsigned (&c)[4]) {
+  if (__any(j > nnz - 4 && cnt > 0)) {  // the end of the array: the vector was read up to 3 entries early
+    const int sh = j - gr_clamp4(j, nnz);
+    const unsigned w[4] = {c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      unsigned x = w[t];
+#pragma unroll
+      for (int k = t + 1; k < 4; k++) x = (sh == k - t) ? w[k] : x;
+      c[t] = x;
+    }
+  }
+}
+
+template <typename B, bool POW2>
+__global__ __launch_bounds__(256) void k_gray_rows_tiny(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                        int64_t n, int32_t nnz, uint32_t width, uint32_t magic,
+                                                        uint32_t band, int wshift, int nnz_threshold,
+                                                        int32_t *__restrict__ degree_out,
+                                                        unsigned long long *__restrict__ key_out,
+                                                        GrayCounts *__restrict__ counts, int4 *__restrict__ units,
+                                                        int4 *__restrict__ mrows, GrayLists *__restrict__ lc,
+                                                        int32_t *__restrict__ mid_list, unsigned *__restrict__ mid_count) {
+  __shared__ unsigned s_w[4][3], s_b[3];
+  __shared__ unsigned s_mid[4], s_mbase;
+  __shared__ unsigned long long s_red[4][4];
+  const int lane = sbx_lane(), wv = threadIdx.x >> 6;
+  constexpr int NG = GB_ITERS * GB_GROUPS;
+  unsigned long long c_ns = 0, c_nd = 0;
+  unsigned c_ds = 0, c_dd = 0;
+  int listed[NG];        // lengths of the rows above GR_SHORT_MAX entries: units of k_gray_rows_medium
+  uint64_t midm[NG];     // the rows of GR_TINY + 1 .. GR_SHORT_MAX entries of every group (k_gray_rows_listed)
+#pragma unroll
+  for (int i = 0; i < NG; i++) listed[i] = 0, midm[i] = 0;
+  auto block_row = [&](int it) { return (((int64_t)blockIdx.x + (int64_t)it * gridDim.x) * 4 + wv) * (GB_GROUPS * 64); };
+  auto group_row = [&](int i) { return block_row(i / GB_GROUPS) + (int64_t)(i % GB_GROUPS) * 64; };
+  // The wave's NG groups of 64 rows as one software pipeline, fully unrolled (every index below is a constant): the row
+  // bounds of group i + 2 and the four 16-byte column loads of group i + 1 are issued before group i is worked on.
+  // (A group at a time — bounds, then columns, then the ORs — was 108 us: two load latencies per group and wave.)
+  int32_t rs[NG + 2], re[NG + 2];
+  auto bounds = [&](int i) {  // (unconditional, at a clamped row: loads of a fixed number on every path)
+    const int64_t r = group_row(i < NG ? i : NG - 1) + lane;
+    const int64_t rc = r < n ? r : n - 1;
+    rs[i] = rp[rc], re[i] = rp[rc + 1];
+  };
+  GrU4 v[2][4];
+  // Unconditional loads, but no lane touches a line it has no use for: a vector the row does not reach is read at the
+  // row's first vector again, and the lanes of empty and of longer rows read where the group's first row starts (the
+  // rows' first lines alone are 2 M x 128 bytes on the bench matrix; four vectors per lane whatever the row's length
+  // fetched twice that and the kernel ran at the HBM's pace: 110 us)
+  auto vload = [&](int i) {
+    const int64_t r = group_row(i) + lane;
+    const int d = r < n ? re[i] - rs[i] : 0;
+    const int dt = d <= GR_TINY ? d : 0;
+    const int32_t first = __builtin_amdgcn_readfirstlane(rs[i]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t at = dt > 4 * k ? rs[i] + 4 * k : (dt > 0 ? rs[i] : first);
+      v[i & 1][k] = *(const GrU4 *)(col + gr_clamp4(at, nnz));
+    }
+  };
+  bounds(0);
+  bounds(1);
+  vload(0);
+#pragma unroll
+  for (int i = 0; i < NG; i++) {
+    if (i + 2 < NG) bounds(i + 2);
+    if (i + 1 < NG) vload(i + 1);
+    const int64_t r = group_row(i) + lane;
+    const int d = r < n ? re[i] - rs[i] : 0;
+    listed[i] = d > GR_SHORT_MAX ? d : 0;
+    midm[i] = __ballot(d > GR_TINY && d <= GR_SHORT_MAX);
+    const int dt = d <= GR_TINY ? d : 0;
+    B mask = 0;
+    unsigned inb = 0;
+    const unsigned row_lo = (unsigned)r - band, band2 = 2u * band;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int left = dt - 4 * k;
+      const int cnt = left < 0 ? 0 : (left > 4 ? 4 : left);
+      unsigned c[4] = {v[i & 1][k].x, v[i & 1][k].y, v[i & 1][k].z, v[i & 1][k].w};
+      gr_fix4(rs[i] + 4 * k, cnt, nnz, c);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        unsigned bkt;
+        if (POW2) {
+          bkt = c[t] >> wshift;
+        } else {
+          bkt = __umulhi(c[t], magic);
+          bkt += (c[t] - bkt * width) >= width;
+        }
+        const bool have = t < cnt;
+        mask |= have ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
+        inb += have && c[t] - row_lo <= band2;
+      }
+    }
+    if (r < n && d <= GR_TINY) {
+      degree_out[r] = d;
+      key_out[r] = gray_decode((unsigned long long)mask);
+      if (d <= nnz_threshold) c_ns += (unsigned)d, c_ds += inb;
+      else c_nd += (unsigned)d, c_dd += inb;
+    }
+  }
+  c_ns = sbx_wave_sum(c_ns); c_nd = sbx_wave_sum(c_nd);
+  const unsigned long long w_ds = sbx_wave_sum((unsigned long long)c_ds), w_dd = sbx_wave_sum((unsigned long long)c_dd);
+  unsigned mid_mine = 0;
+#pragma unroll
+  for (int i = 0; i < NG; i++) mid_mine += (unsigned)__popcll(midm[i]);
+  if (lane == 0) {
+    s_red[wv][0] = c_ns; s_red[wv][1] = w_ds; s_red[wv][2] = c_nd; s_red[wv][3] = w_dd;
+    s_mid[wv] = mid_mine;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    if (t) atomicAdd(&counts[(blockIdx.x % GR_SPREAD) * 4].nnz_sparse + threadIdx.x, t);
+  }
+  {  // the mid-length rows: one reservation per workgroup
+    const unsigned tot = s_mid[0] + s_mid[1] + s_mid[2] + s_mid[3];
+    if (threadIdx.x == 0) s_mbase = tot ? atomicAdd(mid_count, tot) : 0u;
+    __syncthreads();
+    unsigned o = s_mbase;
+    for (int i = 0; i < wv; i++) o += s_mid[i];
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+      if ((midm[i] >> lane) & 1ull) mid_list[o + (unsigned)__popcll(midm[i] & sbx_lanemask_lt())] = (int32_t)(group_row(i) + lane);
+      o += (unsigned)__popcll(midm[i]);
+    }
+  }
+  gray_emit_units(listed, [&](int i) { return group_row(i); }, units, mrows, lc, s_w, s_b);
+}
+
+template <typename B, int LV, bool POW2>
+__global__ __launch_bounds__(256) void k_gray_rows_listed(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ list,
+                                                          const unsigned *__restrict__ count, int32_t nnz,
+                                                          uint32_t width, uint32_t magic, uint32_t band, int wshift,
+                                                          int bits, int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                          unsigned long long *__restrict__ key_out,
+                                                          GrayCounts *__restrict__ counts) {
+  __shared__ unsigned long long s_red[4][4];
+  const int tid = threadIdx.x, lane = sbx_lane(), sub = lane & 3;
+  const unsigned total = *count;
+  unsigned long long c_ns = 0, c_ds = 0, c_nd = 0, c_dd = 0;
+  const unsigned gwave = (blockIdx.x * 256u + (unsigned)tid) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+  for (unsigned base = gwave * 16u; base < total; base += nwaves * 16u) {  // 16 rows per wave and step, 4 lanes each
+    const unsigned i = base + (unsigned)(lane >> 2);
+    const bool valid = i < total;
+    const int32_t row = list[valid ? i : total - 1];
+    const int32_t rs = rp[row], re = rp[row + 1];
+    const int d = valid ? re - rs : 0;
+    GrU4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // (a vector behind the row's end is read at the row's start: no line nobody needs)
+      const int32_t at = 16 * sub + 4 * k < d ? rs + 16 * sub + 4 * k : rs;
+      v[k] = *(const GrU4 *)(col + gr_clamp4(at, nnz));
+    }
+    const bool sparse = d <= nnz_threshold;
+    unsigned thr = 0;
+#pragma unroll
+    for (int t = 1; t < LV; t++) thr += d >= t * bits;
+    thr = d > nnz_threshold ? thr : 0u;
+    B ge[LV];
+#pragma unroll
+    for (int t = 0; t < LV; t++) ge[t] = 0;
+    unsigned inb = 0;
+    const unsigned row_lo = (unsigned)row - band, band2 = 2u * band;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int left = d - (16 * sub + 4 * k);
+      const int cnt = left < 0 ? 0 : (left > 4 ? 4 : left);
+      unsigned c[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      gr_fix4(rs + 16 * sub + 4 * k, cnt, nnz, c);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        unsigned bkt;
+        if (POW2) {
+          bkt = c[u] >> wshift;
+        } else {
+          bkt = __umulhi(c[u], magic);
+          bkt += (c[u] - bkt * width) >= width;
+        }
+        const bool have = u < cnt;
+        const B x = have ? (B)1 << (bkt & (sizeof(B) * 8 - 1)) : (B)0;
+#pragma unroll
+        for (int t = LV - 1; t > 0; t--) ge[t] |= ge[t - 1] & x;
+        ge[0] |= x;
+        inb += have && c[u] - row_lo <= band2;
+      }
+    }
+    // merge the four lanes of the row: counts add, saturating at LV (k_gray_rows_short's merge)
+#pragma unroll
+    for (int m = 1; m < 4; m <<= 1) {
+      B o[LV], r[LV];
+#pragma unroll
+      for (int t = 0; t < LV; t++) o[t] = gr_shfl_xor(ge[t], m);
+#pragma unroll
+      for (int t = 0; t < LV; t++) {
+        B w = ge[t] | o[t];
+#pragma unroll
+        for (int q = 0; q < t; q++) w |= ge[q] & o[t - 1 - q];
+        r[t] = w;
+      }
+#pragma unroll
+      for (int t = 0; t < LV; t++) ge[t] = r[t];
+      inb += gr_xor32(inb, m);
+    }
+    if (sub == 0 && valid) {
+      B key = ge[0];
+#pragma unroll
+      for (int t = 1; t < LV; t++) key = thr == (unsigned)t ? ge[t] : key;
+      degree_out[row] = d;
+      key_out[row] = gray_decode((unsigned long long)key);
+      if (sparse) c_ns += (unsigned)d, c_ds += inb;
+      else c_nd += (unsigned)d, c_dd += inb;
+    }
+  }
+  c_ns = sbx_wave_sum(c_ns); c_ds = sbx_wave_sum(c_ds); c_nd = sbx_wave_sum(c_nd); c_dd = sbx_wave_sum(c_dd);
+  if (lane == 0) {
+    s_red[tid >> 6][0] = c_ns; s_red[tid >> 6][1] = c_ds; s_red[tid >> 6][2] = c_nd; s_red[tid >> 6][3] = c_dd;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const unsigned long long t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    if (t) atomicAdd(&counts[(blockIdx.x % GR_SPREAD) * 4].nnz_sparse + tid, t);
+  }
+}
+
 // One wave per listed unit, round-robin over the list.  (Finding the rows where they are — a wave per 64 consecutive
 // rows, or per 64 rows a fixed stride apart — was built first: 8.8 and 9.0 ms on the RMAT bench matrix, whose
 // generator puts the hubs next to each other AND at ids with many trailing zero bits: whatever regular map from row
@@ -1222,6 +1462,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     unsigned flags[GR_FLAGS * 32];
     alignas(128) GrayCounts total2;  // the power-law path's counters (b.c holds what the stopped kernel left)
     GrayLists lists;
+    alignas(128) unsigned mid_count;  // rows listed for k_gray_rows_listed
     alignas(128) GrayCounts spread[GR_SPREAD * 4];
   };
   static_assert(offsetof(GrayAll, flags) == offsetof(GrayBoth, nlong) + GR_FLAG_OFF * 4 && offsetof(GrayAll, flags) % 128 == 0, "flag lines");
@@ -1330,7 +1571,46 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         GrayCounts *spread = all->spread;
         const int64_t brows = (int64_t)GB_ITERS * 4 * GB_GROUPS * 64;  // rows per workgroup
         const unsigned bgrid = (unsigned)((n + brows - 1) / brows);
-        {
+        static const bool tiny_on = !(getenv("SBX_GRAY_TINY_ROWS") && atoi(getenv("SBX_GRAY_TINY_ROWS")) == 0);
+        // (a row of up to GR_TINY entries has threshold 0 when it is shorter than `resolution` or not above the nnz threshold)
+        if (tiny_on && (bits > GR_TINY || nnz_threshold >= GR_TINY)) {
+          int32_t *mid_list = nullptr;
+          SBX_TRY(sbx_salloc(h, (size_t)n, &mid_list));
+#define GRAY_TINY(B)                                                                                                  \
+  do {                                                                                                               \
+    if (wshift >= 0)                                                                                                 \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_tiny<B, true>), dim3(bgrid), dim3(256), rp, cl, n, (int32_t)nnz,        \
+                  (uint32_t)width, magic, (uint32_t)band, wshift, nnz_threshold, (int32_t *)degree_out, keys, spread, \
+                  units, mrows, lc, mid_list, &all->mid_count);                                                      \
+    else                                                                                                             \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_tiny<B, false>), dim3(bgrid), dim3(256), rp, cl, n, (int32_t)nnz,       \
+                  (uint32_t)width, magic, (uint32_t)band, 0, nnz_threshold, (int32_t *)degree_out, keys, spread, units, \
+                  mrows, lc, mid_list, &all->mid_count);                                                             \
+  } while (0)
+          if (bits <= 32) GRAY_TINY(uint32_t);
+          else GRAY_TINY(unsigned long long);
+#undef GRAY_TINY
+#define GRAY_LISTED(B, LV)                                                                                            \
+  do {                                                                                                               \
+    if (wshift >= 0)                                                                                                 \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_listed<B, LV, true>), dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl, \
+                  (const int32_t *)mid_list, (const unsigned *)&all->mid_count, (int32_t)nnz, (uint32_t)width, magic, \
+                  (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, spread);                 \
+    else                                                                                                             \
+      SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_listed<B, LV, false>), dim3((unsigned)h->num_cus * 8), dim3(256), rp,   \
+                  cl, (const int32_t *)mid_list, (const unsigned *)&all->mid_count, (int32_t)nnz, (uint32_t)width,   \
+                  magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, spread);               \
+  } while (0)
+          if (bits <= 32) {
+            if (lv <= 1) GRAY_LISTED(uint32_t, 1);
+            else if (lv <= 3) GRAY_LISTED(uint32_t, 3);
+            else GRAY_LISTED(uint32_t, 5);
+          } else {
+            if (lv <= 1) GRAY_LISTED(unsigned long long, 1);
+            else GRAY_LISTED(unsigned long long, 2);
+          }
+#undef GRAY_LISTED
+        } else {
           GrayCounts *cnt = spread;  // (what the launch macro passes as the counters)
           GRAY_ROWS_BY_LEVELS(k_gray_rows_balanced, bgrid, units, mrows, lc);
         }
