@@ -34,6 +34,7 @@
 #include <utility>
 #include <algorithm>
 #include <vector>
+#include <functional>
 
 namespace {
 
@@ -83,6 +84,7 @@ struct RcmDev {
   unsigned root_pending;        //   unless a grid barrier gave up on the way: k_gb_reset drops it and the old root stands
   unsigned tie_done;            // the last level held one candidate: the cone / descend kernels have nothing to do
   unsigned gb_spins;            // how many polls a barrier waits (k_ubfs_start sets it; SBX_DEBUG_GB_SPINS for tests)
+  unsigned start_done;          // workgroups of a sweep's start kernel that have cleared their share (start_clear_elect)
   // k_ubfs_small_run: its grid barrier (arrivals, exits), the state it hands back and the frontier's degree sum
   unsigned ur_bar, ur_exit;
   unsigned ur_off, ur_size, ur_level, ur_total, ur_status;
@@ -102,8 +104,11 @@ struct RcmDev {
 constexpr int DEG_UNITS = 4096;
 __device__ __forceinline__ int64_t deg_unit_len(int64_t n) { return ((n + DEG_UNITS - 1) / DEG_UNITS + 63) / 64 * 64; }
 
+// (The call's three n-sized fills ride along — component sizes 0, distances and parent positions UNSEEN: as
+// hipMemsetAsync calls they cost the host ~25 us of enqueueing at the head of the call, with the GPU idle.)
 __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int64_t n, unsigned *__restrict__ ucnt,
-                                                   RcmDev *__restrict__ dv) {
+                                                   I *__restrict__ csize, unsigned *__restrict__ dist,
+                                                   unsigned *__restrict__ ppos) {
   const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
   const int64_t len = deg_unit_len(n), v0 = (int64_t)unit * len;
   unsigned mx = 0, fv = UNSEEN, cnt = 0;
@@ -114,7 +119,11 @@ __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int
       fv = (unsigned)v < fv ? (unsigned)v : fv;
       cnt++;
     }
+    csize[v] = 0;
+    dist[v] = UNSEEN;
+    ppos[v] = UNSEEN;
   }
+  if (unit == 0 && lane == 0) csize[n] = 0;
   cnt = sbx_wave_sum(cnt);
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
@@ -125,6 +134,7 @@ __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int
 
 __global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict__ ucnt, RcmDev *__restrict__ dv) {
   __shared__ unsigned s_mx[16], s_fv[16], s_cnt[16];
+  for (unsigned i = threadIdx.x; i < sizeof(RcmDev) / sizeof(unsigned); i += 1024) ((unsigned *)dv)[i] = 0;  // the call's state
   unsigned mx = 0, fv = UNSEEN, cnt = 0;
   for (int u = threadIdx.x; u < DEG_UNITS; u += 1024) {
     cnt += ucnt[u];
@@ -512,13 +522,43 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
 //          level being built (UNSEEN = untouched).  A relaxed agent-scope load shows
 //          whether this edge can still lower it; only then the atomicMin is issued.
 //          The winner of the UNSEEN -> p transition appends the vertex to the frontier.
-__global__ void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                            unsigned *__restrict__ lpos, unsigned *__restrict__ ppos, I *__restrict__ q,
-                            RcmDev *__restrict__ dv, I fixed_root) {
+// The start kernels of a sweep clear the sweep's bitmaps themselves (hipMemsetAsync costs the host ~6 us apiece to
+// enqueue, and a sweep is latency-bound): every workgroup clears its share, and the LAST one to finish — a counter in
+// RcmDev elects it — does the single-threaded part on cleared memory.  Returns true for that workgroup's thread 0.
+constexpr unsigned RCM_START_GRID = 256;
+struct StartClear {
+  unsigned *a;  // up to three word ranges
+  unsigned long long na;
+  unsigned *b;
+  unsigned long long nb;
+  unsigned *c;
+  unsigned long long nc;
+};
+__device__ __forceinline__ bool start_clear_elect(const StartClear &sc, RcmDev *__restrict__ dv) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = t; i < sc.na; i += stride) sc.a[i] = 0;
+  for (unsigned long long i = t; i < sc.nb; i += stride) sc.b[i] = 0;
+  for (unsigned long long i = t; i < sc.nc; i += stride) sc.c[i] = 0;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x != 0) return false;
+  const unsigned done = atomicAdd(&dv->start_done, 1u);
+  if (done != gridDim.x - 1) return false;
+  __threadfence();
+  dv->start_done = 0;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits,
+                                                   unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
+                                                   unsigned *__restrict__ ppos, I *__restrict__ q,
+                                                   RcmDev *__restrict__ dv, I fixed_root, StartClear sc) {
+  if (!start_clear_elect(sc, dv)) return;
   const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
   dv->root_pending = 0;
   dv->root = (unsigned)r;
-  vbits[r >> 5] = 1u << (r & 31);  // both bitmaps were cleared by the host for this sweep
+  vbits[r >> 5] = 1u << (r & 31);  // both bitmaps were cleared above
   fbits[r >> 5] = 1u << (r & 31);
   lpos[r] = 0;
   ppos[r] = 0;  // every vertex of the sweep has a parent position: "ppos set" == "visited" (k_visited_from_ppos)
@@ -1754,7 +1794,14 @@ struct BfsBuffers {
   RcmDev *dv;
   int64_t n;
   unsigned max_deg;  // largest degree of the graph: no hub kernel launches when nothing exceeds RCM_LIGHT
+  // work the host still has to enqueue elsewhere (the degree ranks on their side stream): run once, right after a sweep's
+  // first launch and before the host waits for it, so that its enqueue time hides behind the kernel (bfs_first_launch)
+  std::function<int()> *after_first_launch;
 };
+
+static int bfs_first_launch(const BfsBuffers &b) {  // (the hook ignores every call after its first)
+  return b.after_first_launch ? (*b.after_first_launch)() : SBX_OK;
+}
 
 struct BfsResult {
   unsigned count;        // vertices reached
@@ -1771,8 +1818,9 @@ template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   // vbits and fbits are adjacent pieces of one allocation (sbx_rcm_reorder): one fill clears both
-  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q, b.dv, fixed_root);
+  const StartClear sc = {b.vbits, (unsigned long long)((b.fbits - b.vbits) + bm_bytes / sizeof(unsigned)), nullptr, 0, nullptr, 0};
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(RCM_START_GRID), dim3(256), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q,
+              b.dv, fixed_root, sc);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   // the hub kernel runs as exactly one resident wave of workgroups: a partial second wave (x8 on a kernel that
@@ -1795,6 +1843,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, (k_bfs_small_levels<CM>), dim3(1), dim3(1024), b.rp, b.col, b.q, b.vbits, b.fbits,
                   b.lpos, b.ppos, b.nf_list, b.drank, b.dorder, off, fsize, level, total, b.dv);
       SBX_LAUNCH_CHECK(h);
+      SBX_TRY(bfs_first_launch(b));
       SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
       remaining -= (int64_t)hd.sl_edges;
       if (remaining < 0) remaining = 0;
@@ -1838,6 +1887,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, none);
     }
     SBX_LAUNCH_CHECK(h);
+    SBX_TRY(bfs_first_launch(b));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     }
     frontier_unmarked = false;
@@ -1958,13 +2008,15 @@ static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search
   return on;
 }
 
-__global__ void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits, unsigned *__restrict__ fbits,
-                             unsigned *__restrict__ dist, I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
-                             unsigned gb_spins) {
+__global__ __launch_bounds__(256) void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits,
+                                                    unsigned *__restrict__ fbits, unsigned *__restrict__ dist,
+                                                    I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
+                                                    unsigned gb_spins, StartClear sc) {
+  if (!start_clear_elect(sc, dv)) return;
   const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
   dv->root_pending = 0;
   dv->root = (unsigned)r;
-  vbits[r >> 5] = 1u << (r & 31);  // the bitmaps were cleared by the host for this sweep
+  vbits[r >> 5] = 1u << (r & 31);  // the bitmaps were cleared above
   fbits[r >> 5] = 1u << (r & 31);
   dist[r] = 0;
   q[0] = r;
@@ -2605,19 +2657,22 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
 
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
-static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, I fixed_root,
-                    I comp_label, BfsResult *out, bool *too_deep) {
+static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, unsigned *cone,
+                    I fixed_root, I comp_label, BfsResult *out, bool *too_deep) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const int64_t words = (b.n + 63) / 64;
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
   *too_deep = false;
-  SBX_HIP(h, hipMemsetAsync(b.vbits, 0, (size_t)((char *)b.fbits - (char *)b.vbits) + bm_bytes, h->stream));
-  if (!*b.claim_clean) SBX_HIP(h, hipMemsetAsync(claim8, 0, (size_t)b.n, h->stream));
+  // the start kernel clears the sweep's bitmaps, the tie-break's cone bitmap (ubfs_pick_root) and — after a sweep that
+  // did not run to its end — the claim bytes
+  const StartClear sc = {b.vbits, (unsigned long long)((b.fbits - b.vbits) + bm_bytes / sizeof(unsigned)),
+                         cone, (unsigned long long)(bm_bytes / sizeof(unsigned)),
+                         (unsigned *)claim8, *b.claim_clean ? 0ull : (unsigned long long)((b.n + 3) / 4)};
   *b.claim_clean = false;  // (until this sweep has run to its end: every level's collection pass clears what it read)
   unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
   static const unsigned gb_spins = getenv("SBX_DEBUG_GB_SPINS") ? (unsigned)atoll(getenv("SBX_DEBUG_GB_SPINS")) : GB_SPINS;
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(1), dim3(1), b.rp, b.vbits, b.fbits, dist, b.q, b.dv, fixed_root,
-              gb_spins);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(RCM_START_GRID), dim3(256), b.rp, b.vbits, b.fbits, dist, b.q, b.dv,
+              fixed_root, gb_spins, sc);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
   const unsigned max_grid = (unsigned)h->num_cus * 8;
   static int heavy_per_cu = 0;
@@ -2641,6 +2696,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
                   (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels());
       SBX_LAUNCH_CHECK(h);
+      SBX_TRY(bfs_first_launch(b));
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
       if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
@@ -2719,7 +2775,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const I *last = b.q + r.last_offset;
   I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level after level, one growing list
-  SBX_HIP(h, hipMemsetAsync(cone, 0, bm_bytes, h->stream));
+  // (the cone bitmap was cleared by the sweep's start kernel)
   if (r.last_size <= UB_TIES_SMALL) {
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_small, dim3(1), dim3(1024), b.rp, last, r.last_size, cone, list, b.dv);
   } else {
@@ -2849,17 +2905,14 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
   SBX_TRY(sbx_salloc(h, (size_t)n, &kb));
-  SBX_HIP(h, hipMemsetAsync(dv, 0, sizeof(RcmDev), h->stream));
-  SBX_HIP(h, hipMemsetAsync(csize, 0, (size_t)(n + 1) * sizeof(I), h->stream));
-  SBX_HIP(h, hipMemsetAsync(dist, 0xFF, (size_t)n * sizeof(unsigned), h->stream));
-  SBX_HIP(h, hipMemsetAsync(ppos, 0xFF, (size_t)n * sizeof(unsigned), h->stream));
+  // (dv is cleared by k_deg_reduce; csize, dist and ppos get their initial values from k_deg_count)
 
   const unsigned gn = sbx_grid_for(n, 256, 8192);
   const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
   // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
   unsigned *ucnt = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS * 3, &ucnt));  // per unit: non-empty rows, largest degree, first non-empty vertex
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, dv);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, csize, dist, ppos);
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_reduce, dim3(1), dim3(1024), (const unsigned *)ucnt, dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd0;
@@ -2867,15 +2920,21 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const int64_t n_ranked = (int64_t)hd0.n_nonempty;  // vertices that get a degree rank
   // Only the Cuthill-McKee sweep reads the degree ranks: they are built on a side stream while the plain sweeps —
   // launch- and latency-bound — run on the caller's stream, and joined before the first Cuthill-McKee sweep.
-  const uint32_t *dorder;
+  const uint32_t *dorder = nullptr;
   hipStream_t main_stream = h->stream;
   const bool side = !h->prof_on && rcm_overlap();
-  {
+  BfsBuffers b;
+  if (side) {  // (recorded here: the side stream waits for the counts above, not for the sweep enqueued before its work)
+    SBX_TRY(sbx_aux_streams(h));
+    SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
+  }
+  bool ranks_enqueued = false;
+  std::function<int()> enqueue_ranks = [&]() -> int {
+    if (ranks_enqueued) return SBX_OK;
+    ranks_enqueued = true;
     if (side) {
       void *slot = nullptr;
       SBX_TRY(sbx_arena_alloc(h, SBX_RS_SLOT_BYTES, &slot));
-      SBX_TRY(sbx_aux_streams(h));
-      SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
       SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[0], h->aux_event[0], 0));
       h->aux_dirty = true;
       h->stream = h->aux_stream[0];
@@ -2893,6 +2952,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     int rc = hipGetLastError() == hipSuccess ? SBX_OK : SBX_ERR_HIP;
     if (rc == SBX_OK) rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n_ranked, passes, np, &in_b);
     dorder = in_b ? did_b : did_a;
+    b.dorder = dorder;
     if (rc == SBX_OK && n_ranked > 0) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(sbx_grid_for(n_ranked, 256, 8192)), dim3(256), dorder,
                   drank, n_ranked);
@@ -2901,10 +2961,14 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
     h->stream = main_stream;
     h->rs_override = nullptr;
-    SBX_TRY(rc);
-  }
+    return rc;
+  };
+  // with a side stream the first sweep's first kernel is enqueued first (the host's ~15 enqueues for the ranks then
+  // run while that kernel does); without one the ranks simply come first
+  if (!side) SBX_TRY(enqueue_ranks());
   bool ranks_joined = !side;
   auto join_ranks = [&]() -> int {
+    if (!ranks_enqueued) SBX_TRY(enqueue_ranks());
     if (!ranks_joined) {
       SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[1], 0));
       ranks_joined = true;
@@ -2912,9 +2976,9 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     }
     return SBX_OK;
   };
-  BfsBuffers b;
   bool claim_clean = false;
   b.claim_clean = &claim_clean;
+  b.after_first_launch = &enqueue_ranks;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
@@ -2930,7 +2994,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const I v0 = hd0.first_vertex == UNSEEN ? (I)-1 : (I)hd0.first_vertex;
   BfsResult r0;
   r0.count = 0;
-  SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));
+  if (v0 < 0) SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));  // (else: a copy of the first sweep's visited bitmap)
   // sweeps of the pseudo-peripheral search run unordered (level sets only, run_ubfs) unless the component turns out
   // deep and narrow
   unsigned char *claim8 = nullptr;
@@ -2946,7 +3010,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   if (v0 >= 0) {
     bool deep = true;
     if (unordered_ok) {
-      SBX_TRY(run_ubfs(h, b, claim8, nbits, v0, (I)-1, &r0, &deep));
+      SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, v0, (I)-1, &r0, &deep));
       r0_unordered = !deep;
     }
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
@@ -3091,7 +3155,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
             fixed = -1;  // k_bfs_start left the root on the device
           }
           if (!deep) {
-            SBX_TRY(run_ubfs(h, b, claim8, nbits, fixed, roots[c], &r, &deep));
+            SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, roots[c], &r, &deep));
             unordered = !deep;
           }
           if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
