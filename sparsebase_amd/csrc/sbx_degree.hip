@@ -4,98 +4,297 @@
 // (degree ascending, id descending); "descending" reverses the whole sequence.
 //
 // Degrees are small numbers with a thin tail (a power-law graph: half the rows empty, 98 % below 255 entries), so the
-// rows are presented in descending id order and sorted by ONE stable 8-bit radix pass on min(degree, 255): that pass
-// already is the final order of every row below 255 entries, and its scatter writes the answer itself
-// (inv[id] = position, sbx_radix_sort_emit) instead of a sorted array.  The rows of the last bucket — in id order
-// after the stable pass — are then sorted among themselves by their full degree (a few ten thousand rows: a small
-// radix sort) and get their positions from a second scatter.  One read-back (rows in the last bucket, largest degree)
-// sits behind the big pass, where the host would wait anyway.  8n + 4 algorithmic bytes; n = 4.2 M: 0.157 ms.  Templated on
-// the index type: 64-bit row_ptr arrays are read as they are and the inverse permutation is written in 64 bits.
+// rows are taken in descending id order and placed by ONE stable counting pass on min(degree, 255) — that already is
+// the final position of every row below 255 entries.  The pass is three kernels that never materialise a key: every
+// workgroup owns a tile of 4096 consecutive rows and counts their digits (k_degree_count), one workgroup per digit
+// scans the tiles' counts (k_degree_scan), and the tiles walk their rows again, rank each among the wave's equal
+// digits with ballots and write inv[id] = position — a coalesced store, the rows come in id order (k_degree_place).
+// Two reads of row_ptr and one write of the result: 12n bytes of traffic, 16 + 5 + 17 us for 4.2 M rows (as 64-bit
+// keys through the generic radix sort — keys written, histogram, one digit pass — the same pass took 95).  The rows
+// of the last bucket leave k_degree_place as (degree, id) pairs in id order; they are sorted among themselves by
+// their full degree with the same three kernels per 9-bit digit, the last placement writing inv[id] (76 K rows, two
+// digits: 6 launches of 3 - 7 us; the generic sort's four launches took 46).  One read-back (rows in the last bucket,
+// largest degree) sits behind the big pass.  8n + 4 algorithmic bytes; n = 4.2 M: 0.075 ms.  Templated on the index
+// type: 64-bit row_ptr arrays are read as they are and the inverse permutation is written in 64 bits.
 #include "sbx_device.h"
 #include "sbx_internal.h"
+#include <utility>
 
 namespace {
 
-constexpr unsigned DG_TOP = 255;  // digit of every row with at least this many entries
+constexpr unsigned DG_TOP = 255;   // digit of every row with at least this many entries
+constexpr int DG_BINS = 256;
+constexpr int DG_WAVE_ROWS = 1024;  // rows per wave (16 rounds of 64), the unit of the counting pass
+constexpr int DG_ROUNDS = DG_WAVE_ROWS / 64;
 
 struct DegState {
   unsigned n_top;    // rows with degree >= DG_TOP
   unsigned max_deg;
 };
 
-// key[j] = min(degree, DG_TOP) << 32 | id for id = n - 1 - j (descending id order).  Four consecutive keys per thread:
-// the five row_ptr words behind them in one 16-byte load (4-byte aligned only: gfx950 loads unaligned vectors) and a
-// 4-byte one, the keys out in two 16-byte stores (one key per thread and iteration, two dependent 4-byte loads each:
-// 36 us for 4.2 M rows; this form 15).
-template <typename I>
-struct __attribute__((packed, aligned(4))) DgQuad {
-  I a, b, c, d;
-};
-template <typename I>
-__global__ __launch_bounds__(256) void k_degree_keys(const I *__restrict__ rp, uint64_t *__restrict__ key, int64_t n,
-                                                     DegState *__restrict__ st) {
-  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // keys 4 q .. 4 q + 3
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned mx = 0, top = 0;
-  for (; 4 * q < n; q += stride) {
-    const int64_t j0 = 4 * q, u0 = n - 1 - j0;  // ids u0, u0 - 1, u0 - 2, u0 - 3
-    unsigned d[4];
-    const int cnt = n - j0 < 4 ? (int)(n - j0) : 4;
-    if (cnt == 4) {
-      const DgQuad<I> w = *(const DgQuad<I> *)(rp + u0 - 3);  // rp[u0 - 3 .. u0]
-      const I hi = rp[u0 + 1];
-      d[0] = (unsigned)(hi - w.d), d[1] = (unsigned)(w.d - w.c), d[2] = (unsigned)(w.c - w.b), d[3] = (unsigned)(w.b - w.a);
-    } else {
+// the lanes of the wave that hold the same 8-bit digit as this one (valid lanes only)
+__device__ __forceinline__ unsigned long long dg_peers(unsigned d, bool valid) {
+  unsigned long long peers = __ballot(valid);
 #pragma unroll
-      for (int k = 0; k < 4; k++) d[k] = k < cnt ? (unsigned)(rp[u0 - k + 1] - rp[u0 - k]) : 0u;
-    }
-    uint64_t kk[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      kk[k] = ((uint64_t)(d[k] < DG_TOP ? d[k] : DG_TOP) << 32) | (uint64_t)(uint32_t)(u0 - k);
-      if (k < cnt) {
-        mx = d[k] > mx ? d[k] : mx;
-        top += d[k] >= DG_TOP;
-      }
-    }
-    if (cnt == 4) {  // (key is 256-byte aligned scratch: 32-byte aligned stores)
-      *(ulonglong2 *)(key + j0) = make_ulonglong2(kk[0], kk[1]);
-      *(ulonglong2 *)(key + j0 + 2) = make_ulonglong2(kk[2], kk[3]);
-    } else {
-      for (int k = 0; k < cnt; k++) key[j0 + k] = kk[k];
-    }
+  for (int b = 0; b < 8; b++) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
   }
-  __shared__ unsigned s_mx[4], s_top[4];  // one atomic per workgroup: the result words are hot
-  mx = sbx_wave_max(mx);
-  top = sbx_wave_sum(top);
-  if (sbx_lane() == 0) s_mx[sbx_wave_in_block()] = mx, s_top[sbx_wave_in_block()] = top;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 4; i++) mx = s_mx[i] > mx ? s_mx[i] : mx, top += s_top[i];
-    if (mx >= DG_TOP) atomicMax(&st->max_deg, mx);
-    if (top) atomicAdd(&st->n_top, top);
+  return peers;
+}
+
+// Workgroup t of the launch owns the tile of rows j = t * 4096 .. + 4095 of the descending-id order (id = n - 1 - j), a
+// wave 1024 consecutive ones (16 rounds of 64, all their row_ptr loads issued before the first is used): the counts of
+// the tile's digits go to cnt[digit * n_tiles + t], its largest degree to tmax[t].
+template <typename I>
+__device__ __forceinline__ void dg_load_degrees(const I *__restrict__ rp, int64_t n, int64_t j0, unsigned (&deg)[DG_ROUNDS]) {
+#pragma unroll
+  for (int r = 0; r < DG_ROUNDS; r++) {
+    const int64_t j = j0 + (int64_t)r * 64;
+    const int64_t id = j < n ? n - 1 - j : 0;
+    deg[r] = (unsigned)(rp[id + 1] - rp[id]);
   }
 }
 
-// the last bucket: (degree, id) of its rows, in the order the stable pass left them (descending id)
 template <typename I>
-__global__ __launch_bounds__(256) void k_degree_tail_keys(const I *__restrict__ rp, const uint32_t *__restrict__ ids,
-                                                          int64_t count, uint32_t *__restrict__ key,
-                                                          uint32_t *__restrict__ id) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; t < count; t += stride) {
-    const uint32_t u = ids[t];
-    key[t] = (uint32_t)(rp[u + 1] - rp[u]);
-    id[t] = u;
+__global__ __launch_bounds__(256) void k_degree_count(const I *__restrict__ rp, int64_t n, int64_t n_tiles,
+                                                      unsigned *__restrict__ cnt, unsigned *__restrict__ tmax) {
+  __shared__ unsigned s_hist[DG_BINS];
+  __shared__ unsigned s_mx[4];
+  const int lane = sbx_lane(), wv = sbx_wave_in_block();
+  s_hist[threadIdx.x] = 0;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wv) * DG_WAVE_ROWS + lane;
+  unsigned deg[DG_ROUNDS];
+  dg_load_degrees(rp, n, j0, deg);
+  __syncthreads();
+  unsigned mx = 0;
+#pragma unroll
+  for (int r = 0; r < DG_ROUNDS; r++) {
+    const bool valid = j0 + (int64_t)r * 64 < n;
+    const unsigned d = deg[r] < DG_TOP ? deg[r] : DG_TOP;
+    const unsigned long long peers = dg_peers(d, valid);
+    if (valid) {
+      mx = deg[r] > mx ? deg[r] : mx;
+      if ((peers & sbx_lanemask_lt()) == 0) atomicAdd(&s_hist[d], (unsigned)__popcll(peers));  // the digit's first lane
+    }
+  }
+  mx = sbx_wave_max(mx);
+  if (lane == 0) s_mx[wv] = mx;
+  __syncthreads();
+  cnt[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; i++) mx = s_mx[i] > mx ? s_mx[i] : mx;
+    tmax[blockIdx.x] = mx;
   }
 }
+
+// workgroup d: cnt[d * n_waves + w] -> the number of rows with digit d in the units (tiles of the first pass, waves of
+// the tail's passes) before w; total[d]; the first pass (wmax != nullptr) also leaves the state: rows in the last
+// bucket, largest degree
+__global__ __launch_bounds__(256) void k_degree_scan(unsigned *__restrict__ cnt, const unsigned *__restrict__ wmax,
+                                                     int64_t n_waves, unsigned *__restrict__ total,
+                                                     DegState *__restrict__ st) {
+  __shared__ unsigned s_scan[8];
+  unsigned *row = cnt + (int64_t)blockIdx.x * n_waves;
+  const bool vec = (n_waves & 3) == 0;  // rows of counts start 16-byte aligned: four counts per access
+  int64_t per = (n_waves + 255) / 256;
+  if (vec) per = (per + 3) & ~(int64_t)3;
+  const int64_t lo = (int64_t)threadIdx.x * per < n_waves ? (int64_t)threadIdx.x * per : n_waves;
+  const int64_t hi = lo + per < n_waves ? lo + per : n_waves;
+  unsigned sum = 0, tot;
+  if (vec) {
+    for (int64_t i = lo; i < hi; i += 4) {
+      const uint4 c = *(const uint4 *)(row + i);
+      sum += c.x + c.y + c.z + c.w;
+    }
+    unsigned run = sbx_block_exclusive_sum<unsigned, 256>(sum, s_scan, &tot);
+    for (int64_t i = lo; i < hi; i += 4) {
+      const uint4 c = *(const uint4 *)(row + i);
+      *(uint4 *)(row + i) = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
+      run += c.x + c.y + c.z + c.w;
+    }
+  } else {
+    for (int64_t i = lo; i < hi; i++) sum += row[i];
+    unsigned run = sbx_block_exclusive_sum<unsigned, 256>(sum, s_scan, &tot);
+    for (int64_t i = lo; i < hi; i++) {
+      const unsigned c = row[i];
+      row[i] = run;
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) {
+    total[blockIdx.x] = tot;
+    if (wmax && blockIdx.x == DG_TOP) st->n_top = tot;
+  }
+  if (wmax && blockIdx.x == 0) {
+    unsigned mx = 0;
+    for (int64_t i = threadIdx.x; i < n_waves; i += 256) mx = wmax[i] > mx ? wmax[i] : mx;
+    mx = sbx_wave_max(mx);
+    __syncthreads();
+    if (sbx_lane() == 0) s_scan[sbx_wave_in_block()] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 1; i < 4; i++) mx = s_scan[i] > mx ? s_scan[i] : mx;
+      st->max_deg = mx;
+    }
+  }
+}
+
+// the rows again: position = rows of smaller digits + rows of this digit in the tiles before + in the tile's waves
+// before + in this wave before it; inv[id] = position (or its mirror); rows of the last bucket also leave (degree, id)
+// at their place in it
 template <typename I>
-__global__ __launch_bounds__(256) void k_degree_tail_emit(const uint32_t *__restrict__ sorted_id, I *__restrict__ inv,
-                                                          int64_t count, int64_t first, int64_t n, int ascending) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; t < count; t += stride) inv[sorted_id[t]] = (I)(ascending ? first + t : n - 1 - (first + t));
+__global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, int64_t n, int64_t n_tiles,
+                                                      const unsigned *__restrict__ off, const unsigned *__restrict__ total,
+                                                      I *__restrict__ inv, uint32_t *__restrict__ tail_key,
+                                                      uint32_t *__restrict__ tail_id, int ascending) {
+  __shared__ unsigned s_scan[8];
+  __shared__ unsigned s_wave[4][DG_BINS];  // rows of digit d in wave w; then the position of the wave's first such row
+  __shared__ unsigned s_top_base;
+  const int lane = sbx_lane(), wv = sbx_wave_in_block();
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wv) * DG_WAVE_ROWS + lane;
+  unsigned deg[DG_ROUNDS];
+  dg_load_degrees(rp, n, j0, deg);
+  const unsigned tile_off = off[(int64_t)threadIdx.x * n_tiles + blockIdx.x];  // thread = digit
+#pragma unroll
+  for (int k = 0; k < 4; k++) s_wave[k][threadIdx.x] = 0;
+  unsigned tot;
+  const unsigned dbase = sbx_block_exclusive_sum<unsigned, 256>(total[threadIdx.x], s_scan, &tot);  // (two barriers)
+  if (threadIdx.x == DG_TOP) s_top_base = dbase;
+  unsigned loc[DG_ROUNDS];  // the row's rank among the wave's rows of its digit
+#pragma unroll
+  for (int r = 0; r < DG_ROUNDS; r++) {
+    const bool valid = j0 + (int64_t)r * 64 < n;
+    const unsigned d = deg[r] < DG_TOP ? deg[r] : DG_TOP;
+    const unsigned long long peers = dg_peers(d, valid);
+    const unsigned rank = (unsigned)__popcll(peers & sbx_lanemask_lt());
+    unsigned first = 0;
+    if (valid && rank == 0) first = atomicAdd(&s_wave[wv][d], (unsigned)__popcll(peers));
+    first = (unsigned)__shfl((int)first, valid ? (int)__builtin_ctzll(peers) : 0, 64);
+    loc[r] = first + rank;
+  }
+  __syncthreads();
+  {
+    unsigned run = dbase + tile_off;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned c = s_wave[k][threadIdx.x];
+      s_wave[k][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const unsigned top_base = s_top_base;
+#pragma unroll
+  for (int r = 0; r < DG_ROUNDS; r++) {
+    const int64_t j = j0 + (int64_t)r * 64;
+    if (j < n) {
+      const int64_t id = n - 1 - j;
+      const unsigned d = deg[r] < DG_TOP ? deg[r] : DG_TOP;
+      const unsigned pos = s_wave[wv][d] + loc[r];
+      inv[id] = (I)(ascending ? (int64_t)pos : n - 1 - (int64_t)pos);
+      if (d == DG_TOP) {
+        tail_key[pos - top_base] = deg[r];
+        tail_id[pos - top_base] = (uint32_t)id;
+      }
+    }
+  }
+}
+
+// ---- the last bucket: a stable LSD counting sort of its (degree, id) pairs by the full degree, the same three kernels
+// per digit with 9-bit digits and 256 rows per wave (a few ten thousand rows: every launch is a couple of microseconds,
+// where a digit pass of the generic sort — a chained scan over its tiles — took 11); the last digit's placement writes
+// inv[id] itself.
+constexpr int DT_BINS = 512;
+constexpr int DT_ROUNDS = 4;
+constexpr int DT_WAVE_ROWS = 64 * DT_ROUNDS;
+
+__device__ __forceinline__ unsigned long long dt_peers(unsigned d, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 9; b++) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__global__ __launch_bounds__(256) void k_degree_tail_count(const uint32_t *__restrict__ key, int64_t top, int64_t n_waves,
+                                                           int shift, unsigned mask, unsigned *__restrict__ cnt) {
+  __shared__ unsigned s_hist[4][DT_BINS];
+  const int lane = sbx_lane(), wv = sbx_wave_in_block();
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  if (w >= n_waves) return;
+#pragma unroll
+  for (int k = 0; k < DT_BINS / 64; k++) s_hist[wv][lane + 64 * k] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  unsigned kk[DT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < DT_ROUNDS; r++) {
+    const int64_t j = w * DT_WAVE_ROWS + r * 64 + lane;
+    kk[r] = key[j < top ? j : top - 1];
+  }
+#pragma unroll
+  for (int r = 0; r < DT_ROUNDS; r++) {
+    const bool valid = w * DT_WAVE_ROWS + r * 64 + lane < top;
+    const unsigned d = (kk[r] >> shift) & mask;
+    const unsigned long long peers = dt_peers(d, valid);
+    if (valid && (peers & sbx_lanemask_lt()) == 0) atomicAdd(&s_hist[wv][d], (unsigned)__popcll(peers));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+  for (int k = 0; k < DT_BINS / 64; k++) cnt[(int64_t)(lane + 64 * k) * n_waves + w] = s_hist[wv][lane + 64 * k];
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_degree_tail_place(const uint32_t *__restrict__ key, const uint32_t *__restrict__ id,
+                                                           int64_t top, int64_t n_waves, const unsigned *__restrict__ off,
+                                                           const unsigned *__restrict__ total, int shift, unsigned mask,
+                                                           uint32_t *__restrict__ key_out, uint32_t *__restrict__ id_out,
+                                                           I *__restrict__ inv, int64_t first, int64_t n, int ascending,
+                                                           int last) {
+  __shared__ unsigned s_scan[8];
+  __shared__ unsigned s_run[4][DT_BINS];
+  const int lane = sbx_lane(), wv = sbx_wave_in_block();
+  const unsigned t0 = total[2 * threadIdx.x], t1 = total[2 * threadIdx.x + 1];  // thread = two digits
+  unsigned tot;
+  const unsigned dbase = sbx_block_exclusive_sum<unsigned, 256>(t0 + t1, s_scan, &tot);
+#pragma unroll
+  for (int k = 0; k < 4; k++) s_run[k][2 * threadIdx.x] = dbase, s_run[k][2 * threadIdx.x + 1] = dbase + t0;
+  __syncthreads();
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  if (w >= n_waves) return;
+#pragma unroll
+  for (int k = 0; k < DT_BINS / 64; k++) s_run[wv][lane + 64 * k] += off[(int64_t)(lane + 64 * k) * n_waves + w];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  unsigned kk[DT_ROUNDS], ii[DT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < DT_ROUNDS; r++) {
+    const int64_t j = w * DT_WAVE_ROWS + r * 64 + lane;
+    kk[r] = key[j < top ? j : top - 1];
+    ii[r] = id[j < top ? j : top - 1];
+  }
+#pragma unroll
+  for (int r = 0; r < DT_ROUNDS; r++) {
+    const bool valid = w * DT_WAVE_ROWS + r * 64 + lane < top;
+    const unsigned d = (kk[r] >> shift) & mask;
+    const unsigned long long peers = dt_peers(d, valid);
+    const unsigned rank = (unsigned)__popcll(peers & sbx_lanemask_lt());
+    unsigned start = 0;
+    if (valid && rank == 0) start = atomicAdd(&s_run[wv][d], (unsigned)__popcll(peers));
+    start = (unsigned)__shfl((int)start, valid ? (int)__builtin_ctzll(peers) : 0, 64);
+    if (valid) {
+      const int64_t pos = (int64_t)(start + rank);
+      if (last) {
+        inv[ii[r]] = (I)(ascending ? first + pos : n - 1 - (first + pos));
+      } else {
+        key_out[pos] = kk[r];
+        id_out[pos] = ii[r];
+      }
+    }
+  }
 }
 
 template <typename I>
@@ -113,49 +312,52 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
     return SBX_OK;
   }
   const I *rp = (const I *)row_ptr;
-  uint64_t *ka, *kb;
-  uint32_t *sorted_id;
+  const int64_t n_tiles = (n + 4 * DG_WAVE_ROWS - 1) / (4 * DG_WAVE_ROWS);
+  unsigned *cnt, *wmax, *total;
+  uint32_t *ta, *ia;
   DegState *st;
-  SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &kb));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &sorted_id));
+  SBX_TRY(sbx_salloc(h, (size_t)n_tiles * DG_BINS, &cnt));
+  SBX_TRY(sbx_salloc(h, (size_t)n_tiles, &wmax));
+  SBX_TRY(sbx_salloc(h, (size_t)DG_BINS, &total));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &ta));  // the last bucket's (degree, id), in id order
+  SBX_TRY(sbx_salloc(h, (size_t)n, &ia));
   SBX_TRY(sbx_salloc(h, 1, &st));
-  SBX_HIP(h, hipMemsetAsync(st, 0, sizeof(DegState), h->stream));
-  // (few workgroups: each ends with two adds on one line of DegState, ~7 ns apiece whoever issues them — with 4096
-  // workgroups those adds, not the 64 MB the kernel moves, were its 52 us)
-  const unsigned grid = sbx_grid_for((n + 3) / 4, 256, 512);
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_keys<I>, dim3(grid), dim3(256), rp, ka, n, st);
+  const unsigned grid = (unsigned)n_tiles;
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_count<I>, dim3(grid), dim3(256), rp, n, n_tiles, cnt, wmax);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_scan, dim3(DG_BINS), dim3(256), cnt, (const unsigned *)wmax, n_tiles, total, st);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_place<I>, dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
+              (const unsigned *)total, (I *)inv_perm_out, ta, ia, ascending);
   SBX_LAUNCH_CHECK(h);
-  // one pass over the digit in bits [32, 40); its scatter leaves the ids in order and inv[id] = position (in the
-  // caller's index width: no 32-bit copy of a 64-bit row_ptr, no widening pass over the result)
-  const sbx_radix_pass pass = {32, 8};
-  sbx_radix_emit em;
-  memset(&em, 0, sizeof(em));
-  em.out = sorted_id;
-  if (sizeof(I) == 4) em.pos_of = (unsigned *)inv_perm_out;
-  else em.pos_of64 = (unsigned long long *)inv_perm_out;
-  em.pos_flip = ascending ? 0u : (uint32_t)n;
-  SBX_TRY(sbx_radix_sort_emit(h, ka, kb, n, &pass, 1, &em));
   DegState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(hs)));
   const int64_t top = hs.n_top;
   if (top < 2) return SBX_OK;
   // the last bucket by full degree (stable: equal degrees keep their descending id order)
-  uint32_t *ta, *tb, *ia, *ib;
-  SBX_TRY(sbx_salloc(h, (size_t)top, &ta));
+  uint32_t *tb, *ib;
+  unsigned *tcnt, *ttotal;
+  const int64_t t_waves = (top + DT_WAVE_ROWS - 1) / DT_WAVE_ROWS;
   SBX_TRY(sbx_salloc(h, (size_t)top, &tb));
-  SBX_TRY(sbx_salloc(h, (size_t)top, &ia));
   SBX_TRY(sbx_salloc(h, (size_t)top, &ib));
-  const unsigned tgrid = sbx_grid_for(top, 256, 2048);
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_keys<I>, dim3(tgrid), dim3(256), rp, (const uint32_t *)(sorted_id + (n - top)),
-              top, ta, ia);
-  SBX_LAUNCH_CHECK(h);
-  sbx_radix_pass passes[16];
-  const int np = sbx_radix_plan(0, sbx_bits_for(hs.max_deg), 0, 0, passes);
-  int in_b = 0;
-  SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, top, passes, np, &in_b));
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<I>, dim3(tgrid), dim3(256), (const uint32_t *)(in_b ? ib : ia),
-              (I *)inv_perm_out, top, n - top, n, ascending);
+  SBX_TRY(sbx_salloc(h, (size_t)t_waves * DT_BINS, &tcnt));
+  SBX_TRY(sbx_salloc(h, (size_t)DT_BINS, &ttotal));
+  const int bits = sbx_bits_for(hs.max_deg) > 0 ? sbx_bits_for(hs.max_deg) : 1;
+  const int np = (bits + 8) / 9;
+  const unsigned tgrid = (unsigned)((t_waves + 3) / 4);
+  uint32_t *kin = ta, *iin = ia, *kout = tb, *iout = ib;
+  for (int p = 0, shift = 0; p < np; p++) {
+    const int width = (bits - shift + (np - p) - 1) / (np - p);  // the remaining bits in equal shares
+    const unsigned mask = (1u << width) - 1u;
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_count, dim3(tgrid), dim3(256), (const uint32_t *)kin, top, t_waves, shift, mask,
+                tcnt);
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_scan, dim3(DT_BINS), dim3(256), tcnt, (const unsigned *)nullptr, t_waves, ttotal,
+                (DegState *)nullptr);
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_place<I>, dim3(tgrid), dim3(256), (const uint32_t *)kin, (const uint32_t *)iin,
+                top, t_waves, (const unsigned *)tcnt, (const unsigned *)ttotal, shift, mask, kout, iout, (I *)inv_perm_out,
+                n - top, n, ascending, p == np - 1 ? 1 : 0);
+    std::swap(kin, kout);
+    std::swap(iin, iout);
+    shift += width;
+  }
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }

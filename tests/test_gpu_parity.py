@@ -1033,6 +1033,48 @@ def test_int64_values_beyond_int32(ops, oracle):
     assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("case", ["mixed", "all_tail_one_degree", "wide_int64", "tail_of_one", "tail_of_two", "small_n"])
+def test_degree_reorder_counting_passes(ops, oracle, case):
+    """DegreeReorder's placement (degree_reorder.cc:22-62) through every branch of the device path: the 255-capped
+    counting pass alone, a last bucket of 1 / 2 / tens of thousands / all rows, 1 - 4 digits of the tail sort, ties in
+    the tail (equal degrees keep descending id order), sizes around the 64 / 256 / 1024-row units of the kernels."""
+    g = np.random.default_rng(11)
+    cases = []
+    if case == "mixed":
+        n = 200_000
+        lens = g.integers(0, 300, n)
+        heavy = g.random(n) < 0.3
+        lens[heavy] = g.integers(255, 5000, int(heavy.sum()))          # a tail of 60 K rows with many ties
+        lens[g.integers(0, n, 5)] = (1 << 20) + g.integers(0, 3, 5)      # 21-bit degrees: three digits
+        cases.append((lens, np.int64))
+        cases.append((np.minimum(lens, 9000), np.int32))
+    elif case == "all_tail_one_degree":
+        cases.append((np.full(70_001, 300), np.int32))
+        cases.append((np.full(1025, 255), np.int32))
+    elif case == "wide_int64":
+        n = 50_000
+        lens = g.integers(0, 1 << 30, n)                                 # 30-bit degrees: four digits, nnz ~ 2^45
+        lens[g.random(n) < 0.5] = 0
+        cases.append((lens, np.int64))
+    elif case == "tail_of_one":
+        lens = g.integers(0, 255, 3000)
+        lens[1234] = 255
+        cases.append((lens, np.int32))
+    elif case == "tail_of_two":
+        lens = g.integers(0, 255, 3000)
+        lens[[17, 2999]] = (400, 400)
+        cases.append((lens, np.int32))
+    else:
+        for n in (2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097):
+            lens = g.integers(0, 600, n)
+            cases.append((lens, np.int32))
+    for lens, dt in cases:
+        rp = np.concatenate([[0], np.cumsum(lens.astype(np.int64))]).astype(dt)
+        for asc in (True, False):
+            got = host(ops.degree_reorder(dev(rp), asc))
+            assert np.array_equal(got, oracle.degree_reorder(rp, asc)), (case, len(lens), asc)
+
+
 # ----------------------------------------------------------------------------- degenerate / ragged shapes
 def _check_all_ops(ops, oracle, rp, col, m, seed=0):
     n, nnz = len(rp) - 1, len(col)
