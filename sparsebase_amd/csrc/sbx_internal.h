@@ -235,8 +235,6 @@ struct sbx_radix_emit {
   unsigned *bits_a, *bits_b;
   unsigned *pos_of;
   uint32_t low_mask;  // low32(key) is ANDed with this first (0: all 32 bits) — keys whose fields are packed tightly
-  uint32_t pos_flip;  // non-zero: pos_of[value] = pos_flip - 1 - p (positions counted from the other end)
-  unsigned long long *pos_of64;  // the same table in 64-bit words (an int64 inverse permutation), optional
 };
 int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t count, const sbx_radix_pass *passes,
                         int num_passes, const sbx_radix_emit *emit);

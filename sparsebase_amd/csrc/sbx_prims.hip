@@ -511,8 +511,7 @@ __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__res
           em.out[o] = ev;
           if (em.bits_a) atomicOr(&em.bits_a[ev >> 5], 1u << (ev & 31));
           if (em.bits_b) atomicOr(&em.bits_b[ev >> 5], 1u << (ev & 31));
-          if (em.pos_of) em.pos_of[ev] = em.pos_flip ? em.pos_flip - 1u - o : o;
-          if (em.pos_of64) em.pos_of64[ev] = em.pos_flip ? em.pos_flip - 1u - o : o;
+          if (em.pos_of) em.pos_of[ev] = o;
         } else {
           if constexpr ((IOM & 4) != 0) {
             ((uint32_t *)keys_out)[o] = (uint32_t)kk;

@@ -1892,6 +1892,11 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     }
     frontier_unmarked = false;
     const unsigned nf = hd.nf;
+    static const bool trace_levels = getenv("SBX_DEBUG_RCM_LEVELS") && atoi(getenv("SBX_DEBUG_RCM_LEVELS")) != 0;
+    if (trace_levels)
+      fprintf(stderr, "[rcm %s] level %u: frontier %u vertices / %lld edges, unvisited edges %lld -> %u new vertices / %llu edges\n",
+              CM ? "cm" : "plain", level, fsize, (long long)frontier_edges, (long long)remaining, nf,
+              (unsigned long long)hd.fedges);
     if (nf == 0) break;
     if (frontier_edges < 0) remaining -= (int64_t)0;  // level 0's degree is part of hd.fedges history below
     frontier_edges = (int64_t)hd.fedges;              // degree sum of the level just discovered
