@@ -18,7 +18,7 @@
 // type: 64-bit row_ptr arrays are read as they are and the inverse permutation is written in 64 bits.
 #include "sbx_device.h"
 #include "sbx_internal.h"
-#include <utility>
+#include "sbx_countsort.h"
 
 namespace {
 
@@ -202,99 +202,25 @@ __global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, 
   }
 }
 
-// ---- the last bucket: a stable LSD counting sort of its (degree, id) pairs by the full degree, the same three kernels
-// per digit with 9-bit digits and 256 rows per wave (a few ten thousand rows: every launch is a couple of microseconds,
-// where a digit pass of the generic sort — a chained scan over its tiles — took 11); the last digit's placement writes
-// inv[id] itself.
-constexpr int DT_BINS = 512;
-constexpr int DT_ROUNDS = 4;
-constexpr int DT_WAVE_ROWS = 64 * DT_ROUNDS;
-
-__device__ __forceinline__ unsigned long long dt_peers(unsigned d, bool valid) {
-  unsigned long long peers = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < 9; b++) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long m = __ballot(bit);
-    peers &= bit ? m : ~m;
+// ---- the last bucket: a stable counting sort of its (degree, id) pairs by the full degree (sbx_countsort.h: three
+// small launches per 9-bit digit; a few ten thousand rows, where a digit pass of the generic sort — a chained scan
+// over its tiles — took 11 us); the last digit's placement writes inv[id] itself.
+template <typename I>
+struct DegreeTailEmit {
+  I *inv;
+  int64_t first, n;  // the bucket's first position; the dimension
+  int ascending;
+  __device__ void operator()(unsigned pos, uint32_t, uint32_t id) const {
+    inv[id] = (I)(ascending ? first + (int64_t)pos : n - 1 - (first + (int64_t)pos));
   }
-  return peers;
-}
-
-__global__ __launch_bounds__(256) void k_degree_tail_count(const uint32_t *__restrict__ key, int64_t top, int64_t n_waves,
-                                                           int shift, unsigned mask, unsigned *__restrict__ cnt) {
-  __shared__ unsigned s_hist[4][DT_BINS];
-  const int lane = sbx_lane(), wv = sbx_wave_in_block();
-  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
-  if (w >= n_waves) return;
-#pragma unroll
-  for (int k = 0; k < DT_BINS / 64; k++) s_hist[wv][lane + 64 * k] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  unsigned kk[DT_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < DT_ROUNDS; r++) {
-    const int64_t j = w * DT_WAVE_ROWS + r * 64 + lane;
-    kk[r] = key[j < top ? j : top - 1];
-  }
-#pragma unroll
-  for (int r = 0; r < DT_ROUNDS; r++) {
-    const bool valid = w * DT_WAVE_ROWS + r * 64 + lane < top;
-    const unsigned d = (kk[r] >> shift) & mask;
-    const unsigned long long peers = dt_peers(d, valid);
-    if (valid && (peers & sbx_lanemask_lt()) == 0) atomicAdd(&s_hist[wv][d], (unsigned)__popcll(peers));
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-  for (int k = 0; k < DT_BINS / 64; k++) cnt[(int64_t)(lane + 64 * k) * n_waves + w] = s_hist[wv][lane + 64 * k];
-}
+};
 
 template <typename I>
-__global__ __launch_bounds__(256) void k_degree_tail_place(const uint32_t *__restrict__ key, const uint32_t *__restrict__ id,
-                                                           int64_t top, int64_t n_waves, const unsigned *__restrict__ off,
-                                                           const unsigned *__restrict__ total, int shift, unsigned mask,
-                                                           uint32_t *__restrict__ key_out, uint32_t *__restrict__ id_out,
-                                                           I *__restrict__ inv, int64_t first, int64_t n, int ascending,
-                                                           int last) {
-  __shared__ unsigned s_scan[8];
-  __shared__ unsigned s_run[4][DT_BINS];
-  const int lane = sbx_lane(), wv = sbx_wave_in_block();
-  const unsigned t0 = total[2 * threadIdx.x], t1 = total[2 * threadIdx.x + 1];  // thread = two digits
-  unsigned tot;
-  const unsigned dbase = sbx_block_exclusive_sum<unsigned, 256>(t0 + t1, s_scan, &tot);
-#pragma unroll
-  for (int k = 0; k < 4; k++) s_run[k][2 * threadIdx.x] = dbase, s_run[k][2 * threadIdx.x + 1] = dbase + t0;
-  __syncthreads();
-  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
-  if (w >= n_waves) return;
-#pragma unroll
-  for (int k = 0; k < DT_BINS / 64; k++) s_run[wv][lane + 64 * k] += off[(int64_t)(lane + 64 * k) * n_waves + w];
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  unsigned kk[DT_ROUNDS], ii[DT_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < DT_ROUNDS; r++) {
-    const int64_t j = w * DT_WAVE_ROWS + r * 64 + lane;
-    kk[r] = key[j < top ? j : top - 1];
-    ii[r] = id[j < top ? j : top - 1];
-  }
-#pragma unroll
-  for (int r = 0; r < DT_ROUNDS; r++) {
-    const bool valid = w * DT_WAVE_ROWS + r * 64 + lane < top;
-    const unsigned d = (kk[r] >> shift) & mask;
-    const unsigned long long peers = dt_peers(d, valid);
-    const unsigned rank = (unsigned)__popcll(peers & sbx_lanemask_lt());
-    unsigned start = 0;
-    if (valid && rank == 0) start = atomicAdd(&s_run[wv][d], (unsigned)__popcll(peers));
-    start = (unsigned)__shfl((int)start, valid ? (int)__builtin_ctzll(peers) : 0, 64);
-    if (valid) {
-      const int64_t pos = (int64_t)(start + rank);
-      if (last) {
-        inv[ii[r]] = (I)(ascending ? first + pos : n - 1 - (first + pos));
-      } else {
-        key_out[pos] = kk[r];
-        id_out[pos] = ii[r];
-      }
-    }
-  }
+__global__ __launch_bounds__(256) void k_degree_tail_emit(const uint32_t *__restrict__ sorted_id, I *__restrict__ inv,
+                                                          int64_t count, int64_t first, int64_t n, int ascending) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < count; t += stride) inv[sorted_id[t]] = (I)(ascending ? first + t : n - 1 - (first + t));
 }
 
 template <typename I>
@@ -334,31 +260,20 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   if (top < 2) return SBX_OK;
   // the last bucket by full degree (stable: equal degrees keep their descending id order)
   uint32_t *tb, *ib;
-  unsigned *tcnt, *ttotal;
-  const int64_t t_waves = (top + DT_WAVE_ROWS - 1) / DT_WAVE_ROWS;
   SBX_TRY(sbx_salloc(h, (size_t)top, &tb));
   SBX_TRY(sbx_salloc(h, (size_t)top, &ib));
-  SBX_TRY(sbx_salloc(h, (size_t)t_waves * DT_BINS, &tcnt));
-  SBX_TRY(sbx_salloc(h, (size_t)DT_BINS, &ttotal));
-  const int bits = sbx_bits_for(hs.max_deg) > 0 ? sbx_bits_for(hs.max_deg) : 1;
-  const int np = (bits + 8) / 9;
-  const unsigned tgrid = (unsigned)((t_waves + 3) / 4);
-  uint32_t *kin = ta, *iin = ia, *kout = tb, *iout = ib;
-  for (int p = 0, shift = 0; p < np; p++) {
-    const int width = (bits - shift + (np - p) - 1) / (np - p);  // the remaining bits in equal shares
-    const unsigned mask = (1u << width) - 1u;
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_count, dim3(tgrid), dim3(256), (const uint32_t *)kin, top, t_waves, shift, mask,
-                tcnt);
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_scan, dim3(DT_BINS), dim3(256), tcnt, (const unsigned *)nullptr, t_waves, ttotal,
-                (DegState *)nullptr);
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_place<I>, dim3(tgrid), dim3(256), (const uint32_t *)kin, (const uint32_t *)iin,
-                top, t_waves, (const unsigned *)tcnt, (const unsigned *)ttotal, shift, mask, kout, iout, (I *)inv_perm_out,
-                n - top, n, ascending, p == np - 1 ? 1 : 0);
-    std::swap(kin, kout);
-    std::swap(iin, iout);
-    shift += width;
+  if (top <= ((int64_t)1 << 20)) {
+    const DegreeTailEmit<I> emit = {(I *)inv_perm_out, n - top, n, ascending};
+    SBX_TRY(sbx_cs::sort_emit(h, SBX_K_DEGREE, ta, ia, tb, ib, top, sbx_bits_for(hs.max_deg), emit));
+  } else {  // (millions of rows of 255+ entries: the generic sort's staged stores win; then a scatter)
+    sbx_radix_pass passes[16];
+    const int np = sbx_radix_plan(0, sbx_bits_for(hs.max_deg), 0, 0, passes);
+    int in_b = 0;
+    SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, top, passes, np, &in_b));
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<I>, dim3(sbx_grid_for(top, 256, 2048)), dim3(256),
+                (const uint32_t *)(in_b ? ib : ia), (I *)inv_perm_out, top, n - top, n, ascending);
+    SBX_LAUNCH_CHECK(h);
   }
-  SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 

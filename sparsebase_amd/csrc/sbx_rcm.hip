@@ -30,6 +30,7 @@
 //                   levels, the device radix sort for large ones.
 #include "sbx_device.h"
 #include "sbx_internal.h"
+#include "sbx_countsort.h"
 
 #include <utility>
 #include <algorithm>
@@ -1179,11 +1180,12 @@ __global__ __launch_bounds__(256) void k_fresh_words_ranked(const unsigned *__re
 // One workgroup per RCM_FW_WORDS words.  Its base = totals of the workgroups before it (summed here when there
 // are few of them, taken from their scan otherwise); every wave scans the 64 word counts itself (lane = word) and
 // then writes the keys of its 16 words with lane = vertex: parent positions read and keys written in runs.
-__global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long long *__restrict__ fresh64,
+__global__ __launch_bounds__(256) void k_keys_from_fresh(unsigned long long *__restrict__ fresh64,
                                                          const int *__restrict__ cnt, const int *__restrict__ btot,
                                                          int btot_is_scanned, const unsigned *__restrict__ ppos,
                                                          const uint32_t *__restrict__ dorder,  // ranked form: bit k = rank k
-                                                         uint64_t *__restrict__ key, int64_t words,
+                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ key32,
+                                                         uint32_t *__restrict__ val32, int64_t words,
                                                          RcmDev *__restrict__ dv) {
   constexpr int WPW = RCM_FW_WORDS / 4;
   const int lane = sbx_lane(), wv = threadIdx.x >> 6;
@@ -1199,18 +1201,79 @@ __global__ __launch_bounds__(256) void k_keys_from_fresh(const unsigned long lon
   const int c = wb + lane < words ? cnt[wb + lane] : 0;
   const int inc = sbx_wave_inclusive_sum(c);  // over the workgroup's 64 words
   const int excl = base + inc - c;
-  const unsigned long long mine = (lane >= wv * WPW && lane < (wv + 1) * WPW && wb + lane < words) ? fresh64[wb + lane] : 0ull;
+  const bool own = lane >= wv * WPW && lane < (wv + 1) * WPW && wb + lane < words;
+  const unsigned long long mine = own ? fresh64[wb + lane] : 0ull;
+  if (key32 && mine) fresh64[wb + lane] = 0;  // (the scattered form of the bitmap wants it clear: k_rank_scatter)
+  // (the gathers of the wave's 16 words in three rounds — rank -> vertex, vertex -> parent position, stores — instead
+  // of 16 dependent chains one after the other: 17 -> 6 us on a 28 K-vertex level)
+  uint32_t vtx[WPW], low[WPW];
+  int at[WPW];
+  unsigned long long onmask = 0;  // bit i: this lane holds a vertex of word i
 #pragma unroll
   for (int i = 0; i < WPW; i++) {
     const int src = wv * WPW + i;
     const unsigned long long f = __shfl(mine, src, 64);
     const int o = __shfl(excl, src, 64);
-    if ((f >> lane) & 1ull) {
-      const uint32_t v = (uint32_t)((wb + src) * 64 + lane);  // vertex id, or degree rank in the ranked form
-      key[o + __popcll(f & sbx_lanemask_lt())] = ((uint64_t)ppos[dorder ? dorder[v] : v] << 32) | (uint64_t)v;
+    const bool on = (f >> lane) & 1ull;
+    low[i] = (uint32_t)((wb + src) * 64 + lane);  // vertex id, or degree rank in the ranked form
+    at[i] = o + __popcll(f & sbx_lanemask_lt());
+    if (on) onmask |= 1ull << i;
+    vtx[i] = (on && dorder) ? dorder[low[i]] : low[i];
+  }
+  unsigned pp[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; i++) pp[i] = ((onmask >> i) & 1ull) ? ppos[vtx[i]] : 0u;
+#pragma unroll
+  for (int i = 0; i < WPW; i++) {
+    if ((onmask >> i) & 1ull) {
+      if (key32) {
+        key32[at[i]] = pp[i];
+        val32[at[i]] = low[i];
+      } else {
+        key[at[i]] = ((uint64_t)pp[i] << 32) | (uint64_t)low[i];
+      }
     }
   }
 }
+
+// Levels too small for a pass over every (ranked) vertex: the level's own vertices set their bits — bit drank[v] in
+// rank space (Cuthill-McKee) or bit v (plain sweeps) — in a bitmap that is clear between uses (k_bfs_start clears it,
+// k_keys_from_fresh clears what it reads); k_rank_counts then leaves the per-word counts and per-workgroup totals
+// k_fresh_words_ranked would have.
+__global__ __launch_bounds__(256) void k_rank_scatter(const I *__restrict__ nf_list, unsigned nf,
+                                                      const uint32_t *__restrict__ drank,
+                                                      unsigned long long *__restrict__ fresh64) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; j < nf; j += stride) {
+    const I v = nf_list[j];
+    const uint32_t k = drank ? drank[v] : (uint32_t)v;
+    atomicOr(&fresh64[k >> 6], 1ull << (k & 63));
+  }
+}
+__global__ __launch_bounds__(64) void k_rank_counts(const unsigned long long *__restrict__ fresh64, int *__restrict__ cnt,
+                                                    int *__restrict__ btot, int64_t words) {
+  const int64_t w = (int64_t)blockIdx.x * RCM_FW_WORDS + threadIdx.x;
+  const int c = w < words ? __popcll(fresh64[w]) : 0;
+  if (w < words) cnt[w] = c;
+  const int t = sbx_wave_sum(c);
+  if (threadIdx.x == 0) btot[blockIdx.x] = t;
+}
+
+// what the last digit's placement of a level's counting sort does with a vertex (sbx_countsort.h): the queue entry,
+// the bitmaps (small levels only: big ones rebuild them from ppos), the level position for a bottom-up expansion
+struct LevelEmit {
+  const uint32_t *map;  // rank -> vertex (Cuthill-McKee) or nullptr
+  I *out;
+  unsigned *bits_a, *bits_b, *pos_of;
+  __device__ void operator()(unsigned pos, uint32_t, uint32_t val) const {
+    const uint32_t v = map ? map[val] : val;
+    out[pos] = (I)v;
+    if (bits_a) atomicOr(&bits_a[v >> 5], 1u << (v & 31));
+    if (bits_b) atomicOr(&bits_b[v >> 5], 1u << (v & 31));
+    if (pos_of) pos_of[v] = pos;
+  }
+};
 
 // small level: keys, sort in LDS and emit in one workgroup.  The sort is a bucket rank: the keys (all different)
 // go to 4096 order-preserving buckets by their leading bits above the smallest key, the bucket counts are scanned,
@@ -1766,6 +1829,14 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
   for (; j < cnt; j += stride) inv[q[j]] = base + (I)(cnt - 1 - j);
 }
 
+// SBX_RCM_COUNT_SORT=0: levels above 4096 vertices are ordered by the generic radix sort over (parent position, low field)
+static bool rcm_count_sort() {
+  static const bool on = !(getenv("SBX_RCM_COUNT_SORT") && atoi(getenv("SBX_RCM_COUNT_SORT")) == 0);
+  return on;
+}
+
+constexpr int64_t RCM_COUNT_SORT_MAX = (int64_t)1 << 20;  // levels above this: the generic sort's staged stores win
+
 static bool rcm_ranked_keys() {  // SBX_RCM_RANKED_KEYS=0: big Cuthill-McKee levels sort their full (parent position, rank) keys
   static const bool on = !(getenv("SBX_RCM_RANKED_KEYS") && atoi(getenv("SBX_RCM_RANKED_KEYS")) == 0);
   return on;
@@ -1789,6 +1860,7 @@ struct BfsBuffers {
   uint64_t *ka, *kb;
   unsigned long long *fresh64;  // per 64 vertices: the bits the current level added to the visited bitmap
   int *wcnt, *woff;             // ... their popcounts, and the totals of every RCM_FW_WORDS of them
+  unsigned *cs_scratch;         // the level ordering's counting sort (sbx_cs::scratch_words(n) words)
   const uint32_t *drank, *dorder;
   int64_t n_ranked;  // entries of dorder (vertices with a non-empty row)
   RcmDev *dv;
@@ -1818,7 +1890,9 @@ template <bool CM>
 int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   // vbits and fbits are adjacent pieces of one allocation (sbx_rcm_reorder): one fill clears both
-  const StartClear sc = {b.vbits, (unsigned long long)((b.fbits - b.vbits) + bm_bytes / sizeof(unsigned)), nullptr, 0, nullptr, 0};
+  // (also the bitmap the level ordering scatters into: k_rank_scatter)
+  const StartClear sc = {b.vbits, (unsigned long long)((b.fbits - b.vbits) + bm_bytes / sizeof(unsigned)),
+                         (unsigned *)b.fresh64, (unsigned long long)(2 * ((b.n + 63) / 64 + 1)), nullptr, 0};
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(RCM_START_GRID), dim3(256), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q,
               b.dv, fixed_root, sc);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
@@ -1920,7 +1994,40 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       sbx_radix_pass passes[16];
       int np;
       int low_bits = 32;  // width of the key's low field (vertex id or degree rank); 32: the parent position starts at bit 32
-      if (!CM && !set_bits) {
+      if (rcm_count_sort() && (int64_t)nf <= RCM_COUNT_SORT_MAX) {
+        // The level's vertices in the order of their low key field — ascending degree rank (Cuthill-McKee) or id
+        // (plain) — read off a bitmap, so that only the parent positions are left to sort, stably, by the counting
+        // sort of sbx_countsort.h: three small launches per 9-bit digit.  The bitmap comes from a pass over all
+        // (ranked) vertices when the level holds a good part of them, from the level's own list otherwise.
+        const int64_t span = CM ? b.n_ranked : b.n;
+        const int64_t words = (span + 63) / 64;
+        const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
+        if (!CM && !set_bits) {
+          SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_fresh_words, dim3((unsigned)fw_blocks), dim3(256), (const unsigned *)b.ppos,
+                      (unsigned long long *)b.vbits,
+                      mark_frontier ? (unsigned long long *)b.fbits : (unsigned long long *)nullptr, b.fresh64, b.wcnt,
+                      b.woff, b.n);
+        } else if (CM && (int64_t)nf * 16 >= b.n_ranked) {  // (a scattered bit costs ~16 gathered ones)
+          SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_fresh_words_ranked, dim3((unsigned)fw_blocks), dim3(256),
+                      (const unsigned *)b.ppos, (const unsigned *)b.vbits, b.dorder, b.fresh64, b.wcnt, b.woff, b.n_ranked);
+        } else {
+          SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_rank_scatter, dim3(g), dim3(256), (const I *)b.nf_list, nf,
+                      CM ? b.drank : (const uint32_t *)nullptr, b.fresh64);
+          SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_rank_counts, dim3((unsigned)fw_blocks), dim3(64),
+                      (const unsigned long long *)b.fresh64, b.wcnt, b.woff, words);
+        }
+        const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
+        if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
+        uint32_t *k32 = (uint32_t *)b.ka, *v32 = k32 + b.n, *k32b = (uint32_t *)b.kb, *v32b = k32b + b.n;
+        SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256), b.fresh64,
+                    (const int *)b.wcnt, (const int *)b.woff, scanned, (const unsigned *)b.ppos,
+                    CM ? b.dorder : (const uint32_t *)nullptr, (uint64_t *)nullptr, k32, v32, words, b.dv);
+        const LevelEmit em = {CM ? b.dorder : nullptr, q_next, set_bits ? b.vbits : nullptr,
+                              (set_bits && mark_frontier) ? b.fbits : nullptr, mark_frontier ? b.lpos : nullptr};
+        SBX_TRY(sbx_cs::sort_emit(h, SBX_K_LEVEL_ORDER, k32, v32, k32b, v32b, (int64_t)nf,
+                                  sbx_bits_for((uint64_t)(fsize - 1)), em, b.cs_scratch));
+        np = -1;  // ordered
+      } else if (!CM && !set_bits) {
         // keys in ascending id order straight from the bitmap pass: only the parent positions are left to sort
         const int64_t words = (b.n + 63) / 64;
         const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
@@ -1931,8 +2038,9 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
         const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
         if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
-                    (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
-                    (const unsigned *)b.ppos, (const uint32_t *)nullptr, b.ka, words, b.dv);
+                    b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
+                    (const unsigned *)b.ppos, (const uint32_t *)nullptr, b.ka, (uint32_t *)nullptr, (uint32_t *)nullptr, words,
+                    b.dv);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       } else if (CM && !set_bits && rcm_ranked_keys() && (int64_t)nf * rcm_ranked_div() >= b.n_ranked) {
         // keys in ascending degree-rank order from a bitmap in rank space: only the parent positions are left to sort
@@ -1943,8 +2051,8 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
         const int scanned = fw_blocks > RCM_FW_INLINE ? 1 : 0;
         if (scanned) SBX_TRY(sbx_exclusive_scan_i32(h, b.woff, b.woff, fw_blocks, nullptr));
         SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_keys_from_fresh, dim3((unsigned)fw_blocks), dim3(256),
-                    (const unsigned long long *)b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
-                    (const unsigned *)b.ppos, b.dorder, b.ka, words, b.dv);
+                    b.fresh64, (const int *)b.wcnt, (const int *)b.woff, scanned,
+                    (const unsigned *)b.ppos, b.dorder, b.ka, (uint32_t *)nullptr, (uint32_t *)nullptr, words, b.dv);
         np = sbx_radix_plan(0, 0, 32, 32 + sbx_bits_for((uint64_t)(fsize - 1)), passes);
       } else {
         low_bits = sbx_bits_for((uint64_t)(b.n - 1));
@@ -1952,7 +2060,8 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
                     (const unsigned *)b.ppos, b.drank, b.ka, b.dv, low_bits);
         np = sbx_radix_plan(0, low_bits + sbx_bits_for((uint64_t)(fsize - 1)), 0, 0, passes);
       }
-      if (np > 0) {
+      if (np < 0) {
+      } else if (np > 0) {
         // the last digit pass writes the queue, the bits and the level positions itself (no pass over sorted keys)
         const sbx_radix_emit em = {CM ? b.dorder : nullptr, (uint32_t *)q_next, set_bits ? b.vbits : nullptr,
                                    (set_bits && mark_frontier) ? b.fbits : nullptr, mark_frontier ? b.lpos : nullptr,
@@ -2991,6 +3100,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.fresh64));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.wcnt));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 / RCM_FW_WORDS + 2, &b.woff));
+  SBX_TRY(sbx_salloc(h, sbx_cs::scratch_words(std::min<int64_t>(n, RCM_COUNT_SORT_MAX)), &b.cs_scratch));
   b.max_deg = hd0.max_deg;
   // (2) The smallest non-isolated vertex v0 is the smallest id of its component, i.e. the
   // start of that component's pseudo-peripheral search.  Its first BFS sweep is needed

@@ -1051,6 +1051,7 @@ def test_degree_reorder_counting_passes(ops, oracle, case):
     elif case == "all_tail_one_degree":
         cases.append((np.full(70_001, 300), np.int32))
         cases.append((np.full(1025, 255), np.int32))
+        cases.append((256 + (np.arange(1_200_000) % 3), np.int32))           # a tail above 2^20 rows: the generic sort
     elif case == "wide_int64":
         n = 50_000
         lens = g.integers(0, 1 << 30, n)                                 # 30-bit degrees: four digits, nnz ~ 2^45
