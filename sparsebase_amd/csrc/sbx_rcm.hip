@@ -541,9 +541,9 @@ __device__ __forceinline__ bool start_clear_elect(const StartClear &sc, RcmDev *
   for (unsigned long long i = t; i < sc.na; i += stride) sc.a[i] = 0;
   for (unsigned long long i = t; i < sc.nb; i += stride) sc.b[i] = 0;
   for (unsigned long long i = t; i < sc.nc; i += stride) sc.c[i] = 0;
-  __threadfence();
-  __syncthreads();
+  __syncthreads();  // (every wave's stores have reached L2 ...)
   if (threadIdx.x != 0) return false;
+  __threadfence();  // (... and ONE release per workgroup writes them back: a fence per thread made this kernel 20 us)
   const unsigned done = atomicAdd(&dv->start_done, 1u);
   if (done != gridDim.x - 1) return false;
   __threadfence();
