@@ -1600,12 +1600,15 @@ __host__ __device__ __forceinline__ unsigned ls_slots(int64_t len, int target) {
 
 // exclusive prefix sums over the long rows of their lengths, bin counts and segment slots: one workgroup walks the
 // list (a few hundred to a few ten thousand rows) instead of three scans of three launches each.
-// Its 1024 threads are also the GATE of the long rows' chain (eight dependent kernels on a side stream): a workgroup
-// of 16 waves finds a CU to start on only when the tile kernel has stopped refilling the CUs — when the last of its
-// waves are running out — so the chain starts in the tile kernel's tail and then runs beside the big row classes.
-// Measured on the bench matrix (A/B in one process pair, round 3): gate as is 1.40 / 1.45 ms (random / RCM order);
-// a 256-thread kernel, i.e. the chain beside the tile kernel from the start, 1.53 / 1.59; the chain behind an event
-// recorded after the tile kernel 1.48 / 1.54 (it misses the tail).
+// Its 1024 threads also decide WHEN the long rows' chain (eight dependent kernels on a side stream) runs: in a kernel
+// trace this one-workgroup kernel completes 0.58 ms after its dispatch, when the tile kernel is running out, so the
+// chain runs beside the big row classes instead of beside the tile kernel.  Measured on the bench matrix (A/B in one
+// process pair, round 3): as is 1.40 / 1.45 ms (random / RCM order); with 256 threads — the chain beside the tile
+// kernel from the start, its segment sort then fighting the two big classes for the CUs (three persistent kernels of
+// one 1024-thread workgroup per CU) — 1.53 / 1.59; the chain behind an event recorded after the tile kernel
+// 1.48 / 1.54.  An explicit 1024-thread gate kernel in front of a 256-thread version did NOT reproduce the delay
+// (1.53), so the mechanism is not simply "16 free wave slots on one CU"; it is kept because it measures best, and
+// NOTES §4.4-r3 has the traces.
 template <typename I>
 __global__ __launch_bounds__(1024) void k_long_seg_offsets(const I *__restrict__ rpo, const I *__restrict__ long_rows,
                                                            uint32_t *__restrict__ loff, uint32_t *__restrict__ foff,
