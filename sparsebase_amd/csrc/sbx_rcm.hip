@@ -2549,7 +2549,10 @@ __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
 constexpr unsigned UR_GRID = 64;
 constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
 constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
-constexpr unsigned UR_HEAVY = 2048;       // frontier vertices above this degree are scanned by the whole grid
+#ifndef SBX_UR_HEAVY
+#define SBX_UR_HEAVY 2048
+#endif
+constexpr unsigned UR_HEAVY = SBX_UR_HEAVY;  // frontier vertices above this degree are scanned by the whole grid
 constexpr unsigned UR_CONTINUE = 0, UR_DONE = 1, UR_STOP = 2, UR_DEEP = 3;  // DEEP: too many levels in one launch
 
 template <typename T>
@@ -2590,17 +2593,34 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
     }
     I *q_next = q + off + size;
     unsigned long long degacc = 0;
-    auto visit = [&](I c) {
-      bool won = false;
-      if (c >= 0) {
-        const unsigned bit = 1u << (c & 31);
-        if (!(ur_load(&vbits[c >> 5]) & bit)) won = !(atomicOr(&vbits[c >> 5], bit) & bit);
+    // 256 adjacency entries per wave and step, in phases — columns, bitmap words, claims, ONE reservation, stores —
+    // so that a step costs one chain of dependent memory round trips instead of four (a 2048-entry vertex: 8 steps
+    // of ~2.5 us instead of 32)
+    auto visit4 = [&](const I (&c)[4]) {
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = c[k] >= 0 ? ur_load(&vbits[c[k] >> 5]) : ~0u;
+      unsigned long long m[4];
+      unsigned tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned bit = 1u << (c[k] & 31);
+        const bool won = c[k] >= 0 && !(w[k] & bit) && !(atomicOr(&vbits[c[k] >> 5], bit) & bit);
+        m[k] = __ballot(won);
+        tot += (unsigned)__popcll(m[k]);
       }
-      const unsigned pos = sbx_wave_append(&dv->ur_nf[slot], won);
-      if (won) {
-        ur_store(&q_next[pos], c);
-        dist[c] = level + 1;  // (read by later kernels only)
-        degacc += (unsigned long long)(rp[c + 1] - rp[c]);
+      if (tot == 0) return;
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&dv->ur_nf[slot], tot);
+      base = (unsigned)__shfl((int)base, 0, 64);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if ((m[k] >> lane) & 1ull) {
+          ur_store(&q_next[base + (unsigned)__popcll(m[k] & sbx_lanemask_lt())], c[k]);
+          dist[c[k]] = level + 1;  // (read by later kernels only)
+          degacc += (unsigned long long)(rp[c[k] + 1] - rp[c[k]]);
+        }
+        base += (unsigned)__popcll(m[k]);
       }
     };
     auto flush_degrees = [&]() {
@@ -2616,9 +2636,15 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
         if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
         continue;
       }
-      for (I a = s + lane; __any(a < e); a += 64) {
-        visit(a < e ? col[a] : (I)-1);
-        scanned += a < e ? 1u : 0u;
+      for (I a0 = s; a0 < e; a0 += 256) {
+        I c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const I a = a0 + k * 64 + lane;
+          c[k] = a < e ? col[a] : (I)-1;
+          scanned += a < e ? 1u : 0u;
+        }
+        visit4(c);
       }
     }
     flush_degrees();
@@ -2628,10 +2654,15 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
       for (unsigned i = 0; i < nh; i++) {
         const I u = ur_load(&hq[i]);
         const I s = rp[u], e = rp[u + 1];
-        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
-          const int64_t a = a0 + lane;
-          visit(a < e ? col[a] : (I)-1);
-          scanned += a < e ? 1u : 0u;
+        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 256; a0 < e; a0 += (int64_t)nwaves * 256) {
+          I c[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int64_t a = a0 + k * 64 + lane;
+            c[k] = a < e ? col[a] : (I)-1;
+            scanned += a < e ? 1u : 0u;
+          }
+          visit4(c);
         }
       }
       flush_degrees();
@@ -2714,14 +2745,35 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
     }
     const unsigned slot = k % 3, next_slot = (k + 2) % 3;  // (k counts down: the next level uses (k - 1) % 3)
     if (blockIdx.x == 0 && threadIdx.x == 0) ur_store(&dv->ur_nh[next_slot], 0u);
-    auto visit = [&](I c) {
-      bool won = false;
-      if (c >= 0 && ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k - 1) {
-        const unsigned bit = 1u << (c & 31);
-        if (!(ur_load(&cone[c >> 5]) & bit)) won = !(atomicOr(&cone[c >> 5], bit) & bit);
+    auto visit4 = [&](const I (&c)[4]) {  // (phases as in k_ubfs_small_run)
+      unsigned vb[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) vb[j] = c[j] >= 0 ? vbits[c[j] >> 5] : 0u;
+      unsigned dd[4], cw[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool reached = (vb[j] >> (c[j] & 31)) & 1u;
+        dd[j] = reached ? dist[c[j]] : 0xFFFFFFFFu;
+        cw[j] = reached ? ur_load(&cone[c[j] >> 5]) : ~0u;
       }
-      const unsigned pos = sbx_wave_append(&dv->nf, won);
-      if (won) ur_store(&list[pos], c);
+      unsigned long long m[4];
+      unsigned tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned bit = 1u << (c[j] & 31);
+        const bool won = dd[j] == k - 1 && !(cw[j] & bit) && !(atomicOr(&cone[c[j] >> 5], bit) & bit);
+        m[j] = __ballot(won);
+        tot += (unsigned)__popcll(m[j]);
+      }
+      if (tot == 0) return;
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&dv->nf, tot);
+      base = (unsigned)__shfl((int)base, 0, 64);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if ((m[j] >> lane) & 1ull) ur_store(&list[base + (unsigned)__popcll(m[j] & sbx_lanemask_lt())], c[j]);
+        base += (unsigned)__popcll(m[j]);
+      }
     };
     for (unsigned p = begin + gwave; p < end; p += nwaves) {
       const I u = ur_load(&list[p]);
@@ -2730,7 +2782,15 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
         if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
         continue;
       }
-      for (I a = s + lane; __any(a < e); a += 64) visit(a < e ? col[a] : (I)-1);
+      for (I a0 = s; a0 < e; a0 += 256) {
+        I c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const I a = a0 + j * 64 + lane;
+          c[j] = a < e ? col[a] : (I)-1;
+        }
+        visit4(c);
+      }
     }
     if (!ur_barrier(dv, epoch)) return;
     const unsigned nh = ur_load(&dv->ur_nh[slot]);
@@ -2738,9 +2798,14 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
       for (unsigned i = 0; i < nh; i++) {
         const I u = ur_load(&hq[i]);
         const I s = rp[u], e = rp[u + 1];
-        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 64; a0 < e; a0 += (int64_t)nwaves * 64) {
-          const int64_t a = a0 + lane;
-          visit(a < e ? col[a] : (I)-1);
+        for (int64_t a0 = (int64_t)s + (int64_t)gwave * 256; a0 < e; a0 += (int64_t)nwaves * 256) {
+          I c[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int64_t a = a0 + j * 64 + lane;
+            c[j] = a < e ? col[a] : (I)-1;
+          }
+          visit4(c);
         }
       }
       if (!ur_barrier(dv, epoch)) return;
