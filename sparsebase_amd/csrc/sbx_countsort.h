@@ -19,7 +19,8 @@ namespace {  // (kernels in a header shared by several translation units: intern
 
 constexpr int ROUNDS = 4;                 // pairs per lane
 constexpr int TILE = 256 * ROUNDS;        // pairs per workgroup
-constexpr int64_t MAX_PAIRS = (int64_t)1 << 24;  // (cnt holds bins * n / TILE words; the placement scatters single words: beyond ~10^6 pairs the generic sort's staged stores win)
+constexpr int64_t MAX_PAIRS = (int64_t)1 << 20;  // the callers' switch-over: the placement scatters single words, and beyond ~10^6
+                                                 // pairs the generic sort's LDS-staged stores win (RCM's 1.7 M-vertex level: 161 vs 147 us)
 
 // the lanes of the wave that hold the same BITS-bit digit as this one (valid lanes only)
 template <int BITS>
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_cs_place(const uint32_t *__restrict__ k
 // Sorts the n pairs (ka, va) by the low `bits` bits of the key (stable), kb / vb as the other side of the ping-pong;
 // the last digit's placement calls emit(position, key, value) for every pair instead of storing it.  Digits of up to
 // 9 bits.  Scratch: `scratch` (scratch_words(n) words, for callers that sort many times per call) or, when null, from
-// the arena.  n >= 1; n <= MAX_PAIRS.
+// the arena.  n >= 1 (any n works; callers stay below MAX_PAIRS).
 static inline size_t scratch_words(int64_t n) { return (size_t)((n + TILE - 1) / TILE) * 512 + 512; }
 template <int BITS, typename Emit>
 static int digit_pass(sbx_handle_t h, int kid, const uint32_t *ka, const uint32_t *va, uint32_t *kb, uint32_t *vb, int64_t n,

@@ -262,7 +262,7 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   uint32_t *tb, *ib;
   SBX_TRY(sbx_salloc(h, (size_t)top, &tb));
   SBX_TRY(sbx_salloc(h, (size_t)top, &ib));
-  if (top <= ((int64_t)1 << 20)) {
+  if (top <= sbx_cs::MAX_PAIRS) {
     const DegreeTailEmit<I> emit = {(I *)inv_perm_out, n - top, n, ascending};
     SBX_TRY(sbx_cs::sort_emit(h, SBX_K_DEGREE, ta, ia, tb, ib, top, sbx_bits_for(hs.max_deg), emit));
   } else {  // (millions of rows of 255+ entries: the generic sort's staged stores win; then a scatter)

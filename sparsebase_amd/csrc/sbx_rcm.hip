@@ -2511,7 +2511,9 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ 
     // (not dv->root: if the LAST barrier gave up on the other workgroups while this one passed it, the host redoes the
     // sweep from the root it still expects there — k_gb_reset drops the pending one)
     if (w == 0xFFFFFFFFu) {
-      dv->unsym = 1;  // cannot happen on a symmetric pattern
+      // cannot happen on a symmetric pattern — unless a workgroup gave up at a barrier (gb_wait) and its share of a
+      // later level was never scanned: then the host discards this walk, and the flag must not outlive it
+      if (!__hip_atomic_load(&dv->gb_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dv->unsym = 1;
     } else {
       dv->root_next = w;
       dv->root_pending = 1;
@@ -2636,11 +2638,11 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
         if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
         continue;
       }
-      for (I a0 = s; a0 < e; a0 += 256) {
+      for (int64_t a0 = s; a0 < e; a0 += 256) {
         I c[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const I a = a0 + k * 64 + lane;
+          const int64_t a = a0 + k * 64 + lane;
           c[k] = a < e ? col[a] : (I)-1;
           scanned += a < e ? 1u : 0u;
         }
@@ -2744,7 +2746,10 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
       break;
     }
     const unsigned slot = k % 3, next_slot = (k + 2) % 3;  // (k counts down: the next level uses (k - 1) % 3)
-    if (blockIdx.x == 0 && threadIdx.x == 0) ur_store(&dv->ur_nh[next_slot], 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ur_store(&dv->ur_nh[next_slot], 0u);
+      ur_store(&dv->ur_nf[next_slot], 0u);
+    }
     auto visit4 = [&](const I (&c)[4]) {  // (phases as in k_ubfs_small_run)
       unsigned vb[4];
 #pragma unroll
@@ -2767,7 +2772,10 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
       }
       if (tot == 0) return;
       unsigned base = 0;
-      if (lane == 0) base = atomicAdd(&dv->nf, tot);
+      if (lane == 0) {
+        base = atomicAdd(&dv->nf, tot);        // the member's place in the one growing list ...
+        atomicAdd(&dv->ur_nf[slot], tot);      // ... and the size of the level being marked (see below)
+      }
       base = (unsigned)__shfl((int)base, 0, 64);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -2782,11 +2790,11 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
         if (lane == 0) ur_store(&hq[atomicAdd(&dv->ur_nh[slot], 1u)], u);
         continue;
       }
-      for (I a0 = s; a0 < e; a0 += 256) {
+      for (int64_t a0 = s; a0 < e; a0 += 256) {
         I c[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const I a = a0 + j * 64 + lane;
+          const int64_t a = a0 + j * 64 + lane;
           c[j] = a < e ? col[a] : (I)-1;
         }
         visit4(c);
@@ -2810,8 +2818,11 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
       }
       if (!ur_barrier(dv, epoch)) return;
     }
+    // The level's end is its begin + what THIS level appended (a per-level slot, final behind the barrier) — not the
+    // list counter itself: a workgroup that is slow to get here (a GPU shared with other processes) would read a
+    // counter other workgroups are already appending the next level to, and walk a different range than they do.
     begin = end;
-    end = ur_load(&dv->nf);
+    end = begin + ur_load(&dv->ur_nf[slot]);
     if (end == begin) {  // a level without a path to the level below: not a symmetric pattern
       broken = true;
       break;
@@ -2822,7 +2833,9 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
     dv->cone_end = end;
     dv->cone_k = k;
     dv->cone_status = status;
-    if (broken) dv->unsym = 1;
+    // (a level that found nothing because some workgroup had given up at a barrier is not an unsymmetric pattern: the
+    // host redoes the tie-break the safe way and the flag must not outlive this launch)
+    if (broken && !ur_load(&dv->gb_abort)) dv->unsym = 1;
     dv->n_heavy = 0;
     dv->hub_overflow = 0;
   }
@@ -2830,7 +2843,7 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
   if (threadIdx.x == 0 && atomicAdd(&dv->ur_exit, 1u) == gridDim.x - 1) {
     ur_store(&dv->ur_bar, 0u);
     ur_store(&dv->ur_exit, 0u);
-    for (int i = 0; i < 3; i++) ur_store(&dv->ur_nh[i], 0u);
+    for (int i = 0; i < 3; i++) ur_store(&dv->ur_nh[i], 0u), ur_store(&dv->ur_nf[i], 0u);
   }
 }
 
