@@ -2014,9 +2014,25 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
   return on;
 }
 
+// SBX_PERMUTE_ROW_WAVES: resident waves per CU the grids of the row classes up to 2048 entries are sized for.  Measured on
+// the bench matrix (tools/kt_rowwaves.sh): 4 waves per CU are 25 - 40 % slower, 8 - 12 are level, 16 and more lose
+// 5 - 15 % again — the kernels are bound by the CU's memory path, which eight waves with a row of gathers each in flight
+// keep full.
+static int rq_waves_per_cu() {
+  static const int f = getenv("SBX_PERMUTE_ROW_WAVES") ? atoi(getenv("SBX_PERMUTE_ROW_WAVES")) : 8;
+  return f < 1 ? 1 : f;
+}
+
 static int tile_grid_factor() {  // SBX_PERMUTE_TILE_GRID: persistent tile waves per resident slot (tuning)
   static const int f = getenv("SBX_PERMUTE_TILE_GRID") ? atoi(getenv("SBX_PERMUTE_TILE_GRID")) : 12;
   return f < 1 ? 1 : f;
+}
+
+#include "sbx_rowsort.h"
+
+static bool permute_quad_rows() {  // SBX_PERMUTE_QUAD_ROWS=0: round 3's k_permute_block_rows instead of k_rows_quad
+  static const bool on = !(getenv("SBX_PERMUTE_QUAD_ROWS") && atoi(getenv("SBX_PERMUTE_QUAD_ROWS")) == 0);
+  return on;
 }
 
 // rows of PT_LMAX < length <= 8 K: one workgroup per row, by capacity class
@@ -2058,15 +2074,62 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
       if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
     }                                                                                                             \
   }
-  // threads per class, measured on the bench matrix: one wave (no s_barrier at all) up to 512 entries, 8 entries per
-  // thread up to 2048, 4 for 4096 (8 per thread there: +5 %)
-  BLOCK_ROWS(0, 64);
-  BLOCK_ROWS(1, 64);
-  BLOCK_ROWS(2, 128);
-  BLOCK_ROWS(3, 256);
-  BLOCK_ROWS(4, 1024);
-  if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
+  // k_rows_quad: T threads x Q quads = the class capacity; the column map must fit a buffer descriptor (4 GB)
+  const bool quad = permute_quad_rows() && (!col_order || (uint64_t)m * 4 <= 0xFFFFFFFCull);
+  const unsigned table_bytes = col_order ? (unsigned)((uint64_t)m * 4) : 0u;
+#define QUAD_ROWS(CLS, THREADS, QUADS, MINW)                                                                      \
+  if (n_block[CLS]) {                                                                                             \
+    static_assert(4 * (THREADS) * (QUADS) == br_cap(CLS), "class capacity");                                      \
+    const unsigned by_lds = (unsigned)(160 * 1024 / RqLds<VB, THREADS, QUADS>::BYTES);                            \
+    const unsigned by_waves = (unsigned)((THREADS) >= 512 ? 16 : rq_waves_per_cu()) / ((THREADS) / 64);           \
+    const unsigned per_cu = by_lds < by_waves ? by_lds : by_waves;                                                \
+    unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu) * (unsigned)permute_grid_factor();           \
+    if (grid > n_block[CLS]) grid = n_block[CLS];                                                                 \
+    const int si = (CLS) == 0 ? 0 : (CLS) + 1;                                                                    \
+    if (fork && si) {                                                                                             \
+      h->stream = h->aux_stream[si];                                                                              \
+      SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[0], 0));                                              \
+    }                                                                                                             \
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_rows_quad<I, VB, THREADS, QUADS, MINW>), dim3(grid), dim3(THREADS), rec, \
+                col_in, val_in, col_order, rpo, block_rows + (CLS)*block_stride, (int)n_block[CLS], col_out,      \
+                val_out, st, force, fb_rows, &st->n_fb_rows, (const unsigned *)nullptr, table_bytes);             \
+    if (fork && si) {                                                                                             \
+      const hipError_t e1_ = hipEventRecord(h->aux_event[1 + si], h->stream);                                     \
+      const hipError_t e2_ = hipStreamWaitEvent(base, h->aux_event[1 + si], 0);                                   \
+      h->stream = base;                                                                                           \
+      if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
+    }                                                                                                             \
+  }
+  if (quad) {
+    static const int big = getenv("SBX_PERMUTE_BIG") ? atoi(getenv("SBX_PERMUTE_BIG")) : 0;  // (tuning: shape of the two big classes)
+    QUAD_ROWS(0, 64, 1, 1);
+    QUAD_ROWS(1, 64, 2, 1);
+    QUAD_ROWS(2, 128, 2, 1);
+    QUAD_ROWS(3, 256, 2, 1);
+    if (big == 1) {
+      QUAD_ROWS(4, 256, 4, 1);
+    } else {
+      QUAD_ROWS(4, 512, 2, 4);  // two workgroups per CU: at most 128 registers
+    }
+    if constexpr (VB != 8) {
+      if (big == 1) {
+        QUAD_ROWS(5, 512, 4, 1);
+      } else {
+        QUAD_ROWS(5, 1024, 2, 1);
+      }
+    }
+  } else {
+    // threads per class, measured on the bench matrix: one wave (no s_barrier at all) up to 512 entries, 8 entries per
+    // thread up to 2048, 4 for 4096 (8 per thread there: +5 %)
+    BLOCK_ROWS(0, 64);
+    BLOCK_ROWS(1, 64);
+    BLOCK_ROWS(2, 128);
+    BLOCK_ROWS(3, 256);
+    BLOCK_ROWS(4, 1024);
+    if constexpr (VB != 8) BLOCK_ROWS(5, 1024);  // 8-byte values: 8192 entries do not fit LDS, those rows are "long"
+  }
 #undef BLOCK_ROWS
+#undef QUAD_ROWS
   SBX_KLAUNCH(h, SBX_K_PERMUTE_BLOCK, (k_permute_rows_radix<I, VB>), dim3((unsigned)(n_all < 512 ? n_all : 512)),
               dim3(1024), rec, col_in, val_in, col_order, rpo, (const unsigned *)fb_rows, col_out, val_out, col_bits, st,
               (const unsigned *)&st->n_fb_rows);

@@ -84,6 +84,24 @@ def test_c3_permute_100m_properties(ops, c3):
     assert bool((deg_old[perm.long()][1:] >= deg_old[perm.long()][:-1]).all())
 
 
+def test_c3_permute_100m_bit_exact_vs_oracle(ops, oracle, c3):
+    """The headline operation inside the suite, bit for bit: Permute2D(order, order) of the bench matrix
+    (permute/permute_order_two.cc:23-79 + the constructor's row sort, format/csr.cc:118-157) for the RCM order the bench
+    step uses and for one random order, float32 values, against the oracle's restatement on the host."""
+    rp, col, val = c3
+    n = rp.numel() - 1
+    hrp, hcol, hval = rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    rnd = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).to(torch.int32)
+    for name, order in (("rcm", ops.rcm_reorder(rp, col)), ("random", rnd)):
+        prp, pcol, pval = ops.permute_csr(n, n, rp, col, val, order, order)
+        horder = order.cpu().numpy()
+        wrp, wcol, wval = oracle.permute_csr(hrp, hcol, hval, horder, horder)
+        assert np.array_equal(prp.cpu().numpy(), wrp), name
+        assert np.array_equal(pcol.cpu().numpy(), wcol), name
+        assert np.array_equal(pval.cpu().numpy().view(np.uint32), wval.view(np.uint32)), name
+        del prp, pcol, pval, wrp, wcol, wval
+
+
 def test_c3_csc_and_features_100m(ops, oracle, c3):
     """§8(f) rows at full size: transpose twice = identity, the transpose of a symmetric pattern has the same
     row_ptr/col, features against the oracle, and RCM lowers the profile of the power-law matrix."""
