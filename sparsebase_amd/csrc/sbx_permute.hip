@@ -711,7 +711,7 @@ __device__ __forceinline__ void permute_tile_body(
         if ((int64_t)sp[mid] <= target) lo = mid;
         else hi = mid;
       }
-      if ((int64_t)sp[lo] == target) {  // (rows that add nothing to sp share the value of the short row behind them)
+      if ((int64_t)sp[lo] == target) {  // (rows that add nothing to sp share the value of the tile row behind them)
         const int2 rc = rec[lo];
         s_a[p] = 1;
         s_ob[p] = (int)rpo[lo];
@@ -2015,11 +2015,12 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
 }
 
 // SBX_PERMUTE_ROW_WAVES: resident waves per CU the grids of the row classes up to 2048 entries are sized for.  Measured on
-// the bench matrix (tools/kt_rowwaves.sh): 4 waves per CU are 25 - 40 % slower, 8 - 12 are level, 16 and more lose
-// 5 - 15 % again — the kernels are bound by the CU's memory path, which eight waves with a row of gathers each in flight
-// keep full.
+// the bench matrix (tools/kt_rowwaves.sh; classes of 256 + 512 + 1024 slots): with a random order 8 / 12 / 16 waves per
+// CU take 399 / 401 / 440 us, with the RCM order (every row takes the second, interpolating level: more LDS round trips
+// to hide) 538 / 484 / 463 us; 4 waves are 25 - 60 % slower, more than the 16 the registers admit queue workgroups
+// behind each other.  Orders that come out of a reordering are the common case: 16.
 static int rq_waves_per_cu() {
-  static const int f = getenv("SBX_PERMUTE_ROW_WAVES") ? atoi(getenv("SBX_PERMUTE_ROW_WAVES")) : 8;
+  static const int f = getenv("SBX_PERMUTE_ROW_WAVES") ? atoi(getenv("SBX_PERMUTE_ROW_WAVES")) : 16;
   return f < 1 ? 1 : f;
 }
 
@@ -2109,7 +2110,7 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
     if (big == 1) {
       QUAD_ROWS(4, 256, 4, 1);
     } else {
-      QUAD_ROWS(4, 512, 2, 4);  // two workgroups per CU: at most 128 registers
+      QUAD_ROWS(4, 512, 2, (VB == 8 ? 2 : 4));  // two workgroups per CU: at most 128 registers (8-byte values: LDS allows one)
     }
     if constexpr (VB != 8) {
       if (big == 1) {
@@ -2237,15 +2238,28 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
               (const unsigned *)row_skip, c2, v2);
   // the segments: virtual rows of the one-workgroup-per-row kernel (columns already relabelled: no column map)
   const int force = permute_force_radix() & 0xFE;
-  // (1024-thread workgroups: one resident per CU, as in block_rows_path)
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
-              (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
-              0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
-  if constexpr (VB != 8) {
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
-                dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
-                (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
-                (const unsigned *)&st->n_seg[1]);
+  if (permute_quad_rows()) {
+    // (512 threads, two workgroups per CU for segments of up to 4096 entries; 1024 threads for the longer ones)
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_rows_quad<I, VB, 512, 2, (VB == 8 ? 2 : 4)>), dim3(2 * (unsigned)h->num_cus), dim3(512),
+                (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
+                0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0], 0u);
+    if constexpr (VB != 8) {
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_rows_quad<I, VB, 1024, 2, 1>), dim3((unsigned)h->num_cus), dim3(1024),
+                  (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
+                  (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
+                  (const unsigned *)&st->n_seg[1], 0u);
+    }
+  } else {
+    // (1024-thread workgroups: one resident per CU, as in block_rows_path)
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
+                (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
+                0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
+    if constexpr (VB != 8) {
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
+                  dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
+                  (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
+                  (const unsigned *)&st->n_seg[1]);
+    }
   }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_rows_radix<I, VB>), dim3(256), dim3(1024), (const int2 *)vrec,
               (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const unsigned *)fb_rows, col_out,

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
           }
           rq_barrier();  // B4
           const unsigned big = s_row[par][4];  // 0, or the fullest bucket if it holds more than the ranking step unrolls
-          if (level == 1 || big == 0) {
+          if (level == 1 || (big == 0 && !(force_radix & 8))) {  // (bit 3: timing ablation, level 1 always)
             to_radix = big > (unsigned)BK_MAX || (force_radix & 1);
             break;
           }

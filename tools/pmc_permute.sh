@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
   i=$((i+1)); rm -rf /tmp/pmcp_$i
   # (a TA_* counter set aborted rocprofv3 and hung its finalisation for the whole time limit: every pass is bounded)
-  timeout 150 rocprofv3 --kernel-include-regex "k_permute|k_rows_quad|k_long|k_rowwise|k_rec_" --pmc $set --output-format csv -d /tmp/pmcp_$i -o p -- python3 tools/permute_only.py "$@" > "$OUT/pmc_permute_$i.log" 2>&1
+  timeout 150 rocprofv3 --kernel-include-regex "k_permute|k_rows_quad|k_short|k_long|k_rowwise|k_rec_" --pmc $set --output-format csv -d /tmp/pmcp_$i -o p -- python3 tools/permute_only.py "$@" > "$OUT/pmc_permute_$i.log" 2>&1
 done
 python3 - "$OUT/pmc_permute.json" <<'PY'
 import csv, glob, json, sys, collections
@@ -21,7 +21,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob("/tmp/pmcp_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_permute" not in k and "k_rows_quad" not in k and "k_long" not in k and "k_rowwise" not in k and "k_rec_" not in k: continue
+        if "k_permute" not in k and "k_rows_quad" not in k and "k_short" not in k and "k_long" not in k and "k_rowwise" not in k and "k_rec_" not in k: continue
         k = k.replace("void (anonymous namespace)::", "").replace("void ", "")
         k = k.split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
