@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the CPU-baseline sample (default: the bench matrix itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--no-cpp", action="store_true",
+                    help="skip the legs that run the C++ host layer's reorder_cli in a child process (Gray end to end, "
+                         "the Reorder -> Permute2D -> Convert pipeline)")
     ap.add_argument("--leg-timeout", type=float, default=300.0,
                     help="multi-rank runs: seconds the sharded legs may take before the headline is printed without them")
     return ap.parse_args()
@@ -164,6 +167,8 @@ def main():
         }
         # whole operations (SURVEY §8d figures), timed un-instrumented below
         roofline["op"] = op_fractions(ops, n, nnz, rp, col, val, order, out, stats, args.steps)
+        if not args.no_cpp:  # (after every timed leg of this process: the child shares the GPU)
+            roofline["op"].update(cpp_legs(n, nnz, rp, col, roofline["op"]))
 
     extra = {"permute_apply": None, "convert_apply": None, "cpu_baseline": None}
 
@@ -386,12 +391,9 @@ def op_fractions(ops, n, nnz, rp, col, val, order, out, stats, steps):
 
 
 def gray_fractions(ops, n, nnz, rp, col, steps):
-    """GrayReorder on the bench matrix: the device key stage (4 N + 16 n bytes) timed here, and the whole reorderer —
-    device key stage, degrees and keys to the host, the host ordering stage (std::sort over the row keys, as the
-    reference does it) — through the C++ host layer's reorder_cli, which reports its stages.  (BitSize32, 10, 4):
-    the reference's test parameters, tests/suites/sparsebase/preprocess/preprocess_tests.cc."""
-    import subprocess
-    import tempfile
+    """GrayReorder's device key stage (4 N + 16 n bytes) on the bench matrix; the whole reorderer through the C++ host
+    layer is cpp_legs' business.  (BitSize32, 10, 4): the reference's test parameters,
+    tests/suites/sparsebase/preprocess/preprocess_tests.cc."""
     res_, thr, grp = 32, 10, 4
     ops.gray_row_keys(n, rp, col, res_, thr)
     torch.cuda.synchronize()
@@ -403,7 +405,21 @@ def gray_fractions(ops, n, nnz, rp, col, steps):
     alg = 4 * nnz + 16 * n
     out = {"params": [res_, thr, grp],
            "key_stage": {"ms": t_keys * 1e3, "alg_bytes": alg, "frac_of_hbm_peak": alg / t_keys / 1e9 / HBM_PEAK_GBS}}
+    return out
+
+
+def cpp_legs(n, nnz, rp, col, op):
+    """What a C++ caller of the boundary gets, measured in a child process that runs the host layer's reorder_cli on the
+    bench matrix (device-resident HIPCSR, warm calls): the canonical pipeline of the reference's experiment helper
+    (experiment/experiment_helper.h:81-97: Reorder<RCMReorder> -> Permute2D -> Convert) next to this process's `ops`
+    figures, and GrayReorder end to end (device key stage, degrees and keys to the host, the host ordering stage).  The
+    RCM order crosses PCIe twice inside the pipeline figure: the API returns it as a host array, as the reference does."""
+    import subprocess
+    import tempfile
+    res = {}
     cli = os.path.join(ROOT, "sparsebase_amd", "host", "bin", "reorder_cli")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "sparsebase_amd", "lib") + ":" +
+               os.environ.get("LD_LIBRARY_PATH", ""))
     try:
         if not os.path.exists(cli):
             raise RuntimeError("sparsebase_amd/host/bin/reorder_cli is not built")
@@ -411,17 +427,35 @@ def gray_fractions(ops, n, nnz, rp, col, steps):
             a, b, o = (os.path.join(tmp, x) for x in ("rp.bin", "col.bin", "out.bin"))
             rp.cpu().numpy().tofile(a)
             col.cpu().numpy().tofile(b)
-            env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "sparsebase_amd", "lib") + ":" +
-                       os.environ.get("LD_LIBRARY_PATH", ""))
-            r = subprocess.run([cli, "gray", a, b, o, str(n), str(n), str(res_), str(thr), str(grp), "--device", "--time"],
-                               env=env, capture_output=True, text=True, timeout=600, check=True)
-        lines = r.stdout.split("\n")
-        dev_ms, d2h_ms, host_ms = (float(x) for x in lines[1].split())
-        out["end_to_end"] = {"ms": float(lines[0]) * 1e3, "device_key_stage_ms": dev_ms, "keys_to_host_ms": d2h_ms,
-                             "host_ordering_ms": host_ms, "via": "host/bin/reorder_cli --device --time (warm call)"}
-    except Exception as e:  # noqa: BLE001 — an extra: the line is still the line without it
-        out["end_to_end"] = {"error": repr(e)[:200]}
-    return out
+            try:
+                r = subprocess.run([cli, "pipeline", a, b, o, str(n), str(n)], env=env, capture_output=True, text=True,
+                                   timeout=600, check=True)
+                t_re, t_pe, t_co = (float(x) for x in r.stdout.split("\n")[0].split())
+                pipe = {"reorder_ms": t_re, "permute2d_ms": t_pe, "convert_ms": t_co, "ms": t_re + t_pe + t_co,
+                        "via": "host/bin/reorder_cli pipeline (HIPCSR<int,int,float>, best of five warm rounds)",
+                        "order_vector_over_pcie_mb": round(2 * 4 * n / 1e6, 1)}
+                if "rcm" in op and "permute2d" in op:
+                    pipe["ops_ms"] = op["rcm"]["ms"] + op["permute2d"]["ms"]
+                    pipe["over_ops"] = pipe["ms"] / pipe["ops_ms"]
+                res["pipeline_cpp"] = pipe
+            except Exception as e:  # noqa: BLE001 — an extra: the line is still the line without it
+                res["pipeline_cpp"] = {"error": repr(e)[:200]}
+            try:
+                res_, thr, grp = op["gray"]["params"]
+                r = subprocess.run([cli, "gray", a, b, o, str(n), str(n), str(res_), str(thr), str(grp), "--device", "--time"],
+                                   env=env, capture_output=True, text=True, timeout=600, check=True)
+                lines = r.stdout.split("\n")
+                dev_ms, d2h_ms, host_ms = (float(x) for x in lines[1].split())
+                res["gray"] = dict(op["gray"], end_to_end={
+                    "ms": float(lines[0]) * 1e3, "device_key_stage_ms_incl_clock_ramp": dev_ms, "keys_to_host_ms": d2h_ms,
+                    "host_ordering_ms": host_ms, "via": "host/bin/reorder_cli --device --time (warm call)",
+                    "note": "the key stage reads milliseconds here against key_stage.ms in-process: the GPU clocks down "
+                            "while the host stage of the call before sorts"})
+            except Exception as e:  # noqa: BLE001
+                res["gray"] = dict(op["gray"], end_to_end={"error": repr(e)[:200]})
+    except Exception as e:  # noqa: BLE001
+        res["pipeline_cpp"] = {"error": repr(e)[:200]}
+    return res
 
 
 def run_cpu_baseline(args, synth, rp_dev, col_dev, gpu_result=None):

@@ -50,18 +50,23 @@ __device__ __forceinline__ void block_copy_bytes(char *__restrict__ dst, const c
 }
 
 // ------------------------------------------------------------------ A1 check
+// *flags: bit 0 = some record is out of (row, column) order; bit 1 = some coordinate lies outside [0, n) x [0, m) (only
+// looked for when n >= 0: the constructor sort's hybrid path packs coordinates into bit fields sized by n and m and
+// takes malformed input — which neither this library nor the reference validates — through the plain sort instead)
 template <typename I>
 __global__ __launch_bounds__(CV_THREADS) void k_coo_is_sorted(const I *__restrict__ row, const I *__restrict__ col,
-                                                              int64_t nnz, int *__restrict__ unsorted) {
+                                                              int64_t nnz, int *__restrict__ flags, int64_t n, int64_t m) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  bool bad = false;
+  bool bad = false, outside = false;
   for (; i < nnz; i += stride) {
     const I pr = i ? row[i - 1] : (I)0, pc = i ? col[i - 1] : (I)0;
     const I r = row[i], c = col[i];
     bad |= (pr > r) || (pr == r && pc > c);
+    if (n >= 0) outside |= r < 0 || (int64_t)r >= n || c < 0 || (int64_t)c >= m;
   }
-  if (__any(bad) && sbx_lane() == 0) *unsorted = 1;
+  if (__any(bad) && sbx_lane() == 0) atomicOr(flags, 1);
+  if (__any(outside) && sbx_lane() == 0) atomicOr(flags, 2);
 }
 
 // ------------------------------------------------------------------ A1 sort helpers
@@ -386,19 +391,22 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
   } while (0)
 
 template <typename I>
-static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host) {
+static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host,
+                               int64_t n = -1, int64_t m = -1, int *in_range_host = nullptr) {
   SBX_TRY(sbx_arena_begin(h));
   *sorted_host = 1;
+  if (in_range_host) *in_range_host = 1;
   if (nnz == 0) return SBX_OK;
   int *flag = nullptr;
   SBX_TRY(sbx_salloc(h, 1, &flag));
   SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
   SBX_KLAUNCH(h, SBX_K_CHECK, k_coo_is_sorted<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS),
-              (const I *)row, (const I *)col, nnz, flag);
+              (const I *)row, (const I *)col, nnz, flag, n, m);
   SBX_LAUNCH_CHECK(h);
   int f = 0;
   SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
-  *sorted_host = !f;
+  *sorted_host = !(f & 1);
+  if (in_range_host) *in_range_host = !(f & 2);
   return SBX_OK;
 }
 
@@ -448,8 +456,8 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
   const int vb = val ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   if (nnz <= 1) return SBX_OK;
-  int sorted = 0;
-  SBX_TRY(sbx_coo_is_sorted(h, it, nnz, row, col, &sorted));  // format/coo.cc:96-108
+  int sorted = 0, in_range = 1;
+  SBX_TRY(coo_is_sorted_typed<int32_t>(h, nnz, row, col, &sorted, n, m, &in_range));  // format/coo.cc:96-108
   if (sorted) return SBX_OK;
   SBX_TRY(sbx_arena_begin(h));
   uint64_t *ka = nullptr, *kb = nullptr;
@@ -474,7 +482,8 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
     const int s_bits = rowbits > 8 * p ? rowbits - 8 * p : 0;
     sbx_radix_pass msd[16];
     const int np_msd = sbx_radix_plan(0, 0, 32 + s_bits, 32 + rowbits, msd);
-    if (hybrid_on && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
+    // (coordinates outside [0, n) x [0, m) would overflow the bit fields and the group table: the plain sort takes them)
+    if (hybrid_on && in_range && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
       NestGuard guard(h);  // (the nested conversions below must not rewind the arena)
       char *vtmp2 = nullptr;
       if (vb && np_msd >= 3) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp2));

@@ -47,17 +47,18 @@ __device__ __forceinline__ unsigned long long dg_peers(unsigned d, bool valid) {
 // Workgroup t of the launch owns the tile of rows j = t * 4096 .. + 4095 of the descending-id order (id = n - 1 - j), a
 // wave 1024 consecutive ones (16 rounds of 64, all their row_ptr loads issued before the first is used): the counts of
 // the tile's digits go to cnt[digit * n_tiles + t], its largest degree to tmax[t].
-template <typename I>
+// (IDASC: the walk goes through the rows in ascending id order instead — the degree ranks of the RCM, sbx_degree_ranks)
+template <typename I, bool IDASC>
 __device__ __forceinline__ void dg_load_degrees(const I *__restrict__ rp, int64_t n, int64_t j0, unsigned (&deg)[DG_ROUNDS]) {
 #pragma unroll
   for (int r = 0; r < DG_ROUNDS; r++) {
     const int64_t j = j0 + (int64_t)r * 64;
-    const int64_t id = j < n ? n - 1 - j : 0;
+    const int64_t id = j < n ? (IDASC ? j : n - 1 - j) : 0;
     deg[r] = (unsigned)(rp[id + 1] - rp[id]);
   }
 }
 
-template <typename I>
+template <typename I, bool IDASC = false>
 __global__ __launch_bounds__(256) void k_degree_count(const I *__restrict__ rp, int64_t n, int64_t n_tiles,
                                                       unsigned *__restrict__ cnt, unsigned *__restrict__ tmax) {
   __shared__ unsigned s_hist[DG_BINS];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_degree_count(const I *__restrict__ rp, 
   s_hist[threadIdx.x] = 0;
   const int64_t j0 = ((int64_t)blockIdx.x * 4 + wv) * DG_WAVE_ROWS + lane;
   unsigned deg[DG_ROUNDS];
-  dg_load_degrees(rp, n, j0, deg);
+  dg_load_degrees<I, IDASC>(rp, n, j0, deg);
   __syncthreads();
   unsigned mx = 0;
 #pragma unroll
@@ -144,18 +145,21 @@ __global__ __launch_bounds__(256) void k_degree_scan(unsigned *__restrict__ cnt,
 // the rows again: position = rows of smaller digits + rows of this digit in the tiles before + in the tile's waves
 // before + in this wave before it; inv[id] = position (or its mirror); rows of the last bucket also leave (degree, id)
 // at their place in it
-template <typename I>
+// (RANKS: the degree ranks of the RCM — rows in ascending id order, empty rows left out: rank = position - empty rows,
+// written both ways, inv[id] = rank and order[rank] = id)
+template <typename I, bool RANKS = false>
 __global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, int64_t n, int64_t n_tiles,
                                                       const unsigned *__restrict__ off, const unsigned *__restrict__ total,
                                                       I *__restrict__ inv, uint32_t *__restrict__ tail_key,
-                                                      uint32_t *__restrict__ tail_id, int ascending) {
+                                                      uint32_t *__restrict__ tail_id, int ascending,
+                                                      uint32_t *__restrict__ order) {
   __shared__ unsigned s_scan[8];
   __shared__ unsigned s_wave[4][DG_BINS];  // rows of digit d in wave w; then the position of the wave's first such row
   __shared__ unsigned s_top_base;
   const int lane = sbx_lane(), wv = sbx_wave_in_block();
   const int64_t j0 = ((int64_t)blockIdx.x * 4 + wv) * DG_WAVE_ROWS + lane;
   unsigned deg[DG_ROUNDS];
-  dg_load_degrees(rp, n, j0, deg);
+  dg_load_degrees<I, RANKS>(rp, n, j0, deg);
   const unsigned tile_off = off[(int64_t)threadIdx.x * n_tiles + blockIdx.x];  // thread = digit
 #pragma unroll
   for (int k = 0; k < 4; k++) s_wave[k][threadIdx.x] = 0;
@@ -186,14 +190,22 @@ __global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, 
   }
   __syncthreads();
   const unsigned top_base = s_top_base;
+  const unsigned n_empty = RANKS ? total[0] : 0u;
 #pragma unroll
   for (int r = 0; r < DG_ROUNDS; r++) {
     const int64_t j = j0 + (int64_t)r * 64;
     if (j < n) {
-      const int64_t id = n - 1 - j;
+      const int64_t id = RANKS ? j : n - 1 - j;
       const unsigned d = deg[r] < DG_TOP ? deg[r] : DG_TOP;
       const unsigned pos = s_wave[wv][d] + loc[r];
-      inv[id] = (I)(ascending ? (int64_t)pos : n - 1 - (int64_t)pos);
+      if (RANKS) {
+        if (d != 0 && d != DG_TOP) {  // (the last bucket's rows get theirs from the tail sort)
+          inv[id] = (I)(pos - n_empty);
+          order[pos - n_empty] = (uint32_t)id;
+        }
+      } else {
+        inv[id] = (I)(ascending ? (int64_t)pos : n - 1 - (int64_t)pos);
+      }
       if (d == DG_TOP) {
         tail_key[pos - top_base] = deg[r];
         tail_id[pos - top_base] = (uint32_t)id;
@@ -252,7 +264,7 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_count<I>, dim3(grid), dim3(256), rp, n, n_tiles, cnt, wmax);
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_scan, dim3(DG_BINS), dim3(256), cnt, (const unsigned *)wmax, n_tiles, total, st);
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_place<I>, dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
-              (const unsigned *)total, (I *)inv_perm_out, ta, ia, ascending);
+              (const unsigned *)total, (I *)inv_perm_out, ta, ia, ascending, (uint32_t *)nullptr);
   SBX_LAUNCH_CHECK(h);
   DegState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(hs)));
@@ -272,6 +284,72 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
     SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, top, passes, np, &in_b));
     SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<I>, dim3(sbx_grid_for(top, 256, 2048)), dim3(256),
                 (const uint32_t *)(in_b ? ib : ia), (I *)inv_perm_out, top, n - top, n, ascending);
+    SBX_LAUNCH_CHECK(h);
+  }
+  return SBX_OK;
+}
+
+// Degree ranks of the vertices with a non-empty row, for the Cuthill-McKee keys of sbx_rcm.hip (rcm_reorder.cc:101-118
+// orders a vertex's children by degree; equal degrees keep ascending ids): rank[v] = position of v in the sequence
+// (degree ascending, id ascending) of the non-empty rows, order[rank] = v.  The counting pass above with the rows walked
+// in ascending id order — three launches and, for the rows of 255 entries and more, three per 9-bit digit — instead of a
+// generic radix sort of (degree, id) pairs (keys written, histogram, three digit passes: 0.31 ms for 4.2 M rows against
+// 0.09).  The caller knows how many rows the last bucket holds (n_top) and the largest degree: nothing is read back; the
+// scratch comes from the arena of the call that is running; everything is enqueued on h->stream.
+namespace {
+struct RankTailEmit {
+  uint32_t *rank, *order;
+  uint32_t first;  // rank of the last bucket's first row
+  __device__ void operator()(unsigned pos, uint32_t, uint32_t id) const {
+    rank[id] = first + pos;
+    order[first + pos] = id;
+  }
+};
+__global__ __launch_bounds__(256) void k_rank_tail_emit(const uint32_t *__restrict__ sorted_id, uint32_t *__restrict__ rank,
+                                                        uint32_t *__restrict__ order, int64_t count, uint32_t first) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < count; t += stride) {
+    rank[sorted_id[t]] = first + (uint32_t)t;
+    order[first + t] = sorted_id[t];
+  }
+}
+}  // namespace
+
+int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_nonempty, int64_t n_top, unsigned max_deg,
+                     uint32_t *rank, uint32_t *order) {
+  typedef int32_t I;
+  if (n_nonempty <= 0) return SBX_OK;
+  const int64_t n_tiles = (n + 4 * DG_WAVE_ROWS - 1) / (4 * DG_WAVE_ROWS);
+  unsigned *cnt, *wmax, *total;
+  uint32_t *ta, *ia, *tb, *ib;
+  DegState *st;
+  SBX_TRY(sbx_salloc(h, (size_t)n_tiles * DG_BINS, &cnt));
+  SBX_TRY(sbx_salloc(h, (size_t)n_tiles, &wmax));
+  SBX_TRY(sbx_salloc(h, (size_t)DG_BINS, &total));
+  SBX_TRY(sbx_salloc(h, (size_t)n_top + 1, &ta));
+  SBX_TRY(sbx_salloc(h, (size_t)n_top + 1, &ia));
+  SBX_TRY(sbx_salloc(h, (size_t)n_top + 1, &tb));
+  SBX_TRY(sbx_salloc(h, (size_t)n_top + 1, &ib));
+  SBX_TRY(sbx_salloc(h, 1, &st));
+  const unsigned grid = (unsigned)n_tiles;
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, (k_degree_count<I, true>), dim3(grid), dim3(256), rp, n, n_tiles, cnt, wmax);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_degree_scan, dim3(DG_BINS), dim3(256), cnt, (const unsigned *)wmax, n_tiles, total, st);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, (k_degree_place<I, true>), dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
+              (const unsigned *)total, (I *)rank, ta, ia, 1, order);
+  SBX_LAUNCH_CHECK(h);
+  if (n_top == 0) return SBX_OK;
+  const uint32_t first = (uint32_t)(n_nonempty - n_top);
+  if (n_top == 1 || n_top <= sbx_cs::MAX_PAIRS) {
+    const RankTailEmit emit = {rank, order, first};
+    SBX_TRY(sbx_cs::sort_emit(h, SBX_K_RCM_MISC, ta, ia, tb, ib, n_top, sbx_bits_for(max_deg), emit));
+  } else {
+    sbx_radix_pass passes[16];
+    const int np = sbx_radix_plan(0, sbx_bits_for(max_deg), 0, 0, passes);
+    int in_b = 0;
+    SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, n_top, passes, np, &in_b));
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_tail_emit, dim3(sbx_grid_for(n_top, 256, 2048)), dim3(256),
+                (const uint32_t *)(in_b ? ib : ia), rank, order, n_top, first);
     SBX_LAUNCH_CHECK(h);
   }
   return SBX_OK;

@@ -241,6 +241,11 @@ int sbx_radix_sort_emit(sbx_handle_t h, void *keys_a, void *keys_b, int64_t coun
 
 int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count);
 
+// degree ranks of the non-empty rows, (degree, id) ascending, both ways (sbx_degree.hip; for the RCM's Cuthill-McKee keys);
+// n_top = rows of 255 entries and more; enqueued on h->stream, scratch from the running call's arena, no read-back
+int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_nonempty, int64_t n_top, unsigned max_deg,
+                     uint32_t *rank, uint32_t *order);
+
 // ---- 64-bit index arrays (sbx_i64.hip): narrowed to the int32 kernels when every value fits
 struct sbx_narrowed {
   int32_t *ptr;  // int32 copy in the arena (nullptr if the source was nullptr)

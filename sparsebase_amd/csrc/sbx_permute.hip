@@ -2104,7 +2104,15 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
   if (quad) {
     static const int big = getenv("SBX_PERMUTE_BIG") ? atoi(getenv("SBX_PERMUTE_BIG")) : 0;  // (tuning: shape of the two big classes)
     QUAD_ROWS(0, 64, 1, 1);
-    QUAD_ROWS(1, 64, 2, 1);
+    // the 512-slot class keeps round 3's kernel: one wave per row and two quad steps need 124 registers (16 waves per
+    // CU) where that kernel runs 24 waves — with the RCM order, whose rows all take the second sort level, 146 us against
+    // its 118 on the bench matrix (random order: 128 / 112; capped at 96 registers the quad kernel spills: 240)
+    static const int c512 = getenv("SBX_PERMUTE_C512_QUAD") ? atoi(getenv("SBX_PERMUTE_C512_QUAD")) : 0;
+    if (c512) {
+      QUAD_ROWS(1, 64, 2, 1);
+    } else {
+      BLOCK_ROWS(1, 64);
+    }
     QUAD_ROWS(2, 128, 2, 1);
     QUAD_ROWS(3, 256, 2, 1);
     if (big == 1) {

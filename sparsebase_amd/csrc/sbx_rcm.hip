@@ -74,6 +74,7 @@ struct RcmDev {
   unsigned n_components;        // statistics: union-find roots (isolated vertices included) / vertices with an empty row
   unsigned n_empty_rows;
   unsigned n_nonempty;          // vertices with a non-empty row: what the degree-rank sort sorts
+  unsigned n_top;               // ... of them with 255 entries and more (the counting pass's last bucket, sbx_degree_ranks)
   // unordered sweeps: the deepest level's smallest degree, how many vertices have it, the smallest id among them
   unsigned tie_deg, tie_count, tie_min_id;
   unsigned desc[3];             // tie-break walk root -> w_1 -> ... : w_k in desc[k % 3]
@@ -112,10 +113,11 @@ __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int
                                                    unsigned *__restrict__ ppos) {
   const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
   const int64_t len = deg_unit_len(n), v0 = (int64_t)unit * len;
-  unsigned mx = 0, fv = UNSEEN, cnt = 0;
+  unsigned mx = 0, fv = UNSEEN, cnt = 0, top = 0;
   for (int64_t v = v0 + lane; v < v0 + len && v < n; v += 64) {
     const unsigned d = (unsigned)(rp[v + 1] - rp[v]);
     mx = d > mx ? d : mx;
+    top += d >= 255u;
     if (d) {
       fv = (unsigned)v < fv ? (unsigned)v : fv;
       cnt++;
@@ -126,36 +128,42 @@ __global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int
   }
   if (unit == 0 && lane == 0) csize[n] = 0;
   cnt = sbx_wave_sum(cnt);
+  top = sbx_wave_sum(top);
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
   // per-unit partials, reduced by k_deg_reduce: three adds per workgroup on one line of RcmDev — 3 K adds at ~7 ns
   // apiece whoever issues them — were 20 of this kernel's 31 us, at the head of every RCM call
-  if (lane == 0 && unit < DEG_UNITS) ucnt[unit] = cnt, ucnt[DEG_UNITS + unit] = mx, ucnt[2 * DEG_UNITS + unit] = fv;
+  if (lane == 0 && unit < DEG_UNITS)
+    ucnt[unit] = cnt, ucnt[DEG_UNITS + unit] = mx, ucnt[2 * DEG_UNITS + unit] = fv, ucnt[3 * DEG_UNITS + unit] = top;
 }
 
 __global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict__ ucnt, RcmDev *__restrict__ dv) {
-  __shared__ unsigned s_mx[16], s_fv[16], s_cnt[16];
+  __shared__ unsigned s_mx[16], s_fv[16], s_cnt[16], s_top[16];
   for (unsigned i = threadIdx.x; i < sizeof(RcmDev) / sizeof(unsigned); i += 1024) ((unsigned *)dv)[i] = 0;  // the call's state
-  unsigned mx = 0, fv = UNSEEN, cnt = 0;
+  unsigned mx = 0, fv = UNSEEN, cnt = 0, top = 0;
   for (int u = threadIdx.x; u < DEG_UNITS; u += 1024) {
     cnt += ucnt[u];
+    top += ucnt[3 * DEG_UNITS + u];
     mx = ucnt[DEG_UNITS + u] > mx ? ucnt[DEG_UNITS + u] : mx;
     fv = ucnt[2 * DEG_UNITS + u] < fv ? ucnt[2 * DEG_UNITS + u] : fv;
   }
   cnt = sbx_wave_sum(cnt);
+  top = sbx_wave_sum(top);
   mx = sbx_wave_max(mx);
   fv = sbx_wave_min(fv);
-  if (sbx_lane() == 0) s_mx[threadIdx.x >> 6] = mx, s_fv[threadIdx.x >> 6] = fv, s_cnt[threadIdx.x >> 6] = cnt;
+  if (sbx_lane() == 0) s_mx[threadIdx.x >> 6] = mx, s_fv[threadIdx.x >> 6] = fv, s_cnt[threadIdx.x >> 6] = cnt, s_top[threadIdx.x >> 6] = top;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 16; i++) {
       mx = s_mx[i] > mx ? s_mx[i] : mx;
       fv = s_fv[i] < fv ? s_fv[i] : fv;
       cnt += s_cnt[i];
+      top += s_top[i];
     }
     dv->max_deg = mx;
     dv->first_vertex = fv;
     dv->n_nonempty = cnt;
+    dv->n_top = top;
   }
 }
 
@@ -3103,7 +3111,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   const size_t bm_bytes = (size_t)((n + 31) / 32) * sizeof(unsigned);
   // (1) global (degree,id) rank used by the Cuthill-McKee keys; first non-isolated vertex
   unsigned *ucnt = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS * 3, &ucnt));  // per unit: non-empty rows, largest degree, first non-empty vertex
+  SBX_TRY(sbx_salloc(h, (size_t)DEG_UNITS * 4, &ucnt));  // per unit: non-empty rows, largest degree, first non-empty vertex, rows of 255+ entries
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, csize, dist, ppos);
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_reduce, dim3(1), dim3(1024), (const unsigned *)ucnt, dv);
   SBX_LAUNCH_CHECK(h);
@@ -3136,19 +3144,29 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       }
       h->rs_override = slot;
     }
-    sbx_radix_pass passes[16];
-    const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
-    int in_b = 0;
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(DEG_UNITS / 4), dim3(256), rp, n, (const unsigned *)ucnt, dkey_a,
-                did_a);
-    int rc = hipGetLastError() == hipSuccess ? SBX_OK : SBX_ERR_HIP;
-    if (rc == SBX_OK) rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n_ranked, passes, np, &in_b);
-    dorder = in_b ? did_b : did_a;
-    b.dorder = dorder;
-    if (rc == SBX_OK && n_ranked > 0) {
-      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(sbx_grid_for(n_ranked, 256, 8192)), dim3(256), dorder,
-                  drank, n_ranked);
-      if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
+    int rc = SBX_OK;
+    static const bool rank_radix = getenv("SBX_RCM_RANK_RADIX") && atoi(getenv("SBX_RCM_RANK_RADIX")) != 0;
+    if (!rank_radix) {
+      // one stable counting pass on min(degree, 255) over the rows in id order + the last bucket by its full degree
+      // (sbx_degree.hip): 0.09 ms where the generic sort of (degree, id) pairs below takes 0.31
+      rc = sbx_degree_ranks(h, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
+      dorder = did_a;
+      b.dorder = dorder;
+    } else {
+      sbx_radix_pass passes[16];
+      const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
+      int in_b = 0;
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(DEG_UNITS / 4), dim3(256), rp, n, (const unsigned *)ucnt, dkey_a,
+                  did_a);
+      rc = hipGetLastError() == hipSuccess ? SBX_OK : SBX_ERR_HIP;
+      if (rc == SBX_OK) rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n_ranked, passes, np, &in_b);
+      dorder = in_b ? did_b : did_a;
+      b.dorder = dorder;
+      if (rc == SBX_OK && n_ranked > 0) {
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(sbx_grid_for(n_ranked, 256, 8192)), dim3(256), dorder,
+                    drank, n_ranked);
+        if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
+      }
     }
     if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
     h->stream = main_stream;

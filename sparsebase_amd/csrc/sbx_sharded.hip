@@ -212,18 +212,32 @@ int stitch(sbx_handle_t h, sbx_comm_t comm, const Splits &sp, int64_t chunk, int
   SBX_TRY(sbx_salloc(h, (size_t)world + 3, &offs));
   SBX_TRY(sbx_salloc(h, (size_t)chunk, &send));
   SBX_TRY(sbx_salloc(h, (size_t)chunk * world, &gathered));
+  // From here on a local failure (a launch that did not go out, a collective that reported an error) does not return
+  // before BOTH collectives have been entered: the peers are inside them and would wait for ever.  The first failure is
+  // kept and returned at the end.  (Not covered: a failure of the five small allocations above, and a device that has
+  // stopped executing altogether — include/sbx.h, "Sharded calls".)
+  int first_rc = SBX_OK;
+  char first_err[sizeof(h->err)];
+  first_err[0] = 0;
+  auto note = [&](int rc, const char *what) {
+    if (rc != SBX_OK && first_rc == SBX_OK) {
+      first_rc = rc;
+      snprintf(first_err, sizeof(first_err), "sharded call: %s", what);
+    }
+  };
   // (1) nnz totals + status words -> offsets of the shards in the global entry space (on the device)
   SBX_KLAUNCH(h, SBX_K_MISC, k_set_rec, dim3(1), dim3(1), mine, local_nnz, (int64_t)status);
-  SBX_LAUNCH_CHECK(h);
+  if (hipGetLastError() != hipSuccess) note(SBX_ERR_HIP, "launch of the shard record kernel failed");
   if (comm->allgather(comm->user, mine, recs, sizeof(ShardRec), (void *)h->stream) != SBX_OK)
-    SBX_FAIL(h, SBX_ERR_HIP, "all-gather of the shard totals failed");
+    note(SBX_ERR_HIP, "all-gather of the shard totals failed");
   SBX_KLAUNCH(h, SBX_K_MISC, k_shard_offsets, dim3(1), dim3(1), (const ShardRec *)recs, world, (int)(8 * sizeof(I)), offs);
   // (2) row_ptr segments in padded equal chunks (the all-gatherv of SURVEY §8e), then every rank assembles the whole
   SBX_KLAUNCH(h, SBX_K_MISC, k_seg_prepare<I>, dim3(sbx_grid_for(chunk, 256, 4096)), dim3(256), local, rows,
               (const int64_t *)(offs + rank), send, chunk);
-  SBX_LAUNCH_CHECK(h);
+  if (hipGetLastError() != hipSuccess) note(SBX_ERR_HIP, "launch of the segment kernels failed");
   if (comm->allgather(comm->user, send, gathered, sizeof(I) * (size_t)chunk, (void *)h->stream) != SBX_OK)
-    SBX_FAIL(h, SBX_ERR_HIP, "all-gather of the row_ptr segments failed");
+    note(SBX_ERR_HIP, "all-gather of the row_ptr segments failed");
+  if (first_rc != SBX_OK) SBX_FAIL(h, first_rc, "%s", first_err);
   SBX_KLAUNCH(h, SBX_K_MISC, k_stitch<I>, dim3(sbx_grid_for(n + 1, 256, 8192)), dim3(256), (const I *)gathered, chunk, sp,
               world, n, (const int64_t *)(offs + world), row_ptr_out);
   SBX_LAUNCH_CHECK(h);
@@ -277,10 +291,16 @@ __global__ __launch_bounds__(256) void k_add_const(I *__restrict__ a, int64_t co
 // reaches k * total / world
 template <typename I>
 __global__ __launch_bounds__(256) void k_new_row_lengths(const I *__restrict__ rp, const I *__restrict__ row_order, int64_t n,
-                                                         int64_t *__restrict__ len) {
+                                                         int64_t *__restrict__ len, int64_t *__restrict__ bad) {
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; u < n; u += stride) len[row_order ? (int64_t)row_order[u] : u] = (int64_t)(rp[u + 1] - rp[u]);
+  bool outside = false;
+  for (; u < n; u += stride) {
+    const int64_t r = row_order ? (int64_t)row_order[u] : u;
+    if (r < 0 || r >= n) outside = true;  // (an order vector of the caller's: never written through)
+    else len[r] = (int64_t)(rp[u + 1] - rp[u]);
+  }
+  if (__any(outside) && sbx_lane() == 0) *bad = 1;
 }
 __global__ void k_balanced_splits(const int64_t *__restrict__ prefix, int64_t n, const int64_t *__restrict__ total,
                                   int world, int64_t *__restrict__ out) {
@@ -539,19 +559,26 @@ extern "C" int sbx_balanced_row_splits(sbx_handle_t h, sbx_index_type it, int64_
   int64_t *len = nullptr, *total = nullptr, *out = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)n, &len));
   SBX_TRY(sbx_salloc(h, 1, &total));
-  SBX_TRY(sbx_salloc(h, (size_t)world + 1, &out));
+  SBX_TRY(sbx_salloc(h, (size_t)world + 2, &out));  // [world + 1]: an order entry outside [0, n) was seen
+  // (rows the order never names keep length 0: a vector that is not a permutation gives balanced splits of what it does name)
+  SBX_HIP(h, hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)n, h->stream));
+  SBX_HIP(h, hipMemsetAsync(out + world + 1, 0, sizeof(int64_t), h->stream));
   const unsigned grid = sbx_grid_for(n, 256, 8192);
   if (it == SBX_I32)
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_row_lengths<int32_t>, dim3(grid), dim3(256), (const int32_t *)row_ptr,
-                (const int32_t *)row_order, n, len);
+                (const int32_t *)row_order, n, len, out + world + 1);
   else
     SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_new_row_lengths<int64_t>, dim3(grid), dim3(256), (const int64_t *)row_ptr,
-                (const int64_t *)row_order, n, len);
+                (const int64_t *)row_order, n, len, out + world + 1);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(sbx_exclusive_scan_i64(h, len, len, n, total));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_balanced_splits, dim3(1), dim3(MAX_WORLD + 1), (const int64_t *)len, n,
               (const int64_t *)total, world, out);
   SBX_LAUNCH_CHECK(h);
-  SBX_TRY(sbx_readback(h, splits_host, out, sizeof(int64_t) * (size_t)(world + 1)));
+  std::vector<int64_t> res((size_t)world + 2, 0);
+  SBX_TRY(sbx_readback(h, res.data(), out, sizeof(int64_t) * (size_t)(world + 2)));
+  if (res[(size_t)world + 1] != 0)
+    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_balanced_row_splits: row_order holds an entry outside [0, n)");
+  for (int k = 0; k <= world; k++) splits_host[k] = res[(size_t)k];
   return SBX_OK;
 }

@@ -5,6 +5,13 @@
 // Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time]
 // --time repeats the call five times and prints the last (warm) call's wall time in seconds on stdout (gray: and, on a
 // second line, the ms of its device key stage, of the copy of the keys to the host and of the host ordering stage)
+//        reorder_cli pipeline <row_ptr.bin> <col.bin> <out.bin> <n> <m>
+// the canonical pipeline of the reference's experiment helper (experiment/experiment_helper.h:81-97) on a device-
+// resident HIPCSR<int, int, float>: ReorderBase::Reorder<RCMReorder> -> ReorderBase::Permute2D<HIPCSR> ->
+// Convert<HIPCSR>; warm calls, prints "reorder_ms permute2d_ms convert_ms" of the best of five rounds (what a C++ caller
+// of the boundary pays per call: dispatch, handle lookup, the order vector's trip to the host and back — the API hands
+// it over as a host array, as the reference does —, allocation of the result) and writes the order
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -24,12 +31,50 @@ static std::vector<int> read_bin(const char *path) {
   return v;
 }
 
+static int pipeline(const std::vector<int> &rp, const std::vector<int> &col, int n, int m, const char *out_path) {
+  using clock = std::chrono::steady_clock;
+  auto ms = [](clock::time_point a) { return std::chrono::duration<double, std::milli>(clock::now() - a).count(); };
+  utils::Logger::set_level(utils::LOG_LVL_NONE);
+  std::vector<float> val(col.size());
+  for (size_t i = 0; i < val.size(); i++) val[i] = (float)(i % 1021);
+  format::CSR<int, int, float> csr(n, m, const_cast<int *>(rp.data()), const_cast<int *>(col.data()), val.data(),
+                                   format::kNotOwned, true);
+  context::HIPContext gpu(0);
+  std::unique_ptr<format::HIPCSR<int, int, float>> dcsr(csr.Convert<format::HIPCSR>(&gpu));
+  std::vector<context::Context *> ctxs{&gpu};
+  double best[3] = {1e30, 1e30, 1e30};
+  int *order = nullptr;
+  for (int round = 0; round < 7; round++) {  // (two rounds to settle the scratch arena, five measured)
+    delete[] order;
+    auto t = clock::now();
+    order = bases::ReorderBase::Reorder<reorder::RCMReorder>({}, dcsr.get(), ctxs, true);
+    const double t_reorder = ms(t);
+    t = clock::now();
+    auto *perm = bases::ReorderBase::Permute2D<format::HIPCSR>(order, dcsr.get(), ctxs, true);
+    const double t_permute = ms(t);
+    t = clock::now();
+    auto *conv = perm->Convert<format::HIPCSR>(&gpu);  // (the experiment helper's third step; same format: no copy is due)
+    const double t_convert = ms(t);
+    if (round >= 2) {
+      best[0] = std::min(best[0], t_reorder), best[1] = std::min(best[1], t_permute), best[2] = std::min(best[2], t_convert);
+    }
+    if ((void *)conv != (void *)perm) delete conv;
+    delete perm;
+  }
+  std::printf("%.4f %.4f %.4f\n", best[0], best[1], best[2]);
+  std::ofstream out(out_path, std::ios::binary);
+  out.write((const char *)order, (size_t)n * sizeof(int));
+  delete[] order;
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 7) return 1;
   const std::string kind = argv[1];
   auto rp = read_bin(argv[2]);
   auto col = read_bin(argv[3]);
   const int n = atoi(argv[5]), m = atoi(argv[6]);
+  if (kind == "pipeline") return pipeline(rp, col, n, m, argv[4]);
   bool on_device = false, timed = false;
   for (int i = 7; i < argc; i++) {
     on_device |= !strcmp(argv[i], "--device");

@@ -49,7 +49,7 @@ class GrayReorder : public Reorderer<IDType> {
   /// with a blocking read-back), the copy of degrees and keys to the host, the host ordering stage.  (Not in the
   /// reference: what bench.py reports as Gray end to end.)
   static double *last_stage_ms() {
-    static double ms[3] = {0, 0, 0};
+    static thread_local double ms[3] = {0, 0, 0};  // (per thread: concurrent reorder calls do not share it)
     return ms;
   }
 

@@ -13,6 +13,14 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port the OS hands out as free right now (parallel test runs must not meet on a fixed one)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _child(rank, world, port, q):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -111,7 +119,7 @@ def test_sharded_steps_two_ranks_one_gpu():
         pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
     import torch.multiprocessing as mp
     world = 2
-    port = 29800 + os.getpid() % 150
+    port = _free_port()
     ctx = mp.get_context("spawn")  # fresh interpreters: nothing GPU-related is inherited
     q = ctx.Queue()
     procs = [ctx.Process(target=_child, args=(r, world, port, q)) for r in range(world)]
@@ -166,7 +174,7 @@ def test_bench_eight_ranks_on_one_gpu():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
     env = dict(os.environ, SBX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29500 + os.getpid() % 200
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scale", "16", "--steps", "2",
            "--warmup", "1", "--leg-timeout", "240"]
