@@ -50,7 +50,7 @@ __device__ __forceinline__ void block_copy_bytes(char *__restrict__ dst, const c
 }
 
 // ------------------------------------------------------------------ A1 check
-// *flags: bit 0 = some record is out of (row, column) order; bit 1 = some coordinate lies outside [0, n) x [0, m) (only
+// flags[0] = some record is out of (row, column) order; flags[1] = some coordinate lies outside [0, n) x [0, m) (only
 // looked for when n >= 0: the constructor sort's hybrid path packs coordinates into bit fields sized by n and m and
 // takes malformed input — which neither this library nor the reference validates — through the plain sort instead)
 template <typename I>
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(CV_THREADS) void k_coo_is_sorted(const I *__restric
     bad |= (pr > r) || (pr == r && pc > c);
     if (n >= 0) outside |= r < 0 || (int64_t)r >= n || c < 0 || (int64_t)c >= m;
   }
-  if (__any(bad) && sbx_lane() == 0) atomicOr(flags, 1);
-  if (__any(outside) && sbx_lane() == 0) atomicOr(flags, 2);
+  // (plain stores of the same value: on shuffled input every wave raises the flag, and 10^5 atomics on one word are 0.3 ms)
+  if (__any(bad) && sbx_lane() == 0) flags[0] = 1;
+  if (__any(outside) && sbx_lane() == 0) flags[1] = 1;
 }
 
 // ------------------------------------------------------------------ A1 sort helpers
@@ -398,15 +399,15 @@ static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, con
   if (in_range_host) *in_range_host = 1;
   if (nnz == 0) return SBX_OK;
   int *flag = nullptr;
-  SBX_TRY(sbx_salloc(h, 1, &flag));
-  SBX_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  SBX_TRY(sbx_salloc(h, 2, &flag));
+  SBX_HIP(h, hipMemsetAsync(flag, 0, 2 * sizeof(int), h->stream));
   SBX_KLAUNCH(h, SBX_K_CHECK, k_coo_is_sorted<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS),
               (const I *)row, (const I *)col, nnz, flag, n, m);
   SBX_LAUNCH_CHECK(h);
-  int f = 0;
-  SBX_TRY(sbx_readback(h, &f, flag, sizeof(int)));
-  *sorted_host = !(f & 1);
-  if (in_range_host) *in_range_host = !(f & 2);
+  int f[2] = {0, 0};
+  SBX_TRY(sbx_readback(h, f, flag, 2 * sizeof(int)));
+  *sorted_host = !f[0];
+  if (in_range_host) *in_range_host = !f[1];
   return SBX_OK;
 }
 

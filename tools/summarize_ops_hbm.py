@@ -6,7 +6,7 @@ usage: summarize_ops_hbm.py <kernel_stats.csv> <fetch_dir> <write_dir> <out.json
 import collections, csv, glob, json, sys
 # (first match wins: longer names in front of their prefixes)
 KERNELS = ["k_coo_to_csr", "k_csr_to_coo", "k_permute_copy", "k_permute_tile_radix", "k_permute_tile",
-           "k_permute_block_rows", "k_permute_rows_radix", "k_long_seg_gather", "k_long_seg_partition", "k_gray_tile",
+           "k_permute_block_rows", "k_rows_quad", "k_permute_rows_radix", "k_long_seg_gather", "k_long_seg_partition", "k_gray_tile",
            "k_gray_rows_short", "k_onesweep_pass", "k_bandwidth_csr", "k_profile_csr", "k_tile_spans",
            "k_degrees", "k_rowwise_prep", "k_classify_scan"]
 

@@ -15,7 +15,7 @@ GROUPS = [("k_bfs_bottom_up", "bfs_bottom_up"), ("k_ubfs_bottom_up", "bfs_bottom
           ("k_ubfs_", "rcm_misc"), ("k_classify_scan", "permute_prep"),
           ("k_bfs_expand_heavy", "bfs_heavy"), ("k_bfs_expand", "bfs_expand"),
           ("k_bfs_small_levels", "bfs_small_levels"), ("k_permute_tile", "permute_tile"), ("k_permute_copy", "permute_tile"),
-          ("k_permute_block_rows", "permute_block"), ("k_permute_rows_radix", "permute_block"), ("k_long_", "permute_long"),
+          ("k_permute_block_rows", "permute_block"), ("k_rows_quad", "permute_block"), ("k_permute_rows_radix", "permute_block"), ("k_long_", "permute_long"),
           ("k_rowwise_prep", "permute_prep"), ("k_rec_classify", "permute_prep"), ("k_tile_first", "permute_prep"),
           ("k_onesweep_pass", "radix_scatter"), ("k_onesweep_hist", "radix_hist"), ("k_onesweep_bins", "radix_hist"),
           ("k_scan_", "scan"), ("k_cc_", "cc"), ("k_classify", "cc"), ("k_level_", "level_order"),
