@@ -366,7 +366,12 @@ int sbx_permute_csr_rows_nnz(sbx_handle_t h, sbx_index_type it, int64_t n, const
  * the host waits once, behind them (the shards' offsets are computed on the device from the
  * gathered totals).  A rank whose own part fails (a slab beyond out_capacity, ...) still takes
  * part in both collectives with a status word, so every rank of the call returns an error
- * instead of waiting for ever (SBX_ERR_INTERNAL "rank r reported a failure" on the others). */
+ * instead of waiting for ever (SBX_ERR_INTERNAL "rank r reported a failure" on the others); a
+ * launch or a collective that reports an error between the two all-gathers is remembered and the
+ * second one is still entered.  Not covered: a rank that cannot allocate the call's few KB +
+ * 2 x (largest range + 1) x world index words of scratch before the first collective, or whose
+ * device has stopped executing — its peers then wait inside the collective (the RCCL watchdog's
+ * business, as for any collective). */
 int sbx_permute_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index_type it, sbx_value_type vt,
                             int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
                             const void *col, const void *val, const void *row_order,
