@@ -524,6 +524,45 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
 
 
+def test_permute_quad_class_boundaries(ops, oracle):
+    """k_rows_quad (sbx_rowsort.h): every class boundary and every remainder modulo the quad (a row's last, partial quad is
+    cut by the row's buffer descriptor, not by a predicate), the last row of the arrays ending in a partial quad (the
+    16-byte accesses of its last lane reach past the allocation's logical end), a bucket of more than eight equal-ish
+    columns (the ranking loop), more than 96 (the radix list), every value width, distinct and duplicate columns, a random
+    and a clustered (run-structured, RCM-like) column map."""
+    g = np.random.default_rng(41)
+    m = 1 << 18
+    lens = [129, 130, 131, 132, 255, 256, 257, 258, 259, 260, 511, 512, 513, 1023, 1024, 1025, 1026, 1027, 2047, 2048, 2049,
+            4095, 4096, 4097, 4098, 8189, 8190, 8191, 8192, 700, 3001, 6002, 1, 0, 5, 300, 1301, 2302, 8003]
+    n = len(lens)
+    rows = [np.sort(g.choice(m, l, replace=False)) for l in lens]
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(rows).astype(np.int32)
+    val = g.integers(-1000, 1000, len(col)).astype(np.int32)
+    ro = synth.random_permutation(n, 3)
+    ro[-1], ro[int(np.argmax(ro == n - 1))] = n - 1, ro[-1]   # the last old row (8003 = 3 mod 4) stays the last new row
+    rnd = synth.random_permutation(m, 4)
+    runs = np.arange(m, dtype=np.int64)                        # runs of 977 consecutive labels, the runs shuffled
+    blocks = g.permutation((m + 976) // 977)
+    clustered = np.concatenate([np.arange(b * 977, min(m, (b + 1) * 977)) for b in blocks])[:m]
+    inv = np.empty(m, np.int64)
+    inv[clustered] = runs
+    for co in (rnd, inv.astype(np.int32)):
+        for v in (val.astype(np.float32), None, val.astype(np.float64)):
+            same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
+    # equal columns: 9, 40 and 200 copies of one column inside rows of every big class (ranking loop / radix list);
+    # duplicates end in value order (csr.cc:143-156)
+    rows2 = []
+    for l, rep in ((300, 9), (900, 40), (3000, 200), (7000, 9), (200, 97), (5000, 1200)):
+        rows2.append(np.sort(np.concatenate([g.choice(m, l - rep, replace=False), np.full(rep, int(g.integers(0, m)))])))
+    rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(np.int32)
+    col2 = np.concatenate(rows2).astype(np.int32)
+    ro2 = synth.random_permutation(len(rows2), 5)
+    for v2 in (g.integers(-9, 9, len(col2)).astype(np.int32), g.random(len(col2)).astype(np.float32), None):
+        same(ops.permute_csr(len(rows2), m, dev(rp2), dev(col2), dev(v2), dev(ro2), dev(rnd)),
+             oracle.permute_csr(rp2, col2, v2, ro2, rnd))
+
+
 def test_permute_long_row_segments(ops, oracle):
     """Rows above the one-workgroup capacity under a column map (sbx_permute.hip, k_long_seg_*): split into column-range
     segments that are sorted in LDS.  Covers: rows of 8 K .. 300 K entries (8 .. 256 segments; chunks of the compact buffer
