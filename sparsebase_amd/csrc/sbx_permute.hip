@@ -2019,6 +2019,27 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
 // CU take 399 / 401 / 440 us, with the RCM order (every row takes the second, interpolating level: more LDS round trips
 // to hide) 538 / 484 / 463 us; 4 waves are 25 - 60 % slower, more than the 16 the registers admit queue workgroups
 // behind each other.  Orders that come out of a reordering are the common case: 16.
+// Side stream of a row class (0: the stage's class stream itself; 1 belongs to the long rows).  HIP feeds its streams
+// through four hardware queues by default, so some of the stage's eight streams share a queue with each other or with
+// the caller's stream, and kernels that look concurrent wait behind unrelated ones (a kernel trace of the stage,
+// tools/permute_span.py, shows it).  More queues do not help — GPU_MAX_HW_QUEUES=8 / 16: the stage is 3 - 6 % SLOWER,
+// persistent kernels that all run at once fight for the CUs' LDS and wave slots — and fewer streams are a coin toss:
+// all classes on one stream 1.32 / 1.49 ms (random / RCM order) on one box and 1.34 / 1.44 on another, where the six
+// streams below gave 1.31 / 1.42 and 1.35 / 1.46; big and small classes on two streams 1.34 / 1.40 and 1.40 / 1.50
+// (tools/permute_streams.sh).  Left at one stream per class.  SBX_PERMUTE_CLASS_STREAMS: six digits, class 0 ... 5.
+static int class_stream(int cls) {
+  static int map[BR_CLASSES] = {-1};
+  if (map[0] < 0) {
+    const char *e = getenv("SBX_PERMUTE_CLASS_STREAMS");
+    const char *d = (e && strlen(e) == BR_CLASSES) ? e : "023456";
+    for (int c = 0; c < BR_CLASSES; c++) {
+      const int v = d[c] - '0';
+      map[c] = (v < 0 || v >= SBX_AUX_STREAMS || v == 1) ? 0 : v;
+    }
+  }
+  return map[cls];
+}
+
 static int rq_waves_per_cu() {
   static const int f = getenv("SBX_PERMUTE_ROW_WAVES") ? atoi(getenv("SBX_PERMUTE_ROW_WAVES")) : 16;
   return f < 1 ? 1 : f;
@@ -2059,7 +2080,7 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
     const unsigned per_cu = by_lds < by_waves ? by_lds : by_waves;                                                \
     unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu) * (unsigned)permute_grid_factor();           \
     if (grid > n_block[CLS]) grid = n_block[CLS];                                                                 \
-    const int si = (CLS) == 0 ? 0 : (CLS) + 1;                                                                    \
+    const int si = class_stream(CLS);                                                                             \
     if (fork && si) {                                                                                             \
       h->stream = h->aux_stream[si];                                                                              \
       SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[0], 0));                                              \
@@ -2088,7 +2109,7 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
     const unsigned per_cu = by_lds < by_waves ? by_lds : by_waves;                                                \
     unsigned grid = (unsigned)h->num_cus * (per_cu < 1 ? 1 : per_cu) * (unsigned)permute_grid_factor();           \
     if (grid > n_block[CLS]) grid = n_block[CLS];                                                                 \
-    const int si = (CLS) == 0 ? 0 : (CLS) + 1;                                                                    \
+    const int si = class_stream(CLS);                                                                             \
     if (fork && si) {                                                                                             \
       h->stream = h->aux_stream[si];                                                                              \
       SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[0], 0));                                              \
