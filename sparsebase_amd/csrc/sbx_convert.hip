@@ -120,6 +120,59 @@ __global__ __launch_bounds__(CV_THREADS) void k_coo_bucket_unpack(const int32_t 
   }
 }
 
+// ---- 64-bit index arrays: the same sort on packed keys (row << colbits | column; needs rowbits + colbits <= 64) ----
+__global__ __launch_bounds__(CV_THREADS) void k_pack_rc64(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                                          int colbits, uint64_t *__restrict__ key, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) key[i] = (colbits < 64 ? (uint64_t)row[i] << colbits : 0ull) | (uint64_t)col[i];
+}
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_unpack_rc64(const uint64_t *__restrict__ key, const char *__restrict__ vsorted,
+                                                            int colbits, int64_t *__restrict__ row,
+                                                            int64_t *__restrict__ col, char *__restrict__ val, int64_t nnz) {
+  typedef typename ValT<VB>::type V;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t cmask = colbits >= 64 ? ~0ull : (1ull << colbits) - 1ull;
+  for (; i < nnz; i += stride) {
+    const uint64_t k = key[i];
+    row[i] = (int64_t)(colbits < 64 ? k >> colbits : 0ull);
+    col[i] = (int64_t)(k & cmask);
+    if (VB) ((V *)val)[i] = ((const V *)vsorted)[i];  // (VB = 0: the values are already where they belong)
+  }
+}
+// hybrid sort, 64-bit arrays: group id and in-group key of a record from its packed key (grouped by the digit passes)
+__global__ __launch_bounds__(CV_THREADS) void k_coo_bucket_keys64(const uint64_t *__restrict__ packed, int lowbits,
+                                                                  int32_t *__restrict__ hi, int32_t *__restrict__ key,
+                                                                  int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t lmask = (1ull << lowbits) - 1ull;
+  for (; i < nnz; i += stride) {
+    const uint64_t k = packed[i];
+    hi[i] = (int32_t)(k >> lowbits);
+    key[i] = (int32_t)(k & lmask);
+  }
+}
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_coo_bucket_unpack64(const int32_t *__restrict__ hi,
+                                                                    const int32_t *__restrict__ key,
+                                                                    const char *__restrict__ vsorted, int s, int colbits,
+                                                                    int64_t *__restrict__ row, int64_t *__restrict__ col,
+                                                                    char *__restrict__ val, int64_t nnz) {
+  typedef typename ValT<VB>::type V;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint32_t cmask = (1u << colbits) - 1u;
+  for (; i < nnz; i += stride) {
+    const uint32_t k = (uint32_t)key[i];
+    row[i] = ((int64_t)(uint32_t)hi[i] << s) | (int64_t)(k >> colbits);
+    col[i] = (int64_t)(k & cmask);
+    if (VB) ((V *)val)[i] = ((const V *)vsorted)[i];
+  }
+}
+
 template <typename I>
 __global__ __launch_bounds__(CV_THREADS) void k_unpack_rc(const uint64_t *__restrict__ key, I *__restrict__ row,
                                                           I *__restrict__ col, int64_t nnz) {
@@ -449,11 +502,85 @@ extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n,
   return csr_rows_sorted_typed<int32_t>(h, n, row_ptr, col, sorted_host);
 }
 
+// format/coo.cc:96-157 for 64-bit index arrays, native: coordinates of any size inside [0, n) x [0, m) as long as a
+// record's (row, column) packs into 64 bits.  One pack pass (16 -> 8 bytes per record), then the 32-bit sort's plan on
+// the packed keys: digit passes over the row's leading bits + the LDS sort of the groups when the rest of the key fits
+// 31 bits, the plain LSD sort otherwise; the last kernel writes 64-bit rows and columns back where they came from.
+static int coo_sort_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
+                        void *val) {
+  const int vb = val ? sbx_value_bytes(vt) : 0;
+  SBX_REQUIRE(h, vb >= 0, "unknown value type");
+  if (nnz <= 1) return SBX_OK;
+  int sorted = 0, in_range = 1;
+  SBX_TRY(coo_is_sorted_typed<int64_t>(h, nnz, row, col, &sorted, n, m, &in_range));
+  if (sorted) return SBX_OK;
+  // (coordinates outside the matrix: the narrowing path's plain sort takes them if they fit 31 bits, and refuses the rest)
+  if (!in_range) return sbx_i64_coo_sort(h, vt, n, m, nnz, row, col, val);
+  const int colbits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), rowbits = sbx_bits_for(n > 0 ? (uint64_t)(n - 1) : 0);
+  if (colbits + rowbits > 64)
+    SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_coo_sort: %d row bits + %d column bits do not fit a 64-bit sort key", rowbits, colbits);
+  SBX_TRY(sbx_arena_begin(h));
+  NestGuard guard(h);  // (the nested calls below must not rewind the arena)
+  uint64_t *ka = nullptr, *kb = nullptr;
+  char *vtmp = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
+  if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
+  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
+  SBX_KLAUNCH(h, SBX_K_MISC, k_pack_rc64, dim3(grid), dim3(CV_THREADS), (const int64_t *)row, (const int64_t *)col, colbits,
+              ka, nnz);
+  SBX_LAUNCH_CHECK(h);
+  static const bool hybrid_on = !(getenv("SBX_COO_SORT_HYBRID") && atoi(getenv("SBX_COO_SORT_HYBRID")) == 0);
+  int p = 2;
+  if (rowbits > 16 && nnz / 65536 > 512) p = 3;
+  const int s_bits = rowbits > 8 * p ? rowbits - 8 * p : 0;
+  sbx_radix_pass msd[16], passes[16];
+  const int np = sbx_radix_plan(0, colbits + rowbits, 0, 0, passes);
+  const int np_msd = sbx_radix_plan(colbits + s_bits, colbits + rowbits, 0, 0, msd);
+  int in_b = 0;
+  if (hybrid_on && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
+    SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, msd, np_msd, &in_b));
+    const uint64_t *grouped = in_b ? kb : ka;
+    const char *vcur = in_b ? vtmp : (const char *)val;
+    char *vother = in_b ? (char *)val : vtmp;
+    int32_t *hk = nullptr, *bptr = nullptr;  // group ids | in-group keys
+    SBX_TRY(sbx_salloc(h, (size_t)nnz * 2, &hk));
+    int32_t *hi = hk, *key = hk + nnz, *ksorted = (int32_t *)(in_b ? ka : kb);
+    const int64_t groups = ((n - 1) >> s_bits) + 1;
+    SBX_TRY(sbx_salloc(h, (size_t)groups + 1, &bptr));
+    SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_keys64, dim3(grid), dim3(CV_THREADS), grouped, s_bits + colbits, hi, key, nnz);
+    SBX_TRY(sbx_coo_to_csr(h, SBX_I32, SBX_V_NONE, groups, groups, nnz, hi, nullptr, nullptr, bptr, nullptr, nullptr,
+                           SBX_FLAG_MOVE | SBX_FLAG_ROWS_SORTED));
+    SBX_TRY(sbx_sort_segments(h, vb, groups, (int64_t)1 << (s_bits + colbits), nnz, bptr, key, vcur, ksorted, vother));
+    const bool copy = vb && vother != (char *)val;
+#define UNPACK(VBX)                                                                                                     \
+  SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_unpack64<VBX>, dim3(grid), dim3(CV_THREADS), (const int32_t *)hi,             \
+              (const int32_t *)ksorted, (const char *)vother, s_bits, colbits, (int64_t *)row, (int64_t *)col, (char *)val, nnz)
+    if (!copy) UNPACK(0);
+    else if (vb == 4) UNPACK(4);
+    else UNPACK(8);
+#undef UNPACK
+    SBX_LAUNCH_CHECK(h);
+    return SBX_OK;
+  }
+  SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, passes, np, &in_b));
+  const bool copy = vb && in_b;
+#define UNPACK(VBX)                                                                                                   \
+  SBX_KLAUNCH(h, SBX_K_MISC, k_unpack_rc64<VBX>, dim3(grid), dim3(CV_THREADS), (const uint64_t *)(in_b ? kb : ka),    \
+              (const char *)vtmp, colbits, (int64_t *)row, (int64_t *)col, (char *)val, nnz)
+  if (!copy) UNPACK(0);
+  else if (vb == 4) UNPACK(4);
+  else UNPACK(8);
+#undef UNPACK
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
 extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
                             void *row, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, nnz >= 0 && n >= 0 && m >= 0 && (nnz == 0 || (row && col)), "bad argument");
-  if (it == SBX_I64) return sbx_i64_coo_sort(h, vt, n, m, nnz, row, col, val);
+  if (it == SBX_I64) return coo_sort_i64(h, vt, n, m, nnz, row, col, val);
   const int vb = val ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   if (nnz <= 1) return SBX_OK;

@@ -1,9 +1,10 @@
 // sbx_i64.hip — SBX_I64 support: 64-bit IDType/NNZType arrays (the reference's
-// <int64,int64,double> tuple).  NATIVE 64-bit kernels (index values and nnz of any size, no copies): the conversions
-// COO <-> CSR and the two sortedness checks (sbx_convert.hip), the four features (sbx_features.hip), DegreeReorder
-// (sbx_degree.hip), InversePermutation, PermuteArray and the row-wise CSR permute (sbx_permute.hip).  The entry points in THIS file — the sorts,
-// CSC, RCM, Gray keys, the CSR permute, the text parsers — narrow their index arrays to int32 scratch copies (with an
-// overflow check), run the int32 kernels and widen the index outputs back; values are opaque payload and pass
+// <int64,int64,double> tuple).  NATIVE 64-bit kernels (no copies): the conversions COO <-> CSR and the two sortedness
+// checks (sbx_convert.hip), the four features (sbx_features.hip), DegreeReorder (sbx_degree.hip), InversePermutation,
+// PermuteArray, the CSR permute with and without a column map, the CSR constructor's row sort (sbx_permute.hip) and the
+// COO constructor's sort (sbx_convert.hip).  The entry points in THIS file — CSC, RCM, Gray keys, the text parsers, and
+// the COO sort of coordinates that lie outside their matrix — narrow their index arrays to int32 scratch copies (with
+// an overflow check), run the int32 kernels and widen the index outputs back; values are opaque payload and pass
 // through untouched; arrays with entries >= 2^31 return SBX_ERR_UNSUPPORTED there.
 #include "sbx_device.h"
 #include "sbx_internal.h"
@@ -110,16 +111,6 @@ static int read_nnz_i64(sbx_handle_t h, const void *row_ptr, int64_t n, int64_t 
   return sbx_readback(h, nnz, (const int64_t *)row_ptr + n, sizeof(int64_t));
 }
 
-int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                          void *col, void *val) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_csr_sort_rows(h, SBX_I32, vt, n, m, nnz, rp, c, val));
-  return sbx_widen_i32(h, c, col, nnz);
-}
-
 int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
   I64_BEGIN();
@@ -194,27 +185,3 @@ int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, con
   SBX_TRY(sbx_gray_row_keys(h, SBX_I32, n, m, nnz, rp, c, resolution, nnz_threshold, deg, key_out, counts_host));
   return sbx_widen_i32(h, deg, degree_out, n);
 }
-
-int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                             const void *col, const void *val, const void *row_order, const void *col_order,
-                             int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
-                             int64_t out_capacity, int64_t *shard_nnz_host) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  NARROW(ro, row_order, n);
-  int32_t *co = nullptr;
-  if (col_order == row_order && n == m) co = ro;
-  else SBX_TRY(sbx_narrow_i64(h, col_order, m, &co, ovf));
-  const int64_t nr = row_end - row_begin;
-  SCRATCH32(rpo, nr + 1, true);
-  SCRATCH32(colo, out_capacity, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  int64_t got = 0;
-  SBX_TRY(sbx_permute_csr_rows(h, SBX_I32, vt, n, m, nnz, rp, c, val, ro, co, row_begin, row_end, rpo, colo, val_out,
-                               out_capacity, &got));
-  if (shard_nnz_host) *shard_nnz_host = got;
-  SBX_TRY(sbx_widen_i32(h, rpo, row_ptr_out, nr + 1));
-  return sbx_widen_i32(h, colo, col_out, got);
-}
-

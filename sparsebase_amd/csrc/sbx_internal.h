@@ -257,8 +257,6 @@ int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev);     // synchron
 void sbx_i64_end(sbx_handle_t h);
 int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
                      void *val);
-int sbx_i64_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                          void *col, void *val);
 int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
                        const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
 int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
@@ -274,8 +272,4 @@ int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_
 int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
                           int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
                           int64_t *counts_host);
-int sbx_i64_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                             const void *col, const void *val, const void *row_order, const void *col_order,
-                             int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
-                             int64_t out_capacity, int64_t *shard_nnz_host);
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);

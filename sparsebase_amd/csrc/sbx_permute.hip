@@ -2058,11 +2058,10 @@ static bool permute_quad_rows() {  // SBX_PERMUTE_QUAD_ROWS=0: round 3's k_permu
 }
 
 // rows of PT_LMAX < length <= 8 K: one workgroup per row, by capacity class
-template <int VB>
-int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
-                    const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *block_rows,
+template <typename I, int VB>
+int block_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char *val_in, const I *col_order,
+                    const I *rpo, I *col_out, char *val_out, int64_t m, const I *block_rows,
                     const unsigned *n_block, int64_t block_stride, int64_t block_nnz, PermState *st, bool fork) {
-  typedef int32_t I;
   // fork: h->stream is side stream 0, which already waits for the fork event; the classes spread over side streams
   // 0, 2, 3, ... (1 belongs to the long rows) and the radix kernel behind them joins them again on stream 0
   hipStream_t base = h->stream;
@@ -2099,7 +2098,8 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
   // k_rows_quad: T threads x Q quads = the class capacity; the column map must fit a buffer descriptor (4 GB)
   // (without a column map — csr_sort_rows, the hybrid COO sort's groups — there is no gather to hide the sort behind and
   // round 3's kernels, lighter in registers, measure 6 % better on C2B: 0.536 against 0.570 ms)
-  const bool quad = permute_quad_rows() && col_order && (uint64_t)m * 4 <= 0xFFFFFFFCull;
+  // (64-bit index arrays: round 3's kernels, which read and write the columns through plain pointers of either width)
+  const bool quad = sizeof(I) == 4 && permute_quad_rows() && col_order && (uint64_t)m * 4 <= 0xFFFFFFFCull;
   const unsigned table_bytes = col_order ? (unsigned)((uint64_t)m * 4) : 0u;
 #define QUAD_ROWS(CLS, THREADS, QUADS, MINW)                                                                      \
   if (n_block[CLS]) {                                                                                             \
@@ -2124,7 +2124,7 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
       if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
     }                                                                                                             \
   }
-  if (quad) {
+  if constexpr (sizeof(I) == 4) if (quad) {
     static const int big = getenv("SBX_PERMUTE_BIG") ? atoi(getenv("SBX_PERMUTE_BIG")) : 0;  // (tuning: shape of the two big classes)
     QUAD_ROWS(0, 64, 1, 1);
     // the 512-slot class keeps round 3's kernel: one wave per row and two quad steps need 124 registers (16 waves per
@@ -2150,7 +2150,8 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
         QUAD_ROWS(5, 1024, 2, 1);
       }
     }
-  } else {
+  }
+  if (!quad) {
     // threads per class, measured on the bench matrix: one wave (no s_barrier at all) up to 512 entries, 8 entries per
     // thread up to 2048, 4 for 4096 (8 per thread there: +5 %)
     BLOCK_ROWS(0, 64);
@@ -2171,11 +2172,10 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, cons
 }
 
 // longer rows: flat gather, device radix sort on (row rank, column), scatter back
-template <int VB>
-int long_rows_radix_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
-                   const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *long_rows,
+template <typename I, int VB>
+int long_rows_radix_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char *val_in, const I *col_order,
+                   const I *rpo, I *col_out, char *val_out, int64_t m, const I *long_rows,
                    unsigned n_long, int64_t long_nnz, PermState *st) {
-  typedef int32_t I;
   uint32_t *loff = nullptr;
   uint64_t *ka = nullptr, *kb = nullptr;
   char *pa = nullptr, *pb = nullptr;
@@ -2214,13 +2214,12 @@ static bool permute_long_segments() {  // SBX_PERMUTE_LONG_SEGMENTS=0: long rows
 
 // longer rows of a permute that relabels columns: segments sorted in LDS (kernels above); what that path declines
 // (rows already in order, overfull segments) and every long row of the other callers goes through the radix path
-template <int VB>
-int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const char *val_in, const int32_t *col_order,
-                   const int32_t *rpo, int32_t *col_out, char *val_out, int64_t m, const int32_t *long_rows,
+template <typename I, int VB>
+int long_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char *val_in, const I *col_order,
+                   const I *rpo, I *col_out, char *val_out, int64_t m, const I *long_rows,
                    unsigned n_long, int64_t long_nnz, PermState *st) {
-  typedef int32_t I;
   if (!col_order || !permute_long_segments() || (permute_force_radix() & 1) || long_nnz >= ((int64_t)1 << 31))
-    return long_rows_radix_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
+    return long_rows_radix_path<I, VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
                                     long_nnz, st);
   const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
   const int seg_cap = BlockRowCap<VB>::value;
@@ -2269,7 +2268,9 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
               (const unsigned *)row_skip, c2, v2);
   // the segments: virtual rows of the one-workgroup-per-row kernel (columns already relabelled: no column map)
   const int force = permute_force_radix() & 0xFE;
-  if (permute_quad_rows()) {
+  bool seg_quad = false;
+  if constexpr (sizeof(I) == 4) seg_quad = permute_quad_rows();
+  if constexpr (sizeof(I) == 4) if (seg_quad) {
     // (512 threads, two workgroups per CU for segments of up to 4096 entries; 1024 threads for the longer ones)
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_rows_quad<I, VB, 512, 2, (VB == 8 ? 2 : 4)>), dim3(2 * (unsigned)h->num_cus), dim3(512),
                 (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
@@ -2280,7 +2281,8 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
                   (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
                   (const unsigned *)&st->n_seg[1], 0u);
     }
-  } else {
+  }
+  if (!seg_quad) {
     // (1024-thread workgroups: one resident per CU, as in block_rows_path)
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
                 (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
@@ -2303,19 +2305,114 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const int32_t *col_in, const
     fprintf(stderr, "long rows %u (%lld entries): segments %u + %u, clustered segments %u, rows left to the radix sort %u (%llu entries)\n",
             n_long, (long long)long_nnz, hs2.n_seg[0], hs2.n_seg[1], hs2.n_seg_fb_rows, hs2.n_long_fb, hs2.long_fb_nnz);
   if (hs2.n_long_fb)
-    SBX_TRY(long_rows_radix_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, (const I *)fb_list,
-                                     hs2.n_long_fb, (int64_t)hs2.long_fb_nnz, st));
+    SBX_TRY((long_rows_radix_path<I, VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, (const I *)fb_list,
+                                         hs2.n_long_fb, (int64_t)hs2.long_fb_nnz, st)));
+  return SBX_OK;
+}
+
+// ---- the wide path --------------------------------------------------------------------------------------------------
+// 64-bit index arrays whose column ids do not fit the 32-bit keys of the LDS sorts (m beyond 2^31): every entry becomes
+// the key (new row << col_bits | new column), one stable radix sort over all of them, and the sorted position of a key IS
+// its place in the output (rows are contiguous there).  8 - 9 digit passes over 8 + VB bytes per entry instead of one
+// pass through LDS: the price of generality, paid only by matrices with more than two billion columns.
+constexpr int64_t KEY32_MAX_COLS = 0x7FFFFFF0ll;  // the LDS sorts keep a column in an int; ids up to here leave room for their sentinels
+
+template <typename I, int VB>
+__global__ __launch_bounds__(256) void k_wide_gather(const int2 *__restrict__ rec, const I *__restrict__ col_in,
+                                                     const char *__restrict__ val_in, const I *__restrict__ col_order,
+                                                     const I *__restrict__ rpo, int64_t nr, int64_t total, int col_bits,
+                                                     uint64_t *__restrict__ keys, char *__restrict__ pay,
+                                                     PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  bool unsorted = false;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; p < total; p += stride) {
+    int64_t lo = 0, hi = nr - 1;  // the last row with rpo[r] <= p: the non-empty one that owns the position
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if ((int64_t)rpo[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int64_t j = p - (int64_t)rpo[lo], src = (int64_t)rec[lo].y + j;
+    I c = col_in[src];
+    if (col_order) c = col_order[c];
+    if (j) {
+      I pc = col_in[src - 1];
+      if (col_order) pc = col_order[pc];
+      unsorted |= c < pc;
+    }
+    keys[p] = ((uint64_t)lo << col_bits) | (uint64_t)c;
+    if (VB) ((V *)pay)[p] = ((const V *)val_in)[src];
+  }
+  if (__any(unsorted) && sbx_lane() == 0) {
+    st->any_unsorted = 1;
+    st->long_unsorted = 1;
+  }
+}
+
+template <typename I, int VB>
+__global__ __launch_bounds__(256) void k_wide_scatter(const uint64_t *__restrict__ keys, const char *__restrict__ pay,
+                                                      int64_t total, int col_bits, I *__restrict__ col_out,
+                                                      char *__restrict__ val_out, PermState *__restrict__ st) {
+  typedef typename ValT<VB>::type V;
+  const uint64_t mask = col_bits >= 64 ? ~0ull : ((1ull << col_bits) - 1ull);
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool dup = false;
+  for (; p < total; p += stride) {
+    const uint64_t key = keys[p];
+    col_out[p] = (I)(key & mask);
+    if (VB) ((V *)val_out)[p] = ((const V *)pay)[p];
+    if (p && keys[p - 1] == key) dup = true;
+  }
+  if (__any(dup) && sbx_lane() == 0) st->any_dup = 1;
+}
+
+template <typename I, int VB>
+int wide_rows_path(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_in, const char *val_in,
+                   const I *col_order, const I *rpo, I *col_out, char *val_out, int64_t nr, int64_t m, int64_t total,
+                   PermState *st) {
+  const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), row_bits = sbx_bits_for(nr > 0 ? (uint64_t)(nr - 1) : 0);
+  if (col_bits + row_bits > 64)
+    SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "permute: %d row bits + %d column bits do not fit a 64-bit sort key", row_bits, col_bits);
+  uint64_t *ka = nullptr, *kb = nullptr;
+  char *pa = nullptr, *pb = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)total, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)total, &kb));
+  if (VB) {
+    SBX_TRY(sbx_salloc(h, (size_t)total * VB, &pa));
+    SBX_TRY(sbx_salloc(h, (size_t)total * VB, &pb));
+  }
+  const unsigned grid = sbx_grid_for(total, 256, 8192);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_wide_gather<I, VB>), dim3(grid), dim3(256), rec, col_in, val_in, col_order, rpo, nr,
+              total, col_bits, ka, pa, st);
+  SBX_LAUNCH_CHECK(h);
+  PermState hs2;  // rows that are already ordered skip the sort
+  SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
+  int in_b = 0;
+  if (hs2.long_unsorted && col_bits + row_bits > 0) {
+    sbx_radix_pass passes[16];
+    const int np = sbx_radix_plan(0, col_bits + row_bits, 0, 0, passes);
+    SBX_TRY(sbx_radix_sort(h, 8, VB, ka, kb, pa, pb, total, passes, np, &in_b));
+  }
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_wide_scatter<I, VB>), dim3(grid), dim3(256), (const uint64_t *)(in_b ? kb : ka),
+              (const char *)(in_b ? pb : pa), total, col_bits, col_out, val_out, st);
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_PERMUTE_LONG, total * (int64_t)(2 * (sizeof(I) + VB)));
+  if (VB) SBX_TRY(launch_fix<I>(h, vt, rpo, (const I *)col_out, val_out, nr, st));
   return SBX_OK;
 }
 
 // Sort stage shared by permute and csr_sort_rows: rows of `rpo` (nr rows, already
 // on device) are produced from the source CSR through the row/col maps.
-template <int VB>
-int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t *col_in, const char *val_in,
-               const int32_t *col_order, const int32_t *rpo, int32_t *col_out, char *val_out, int64_t nr, int64_t m,
-               int64_t total, const int32_t *long_rows, const int32_t *block_rows, int64_t block_stride,
-               const PermState &hs, PermState *st, const int32_t *sp) {
-  typedef int32_t I;
+template <typename I, int VB>
+int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_in, const char *val_in,
+               const I *col_order, const I *rpo, I *col_out, char *val_out, int64_t nr, int64_t m,
+               int64_t total, const I *long_rows, const I *block_rows, int64_t block_stride,
+               const PermState &hs, PermState *st, const I *sp) {
+  if constexpr (sizeof(I) == 8)
+    if (m > KEY32_MAX_COLS)
+      return wide_rows_path<I, VB>(h, vt, rec, col_in, val_in, col_order, rpo, col_out, val_out, nr, m, total, st);
   const unsigned n_long = hs.n_long;
   const unsigned *n_block = hs.n_block;
   const int64_t long_nnz = (int64_t)hs.long_nnz, block_nnz = (int64_t)hs.block_nnz;
@@ -2372,7 +2469,7 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   }
   if (has_block) {
     if (fork) h->stream = h->aux_stream[0];
-    const int rc = block_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
+    const int rc = block_rows_path<I, VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, block_rows, n_block,
                                        block_stride, block_nnz, st, fork);
     if (fork) {
       if (rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
@@ -2382,8 +2479,8 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const int32_t
   }
   if (n_long) {
     if (fork) h->stream = h->aux_stream[1];
-    const int rc = long_rows_path<VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
-                                      long_nnz, st);
+    const int rc = long_rows_path<I, VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
+                                         long_nnz, st);
     if (fork) {
       if (rc == SBX_OK && hipEventRecord(h->aux_event[2], h->stream) != hipSuccess) { h->stream = main_stream; SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed"); }
       h->stream = main_stream;
@@ -2489,92 +2586,23 @@ extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   return SBX_OK;
 }
 
-// Row-wise permute (no column map) of a CSR with 64-bit indices, native: the records (length, source offset) stay
-// 32-bit — nnz < 2^31, checked by the caller — while row_ptr, the row order and the columns are read and written as
-// they are: no narrowed copies, column ids of any size.  Returns SBX_ROWWISE_NEEDS_SORT when some input row turns out
-// unsorted (arrays that never went through a CSR constructor): the caller then takes the sorting pipeline.
-constexpr int SBX_ROWWISE_NEEDS_SORT = -1000;
-static int permute_rows_rowwise_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row_ptr,
-                                    const void *col, const void *val, const void *row_order, int64_t row_begin,
-                                    int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
-                                    int64_t out_capacity, int64_t *shard_nnz_host) {
-  typedef int64_t I;
+// One shard of the permute for either index width.  The records (length, source offset) stay 32-bit — nnz < 2^31, checked
+// by the caller — while row_ptr, the orders and the columns are read and written as they are: no narrowed copies.
+template <typename I>
+static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                                  const void *col, const void *val, const void *row_order, const void *col_order,
+                                  int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                                  int64_t out_capacity, int64_t *shard_nnz_host) {
   const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
   const int64_t nr = row_end - row_begin;
   I *rpo = (I *)row_ptr_out;
   if (shard_nnz_host) *shard_nnz_host = 0;
-  if (nr == 0) return sbx_fill_i64(h, rpo, 0, 1);
-  PermState *st = nullptr;
-  int2 *rec = nullptr;
-  I *sp = nullptr;
-  SBX_TRY(perm_state_alloc(h, &st));
-  SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
-  SBX_TRY(sbx_salloc(h, (size_t)nr + 1, &sp));
-  SBX_TRY(perm_state_zero(h, st));
-  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nr, h->stream));
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((n + 3) / 4, 256, 8192)), dim3(256),
-              (const I *)row_ptr, (const I *)row_order, n, row_begin, nr, rec);
-  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, (I *)nullptr, (I *)nullptr, 0, 0, st));
-  int64_t total = nnz;
-  if (nr != n) {
-    PermState hs;
-    SBX_TRY(perm_fetch(h, &hs, st));
-    total = (int64_t)hs.total;
+  if (nr == 0) {
+    if constexpr (sizeof(I) == 8) return sbx_fill_i64(h, (int64_t *)rpo, 0, 1);
+    else return sbx_fill_i32(h, (int32_t *)rpo, 0, 1);
   }
-  if (shard_nnz_host) *shard_nnz_host = total;
-  if (total > out_capacity)
-    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: shard needs %lld entries, capacity %lld", (long long)total,
-             (long long)out_capacity);
-  if (total == 0) return SBX_OK;
-  const unsigned tiles = (unsigned)((total + PC_TILE - 1) / PC_TILE);
-  I *tile_row = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_row));
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_rows<I>, dim3(tiles / 256 + 1), dim3(256), (const I *)rpo, nr, total, PC_TILE,
-              (int64_t)tiles, tile_row);
-#define COPY(VBX)                                                                                              \
-  SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_copy<I, VBX>), dim3(tiles), dim3(PC_THREADS), (const int2 *)rec, \
-              (const I *)tile_row, (const I *)col, (const char *)val, (const I *)rpo, (I *)col_out, (char *)val_out, \
-              nr, total, st)
-  if (vb == 0) COPY(0);
-  else if (vb == 4) COPY(4);
-  else COPY(8);
-#undef COPY
-  SBX_LAUNCH_CHECK(h);
-  SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, total * (int64_t)(2 * (sizeof(I) + vb)));
-  PermState hc;
-  SBX_TRY(sbx_readback(h, &hc, st, sizeof(PermState)));
-  return hc.any_unsorted ? SBX_ROWWISE_NEEDS_SORT : SBX_OK;
-}
-
-extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
-                                    int64_t nnz, const void *row_ptr, const void *col, const void *val,
-                                    const void *row_order, const void *col_order, int64_t row_begin, int64_t row_end,
-                                    void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
-                                    int64_t *shard_nnz_host) {
-  if (!h) return SBX_ERR_BAD_ARG;
-  SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && row_ptr_out, "bad argument");
-  SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
-  SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
-  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
-  if (it == SBX_I64) {
-    if (!col_order) {  // row-wise: native 64-bit kernels (no copies; column ids of any size); falls through when a row is unsorted
-      const int rc = permute_rows_rowwise_i64(h, vt, n, nnz, row_ptr, col, val, row_order, row_begin, row_end, row_ptr_out,
-                                              col_out, val_out, out_capacity, shard_nnz_host);
-      if (rc != SBX_ROWWISE_NEEDS_SORT) return rc;
-    }
-    return sbx_i64_permute_csr_rows(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
-                                    row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
-  }
-  const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
-  SBX_REQUIRE(h, vb >= 0, "unknown value type");
-  SBX_TRY(sbx_arena_begin(h));
-  typedef int32_t I;
-  const int64_t nr = row_end - row_begin;
-  I *rpo = (I *)row_ptr_out;
-  if (shard_nnz_host) *shard_nnz_host = 0;
-  if (nr == 0) return sbx_fill_i32(h, rpo, 0, 1);
 
   // (row length, source offset) per new row, written from the old-row side; lengths -> scan -> row_ptr_out
   PermState *st = nullptr;
@@ -2644,13 +2672,30 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
   }
   int rc;
 #define STAGE(VBX)                                                                                                  \
-  rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
+  rc = sort_stage<I, VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
                        (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st, sp)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
 #undef STAGE
   return rc;
+}
+
+extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                                    int64_t nnz, const void *row_ptr, const void *col, const void *val,
+                                    const void *row_order, const void *col_order, int64_t row_begin, int64_t row_end,
+                                    void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
+                                    int64_t *shard_nnz_host) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && row_ptr_out, "bad argument");
+  SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
+  SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  if (it == SBX_I64)
+    return permute_csr_rows_typed<int64_t>(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
+                                           row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
+  return permute_csr_rows_typed<int32_t>(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
+                                         row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
 }
 
 extern "C" int sbx_permute_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
@@ -2688,30 +2733,27 @@ int sbx_sort_segments(sbx_handle_t h, int vb, int64_t nseg, int64_t key_limit, i
   SBX_TRY(perm_fetch(h, &hs, st));
   // (SBX_V_NONE: no value ordering of equal keys behind the sort)
   if (vb == 0)
-    return sort_stage<0>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+    return sort_stage<I, 0>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
                          nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
   if (vb == 4)
-    return sort_stage<4>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+    return sort_stage<I, 4>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
                          nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
-  return sort_stage<8>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
+  return sort_stage<I, 8>(h, SBX_V_NONE, (const int2 *)rec, key_in, val_in, (const I *)nullptr, seg_ptr, key_out, val_out,
                        nseg, key_limit, nnz, long_rows, block_rows, nseg, hs, st, sp);
 }
 
-extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
-                                 int64_t nnz, const void *row_ptr, void *col, void *val) {
-  if (!h) return SBX_ERR_BAD_ARG;
-  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || col), "bad argument");
-  if (it == SBX_I64) return sbx_i64_csr_sort_rows(h, vt, n, m, nnz, row_ptr, col, val);
+template <typename I>
+static int csr_sort_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                               void *col, void *val) {
   if (nnz <= 1 || n == 0) return SBX_OK;
   int sorted = 1;
-  SBX_TRY(sbx_csr_rows_sorted(h, it, n, row_ptr, col, &sorted));  // csr.cc:102-116
+  SBX_TRY(sbx_csr_rows_sorted(h, sizeof(I) == 8 ? SBX_I64 : SBX_I32, n, row_ptr, col, &sorted));  // csr.cc:102-116
   if (sorted) return SBX_OK;
   // out-of-place into scratch, then copied back (tiles may read rows another
   // tile has already rewritten if the sort ran in place across tiles)
   const int vb = val ? sbx_value_bytes(vt) : 0;
   SBX_REQUIRE(h, vb >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
-  typedef int32_t I;
   PermState *st = nullptr;
   I *long_rows = nullptr, *block_rows = nullptr, *ctmp = nullptr;
   int2 *rec = nullptr;
@@ -2734,7 +2776,7 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_TRY(perm_fetch(h, &hs, st));
   int rc;
 #define STAGE(VBX)                                                                                               \
-  rc = sort_stage<VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)nullptr,          \
+  rc = sort_stage<I, VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)nullptr,          \
                        (const I *)row_ptr, ctmp, vtmp, n, m, nnz, long_rows, block_rows, (int64_t)n, hs, st, sp)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
@@ -2744,4 +2786,13 @@ extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_ty
   SBX_HIP(h, hipMemcpyAsync(col, ctmp, (size_t)nnz * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
   if (vb) SBX_HIP(h, hipMemcpyAsync(val, vtmp, (size_t)nnz * vb, hipMemcpyDeviceToDevice, h->stream));
   return SBX_OK;
+}
+
+extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
+                                 int64_t nnz, const void *row_ptr, void *col, void *val) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || col), "bad argument");
+  SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
+  if (it == SBX_I64) return csr_sort_rows_typed<int64_t>(h, vt, n, m, nnz, row_ptr, col, val);
+  return csr_sort_rows_typed<int32_t>(h, vt, n, m, nnz, row_ptr, col, val);
 }

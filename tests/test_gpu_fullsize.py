@@ -269,3 +269,47 @@ def test_c4_one_of_eight_shards_of_1b_nnz(ops, oracle):
         assert np.array_equal(srp.cpu().numpy(), want[0])
         assert np.array_equal(scol.cpu().numpy(), want[1])
         assert np.array_equal(sval.cpu().numpy(), want[2])
+
+
+def test_int64_permute_column_map_beyond_2_31(ops, oracle):
+    """Permute2D of 64-bit arrays under a column map whose ids need more than 31 bits (m = 3 * 2^30 + 1: the map alone is
+    26 GB of HBM): the wide path of sbx_permute.hip — keys (new row << 32 | new column) through the device radix sort —
+    against the oracle fed with the relabelled columns (it sorts the rows like the reference's CSR constructor,
+    format/csr.cc:99-157).  Also one shard of it, and C2-sized 64-bit COO records with columns up to 2^33 through the
+    packed-key constructor sort (format/coo.cc:96-157)."""
+    g = np.random.default_rng(23)
+    m = 3 * (1 << 30) + 1
+    co = torch.arange(m, dtype=torch.int64, device="cuda").mul_(5).add_(7).remainder_(m)   # 5 does not divide m: a bijection
+    lens = np.concatenate([g.integers(0, 300, 3000), [9000, 20000, 129, 4096]]).astype(np.int64)
+    n = len(lens)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([np.sort(g.choice(m, l, replace=False)) for l in lens]).astype(np.int64)
+    col[rp[5]:rp[5] + 2] = col[rp[5] + 2]                                           # duplicates: value order
+    val = g.integers(-50, 50, len(col)).astype(np.float64)
+    order = synth.random_permutation(n, 9, np.int64)
+    d = lambda a: torch.from_numpy(a).cuda()
+    relabelled = co[d(col)].cpu().numpy()
+    assert relabelled.max() >= 1 << 31
+    want = oracle.permute_csr(rp, relabelled, val, order, None, m=m)
+    got = ops.permute_csr(n, m, d(rp), d(col), d(val), d(order), co)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cpu().numpy(), b)
+    srp, scol, sval = ops.permute_csr_rows(n, m, d(rp), d(col), d(val), d(order), co, n // 3, n // 2)
+    lo, hi = want[0][n // 3], want[0][n // 2]
+    assert np.array_equal(srp.cpu().numpy(), want[0][n // 3:n // 2 + 1] - lo)
+    assert np.array_equal(scol.cpu().numpy(), want[1][lo:hi]) and np.array_equal(sval.cpu().numpy(), want[2][lo:hi])
+    del co
+    # the COO constructor's sort: 10 M records, 20 row bits + 34 column bits (plain digit passes on the packed key) and
+    # 20 + 11 (the hybrid: digit passes over the row's leading bits, groups sorted in LDS)
+    for mm in (1 << 34, 1 << 11):
+        nn, nnz = 1 << 20, 10_000_000
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        row = torch.randint(0, nn, (nnz,), device="cuda", generator=gen, dtype=torch.int64)
+        colr = torch.randint(0, mm, (nnz,), device="cuda", generator=gen, dtype=torch.int64)
+        v = torch.arange(nnz, device="cuda", dtype=torch.float32)
+        key, perm = torch.sort(row * mm + colr, stable=True)
+        r2, c2, v2 = row.clone(), colr.clone(), v.clone()
+        ops.coo_sort_(nn, mm, r2, c2, v2)
+        assert torch.equal(r2, key // mm) and torch.equal(c2, key % mm)
+        # equal coordinates keep no particular order in the reference (std::sort on (row, col) only): compare as sets
+        assert torch.equal(torch.sort(v2)[0], v) and torch.equal(row[v2.long()], r2) and torch.equal(colr[v2.long()], c2)

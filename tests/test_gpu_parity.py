@@ -524,30 +524,32 @@ def test_permute_long_rows_and_duplicates(ops, oracle):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), None, None), oracle.permute_csr(rp, col, v, None, None))
 
 
-def test_permute_quad_class_boundaries(ops, oracle):
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_permute_quad_class_boundaries(ops, oracle, idt):
     """k_rows_quad (sbx_rowsort.h): every class boundary and every remainder modulo the quad (a row's last, partial quad is
     cut by the row's buffer descriptor, not by a predicate), the last row of the arrays ending in a partial quad (the
     16-byte accesses of its last lane reach past the allocation's logical end), a bucket of more than eight equal-ish
     columns (the ranking loop), more than 96 (the radix list), every value width, distinct and duplicate columns, a random
-    and a clustered (run-structured, RCM-like) column map."""
+    and a clustered (run-structured, RCM-like) column map.  int64: the same rows through the native 64-bit instances of
+    round 3's class kernels (no narrowed copies)."""
     g = np.random.default_rng(41)
     m = 1 << 18
     lens = [129, 130, 131, 132, 255, 256, 257, 258, 259, 260, 511, 512, 513, 1023, 1024, 1025, 1026, 1027, 2047, 2048, 2049,
             4095, 4096, 4097, 4098, 8189, 8190, 8191, 8192, 700, 3001, 6002, 1, 0, 5, 300, 1301, 2302, 8003]
     n = len(lens)
     rows = [np.sort(g.choice(m, l, replace=False)) for l in lens]
-    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    col = np.concatenate(rows).astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(idt)
+    col = np.concatenate(rows).astype(idt)
     val = g.integers(-1000, 1000, len(col)).astype(np.int32)
-    ro = synth.random_permutation(n, 3)
+    ro = synth.random_permutation(n, 3, idt)
     ro[-1], ro[int(np.argmax(ro == n - 1))] = n - 1, ro[-1]   # the last old row (8003 = 3 mod 4) stays the last new row
-    rnd = synth.random_permutation(m, 4)
+    rnd = synth.random_permutation(m, 4, idt)
     runs = np.arange(m, dtype=np.int64)                        # runs of 977 consecutive labels, the runs shuffled
     blocks = g.permutation((m + 976) // 977)
     clustered = np.concatenate([np.arange(b * 977, min(m, (b + 1) * 977)) for b in blocks])[:m]
     inv = np.empty(m, np.int64)
     inv[clustered] = runs
-    for co in (rnd, inv.astype(np.int32)):
+    for co in (rnd, inv.astype(idt)):
         for v in (val.astype(np.float32), None, val.astype(np.float64)):
             same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
     # equal columns: 9, 40 and 200 copies of one column inside rows of every big class (ranking loop / radix list);
@@ -555,20 +557,22 @@ def test_permute_quad_class_boundaries(ops, oracle):
     rows2 = []
     for l, rep in ((300, 9), (900, 40), (3000, 200), (7000, 9), (200, 97), (5000, 1200)):
         rows2.append(np.sort(np.concatenate([g.choice(m, l - rep, replace=False), np.full(rep, int(g.integers(0, m)))])))
-    rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(np.int32)
-    col2 = np.concatenate(rows2).astype(np.int32)
-    ro2 = synth.random_permutation(len(rows2), 5)
+    rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(idt)
+    col2 = np.concatenate(rows2).astype(idt)
+    ro2 = synth.random_permutation(len(rows2), 5, idt)
     for v2 in (g.integers(-9, 9, len(col2)).astype(np.int32), g.random(len(col2)).astype(np.float32), None):
         same(ops.permute_csr(len(rows2), m, dev(rp2), dev(col2), dev(v2), dev(ro2), dev(rnd)),
              oracle.permute_csr(rp2, col2, v2, ro2, rnd))
 
 
-def test_permute_long_row_segments(ops, oracle):
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_permute_long_row_segments(ops, oracle, idt):
     """Rows above the one-workgroup capacity under a column map (sbx_permute.hip, k_long_seg_*): split into column-range
     segments that are sorted in LDS.  Covers: rows of 8 K .. 300 K entries (8 .. 256 segments; chunks of the compact buffer
     that straddle two rows), duplicate columns with values, a row whose relabelled columns all fall into one segment (too
     full: that row takes the global radix sort), a row the map leaves in order (the reference does not touch it: stable
-    path) next to rows it scrambles, and 8-byte values (segments of at most 4096 entries)."""
+    path) next to rows it scrambles, and 8-byte values (segments of at most 4096 entries).  int64: 64-bit index arrays
+    through the same kernels, natively."""
     g = np.random.default_rng(11)
     n, m = 40, 1 << 20
     lens = [8193, 12000, 4097, 300000, 8200, 70000, 16385, 9000, 0, 5, 30000, 10000] + [int(x) for x in g.integers(0, 200, n - 12)]
@@ -583,12 +587,12 @@ def test_permute_long_row_segments(ops, oracle):
         else:
             c = (1 << 19) + g.choice(1 << 19, l, replace=False) if l else np.zeros(0, np.int64)
         cols.append(np.sort(c))
-    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    col = np.concatenate(cols).astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(idt)
+    col = np.concatenate(cols).astype(idt)
     co = np.arange(m, dtype=np.int64)
     co[1 << 19:] = (1 << 19) + g.permutation(1 << 19)   # lower half stays put (monotone), upper half is scrambled
-    co = co.astype(np.int32)
-    ro = synth.random_permutation(n, 4)
+    co = co.astype(idt)
+    ro = synth.random_permutation(n, 4, idt)
     val = g.integers(-3, 3, len(col)).astype(np.int32)
     for v in (val.astype(np.float32), None, val.astype(np.float64)):
         same(ops.permute_csr(n, m, dev(rp), dev(col), dev(v), dev(ro), dev(co)), oracle.permute_csr(rp, col, v, ro, co))
@@ -597,13 +601,13 @@ def test_permute_long_row_segments(ops, oracle):
     # (one bucket gets them all) and goes through the radix kernel for clustered segments; equal columns end in value order
     for rep in (300, 3000):
         rows2 = [np.sort(np.concatenate([g.integers(0, m, l - rep), np.full(rep, int(g.integers(0, m)))])) for l in (20000, 9000, 5000)]
-        rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(np.int32)
-        col2 = np.concatenate(rows2).astype(np.int32)
-        ro2 = synth.random_permutation(3, rep)
+        rp2 = np.concatenate([[0], np.cumsum([len(r) for r in rows2])]).astype(idt)
+        col2 = np.concatenate(rows2).astype(idt)
+        ro2 = synth.random_permutation(3, rep, idt)
         for v2 in (g.integers(-9, 9, len(col2)).astype(np.int32), g.random(len(col2))):
             same(ops.permute_csr(3, m, dev(rp2), dev(col2), dev(v2), dev(ro2), dev(co)), oracle.permute_csr(rp2, col2, v2, ro2, co))
     # a monotone map over everything: every long row stays in order, duplicates keep their input order
-    mono = np.arange(m, dtype=np.int32)
+    mono = np.arange(m, dtype=idt)
     same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(mono)), oracle.permute_csr(rp, col, val, ro, mono))
     # shards (sbx_permute_csr_rows) go through the same stage
     whole = oracle.permute_csr(rp, col, val, ro, co)
@@ -1011,8 +1015,8 @@ def test_int64_tuple_all_ops(ops, oracle):
 
 def test_int64_values_beyond_int32(ops, oracle):
     """64-bit indices with values >= 2^31.  The conversions COO <-> CSR and the two sortedness checks run native 64-bit
-    kernels: column ids of any size are accepted and the results are the oracle's, bit for bit.  The entry points that
-    still narrow to the int32 kernels refuse such arrays loudly (SBX_ERR_UNSUPPORTED), never silently truncate."""
+    kernels: column ids of any size are accepted and the results are the oracle's, bit for bit; so do both constructor
+    sorts and the permute.  What a 64-bit sort key cannot hold is refused loudly (SBX_ERR_UNSUPPORTED), never truncated."""
     from sparsebase_amd import capi
     g = np.random.default_rng(5)
     n, m = 300, 1 << 40
@@ -1065,11 +1069,33 @@ def test_int64_values_beyond_int32(ops, oracle):
     lo, hi = want[0][n // 3], want[0][n // 2]
     assert np.array_equal(host(srp), want[0][n // 3:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
     assert np.array_equal(host(sval), want[2][lo:hi])
-    # the operations that still run on narrowed copies refuse what does not fit, loudly
-    r_big, c_big, v_big = dev(r_u.copy()), dev(c_u.copy()), dev(v_u.copy())
-    with pytest.raises(capi.SbxError) as e:
-        ops.coo_sort_(n, m, r_big, c_big, v_big)
+    # the COO constructor's sort is native: coordinates of any size inside the matrix (packed keys: 9 + 40 bits here)
+    for v in (v_u, v_u.astype(np.float32), None):
+        r_s, c_s, v_s = dev(r_u.copy()), dev(c_u.copy()), dev(v)
+        ops.coo_sort_(n, m, r_s, c_s, v_s)
+        same((r_s, c_s, v_s), oracle.coo_sort(r_u, c_u, v, n=n, m=m))
+    # ... and so are the CSR constructor's row sort and the permute of rows that arrive out of order: column ids beyond
+    # 2^31 do not fit the LDS sorts' 32-bit keys and take the wide path (64-bit keys: new row | column)
+    scol, sval = col.copy(), val.copy()
+    for i in range(n):
+        q = g.permutation(lens[i])
+        scol[rp[i]:rp[i + 1]], sval[rp[i]:rp[i + 1]] = col[rp[i]:rp[i + 1]][q], val[rp[i]:rp[i + 1]][q]
+    for v in (sval, sval.astype(np.float32), None):
+        dc, dv_ = dev(scol.copy()), dev(v)
+        ops.csr_sort_rows_(n, m, dev(rp), dc, dv_)
+        same((dc, dv_), oracle.csr_sort_rows(rp, scol, v, m=m))
+        same(ops.permute_csr(n, m, dev(rp), dev(scol), dev(v), dev(order), None), oracle.permute_csr(rp, scol, v, order, None, m=m))
+    dcol, r9 = scol.copy(), int(np.argmax(lens >= 8))
+    dcol[rp[r9]:rp[r9] + 3] = dcol[rp[r9] + 3]                                        # duplicates end in value order
+    same(ops.permute_csr(n, m, dev(rp), dev(dcol), dev(sval), dev(order), None), oracle.permute_csr(rp, dcol, sval, order, None, m=m))
+    # a column map over ids that need 64 bits is the same wide path: see test_int64_permute_column_map_beyond_2_31
+    # (tests/test_gpu_fullsize.py: the map alone is 26 GB).  What cannot be represented is refused loudly:
+    with pytest.raises(capi.SbxError) as e:                                           # 40 + 40 key bits
+        ops.coo_sort_(1 << 40, m, dev(r_u.copy()), dev(c_u.copy()), dev(v_u.copy()))
     assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
+    with pytest.raises(capi.SbxError) as e:                                           # columns outside the matrix AND beyond int32
+        ops.coo_sort_(n, 1 << 20, dev(r_u.copy()), dev(c_u.copy()), dev(v_u.copy()))
+    assert e.value.status == 5
 
 
 @pytest.mark.parametrize("case", ["mixed", "all_tail_one_degree", "wide_int64", "tail_of_one", "tail_of_two", "small_n"])
