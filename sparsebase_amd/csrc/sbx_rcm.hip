@@ -751,6 +751,8 @@ __device__ __forceinline__ void bfs_visit(I v, unsigned p, const I *__restrict__
 constexpr int RCM_GROUP = 16;
 constexpr int RCM_VPW = 64 / RCM_GROUP;  // frontier vertices per wave
 constexpr int RCM_BU_INLINE = 16;        // bottom-up: candidates up to this degree get one lane each
+constexpr int RCM_BU_HEAVY = 256;        // ... above this one their rows are queued as chunks of
+constexpr int RCM_BU_CHUNK = 1024;       //     this many entries, a wave each (k_bfs_bottom_up_heavy)
 
 constexpr int RCM_HUB_STAGE = 256;  // hubs a workgroup stages before it reserves their chunk descriptors
 constexpr int RCM_DIR_MAX = 2048;    // workgroups of k_bfs_expand the hub kernel can follow through the directory
@@ -934,12 +936,14 @@ __global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ 
 // current frontier (fbits / lpos) and, if it found one, joins the next level.  No atomics
 // on vertex state, no hot words; chosen by the host when the frontier owns more edges
 // than the unvisited remainder.
-__global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
+// (eight waves per SIMD: the chunk reservation below, which hardly ever runs, would otherwise cost the scans 30 registers)
+__global__ __launch_bounds__(256, 8) void k_bfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
                                                        const I *__restrict__ label, I comp_label,
                                                        const unsigned *__restrict__ vbits,
                                                        const unsigned *__restrict__ fbits,
                                                        const unsigned *__restrict__ lpos, unsigned *__restrict__ ppos,
-                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv) {
+                                                       I *__restrict__ nf_list, int64_t n, RcmDev *__restrict__ dv,
+                                                       uint64_t *__restrict__ heavy, uint64_t heavy_cap) {
   __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -955,6 +959,27 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       s = rp[v];
       e = rp[v + 1];
       cand = (e > s) && (label == nullptr || label[v] == comp_label);
+    }
+    // hubs that are still unvisited (a sweep from the periphery meets the largest ones late) would keep one 16-lane
+    // group busy for milliseconds — 64 entries per step of three dependent loads; forcing the bench matrix's widest level
+    // bottom-up showed it: 6.1 ms for that level, 8000 waves waiting for a handful.  Rows above RCM_BU_HEAVY entries are
+    // queued as chunks of RCM_BU_CHUNK for k_bfs_bottom_up_heavy, a wave each (the queue holds nnz / 256 + nnz / 1024
+    // descriptors and more: enough for every such row of the graph)
+    const bool hv = cand && (e - s) > RCM_BU_HEAVY;
+    if (__any(hv)) {  // one reservation per wave: a lane's slots follow those of the lanes before it
+      const unsigned nch = hv ? (unsigned)((e - s + RCM_BU_CHUNK - 1) / RCM_BU_CHUNK) : 0u;
+      const unsigned incl = sbx_wave_inclusive_sum(nch);
+      unsigned at = 0;
+      if (lane == 63) at = atomicAdd(&dv->n_heavy, incl);
+      at = __shfl(at, 63, 64) + incl - nch;
+      if (hv) {
+        if ((uint64_t)at + nch <= heavy_cap) {
+          for (unsigned c = 0; c < nch; c++) heavy[at + c] = ((uint64_t)(uint32_t)v << 32) | c;
+          cand = false;
+        } else {  // a full queue: the row stays with its 16-lane group below, the slots it got in front of the end are voided
+          for (uint64_t q = at; q < heavy_cap; q++) heavy[q] = ~0ull;
+        }
+      }
     }
     // low-degree candidates: one lane each (64 independent load chains per wave; the
     // rows of consecutive vertices are adjacent in col[], so the lanes share lines)
@@ -1019,6 +1044,57 @@ __global__ __launch_bounds__(256) void k_bfs_bottom_up(const I *__restrict__ rp,
       if (found) ppos[nv] = best;
       stage_push(nv, found, rp, st, nf_list, dv);
     }
+  }
+  stage_end_block(st, nf_list, dv, scanned, true);
+}
+
+// The queued row chunks of a bottom-up level: a wave scans the RCM_BU_CHUNK entries of one (four loads per lane in
+// flight), the chunks of a row meet in an atomicMin on the candidate's parent position, and the chunk that finds it
+// UNSEEN appends the vertex to the level.
+__global__ __launch_bounds__(256) void k_bfs_bottom_up_heavy(const I *__restrict__ rp, const I *__restrict__ col,
+                                                             const unsigned *__restrict__ fbits,
+                                                             const unsigned *__restrict__ lpos, unsigned *ppos,
+                                                             I *__restrict__ nf_list, RcmDev *dv,
+                                                             const uint64_t *__restrict__ heavy, uint64_t heavy_cap) {
+  // (the counter may have run past the queue's end: a reservation that did not fit voided its slots)
+  const unsigned nh = dv->n_heavy < heavy_cap ? dv->n_heavy : (unsigned)heavy_cap;
+  __shared__ I s_stage[4][RCM_STAGE];
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int lane = sbx_lane();
+  // (the level's counter is a hot word: winners are staged per wave and appended in batches, as in the kernel above)
+  WaveStage st{s_stage[sbx_wave_in_block()], 0u, 0ull, &dv->nf, &dv->fedges};
+  unsigned long long scanned = 0;
+  for (unsigned i = wave; i < nh; i += nwaves) {
+    const uint64_t d = heavy[i];
+    if (d == ~0ull) continue;
+    const I v = (I)(uint32_t)(d >> 32);
+    const I r0 = rp[v];
+    const I s = r0 + (I)(uint32_t)d * RCM_BU_CHUNK;
+    const I r1 = rp[v + 1];
+    const I e = (r1 - s) > RCM_BU_CHUNK ? s + RCM_BU_CHUNK : r1;
+    unsigned best = UNSEEN;
+    for (I j = s + lane; j < e; j += 4 * 64) {
+      I us[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) us[k] = (j + k * 64) < e ? col[j + k * 64] : (I)-1;
+      unsigned hit = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (us[k] >= 0 && ((fbits[us[k] >> 5] >> (us[k] & 31)) & 1u)) hit |= 1u << k;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned lp = ((hit >> k) & 1u) ? lpos[us[k]] : UNSEEN;
+        best = lp < best ? lp : best;
+      }
+    }
+    best = sbx_wave_min(best);
+    bool won = false;
+    if (lane == 0) {
+      scanned += (unsigned long long)(e - s);
+      // a row of one chunk — most of them — has nobody to meet
+      if (best != UNSEEN) won = (r1 - r0) <= RCM_BU_CHUNK ? (ppos[v] = best, true) : atomicMin(&ppos[v], best) == UNSEEN;
+    }
+    stage_push(v, won, rp, st, nf_list, dv);
   }
   stage_end_block(st, nf_list, dv, scanned, true);
 }
@@ -1864,6 +1940,7 @@ struct BfsBuffers {
   I *q;         // visiting order of the current BFS (levels concatenated)
   I *nf_list;   // unordered next frontier
   uint64_t *heavy;
+  uint64_t heavy_cap;  // descriptors the queue holds
   uint2 *hub_dir;  // per workgroup of k_bfs_expand: (first chunk descriptor, count)
   uint64_t *ka, *kb;
   unsigned long long *fresh64;  // per 64 vertices: the bits the current level added to the visited bitmap
@@ -1954,7 +2031,11 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       }
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   (const unsigned *)b.vbits, (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list,
-                  b.n, b.dv);
+                  b.n, b.dv, b.heavy, b.heavy_cap);
+      if (b.max_deg > (unsigned)RCM_BU_HEAVY)
+        SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_bfs_bottom_up_heavy, dim3(8 * (unsigned)h->num_cus), dim3(256), b.rp, b.col,
+                    (const unsigned *)b.fbits, (const unsigned *)b.lpos, b.ppos, b.nf_list, b.dv,
+                    (const uint64_t *)b.heavy, b.heavy_cap);
     } else {
       const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
       unsigned grid = (waves_needed + 3) / 4;
@@ -3102,7 +3183,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   cbits = fbits + bm_words;
   SBX_TRY(sbx_salloc(h, (size_t)n, &q_small));
   SBX_TRY(sbx_salloc(h, (size_t)n, &lpos));
-  SBX_TRY(sbx_salloc(h, (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024), &heavy));
+  const size_t heavy_cap = (size_t)(nnz / RCM_LIGHT + nnz / RCM_CHUNK + 1024);
+  SBX_TRY(sbx_salloc(h, heavy_cap, &heavy));
   SBX_TRY(sbx_salloc(h, (size_t)n, &ka));
   SBX_TRY(sbx_salloc(h, (size_t)n, &kb));
   // (dv is cleared by k_deg_reduce; csize, dist and ppos get their initial values from k_deg_count)
@@ -3190,7 +3272,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   b.claim_clean = &claim_clean;
   b.after_first_launch = &enqueue_ranks;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
-  b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy;
+  b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy; b.heavy_cap = heavy_cap;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
   b.ka = ka; b.kb = kb; b.drank = drank; b.dorder = dorder; b.n_ranked = n_ranked; b.dv = dv; b.n = n;
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.fresh64));
