@@ -93,6 +93,11 @@ struct RcmDev {
   unsigned long long ur_fe, ur_esum;
   unsigned ur_nf[3], ur_nh[3];          // per level (slot = level % 3): vertices appended, hubs queued
   unsigned long long ur_deg[3];         // ... and the degree sum of the level
+  // unordered sweeps, levels chained on the device (run_ubfs): the frontier that is current for the next kernel of the
+  // chain, the unvisited edges, what that kernel is to be (UC_*), and how often the chain swapped the frontier bitmaps
+  unsigned uc_off, uc_size, uc_level, uc_total, uc_mode, uc_flips, uc_small_ran, uc_done;
+  unsigned long long uc_fe;
+  long long uc_remaining;
   // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
   alignas(128) unsigned unf[2];
   alignas(128) unsigned long long ufedges[2];
@@ -2206,6 +2211,55 @@ static double ubu_ratio() {
   return r;
 }
 
+constexpr unsigned UR_GRID = 64;
+constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
+constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
+// what the next kernel of a device-driven chain is to be: nothing more (the sweep is over), a bottom-up level, the
+// persistent small-level kernel, or a level the host has to launch
+constexpr unsigned UC_DONE = 1, UC_BU = 2, UC_SMALL = 3, UC_HOST = 4;
+struct ChainInit {  // what the host knows when it launches the level a chain starts behind
+  unsigned off, size, level, total;
+  long long remaining;
+  double bu_ratio;
+};
+// Level uc_level + 1 has just been built (its size and degree sum are in the level's slot): the chain's frontier moves
+// on to it and the next kernel's kind is decided by the host loop's own rules.  One thread, after the level's kernel
+// has finished (its last workgroup out, or k_ubfs_chain_next behind it).
+__device__ __forceinline__ void uc_advance(RcmDev *dv, double bu_ratio) {
+  const unsigned built = dv->uc_level + 1;
+  const unsigned nf = __hip_atomic_load(&dv->unf[built & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long fe = __hip_atomic_load(&dv->ufedges[built & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nf == 0) {  // the frontier just expanded was the deepest level: the chain's state stays on it
+    dv->uc_mode = UC_DONE;
+    return;
+  }
+  long long rem = dv->uc_remaining - (long long)fe;
+  if (rem < 0) rem = 0;
+  dv->uc_remaining = rem;
+  dv->uc_off += dv->uc_size;
+  dv->uc_size = nf;
+  dv->uc_total += nf;
+  dv->uc_level = built;
+  dv->uc_fe = fe;
+  if (fe <= (unsigned long long)UR_MAX_E && nf <= UR_MAX_N) dv->uc_mode = UC_SMALL;
+  else if (nf >= 1024 && (double)fe > bu_ratio * (double)rem) dv->uc_mode = UC_BU;
+  else dv->uc_mode = UC_HOST;
+}
+__device__ __forceinline__ void uc_begin(RcmDev *dv, const ChainInit &ci) {
+  dv->uc_off = ci.off, dv->uc_size = ci.size, dv->uc_level = ci.level, dv->uc_total = ci.total;
+  dv->uc_remaining = ci.remaining;
+  dv->uc_flips = 0;
+  dv->uc_small_ran = 0;
+}
+// levels an unordered sweep enqueues behind a big one without waiting for it (run_ubfs); SBX_RCM_UBFS_CHAIN=0: none
+static int ubfs_chain() {
+  // (3: a sweep of the bench matrix has three bottom-up levels in a row — behind a bottom-up level of the host's the
+  // last link finds nothing to do, 5 us; behind a top-down level all three run.  With 2 the second sweep needs another
+  // round trip and leaves two links idle)
+  static const int k = getenv("SBX_RCM_UBFS_CHAIN") ? atoi(getenv("SBX_RCM_UBFS_CHAIN")) : 3;
+  return k < 0 ? 0 : (k > 8 ? 8 : k);
+}
+
 static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search keeps the order inside its levels
   static const bool on = !(getenv("SBX_RCM_UNORDERED") && atoi(getenv("SBX_RCM_UNORDERED")) == 0);
   return on;
@@ -2231,6 +2285,8 @@ __global__ __launch_bounds__(256) void k_ubfs_start(const I *__restrict__ rp, un
   dv->ufedges[0] = dv->ufedges[1] = 0;
   dv->ur_bar = 0;
   dv->ur_exit = 0;
+  dv->uc_done = 0;
+  dv->uc_mode = 0;
   for (int i = 0; i < 3; i++) dv->ur_nf[i] = 0, dv->ur_nh[i] = 0, dv->ur_deg[i] = 0;
   dv->gb_spins = gb_spins;
 }
@@ -2315,7 +2371,15 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
                                                         unsigned *vbits, const unsigned *__restrict__ fbits,
                                                         unsigned *__restrict__ nbits, unsigned *__restrict__ dist,
                                                         unsigned level, I *__restrict__ nf_list, int64_t n,
-                                                        RcmDev *dv) {
+                                                        RcmDev *dv, int chain, ChainInit ci) {
+  // chain 1: a link of a device-driven chain (run_ubfs) — nf_list is the queue's base, level and place come from the
+  // chain, and the link runs only if the chain asks for a bottom-up level; chain 2: the level the host launched in front
+  // of a chain (its state in ci).  Either way the last workgroup out moves the chain on (uc_advance).
+  if (chain == 1) {
+    if (dv->uc_mode != UC_BU) return;
+    level = dv->uc_level + 1;
+    nf_list += dv->uc_off + dv->uc_size;
+  }
   __shared__ I s_stage[4][RCM_STAGE];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -2414,6 +2478,18 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
     stage_push((I)v, found, rp, st, nf_list, dv);
   }
   stage_end_block(st, nf_list, dv, scanned, true);
+  if (chain && threadIdx.x == 0) {
+    // This workgroup's additions to the level's counters were returning atomics or thread 0's own: waiting for the
+    // latter is all the ordering the election needs (the counters live in L2 and are read there).  A release fence
+    // here — a write-back of the L2 per workgroup, 2048 of them — doubled the kernel's time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (atomicAdd(&dv->uc_done, 1u) == gridDim.x - 1) {
+      dv->uc_done = 0;
+      if (chain == 2) uc_begin(dv, ci);
+      else dv->uc_flips++;
+      uc_advance(dv, ci.bu_ratio);
+    }
+  }
 }
 
 // deepest level: smallest degree, then the vertices that have it — marked in the cone bitmap, listed (the list counter
@@ -2637,9 +2713,6 @@ __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
 // with agent-scope atomics, which go past the per-XCD L2s.  The kernel returns when the sweep is over (UR_DONE) or
 // the level it just built is too big for it (UR_STOP: the host continues with the byte-claim / bottom-up kernels; the
 // frontier bitmap is not kept here and is rebuilt if a bottom-up step wants it).
-constexpr unsigned UR_GRID = 64;
-constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
-constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
 #ifndef SBX_UR_HEAVY
 #define SBX_UR_HEAVY 2048
 #endif
@@ -2662,7 +2735,12 @@ __device__ __forceinline__ bool ur_barrier(RcmDev *dv, unsigned &epoch) {
 __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp, const I *__restrict__ col,
                                                         unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
                                                         unsigned off, unsigned size, unsigned level, unsigned total,
-                                                        long long fe_in, unsigned max_levels) {
+                                                        long long fe_in, unsigned max_levels, int from_dev) {
+  if (from_dev) {  // the tail of a device-driven chain (run_ubfs): the frontier is the chain's, if it asks for this kernel at all
+    if (dv->uc_mode != UC_SMALL) return;
+    off = dv->uc_off, size = dv->uc_size, level = dv->uc_level, total = dv->uc_total;
+    fe_in = (long long)dv->uc_fe;
+  }
   // Counters live in three slots used in rotation (slot = level being built % 3): every workgroup reads a level's
   // totals right after its barrier and derives the next state itself — no broadcast, no reset in between; the slot
   // the NEXT level will use is cleared during this one (its last readers passed the previous barrier).  One barrier
@@ -2783,6 +2861,11 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
     dv->ur_status = status;
     dv->ur_fe = fe_cur;
     dv->ur_esum = esum;
+    if (from_dev) {  // (the host reads the unvisited edges back with the rest)
+      const long long rem = dv->uc_remaining - (long long)esum;
+      dv->uc_remaining = rem < 0 ? 0 : rem;
+      dv->uc_small_ran = 1;  // (uc_mode itself stays: workgroups that start late still have to read it)
+    }
     dv->unf[0] = dv->unf[1] = 0;  // (the level slots of the other kernels: levels may change parity in here)
     dv->ufedges[0] = dv->ufedges[1] = 0;
     dv->n_heavy = 0;
@@ -2936,6 +3019,12 @@ __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp,
   }
 }
 
+// The link behind a top-down level (three kernels, none of which knows it is the last): the chain begins here.
+__global__ void k_ubfs_chain_next(RcmDev *dv, ChainInit ci) {
+  uc_begin(dv, ci);
+  uc_advance(dv, ci.bu_ratio);
+}
+
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, unsigned *cone,
@@ -2975,7 +3064,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     if (frontier_edges < 0 || (frontier_edges <= (int64_t)UR_MAX_E && fsize <= UR_MAX_N)) {
       // small levels: as many as stay small, in one launch
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
-                  (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels());
+                  (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels(), 0);
       SBX_LAUNCH_CHECK(h);
       SBX_TRY(bfs_first_launch(b));
       RcmDev hs;
@@ -3003,6 +3092,8 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     I *q_next = b.q + off + fsize;  // the next level is appended to the queue
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
     const bool bottom_up = frontier_edges >= 0 && fsize >= 1024 && (double)frontier_edges > ubu_ratio() * (double)remaining;
+    const int chain_len = ubfs_chain();
+    const ChainInit ci = {off, fsize, level, total, (long long)remaining, ubu_ratio()};
     if (bottom_up) {
       if (!fbits_valid) {
         SBX_HIP(h, hipMemsetAsync(cur_f, 0, bm_bytes, h->stream));
@@ -3011,7 +3102,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       }
       // publishes the level itself (bitmaps, distances, queue): no collection pass
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
-                  b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv);
+                  b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv, chain_len > 0 ? 2 : 0, ci);
       std::swap(cur_f, cur_n);
     } else {
       const unsigned waves_needed = (fsize + RCM_VPW - 1) / RCM_VPW;
@@ -3026,10 +3117,52 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, us);
       SBX_KLAUNCH(h, SBX_K_LEVEL_ORDER, k_ubfs_collect, dim3((unsigned)fw_blocks), dim3(256), claim8,
                   (unsigned long long *)b.vbits, (unsigned long long *)cur_f, dist, level + 1, b.rp, q_next, b.n, b.dv);
+      if (chain_len > 0) SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_chain_next, dim3(1), dim3(1), b.dv, ci);
     }
     SBX_LAUNCH_CHECK(h);
     fbits_valid = true;
     RcmDev hd;
+    if (chain_len > 0) {
+      // The levels behind this one are enqueued without waiting for it: up to ubfs_chain() bottom-up levels and the
+      // persistent small-level kernel.  Each runs only if the state the level in front of it left says so — its last
+      // workgroup out applies the rules of this loop on the device (uc_advance) — and ONE read-back serves them all.
+      // A sweep of the bench matrix: a small run, three bottom-up levels, a small run — five round trips, now two.
+      unsigned *cf = cur_f, *cn = cur_n;
+      for (int i = 0; i < chain_len; i++) {
+        SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
+                    b.vbits, (const unsigned *)cf, cn, dist, 0u, b.q, b.n, b.dv, 1, ci);
+        std::swap(cf, cn);
+      }
+      SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
+                  (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), 1);
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+      if (hd.uc_flips & 1u) std::swap(cur_f, cur_n);
+      rounds += hd.uc_flips;
+      remaining = (int64_t)hd.uc_remaining;
+      if (hd.uc_small_ran) {  // as after the small-level kernel at the head of the loop
+        if (hd.gb_abort) {
+          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+          h->rcm_gb_backoff = 16;
+          *too_deep = true;
+          return SBX_OK;
+        }
+        const bool moved = hd.ur_level != hd.uc_level;
+        off = hd.ur_off, fsize = hd.ur_size, level = hd.ur_level, total = hd.ur_total;
+        frontier_edges = (int64_t)hd.ur_fe;
+        if (moved) fbits_valid = false;
+        if (hd.ur_status == UR_DONE) break;
+        if (hd.ur_status == UR_DEEP) {
+          *too_deep = true;
+          return SBX_OK;
+        }
+        continue;  // UR_STOP: a frontier for the big kernels again (the head of the loop looks at it and passes it on)
+      }
+      off = hd.uc_off, fsize = hd.uc_size, level = hd.uc_level, total = hd.uc_total;
+      if (hd.uc_mode == UC_DONE) break;
+      frontier_edges = (int64_t)hd.uc_fe;  // UC_BU (the chain was too short) / UC_HOST (a top-down level): the loop goes on
+      continue;
+    }
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     const unsigned nf = hd.unf[(level + 1) & 1];
     if (nf == 0) break;

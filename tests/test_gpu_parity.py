@@ -1334,7 +1334,8 @@ def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
     assert np.array_equal(host(got), oracle.rcm_reorder(rp, col)), stats
 
 
-@pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere", "bottom_up_early"])
+@pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere", "bottom_up_early",
+                                  "no_chain", "chain_of_one"])
 def test_rcm_sweep_variants_in_a_child(mode):
     """The switches of the RCM's pseudo-peripheral sweeps are read once per process, hence the children:
     SBX_DEBUG_GB_SPINS=0 makes every grid barrier of the persistent kernels give up at once (what a barrier does when its
@@ -1342,7 +1343,10 @@ def test_rcm_sweep_variants_in_a_child(mode):
     by the one-launch-per-level kernels; SBX_RCM_UNORDERED=0 keeps the order inside every level (round 1's sweeps);
     SBX_DEBUG_UB_MAX_LEVELS lifts the depth limit so that grids and bands take the unordered sweeps too;
     SBX_DEBUG_BU_RATIO=0.3 turns the ordered sweeps bottom-up while hubs are still unvisited: their rows go through the
-    chunk queue of k_bfs_bottom_up / k_bfs_bottom_up_heavy (several chunks of one row meeting in an atomicMin)."""
+    chunk queue of k_bfs_bottom_up / k_bfs_bottom_up_heavy (several chunks of one row meeting in an atomicMin);
+    SBX_RCM_UBFS_CHAIN=0 / 1: the unordered sweeps read back after every big level / chain one bottom-up level behind it
+    (the default chains three: every way a chain can end — sweep over, small frontier, chain too short, a top-down
+    level — comes up between the three settings and these graphs)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1358,7 +1362,8 @@ def test_rcm_sweep_variants_in_a_child(mode):
         "print('rcm variant ok')\n" % (root, os.path.join(root, "tests")))
     extra = {"barriers_give_up": {"SBX_DEBUG_GB_SPINS": "0"}, "ordered_sweeps": {"SBX_RCM_UNORDERED": "0"},
              "unordered_everywhere": {"SBX_DEBUG_UB_MAX_LEVELS": "1000000"},
-             "bottom_up_early": {"SBX_DEBUG_BU_RATIO": "0.3", "SBX_RCM_UNORDERED": "0"}}[mode]
+             "bottom_up_early": {"SBX_DEBUG_BU_RATIO": "0.3", "SBX_RCM_UNORDERED": "0"},
+             "no_chain": {"SBX_RCM_UBFS_CHAIN": "0"}, "chain_of_one": {"SBX_RCM_UBFS_CHAIN": "1"}}[mode]
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
