@@ -614,9 +614,13 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
     if (hybrid_on && in_range && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
       NestGuard guard(h);  // (the nested conversions below must not rewind the arena)
       char *vtmp2 = nullptr;
-      if (vb && np_msd >= 3) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp2));
+      if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp2));
+      // the digit passes leave rows and columns where they came from and the values in the scratch buffer their last
+      // pass does not read, so that the group sort below can write them straight back into the caller's array
+      char *vgrouped = (np_msd & 1) ? vtmp : vtmp2;
       const sbx_radix_side side = {{col, row}, {val, nullptr}, true, false};
-      SBX_TRY(sbx_radix_sort_io(h, 8, vb, &side, ka, kb, vtmp, vtmp2, &side, nnz, msd, np_msd));
+      const sbx_radix_side grouped = {{col, row}, {vb ? vgrouped : nullptr, nullptr}, true, false};
+      SBX_TRY(sbx_radix_sort_io(h, 8, vb, &side, ka, kb, vtmp, vtmp2, &grouped, nnz, msd, np_msd));
       // ka / kb are free again: group ids | in-group keys in one, sorted keys in the other
       int32_t *hi = (int32_t *)ka, *key = hi + nnz, *ksorted = (int32_t *)kb, *bptr = nullptr;
       const int64_t groups = ((n - 1) >> s_bits) + 1;
@@ -626,17 +630,10 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
                   (const int32_t *)col, s_bits, colbits, hi, key, nnz);
       SBX_TRY(sbx_coo_to_csr(h, SBX_I32, SBX_V_NONE, groups, groups, nnz, hi, nullptr, nullptr, bptr, nullptr, nullptr,
                              SBX_FLAG_MOVE | SBX_FLAG_ROWS_SORTED));
-      SBX_TRY(sbx_sort_segments(h, vb, groups, (int64_t)1 << (s_bits + colbits), nnz, bptr, key, (const char *)val,
-                                ksorted, vtmp));
-      if (vb == 0)
-        SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_unpack<0>, dim3(grid), dim3(CV_THREADS), (const int32_t *)ksorted,
-                    (const char *)nullptr, s_bits, colbits, (int32_t *)row, (int32_t *)col, (char *)nullptr, nnz);
-      else if (vb == 4)
-        SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_unpack<4>, dim3(grid), dim3(CV_THREADS), (const int32_t *)ksorted,
-                    (const char *)vtmp, s_bits, colbits, (int32_t *)row, (int32_t *)col, (char *)val, nnz);
-      else
-        SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_unpack<8>, dim3(grid), dim3(CV_THREADS), (const int32_t *)ksorted,
-                    (const char *)vtmp, s_bits, colbits, (int32_t *)row, (int32_t *)col, (char *)val, nnz);
+      SBX_TRY(sbx_sort_segments(h, vb, groups, (int64_t)1 << (s_bits + colbits), nnz, bptr, key, (const char *)vgrouped,
+                                ksorted, (char *)val));
+      SBX_KLAUNCH(h, SBX_K_MISC, k_coo_bucket_unpack<0>, dim3(grid), dim3(CV_THREADS), (const int32_t *)ksorted,
+                  (const char *)nullptr, s_bits, colbits, (int32_t *)row, (int32_t *)col, (char *)nullptr, nnz);
       SBX_LAUNCH_CHECK(h);
       return SBX_OK;
     }

@@ -2496,10 +2496,19 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_
   return SBX_OK;
 }
 
-static int perm_state_alloc(sbx_handle_t h, PermState **st) {
-  PermAll *all = nullptr;
-  SBX_TRY(sbx_salloc(h, 1, &all));
-  *st = &all->st;
+// The call's state, the classification's look-back words and the row records in ONE allocation, zeroed by ONE fill
+// (three fills cost three launches of ~4.5 us in front of the first kernel).  status: for classify_and_scan.
+static int64_t cs_tiles(int64_t nr) { return (nr + CS_TILE - 1) / CS_TILE > 0 ? (nr + CS_TILE - 1) / CS_TILE : 1; }
+static int perm_prep_alloc(sbx_handle_t h, int64_t nr, PermState **st, unsigned long long **status, int2 **rec) {
+  const size_t status_bytes = sizeof(unsigned long long) * (size_t)(cs_tiles(nr) + 2);
+  const size_t bytes = sizeof(PermAll) + status_bytes + sizeof(int2) * (size_t)nr;
+  char *base = nullptr;
+  SBX_TRY(sbx_salloc(h, bytes + 128, &base));
+  base = (char *)(((uintptr_t)base + 127) & ~(uintptr_t)127);  // (PermAll keeps its counters on lines of their own)
+  *st = &((PermAll *)base)->st;
+  *status = (unsigned long long *)(base + sizeof(PermAll));
+  *rec = (int2 *)(base + sizeof(PermAll) + status_bytes);
+  SBX_HIP(h, hipMemsetAsync(base, 0, bytes, h->stream));
   return SBX_OK;
 }
 static int perm_state_zero(sbx_handle_t h, PermState *st) {
@@ -2522,11 +2531,12 @@ static int perm_fetch(sbx_handle_t h, PermState *hs, const PermState *st) {
 // st must have been zeroed by the caller
 template <typename I>
 int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr, I *long_rows, I *block_rows,
-                      int64_t block_stride, int block_cap, PermState *st) {
-  const int64_t tiles = (nr + CS_TILE - 1) / CS_TILE > 0 ? (nr + CS_TILE - 1) / CS_TILE : 1;
-  unsigned long long *status = nullptr;
-  SBX_TRY(sbx_salloc(h, (size_t)(tiles + 2), &status));
-  SBX_HIP(h, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 2), h->stream));
+                      int64_t block_stride, int block_cap, PermState *st, unsigned long long *status = nullptr) {
+  const int64_t tiles = cs_tiles(nr);
+  if (!status) {  // (else: zeroed words from perm_prep_alloc)
+    SBX_TRY(sbx_salloc(h, (size_t)(tiles + 2), &status));
+    SBX_HIP(h, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 2), h->stream));
+  }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_scan<I>, dim3((unsigned)tiles), dim3(256), rec, rpo, sp, nr, long_rows,
               block_rows, block_stride, block_cap, st, status, tiles, (int)(((uintptr_t)rpo & 15) == 0));
   SBX_LAUNCH_CHECK(h);
@@ -2607,10 +2617,8 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
   // (row length, source offset) per new row, written from the old-row side; lengths -> scan -> row_ptr_out
   PermState *st = nullptr;
   int2 *rec = nullptr;
-  SBX_TRY(perm_state_alloc(h, &st));
-  SBX_TRY(sbx_salloc(h, (size_t)nr, &rec));
-  SBX_TRY(perm_state_zero(h, st));
-  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nr, h->stream));
+  unsigned long long *status = nullptr;
+  SBX_TRY(perm_prep_alloc(h, nr, &st, &status, &rec));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((n + 3) / 4, 256, 8192)), dim3(256),
               (const I *)row_ptr, (const I *)row_order, n, row_begin, nr, rec);
   I *long_rows = nullptr, *block_rows = nullptr, *sp = nullptr;
@@ -2625,7 +2633,8 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
     block_stride = cap_long;
   }
   // lengths -> row_ptr_out, the short rows' prefix sums and the class lists: one launch
-  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, long_rows, block_rows, block_stride, block_cap, st));
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, long_rows, block_rows, block_stride, block_cap, st,
+                               status));
   int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
   PermState hs;
   memset(&hs, 0, sizeof(hs));
@@ -2718,17 +2727,16 @@ int sbx_sort_segments(sbx_handle_t h, int vb, int64_t nseg, int64_t key_limit, i
   I *long_rows = nullptr, *block_rows = nullptr;
   int2 *rec = nullptr;
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
-  SBX_TRY(perm_state_alloc(h, &st));
-  SBX_TRY(sbx_salloc(h, (size_t)nseg, &rec));
+  unsigned long long *status = nullptr;
+  SBX_TRY(perm_prep_alloc(h, nseg, &st, &status, &rec));
   SBX_TRY(sbx_salloc(h, (size_t)nseg, &long_rows));
   SBX_TRY(sbx_salloc(h, (size_t)nseg * BR_CLASSES, &block_rows));
-  SBX_TRY(perm_state_zero(h, st));
-  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)nseg, h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((nseg + 3) / 4, 256, 8192)), dim3(256), seg_ptr,
               (const I *)nullptr, nseg, (int64_t)0, nseg, rec);
   I *sp = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)nseg + 1, &sp));
-  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, nseg, long_rows, block_rows, nseg, block_cap, st));
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, nseg, long_rows, block_rows, nseg, block_cap, st,
+                               status));
   PermState hs;
   SBX_TRY(perm_fetch(h, &hs, st));
   // (SBX_V_NONE: no value ordering of equal keys behind the sort)
@@ -2759,19 +2767,18 @@ static int csr_sort_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int
   int2 *rec = nullptr;
   const int block_cap = vb == 8 ? BlockRowCap<8>::value : BlockRowCap<4>::value;
   char *vtmp = nullptr;
-  SBX_TRY(perm_state_alloc(h, &st));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &rec));
+  unsigned long long *status = nullptr;
+  SBX_TRY(perm_prep_alloc(h, n, &st, &status, &rec));
   SBX_TRY(sbx_salloc(h, (size_t)n, &long_rows));
   SBX_TRY(sbx_salloc(h, (size_t)n * BR_CLASSES, &block_rows));
   SBX_TRY(sbx_salloc(h, (size_t)nnz, &ctmp));
   if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp));
-  SBX_TRY(perm_state_zero(h, st));
-  SBX_HIP(h, hipMemsetAsync(rec, 0, sizeof(int2) * (size_t)n, h->stream));
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((n + 3) / 4, 256, 8192)), dim3(256),
               (const I *)row_ptr, (const I *)nullptr, n, (int64_t)0, n, rec);
   I *sp = nullptr;
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &sp));
-  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, n, long_rows, block_rows, (int64_t)n, block_cap, st));
+  SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, (I *)nullptr, sp, n, long_rows, block_rows, (int64_t)n, block_cap, st,
+                               status));
   PermState hs;
   SBX_TRY(perm_fetch(h, &hs, st));
   int rc;

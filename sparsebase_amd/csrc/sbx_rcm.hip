@@ -438,14 +438,10 @@ __device__ void rcm_sort_children(const I *__restrict__ rp, I *a, int cnt) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, const I *__restrict__ col,
-                                                  const I *__restrict__ list, unsigned count,
-                                                  const I *__restrict__ csize, const I *__restrict__ cbase,
-                                                  unsigned *dist, I *order, I *__restrict__ inv,
-                                                  RcmDev *__restrict__ dv) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const I start = list[k];
+// One component (its root `start`), one lane.
+__device__ void rcm_small_component(const I *__restrict__ rp, const I *__restrict__ col, const I start,
+                                    const I *__restrict__ csize, const I *__restrict__ cbase, unsigned *dist, I *order,
+                                    I *__restrict__ inv, RcmDev *__restrict__ dv) {
   const I base = cbase[start], sz = csize[start];
   I *q = order + base;
   // --- pseudo-peripheral search (rcm_reorder.cc:22-81)
@@ -525,6 +521,19 @@ __global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, cons
   for (int i = 0; i < sz; i++) inv[q[i]] = base + (sz - 1 - i);  // reverse + invert (:146-160)
 }
 
+// count_dev: the number of listed components, still on the device (the launch then covers an upper bound: a lane takes
+// every (lanes of the grid)-th component)
+__global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, const I *__restrict__ col,
+                                                  const I *__restrict__ list, unsigned count,
+                                                  const I *__restrict__ csize, const I *__restrict__ cbase,
+                                                  unsigned *dist, I *order, I *__restrict__ inv,
+                                                  RcmDev *__restrict__ dv, const unsigned *__restrict__ count_dev) {
+  if (count_dev) count = *count_dev;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride)
+    rcm_small_component(rp, col, list[k], csize, cbase, dist, order, inv, dv);
+}
+
 // ------------------------------------------------------------------ large components: BFS machinery
 // BFS bookkeeping (sized by the measured scatter ceilings of the chip: scattered
 // atomics run at ~27 G/s, scattered 4-byte loads at ~70 G/s from a 16 MB table and
@@ -593,6 +602,11 @@ constexpr int RCM_STAGE = 512;  // staged vertices per wave
 static double bu_ratio() {
   static const double r = getenv("SBX_DEBUG_BU_RATIO") ? atof(getenv("SBX_DEBUG_BU_RATIO")) : 4.0;
   return r;
+}
+
+static bool rcm_cc_overlap() {  // SBX_RCM_CC_OVERLAP=0: the labelling of the other components runs in line (see sbx_rcm_reorder)
+  static const bool on = !(getenv("SBX_RCM_CC_OVERLAP") && atoi(getenv("SBX_RCM_CC_OVERLAP")) == 0);
+  return on;
 }
 
 static bool rcm_overlap() {
@@ -1912,7 +1926,8 @@ __global__ __launch_bounds__(256) void k_comp_info(const I *__restrict__ roots, 
 }
 
 __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q, unsigned cnt, I base,
-                                                         I *__restrict__ inv) {
+                                                         I *__restrict__ inv, const I *__restrict__ base_dev) {
+  if (base_dev) base = *base_dev;  // (the component's place, still on the device: the size scan's entry of its root)
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; j < cnt; j += stride) inv[q[j]] = base + (I)(cnt - 1 - j);
@@ -3202,6 +3217,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   RcmDev hd;
   if (r.last_size > UB_TIES_SMALL) {
     // (the one-workgroup kernel of the small case names a single candidate itself: no round trip for the count)
+    SBX_TRY(bfs_first_launch(b));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.nf <= 1) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
@@ -3227,6 +3243,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_cone_run, dim3(UR_GRID), dim3(256), b.rp, b.col, (const unsigned *)b.vbits,
                 (const unsigned *)b.lpos, cone, list, (I *)b.heavy, b.dv, k);
     SBX_LAUNCH_CHECK(h);
+    SBX_TRY(bfs_first_launch(b));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.gb_abort) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
@@ -3344,6 +3361,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
   }
   bool ranks_enqueued = false;
+  bool cc_forked = false;  // the labelling of the other components is running on a side stream of its own (below)
   std::function<int()> enqueue_ranks = [&]() -> int {
     if (ranks_enqueued) return SBX_OK;
     ranks_enqueued = true;
@@ -3397,7 +3415,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     if (!ranks_joined) {
       SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[1], 0));
       ranks_joined = true;
-      h->aux_dirty = false;
+      if (!cc_forked) h->aux_dirty = false;
     }
     return SBX_OK;
   };
@@ -3442,6 +3460,91 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
     SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
   }
+  // Pseudo-peripheral search and Cuthill-McKee sweep of one host-ordered component (root = its smallest vertex): leaves
+  // the component's order in q.
+  struct Searched {
+    BfsResult r;
+    int64_t sweeps, levels, candidate;
+    bool cm_done;
+  };
+  Searched sd0;
+  bool comp0_searched = false, small_on_side = false;
+  auto search_component = [&](I root, I size, bool have_first_sweep, Searched &out) -> int {
+    BfsResult &r = out.r;
+    int64_t prev_ecc = -1, ecc = 0;
+    int64_t &sweeps = out.sweeps, &levels = out.levels, &candidate = out.candidate;
+    sweeps = levels = candidate = 0;
+    I fixed = root;
+    bool &cm_done = out.cm_done;
+    cm_done = false;
+    bool deep = !unordered_ok;  // a sweep of more than UB_MAX_LEVELS levels: this component keeps ordered sweeps
+    while (prev_ecc != ecc) {
+      prev_ecc = ecc;
+      bool unordered = false;  // the sweep just run kept no order inside its levels
+      if (have_first_sweep) {
+        r = r0;  // sweep (2) above was exactly this component's first sweep
+        have_first_sweep = false;
+        unordered = r0_unordered;
+        if (!unordered) deep = true;
+      } else {
+        if (candidate >= rcm_speculate_from()) {
+          SBX_TRY(join_ranks());
+          SBX_TRY(run_bfs<true>(h, b, fixed, root, &r));
+          sweeps++;
+          levels += r.levels;
+          const int64_t e = (int64_t)r.levels - 1;
+          const int64_t deepest = e > ecc ? e : ecc;
+          if (deepest == ecc || (int64_t)r.count == deepest + 1) {
+            cm_done = true;  // this candidate is the root and q already holds its Cuthill-McKee order
+            break;
+          }
+          SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
+          fixed = -1;  // k_bfs_start left the root on the device
+        }
+        if (!deep) {
+          SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, root, &r, &deep));
+          unordered = !deep;
+        }
+        if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, root, &r));
+      }
+      fixed = -1;  // later sweeps start from the device-resident root
+      candidate++;
+      sweeps++;
+      levels += r.levels;
+      const int64_t e = (int64_t)r.levels - 1;
+      if (e > ecc) ecc = e;
+      const bool path = (int64_t)r.count == ecc + 1;
+      if (!path && prev_ecc != ecc) {
+        bool tie_aborted = false;
+        if (unordered) SBX_TRY(ubfs_pick_root(h, b, cone, r, &tie_aborted));
+        if (unordered && tie_aborted) {
+          // a grid barrier of the tie-break gave up: the same sweep again, ordered (dv->root still is its root)
+          deep = true;
+          unordered = false;
+          SBX_TRY(run_bfs<false>(h, b, -1, root, &r));
+        }
+        if (!unordered) {
+          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
+                             (const I *)(q + r.last_offset), r.last_size, dv);
+          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
+        }
+      }
+      if (!unordered) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
+      if (path) break;
+    }
+    // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
+    if (!cm_done) {
+      SBX_TRY(join_ranks());
+      SBX_TRY(run_bfs<true>(h, b, -1, root, &r));
+      sweeps++;
+      levels += r.levels;
+    }
+    if ((int64_t)r.count != (int64_t)size)
+      SBX_FAIL(h, SBX_ERR_BAD_ARG,
+               "sbx_rcm_reorder: BFS reached %u of %d vertices of a component (pattern not symmetric?)", r.count,
+               size);
+    return SBX_OK;
+  };
   // (3) connected components of the rest; the root of each tree is the component's smallest id.  When the first sweep
   // reached every non-empty row there is no rest: one kernel places the empty rows and the stage ends (a power-law
   // input: ~0.2 ms of union-find, size scan, classification and two round trips saved)
@@ -3461,6 +3564,13 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     n_host = 1;
     first_is_large = true;
   } else {
+  // The first sweep's component, when it is one the host orders anyway (more than RCM_MID vertices), does not wait for
+  // the labelling of the rest: union-find, size scan and classification — streaming passes over all n vertices, 0.13 ms
+  // on the bench matrix — run on a side stream while the caller's stream goes on with that component's search and
+  // Cuthill-McKee sweep, which are bound by launches and latency, not by bandwidth.  The search needs no labels (a sweep
+  // cannot leave its component; unlabelled, the bottom-up levels merely look at the other components' vertices too).
+  cc_forked = side && v0 >= 0 && r0.count > (unsigned)RCM_MID && r0_unordered && rcm_cc_overlap();
+  auto enqueue_cc_kernels = [&]() -> int {
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n, (const unsigned *)cbits);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list,
               (const unsigned *)cbits, dv);
@@ -3477,6 +3587,50 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gcount), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
               small_list, mid_list, large_list, n, dv);
   SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+  };
+  if (cc_forked) {
+    // The side stream's ten launches are enqueued behind the search's first kernels (the hook every sweep and tie-break
+    // calls before its first read-back): the host needs ~50 us for them, which the caller's stream would spend idle.
+    SBX_HIP(h, hipEventRecord(h->aux_event[2], main_stream));
+    h->aux_dirty = true;
+    bool cc_enqueued = false;
+    std::function<int()> enqueue_cc = [&]() -> int {
+      SBX_TRY(enqueue_ranks());
+      if (cc_enqueued) return SBX_OK;
+      cc_enqueued = true;
+      SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[2], 0));
+      h->stream = h->aux_stream[1];
+      int rc = enqueue_cc_kernels();
+      if (rc == SBX_OK) {  // the small components too: their number stays on the device, the launch covers any
+        const unsigned lanes = (unsigned)std::min<int64_t>((n / 2 + 63) / 64 * 64, (int64_t)h->num_cus * 32 * 64);
+        SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3(lanes / 64 > 0 ? lanes / 64 : 1), dim3(64), rp, col,
+                    (const I *)small_list, 0u, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv,
+                    (const unsigned *)&dv->n_small);
+        if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
+      }
+      if (rc == SBX_OK && hipEventRecord(h->aux_event[3], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
+      h->stream = main_stream;
+      return rc;
+    };
+    b.after_first_launch = &enqueue_cc;
+    const int src = search_component(v0, (I)r0.count, true, sd0);
+    b.after_first_launch = &enqueue_ranks;
+    SBX_TRY(src);
+    SBX_TRY(enqueue_cc());  // (a search that never waited for anything)
+    comp0_searched = true;
+    SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[3], 0));
+    cc_forked = false;
+    if (ranks_joined || !ranks_enqueued) h->aux_dirty = false;
+    // the component's order is complete in q: written at once, its place read from the size scan on the device — when
+    // it is the only one the host orders, the read-back below is the call's last
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(sd0.r.count, 256, 4096)), dim3(256), (const I *)q,
+                sd0.r.count, (I)0, inv, (const I *)(cbase + v0));
+    SBX_LAUNCH_CHECK(h);
+    small_on_side = true;
+  } else {
+    SBX_TRY(enqueue_cc_kernels());
+  }
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
   if (hd.unsym)
     SBX_FAIL(h, SBX_ERR_BAD_ARG,
@@ -3495,14 +3649,15 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_TRY(reset_ppos(h, (const I *)q, r0.count, ppos, n));
   }
   // (3) small (and, batched, mid-size) components: one lane each
-  if (hd.n_small) {
+  if (hd.n_small && !small_on_side) {
     SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_small + 63) / 64), dim3(64), rp, col,
-                       (const I *)small_list, hd.n_small, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
+                       (const I *)small_list, hd.n_small, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv,
+                       (const unsigned *)nullptr);
     SBX_LAUNCH_CHECK(h);
   }
   if (mid_batched) {
     SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3((hd.n_mid + 63) / 64), dim3(64), rp, col, (const I *)mid_list,
-                hd.n_mid, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv);
+                hd.n_mid, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv, (const unsigned *)nullptr);
     SBX_LAUNCH_CHECK(h);
   }
   }
@@ -3514,6 +3669,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_TRY(sbx_salloc(h, (size_t)3 * n_host, &info));
     if (single_component) {  // root v0; every vertex in front of it has an empty row, i.e. is a component of its own
       roots[0] = v0, sizes[0] = (I)r0.count, bases[0] = v0;
+    } else if (comp0_searched && n_host == 1) {  // (already written, its place taken from the device)
+      roots[0] = v0, sizes[0] = (I)r0.count, bases[0] = 0;
     } else {
     if (hd.n_large)
       SBX_HIP(h, hipMemcpyAsync(info, large_list, hd.n_large * sizeof(I), hipMemcpyDeviceToDevice, h->stream));
@@ -3551,80 +3708,17 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       // one sweep saved; if it did, the plain sweep is still needed (its order inside the last
       // level breaks the ties for the next candidate) and the speculative one was wasted.
       // Either way the output is the reference's; only the number of sweeps differs.
-      BfsResult r;
-      int64_t prev_ecc = -1, ecc = 0, sweeps = 0, levels = 0, candidate = 0;
-      I fixed = roots[c];
-      bool have_first_sweep = first_is_large && roots[c] == v0;
-      bool cm_done = false;
-      bool deep = !unordered_ok;  // a sweep of more than UB_MAX_LEVELS levels: this component keeps ordered sweeps
-      while (prev_ecc != ecc) {
-        prev_ecc = ecc;
-        bool unordered = false;  // the sweep just run kept no order inside its levels
-        if (have_first_sweep) {
-          r = r0;  // sweep (2) above was exactly this component's first sweep
-          have_first_sweep = false;
-          unordered = r0_unordered;
-          if (!unordered) deep = true;
-        } else {
-          if (candidate >= rcm_speculate_from()) {
-            SBX_TRY(join_ranks());
-            SBX_TRY(run_bfs<true>(h, b, fixed, roots[c], &r));
-            sweeps++;
-            levels += r.levels;
-            const int64_t e = (int64_t)r.levels - 1;
-            const int64_t deepest = e > ecc ? e : ecc;
-            if (deepest == ecc || (int64_t)r.count == deepest + 1) {
-              cm_done = true;  // this candidate is the root and q already holds its Cuthill-McKee order
-              break;
-            }
-            SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
-            fixed = -1;  // k_bfs_start left the root on the device
-          }
-          if (!deep) {
-            SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, roots[c], &r, &deep));
-            unordered = !deep;
-          }
-          if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, roots[c], &r));
-        }
-        fixed = -1;  // later sweeps start from the device-resident root
-        candidate++;
-        sweeps++;
-        levels += r.levels;
-        const int64_t e = (int64_t)r.levels - 1;
-        if (e > ecc) ecc = e;
-        const bool path = (int64_t)r.count == ecc + 1;
-        if (!path && prev_ecc != ecc) {
-          bool tie_aborted = false;
-          if (unordered) SBX_TRY(ubfs_pick_root(h, b, cone, r, &tie_aborted));
-          if (unordered && tie_aborted) {
-            // a grid barrier of the tie-break gave up: the same sweep again, ordered (dv->root still is its root)
-            deep = true;
-            unordered = false;
-            SBX_TRY(run_bfs<false>(h, b, -1, roots[c], &r));
-          }
-          if (!unordered) {
-            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
-                               (const I *)(q + r.last_offset), r.last_size, dv);
-            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
-          }
-        }
-        if (!unordered) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
-        if (path) break;
+      Searched sd;
+      if (c == 0 && comp0_searched) sd = sd0;
+      else SBX_TRY(search_component(roots[c], sizes[c], first_is_large && roots[c] == v0, sd));
+      const BfsResult &r = sd.r;
+      const int64_t sweeps = sd.sweeps, levels = sd.levels, candidate = sd.candidate;
+      const bool cm_done = sd.cm_done;
+      if (!(c == 0 && comp0_searched)) {
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
+                           (const I *)q, r.count, bases[c], inv, (const I *)nullptr);
+        SBX_LAUNCH_CHECK(h);
       }
-      // Cuthill-McKee BFS from the pseudo-peripheral vertex (:118-144)
-      if (!cm_done) {
-        SBX_TRY(join_ranks());
-        SBX_TRY(run_bfs<true>(h, b, -1, roots[c], &r));
-        sweeps++;
-        levels += r.levels;
-      }
-      if ((int64_t)r.count != (int64_t)sizes[c])
-        SBX_FAIL(h, SBX_ERR_BAD_ARG,
-                 "sbx_rcm_reorder: BFS reached %u of %d vertices of a component (pattern not symmetric?)", r.count,
-                 sizes[c]);
-      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(r.count, 256, 4096)), dim3(256),
-                         (const I *)q, r.count, bases[c], inv);
-      SBX_LAUNCH_CHECK(h);
       // invariant of the sweeps (k_visited_from_ppos relies on it): ppos is UNSEEN outside the running sweep
       if (c + 1 < n_host) SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
       if (sizes[c] > largest) {
@@ -3639,7 +3733,8 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   }
   SBX_TRY(join_ranks());  // inputs without a large component never ran a Cuthill-McKee sweep
   RcmDev fin;  // (also the synchronisation point of the call)
-  SBX_TRY(sbx_readback(h, &fin, dv, sizeof(RcmDev)));
+  if (comp0_searched && n_host == 1 && !mid_batched) fin = hd;  // nothing was launched behind that read-back
+  else SBX_TRY(sbx_readback(h, &fin, dv, sizeof(RcmDev)));
   if (fin.unsym)
     SBX_FAIL(h, SBX_ERR_BAD_ARG,
              "sbx_rcm_reorder: the pattern is not structurally symmetric (a BFS cannot reach its whole component); "
