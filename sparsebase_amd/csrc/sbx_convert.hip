@@ -926,6 +926,63 @@ int coo_to_csc_core(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int
   return sbx_csr_sort_rows(h, SBX_I32, vb ? vt : SBX_V_NONE, m, n, nnz, col_ptr_out, row_out, vb ? val_out : nullptr);
 }
 
+// ---- 64-bit index arrays, native: (column, source index) pairs through the radix sort — 8-byte keys over the column's
+// significant bits, 4-byte payload (nnz < 2^31) — rows and values gathered through the sorted indices, col_ptr from the
+// sorted columns.  No narrowed copies; one gather pass more than the 32-bit path, whose payload carries row and value.
+__global__ __launch_bounds__(CV_THREADS) void k_csc_keys64(const int64_t *__restrict__ col, uint64_t *__restrict__ key,
+                                                           uint32_t *__restrict__ idx, int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    key[i] = (uint64_t)col[i];
+    idx[i] = (uint32_t)i;
+  }
+}
+template <int VB>
+__global__ __launch_bounds__(CV_THREADS) void k_csc_gather64(const uint32_t *__restrict__ idx,
+                                                             const int64_t *__restrict__ row,
+                                                             const char *__restrict__ val,
+                                                             int64_t *__restrict__ row_out, char *__restrict__ val_out,
+                                                             int64_t nnz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    const uint32_t j = idx[i];
+    row_out[i] = row[j];
+    if (VB == 4) ((uint32_t *)val_out)[i] = ((const uint32_t *)val)[j];
+    if (VB == 8) ((uint64_t *)val_out)[i] = ((const uint64_t *)val)[j];
+  }
+}
+int coo_to_csc_core64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const int64_t *row,
+                      const int64_t *col, const char *val, int64_t *col_ptr_out, int64_t *row_out, char *val_out,
+                      bool rows_ascend = false) {
+  if (nnz == 0) return sbx_fill_i64(h, col_ptr_out, 0, m + 1);
+  const int vb = (val && val_out) ? sbx_value_bytes(vt) : 0;
+  const unsigned grid = sbx_grid_for(nnz, CV_THREADS, 8192);
+  sbx_radix_pass passes[16];
+  const int np = sbx_radix_plan(0, sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0), 0, 0, passes);
+  uint64_t *ka = nullptr, *kb = nullptr;
+  uint32_t *ia = nullptr, *ib = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ka));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &kb));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ia));
+  SBX_TRY(sbx_salloc(h, (size_t)nnz, &ib));
+  SBX_KLAUNCH(h, SBX_K_CSC, k_csc_keys64, dim3(grid), dim3(CV_THREADS), col, ka, ia, nnz);
+  SBX_LAUNCH_CHECK(h);
+  int in_b = 0;
+  if (np > 0 && nnz >= 2) SBX_TRY(sbx_radix_sort(h, 8, 4, ka, kb, ia, ib, nnz, passes, np, &in_b));
+  const uint32_t *idx = in_b ? ib : ia;
+  if (vb == 0) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather64<0>, dim3(grid), dim3(CV_THREADS), idx, row, val, row_out, val_out, nnz);
+  else if (vb == 4) SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather64<4>, dim3(grid), dim3(CV_THREADS), idx, row, val, row_out, val_out, nnz);
+  else SBX_KLAUNCH(h, SBX_K_CSC, k_csc_gather64<8>, dim3(grid), dim3(CV_THREADS), idx, row, val, row_out, val_out, nnz);
+  SBX_LAUNCH_CHECK(h);
+  SBX_PROF_BYTES(h, SBX_K_CSC, nnz * (int64_t)(16 + 2 * (8 + vb)));
+  SBX_TRY(sbx_coo_to_csr(h, SBX_I64, SBX_V_NONE, m, n, nnz, in_b ? kb : ka, nullptr, nullptr, col_ptr_out, nullptr, nullptr,
+                         SBX_FLAG_MOVE));
+  if (rows_ascend) return SBX_OK;  // (see coo_to_csc_core)
+  return sbx_csr_sort_rows(h, SBX_I64, vb ? vt : SBX_V_NONE, m, n, nnz, col_ptr_out, row_out, vb ? val_out : nullptr);
+}
+
 }  // namespace
 
 extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
@@ -967,10 +1024,12 @@ extern "C" int sbx_coo_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && col_ptr_out && (nnz == 0 || (row && col && row_out)), "bad argument");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,
               "dimension exceeds int32");
-  if (it == SBX_I64) return sbx_i64_coo_to_csc(h, vt, n, m, nnz, row, col, val, col_ptr_out, row_out, val_out);
   SBX_REQUIRE(h, !(val && val_out) || sbx_value_bytes(vt) >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
   NestGuard guard(h);
+  if (it == SBX_I64)  // native 64-bit kernels
+    return coo_to_csc_core64(h, vt, n, m, nnz, (const int64_t *)row, (const int64_t *)col, (const char *)val,
+                             (int64_t *)col_ptr_out, (int64_t *)row_out, (char *)val_out);
   return coo_to_csc_core(h, vt, n, m, nnz, (const int32_t *)row, (const int32_t *)col, (const char *)val,
                          (int32_t *)col_ptr_out, (int32_t *)row_out, (char *)val_out);
 }
@@ -984,10 +1043,19 @@ extern "C" int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type 
               "bad argument");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,
               "dimension exceeds int32");
-  if (it == SBX_I64) return sbx_i64_csr_to_csc(h, vt, n, m, nnz, row_ptr, col, val, col_ptr_out, row_out, val_out);
   SBX_REQUIRE(h, !(val && val_out) || sbx_value_bytes(vt) >= 0, "unknown value type");
   SBX_TRY(sbx_arena_begin(h));
   NestGuard guard(h);
+  if (it == SBX_I64) {  // native 64-bit kernels
+    int64_t *rows64 = nullptr;
+    if (nnz > 0) {
+      SBX_TRY(sbx_salloc(h, (size_t)nnz, &rows64));
+      SBX_TRY(sbx_csr_to_coo(h, SBX_I64, SBX_V_NONE, n, m, nnz, row_ptr, nullptr, nullptr, rows64, nullptr, nullptr,
+                             SBX_FLAG_MOVE));
+    }
+    return coo_to_csc_core64(h, vt, n, m, nnz, rows64, (const int64_t *)col, (const char *)val, (int64_t *)col_ptr_out,
+                             (int64_t *)row_out, (char *)val_out, /*rows_ascend=*/true);
+  }
   int32_t *rows = nullptr;
   if (nnz > 0) {
     SBX_TRY(sbx_salloc(h, (size_t)nnz, &rows));

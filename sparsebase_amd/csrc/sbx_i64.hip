@@ -2,7 +2,7 @@
 // <int64,int64,double> tuple).  NATIVE 64-bit kernels (no copies): the conversions COO <-> CSR and the two sortedness
 // checks (sbx_convert.hip), the four features (sbx_features.hip), DegreeReorder (sbx_degree.hip), InversePermutation,
 // PermuteArray, the CSR permute with and without a column map, the CSR constructor's row sort (sbx_permute.hip) and the
-// COO constructor's sort (sbx_convert.hip).  The entry points in THIS file — CSC, RCM, Gray keys, the text parsers, and
+// COO constructor's sort and the CSC conversions (sbx_convert.hip).  The entry points in THIS file — RCM, Gray keys, the text parsers, and
 // the COO sort of coordinates that lie outside their matrix — narrow their index arrays to int32 scratch copies (with
 // an overflow check), run the int32 kernels and widen the index outputs back; values are opaque payload and pass
 // through untouched; arrays with entries >= 2^31 return SBX_ERR_UNSUPPORTED there.
@@ -109,32 +109,6 @@ int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, in
 
 static int read_nnz_i64(sbx_handle_t h, const void *row_ptr, int64_t n, int64_t *nnz) {
   return sbx_readback(h, nnz, (const int64_t *)row_ptr + n, sizeof(int64_t));
-}
-
-int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
-                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
-  I64_BEGIN();
-  NARROW(r, row, nnz);
-  NARROW(c, col, nnz);
-  SCRATCH32(cp, m + 1, true);
-  SCRATCH32(ro, nnz, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_coo_to_csc(h, SBX_I32, vt, n, m, nnz, r, c, val, cp, ro, val_out));
-  SBX_TRY(sbx_widen_i32(h, cp, col_ptr_out, m + 1));
-  return sbx_widen_i32(h, ro, row_out, nnz);
-}
-
-int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SCRATCH32(cp, m + 1, true);
-  SCRATCH32(ro, nnz, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_csr_to_csc(h, SBX_I32, vt, n, m, nnz, rp, c, val, cp, ro, val_out));
-  SBX_TRY(sbx_widen_i32(h, cp, col_ptr_out, m + 1));
-  return sbx_widen_i32(h, ro, row_out, nnz);
 }
 
 int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t n_rows,

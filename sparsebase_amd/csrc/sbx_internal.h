@@ -257,10 +257,6 @@ int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev);     // synchron
 void sbx_i64_end(sbx_handle_t h);
 int sbx_i64_coo_sort(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, void *row, void *col,
                      void *val);
-int sbx_i64_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
-                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
-int sbx_i64_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
-                       const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
 int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t n_rows,
                                  int64_t n_cols, int64_t entries, int fields, int symmetry, unsigned flags,
                                  int64_t capacity, void *row_out, void *col_out, void *val_out, int64_t *nnz_host);

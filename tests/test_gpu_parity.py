@@ -80,9 +80,11 @@ def test_csc_vs_oracle(ops, oracle, seed):
     rp, cc, _ = oracle.coo_to_csr(n, srow, scol)
     val = g.random(nnz).astype(np.float32)
     same(ops.csr_to_csc(n, m, dev(rp), dev(cc), dev(val)), oracle.csr_to_csc(m, rp, cc, val))
-    # int64 tuple
-    same(ops.csr_to_csc(n, m, dev(rp.astype(np.int64)), dev(cc.astype(np.int64)), dev(val.astype(np.float64))),
-         oracle.csr_to_csc(m, rp.astype(np.int64), cc.astype(np.int64), val.astype(np.float64)))
+    # int64 tuple: native 64-bit kernels (a (column, source index) sort + a gather), every value width, both entry points
+    rp64, cc64, row64, col64 = (a.astype(np.int64) for a in (rp, cc, row, col))
+    for v in (val.astype(np.float64), val, None):
+        same(ops.csr_to_csc(n, m, dev(rp64), dev(cc64), dev(v)), oracle.csr_to_csc(m, rp64, cc64, v))
+        same(ops.coo_to_csc(n, m, dev(row64), dev(col64), dev(v)), oracle.coo_to_csc(n, m, row64, col64, v))
     # transposing twice restores the CSR
     cp, ro, vo = ops.csr_to_csc(n, m, dev(rp), dev(cc), dev(val))
     back = ops.csr_to_csc(m, n, cp, ro, vo)
