@@ -157,7 +157,10 @@ int sbx_radix_plan(int lo0, int hi0, int lo1, int hi1, sbx_radix_pass *passes) {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_MAX_PASSES = 8;
-constexpr int RS_LOOKBACK = 8;  // predecessor status words fetched per look-back round
+#ifndef SBX_RS_LOOKBACK
+#define SBX_RS_LOOKBACK 8
+#endif
+constexpr int RS_LOOKBACK = SBX_RS_LOOKBACK;  // predecessor status words fetched per look-back round
 #ifndef RS_STALL_SLEEP
 #define RS_STALL_SLEEP 1
 #endif

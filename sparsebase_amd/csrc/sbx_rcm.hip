@@ -2716,6 +2716,8 @@ __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
   dv->hub_overflow = 0;
   dv->unf[0] = dv->unf[1] = 0;
   dv->ufedges[0] = dv->ufedges[1] = 0;
+  dv->uc_mode = 0;
+  dv->uc_done = 0;
 }
 
 // ---- unordered sweeps, small levels: one launch for as many consecutive levels as stay small ------------------
@@ -2753,6 +2755,10 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
                                                         long long fe_in, unsigned max_levels, int from_dev) {
   if (from_dev) {  // the tail of a device-driven chain (run_ubfs): the frontier is the chain's, if it asks for this kernel at all
     if (dv->uc_mode != UC_SMALL) return;
+    // (tests, SBX_DEBUG_CHAIN_TAIL_ABORT: the grid barriers of this launch give up — after the workgroups have claimed
+    // their first vertices, which is what a barrier that gives up on a shared GPU leaves behind)
+    if (from_dev == 2 && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(&dv->gb_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     off = dv->uc_off, size = dv->uc_size, level = dv->uc_level, total = dv->uc_total;
     fe_in = (long long)dv->uc_fe;
   }
@@ -3148,20 +3154,23 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                     b.vbits, (const unsigned *)cf, cn, dist, 0u, b.q, b.n, b.dv, 1, ci);
         std::swap(cf, cn);
       }
+      static const int tail_mode = getenv("SBX_DEBUG_CHAIN_TAIL_ABORT") && atoi(getenv("SBX_DEBUG_CHAIN_TAIL_ABORT")) ? 2 : 1;
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
-                  (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), 1);
+                  (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), tail_mode);
       SBX_LAUNCH_CHECK(h);
       SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+      if (hd.gb_abort) {
+        // a grid barrier of the chain's small-level kernel gave up — before it could say that it ran at all: the sweep
+        // is redone by the ordered kernels, as after the small-level kernel at the head of the loop
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
+        h->rcm_gb_backoff = 16;
+        *too_deep = true;
+        return SBX_OK;
+      }
       if (hd.uc_flips & 1u) std::swap(cur_f, cur_n);
       rounds += hd.uc_flips;
       remaining = (int64_t)hd.uc_remaining;
       if (hd.uc_small_ran) {  // as after the small-level kernel at the head of the loop
-        if (hd.gb_abort) {
-          SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
-          h->rcm_gb_backoff = 16;
-          *too_deep = true;
-          return SBX_OK;
-        }
         const bool moved = hd.ur_level != hd.uc_level;
         off = hd.ur_off, fsize = hd.ur_size, level = hd.ur_level, total = hd.ur_total;
         frontier_edges = (int64_t)hd.ur_fe;
