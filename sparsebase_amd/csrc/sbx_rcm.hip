@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <vector>
 #include <functional>
+#include <string>
 
 namespace {
 
@@ -602,6 +603,13 @@ constexpr int RCM_STAGE = 512;  // staged vertices per wave
 static double bu_ratio() {
   static const double r = getenv("SBX_DEBUG_BU_RATIO") ? atof(getenv("SBX_DEBUG_BU_RATIO")) : 4.0;
   return r;
+}
+
+// calls a handle keeps away from the persistent kernels after a grid barrier gave up (SBX_DEBUG_GB_BACKOFF: stress tests
+// set 0 so that every call tries them again)
+static int gb_backoff_calls() {
+  static const int k = getenv("SBX_DEBUG_GB_BACKOFF") ? atoi(getenv("SBX_DEBUG_GB_BACKOFF")) : 16;
+  return k;
 }
 
 static bool rcm_cc_overlap() {  // SBX_RCM_CC_OVERLAP=0: the labelling of the other components runs in line (see sbx_rcm_reorder)
@@ -2635,7 +2643,14 @@ constexpr unsigned UB_DESC_GRID = 64;
 constexpr unsigned GB_SPINS = 1u << 16;
 __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned target) {
   __shared__ int s_ok;
-  __syncthreads();  // (also waits for this workgroup's outstanding stores and atomics: vmcnt)
+  // Everything this workgroup stored for the others (queue entries, hub queue, counters: agent-scope stores and atomics,
+  // written through to the memory side) must have ARRIVED before the arrival below is counted.  __syncthreads() does
+  // not wait for that — it compiles to s_barrier with no vmcnt wait in front — and the arrival, an atomic on another
+  // address, can overtake a store that is still on its way: a workgroup on another XCD then passes the barrier and
+  // reads the old word.  Seen only with several processes on the GPU (the memory side congested): one call in ~5000
+  // lost part of a level — a hub's neighbours scanned from a stale hub queue — and with it vertices of its component.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every wave, for its own stores
+  __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(word, 1u);
     int ok = 1;
@@ -3046,6 +3061,25 @@ __global__ void k_ubfs_chain_next(RcmDev *dv, ChainInit ci) {
   uc_advance(dv, ci.bu_ratio);
 }
 
+// SBX_DEBUG_RCM_CHECK=1: after an unordered sweep, every edge that leaves its visited set (there must be none) is counted
+// and the first few are recorded: (visited end, unvisited end, the visited end's level).
+__global__ __launch_bounds__(256) void k_check_closed(const I *__restrict__ rp, const I *__restrict__ col,
+                                                      const unsigned *__restrict__ vbits, const unsigned *__restrict__ dist,
+                                                      int64_t n, unsigned *__restrict__ out) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; u < n; u += stride) {
+    if (!((vbits[u >> 5] >> (u & 31)) & 1u)) continue;
+    for (I j = rp[u]; j < rp[u + 1]; j++) {
+      const I w = col[j];
+      if (!((vbits[w >> 5] >> (w & 31)) & 1u)) {
+        const unsigned k = atomicAdd(&out[0], 1u);
+        if (k < 8) out[1 + 3 * k] = (unsigned)u, out[2 + 3 * k] = (unsigned)w, out[3 + 3 * k] = dist[u];
+      }
+    }
+  }
+}
+
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, unsigned *cone,
@@ -3077,6 +3111,15 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   unsigned *cur_f = b.fbits, *cur_n = nbits_buf;  // frontier bitmap / the one a bottom-up level writes (swapped after it)
   bool fbits_valid = true;  // cur_f holds exactly the current frontier (the root, or what the level kernels left)
   unsigned rounds = 0;      // host round trips of this sweep
+  static const bool dbg_check = getenv("SBX_DEBUG_RCM_CHECK") && atoi(getenv("SBX_DEBUG_RCM_CHECK")) != 0;
+  std::vector<std::string> trace;
+  auto note = [&](const char *what, unsigned a, unsigned b_, long long c) {
+    if (!dbg_check) return;
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s level %u off %u fsize %u total %u fe %lld rem %lld | %u %u %lld", what, level, off, fsize, total,
+             (long long)frontier_edges, (long long)remaining, a, b_, c);
+    trace.push_back(buf);
+  };
   while (true) {
     if (++rounds > ub_max_levels()) {
       *too_deep = true;
@@ -3092,11 +3135,12 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
       if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
-        h->rcm_gb_backoff = 16;
+        h->rcm_gb_backoff = gb_backoff_calls();
         *too_deep = true;
         return SBX_OK;
       }
       const bool moved = hs.ur_level != level;
+      note("small_run(before)", hs.ur_status, hs.ur_level, (long long)hs.ur_esum);
       off = hs.ur_off, fsize = hs.ur_size, level = hs.ur_level, total = hs.ur_total;
       remaining -= (int64_t)hs.ur_esum;
       if (remaining < 0) remaining = 0;
@@ -3113,6 +3157,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     I *q_next = b.q + off + fsize;  // the next level is appended to the queue
     const UnorderedSweep us = {claim8, nullptr, dist, level + 1};
     const bool bottom_up = frontier_edges >= 0 && fsize >= 1024 && (double)frontier_edges > ubu_ratio() * (double)remaining;
+    note(bottom_up ? "bottom-up" : "top-down", fbits_valid, 0, 0);
     const int chain_len = ubfs_chain();
     const ChainInit ci = {off, fsize, level, total, (long long)remaining, ubu_ratio()};
     if (bottom_up) {
@@ -3163,7 +3208,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
         // a grid barrier of the chain's small-level kernel gave up — before it could say that it ran at all: the sweep
         // is redone by the ordered kernels, as after the small-level kernel at the head of the loop
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
-        h->rcm_gb_backoff = 16;
+        h->rcm_gb_backoff = gb_backoff_calls();
         *too_deep = true;
         return SBX_OK;
       }
@@ -3189,6 +3234,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     }
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     const unsigned nf = hd.unf[(level + 1) & 1];
+    note("  -> built", nf, 0, (long long)hd.ufedges[(level + 1) & 1]);
     if (nf == 0) break;
     frontier_edges = (int64_t)hd.ufedges[(level + 1) & 1];
     remaining -= frontier_edges;
@@ -3199,6 +3245,21 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     level++;
   }
   *b.claim_clean = true;
+  if (dbg_check) {
+    unsigned *chk = nullptr;
+    SBX_TRY(sbx_salloc(h, 32, &chk));
+    SBX_HIP(h, hipMemsetAsync(chk, 0, 32 * sizeof(unsigned), h->stream));
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_check_closed, dim3(1024), dim3(256), b.rp, b.col, (const unsigned *)b.vbits,
+                (const unsigned *)dist, b.n, chk);
+    unsigned hc[32];
+    SBX_TRY(sbx_readback(h, hc, chk, sizeof(hc)));
+    if (hc[0]) {
+      fprintf(stderr, "[rcm check] unordered sweep left %u edges open; root %d, total %u, levels %u\n", hc[0], (int)fixed_root, total, level + 1);
+      for (unsigned k = 0; k < (hc[0] < 8 ? hc[0] : 8); k++)
+        fprintf(stderr, "   visited %u (level %u) -> unvisited %u\n", hc[1 + 3 * k], hc[3 + 3 * k], hc[2 + 3 * k]);
+      for (auto &t : trace) fprintf(stderr, "   %s\n", t.c_str());
+    }
+  }
   out->count = total;
   out->levels = level + 1;
   out->last_offset = off;
@@ -3256,7 +3317,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.gb_abort) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
-      h->rcm_gb_backoff = 16;
+      h->rcm_gb_backoff = gb_backoff_calls();
       *aborted = true;
       return SBX_OK;
     }
@@ -3278,7 +3339,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
   if (hd.gb_abort) {
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
-    h->rcm_gb_backoff = 16;
+    h->rcm_gb_backoff = gb_backoff_calls();
     *aborted = true;
   }
   return SBX_OK;

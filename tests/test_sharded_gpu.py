@@ -211,3 +211,21 @@ def test_rcm_eight_processes_on_one_gpu():
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-1500:]
+
+
+def test_rcm_eight_processes_thousands_of_calls():
+    """Eight processes, 400 rounds over four graphs each, on ONE GPU, every call trying the persistent kernels again
+    (SBX_DEBUG_GB_BACKOFF=0): 12 800 orderings against the oracle.  What this guards: a workgroup's stores for the other
+    workgroups — the small levels' queue entries and hub queue — have to arrive before its arrival at the grid barrier
+    is counted (gb_wait waits for them; `__syncthreads()` alone does not), or a workgroup on another XCD passes the
+    barrier and reads the old word.  With the memory side congested by the other processes that lost part of a level
+    about once in 5000 calls — rounds 2 to 4 carried it."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    env = dict(os.environ, SBX_DEBUG_GB_BACKOFF="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "rcm_shared_loop.py"), "400"], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(8)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "mismatches 0 exceptions 0" in o, o[-1500:]
