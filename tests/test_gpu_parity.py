@@ -1100,6 +1100,17 @@ def test_int64_values_beyond_int32(ops, oracle):
     assert e.value.status == 5
 
 
+def test_int64_degenerate_inputs():
+    """Empty matrices, empty rows only, one entry, a shard of no rows, duplicate coordinates — through the native 64-bit
+    entry points of the permute, both constructor sorts and the CSC conversions (tools/int64_degenerate.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "int64_degenerate.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "int64 degenerate ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("case", ["mixed", "all_tail_one_degree", "wide_int64", "tail_of_one", "tail_of_two", "small_n"])
 def test_degree_reorder_counting_passes(ops, oracle, case):
     """DegreeReorder's placement (degree_reorder.cc:22-62) through every branch of the device path: the 255-capped
