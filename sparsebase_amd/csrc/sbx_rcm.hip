@@ -612,6 +612,11 @@ static int gb_backoff_calls() {
   return k;
 }
 
+static bool rcm_split_expand() {  // SBX_RCM_SPLIT_EXPAND=0: a wide frontier's light rows are expanded in front of its hubs
+  static const bool on = !(getenv("SBX_RCM_SPLIT_EXPAND") && atoi(getenv("SBX_RCM_SPLIT_EXPAND")) == 0);
+  return on;
+}
+
 static bool rcm_cc_overlap() {  // SBX_RCM_CC_OVERLAP=0: the labelling of the other components runs in line (see sbx_rcm_reorder)
   static const bool on = !(getenv("SBX_RCM_CC_OVERLAP") && atoi(getenv("SBX_RCM_CC_OVERLAP")) == 0);
   return on;
@@ -790,7 +795,9 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
                                                     unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
                                                     uint2 *__restrict__ hub_dir, RcmDev *__restrict__ dv,
-                                                    UnorderedSweep us) {
+                                                    UnorderedSweep us, int part) {
+  // part 0: everything; 1: only the hubs' chunk descriptors (so that the hub kernel can start at once), 2: only the
+  // light rows (beside the hub kernel, on a stream of its own) — how a wide frontier is expanded (run_bfs)
   __shared__ I s_stage[4][RCM_STAGE];
   // hubs found by this workgroup: (frontier position, number of chunks).  A frontier of the RMAT input holds
   // ~20 K hubs; one returning atomic each on dv->n_heavy is 0.2 ms of queueing on that word.  (The hub kernel
@@ -822,6 +829,8 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
       s = rp[u];
       e = rp[u + 1];
     }
+    if (part == 2 && e - s > RCM_LIGHT) e = s;  // (queued by the launch in front)
+    if (part == 1 && e - s <= RCM_LIGHT) e = s;  // (the other launch's)
     if (e - s > RCM_LIGHT) {
       // hub: one descriptor (position, chunk) per 1024-neighbour chunk, queued at the end of the kernel
       const unsigned nchunks = (unsigned)((e - s + RCM_CHUNK - 1) / RCM_CHUNK);
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
     }
   }
   __syncthreads();
-  {  // the staged hubs: one reservation for the whole workgroup
+  if (part != 2) {  // the staged hubs: one reservation for the whole workgroup
     const unsigned nh = s_hub_cnt < (unsigned)RCM_HUB_STAGE ? s_hub_cnt : (unsigned)RCM_HUB_STAGE;
     const unsigned mine = threadIdx.x < nh ? s_hub_n[threadIdx.x] : 0u;
     unsigned all;
@@ -2070,12 +2079,38 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       if (grid > max_grid) grid = max_grid;
       if (grid < 1) grid = 1;
       const UnorderedSweep none = {nullptr, nullptr, nullptr, 0u};
+      // A wide frontier with hubs: the light rows' kernel — tens of thousands of short dependent chains, the GPU mostly
+      // idle — used to run in front of the hub kernel because it also queues the hubs' chunks.  Now a first launch only
+      // queues (part 1: ~10 us), the hub kernel follows at once and the light rows (part 2) run beside it on a side
+      // stream: 85 us off the widest level of the bench matrix's Cuthill-McKee sweep.
+      const bool split = b.max_deg > (unsigned)RCM_LIGHT && fsize >= 4096 && !h->prof_on && rcm_split_expand() && h->aux_ready;
+      if (split) {
+        hipStream_t main_s = h->stream;
+        const bool was_dirty = h->aux_dirty;
+        SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<0>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
+                    fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, none, 1);
+        SBX_HIP(h, hipEventRecord(h->aux_event[4], main_s));
+        SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[2], h->aux_event[4], 0));
+        h->aux_dirty = true;
+        h->stream = h->aux_stream[2];
+        hipLaunchKernelGGL(k_bfs_expand<0>, dim3(grid), dim3(256), 0, h->stream, b.rp, b.col, (const I *)(b.q + off), fsize,
+                           level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, none, 2);
+        const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(h->aux_event[5], h->stream);
+        h->stream = main_s;
+        if (e1 != hipSuccess || e2 != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "run_bfs: side launch failed");
+        SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<0>, dim3(heavy_grid), dim3(256), b.rp, b.col,
+                    (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
+                    (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, none);
+        SBX_HIP(h, hipStreamWaitEvent(main_s, h->aux_event[5], 0));
+        h->aux_dirty = was_dirty;
+      } else {
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<0>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
-                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, none);
+                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, none, 0);
       if (b.max_deg > (unsigned)RCM_LIGHT)  // mesh-like inputs have no hubs: one launch less per level
         SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<0>, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, none);
+      }
     }
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(bfs_first_launch(b));
@@ -3176,7 +3211,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       if (grid > max_grid) grid = max_grid;
       if (grid < 1) grid = 1;
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<1>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
-                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, us);
+                  fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, us, 0);
       if (b.max_deg > (unsigned)RCM_LIGHT)
         SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<1>, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
@@ -3325,7 +3360,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
     SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(cone_grid), dim3(256), b.rp, b.col, (const I *)list, 0u, k,
-                (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us);
+                (const unsigned *)b.vbits, b.ppos, list, b.heavy, b.hub_dir, b.dv, us, 0);
     if (b.max_deg > (unsigned)RCM_LIGHT)
       SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<2>, dim3(heavy_grid), dim3(256), b.rp, b.col, (const I *)list, k,
                   (const unsigned *)b.vbits, b.ppos, list, (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, cone_grid,
