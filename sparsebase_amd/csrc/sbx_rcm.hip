@@ -891,8 +891,11 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
   stage_end_block(st, nf_list, dv, scanned, false);
 }
 
+#ifndef RCM_HEAVY_MINW
+#define RCM_HEAVY_MINW 1
+#endif
 template <int U>
-__global__ __launch_bounds__(256) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256, RCM_HEAVY_MINW) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
                                                           const I *__restrict__ frontier, unsigned next_level,
                                                           const unsigned *__restrict__ vbits, unsigned *ppos,
                                                           I *__restrict__ nf_list,
