@@ -175,8 +175,12 @@ struct RadixPlan {
 
 // Upfront digit histograms of every pass in one read of the keys.
 // KS: the 64-bit keys are two 32-bit arrays (keys = low words, keys_hi = high words).
+#ifndef SBX_RSH_THREADS
+#define SBX_RSH_THREADS 256
+#endif
+constexpr int RSH_THREADS = SBX_RSH_THREADS;  // threads of a histogram workgroup (the first 256 own one digit each)
 template <typename K, bool KS = false>
-__global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
+__global__ __launch_bounds__(RSH_THREADS) void k_onesweep_hist(const K *__restrict__ keys, int64_t count, RadixPlan plan,
                                                               unsigned long long *__restrict__ ghist,
                                                               rs_word *__restrict__ state,
                                                               size_t state_words,
@@ -187,15 +191,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
   };
   __shared__ unsigned lh[RS_MAX_PASSES][256];
   // the look-back status words of all passes are only touched by the pass kernels: clear them here
-  for (size_t j = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; j < state_words; j += (size_t)gridDim.x * RS_THREADS)
+  for (size_t j = (size_t)blockIdx.x * RSH_THREADS + threadIdx.x; j < state_words; j += (size_t)gridDim.x * RSH_THREADS)
     state[j] = 0;
-  for (int i = threadIdx.x; i < RS_MAX_PASSES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < RS_MAX_PASSES * 256; i += RSH_THREADS) (&lh[0][0])[i] = 0;
   __syncthreads();
   // HU keys per thread and round, all loads issued before the first counter update: one key per round leaves a
   // thread with one load in flight and the kernel at 1 TB/s
   constexpr int HU = 8;
-  const int64_t stride = (int64_t)gridDim.x * RS_THREADS;
-  int64_t i = (int64_t)blockIdx.x * RS_THREADS + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * RSH_THREADS;
+  int64_t i = (int64_t)blockIdx.x * RSH_THREADS + threadIdx.x;
   for (; i + (HU - 1) * stride < count; i += HU * stride) {
     K k[HU];
 #pragma unroll
@@ -211,10 +215,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_onesweep_hist(const K *__restric
       atomicAdd(&lh[p][(unsigned)(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
   }
   __syncthreads();
-  for (int p = 0; p < plan.n; p++) {
-    const unsigned c = lh[p][threadIdx.x];
-    if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)c);
-  }
+  if (threadIdx.x < 256)
+    for (int p = 0; p < plan.n; p++) {
+      const unsigned c = lh[p][threadIdx.x];
+      if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)c);
+    }
 }
 
 // diagnostic build only (-DSBX_RADIX_STAMPS, tools/radix_stamps.py): wall-clock cycles from kernel entry to the end of
@@ -576,7 +581,7 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   // few, fat workgroups: every workgroup ends with passes x 256 adds on the same histogram words, and one word takes
   // only ~88 adds per microsecond whoever issues them
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K>),
-              dim3(sbx_grid_for(count, RS_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RS_THREADS),
+              dim3(sbx_grid_for(count, RSH_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RSH_THREADS),
               (const K *)ka, count, plan, ghist, state, state_words);
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));  // one read of the keys for all passes
   K *src_k = ka, *dst_k = kb;
@@ -631,7 +636,7 @@ static int radix_sort_io_impl(sbx_handle_t h, const sbx_radix_side *src, K *ka, 
   rs_word *state = nullptr;
   SBX_TRY(sbx_salloc(h, state_words, &state));
   SBX_KLAUNCH(h, SBX_K_RADIX_HIST, (k_onesweep_hist<K, KSPLIT>),
-              dim3(sbx_grid_for(count, RS_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RS_THREADS),
+              dim3(sbx_grid_for(count, RSH_THREADS * 16, (int64_t)h->num_cus * rs_hist_grid_factor())), dim3(RSH_THREADS),
               (const K *)src->k[0], count, plan, ghist, state, state_words, (const uint32_t *)src->k[1]);
   SBX_PROF_BYTES(h, SBX_K_RADIX_HIST, count * (int64_t)sizeof(K));
   constexpr size_t lds_bytes = sizeof(K) * TILE + (HAS_P ? sizeof(P) * TILE : 0) + (RSP_WAVES + 2) * 256 * 4 + 64;
