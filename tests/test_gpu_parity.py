@@ -1348,7 +1348,7 @@ def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
 
 
 @pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere", "bottom_up_early",
-                                  "no_chain", "chain_of_one", "chain_tail_gives_up"])
+                                  "no_chain", "chain_of_one", "chain_tail_gives_up", "in_line"])
 def test_rcm_sweep_variants_in_a_child(mode):
     """The switches of the RCM's pseudo-peripheral sweeps are read once per process, hence the children:
     SBX_DEBUG_GB_SPINS=0 makes every grid barrier of the persistent kernels give up at once (what a barrier does when its
@@ -1361,7 +1361,9 @@ def test_rcm_sweep_variants_in_a_child(mode):
     (the default chains three: every way a chain can end — sweep over, small frontier, chain too short, a top-down
     level — comes up between the three settings and these graphs); SBX_DEBUG_CHAIN_TAIL_ABORT=1: the small-level kernel
     at the tail of a chain gives up at its first grid barrier, after claiming vertices and before it could report that
-    it ran — the sweep must be thrown away all the same (it was not, once: a 1-in-80 failure of the eight-process test)."""
+    it ran — the sweep must be thrown away all the same; "in_line": no side streams inside the call (SBX_RCM_CC_OVERLAP=0,
+    SBX_RCM_SPLIT_EXPAND=0, SBX_RCM_OVERLAP=0: the other components are labelled, a wide frontier's light rows expanded
+    and the degree ranks built on the caller's stream — what a call under the handle's profiler does)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1369,7 +1371,7 @@ def test_rcm_sweep_variants_in_a_child(mode):
         "import sys, numpy as np, torch; sys.path[:0] = [%r, %r]\n"
         "from orc import Oracle; from sparsebase_amd import ops, synth\n"
         "orc = Oracle(); d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
-        "cases = [synth.rmat_symmetric(16, 8, seed=3), synth.rmat_symmetric(14, 3, seed=5),\n"
+        "cases = [synth.rmat_symmetric(16, 8, seed=3), synth.rmat_symmetric(14, 3, seed=5), synth.rmat_symmetric(19, 12, seed=2),\n"
         "         synth.random_symmetric_graph(30000, avg_deg=3, seed=2, n_blocks=3, isolated_frac=0.1),\n"
         "         synth.banded_symmetric(40000, 6, per_row=4, seed=1), synth.grid_graph(150, 150, shuffle_seed=4)]\n"
         "for rp, col in cases:\n"
@@ -1379,7 +1381,8 @@ def test_rcm_sweep_variants_in_a_child(mode):
              "unordered_everywhere": {"SBX_DEBUG_UB_MAX_LEVELS": "1000000"},
              "bottom_up_early": {"SBX_DEBUG_BU_RATIO": "0.3", "SBX_RCM_UNORDERED": "0"},
              "no_chain": {"SBX_RCM_UBFS_CHAIN": "0"}, "chain_of_one": {"SBX_RCM_UBFS_CHAIN": "1"},
-             "chain_tail_gives_up": {"SBX_DEBUG_CHAIN_TAIL_ABORT": "1"}}[mode]
+             "chain_tail_gives_up": {"SBX_DEBUG_CHAIN_TAIL_ABORT": "1"},
+             "in_line": {"SBX_RCM_CC_OVERLAP": "0", "SBX_RCM_SPLIT_EXPAND": "0", "SBX_RCM_OVERLAP": "0"}}[mode]
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
