@@ -40,16 +40,25 @@
 namespace {
 
 constexpr int PT_THREADS = 64;
-constexpr int PT_ITEMS = 8;  // a multiple of 4: the thread-consecutive sweeps move 16 bytes per LDS access
+#ifndef SBX_PT_ITEMS
+#define SBX_PT_ITEMS 8
+#endif
+#ifndef SBX_PT_W
+#define SBX_PT_W 384
+#endif
+#ifndef SBX_PT_LMAX
+#define SBX_PT_LMAX 128
+#endif
+constexpr int PT_ITEMS = SBX_PT_ITEMS;  // a multiple of 4: the thread-consecutive sweeps move 16 bytes per LDS access
 constexpr int PT_CAP = PT_THREADS * PT_ITEMS;  // LDS capacity of one tile, in entries
-constexpr int PT_W = 384;                      // a tile owns the rows that start in a window of PT_W output positions
+constexpr int PT_W = SBX_PT_W;                      // a tile owns the rows that start in a window of PT_W output positions
 // waves per SIMD the persistent tile kernel is compiled for: 4 = at most 128 VGPRs, where the kernels that carry values
 // do not spill (uncapped they take 169 and lose occupancy: Permute2D 1.56 vs 1.49 ms); the pattern-only kernel spills 9
 // registers under the cap and is 7 % faster without it
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
 #endif
-constexpr int PT_LMAX = 128;                   // rows up to this many entries are sorted by the tile kernel
+constexpr int PT_LMAX = SBX_PT_LMAX;                   // rows up to this many entries are sorted by the tile kernel
 static_assert(PT_W + PT_LMAX - 1 <= PT_CAP, "a tile must hold its window plus the tail of its last row");
 constexpr int BK_SHORT = 8;   // rows up to this length are one bucket (plain all-pairs ranking)
 constexpr int BK_MAX = 96;    // a larger bucket sends the tile / row to the radix sort
@@ -799,10 +808,11 @@ __device__ __forceinline__ void permute_tile_body(
     // (one opaque use of all the columns: the compiler waits for their loads HERE, once — they were issued under
     // `p < cnt`, and without this it waits before every gather for all but the latest outstanding operation, i.e. for
     // the gather before the last one)
-    static_assert(ITEMS == 8, "operand list below");
-    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+    static_assert(ITEMS == 8 || ITEMS == 4, "operand list below");
+    if constexpr (ITEMS == 8) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4 % ITEMS]), "+v"(c[5 % ITEMS]), "+v"(c[6 % ITEMS]), "+v"(c[7 % ITEMS]));
+    else asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) kc[k] = (int)(col_order ? col_order[c[k]] : c[k]);
+    for (int k = 0; k < ITEMS; k++) kc[k] = (int)((col_order && !(force_radix & 4)) ? col_order[c[k]] : c[k]);  // (bit 2: timing ablation without the gathers)
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
       const int p = k * THREADS + tid;
@@ -835,7 +845,7 @@ __device__ __forceinline__ void permute_tile_body(
           *(uint2 *)&s_c[2 * p] = make_uint2(0xFFFFFFFFu, 0u);
       }
     }
-    if (__any(unsorted) && lane == 0) {
+    if (__any(unsorted) && lane == 0 && !(force_radix & 2)) {  // (bit 1: timing ablation, rows stream out unsorted)
       st->any_unsorted = 1;
       s_flag[0] = 1;
     }
@@ -923,7 +933,7 @@ __device__ __forceinline__ void permute_tile_body(
         sh[k] = (unsigned char)(shift >= 32 ? 32 : shift);
       }
     }
-    if ((__any(bad) || force_radix || RADIX) && lane == 0) s_flag[1] = 1;
+    if ((__any(bad) || (force_radix & 1) || RADIX) && lane == 0) s_flag[1] = 1;
   }
   TILE_SYNC();  // the (min, max) words and the column copies in r0 have been read
   TILE_STAMP(8);

@@ -32,6 +32,9 @@ typedef int sbx_i4a __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte
 typedef unsigned sbx_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long sbx_l2a __attribute__((ext_vector_type(2), aligned(8)));
 
+#ifndef RQ_GPOINTS
+#define RQ_GPOINTS 8  // issue points of a row's relabel gathers inside the sort of the row in front of it
+#endif
 #define RQ_NEIGHBOURS 8  // words of its own bucket an entry ranks itself against without a loop; a fuller bucket at level 0 sends the row to level 1
 
 template <int VB> struct RqVal { typedef uint32_t type; };
@@ -125,12 +128,17 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
     const int rid_s = valid_d ? rid_d : 0;
     const int r0_d = (int)rpo[rid_s], r1_d = (int)rpo[rid_s + 1], src_d = rec[rid_s].y;
     // ---- B: relabel gathers (permute_order_two.cc:68) of row it - 3; its columns are in cq (entries past the row's
-    // end hold 0: they gather map entry 0 and are never used)
+    // end hold 0: they gather map entry 0 and are never used).  They are NOT issued here in one burst: a wave that
+    // has handed the memory pipeline a dozen instructions waits at the next one until the queue has room, and would
+    // start its sort only then; gather_pt(k) issues the k-th eighth of them, between the phases of the sort
+    auto gather_span = [&](const int lo, const int hi) RQ_INLINE {
 #pragma unroll
-    for (int q = 0; q < Q; q++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        kb[q][j] = (col_order && !(force_radix & 4)) ? (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (unsigned)cq[q][j] << 2, 0, 0) : cq[q][j];  // (bit 2: timing ablation without the gathers)
+      for (int i = 0; i < 4 * Q; i++)
+        if (i >= lo && i < hi)
+          kb[i >> 2][i & 3] = (col_order && !(force_radix & 4)) ? (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (unsigned)cq[i >> 2][i & 3] << 2, 0, 0) : cq[i >> 2][i & 3];  // (bit 2: timing ablation without the gathers)
+    };
+    auto gather_pt = [&](const int k) RQ_INLINE { gather_span(k * (4 * Q) / RQ_GPOINTS, (k + 1) * (4 * Q) / RQ_GPOINTS); };
+    auto gather_rest = [&](const int k) RQ_INLINE { gather_span(k * (4 * Q) / RQ_GPOINTS, 4 * Q); };
     // ---- the values of row it - 4, the row sorted in this step: they are needed when the sort ends
     V va[HASV ? Q : 1][4];
     if (HASV) {
@@ -151,8 +159,8 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
         }
       }
     }
-    // ---- C: columns of row it - 2
-    {
+    // ---- C: columns of row it - 2, loaded behind the last gather of the step (which reads cq)
+    auto load_cols = [&]() RQ_INLINE {
       const int lenc = __builtin_amdgcn_readfirstlane(len_c), srcc = __builtin_amdgcn_readfirstlane(src_c);
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(col_in + (int64_t)(lenc > 0 ? srcc : 0)), 0, (lenc > 0 ? lenc : 0) * 4, RQ_RSRC_FLAGS);
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
         const sbx_u4 x = __builtin_amdgcn_raw_buffer_load_b128(rc, (unsigned)(q * 4 * T + 4 * tid) * 4, 0, RQ_NT);
         cq[q][0] = (int)x.x, cq[q][1] = (int)x.y, cq[q][2] = (int)x.z, cq[q][3] = (int)x.w;
       }
-    }
+    };
 
     // ---- A: sort row it - 4
     const int len = __builtin_amdgcn_readfirstlane(len_a);
@@ -262,6 +270,8 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
       if (force_radix & 2) row_uns = false;  // (timing ablation: rows stream out unsorted)
       if (!row_uns) {
         // an ordered row needs no sort (csr.cc:102-116): straight out of the registers
+        gather_rest(0);
+        load_cols();
         RQ_WAIT_LOADS();
         store_row([&](int q, unsigned (&c)[4], V (&v)[4]) RQ_INLINE {
 #pragma unroll
@@ -292,7 +302,9 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
             });
           }
           for_slots([&](int q, int j, int p, bool live) RQ_INLINE { ar[q][j] = atomicAdd(&s_cnt[bk[q][j]], 1u); });
+          if (level == 0) gather_pt(0);
           rq_barrier();  // B2
+          if (level == 0) gather_pt(1);
           {
             // in-place inclusive scan of the counters; a thread owns E consecutive ones
             unsigned v[E];
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
             if (lane == 63) s_scan[w] = inc;
             const unsigned wmx = sbx_wave_max(mxc);
             if (wmx > (unsigned)RQ_NEIGHBOURS && lane == 0) atomicMax(&s_row[par][4], wmx);
+            if (level == 0) gather_pt(2);
             rq_barrier();  // B3
             unsigned ex = inc - sum;
 #pragma unroll
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
               *(sbx_u4 *)&s_cnt[E * tid + 4 * q] = x;
             }
           }
+          if (level == 0) gather_pt(3);
           rq_barrier();  // B4
           const unsigned big = s_row[par][4];  // 0, or the fullest bucket if it holds more than the ranking step unrolls
           if (level == 1 || (big == 0 && !(force_radix & 8))) {  // (bit 3: timing ablation, level 1 always)
@@ -347,13 +361,19 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
         if (to_radix) {
           // (rare) the row's columns cluster below what two levels resolve: the LSD radix kernel sorts it
           if (tid == 0) fb_rows[atomicAdd(fb_count, 1u)] = (unsigned)rid_a;
+          gather_rest(4);
+          load_cols();
         } else {
+          gather_pt(4);
           // placement: slot = bucket start + arrival; the word orders the bucket by (low column bits, position)
           for_slots([&](int q, int j, int p, bool live) RQ_INLINE {
             const unsigned start = s_cnt[(int)bk[q][j] - 1];
             s_w[start + ar[q][j]] = ((((unsigned)ka[q][j] - mn) & lowmask) << ib) | (unsigned)p;
           });
+          gather_pt(5);
           rq_barrier();  // B5
+          gather_rest(6);
+          load_cols();
           // rank among the words of the own bucket: four unrolled, the next four only in waves that hold a bucket of more
           // than four, a loop for what level 1 left fuller than eight (more than BK_MAX went to the radix list)
           for_slots([&](int q, int j, int p, bool live) RQ_INLINE {
@@ -382,6 +402,8 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
         RQ_WAIT_LOADS();
       }
     } else {
+      gather_rest(0);
+      load_cols();
       RQ_WAIT_LOADS();
     }
 

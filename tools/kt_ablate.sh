@@ -1,6 +1,10 @@
 #!/bin/bash
-# row-class kernels: everything / no sort (rows stream out unsorted) / no relabel gathers (and therefore no sort) — timing ablation
-for f in 0 2 4 6; do
-  SBX_PERMUTE_ROW_WAVES=${RW:-8} SBX_PERMUTE_FORCE_RADIX=$f KT_N=40 tools/kt_permute.sh ab$f "$@" > /dev/null
-  echo "== force_radix $f (2: no sort, 4: no gathers, 6: neither)"; grep -E "k_rows_quad|k_permute_block_rows<int, 4, (256|512|1024)," gpurun_out/kt_ab$f.txt | head -6
+# sort stage of the permute, per kernel: everything / no sort (rows stream out unsorted) / sort only (columns arrive
+# relabelled: the same keys, no gather issued) / neither — timing ablation.  usage: tools/kt_ablate.sh [--rcm]
+PAT="k_permute_tile<|k_rows_quad|k_permute_block_rows<int, 4, (256|512|1024),"
+for mode in "0:full" "2:nosort" "4p:sortonly" "6:neither"; do
+  f=${mode%%:*}; tag=${mode##*:}; extra=""
+  if [ "$f" = "4p" ]; then f=4; extra="--prerelabel"; fi
+  SBX_PERMUTE_ROW_WAVES=${RW:-16} SBX_PERMUTE_FORCE_RADIX=$f KT_N=40 tools/kt_permute.sh ab_$tag "$@" $extra > /dev/null
+  echo "== $tag (SBX_PERMUTE_FORCE_RADIX=$f $extra)"; grep -E "$PAT" gpurun_out/kt_ab_$tag.txt | head -8
 done

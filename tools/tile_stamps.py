@@ -9,6 +9,8 @@ rp, col = synth.rmat_symmetric_torch(22, 13, seed=1)
 n, nnz = rp.numel() - 1, col.numel()
 val = torch.arange(nnz, device="cuda", dtype=torch.float32)
 perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).to(torch.int32)
+if "--rcm" in sys.argv:
+    perm = ops.rcm_reorder(rp, col)
 out = (torch.empty_like(rp), torch.empty_like(col), torch.empty_like(val))
 for _ in range(3):
     ops.permute_csr(n, n, rp, col, val, perm, perm, out=out)
