@@ -39,6 +39,49 @@ class ReorderBase {
     Reordering<I, N, V> reordering(params);
     return reordering.GetReorder(format, contexts, convert_input);
   }
+  // Device-resident form (additive; the context is taken by reference so that the reference's `{&context}` call sites
+  // keep selecting the overload above): the order vector comes back as an HIPArray<I> in the HBM of `context`'s device and
+  // goes into the Permute2D overloads below as it is — the canonical pipeline (experiment/experiment_helper.h:81-97)
+  // without the order vector's two trips over PCIe.  The caller owns the array.
+  template <template <typename, typename, typename> typename Reordering, typename I, typename N, typename V>
+  static format::HIPArray<I> *Reorder(typename Reordering<I, N, V>::ParamsType params, F2<I, N, V> *format,
+                                      context::HIPContext &context, bool convert_input = true) {
+    static_assert(std::is_base_of_v<reorder::Reorderer<I>, Reordering<I, N, V>>,
+                  "You must pass a reordering function (with base Reorderer) to ReorderBase::Reorder");
+    Reordering<I, N, V> reordering(params);
+    return reordering.GetReorderDevice(format, &context, convert_input);
+  }
+  template <template <typename, typename, typename> typename Ret = format::FormatOrderTwo, typename I, typename N,
+            typename V>
+  static Ret<I, N, V> *Permute2D(format::HIPArray<I> *ordering, F2<I, N, V> *format,
+                                 std::vector<context::Context *> contexts, bool convert_input,
+                                 bool convert_output = false) {
+    return Permute2DRowColumnWise<Ret>(ordering, ordering, format, contexts, convert_input, convert_output);
+  }
+  template <template <typename, typename, typename> typename Ret = format::FormatOrderTwo, typename I, typename N,
+            typename V>
+  static Ret<I, N, V> *Permute2DRowColumnWise(format::HIPArray<I> *row_ordering, format::HIPArray<I> *col_ordering,
+                                              F2<I, N, V> *format, std::vector<context::Context *> contexts,
+                                              bool convert_input, bool convert_output = false) {
+    permute::PermuteOrderTwo<I, N, V> perm(row_ordering, col_ordering);
+    return Finish<Ret>(perm.GetPermutation(format, contexts, convert_input), convert_output);
+  }
+  template <template <typename, typename, typename> typename Ret = format::FormatOrderTwo, typename I, typename N,
+            typename V>
+  static Ret<I, N, V> *Permute2DRowWise(format::HIPArray<I> *ordering, F2<I, N, V> *format,
+                                        std::vector<context::Context *> contexts, bool convert_input,
+                                        bool convert_output = false) {
+    return Permute2DRowColumnWise<Ret>(ordering, (format::HIPArray<I> *)nullptr, format, contexts, convert_input,
+                                       convert_output);
+  }
+  template <template <typename, typename, typename> typename Ret = format::FormatOrderTwo, typename I, typename N,
+            typename V>
+  static Ret<I, N, V> *Permute2DColWise(format::HIPArray<I> *ordering, F2<I, N, V> *format,
+                                        std::vector<context::Context *> contexts, bool convert_input,
+                                        bool convert_output = false) {
+    return Permute2DRowColumnWise<Ret>((format::HIPArray<I> *)nullptr, ordering, format, contexts, convert_input,
+                                       convert_output);
+  }
   template <template <typename, typename, typename> typename Reordering, typename I, typename N, typename V>
   static std::pair<std::vector<F2<I, N, V> *>, I *> ReorderCached(typename Reordering<I, N, V>::ParamsType params,
                                                                   F2<I, N, V> *format,

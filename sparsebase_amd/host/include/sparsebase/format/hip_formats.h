@@ -94,9 +94,10 @@ class HIPCSR : public utils::IdentifiableImplementation<HIPCSR<IDType, NNZType, 
     this->context_ = std::unique_ptr<context::Context>(new context::HIPContext(did));
   }
   template <typename T>
-  static T *Release(detail::OwnedPtr<T> &p) {
+  T *Release(detail::OwnedPtr<T> &p) {
     T *raw = p.release();
     p = detail::OwnedPtr<T>(raw, BlankDeleter<T>());
+    device().Forget((void *)raw);  // (whoever frees it now does so past the host layer's block pool)
     return raw;
   }
 };
@@ -160,9 +161,10 @@ class HIPCOO : public utils::IdentifiableImplementation<HIPCOO<IDType, NNZType, 
 
  private:
   template <typename T>
-  static T *Release(detail::OwnedPtr<T> &p) {
+  T *Release(detail::OwnedPtr<T> &p) {
     T *raw = p.release();
     p = detail::OwnedPtr<T>(raw, BlankDeleter<T>());
+    device().Forget((void *)raw);  // (whoever frees it now does so past the host layer's block pool)
     return raw;
   }
 };
@@ -247,6 +249,7 @@ class HIPArray
   ValueType *release_vals() {
     ValueType *raw = vals_.release();
     vals_ = detail::OwnedPtr<ValueType>(raw, BlankDeleter<ValueType>());
+    hip::Device::Get(get_hip_context()->device_id).Forget((void *)raw);
     return raw;
   }
   context::HIPContext *get_hip_context() const { return static_cast<context::HIPContext *>(this->get_context()); }

@@ -8,6 +8,8 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "sbx.h"
 #include "sparsebase/utils/exception.h"
@@ -49,12 +51,77 @@ class Device {
     if (rc != SBX_OK)
       throw utils::HIPDeviceException(std::string("sbx: ") + sbx_status_string(rc) + ": " + sbx_last_error(h_));
   }
+  // Device blocks released by the host layer's formats and staging buffers are kept (up to pool_limit() bytes) and handed
+  // out again to a request of the same size: a pipeline that produces a permuted HIPCSR per call (Reorder -> Permute2D,
+  // experiment/experiment_helper.h:81-97) otherwise pays three hipMalloc / hipFree pairs of hundreds of megabytes per
+  // call.  SBX_HOST_POOL_MB sets the limit (default 4096; 0: every block goes straight back to the driver).
   void *Malloc(size_t bytes) const {
+    if (bytes == 0) bytes = 1;
+    {
+      std::lock_guard<std::mutex> lock(pool_mu_);
+      auto it = pool_free_.find(bytes);
+      if (it != pool_free_.end() && !it->second.empty()) {
+        void *p = it->second.back();
+        it->second.pop_back();
+        pooled_bytes_ -= bytes;
+        pool_live_[p] = bytes;
+        return p;
+      }
+    }
     void *p = nullptr;
-    Check(sbx_malloc(h_, bytes, &p));
+    int rc = sbx_malloc(h_, bytes, &p);
+    if (rc != SBX_OK && TrimPool(0)) rc = sbx_malloc(h_, bytes, &p);  // (the pool may hold what the request needs)
+    Check(rc);
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    pool_live_[p] = bytes;
     return p;
   }
-  void Free(void *p) const { sbx_free(h_, p); }
+  void Free(void *p) const {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lock(pool_mu_);
+      auto it = pool_live_.find(p);
+      if (it != pool_live_.end()) {
+        const size_t bytes = it->second;
+        pool_live_.erase(it);
+        if (bytes <= pool_limit() && pooled_bytes_ + bytes <= pool_limit()) {
+          pool_free_[bytes].push_back(p);
+          pooled_bytes_ += bytes;
+          return;
+        }
+      }
+    }
+    sbx_free(h_, p);
+  }
+  // a block leaves the host layer's ownership (release_*() of a device format): whoever frees it does so directly
+  void Forget(void *p) const {
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    pool_live_.erase(p);
+  }
+  // returns every pooled block beyond `keep_bytes` to the driver; true if anything was released
+  bool TrimPool(size_t keep_bytes) const {
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> lock(pool_mu_);
+      for (auto it = pool_free_.begin(); it != pool_free_.end() && pooled_bytes_ > keep_bytes;) {
+        while (!it->second.empty() && pooled_bytes_ > keep_bytes) {
+          drop.push_back(it->second.back());
+          it->second.pop_back();
+          pooled_bytes_ -= it->first;
+        }
+        it = it->second.empty() ? pool_free_.erase(it) : std::next(it);
+      }
+    }
+    for (void *p : drop) sbx_free(h_, p);
+    return !drop.empty();
+  }
+  static size_t pool_limit() {
+    static const size_t lim = [] {
+      const char *e = std::getenv("SBX_HOST_POOL_MB");
+      return (size_t)(e ? std::atoll(e) : 4096) << 20;
+    }();
+    return lim;
+  }
   void ToDevice(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_h2d(h_, dst, src, bytes)); }
   void ToHost(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2h(h_, dst, src, bytes)); }
   void Copy(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2d(h_, dst, src, bytes)); }
@@ -79,6 +146,10 @@ class Device {
   Device(int id, sbx_handle_t h) : id_(id), h_(h) {}
   int id_;
   sbx_handle_t h_;
+  mutable std::mutex pool_mu_;
+  mutable std::unordered_map<void *, size_t> pool_live_;       // blocks handed out by Malloc: their sizes
+  mutable std::map<size_t, std::vector<void *>> pool_free_;    // released blocks by size
+  mutable size_t pooled_bytes_ = 0;
 };
 
 // RAII device allocation used for staging host-resident formats through the GPU

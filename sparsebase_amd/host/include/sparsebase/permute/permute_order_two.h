@@ -36,6 +36,9 @@ template <typename IDType>
 struct PermuteOrderTwoParams : utils::Parameters {
   IDType *row_order;
   IDType *col_order;
+  // the order vectors are device arrays on device `orders_device` (>= 0) instead of host arrays: set by the
+  // PermuteOrderTwo constructor that takes HIPArrays (additive; the reference trades host arrays only)
+  int orders_device = -1;
   explicit PermuteOrderTwoParams(IDType *r_order, IDType *c_order) : row_order(r_order), col_order(c_order) {}
 };
 
@@ -54,7 +57,20 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
   // the reference's params constructor builds a temporary and registers nothing
   // (permute_order_two.cc:17-20); here it delegates properly
   explicit PermuteOrderTwo(PermuteOrderTwoParams<IDType> params)
-      : PermuteOrderTwo(params.row_order, params.col_order) {}
+      : PermuteOrderTwo(params.row_order, params.col_order) {
+    static_cast<PermuteOrderTwoParams<IDType> *>(this->params_.get())->orders_device = params.orders_device;
+  }
+  // Order vectors that already live on the device (what Reorderer::GetReorderDevice returns): nothing is uploaded, and
+  // an HIPCSR on the same device is permuted with them in place.  nullptr: identity on that axis.  Both arrays must be
+  // on one device; they stay the caller's.
+  PermuteOrderTwo(format::HIPArray<IDType> *row_order, format::HIPArray<IDType> *col_order)
+      : PermuteOrderTwo(row_order ? row_order->get_vals() : nullptr, col_order ? col_order->get_vals() : nullptr) {
+    auto *a = row_order ? row_order : col_order;
+    if (row_order && col_order && row_order->get_hip_context()->device_id != col_order->get_hip_context()->device_id)
+      throw utils::HIPDeviceException("PermuteOrderTwo: the two order vectors live on different devices");
+    static_cast<PermuteOrderTwoParams<IDType> *>(this->params_.get())->orders_device =
+        a ? a->get_hip_context()->device_id : -1;
+  }
 
  protected:
   struct DeviceResult {
@@ -65,11 +81,22 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
   static DeviceResult Run(reorder::detail::DeviceCsrView<IDType, NNZType, ValueType> &v, utils::Parameters *poly) {
     auto *params = static_cast<PermuteOrderTwoParams<IDType> *>(poly);
     auto &dev = *v.dev;
-    IDType *d_ro = params->row_order ? dev.Upload(params->row_order, (size_t)v.n) : nullptr;
-    IDType *d_co = nullptr;
-    if (params->col_order) d_co = (params->col_order == params->row_order && v.n == v.m)
-                                      ? d_ro
-                                      : dev.Upload(params->col_order, (size_t)v.m);
+    const bool on_device = params->orders_device >= 0 && (params->row_order || params->col_order);
+    if (on_device && params->orders_device != dev.id()) {
+      v.Release();
+      throw utils::HIPDeviceException("PermuteOrderTwo: the order vectors live on device " +
+                                      std::to_string(params->orders_device) + ", the matrix on device " +
+                                      std::to_string(dev.id()));
+    }
+    IDType *d_ro = nullptr, *d_co = nullptr;
+    if (on_device) {
+      d_ro = params->row_order, d_co = params->col_order;
+    } else {
+      d_ro = params->row_order ? dev.Upload(params->row_order, (size_t)v.n) : nullptr;
+      if (params->col_order) d_co = (params->col_order == params->row_order && v.n == v.m)
+                                        ? d_ro
+                                        : dev.Upload(params->col_order, (size_t)v.m);
+    }
     DeviceResult out;
     out.row_ptr = (NNZType *)dev.Malloc(((size_t)v.n + 1) * sizeof(NNZType));
     out.col = (IDType *)dev.Malloc((size_t)(v.nnz ? v.nnz : 1) * sizeof(IDType));
@@ -77,8 +104,10 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
     if (v.vals) out.vals = (ValueType *)dev.Malloc((size_t)v.nnz * hip::ValueBytes<ValueType>());
     const int rc = sbx_permute_csr(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), v.n, v.m, v.nnz,
                                    v.row_ptr, v.col, v.vals, d_ro, d_co, out.row_ptr, out.col, out.vals);
-    if (d_co && d_co != d_ro) dev.Free(d_co);
-    if (d_ro) dev.Free(d_ro);
+    if (!on_device) {
+      if (d_co && d_co != d_ro) dev.Free(d_co);
+      if (d_ro) dev.Free(d_ro);
+    }
     if (rc != SBX_OK) {
       dev.Free(out.row_ptr);
       dev.Free(out.col);

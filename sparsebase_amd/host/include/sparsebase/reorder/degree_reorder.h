@@ -23,6 +23,22 @@ class DegreeReorder : public Reorderer<IDType> {
     this->params_ = std::make_unique<DegreeReorderParams>(ascending);
   }
   explicit DegreeReorder(DegreeReorderParams params) : DegreeReorder(params.ascending) {}
+  // the order vector stays where sbx_degree_reorder writes it (see Reorderer::GetReorderDevice)
+  format::HIPArray<IDType> *GetReorderDevice(format::Format *format, context::HIPContext *context,
+                                             bool convert_input) override {
+    typedef format::HIPCSR<IDType, NNZType, ValueType> D;
+    if (!format->template IsAbsolute<D>() || format->template AsAbsolute<D>()->get_hip_context()->device_id != context->device_id)
+      return Reorderer<IDType>::GetReorderDevice(format, context, convert_input);
+    auto v = detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(format->template AsAbsolute<D>());
+    const bool ascending = static_cast<DegreeReorderParams *>(this->params_.get())->ascending;
+    IDType *d_inv = (IDType *)v.dev->Malloc((size_t)(v.n ? v.n : 1) * sizeof(IDType));
+    const int rc = sbx_degree_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, ascending ? 1 : 0, d_inv);
+    if (rc != SBX_OK) {
+      v.dev->Free(d_inv);
+      v.dev->Check(rc);
+    }
+    return new format::HIPArray<IDType>((format::DimensionType)v.n, d_inv, *context, format::kOwned);
+  }
 
  protected:
   static IDType *Run(detail::DeviceCsrView<IDType, NNZType, ValueType> v, utils::Parameters *params) {

@@ -17,6 +17,21 @@ class RCMReorder : public Reorderer<IDType> {
     this->RegisterFunction({format::HIPCSR<IDType, NNZType, ValueType>::get_id_static()}, GetReorderHIPCSR);
   }
   explicit RCMReorder(RCMReorderParams) : RCMReorder() {}
+  // the order vector stays where sbx_rcm_reorder writes it (see Reorderer::GetReorderDevice)
+  format::HIPArray<IDType> *GetReorderDevice(format::Format *format, context::HIPContext *context,
+                                             bool convert_input) override {
+    typedef format::HIPCSR<IDType, NNZType, ValueType> D;
+    if (!format->template IsAbsolute<D>() || format->template AsAbsolute<D>()->get_hip_context()->device_id != context->device_id)
+      return Reorderer<IDType>::GetReorderDevice(format, context, convert_input);
+    auto v = detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(format->template AsAbsolute<D>());
+    IDType *d_inv = (IDType *)v.dev->Malloc((size_t)(v.n ? v.n : 1) * sizeof(IDType));
+    const int rc = sbx_rcm_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr, v.col, d_inv, nullptr);
+    if (rc != SBX_OK) {
+      v.dev->Free(d_inv);
+      v.dev->Check(rc);
+    }
+    return new format::HIPArray<IDType>((format::DimensionType)v.n, d_inv, *context, format::kOwned);
+  }
 
  protected:
   static IDType *Run(detail::DeviceCsrView<IDType, NNZType, ValueType> v) {

@@ -34,6 +34,26 @@ class Reorderer : public utils::FunctionMatcherMixin<IDType *> {
       bool convert_input) {
     return this->CachedExecute(params, contexts, convert_input, false, format);
   }
+  // Device-resident result (additive; the reference hands the order back as a host IDType*, bases/reorder_base.h:145-150,
+  // and keeps device arrays in format/cuda_array_cuda.cuh): the inverse permutation stays in the HBM of `context`'s
+  // device as an HIPArray<IDType> the caller owns, ready for PermuteOrderTwo / ReorderBase::Permute2D without a trip
+  // over PCIe.  Reorderers whose result is born on the device (RCM, Degree) override this and return it as it is;
+  // the default runs GetReorder and uploads the result.
+  virtual format::HIPArray<IDType> *GetReorderDevice(format::Format *format, context::HIPContext *context,
+                                                     bool convert_input) {
+    IDType *host = GetReorder(format, {context}, convert_input);
+    const size_t n = (size_t)format->get_dimensions()[0];
+    auto &dev = hip::Device::Get(context->device_id);
+    IDType *d = nullptr;
+    try {
+      d = dev.Upload(host, n ? n : 1);
+    } catch (...) {
+      delete[] host;
+      throw;
+    }
+    delete[] host;
+    return new format::HIPArray<IDType>((format::DimensionType)n, d, *context, format::kOwned);
+  }
   virtual ~Reorderer() = default;
 };
 

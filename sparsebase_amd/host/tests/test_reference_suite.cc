@@ -840,6 +840,83 @@ TEST(HIPFormats, RoundTripsAndDeviceOperators) {  // converter_order_two_cuda_te
   EXPECT_THROW(context::HIPContext bad(hip::DeviceCount() + 3), utils::HIPDeviceException);
 }
 
+// The device-resident overloads (additive; the reference trades the order vector as a host array,
+// bases/reorder_base.h:50-66,:145-150): same results as the host-array signatures, nothing crosses PCIe in between.
+TEST(ReorderBase, DeviceResidentOrderVector) {
+  CSR3 global_csr(n, n, row_ptr, cols, vals, format::kNotOwned);
+  std::unique_ptr<DCSR3> dcsr(global_csr.Convert<format::HIPCSR>(hip_context.get()));
+  auto &dev = dcsr->device();
+  // Reorder -> HIPArray on the format's device; RCM and Degree return what the kernels wrote, Gray uploads its host result
+  std::unique_ptr<format::HIPArray<int>> d_rcm(bases::ReorderBase::Reorder<reorder::RCMReorder>({}, dcsr.get(), *hip_context));
+  const int want_rcm[3] = {1, 2, 0};
+  EXPECT_EQ(d_rcm->get_num_nnz(), (format::DimensionType)n);
+  EXPECT_TRUE(d_rcm->get_context()->IsEquivalent(hip_context.get()));
+  EXPECT_TRUE(same(fetch(dev, d_rcm->get_vals(), n).data(), want_rcm, n));
+  for (bool asc : {true, false}) {
+    std::unique_ptr<format::HIPArray<int>> d_deg(
+        bases::ReorderBase::Reorder<reorder::DegreeReorder>({asc}, dcsr.get(), *hip_context));
+    const int want_asc[3] = {2, 1, 0}, want_desc[3] = {0, 1, 2};
+    EXPECT_TRUE(same(fetch(dev, d_deg->get_vals(), n).data(), asc ? want_asc : want_desc, n));
+  }
+  std::unique_ptr<format::HIPArray<int>> d_gray(
+      bases::ReorderBase::Reorder<reorder::GrayReorder>({reorder::BitSize16, 100, 10}, dcsr.get(), *hip_context));
+  const int want_gray[3] = {2, 0, 1};
+  EXPECT_TRUE(same(fetch(dev, d_gray->get_vals(), n).data(), want_gray, n));
+  // a host CSR is converted on the way (convert_input) and the result still lands on the device
+  std::unique_ptr<format::HIPArray<int>> d_from_host(
+      bases::ReorderBase::Reorder<reorder::RCMReorder>({}, &global_csr, *hip_context, true));
+  EXPECT_TRUE(same(fetch(dev, d_from_host->get_vals(), n).data(), want_rcm, n));
+  // Permute2D with device-resident order vectors == the host-array call
+  format::HIPArray<int> d_r(n, dev.Upload(r_reorder_vector, n), *hip_context, format::kOwned);
+  format::HIPArray<int> d_c(n, dev.Upload(c_reorder_vector, n), *hip_context, format::kOwned);
+  auto *rc = bases::ReorderBase::Permute2DRowColumnWise<format::HIPCSR>(&d_r, &d_c, dcsr.get(), {hip_context.get()}, false);
+  EXPECT_TRUE(same(fetch(dev, rc->get_row_ptr(), n + 1).data(), rc_row_ptr, n + 1));
+  EXPECT_TRUE(same(fetch(dev, rc->get_col(), nnz).data(), rc_cols, nnz));
+  EXPECT_TRUE(same(fetch(dev, rc->get_vals(), nnz).data(), rc_vals, nnz));
+  delete rc;
+  auto *rw = bases::ReorderBase::Permute2DRowWise<format::HIPCSR>(&d_r, dcsr.get(), {hip_context.get()}, false);
+  EXPECT_TRUE(same(fetch(dev, rw->get_col(), nnz).data(), r_cols, nnz) && same(fetch(dev, rw->get_vals(), nnz).data(), r_vals, nnz));
+  delete rw;
+  auto *both = bases::ReorderBase::Permute2D<format::HIPCSR>(d_rcm.get(), dcsr.get(), {hip_context.get()}, false);
+  auto *both_host = bases::ReorderBase::Permute2D<format::HIPCSR>(const_cast<int *>(want_rcm), dcsr.get(), {hip_context.get()}, false);
+  EXPECT_TRUE(fetch(dev, both->get_col(), nnz) == fetch(dev, both_host->get_col(), nnz));
+  EXPECT_TRUE(fetch(dev, both->get_vals(), nnz) == fetch(dev, both_host->get_vals(), nnz));
+  EXPECT_TRUE(fetch(dev, both->get_row_ptr(), n + 1) == fetch(dev, both_host->get_row_ptr(), n + 1));
+  delete both;
+  delete both_host;
+  // a host CSR with device-resident orders: staged through the same device, host result
+  auto *hp = bases::ReorderBase::Permute2DRowColumnWise<format::CSR>(&d_r, &d_c, &global_csr, {&cpu_context}, true);
+  EXPECT_TRUE(same(hp->get_col(), rc_cols, nnz) && same(hp->get_vals(), rc_vals, nnz));
+  delete hp;
+  // the order vectors stay the caller's: still readable afterwards
+  EXPECT_TRUE(same(fetch(dev, d_r.get_vals(), n).data(), r_reorder_vector, n));
+}
+
+// The host layer's block pool (hip/device.h): a released block serves the next request of its size; a block whose
+// ownership left the layer (release_*()) is forgotten and never handed out again.
+TEST(HIPDevice, BlockPool) {
+  auto &dev = hip::Device::Get(hip_context->device_id);
+  if (hip::Device::pool_limit() == 0) return;
+  dev.TrimPool(0);
+  void *a = dev.Malloc(1 << 20);
+  dev.Free(a);
+  void *b = dev.Malloc(1 << 20);
+  EXPECT_EQ(a, b);                       // served from the pool
+  void *c = dev.Malloc(1 << 20);
+  EXPECT_NE(c, b);
+  dev.Free(c);
+  dev.Free(b);
+  EXPECT_TRUE(dev.TrimPool(0));          // both blocks go back to the driver
+  EXPECT_FALSE(dev.TrimPool(0));
+  int host[4] = {1, 2, 3, 4};
+  auto *arr = new format::HIPArray<int>(4, dev.Upload(host, 4), *hip_context, format::kOwned);
+  int *raw = arr->release_vals();        // ownership leaves the layer
+  delete arr;
+  EXPECT_TRUE(same(fetch(dev, raw, 4).data(), host, 4));
+  EXPECT_EQ(sbx_free(dev.handle(), raw), SBX_OK);
+  EXPECT_FALSE(dev.TrimPool(0));         // nothing of it stayed behind in the pool
+}
+
 int main() {
   if (hip::DeviceCount() < 1) {
     std::printf("test_reference_suite needs a GPU (the path has no CPU fallback)\n");
