@@ -303,6 +303,19 @@ int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, i
                       const void *row_ptr, const void *col, int resolution, int nnz_threshold,
                       void *degree_out, uint64_t *key_out, int64_t *counts_host);
 
+/* GrayReorder with its ordering stage on the device — the opt-in mode SURVEY.md section 8(b) sketches (`exact_ties`).  *
+ * exact_ties = 0: every sort of the reference (gray_reorder.cc:199-203 by degree, :293-301 / :354-360 the sections by
+ * decoded key, ascending and descending in turn, :404 the dense rows) runs as a STABLE device sort: the ordering is
+ * (class, section, +-key, degree, row id), three radix sorts of (key, row) pairs behind sbx_gray_row_keys.  It equals
+ * the reference's wherever the reference's comparators decide the order; tied rows come in stable order instead of
+ * libstdc++'s introsort order.  exact_ties != 0 is refused with SBX_ERR_UNSUPPORTED: the exact mode — the default of
+ * reorder::GrayReorder — issues the reference's own std::sort calls in the host layer over the device-computed keys
+ * (DESIGN.md section 5).  inv_perm_out[n] (index type `it`) on the device.  m must be a multiple of the resolution
+ * (see sbx_gray_row_keys).  Synchronous. */
+int sbx_gray_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, int64_t nnz,
+                     const void *row_ptr, const void *col, int resolution, int nnz_threshold,
+                     int group_size, int exact_ties, void *inv_perm_out);
+
 /* ------------------------------------------------------------------ *
  * A13 ReorderBase::InversePermutation — bases/reorder_base.h:663-672   *
  * ------------------------------------------------------------------ */

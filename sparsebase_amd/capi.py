@@ -80,6 +80,7 @@ PROTOTYPES = {
     "sbx_degree_reorder": ([_H, _int, _i64, _vp, _int, _vp], _int),
     "sbx_rcm_reorder": ([_H, _int, _i64, _i64, _vp, _vp, _vp, C.POINTER(RcmStats)], _int),
     "sbx_gray_row_keys": ([_H, _int, _i64, _i64, _i64, _vp, _vp, _int, _int, _vp, _vp, C.POINTER(_i64)], _int),
+    "sbx_gray_reorder": ([_H, _int, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp], _int),
     "sbx_inverse_permutation": ([_H, _int, _i64, _vp, _vp], _int),
     "sbx_permute_csr": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _int),
     "sbx_permute_csr_rows": ([_H, _int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,

@@ -9,11 +9,16 @@
 //           404); its result therefore depends on libstdc++'s introsort visiting
 //           order, which no parallel sort reproduces.  To stay bit-exact this stage
 //           issues the same std::sort calls, on the same sequences, over the
-//           device-computed keys (O(n log n) on rows, nothing touches the nonzeros).
+//           device-computed keys (O(n log n) on rows, nothing touches the nonzeros);
+//           calls that do not depend on each other (the sections, the dense rows) run on
+//           threads of their own.
 #ifndef SPARSEBASE_REORDER_GRAY_REORDER_H_
 #define SPARSEBASE_REORDER_GRAY_REORDER_H_
-#include <chrono>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -27,6 +32,10 @@ struct GrayReorderParams : utils::Parameters {
   BitMapSize resolution;
   int nnz_threshold;
   int sparse_density_group_size;
+  // Opt-in, not in the reference: order the row keys on the device with STABLE sorts (sbx_gray_reorder) instead of
+  // issuing the reference's std::sort calls on the host.  The result equals the reference's wherever its comparators
+  // decide a row's place; tied rows come in stable order instead of libstdc++'s introsort order.  Default: exact.
+  bool stable_device_ordering = false;
   explicit GrayReorderParams() : resolution(BitSize32), nnz_threshold(0), sparse_density_group_size(1) {}
   GrayReorderParams(BitMapSize r, int nnz_thresh, int group_size)
       : resolution(r), nnz_threshold(nnz_thresh), sparse_density_group_size(group_size) {}
@@ -44,7 +53,9 @@ class GrayReorder : public Reorderer<IDType> {
     this->RegisterFunction({format::HIPCSR<IDType, NNZType, ValueType>::get_id_static()}, GrayReorderingHIPCSR);
   }
   explicit GrayReorder(GrayReorderParams p)
-      : GrayReorder(p.resolution, p.nnz_threshold, p.sparse_density_group_size) {}
+      : GrayReorder(p.resolution, p.nnz_threshold, p.sparse_density_group_size) {
+    static_cast<GrayReorderParams *>(this->params_.get())->stable_device_ordering = p.stable_device_ordering;
+  }
   /// Wall time of the last call's stages in this process, in ms: the device key stage (sbx_gray_row_keys, which ends
   /// with a blocking read-back), the copy of degrees and keys to the host, the host ordering stage.  (Not in the
   /// reference: what bench.py reports as Gray end to end.)
@@ -60,6 +71,17 @@ class GrayReorder : public Reorderer<IDType> {
   static IDType *Run(detail::DeviceCsrView<IDType, NNZType, ValueType> v, utils::Parameters *poly) {
     auto *params = static_cast<GrayReorderParams *>(poly);
     const int64_t n = v.n;
+    if (params->stable_device_ordering) {  // (opt-in: see GrayReorderParams)
+      hip::Staged<IDType> d_inv(*v.dev, (size_t)(n ? n : 1));
+      const int rc = sbx_gray_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
+                                      (int)params->resolution, params->nnz_threshold, params->sparse_density_group_size,
+                                      0, d_inv.get());
+      IDType *inv = nullptr;
+      if (rc == SBX_OK) inv = n ? v.dev->Download(d_inv.get(), (size_t)n) : new IDType[1]();
+      v.Release();
+      v.dev->Check(rc);
+      return inv;
+    }
     using clock = std::chrono::steady_clock;
     auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
     // ---- device stage
@@ -99,21 +121,52 @@ class GrayReorder : public Reorderer<IDType> {
     // the reference keeps these counters in `int` (gray_reorder.cc:134-137)
     const bool sparse_banded = double((int)counts[1]) / (int)counts[0] > 0.3;
     const bool dense_banded = double((int)counts[3]) / (int)counts[2] > 0.2;
-    std::sort(sparse_rows.begin(), sparse_rows.end(), [&](int a, int b) -> bool { return deg[a] < deg[b]; });
+    // The std::sort calls below are the reference's, on the same sequences with comparators that answer the same — so
+    // each leaves the permutation libstdc++'s introsort leaves in the reference — but they do not run one after the
+    // other: the dense rows' sort (gray_reorder.cc:404) depends on nothing and runs beside everything else, and the
+    // sections (:293-301,:354-360) are disjoint ranges whose comparator is fixed by their index, so once the walk
+    // over the degree-sorted rows has found their bounds they are sorted concurrently.
+    std::thread dense_thread;
+    std::exception_ptr dense_error;
+    if (!dense_banded && !dense_rows.empty()) {
+      dense_thread = std::thread([&]() {
+        try {
+          std::vector<row_grey_pair> d;
+          d.reserve(dense_rows.size());
+          for (IDType r : dense_rows) d.push_back(row_grey_pair(r, (unsigned long)key[r]));
+          std::sort(d.begin(), d.end(), asc_comparator);
+          for (size_t a = 0; a < dense_rows.size(); a++) dense_rows[a] = d[a].first;
+        } catch (...) {
+          dense_error = std::current_exception();
+        }
+      });
+    }
+    struct JoinGuard {  // (the ordering stage may leave through an exception)
+      std::thread &t;
+      ~JoinGuard() { if (t.joinable()) t.join(); }
+    } dense_guard{dense_thread};
+    {
+      // gray_reorder.cc:199-203: std::sort of the row ids by degree.  The (degree, id) pairs are sorted instead, with a
+      // comparator that looks at the degree only: every comparison answers what `deg[a] < deg[b]` answers, so the
+      // elements make the same moves, without two dependent loads per comparison.
+      typedef std::pair<IDType, IDType> deg_row;  // (degree, row)
+      std::vector<deg_row> byd(sparse_rows.size());
+      for (size_t a = 0; a < sparse_rows.size(); a++) byd[a] = deg_row(deg[sparse_rows[a]], sparse_rows[a]);
+      std::sort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
+      for (size_t a = 0; a < sparse_rows.size(); a++) sparse_rows[a] = byd[a].second;
+    }
 
-    std::vector<row_grey_pair> section;
-    section.reserve((size_t)n);
     if (!sparse_banded) {
+      struct Section { int64_t start, end; bool descending; };
+      std::vector<Section> sections;
       bool descending = false;
       int64_t start = 0;
       IDType last_deg = 0;
       int groups = 0;
       const int64_t ns = (int64_t)sparse_rows.size();
-      auto flush = [&](int64_t end) {
-        if (!descending) std::sort(section.begin(), section.end(), asc_comparator);
-        else std::sort(section.begin(), section.end(), desc_comparator);
+      auto flush = [&](int64_t end) {  // rows [start, end) of the degree-sorted list are one section
+        if (end > start) sections.push_back(Section{start, end, descending});
         descending = !descending;
-        for (int64_t a = start; a < end; a++) sparse_rows[a] = section[a - start].first;
       };
       for (int64_t i = 0; i < ns; i++) {
         const IDType d = deg[sparse_rows[i]];
@@ -132,20 +185,43 @@ class GrayReorder : public Reorderer<IDType> {
           if (groups == group_size) {
             flush(i);
             start = i;
-            section.clear();
             groups = 0;
           }
         }
-        section.push_back(row_grey_pair(sparse_rows[i], (unsigned long)key[sparse_rows[i]]));
         if (i == ns - 1) flush(ns);
       }
-      section.clear();
+      auto sort_section = [&](const Section &sc) {
+        std::vector<row_grey_pair> section;
+        section.reserve((size_t)(sc.end - sc.start));
+        for (int64_t a = sc.start; a < sc.end; a++)
+          section.push_back(row_grey_pair(sparse_rows[a], (unsigned long)key[sparse_rows[a]]));
+        if (!sc.descending) std::sort(section.begin(), section.end(), asc_comparator);
+        else std::sort(section.begin(), section.end(), desc_comparator);
+        for (int64_t a = sc.start; a < sc.end; a++) sparse_rows[a] = section[a - sc.start].first;
+      };
+      const unsigned hw = std::thread::hardware_concurrency();
+      const size_t workers = std::min<size_t>(sections.size(), std::min<unsigned>(hw ? hw : 1u, 16u));
+      if (workers <= 1) {
+        for (const Section &sc : sections) sort_section(sc);
+      } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::exception_ptr> errors(workers);
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; w++)
+          pool.emplace_back([&, w]() {
+            try {
+              for (size_t k = next++; k < sections.size(); k = next++) sort_section(sections[k]);
+            } catch (...) {
+              errors[w] = std::current_exception();
+            }
+          });
+        for (auto &t : pool) t.join();
+        for (auto &e : errors)
+          if (e) std::rethrow_exception(e);
+      }
     }
-    if (!dense_banded) {
-      for (IDType r : dense_rows) section.push_back(row_grey_pair(r, (unsigned long)key[r]));
-      std::sort(section.begin(), section.end(), asc_comparator);
-      for (size_t a = 0; a < dense_rows.size(); a++) dense_rows[a] = section[a].first;
-    }
+    if (dense_thread.joinable()) dense_thread.join();
+    if (dense_error) std::rethrow_exception(dense_error);
     IDType *order = new IDType[n > 0 ? n : 1]();
     int64_t pos = 0;
     for (IDType r : sparse_rows) order[r] = (IDType)pos++;

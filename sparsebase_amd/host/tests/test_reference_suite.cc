@@ -862,6 +862,12 @@ TEST(ReorderBase, DeviceResidentOrderVector) {
       bases::ReorderBase::Reorder<reorder::GrayReorder>({reorder::BitSize16, 100, 10}, dcsr.get(), *hip_context));
   const int want_gray[3] = {2, 0, 1};
   EXPECT_TRUE(same(fetch(dev, d_gray->get_vals(), n).data(), want_gray, n));
+  // opt-in device ordering of GrayReorder (stable ties): on this fixture every key is unique, so it is the reference's order
+  reorder::GrayReorderParams stable(reorder::BitSize16, 100, 10);
+  stable.stable_device_ordering = true;
+  std::unique_ptr<format::HIPArray<int>> d_gray_stable(
+      bases::ReorderBase::Reorder<reorder::GrayReorder>(stable, dcsr.get(), *hip_context));
+  EXPECT_TRUE(same(fetch(dev, d_gray_stable->get_vals(), n).data(), want_gray, n));
   // a host CSR is converted on the way (convert_input) and the result still lands on the device
   std::unique_ptr<format::HIPArray<int>> d_from_host(
       bases::ReorderBase::Reorder<reorder::RCMReorder>({}, &global_csr, *hip_context, true));

@@ -299,6 +299,17 @@ def gray_row_keys(m, row_ptr, col, resolution, nnz_threshold):
     return deg, key, list(counts)
 
 
+def gray_reorder(m, row_ptr, col, resolution, nnz_threshold, group_size, exact_ties=False):
+    """GrayReorder with the ordering stage on the device (stable ties; exact_ties=True is refused by the library: the
+    exact mode is the host layer's reorder::GrayReorder)."""
+    hd = handle_for(_check_dev(row_ptr, col))
+    n = row_ptr.numel() - 1
+    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
+    hd.check(hd.lib.sbx_gray_reorder(hd.h, _it(row_ptr), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
+                                     int(nnz_threshold), int(group_size), 1 if exact_ties else 0, _p(inv)))
+    return inv
+
+
 # ----------------------------------------------------------------------------- permutation
 def inverse_permutation(perm):
     hd = handle_for(_check_dev(perm))

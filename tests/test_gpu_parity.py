@@ -783,6 +783,71 @@ def test_gray_row_keys(ops, oracle):
         assert list(counts) == wcounts.tolist()
 
 
+def _gray_stable_model(deg, key, counts, bits, thr, grp):
+    """numpy statement of sbx_gray_reorder's ordering (gray_reorder.cc:181-420 with every std::sort read as a stable sort):
+    returns (inv, group) — the inverse permutation and, per row, the (class, section, signed key) tuple that decides
+    its place up to ties."""
+    n = len(deg)
+    deg = deg.astype(np.int64)
+    key = key.astype(np.uint64)
+    mask = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    sparse_banded = float(np.int32(counts[1])) / float(np.int32(counts[0])) > 0.3 if counts[0] else False
+    dense_banded = float(np.int32(counts[3])) / float(np.int32(counts[2])) > 0.2 if counts[2] else False
+    sparse = deg <= thr
+    present = np.unique(deg[sparse & (deg > 0)])
+    section = np.zeros(n, np.int64)
+    if not sparse_banded and len(present):
+        rank = np.searchsorted(present, deg)
+        section = np.where(sparse & (deg > 0), 1 + rank // grp, 0)
+    n_sections = 0 if sparse_banded else (len(present) + grp - 1) // grp
+    cls = np.where(sparse, section, n_sections + 1)
+    skey = np.zeros(n, np.uint64)
+    if not dense_banded:
+        skey = np.where(~sparse, key & mask, skey)
+    if not sparse_banded:
+        odd = sparse & (deg > 0) & ((section - 1) % 2 == 1)
+        even = sparse & (deg > 0) & ~odd
+        skey = np.where(even, key & mask, skey)
+        skey = np.where(odd, ~key & mask, skey)
+    dkey = np.where(sparse, deg, 0)
+    order = np.lexsort((np.arange(n), dkey, skey, cls))
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    return inv, np.stack([cls.astype(np.uint64), skey, np.where(sparse & (sparse_banded | (deg == 0)), dkey, 0).astype(np.uint64)], 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rmat_32_10_4", "rmat_16_20_2", "rmat_64_3_1", "banded_32_10_4", "banded_wide_16_0_1",
+                                  "rmat_32_neg", "rmat_32_huge_thr"])
+def test_gray_reorder_device_ordering(ops, oracle, case):
+    """sbx_gray_reorder (exact_ties = 0): the ordering stage on the device with stable ties — equals the numpy statement
+    of that order row for row, is a permutation, and equals the reference-exact oracle wherever the reference's
+    comparators decide a row's place (its (class, section, key) is unique); exact_ties = 1 is refused."""
+    kind, res, thr, grp = {"rmat_32_10_4": ("rmat", 32, 10, 4), "rmat_16_20_2": ("rmat", 16, 20, 2),
+                           "rmat_64_3_1": ("rmat", 64, 3, 1), "banded_32_10_4": ("banded", 32, 10, 4),
+                           "banded_wide_16_0_1": ("wide", 16, 0, 1), "rmat_32_neg": ("rmat", 32, -1, 3),
+                           "rmat_32_huge_thr": ("rmat", 32, 1 << 20, 5)}[case]
+    if kind == "rmat":
+        rp, col = synth.rmat_symmetric(13, 8, seed=5)
+    elif kind == "banded":
+        rp, col = synth.banded_symmetric(8192, 40, 9, 3)
+    else:
+        rp, col = synth.banded_symmetric(8192, 2048, 9, 4)
+    n = len(rp) - 1
+    inv = host(ops.gray_reorder(n, dev(rp), dev(col), res, thr, grp)).astype(np.int64)
+    assert np.array_equal(np.sort(inv), np.arange(n))
+    deg, key, counts = oracle.gray_row_keys(rp, col, n, res, thr)
+    model, group = _gray_stable_model(deg, key, counts, min(res, n), thr, grp)
+    assert np.array_equal(inv, model)
+    want = oracle.gray_reorder(rp, col, n, res, thr, grp).astype(np.int64)
+    _, first, cnt = np.unique(group, axis=0, return_index=True, return_counts=True)
+    decided = first[cnt == 1]  # rows whose place the reference's comparators decide
+    assert len(decided) > 0
+    assert np.array_equal(inv[decided], want[decided])
+    with pytest.raises(Exception):
+        ops.gray_reorder(n, dev(rp), dev(col), res, thr, grp, exact_ties=True)
+
+
 def test_gray_row_keys_long_rows_and_odd_widths(ops, oracle):
     """Rows that span several 2048-nonzero tiles in both classes (threshold 0: OR across tiles; counted: per-block
     counts across tiles), column-block widths that are not powers of two, resolution 64, single-entry and empty rows."""

@@ -22,7 +22,9 @@ for name, make in cases.items():
     for tag, params in (("32_10_4", (32, 10, 4)),):
         p = subprocess.run([cli, "gray", a, b, o, str(n), str(n), *map(str, params), "--device", "--time"],
                            capture_output=True, text=True, timeout=600)
-        r["gpu_path_s"] = float(p.stdout.strip().splitlines()[-1])
+        lines = p.stdout.strip().splitlines()
+        r["gpu_path_s"] = float(lines[-2])
+        r["stages_ms(device keys, keys to host, host ordering)"] = [float(x) for x in lines[-1].split()]
         got = np.fromfile(o, np.int32)
         if ref is not None:
             t = time.perf_counter(); want = ref.gray_reorder(rp, col, n, *params); r["reference_s"] = round(time.perf_counter() - t, 3)
