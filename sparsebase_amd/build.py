@@ -66,5 +66,36 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# Checking builds that travel with the product library (built by __graft_entry__.build(), loaded only by tests):
+#   fenced: sbx_rcm.hip with -DSBX_GB_FENCED — release / acquire fences at every grid barrier and election (see gb_wait)
+VARIANTS = {"fenced": ("sbx_rcm.hip", ["-DSBX_GB_FENCED"])}
+
+
+def variant_path(name):
+    return os.path.join(LIBDIR, f"libsbx_{name}.so")
+
+
+def build_variant(name, verbose=False):
+    """libsbx_<name>.so: the product's objects with one source recompiled under the variant's flags."""
+    src, extra = VARIANTS[name]
+    build(verbose=verbose)
+    srcpath = os.path.join(CSRC, src)
+    obj = os.path.join(OBJDIR, f"{src[:-4]}_{name}.o")
+    lib = variant_path(name)
+    stale = not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(srcpath), _headers_mtime())
+    if stale:
+        cmd = [HIPCC] + FLAGS + extra + ["-c", srcpath, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src} ({name}):\n{r.stdout}\n{r.stderr}")
+    if stale or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(LIB):
+        objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in _sources() if not s.endswith("/" + src)]
+        r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + [obj, "-ldl"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed ({name}):\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

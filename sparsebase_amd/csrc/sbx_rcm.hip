@@ -104,6 +104,16 @@ struct RcmDev {
   alignas(128) unsigned long long ufedges[2];
 };
 
+// release / acquire fences of the grid barriers and elections: only in the checking build (see gb_wait)
+#ifdef SBX_GB_FENCED
+#define SBX_GB_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define SBX_GB_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define SBX_GB_RELEASE() ((void)0)
+#define SBX_GB_ACQUIRE() ((void)0)
+#endif
+
+
 // ------------------------------------------------------------------ degree rank
 // Only vertices with a non-empty row ever meet a BFS, so only they get a (degree, id) rank: on a power-law graph that
 // halves the sort.  DEG_UNITS waves own contiguous vertex ranges; the first kernel counts each unit's non-empty rows
@@ -2543,8 +2553,13 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
     // This workgroup's additions to the level's counters were returning atomics or thread 0's own: waiting for the
     // latter is all the ordering the election needs (the counters live in L2 and are read there).  A release fence
     // here — a write-back of the L2 per workgroup, 2048 of them — doubled the kernel's time.
+    // Words under the invariant (see gb_wait): the level's counters unf[] / ufedges[] / n_heavy (returning atomics of the
+    // waves, or thread 0's own adds), uc_done (the election), and what uc_advance / uc_begin write for the next link
+    // of the chain (uc_mode, uc_level, uc_off, ...: read by kernels launched behind this one, i.e. behind a kernel boundary).
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    SBX_GB_RELEASE();
     if (atomicAdd(&dv->uc_done, 1u) == gridDim.x - 1) {
+      SBX_GB_ACQUIRE();
       dv->uc_done = 0;
       if (chain == 2) uc_begin(dv, ci);
       else dv->uc_flips++;
@@ -2679,6 +2694,15 @@ constexpr unsigned UB_DESC_GRID = 64;
 // waiter sees the flag and leaves too, late workgroups leave at their first barrier, and the host — which finds the flag
 // in its next read-back — throws the sweep away and runs it again with the one-launch-per-level kernels.
 constexpr unsigned GB_SPINS = 1u << 16;
+// THE INVARIANT the barriers rest on: every word one workgroup hands to another between two barriers is written and
+// read with agent-scope atomics (relaxed: they go past the per-XCD L2s, the barrier orders them), and a wave drains its
+// vector-memory counter (vmcnt 0) before its workgroup's arrival is counted.  There is no release / acquire fence in
+// the product build: an agent-scope fence writes a whole L2 back.  The words under the invariant are listed at each
+// persistent kernel (k_ubfs_descend_all, k_ubfs_small_run, k_ubfs_cone_run) and at the chained bottom-up level's
+// election (k_ubfs_bottom_up).  A build with -DSBX_GB_FENCED puts a release fence in front of every arrival and an
+// acquire fence behind every wait, so that ordinary stores and loads would be enough: if the product build ever
+// returns something the fenced build does not, a word has escaped the invariant
+// (tests/test_gpu_parity.py::test_rcm_fenced_build_agrees runs both on the stress graphs, several processes at once).
 __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned target) {
   __shared__ int s_ok;
   // Everything this workgroup stored for the others (queue entries, hub queue, counters: agent-scope stores and atomics,
@@ -2688,6 +2712,7 @@ __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned tar
   // reads the old word.  Seen only with several processes on the GPU (the memory side congested): one call in ~5000
   // lost part of a level — a hub's neighbours scanned from a stale hub queue — and with it vertices of its component.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every wave, for its own stores
+  SBX_GB_RELEASE();                    // (SBX_GB_FENCED builds: the checking build of the invariant below)
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(word, 1u);
@@ -2704,11 +2729,14 @@ __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned tar
     s_ok = ok;
   }
   __syncthreads();
+  SBX_GB_ACQUIRE();
   return s_ok != 0;
 }
 
 // (No __threadfence() around a barrier: on a multi-XCD part an agent-scope fence writes the L2 back — ~5 us a piece — and
 // everything the workgroups exchange between two barriers moves through agent-scope atomics anyway.)
+// Words under the barrier invariant (gb_wait) in k_ubfs_descend_all: dv->desc[0..2] (agent-scope stores, atomicMin, agent-
+// scope loads), dv->bar, dv->gb_abort.  cone / vbits / dist were written by the kernels in front (a kernel boundary).
 __global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ rp, const I *__restrict__ col,
                                                           const unsigned *__restrict__ vbits,
                                                           const unsigned *__restrict__ dist,
@@ -2802,6 +2830,11 @@ __device__ __forceinline__ bool ur_barrier(RcmDev *dv, unsigned &epoch) {
   return gb_wait(dv, &dv->ur_bar, epoch * gridDim.x);
 }
 
+// Words under the barrier invariant (gb_wait) in k_ubfs_small_run: the queue entries q[] and the hub queue hq[]
+// (ur_store / ur_load), the visited words vbits[] (ur_load, atomicOr), the level slots dv->ur_nf / ur_nh / ur_deg[0..2]
+// (atomicAdd, ur_store, ur_load), dv->ur_bar, dv->ur_exit, dv->gb_abort.  dist[] is written with plain stores: no
+// workgroup of THIS kernel reads it.  The hand-over state (dv->ur_off ...) is thread 0's alone and read behind the
+// kernel's end.
 __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp, const I *__restrict__ col,
                                                         unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
                                                         unsigned off, unsigned size, unsigned level, unsigned total,
@@ -2971,6 +3004,10 @@ __global__ __launch_bounds__(256) void k_ubfs_mark_fbits(const I *__restrict__ f
 // back to the host (UR_STOP, dv->cone_k = k: the expansion kernels in their cone mode take it), a finished walk returns
 // UR_DONE.  The list is one growing array with one counter (dv->nf); members and hub queue move through agent-scope
 // atomics, the cone bits through atomicOr.
+// Words under the barrier invariant (gb_wait) in k_ubfs_cone_run: the member list list[] and the hub queue hq[] (ur_store /
+// ur_load), the cone words cone[] (ur_load, atomicOr), dv->nf (atomicAdd), dv->ur_nf / ur_nh[0..2], dv->cone_begin /
+// cone_end (ur_load: written by the one-thread kernel in front), dv->ur_bar, dv->ur_exit, dv->gb_abort.  vbits[] and
+// dist[] are the finished sweep's (a kernel boundary): plain loads.
 constexpr unsigned CONE_SMALL = 256;  // (a wave takes a member: 256 waves; 1024 measured 0.3 ms slower per RCM)
 __global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp, const I *__restrict__ col,
                                                        const unsigned *__restrict__ vbits,

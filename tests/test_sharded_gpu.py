@@ -229,3 +229,34 @@ def test_rcm_eight_processes_thousands_of_calls():
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "mismatches 0 exceptions 0" in o, o[-1500:]
+
+
+def test_rcm_fenced_build_agrees():
+    """The grid barriers of the persistent RCM kernels carry no release / acquire fence: they are sound while every word
+    one workgroup hands another between two barriers moves through agent-scope atomics (sbx_rcm.hip, gb_wait).  The
+    checking build libsbx_fenced.so (-DSBX_GB_FENCED: fences at every barrier and election) needs no such invariant.
+    Both builds run the stress loop — four processes at once on the GPU, every call trying the persistent kernels again,
+    the closure check behind every unordered sweep (SBX_DEBUG_RCM_CHECK) — and must agree: the oracle's orders in every
+    call, no edge left open, identical digests."""
+    import subprocess
+    from sparsebase_amd import build as hip_build
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no CPU fallback)")
+    fenced = hip_build.variant_path("fenced")
+    assert os.path.exists(fenced), "libsbx_fenced.so is not built (__graft_entry__.build() builds it)"
+    digests = {}
+    for tag in ("product", "fenced"):
+        env = dict(os.environ, SBX_DEBUG_GB_BACKOFF="0", SBX_DEBUG_RCM_CHECK="1")
+        if tag == "fenced":
+            env["SBX_PROBE_LIB"] = "fenced"
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "rcm_shared_loop.py"), "100", "--digests"],
+                                  cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for _ in range(4)]
+        outs = [p.communicate(timeout=900)[0] for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0 and "mismatches 0 exceptions 0" in o, (tag, o[-1500:])
+            assert "[rcm check]" not in o, (tag, o[-1500:])  # an unordered sweep left an edge open
+            d = tuple(l for l in o.splitlines() if l.startswith("digest"))
+            assert len(d) == 4, (tag, o[-800:])
+            digests.setdefault(tag, set()).add(d)
+    assert len(digests["product"]) == 1 and digests["product"] == digests["fenced"]

@@ -24,5 +24,9 @@ for r in range(rounds):
             if not np.array_equal(got.cpu().numpy(), want): bad += 1; print("MISMATCH round", r, "case", i, flush=True)
         except Exception as e:
             exc += 1; print("EXC round", r, "case", i, str(e)[:100], flush=True)
+if "--digests" in sys.argv:  # what the fenced-build comparison reads: one digest per graph, of the last round's order
+    import hashlib
+    for i, (rp, col, want) in enumerate(dev):
+        print("digest", i, hashlib.sha256(ops.rcm_reorder(rp, col).cpu().numpy().tobytes()).hexdigest(), flush=True)
 print("loop: rounds", rounds, "mismatches", bad, "exceptions", exc)
 sys.exit(1 if bad or exc else 0)
