@@ -730,9 +730,18 @@ __device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, un
                                            const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
                                            I *__restrict__ nf_list, RcmDev *__restrict__ dv, const UnorderedSweep &us) {
   unsigned seen = 0;  // bit k: v[k] is in the sweep's visited bitmap
+  // (MODE 0 does not look: every visited vertex has a parent position, and that position lies in front of the frontier
+  // being expanded — `ppos[v] > p` below is false for it.  One gather per edge instead of two for the unvisited ends.)
+#ifdef SBX_RCM_ORDERED_VBITS
+  constexpr bool LOOK = true;
+#else
+  constexpr bool LOOK = MODE != 0;
+#endif
+  if (LOOK) {
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (((actmask >> k) & 1u) && ((vbits[v[k] >> 5] >> (v[k] & 31)) & 1u)) seen |= 1u << k;
+    for (int k = 0; k < 4; k++)
+      if (((actmask >> k) & 1u) && ((vbits[v[k] >> 5] >> (v[k] & 31)) & 1u)) seen |= 1u << k;
+  }
   unsigned unv = MODE == 2 ? seen : (actmask & ~seen & 0xFu);
   unsigned won = 0;
   if (MODE == 2) {
@@ -2004,10 +2013,17 @@ struct BfsBuffers {
   // work the host still has to enqueue elsewhere (the degree ranks on their side stream): run once, right after a sweep's
   // first launch and before the host waits for it, so that its enqueue time hides behind the kernel (bfs_first_launch)
   std::function<int()> *after_first_launch;
+  // the hook enqueues a dozen launches or more (~5 us of host time each): it is only run where the GPU has that much
+  // work in front of the next read-back — a chain of big levels (run_ubfs) or an ordered sweep's launches — and not
+  // behind a 40 us kernel, which it would outlast with the caller's stream idle
+  bool hook_wants_long_cover;
 };
 
-static int bfs_first_launch(const BfsBuffers &b) {  // (the hook ignores every call after its first)
-  return b.after_first_launch ? (*b.after_first_launch)() : SBX_OK;
+// cover_us: roughly how long the kernels just enqueued keep the GPU busy before the host's next read-back returns
+static int bfs_first_launch(const BfsBuffers &b, int cover_us = 1000) {  // (the hook ignores every call after its last stage)
+  if (!b.after_first_launch) return SBX_OK;
+  if (b.hook_wants_long_cover && cover_us < 100) return SBX_OK;
+  return (*b.after_first_launch)();
 }
 
 struct BfsResult {
@@ -3205,7 +3221,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
                   (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels(), 0);
       SBX_LAUNCH_CHECK(h);
-      SBX_TRY(bfs_first_launch(b));
+      SBX_TRY(bfs_first_launch(b, 40));
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
       if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
@@ -3278,6 +3294,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
                   (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), tail_mode);
       SBX_LAUNCH_CHECK(h);
+      SBX_TRY(bfs_first_launch(b, 150));  // (a chain of big levels is in flight: the host has nothing else to do)
       SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
       if (hd.gb_abort) {
         // a grid barrier of the chain's small-level kernel gave up — before it could say that it ran at all: the sweep
@@ -3362,7 +3379,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   RcmDev hd;
   if (r.last_size > UB_TIES_SMALL) {
     // (the one-workgroup kernel of the small case names a single candidate itself: no round trip for the count)
-    SBX_TRY(bfs_first_launch(b));
+    SBX_TRY(bfs_first_launch(b, 20));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.nf <= 1) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_root_from_single_tie, dim3(1), dim3(1), b.dv);
@@ -3388,7 +3405,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_cone_run, dim3(UR_GRID), dim3(256), b.rp, b.col, (const unsigned *)b.vbits,
                 (const unsigned *)b.lpos, cone, list, (I *)b.heavy, b.dv, k);
     SBX_LAUNCH_CHECK(h);
-    SBX_TRY(bfs_first_launch(b));
+    SBX_TRY(bfs_first_launch(b, 40));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
     if (hd.gb_abort) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
@@ -3411,6 +3428,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
               (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv);
   SBX_LAUNCH_CHECK(h);
+  SBX_TRY(bfs_first_launch(b, 40));
   SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
   if (hd.gb_abort) {
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
@@ -3567,6 +3585,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   bool claim_clean = false;
   b.claim_clean = &claim_clean;
   b.after_first_launch = &enqueue_ranks;
+  b.hook_wants_long_cover = true;  // (~15 launches)
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy; b.heavy_cap = heavy_cap;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
@@ -3715,7 +3734,10 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   // Cuthill-McKee sweep, which are bound by launches and latency, not by bandwidth.  The search needs no labels (a sweep
   // cannot leave its component; unlabelled, the bottom-up levels merely look at the other components' vertices too).
   cc_forked = side && v0 >= 0 && r0.count > (unsigned)RCM_MID && r0_unordered && rcm_cc_overlap();
-  auto enqueue_cc_kernels = [&]() -> int {
+  // (in two halves: on the side stream each half is enqueued behind one of the tie-break's ~45 us kernels)
+  auto enqueue_cc_kernels = [&](int half) -> int {
+  const unsigned gcount = gn < 1024u ? gn : 1024u;
+  if (half != 1) {
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_init, dim3(gn), dim3(256), rp, col, label, n, (const unsigned *)cbits);
   SBX_KLAUNCH(h, SBX_K_CC, k_cc_hook_small, dim3(gn), dim3(256), rp, col, label, n, big_list,
               (const unsigned *)cbits, dv);
@@ -3723,15 +3745,17 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
               (const I *)big_list, (const RcmDev *)dv);
   // (phase 0 and the classification end in one counter add per workgroup: few workgroups, or the counter word is the
   // bottleneck — 16 K adds on one word cost 0.19 ms)
-  const unsigned gcount = gn < 1024u ? gn : 1024u;
   for (int phase = 0; phase < 2; phase++)
     SBX_KLAUNCH(h, SBX_K_CC, k_cc_finalize, dim3(phase == 0 ? gcount : gn), dim3(256), rp, label, csize, n,
                 (const unsigned *)cbits, v0 >= 0 ? v0 : (I)0, (I)r0.count, phase, dv);
   SBX_LAUNCH_CHECK(h);
+  }
+  if (half != 0) {
   SBX_TRY(sbx_exclusive_scan_i32(h, csize, cbase, n + 1, nullptr));
   SBX_KLAUNCH(h, SBX_K_CC, k_classify, dim3(gcount), dim3(256), (const I *)label, (const I *)csize, (const I *)cbase, inv,
               small_list, mid_list, large_list, n, dv);
   SBX_LAUNCH_CHECK(h);
+  }
   return SBX_OK;
   };
   if (cc_forked) {
@@ -3739,30 +3763,36 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     // calls before its first read-back): the host needs ~50 us for them, which the caller's stream would spend idle.
     SBX_HIP(h, hipEventRecord(h->aux_event[2], main_stream));
     h->aux_dirty = true;
-    bool cc_enqueued = false;
+    int cc_stage = 0;  // halves of the labelling enqueued so far
     std::function<int()> enqueue_cc = [&]() -> int {
       SBX_TRY(enqueue_ranks());
-      if (cc_enqueued) return SBX_OK;
-      cc_enqueued = true;
-      SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[2], 0));
+      if (cc_stage >= 2) return SBX_OK;
+      if (cc_stage == 0) SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[2], 0));
       h->stream = h->aux_stream[1];
-      int rc = enqueue_cc_kernels();
-      if (rc == SBX_OK) {  // the small components too: their number stays on the device, the launch covers any
+      int rc = enqueue_cc_kernels(cc_stage);
+      if (rc == SBX_OK && cc_stage == 1) {  // the small components too: their number stays on the device, the launch covers any
         const unsigned lanes = (unsigned)std::min<int64_t>((n / 2 + 63) / 64 * 64, (int64_t)h->num_cus * 32 * 64);
         SBX_KLAUNCH(h, SBX_K_RCM_SMALL, k_rcm_small, dim3(lanes / 64 > 0 ? lanes / 64 : 1), dim3(64), rp, col,
                     (const I *)small_list, 0u, (const I *)csize, (const I *)cbase, dist, q_small, inv, dv,
                     (const unsigned *)&dv->n_small);
         if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
+        if (rc == SBX_OK && hipEventRecord(h->aux_event[3], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
       }
-      if (rc == SBX_OK && hipEventRecord(h->aux_event[3], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
+      cc_stage++;
       h->stream = main_stream;
       return rc;
     };
     b.after_first_launch = &enqueue_cc;
+    b.hook_wants_long_cover = false;  // (half a dozen launches per call)
     const int src = search_component(v0, (I)r0.count, true, sd0);
     b.after_first_launch = &enqueue_ranks;
-    SBX_TRY(src);
+    b.hook_wants_long_cover = true;
+    if (src != SBX_OK) {  // (the side stream must not be left waiting for a half that never comes)
+      h->stream = main_stream;
+      return src;
+    }
     SBX_TRY(enqueue_cc());  // (a search that never waited for anything)
+    SBX_TRY(enqueue_cc());
     comp0_searched = true;
     SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[3], 0));
     cc_forked = false;
@@ -3774,7 +3804,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     SBX_LAUNCH_CHECK(h);
     small_on_side = true;
   } else {
-    SBX_TRY(enqueue_cc_kernels());
+    SBX_TRY(enqueue_cc_kernels(2));
   }
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
   if (hd.unsym)

@@ -17,7 +17,7 @@ for r in rows:
     gap = max(0, s - prev_end)
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:40]
     if "--all" in sys.argv:
-        print(f"{(s - t0) / 1e3:9.1f} us  +{gap / 1e3:6.1f} gap  {(e - s) / 1e3:8.1f} us  {name}")
+        print(f"{(s - t0) / 1e3:9.1f} us  +{gap / 1e3:6.1f} gap  {(e - s) / 1e3:8.1f} us  q{r.get('Queue_Id', '?'):>2} s{r.get('Stream_Id', '?'):>2}  {name}")
     busy += max(0, e - max(s, prev_end))
     gaps += gap
     if gap > 4000:
