@@ -3007,11 +3007,21 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp
   }
 }
 
-__global__ __launch_bounds__(256) void k_ubfs_mark_fbits(const I *__restrict__ frontier, unsigned fsize,
-                                                         unsigned *__restrict__ fbits) {
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < fsize; j += gridDim.x * blockDim.x) {
-    const I v = frontier[j];
-    atomicOr(&fbits[v >> 5], 1u << (v & 31));
+// The frontier bitmap of an unordered sweep rebuilt from what every level kernel leaves behind — frontier = visited
+// vertices at distance `level` — in one streaming pass that writes every word (a fill of the bitmap + a scatter of the
+// frontier's bits were four launches: hipMemsetAsync splits into three).  Unvisited vertices may hold stale distances.
+__global__ __launch_bounds__(256) void k_ubfs_fbits_from_dist(const unsigned *__restrict__ vbits,
+                                                              const unsigned *__restrict__ dist, unsigned level,
+                                                              int64_t n, unsigned *__restrict__ fbits) {
+  const int64_t words = (n + 31) / 32;
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // (a multiple of 64: a wave covers two whole words)
+  for (; v < words * 32; v += stride) {
+    const bool in = v < n && ((vbits[v >> 5] >> (v & 31)) & 1u) && dist[v] == level;
+    const unsigned long long m = __ballot(in);
+    const int lane = sbx_lane();
+    if (lane == 0) fbits[v >> 5] = (unsigned)m;
+    if (lane == 32) fbits[v >> 5] = (unsigned)(m >> 32);
   }
 }
 
@@ -3252,11 +3262,9 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     const int chain_len = ubfs_chain();
     const ChainInit ci = {off, fsize, level, total, (long long)remaining, ubu_ratio()};
     if (bottom_up) {
-      if (!fbits_valid) {
-        SBX_HIP(h, hipMemsetAsync(cur_f, 0, bm_bytes, h->stream));
-        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_fbits, dim3(sbx_grid_for(fsize, 256, 1024)), dim3(256),
-                    (const I *)(b.q + off), fsize, cur_f);
-      }
+      if (!fbits_valid)
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_fbits_from_dist, dim3(sbx_grid_for(b.n, 256, 4096)), dim3(256),
+                    (const unsigned *)b.vbits, (const unsigned *)dist, level, b.n, cur_f);
       // publishes the level itself (bitmaps, distances, queue): no collection pass
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv, chain_len > 0 ? 2 : 0, ci);
