@@ -97,5 +97,37 @@ def build_variant(name, verbose=False):
     return lib
 
 
+def build_tuning(verbose=False):
+    """libsbx_tuning.so: every source with -DSBX_TUNING — the build whose tuning and diagnostic environment switches
+    (sbx_env_tuning in sbx_internal.h) are live.  For tools (SBX_PROBE_LIB=tuning); the product library ignores them."""
+    odir = os.path.join(LIBDIR, "obj_tuning")
+    os.makedirs(odir, exist_ok=True)
+    hdr_m = _headers_mtime()
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            jobs.append((src, obj))
+
+    def one(so):
+        r = subprocess.run([HIPCC] + FLAGS + ["-DSBX_TUNING", "-c", so[0], "-o", so[1]], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {so[0]} (tuning):\n{r.stdout}\n{r.stderr}")
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(one, jobs))
+    lib = variant_path("tuning")
+    if jobs or not os.path.exists(lib):
+        r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-ldl"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed (tuning):\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--tuning" in sys.argv:
+        print(build_tuning(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

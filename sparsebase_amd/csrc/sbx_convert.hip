@@ -530,7 +530,6 @@ static int coo_sort_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m,
   SBX_KLAUNCH(h, SBX_K_MISC, k_pack_rc64, dim3(grid), dim3(CV_THREADS), (const int64_t *)row, (const int64_t *)col, colbits,
               ka, nnz);
   SBX_LAUNCH_CHECK(h);
-  static const bool hybrid_on = !(getenv("SBX_COO_SORT_HYBRID") && atoi(getenv("SBX_COO_SORT_HYBRID")) == 0);
   int p = 2;
   if (rowbits > 16 && nnz / 65536 > 512) p = 3;
   const int s_bits = rowbits > 8 * p ? rowbits - 8 * p : 0;
@@ -538,7 +537,7 @@ static int coo_sort_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m,
   const int np = sbx_radix_plan(0, colbits + rowbits, 0, 0, passes);
   const int np_msd = sbx_radix_plan(colbits + s_bits, colbits + rowbits, 0, 0, msd);
   int in_b = 0;
-  if (hybrid_on && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
+  if (np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
     SBX_TRY(sbx_radix_sort(h, 8, vb, ka, kb, val, vtmp, nnz, msd, np_msd, &in_b));
     const uint64_t *grouped = in_b ? kb : ka;
     const char *vcur = in_b ? vtmp : (const char *)val;
@@ -602,7 +601,6 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
     // group by the permute's LDS sort stage (stable: (key, position)); rows and columns are then unpacked in place.
     // 2 – 3 global passes + one LDS sort instead of 5 – 6 passes: C2B (10 M uniform records) 0.66 -> 0.52 ms, C3 (105 M
     // power-law records, three passes: groups = rows) 6.1 -> 5.8 ms.  SBX_COO_SORT_HYBRID=0: the plain LSD sort.
-    static const bool hybrid_on = !(getenv("SBX_COO_SORT_HYBRID") && atoi(getenv("SBX_COO_SORT_HYBRID")) == 0);
     // groups of 2^s rows must stay LDS-sized when the rows are skewed (a group above 8192 records takes the long-row
     // path, six more global passes over its records): two passes only while the AVERAGE group holds <= 512 records
     int p = 2;
@@ -611,7 +609,7 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
     sbx_radix_pass msd[16];
     const int np_msd = sbx_radix_plan(0, 0, 32 + s_bits, 32 + rowbits, msd);
     // (coordinates outside [0, n) x [0, m) would overflow the bit fields and the group table: the plain sort takes them)
-    if (hybrid_on && in_range && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
+    if (in_range && np_msd >= 2 && np >= np_msd + 2 && s_bits + colbits <= 31 && nnz < ((int64_t)1 << 31)) {
       NestGuard guard(h);  // (the nested conversions below must not rewind the arena)
       char *vtmp2 = nullptr;
       if (vb) SBX_TRY(sbx_salloc(h, (size_t)nnz * vb, &vtmp2));

@@ -1484,7 +1484,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     unsigned *nlong = &both->nlong;
     int32_t *long_list = nullptr;
     SBX_TRY(sbx_salloc(h, (size_t)GR_LONG_LIST, &long_list));
-    static const bool allow = !(getenv("SBX_GRAY_SHORT_ROWS") && atoi(getenv("SBX_GRAY_SHORT_ROWS")) == 0);
+    static const bool allow = !(sbx_env_tuning("SBX_GRAY_SHORT_ROWS") && atoi(sbx_env_tuning("SBX_GRAY_SHORT_ROWS")) == 0);
     const unsigned hmax = (unsigned)GR_SHORT_MAX;  // bound of the rows the kernel handles
     // a row of d <= hmax entries compares its block counts with d / resolution <= hmax / resolution: that many
     // saturating counter slices + 1.  The kernel is built for up to 5 (resolution >= 16) — what the tests of round 2
@@ -1517,7 +1517,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
       else GRAY_ROWS(K, GRID, unsigned long long, 2, ##__VA_ARGS__); /* 64 blocks: thr <= 64 / 64 */               \
     }                                                                                                              \
   } while (0)
-      static const bool try_banded = !(getenv("SBX_GRAY_BANDED_FIRST") && atoi(getenv("SBX_GRAY_BANDED_FIRST")) == 0);
+      static const bool try_banded = !(sbx_env_tuning("SBX_GRAY_BANDED_FIRST") && atoi(sbx_env_tuning("SBX_GRAY_BANDED_FIRST")) == 0);
       GrayBoth hb;
       hb.nlong = 0, hb.pad = GR_POWER_LAW;
       // the counters (what the later kernels of the banded path added) + k_gray_rows_short's GR_EARLY copies, summed here
@@ -1571,7 +1571,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         GrayCounts *spread = all->spread;
         const int64_t brows = (int64_t)GB_ITERS * 4 * GB_GROUPS * 64;  // rows per workgroup
         const unsigned bgrid = (unsigned)((n + brows - 1) / brows);
-        static const bool tiny_on = !(getenv("SBX_GRAY_TINY_ROWS") && atoi(getenv("SBX_GRAY_TINY_ROWS")) == 0);
+        static const bool tiny_on = !(sbx_env_tuning("SBX_GRAY_TINY_ROWS") && atoi(sbx_env_tuning("SBX_GRAY_TINY_ROWS")) == 0);
         // (a row of up to GR_TINY entries has threshold 0 when it is shorter than `resolution` or not above the nnz threshold)
         if (tiny_on && (bits > GR_TINY || nnz_threshold >= GR_TINY)) {
           int32_t *mid_list = nullptr;

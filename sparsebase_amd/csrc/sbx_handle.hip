@@ -103,7 +103,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->rs_pool = nullptr;
   h->rs_next = 0;
   {
-    const char *e = getenv("SBX_READBACK_POLL");
+    const char *e = sbx_env_tuning("SBX_READBACK_POLL");
     h->rb_poll = !(e && e[0] == '0');
   }
   memset(h->pinned, 0, kPinnedBytes);

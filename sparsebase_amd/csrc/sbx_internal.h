@@ -1,6 +1,7 @@
 // sbx_internal.h — handle, scratch arena and launch helpers shared by the HIP
 // translation units of libsbx.  gfx950 (MI355X) only: wave64, 160 KiB LDS/CU.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -157,6 +158,22 @@ int sbx_radix_slot(sbx_handle_t h, void **slot);
 
 // blocking read-back of `bytes` (<= pinned buffer) from device memory
 int sbx_readback(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes);
+
+// ---- environment switches ------------------------------------------------------------------------------------------------
+// Two kinds.  sbx_env_test(): what the test-suite needs to reach a code path that production takes only under conditions a
+// test cannot arrange (a grid barrier giving up, a level beyond a size limit, every row on the radix fallback) — always
+// read; every one of them selects code that also runs without the switch.  sbx_env_tuning(): tuning ranges and
+// diagnostics — read only in builds with -DSBX_TUNING (python -m sparsebase_amd.build --tuning -> libsbx_tuning.so); the
+// product library does not look at them.
+static inline const char *sbx_env_test(const char *name) { return getenv(name); }
+static inline const char *sbx_env_tuning(const char *name) {
+#ifdef SBX_TUNING
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 static inline int sbx_value_bytes(sbx_value_type vt) {
   switch (vt) {

@@ -2009,18 +2009,18 @@ int launch_fix(sbx_handle_t h, sbx_value_type vt, const I *rpo, const I *col, vo
 }
 
 static bool permute_overlap() {
-  static const bool on = !(getenv("SBX_PERMUTE_OVERLAP") && atoi(getenv("SBX_PERMUTE_OVERLAP")) == 0);
+  static const bool on = !(sbx_env_test("SBX_PERMUTE_OVERLAP") && atoi(sbx_env_test("SBX_PERMUTE_OVERLAP")) == 0);
   return on;
 }
 
 static int permute_grid_factor() {  // SBX_PERMUTE_GRID_FACTOR: workgroups launched per resident slot (tuning)
-  static const int f = getenv("SBX_PERMUTE_GRID_FACTOR") ? atoi(getenv("SBX_PERMUTE_GRID_FACTOR")) : 1;
+  static const int f = sbx_env_tuning("SBX_PERMUTE_GRID_FACTOR") ? atoi(sbx_env_tuning("SBX_PERMUTE_GRID_FACTOR")) : 1;
   return f < 1 ? 1 : f;
 }
 
 static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / row takes the radix path (tests)
-  static const int on = (getenv("SBX_PERMUTE_FORCE_RADIX") ? atoi(getenv("SBX_PERMUTE_FORCE_RADIX")) & 0xFF : 0) |
-                        (getenv("SBX_DEBUG_TILE_STOP") ? atoi(getenv("SBX_DEBUG_TILE_STOP")) << 8 : 0);
+  static const int on = (sbx_env_test("SBX_PERMUTE_FORCE_RADIX") ? atoi(sbx_env_test("SBX_PERMUTE_FORCE_RADIX")) & 0xFF : 0) |
+                        (sbx_env_test("SBX_DEBUG_TILE_STOP") ? atoi(sbx_env_test("SBX_DEBUG_TILE_STOP")) << 8 : 0);
   return on;
 }
 
@@ -2040,7 +2040,7 @@ static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / r
 static int class_stream(int cls) {
   static int map[BR_CLASSES] = {-1};
   if (map[0] < 0) {
-    const char *e = getenv("SBX_PERMUTE_CLASS_STREAMS");
+    const char *e = sbx_env_tuning("SBX_PERMUTE_CLASS_STREAMS");
     const char *d = (e && strlen(e) == BR_CLASSES) ? e : "023456";
     for (int c = 0; c < BR_CLASSES; c++) {
       const int v = d[c] - '0';
@@ -2051,21 +2051,17 @@ static int class_stream(int cls) {
 }
 
 static int rq_waves_per_cu() {
-  static const int f = getenv("SBX_PERMUTE_ROW_WAVES") ? atoi(getenv("SBX_PERMUTE_ROW_WAVES")) : 16;
+  static const int f = sbx_env_tuning("SBX_PERMUTE_ROW_WAVES") ? atoi(sbx_env_tuning("SBX_PERMUTE_ROW_WAVES")) : 16;
   return f < 1 ? 1 : f;
 }
 
 static int tile_grid_factor() {  // SBX_PERMUTE_TILE_GRID: persistent tile waves per resident slot (tuning)
-  static const int f = getenv("SBX_PERMUTE_TILE_GRID") ? atoi(getenv("SBX_PERMUTE_TILE_GRID")) : 12;
+  static const int f = sbx_env_tuning("SBX_PERMUTE_TILE_GRID") ? atoi(sbx_env_tuning("SBX_PERMUTE_TILE_GRID")) : 12;
   return f < 1 ? 1 : f;
 }
 
 #include "sbx_rowsort.h"
 
-static bool permute_quad_rows() {  // SBX_PERMUTE_QUAD_ROWS=0: round 3's k_permute_block_rows instead of k_rows_quad
-  static const bool on = !(getenv("SBX_PERMUTE_QUAD_ROWS") && atoi(getenv("SBX_PERMUTE_QUAD_ROWS")) == 0);
-  return on;
-}
 
 // rows of PT_LMAX < length <= 8 K: one workgroup per row, by capacity class
 template <typename I, int VB>
@@ -2108,9 +2104,9 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char
   // k_rows_quad: T threads x Q quads = the class capacity; the column map must fit a buffer descriptor (4 GB)
   // (without a column map — csr_sort_rows, the hybrid COO sort's groups — there is no gather to hide the sort behind and
   // round 3's kernels, lighter in registers, measure 6 % better on C2B: 0.536 against 0.570 ms)
-  // (64-bit index arrays: round 3's kernels, which read and write the columns through plain pointers of either width)
-  const bool quad = sizeof(I) == 4 && permute_quad_rows() && col_order && (uint64_t)m * 4 <= 0xFFFFFFFCull;
-  const unsigned table_bytes = col_order ? (unsigned)((uint64_t)m * 4) : 0u;
+  // (64-bit index arrays: the same kernel, two 16-byte accesses per quad of columns, the map's low words gathered)
+  const bool quad = col_order && (uint64_t)m * sizeof(I) <= 0xFFFFFFFCull;
+  const unsigned table_bytes = col_order ? (unsigned)((uint64_t)m * sizeof(I)) : 0u;
 #define QUAD_ROWS(CLS, THREADS, QUADS, MINW)                                                                      \
   if (n_block[CLS]) {                                                                                             \
     static_assert(4 * (THREADS) * (QUADS) == br_cap(CLS), "class capacity");                                      \
@@ -2134,32 +2130,16 @@ int block_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char
       if (e1_ != hipSuccess || e2_ != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "side stream hand-over failed");       \
     }                                                                                                             \
   }
-  if constexpr (sizeof(I) == 4) if (quad) {
-    static const int big = getenv("SBX_PERMUTE_BIG") ? atoi(getenv("SBX_PERMUTE_BIG")) : 0;  // (tuning: shape of the two big classes)
+  if (quad) {
     QUAD_ROWS(0, 64, 1, 1);
-    // the 512-slot class keeps round 3's kernel: one wave per row and two quad steps need 124 registers (16 waves per
+    // the 512-slot class keeps round 3's kernel: one wave per row and two quad steps need 112 registers (16 waves per
     // CU) where that kernel runs 24 waves — with the RCM order, whose rows all take the second sort level, 146 us against
-    // its 118 on the bench matrix (random order: 128 / 112; capped at 96 registers the quad kernel spills: 240)
-    static const int c512 = getenv("SBX_PERMUTE_C512_QUAD") ? atoi(getenv("SBX_PERMUTE_C512_QUAD")) : 0;
-    if (c512) {
-      QUAD_ROWS(1, 64, 2, 1);
-    } else {
-      BLOCK_ROWS(1, 64);
-    }
-    QUAD_ROWS(2, 128, 2, 1);
-    QUAD_ROWS(3, 256, 2, 1);
-    if (big == 1) {
-      QUAD_ROWS(4, 256, 4, 1);
-    } else {
-      QUAD_ROWS(4, 512, 2, (VB == 8 ? 2 : 4));  // two workgroups per CU: at most 128 registers (8-byte values: LDS allows one)
-    }
-    if constexpr (VB != 8) {
-      if (big == 1) {
-        QUAD_ROWS(5, 512, 4, 1);
-      } else {
-        QUAD_ROWS(5, 1024, 2, 1);
-      }
-    }
+    // its 118 on the bench matrix (random order: 128 / 112; measured again with the interleaved gathers of round 5: level)
+    BLOCK_ROWS(1, 64);
+    QUAD_ROWS(2, 128, 2, (sizeof(I) == 8 ? 4 : 1));  // (64-bit index arrays: held to 128 registers, four waves per SIMD)
+    QUAD_ROWS(3, 256, 2, (sizeof(I) == 8 ? 4 : 1));
+    QUAD_ROWS(4, 512, 2, (VB == 8 ? 2 : 4));  // two workgroups per CU: at most 128 registers (8-byte values: LDS allows one)
+    if constexpr (VB != 8) QUAD_ROWS(5, 1024, 2, 1);
   }
   if (!quad) {
     // threads per class, measured on the bench matrix: one wave (no s_barrier at all) up to 512 entries, 8 entries per
@@ -2217,10 +2197,6 @@ int long_rows_radix_path(sbx_handle_t h, const int2 *rec, const I *col_in, const
 }
 
 
-static bool permute_long_segments() {  // SBX_PERMUTE_LONG_SEGMENTS=0: long rows always take the global radix sort
-  static const bool on = !(getenv("SBX_PERMUTE_LONG_SEGMENTS") && atoi(getenv("SBX_PERMUTE_LONG_SEGMENTS")) == 0);
-  return on;
-}
 
 // longer rows of a permute that relabels columns: segments sorted in LDS (kernels above); what that path declines
 // (rows already in order, overfull segments) and every long row of the other callers goes through the radix path
@@ -2228,7 +2204,7 @@ template <typename I, int VB>
 int long_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char *val_in, const I *col_order,
                    const I *rpo, I *col_out, char *val_out, int64_t m, const I *long_rows,
                    unsigned n_long, int64_t long_nnz, PermState *st) {
-  if (!col_order || !permute_long_segments() || (permute_force_radix() & 1) || long_nnz >= ((int64_t)1 << 31))
+  if (!col_order || (permute_force_radix() & 1) || long_nnz >= ((int64_t)1 << 31))
     return long_rows_radix_path<I, VB>(h, rec, col_in, val_in, col_order, rpo, col_out, val_out, m, long_rows, n_long,
                                     long_nnz, st);
   const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
@@ -2278,9 +2254,7 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char 
               (const unsigned *)row_skip, c2, v2);
   // the segments: virtual rows of the one-workgroup-per-row kernel (columns already relabelled: no column map)
   const int force = permute_force_radix() & 0xFE;
-  bool seg_quad = false;
-  if constexpr (sizeof(I) == 4) seg_quad = permute_quad_rows();
-  if constexpr (sizeof(I) == 4) if (seg_quad) {
+  {
     // (512 threads, two workgroups per CU for segments of up to 4096 entries; 1024 threads for the longer ones)
     SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_rows_quad<I, VB, 512, 2, (VB == 8 ? 2 : 4)>), dim3(2 * (unsigned)h->num_cus), dim3(512),
                 (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
@@ -2292,18 +2266,6 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char 
                   (const unsigned *)&st->n_seg[1], 0u);
     }
   }
-  if (!seg_quad) {
-    // (1024-thread workgroups: one resident per CU, as in block_rows_path)
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 4096, 1024>), dim3((unsigned)h->num_cus), dim3(1024),
-                (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const I *)vlist,
-                0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows, (const unsigned *)&st->n_seg[0]);
-    if constexpr (VB != 8) {
-      SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_block_rows<I, VB, 8192, 1024>), dim3((unsigned)h->num_cus),
-                  dim3(1024), (const int2 *)vrec, (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo,
-                  (const I *)(vlist + seg_max), 0, col_out, val_out, st, force, fb_rows, &st->n_seg_fb_rows,
-                  (const unsigned *)&st->n_seg[1]);
-    }
-  }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_LONG, (k_permute_rows_radix<I, VB>), dim3(256), dim3(1024), (const int2 *)vrec,
               (const I *)c2, (const char *)v2, (const I *)nullptr, (const I *)vrpo, (const unsigned *)fb_rows, col_out,
               val_out, col_bits, st, (const unsigned *)&st->n_seg_fb_rows);
@@ -2311,7 +2273,7 @@ int long_rows_path(sbx_handle_t h, const int2 *rec, const I *col_in, const char 
   SBX_PROF_BYTES(h, SBX_K_PERMUTE_LONG, long_nnz * (int64_t)(2 * (sizeof(I) + VB)));
   PermState hs2;
   SBX_TRY(sbx_readback(h, &hs2, st, sizeof(PermState)));
-  if (getenv("SBX_DEBUG_LONG"))
+  if (sbx_env_tuning("SBX_DEBUG_LONG"))
     fprintf(stderr, "long rows %u (%lld entries): segments %u + %u, clustered segments %u, rows left to the radix sort %u (%llu entries)\n",
             n_long, (long long)long_nnz, hs2.n_seg[0], hs2.n_seg[1], hs2.n_seg_fb_rows, hs2.n_long_fb, hs2.long_fb_nnz);
   if (hs2.n_long_fb)

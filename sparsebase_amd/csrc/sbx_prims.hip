@@ -549,7 +549,7 @@ __global__ __launch_bounds__(RSP_THREADS, 4) void k_onesweep_pass(const K *__res
 }
 
 static int rs_hist_grid_factor() {  // SBX_RADIX_HIST_GRID: workgroups per CU of the histogram kernel (tuning)
-  static const int f = getenv("SBX_RADIX_HIST_GRID") ? atoi(getenv("SBX_RADIX_HIST_GRID")) : 2;
+  static const int f = sbx_env_tuning("SBX_RADIX_HIST_GRID") ? atoi(sbx_env_tuning("SBX_RADIX_HIST_GRID")) : 2;
   return f < 1 ? 1 : f;
 }
 

@@ -183,31 +183,10 @@ __global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void k_deg_keys(const I *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
-                                                  uint32_t *__restrict__ key, uint32_t *__restrict__ id) {
-  const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
-  if (unit >= DEG_UNITS) return;
-  unsigned base = 0;
-  for (int j = lane; j < unit; j += 64) base += ucnt[j];
-  base = sbx_wave_sum(base);
-  const int64_t len = deg_unit_len(n), v0 = (int64_t)unit * len;
-  for (int64_t vb = v0; vb < v0 + len && vb < n; vb += 64) {
-    const int64_t v = vb + lane;
-    const unsigned d = v < n ? (unsigned)(rp[v + 1] - rp[v]) : 0u;
-    const uint64_t m = __ballot(d != 0);
-    if (d) {
-      const unsigned o = base + (unsigned)__popcll(m & sbx_lanemask_lt());
-      key[o] = d;
-      id[o] = (uint32_t)v;
-    }
-    base += (unsigned)__popcll(m);
-  }
-}
-
 // One non-trivial component (the usual power-law input: a giant component and isolated vertices): every vertex with an
 // empty row is a component of its own, placed by the count of components in front of it — the empty rows with a smaller
 // id, plus the whole first component if its root v0 lies in front (format of k_classify / cbase: rcm_reorder.cc visits
-// the components in the order of their smallest vertex).  Same unit walk as k_deg_keys; replaces the union-find, its
+// the components in the order of their smallest vertex).  Same unit walk as k_deg_count; replaces the union-find, its
 // size scan and the classification when the first sweep already reached every non-empty row.
 __global__ __launch_bounds__(256) void k_iso_positions(const I *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
                                                        I v0, I comp_size, I *__restrict__ inv) {
@@ -227,13 +206,6 @@ __global__ __launch_bounds__(256) void k_iso_positions(const I *__restrict__ rp,
     }
     base += (unsigned)__popcll(m);
   }
-}
-
-__global__ __launch_bounds__(256) void k_rank_from_order(const uint32_t *__restrict__ dorder,
-                                                         uint32_t *__restrict__ drank, int64_t n) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; k < n; k += stride) drank[dorder[k]] = (uint32_t)k;
 }
 
 // ------------------------------------------------------------------ connected components
@@ -611,35 +583,35 @@ constexpr int RCM_STAGE = 512;  // staged vertices per wave
 
 // bottom-up is chosen when the frontier owns more than this many times the edges of the unvisited rest
 static double bu_ratio() {
-  static const double r = getenv("SBX_DEBUG_BU_RATIO") ? atof(getenv("SBX_DEBUG_BU_RATIO")) : 4.0;
+  static const double r = sbx_env_test("SBX_DEBUG_BU_RATIO") ? atof(sbx_env_test("SBX_DEBUG_BU_RATIO")) : 4.0;
   return r;
 }
 
 // calls a handle keeps away from the persistent kernels after a grid barrier gave up (SBX_DEBUG_GB_BACKOFF: stress tests
 // set 0 so that every call tries them again)
 static int gb_backoff_calls() {
-  static const int k = getenv("SBX_DEBUG_GB_BACKOFF") ? atoi(getenv("SBX_DEBUG_GB_BACKOFF")) : 16;
+  static const int k = sbx_env_test("SBX_DEBUG_GB_BACKOFF") ? atoi(sbx_env_test("SBX_DEBUG_GB_BACKOFF")) : 16;
   return k;
 }
 
 static bool rcm_split_expand() {  // SBX_RCM_SPLIT_EXPAND=0: a wide frontier's light rows are expanded in front of its hubs
-  static const bool on = !(getenv("SBX_RCM_SPLIT_EXPAND") && atoi(getenv("SBX_RCM_SPLIT_EXPAND")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_SPLIT_EXPAND") && atoi(sbx_env_test("SBX_RCM_SPLIT_EXPAND")) == 0);
   return on;
 }
 
 static bool rcm_cc_overlap() {  // SBX_RCM_CC_OVERLAP=0: the labelling of the other components runs in line (see sbx_rcm_reorder)
-  static const bool on = !(getenv("SBX_RCM_CC_OVERLAP") && atoi(getenv("SBX_RCM_CC_OVERLAP")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_CC_OVERLAP") && atoi(sbx_env_test("SBX_RCM_CC_OVERLAP")) == 0);
   return on;
 }
 
 static bool rcm_overlap() {
-  static const bool on = !(getenv("SBX_RCM_OVERLAP") && atoi(getenv("SBX_RCM_OVERLAP")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_OVERLAP") && atoi(sbx_env_test("SBX_RCM_OVERLAP")) == 0);
   return on;
 }
 
 // first candidate root of the pseudo-peripheral search whose Cuthill-McKee sweep is run speculatively
 static int64_t rcm_speculate_from() {
-  static const int64_t k = getenv("SBX_DEBUG_RCM_SPECULATE") ? atoll(getenv("SBX_DEBUG_RCM_SPECULATE")) : 2;
+  static const int64_t k = sbx_env_tuning("SBX_DEBUG_RCM_SPECULATE") ? atoll(sbx_env_tuning("SBX_DEBUG_RCM_SPECULATE")) : 2;
   return k;
 }
 
@@ -1974,19 +1946,19 @@ __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q
 
 // SBX_RCM_COUNT_SORT=0: levels above 4096 vertices are ordered by the generic radix sort over (parent position, low field)
 static bool rcm_count_sort() {
-  static const bool on = !(getenv("SBX_RCM_COUNT_SORT") && atoi(getenv("SBX_RCM_COUNT_SORT")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_COUNT_SORT") && atoi(sbx_env_test("SBX_RCM_COUNT_SORT")) == 0);
   return on;
 }
 
 constexpr int64_t RCM_COUNT_SORT_MAX = (int64_t)1 << 20;  // levels above this: the generic sort's staged stores win
 
 static bool rcm_ranked_keys() {  // SBX_RCM_RANKED_KEYS=0: big Cuthill-McKee levels sort their full (parent position, rank) keys
-  static const bool on = !(getenv("SBX_RCM_RANKED_KEYS") && atoi(getenv("SBX_RCM_RANKED_KEYS")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_RANKED_KEYS") && atoi(sbx_env_test("SBX_RCM_RANKED_KEYS")) == 0);
   return on;
 }
 
 static int rcm_ranked_div() {  // ... for levels of at least n_ranked / this many vertices (SBX_DEBUG_RCM_RANKED_DIV)
-  static const int v = getenv("SBX_DEBUG_RCM_RANKED_DIV") ? atoi(getenv("SBX_DEBUG_RCM_RANKED_DIV")) : 3;
+  static const int v = sbx_env_test("SBX_DEBUG_RCM_RANKED_DIV") ? atoi(sbx_env_test("SBX_DEBUG_RCM_RANKED_DIV")) : 3;
   return v > 0 ? v : 1;
 }
 
@@ -2147,7 +2119,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     }
     frontier_unmarked = false;
     const unsigned nf = hd.nf;
-    static const bool trace_levels = getenv("SBX_DEBUG_RCM_LEVELS") && atoi(getenv("SBX_DEBUG_RCM_LEVELS")) != 0;
+    static const bool trace_levels = sbx_env_tuning("SBX_DEBUG_RCM_LEVELS") && atoi(sbx_env_tuning("SBX_DEBUG_RCM_LEVELS")) != 0;
     if (trace_levels)
       fprintf(stderr, "[rcm %s] level %u: frontier %u vertices / %lld edges, unvisited edges %lld -> %u new vertices / %llu edges\n",
               CM ? "cm" : "plain", level, fsize, (long long)frontier_edges, (long long)remaining, nf,
@@ -2287,14 +2259,14 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
 // Deep, narrow graphs (a sweep of more than 64 levels) keep the ordered sweep, whose small levels run in one
 // persistent workgroup.
 static unsigned ub_max_levels() {  // SBX_DEBUG_UB_MAX_LEVELS: deeper sweeps fall back to the ordered kind (tests raise it)
-  static const unsigned v = getenv("SBX_DEBUG_UB_MAX_LEVELS") ? (unsigned)atoll(getenv("SBX_DEBUG_UB_MAX_LEVELS")) : 64u;
+  static const unsigned v = sbx_env_test("SBX_DEBUG_UB_MAX_LEVELS") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_UB_MAX_LEVELS")) : 64u;
   return v;
 }
 
 // an unordered bottom-up step stops at a vertex's first frontier neighbour, so it pays off much earlier than the ordered
 // one, which must see every neighbour: bottom-up when the frontier owns more than this many times the unvisited edges
 static double ubu_ratio() {
-  static const double r = getenv("SBX_DEBUG_UBU_RATIO") ? atof(getenv("SBX_DEBUG_UBU_RATIO")) : 0.5;
+  static const double r = sbx_env_tuning("SBX_DEBUG_UBU_RATIO") ? atof(sbx_env_tuning("SBX_DEBUG_UBU_RATIO")) : 0.5;
   return r;
 }
 
@@ -2343,12 +2315,12 @@ static int ubfs_chain() {
   // (3: a sweep of the bench matrix has three bottom-up levels in a row — behind a bottom-up level of the host's the
   // last link finds nothing to do, 5 us; behind a top-down level all three run.  With 2 the second sweep needs another
   // round trip and leaves two links idle)
-  static const int k = getenv("SBX_RCM_UBFS_CHAIN") ? atoi(getenv("SBX_RCM_UBFS_CHAIN")) : 3;
+  static const int k = sbx_env_test("SBX_RCM_UBFS_CHAIN") ? atoi(sbx_env_test("SBX_RCM_UBFS_CHAIN")) : 3;
   return k < 0 ? 0 : (k > 8 ? 8 : k);
 }
 
 static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search keeps the order inside its levels
-  static const bool on = !(getenv("SBX_RCM_UNORDERED") && atoi(getenv("SBX_RCM_UNORDERED")) == 0);
+  static const bool on = !(sbx_env_test("SBX_RCM_UNORDERED") && atoi(sbx_env_test("SBX_RCM_UNORDERED")) == 0);
   return on;
 }
 
@@ -3196,7 +3168,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                          (unsigned *)claim8, *b.claim_clean ? 0ull : (unsigned long long)((b.n + 3) / 4)};
   *b.claim_clean = false;  // (until this sweep has run to its end: every level's collection pass clears what it read)
   unsigned *dist = b.lpos;  // level positions are an ordered sweep's business: the array is free here
-  static const unsigned gb_spins = getenv("SBX_DEBUG_GB_SPINS") ? (unsigned)atoll(getenv("SBX_DEBUG_GB_SPINS")) : GB_SPINS;
+  static const unsigned gb_spins = sbx_env_test("SBX_DEBUG_GB_SPINS") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_GB_SPINS")) : GB_SPINS;
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_start, dim3(RCM_START_GRID), dim3(256), b.rp, b.vbits, b.fbits, dist, b.q, b.dv,
               fixed_root, gb_spins, sc);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
@@ -3212,7 +3184,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
   unsigned *cur_f = b.fbits, *cur_n = nbits_buf;  // frontier bitmap / the one a bottom-up level writes (swapped after it)
   bool fbits_valid = true;  // cur_f holds exactly the current frontier (the root, or what the level kernels left)
   unsigned rounds = 0;      // host round trips of this sweep
-  static const bool dbg_check = getenv("SBX_DEBUG_RCM_CHECK") && atoi(getenv("SBX_DEBUG_RCM_CHECK")) != 0;
+  static const bool dbg_check = sbx_env_test("SBX_DEBUG_RCM_CHECK") && atoi(sbx_env_test("SBX_DEBUG_RCM_CHECK")) != 0;
   std::vector<std::string> trace;
   auto note = [&](const char *what, unsigned a, unsigned b_, long long c) {
     if (!dbg_check) return;
@@ -3298,7 +3270,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
                     b.vbits, (const unsigned *)cf, cn, dist, 0u, b.q, b.n, b.dv, 1, ci);
         std::swap(cf, cn);
       }
-      static const int tail_mode = getenv("SBX_DEBUG_CHAIN_TAIL_ABORT") && atoi(getenv("SBX_DEBUG_CHAIN_TAIL_ABORT")) ? 2 : 1;
+      static const int tail_mode = sbx_env_test("SBX_DEBUG_CHAIN_TAIL_ABORT") && atoi(sbx_env_test("SBX_DEBUG_CHAIN_TAIL_ABORT")) ? 2 : 1;
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
                   (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), tail_mode);
       SBX_LAUNCH_CHECK(h);
@@ -3475,16 +3447,13 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
   I *inv = (I *)inv_perm_out;
 
   RcmDev *dv;
-  uint32_t *dkey_a, *dkey_b, *did_a, *did_b, *drank;
+  uint32_t *did_a, *drank;
   I *label, *csize, *cbase, *small_list, *mid_list, *large_list, *big_list, *q, *nf_list;
   unsigned *dist, *ppos, *vbits, *fbits, *cbits, *lpos;
   I *q_small;
   uint64_t *ka, *kb, *heavy;
   SBX_TRY(sbx_salloc(h, 1, &dv));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_a));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &dkey_b));
   SBX_TRY(sbx_salloc(h, (size_t)n, &did_a));
-  SBX_TRY(sbx_salloc(h, (size_t)n, &did_b));
   SBX_TRY(sbx_salloc(h, (size_t)n, &drank));
   SBX_TRY(sbx_salloc(h, (size_t)n, &label));
   SBX_TRY(sbx_salloc(h, (size_t)n + 1, &csize));
@@ -3549,29 +3518,11 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
       h->rs_override = slot;
     }
     int rc = SBX_OK;
-    static const bool rank_radix = getenv("SBX_RCM_RANK_RADIX") && atoi(getenv("SBX_RCM_RANK_RADIX")) != 0;
-    if (!rank_radix) {
-      // one stable counting pass on min(degree, 255) over the rows in id order + the last bucket by its full degree
-      // (sbx_degree.hip): 0.09 ms where the generic sort of (degree, id) pairs below takes 0.31
-      rc = sbx_degree_ranks(h, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
-      dorder = did_a;
-      b.dorder = dorder;
-    } else {
-      sbx_radix_pass passes[16];
-      const int np = sbx_radix_plan(0, sbx_bits_for(hd0.max_deg), 0, 0, passes);
-      int in_b = 0;
-      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_keys, dim3(DEG_UNITS / 4), dim3(256), rp, n, (const unsigned *)ucnt, dkey_a,
-                  did_a);
-      rc = hipGetLastError() == hipSuccess ? SBX_OK : SBX_ERR_HIP;
-      if (rc == SBX_OK) rc = sbx_radix_sort(h, 4, 4, dkey_a, dkey_b, did_a, did_b, n_ranked, passes, np, &in_b);
-      dorder = in_b ? did_b : did_a;
-      b.dorder = dorder;
-      if (rc == SBX_OK && n_ranked > 0) {
-        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_rank_from_order, dim3(sbx_grid_for(n_ranked, 256, 8192)), dim3(256), dorder,
-                    drank, n_ranked);
-        if (hipGetLastError() != hipSuccess) rc = SBX_ERR_HIP;
-      }
-    }
+    // one stable counting pass on min(degree, 255) over the rows in id order + the last bucket by its full degree
+    // (sbx_degree.hip): 0.09 ms where a generic sort of (degree, id) pairs took 0.31
+    rc = sbx_degree_ranks(h, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
+    dorder = did_a;
+    b.dorder = dorder;
     if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
     h->stream = main_stream;
     h->rs_override = nullptr;

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
     const I *__restrict__ rpo, const I *__restrict__ rows, int n_rows, I *col_out, char *val_out,
     PermState *__restrict__ st, int force_radix, unsigned *__restrict__ fb_rows, unsigned *__restrict__ fb_count,
     const unsigned *__restrict__ n_rows_dev, unsigned table_bytes) {
-  static_assert(sizeof(I) == 4, "32-bit indices");
+  static_assert(sizeof(I) == 4 || sizeof(I) == 8, "32- or 64-bit index arrays (a column is a 32-bit key in LDS either way: m < 2^31)");
+  constexpr int IB = (int)sizeof(I);  // bytes of a column / row-pointer word in memory
   typedef typename RqVal<VB>::type V;
   constexpr bool HASV = VB != 0;
   constexpr int W = T / 64, E = 4 * Q, CAP = 4 * T * Q, CHUNKS = Q * W;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
 #pragma unroll
       for (int i = 0; i < 4 * Q; i++)
         if (i >= lo && i < hi)
-          kb[i >> 2][i & 3] = (col_order && !(force_radix & 4)) ? (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (unsigned)cq[i >> 2][i & 3] << 2, 0, 0) : cq[i >> 2][i & 3];  // (bit 2: timing ablation without the gathers)
+          kb[i >> 2][i & 3] = (col_order && !(force_radix & 4)) ? (int)__builtin_amdgcn_raw_buffer_load_b32(tab, (unsigned)cq[i >> 2][i & 3] * (unsigned)IB, 0, 0)  /* (64-bit map: the low word) */ : cq[i >> 2][i & 3];  // (bit 2: timing ablation without the gathers)
     };
     auto gather_pt = [&](const int k) RQ_INLINE { gather_span(k * (4 * Q) / RQ_GPOINTS, (k + 1) * (4 * Q) / RQ_GPOINTS); };
     auto gather_rest = [&](const int k) RQ_INLINE { gather_span(k * (4 * Q) / RQ_GPOINTS, 4 * Q); };
@@ -163,11 +164,17 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
     auto load_cols = [&]() RQ_INLINE {
       const int lenc = __builtin_amdgcn_readfirstlane(len_c), srcc = __builtin_amdgcn_readfirstlane(src_c);
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(col_in + (int64_t)(lenc > 0 ? srcc : 0)), 0, (lenc > 0 ? lenc : 0) * 4, RQ_RSRC_FLAGS);
+          (void *)(col_in + (int64_t)(lenc > 0 ? srcc : 0)), 0, (lenc > 0 ? lenc : 0) * IB, RQ_RSRC_FLAGS);
 #pragma unroll
       for (int q = 0; q < Q; q++) {
-        const sbx_u4 x = __builtin_amdgcn_raw_buffer_load_b128(rc, (unsigned)(q * 4 * T + 4 * tid) * 4, 0, RQ_NT);
-        cq[q][0] = (int)x.x, cq[q][1] = (int)x.y, cq[q][2] = (int)x.z, cq[q][3] = (int)x.w;
+        const unsigned off = (unsigned)(q * 4 * T + 4 * tid) * (unsigned)IB;
+        const sbx_u4 x = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, RQ_NT);
+        if (IB == 4) {
+          cq[q][0] = (int)x.x, cq[q][1] = (int)x.y, cq[q][2] = (int)x.z, cq[q][3] = (int)x.w;
+        } else {  // 64-bit columns: two entries per 16 bytes, the low words are the keys
+          const sbx_u4 y = __builtin_amdgcn_raw_buffer_load_b128(rc, off + 16, 0, RQ_NT);
+          cq[q][0] = (int)x.x, cq[q][1] = (int)x.z, cq[q][2] = (int)y.x, cq[q][3] = (int)y.z;
+        }
       }
     };
 
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
     // writes the row: fill(q, c, v) supplies the four entries of quad q; the stores carry no predicate (the row's
     // descriptors drop what lies past its end)
     auto store_row = [&](auto &&fill) RQ_INLINE {
-      const __amdgpu_buffer_rsrc_t oc = __builtin_amdgcn_make_buffer_rsrc((void *)(col_out + (int64_t)e0), 0, len * 4, RQ_RSRC_FLAGS);
+      const __amdgpu_buffer_rsrc_t oc = __builtin_amdgcn_make_buffer_rsrc((void *)(col_out + (int64_t)e0), 0, len * IB, RQ_RSRC_FLAGS);
       const __amdgpu_buffer_rsrc_t ov = __builtin_amdgcn_make_buffer_rsrc((void *)(val_out + (int64_t)e0 * VB), 0, len * VB, RQ_RSRC_FLAGS);
 #pragma unroll
       for (int q = 0; q < Q; q++) {
@@ -199,8 +206,16 @@ __global__ __launch_bounds__(T, MINW) void k_rows_quad(
           fill(q, c, v);
           const unsigned off = (unsigned)(q * 4 * T + 4 * tid);
           sbx_u4 x;
-          x.x = c[0], x.y = c[1], x.z = c[2], x.w = c[3];
-          __builtin_amdgcn_raw_buffer_store_b128(x, oc, off * 4, 0, 0);
+          if (IB == 4) {
+            x.x = c[0], x.y = c[1], x.z = c[2], x.w = c[3];
+            __builtin_amdgcn_raw_buffer_store_b128(x, oc, off * 4, 0, 0);
+          } else {  // widened: (c, 0) pairs
+            sbx_u4 x2;
+            x.x = c[0], x.y = 0u, x.z = c[1], x.w = 0u;
+            x2.x = c[2], x2.y = 0u, x2.z = c[3], x2.w = 0u;
+            __builtin_amdgcn_raw_buffer_store_b128(x, oc, off * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(x2, oc, off * 8 + 16, 0, 0);
+          }
           if (VB == 4) {
             sbx_u4 y;
             y.x = (unsigned)v[0], y.y = (unsigned)v[1], y.z = (unsigned)v[2], y.w = (unsigned)v[3];
