@@ -50,7 +50,8 @@ def build(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m)
+        dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_rcm.hip")) if src.endswith("sbx_rcm64.hip") else 0  # (it includes that file)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m, dep_m)
         if stale:
             jobs.append((src, obj))
     if jobs:
@@ -68,7 +69,7 @@ def build(force=False, verbose=False):
 
 # Checking builds that travel with the product library (built by __graft_entry__.build(), loaded only by tests):
 #   fenced: sbx_rcm.hip with -DSBX_GB_FENCED — release / acquire fences at every grid barrier and election (see gb_wait)
-VARIANTS = {"fenced": ("sbx_rcm.hip", ["-DSBX_GB_FENCED"])}
+VARIANTS = {"fenced": (("sbx_rcm.hip", "sbx_rcm64.hip"), ["-DSBX_GB_FENCED"])}
 
 
 def variant_path(name):
@@ -77,20 +78,25 @@ def variant_path(name):
 
 def build_variant(name, verbose=False):
     """libsbx_<name>.so: the product's objects with one source recompiled under the variant's flags."""
-    src, extra = VARIANTS[name]
+    srcs, extra = VARIANTS[name]
     build(verbose=verbose)
-    srcpath = os.path.join(CSRC, src)
-    obj = os.path.join(OBJDIR, f"{src[:-4]}_{name}.o")
     lib = variant_path(name)
-    stale = not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(srcpath), _headers_mtime())
-    if stale:
-        cmd = [HIPCC] + FLAGS + extra + ["-c", srcpath, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src} ({name}):\n{r.stdout}\n{r.stderr}")
+    stale = False
+    vobjs = []
+    for src in srcs:
+        srcpath = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, f"{src[:-4]}_{name}.o")
+        vobjs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(srcpath), _headers_mtime(),
+                                                                  os.path.getmtime(os.path.join(CSRC, "sbx_rcm.hip"))):
+            stale = True
+            r = subprocess.run([HIPCC] + FLAGS + extra + ["-c", srcpath, "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src} ({name}):\n{r.stdout}\n{r.stderr}")
     if stale or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(LIB):
-        objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in _sources() if not s.endswith("/" + src)]
-        r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + [obj, "-ldl"],
+        objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in _sources()
+                if os.path.basename(s) not in srcs]
+        r = subprocess.run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + vobjs + ["-ldl"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed ({name}):\n{r.stdout}\n{r.stderr}")

@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void k_degree_scan(unsigned *__restrict__ cnt,
 // at their place in it
 // (RANKS: the degree ranks of the RCM — rows in ascending id order, empty rows left out: rank = position - empty rows,
 // written both ways, inv[id] = rank and order[rank] = id)
-template <typename I, bool RANKS = false>
+template <typename I, bool RANKS = false, typename O = I>
 __global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, int64_t n, int64_t n_tiles,
                                                       const unsigned *__restrict__ off, const unsigned *__restrict__ total,
-                                                      I *__restrict__ inv, uint32_t *__restrict__ tail_key,
+                                                      O *__restrict__ inv, uint32_t *__restrict__ tail_key,
                                                       uint32_t *__restrict__ tail_id, int ascending,
                                                       uint32_t *__restrict__ order) {
   __shared__ unsigned s_scan[8];
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(256) void k_degree_place(const I *__restrict__ rp, 
       const unsigned pos = s_wave[wv][d] + loc[r];
       if (RANKS) {
         if (d != 0 && d != DG_TOP) {  // (the last bucket's rows get theirs from the tail sort)
-          inv[id] = (I)(pos - n_empty);
+          inv[id] = (O)(pos - n_empty);
           order[pos - n_empty] = (uint32_t)id;
         }
       } else {
-        inv[id] = (I)(ascending ? (int64_t)pos : n - 1 - (int64_t)pos);
+        inv[id] = (O)(ascending ? (int64_t)pos : n - 1 - (int64_t)pos);
       }
       if (d == DG_TOP) {
         tail_key[pos - top_base] = deg[r];
@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void k_rank_tail_emit(const uint32_t *__restri
 }
 }  // namespace
 
-int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_nonempty, int64_t n_top, unsigned max_deg,
-                     uint32_t *rank, uint32_t *order) {
-  typedef int32_t I;
+template <typename I>
+static int degree_ranks_typed(sbx_handle_t h, const I *rp, int64_t n, int64_t n_nonempty, int64_t n_top, unsigned max_deg,
+                              uint32_t *rank, uint32_t *order) {
   if (n_nonempty <= 0) return SBX_OK;
   const int64_t n_tiles = (n + 4 * DG_WAVE_ROWS - 1) / (4 * DG_WAVE_ROWS);
   unsigned *cnt, *wmax, *total;
@@ -335,8 +335,8 @@ int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_non
   const unsigned grid = (unsigned)n_tiles;
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, (k_degree_count<I, true>), dim3(grid), dim3(256), rp, n, n_tiles, cnt, wmax);
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_degree_scan, dim3(DG_BINS), dim3(256), cnt, (const unsigned *)wmax, n_tiles, total, st);
-  SBX_KLAUNCH(h, SBX_K_RCM_MISC, (k_degree_place<I, true>), dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
-              (const unsigned *)total, (I *)rank, ta, ia, 1, order);
+  SBX_KLAUNCH(h, SBX_K_RCM_MISC, (k_degree_place<I, true, uint32_t>), dim3(grid), dim3(256), rp, n, n_tiles,
+              (const unsigned *)cnt, (const unsigned *)total, rank, ta, ia, 1, order);
   SBX_LAUNCH_CHECK(h);
   if (n_top == 0) return SBX_OK;
   const uint32_t first = (uint32_t)(n_nonempty - n_top);
@@ -353,6 +353,13 @@ int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_non
     SBX_LAUNCH_CHECK(h);
   }
   return SBX_OK;
+}
+
+// rank[id] / order[rank] of the non-empty rows by (degree, id): the degree ranks of the RCM (row_ptr of either width)
+int sbx_degree_ranks(sbx_handle_t h, sbx_index_type it, const void *rp, int64_t n, int64_t n_nonempty, int64_t n_top,
+                     unsigned max_deg, uint32_t *rank, uint32_t *order) {
+  return it == SBX_I64 ? degree_ranks_typed<int64_t>(h, (const int64_t *)rp, n, n_nonempty, n_top, max_deg, rank, order)
+                       : degree_ranks_typed<int32_t>(h, (const int32_t *)rp, n, n_nonempty, n_top, max_deg, rank, order);
 }
 
 extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, int ascending,

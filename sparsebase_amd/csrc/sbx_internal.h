@@ -260,8 +260,8 @@ int sbx_fill_i32(sbx_handle_t h, int32_t *dst, int32_t value, int64_t count);
 
 // degree ranks of the non-empty rows, (degree, id) ascending, both ways (sbx_degree.hip; for the RCM's Cuthill-McKee keys);
 // n_top = rows of 255 entries and more; enqueued on h->stream, scratch from the running call's arena, no read-back
-int sbx_degree_ranks(sbx_handle_t h, const int32_t *rp, int64_t n, int64_t n_nonempty, int64_t n_top, unsigned max_deg,
-                     uint32_t *rank, uint32_t *order);
+int sbx_degree_ranks(sbx_handle_t h, sbx_index_type it, const void *rp, int64_t n, int64_t n_nonempty, int64_t n_top,
+                     unsigned max_deg, uint32_t *rank, uint32_t *order);
 
 // ---- 64-bit index arrays (sbx_i64.hip): narrowed to the int32 kernels when every value fits
 struct sbx_narrowed {
@@ -280,8 +280,6 @@ int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *
 int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t entries,
                             int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
                             int64_t *dims_nnz_host);
-int sbx_i64_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
-                        void *inv_perm_out, sbx_rcm_stats *stats_host);
 int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
                           int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
                           int64_t *counts_host);

@@ -40,7 +40,19 @@
 
 namespace {
 
-typedef int32_t I;
+typedef int32_t I;  // vertex ids, offsets and every internal list: 32 bits (n < 2^31 - 1, nnz < 2^31 in either build)
+// element type of the CALLER's arrays — row_ptr, col, the inverse permutation: this file is compiled twice, for 32-bit
+// index arrays (sbx_rcm.hip) and, through sbx_rcm64.hip, for 64-bit ones, which are read and written as they are (no
+// narrowed copies); every value is used as a 32-bit id or offset once it is in a register
+#ifdef SBX_RCM_I64
+typedef int64_t X;
+#define SBX_RCM_IT SBX_I64
+#define SBX_RCM_ENTRY sbx_rcm_reorder_x64
+#else
+typedef int32_t X;
+#define SBX_RCM_IT SBX_I32
+#define SBX_RCM_ENTRY sbx_rcm_reorder_x32
+#endif
 constexpr int RCM_SMALL = 64;        // components up to this size: one lane each
 constexpr int RCM_MID = 2048;        // ... and up to this size too when there are RCM_MID_BATCH or more of them: a mesh
 constexpr int RCM_MID_BATCH = 64;    // collection with 10^5 components would otherwise be ordered one by one from the host
@@ -124,7 +136,7 @@ __device__ __forceinline__ int64_t deg_unit_len(int64_t n) { return ((n + DEG_UN
 
 // (The call's three n-sized fills ride along — component sizes 0, distances and parent positions UNSEEN: as
 // hipMemsetAsync calls they cost the host ~25 us of enqueueing at the head of the call, with the GPU idle.)
-__global__ __launch_bounds__(256) void k_deg_count(const I *__restrict__ rp, int64_t n, unsigned *__restrict__ ucnt,
+__global__ __launch_bounds__(256) void k_deg_count(const X *__restrict__ rp, int64_t n, unsigned *__restrict__ ucnt,
                                                    I *__restrict__ csize, unsigned *__restrict__ dist,
                                                    unsigned *__restrict__ ppos) {
   const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
@@ -188,8 +200,8 @@ __global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict_
 // id, plus the whole first component if its root v0 lies in front (format of k_classify / cbase: rcm_reorder.cc visits
 // the components in the order of their smallest vertex).  Same unit walk as k_deg_count; replaces the union-find, its
 // size scan and the classification when the first sweep already reached every non-empty row.
-__global__ __launch_bounds__(256) void k_iso_positions(const I *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
-                                                       I v0, I comp_size, I *__restrict__ inv) {
+__global__ __launch_bounds__(256) void k_iso_positions(const X *__restrict__ rp, int64_t n, const unsigned *__restrict__ ucnt,
+                                                       I v0, I comp_size, X *__restrict__ inv) {
   const int unit = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = sbx_lane();
   if (unit >= DEG_UNITS) return;
   unsigned base = 0;  // non-empty rows in front of the unit
@@ -239,7 +251,7 @@ __device__ __forceinline__ void cc_hook(I *parent, I a, I b) {
   } while (again);
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_cc_init(const X *__restrict__ rp, const X *__restrict__ col,
                                                  I *__restrict__ parent, int64_t n,
                                                  const unsigned *__restrict__ cbits) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(256) void k_cc_init(const I *__restrict__ rp, const
 }
 
 // low-degree vertices: one lane per vertex; others queued for the wave kernel
-__global__ __launch_bounds__(256) void k_cc_hook_small(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_cc_hook_small(const X *__restrict__ rp, const X *__restrict__ col,
                                                        I *parent, int64_t n, I *__restrict__ big_list,
                                                        const unsigned *__restrict__ cbits, RcmDev *__restrict__ dv) {
   const int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(256) void k_cc_hook_small(const I *__restrict__ rp,
   }
 }
 
-__global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, const I *__restrict__ col, I *parent,
+__global__ __launch_bounds__(256) void k_cc_hook_big(const X *__restrict__ rp, const X *__restrict__ col, I *parent,
                                                      const I *__restrict__ big_list,
                                                      const RcmDev *__restrict__ dv) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void k_cc_hook_big(const I *__restrict__ rp, c
 // label[v] = root; component sizes.  Equal roots are combined inside the wave, and the
 // workgroup's dominant root (the giant component) is accumulated in LDS and flushed
 // once, so the giant's counter word is not hammered by one atomic per wave.
-__global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I *parent, I *__restrict__ csize,
+__global__ __launch_bounds__(256) void k_cc_finalize(const X *__restrict__ rp, I *parent, I *__restrict__ csize,
                                                      int64_t n, const unsigned *__restrict__ cbits, I first_root,
                                                      I first_size, int phase, RcmDev *__restrict__ dv) {
   __shared__ I s_major;
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void k_cc_finalize(const I *__restrict__ rp, I
 
 // classify components: singletons are final here; small / large roots are listed
 __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, const I *__restrict__ csize,
-                                                  const I *__restrict__ cbase, I *__restrict__ inv,
+                                                  const I *__restrict__ cbase, X *__restrict__ inv,
                                                   I *__restrict__ small_list, I *__restrict__ mid_list,
                                                   I *__restrict__ large_list, int64_t n, RcmDev *__restrict__ dv) {
   __shared__ unsigned s_roots[4];
@@ -394,13 +406,13 @@ __global__ __launch_bounds__(256) void k_classify(const I *__restrict__ label, c
 // One lane runs the reference's serial algorithm for one component.  q = the
 // component's own slice of the order array, dist = BFS distances (UNSEEN = unvisited).
 // (degree, id) order of the children a parent discovered (rcm_reorder.cc:125-144 drains a min-heap of such pairs)
-__device__ __forceinline__ bool rcm_child_less(const I *__restrict__ rp, I a, I b) {
+__device__ __forceinline__ bool rcm_child_less(const X *__restrict__ rp, I a, I b) {
   const I da = rp[a + 1] - rp[a], db = rp[b + 1] - rp[b];
   return da < db || (da == db && a < b);
 }
 // in-place heapsort of a parent's children: hubs of mid-size components (a star of 2000 leaves) would cost an
 // insertion sort millions of moves in one lane
-__device__ void rcm_sort_children(const I *__restrict__ rp, I *a, int cnt) {
+__device__ void rcm_sort_children(const X *__restrict__ rp, I *a, int cnt) {
   auto sift = [&](int root, int end) {
     while (2 * root + 1 < end) {
       int child = 2 * root + 1;
@@ -422,9 +434,9 @@ __device__ void rcm_sort_children(const I *__restrict__ rp, I *a, int cnt) {
 }
 
 // One component (its root `start`), one lane.
-__device__ void rcm_small_component(const I *__restrict__ rp, const I *__restrict__ col, const I start,
+__device__ void rcm_small_component(const X *__restrict__ rp, const X *__restrict__ col, const I start,
                                     const I *__restrict__ csize, const I *__restrict__ cbase, unsigned *dist, I *order,
-                                    I *__restrict__ inv, RcmDev *__restrict__ dv) {
+                                    X *__restrict__ inv, RcmDev *__restrict__ dv) {
   const I base = cbase[start], sz = csize[start];
   I *q = order + base;
   // --- pseudo-peripheral search (rcm_reorder.cc:22-81)
@@ -506,10 +518,10 @@ __device__ void rcm_small_component(const I *__restrict__ rp, const I *__restric
 
 // count_dev: the number of listed components, still on the device (the launch then covers an upper bound: a lane takes
 // every (lanes of the grid)-th component)
-__global__ __launch_bounds__(64) void k_rcm_small(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(64) void k_rcm_small(const X *__restrict__ rp, const X *__restrict__ col,
                                                   const I *__restrict__ list, unsigned count,
                                                   const I *__restrict__ csize, const I *__restrict__ cbase,
-                                                  unsigned *dist, I *order, I *__restrict__ inv,
+                                                  unsigned *dist, I *order, X *__restrict__ inv,
                                                   RcmDev *__restrict__ dv, const unsigned *__restrict__ count_dev) {
   if (count_dev) count = *count_dev;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -556,7 +568,7 @@ __device__ __forceinline__ bool start_clear_elect(const StartClear &sc, RcmDev *
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_bfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits,
+__global__ __launch_bounds__(256) void k_bfs_start(const X *__restrict__ rp, unsigned *__restrict__ vbits,
                                                    unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
                                                    unsigned *__restrict__ ppos, I *__restrict__ q,
                                                    RcmDev *__restrict__ dv, I fixed_root, StartClear sc) {
@@ -671,7 +683,7 @@ __device__ __forceinline__ void stage_end_block(WaveStage &st, I *__restrict__ n
 }
 
 // appends v (for lanes with `won`) to the staged frontier; all lanes of the wave call it
-__device__ __forceinline__ void stage_push(I v, bool won, const I *__restrict__ rp, WaveStage &st,
+__device__ __forceinline__ void stage_push(I v, bool won, const X *__restrict__ rp, WaveStage &st,
                                            I *__restrict__ nf_list, RcmDev *__restrict__ dv) {
   const uint64_t winners = __ballot(won);
   if (winners) {
@@ -698,7 +710,7 @@ struct UnorderedSweep {  // state of a sweep that only needs the level SETS (see
 // claims its bit in us.nbits).  MODE 2: cone marking of the tie-break (run_ubfs / ubfs_pick_root): the "frontier" is
 // the marked vertices of level us.level + 1, visited are the REACHED vertices of level us.level not marked yet.
 template <int MODE>
-__device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, unsigned p, const I *__restrict__ rp,
+__device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, unsigned p, const X *__restrict__ rp,
                                            const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
                                            I *__restrict__ nf_list, RcmDev *__restrict__ dv, const UnorderedSweep &us) {
   unsigned seen = 0;  // bit k: v[k] is in the sweep's visited bitmap
@@ -756,7 +768,7 @@ __device__ __forceinline__ void bfs_visit4(const I (&v)[4], unsigned actmask, un
   for (int k = 0; k < 4; k++) stage_push(v[k], (won >> k) & 1u, rp, st, nf_list, dv);
 }
 
-__device__ __forceinline__ void bfs_visit(I v, unsigned p, const I *__restrict__ rp,
+__device__ __forceinline__ void bfs_visit(I v, unsigned p, const X *__restrict__ rp,
                                           const unsigned *__restrict__ vbits, unsigned *ppos, WaveStage &st,
                                           I *__restrict__ nf_list, RcmDev *__restrict__ dv, bool active) {
   bool won = false;
@@ -781,7 +793,7 @@ constexpr int RCM_HUB_STAGE = 256;  // hubs a workgroup stages before it reserve
 constexpr int RCM_DIR_MAX = 2048;    // workgroups of k_bfs_expand the hub kernel can follow through the directory
 
 template <int U>
-__global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_bfs_expand(const X *__restrict__ rp, const X *__restrict__ col,
                                                     const I *__restrict__ frontier, unsigned fsize,
                                                     unsigned next_level, const unsigned *__restrict__ vbits,
                                                     unsigned *ppos, I *__restrict__ nf_list, uint64_t *__restrict__ heavy,
@@ -886,7 +898,7 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const I *__restrict__ rp, co
 #define RCM_HEAVY_MINW 1
 #endif
 template <int U>
-__global__ __launch_bounds__(256, RCM_HEAVY_MINW) void k_bfs_expand_heavy(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256, RCM_HEAVY_MINW) void k_bfs_expand_heavy(const X *__restrict__ rp, const X *__restrict__ col,
                                                           const I *__restrict__ frontier, unsigned next_level,
                                                           const unsigned *__restrict__ vbits, unsigned *ppos,
                                                           I *__restrict__ nf_list,
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(256, RCM_HEAVY_MINW) void k_bfs_expand_heavy(const 
 // on vertex state, no hot words; chosen by the host when the frontier owns more edges
 // than the unvisited remainder.
 // (eight waves per SIMD: the chunk reservation below, which hardly ever runs, would otherwise cost the scans 30 registers)
-__global__ __launch_bounds__(256, 8) void k_bfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256, 8) void k_bfs_bottom_up(const X *__restrict__ rp, const X *__restrict__ col,
                                                        const I *__restrict__ label, I comp_label,
                                                        const unsigned *__restrict__ vbits,
                                                        const unsigned *__restrict__ fbits,
@@ -1081,7 +1093,7 @@ __global__ __launch_bounds__(256, 8) void k_bfs_bottom_up(const I *__restrict__ 
 // The queued row chunks of a bottom-up level: a wave scans the RCM_BU_CHUNK entries of one (four loads per lane in
 // flight), the chunks of a row meet in an atomicMin on the candidate's parent position, and the chunk that finds it
 // UNSEEN appends the vertex to the level.
-__global__ __launch_bounds__(256) void k_bfs_bottom_up_heavy(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_bfs_bottom_up_heavy(const X *__restrict__ rp, const X *__restrict__ col,
                                                              const unsigned *__restrict__ fbits,
                                                              const unsigned *__restrict__ lpos, unsigned *ppos,
                                                              I *__restrict__ nf_list, RcmDev *dv,
@@ -1548,7 +1560,7 @@ constexpr int SL_CH = 8;                // adjacency entries a thread loads toge
 static_assert(SL_MAXE <= 32 * 1024, "the plain sweep keeps one winner bit per entry of a thread's run");
 
 template <bool CM>
-__global__ __launch_bounds__(1024) void k_bfs_small_levels(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(1024) void k_bfs_small_levels(const X *__restrict__ rp, const X *__restrict__ col,
                                                            I *q, unsigned *vbits, unsigned *fbits, unsigned *lpos,
                                                            unsigned *ppos, I *nf_list,
                                                            const uint32_t *__restrict__ drank,
@@ -1902,7 +1914,7 @@ __global__ __launch_bounds__(256) void k_mark_frontier(const I *__restrict__ fro
 }
 
 // deepest level: vertex of strictly smallest degree, first in queue order (:64-75)
-__global__ __launch_bounds__(256) void k_pick_root(const I *__restrict__ rp, const I *__restrict__ level,
+__global__ __launch_bounds__(256) void k_pick_root(const X *__restrict__ rp, const I *__restrict__ level,
                                                    unsigned lsize, RcmDev *__restrict__ dv) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1937,7 +1949,7 @@ __global__ __launch_bounds__(256) void k_comp_info(const I *__restrict__ roots, 
 }
 
 __global__ __launch_bounds__(256) void k_write_component(const I *__restrict__ q, unsigned cnt, I base,
-                                                         I *__restrict__ inv, const I *__restrict__ base_dev) {
+                                                         X *__restrict__ inv, const I *__restrict__ base_dev) {
   if (base_dev) base = *base_dev;  // (the component's place, still on the device: the size scan's entry of its root)
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1964,7 +1976,7 @@ static int rcm_ranked_div() {  // ... for levels of at least n_ranked / this man
 
 struct BfsBuffers {
   bool *claim_clean;  // the claim bytes of the unordered sweeps are all zero (a finished sweep leaves them that way)
-  const I *rp, *col;
+  const X *rp, *col;
   unsigned *vbits, *fbits, *lpos, *ppos;
   const I *label;
   int64_t nnz;
@@ -2324,7 +2336,7 @@ static bool rcm_unordered() {  // SBX_RCM_UNORDERED=0: every sweep of the search
   return on;
 }
 
-__global__ __launch_bounds__(256) void k_ubfs_start(const I *__restrict__ rp, unsigned *__restrict__ vbits,
+__global__ __launch_bounds__(256) void k_ubfs_start(const X *__restrict__ rp, unsigned *__restrict__ vbits,
                                                     unsigned *__restrict__ fbits, unsigned *__restrict__ dist,
                                                     I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
                                                     unsigned gb_spins, StartClear sc) {
@@ -2360,7 +2372,7 @@ __global__ __launch_bounds__(256) void k_ubfs_collect(unsigned char *__restrict_
                                                       unsigned long long *__restrict__ vbits64,
                                                       unsigned long long *__restrict__ fbits64,
                                                       unsigned *__restrict__ dist, unsigned level,
-                                                      const I *__restrict__ rp, I *__restrict__ q_next, int64_t n,
+                                                      const X *__restrict__ rp, I *__restrict__ q_next, int64_t n,
                                                       RcmDev *__restrict__ dv) {
   constexpr int WPW = RCM_FW_WORDS / 4;
   __shared__ unsigned s_wtot[4], s_base;
@@ -2425,7 +2437,7 @@ __global__ __launch_bounds__(256) void k_ubfs_collect(unsigned char *__restrict_
 // four entries, where a 16-lane group fetches 64 at a time (16 -> 1024: 33 M -> 12 M entries scanned bottom-up on the
 // bench matrix, the kernel 0.64 -> 0.36 ms per RCM; beyond 1024 nothing changes)
 constexpr int UB_INLINE = 1024;
-__global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_ubfs_bottom_up(const X *__restrict__ rp, const X *__restrict__ col,
                                                         const I *__restrict__ label, I comp_label,
                                                         unsigned *vbits, const unsigned *__restrict__ fbits,
                                                         unsigned *__restrict__ nbits, unsigned *__restrict__ dist,
@@ -2560,7 +2572,7 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const I *__restrict__ rp
 // is dv->nf), their number and smallest id.  A level of up to UB_TIES_SMALL vertices (the usual case: a handful) is one
 // workgroup's job; larger ones take three launches.
 constexpr unsigned UB_TIES_SMALL = 8192;
-__global__ __launch_bounds__(1024) void k_ubfs_ties_small(const I *__restrict__ rp, const I *__restrict__ level,
+__global__ __launch_bounds__(1024) void k_ubfs_ties_small(const X *__restrict__ rp, const I *__restrict__ level,
                                                           unsigned count, unsigned *__restrict__ cone,
                                                           I *__restrict__ list, RcmDev *__restrict__ dv) {
   __shared__ unsigned s_red[16], s_cnt;
@@ -2617,7 +2629,7 @@ __global__ void k_ubfs_ties_init(RcmDev *__restrict__ dv) {
   dv->n_heavy = 0;
   dv->hub_overflow = 0;
 }
-__global__ __launch_bounds__(256) void k_ubfs_min_degree(const I *__restrict__ rp, const I *__restrict__ level,
+__global__ __launch_bounds__(256) void k_ubfs_min_degree(const X *__restrict__ rp, const I *__restrict__ level,
                                                          unsigned count, RcmDev *__restrict__ dv) {
   unsigned best = 0xFFFFFFFFu;
   for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
@@ -2628,7 +2640,7 @@ __global__ __launch_bounds__(256) void k_ubfs_min_degree(const I *__restrict__ r
   best = sbx_wave_min(best);
   if (sbx_lane() == 0 && best != 0xFFFFFFFFu) atomicMin(&dv->tie_deg, best);
 }
-__global__ __launch_bounds__(256) void k_ubfs_mark_ties(const I *__restrict__ rp, const I *__restrict__ level,
+__global__ __launch_bounds__(256) void k_ubfs_mark_ties(const X *__restrict__ rp, const I *__restrict__ level,
                                                         unsigned count, unsigned *__restrict__ cone,
                                                         I *__restrict__ list, RcmDev *__restrict__ dv) {
   const unsigned dmin = dv->tie_deg;
@@ -2725,7 +2737,7 @@ __device__ __forceinline__ bool gb_wait(RcmDev *dv, unsigned *word, unsigned tar
 // everything the workgroups exchange between two barriers moves through agent-scope atomics anyway.)
 // Words under the barrier invariant (gb_wait) in k_ubfs_descend_all: dv->desc[0..2] (agent-scope stores, atomicMin, agent-
 // scope loads), dv->bar, dv->gb_abort.  cone / vbits / dist were written by the kernels in front (a kernel boundary).
-__global__ __launch_bounds__(256) void k_ubfs_descend_all(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_ubfs_descend_all(const X *__restrict__ rp, const X *__restrict__ col,
                                                           const unsigned *__restrict__ vbits,
                                                           const unsigned *__restrict__ dist,
                                                           const unsigned *__restrict__ cone, unsigned levels,
@@ -2823,7 +2835,7 @@ __device__ __forceinline__ bool ur_barrier(RcmDev *dv, unsigned &epoch) {
 // (atomicAdd, ur_store, ur_load), dv->ur_bar, dv->ur_exit, dv->gb_abort.  dist[] is written with plain stores: no
 // workgroup of THIS kernel reads it.  The hand-over state (dv->ur_off ...) is thread 0's alone and read behind the
 // kernel's end.
-__global__ __launch_bounds__(256) void k_ubfs_small_run(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_ubfs_small_run(const X *__restrict__ rp, const X *__restrict__ col,
                                                         unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
                                                         unsigned off, unsigned size, unsigned level, unsigned total,
                                                         long long fe_in, unsigned max_levels, int from_dev) {
@@ -3007,7 +3019,7 @@ __global__ __launch_bounds__(256) void k_ubfs_fbits_from_dist(const unsigned *__
 // cone_end (ur_load: written by the one-thread kernel in front), dv->ur_bar, dv->ur_exit, dv->gb_abort.  vbits[] and
 // dist[] are the finished sweep's (a kernel boundary): plain loads.
 constexpr unsigned CONE_SMALL = 256;  // (a wave takes a member: 256 waves; 1024 measured 0.3 ms slower per RCM)
-__global__ __launch_bounds__(256) void k_ubfs_cone_run(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_ubfs_cone_run(const X *__restrict__ rp, const X *__restrict__ col,
                                                        const unsigned *__restrict__ vbits,
                                                        const unsigned *__restrict__ dist, unsigned *cone, I *list, I *hq,
                                                        RcmDev *dv, unsigned k_start) {
@@ -3136,7 +3148,7 @@ __global__ void k_ubfs_chain_next(RcmDev *dv, ChainInit ci) {
 
 // SBX_DEBUG_RCM_CHECK=1: after an unordered sweep, every edge that leaves its visited set (there must be none) is counted
 // and the first few are recorded: (visited end, unvisited end, the visited end's level).
-__global__ __launch_bounds__(256) void k_check_closed(const I *__restrict__ rp, const I *__restrict__ col,
+__global__ __launch_bounds__(256) void k_check_closed(const X *__restrict__ rp, const X *__restrict__ col,
                                                       const unsigned *__restrict__ vbits, const unsigned *__restrict__ dist,
                                                       int64_t n, unsigned *__restrict__ out) {
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3432,19 +3444,31 @@ static int reset_ppos(sbx_handle_t h, const I *q, unsigned count, unsigned *ppos
 
 }  // namespace
 
+int sbx_rcm_reorder_x32(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col_v,
+                        void *inv_perm_out, sbx_rcm_stats *stats_host);
+int sbx_rcm_reorder_x64(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col_v,
+                        void *inv_perm_out, sbx_rcm_stats *stats_host);
+#ifndef SBX_RCM_I64
 extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
                                const void *col_v, void *inv_perm_out, sbx_rcm_stats *stats_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   if (n < 0 || nnz < 0 || !row_ptr || (n > 0 && !inv_perm_out) || (nnz > 0 && !col_v))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: bad argument");
-  if (it == SBX_I64) return sbx_i64_rcm_reorder(h, n, nnz, row_ptr, col_v, inv_perm_out, stats_host);
+  // (ids, offsets and queue positions are 32-bit inside, whatever the width of the arrays)
   if (n >= ((int64_t)1 << 31) - 1 || nnz >= ((int64_t)1 << 31))
-    SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: dimension exceeds int32");
+    SBX_FAIL(h, it == SBX_I64 ? SBX_ERR_UNSUPPORTED : SBX_ERR_BAD_ARG, "sbx_rcm_reorder: dimension exceeds int32");
+  return it == SBX_I64 ? sbx_rcm_reorder_x64(h, n, nnz, row_ptr, col_v, inv_perm_out, stats_host)
+                       : sbx_rcm_reorder_x32(h, n, nnz, row_ptr, col_v, inv_perm_out, stats_host);
+}
+#endif
+
+int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col_v, void *inv_perm_out,
+                  sbx_rcm_stats *stats_host) {
   if (stats_host) memset(stats_host, 0, sizeof(*stats_host));
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
-  const I *rp = (const I *)row_ptr, *col = (const I *)col_v;
-  I *inv = (I *)inv_perm_out;
+  const X *rp = (const X *)row_ptr, *col = (const X *)col_v;
+  X *inv = (X *)inv_perm_out;
 
   RcmDev *dv;
   uint32_t *did_a, *drank;
@@ -3520,7 +3544,7 @@ extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int
     int rc = SBX_OK;
     // one stable counting pass on min(degree, 255) over the rows in id order + the last bucket by its full degree
     // (sbx_degree.hip): 0.09 ms where a generic sort of (degree, id) pairs took 0.31
-    rc = sbx_degree_ranks(h, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
+    rc = sbx_degree_ranks(h, SBX_RCM_IT, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
     dorder = did_a;
     b.dorder = dorder;
     if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;

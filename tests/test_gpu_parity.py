@@ -1080,6 +1080,32 @@ def test_int64_tuple_all_ops(ops, oracle):
     assert np.array_equal(host(srp), want[0][n // 4:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
 
 
+def test_rcm_int64_arrays_native(ops, oracle):
+    """RCM on 64-bit index arrays: the kernels of sbx_rcm.hip compiled for int64 row_ptr / col / inv_perm (sbx_rcm64.hip) read
+    and write the arrays as they are — no narrowed copies — over graph families that take every branch of the search
+    (hubs, many small and mid-size components, deep meshes, paths, isolated vertices); a dimension beyond what the 32-bit
+    ids inside can hold is refused, not truncated."""
+    from sparsebase_amd import capi
+    cases = [synth.rmat_symmetric(14, 8, seed=3), synth.rmat_symmetric(16, 16, seed=1),
+             synth.random_symmetric_graph(40000, avg_deg=4, seed=2, n_blocks=3, isolated_frac=0.1),
+             synth.random_symmetric_graph(30000, avg_deg=1.2, seed=9, isolated_frac=0.3),
+             synth.grid_graph(150, 120, shuffle_seed=4), synth.path_graph(5000, shuffle_seed=1), synth.star_graph(3000),
+             synth.clique_graph(70)]
+    for rp, col in cases:
+        rp64, col64 = rp.astype(np.int64), col.astype(np.int64)
+        want = oracle.rcm_reorder(rp, col)
+        got = ops.rcm_reorder(dev(rp64), dev(col64))
+        assert got.dtype == torch.int64
+        assert np.array_equal(host(got), want.astype(np.int64))
+    rp, col = cases[0]
+    with pytest.raises(capi.SbxError) as e:  # nnz beyond 2^31 is announced through the argument: refused up front
+        hd = ops.handle_for(torch.device("cuda"))
+        out = torch.empty(len(rp) - 1, dtype=torch.int64, device="cuda")
+        hd.check(hd.lib.sbx_rcm_reorder(hd.h, 1, len(rp) - 1, 1 << 31, dev(rp.astype(np.int64)).data_ptr(),
+                                        dev(col.astype(np.int64)).data_ptr(), out.data_ptr(), None))
+    assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
+
+
 def test_int64_values_beyond_int32(ops, oracle):
     """64-bit indices with values >= 2^31.  The conversions COO <-> CSR and the two sortedness checks run native 64-bit
     kernels: column ids of any size are accepted and the results are the oracle's, bit for bit; so do both constructor
