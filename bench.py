@@ -405,6 +405,18 @@ def gray_fractions(ops, n, nnz, rp, col, steps):
     alg = 4 * nnz + 16 * n
     out = {"params": [res_, thr, grp],
            "key_stage": {"ms": t_keys * 1e3, "alg_bytes": alg, "frac_of_hbm_peak": alg / t_keys / 1e9 / HBM_PEAK_GBS}}
+    try:  # the opt-in ordering on the device (sbx_gray_reorder, stable ties): key stage + three radix sorts of (key, row) pairs
+        ops.gray_reorder(n, rp, col, res_, thr, grp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ops.gray_reorder(n, rp, col, res_, thr, grp)
+        torch.cuda.synchronize()
+        out["device_ordering_stable_ties"] = {"ms": (time.perf_counter() - t0) / steps * 1e3,
+                                              "note": "opt-in: equals the exact mode wherever the reference's comparators "
+                                                      "decide a row's place; the default (exact) mode is end_to_end"}
+    except Exception as e:  # noqa: BLE001 — an extra
+        out["device_ordering_stable_ties"] = {"error": repr(e)[:200]}
     return out
 
 

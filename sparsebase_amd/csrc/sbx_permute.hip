@@ -121,47 +121,99 @@ __global__ __launch_bounds__(256) void k_permute_array(const I *__restrict__ ord
 // does not matter).
 constexpr int RC_STAGE = 512;  // staged rows per class and workgroup before an early flush
 
-// ---- classification + both prefix sums in ONE launch -------------------------------------------------------
+// ---- classification + both prefix sums ----------------------------------------------------------------------
 // rpo = exclusive scan of the new rows' lengths, sp = the same over the lengths of the rows the tile kernel sorts
-// (<= PT_LMAX), and the lists of longer rows by class — what used to be k_rec_classify + two three-launch scans +
-// k_store_total, i.e. eight launches ahead of every permute.  Single pass with decoupled look-back: workgroups take
-// a ticket, publish (aggregate, flag) granules per tile and sum the predecessors' (64-bit value | flag words written
-// and read with relaxed agent-scope atomics: self-contained, no fence).  `status` holds one word per tile + the ticket
-// word at index `tiles`, all zero on entry.
+// (<= PT_LMAX), and the lists of longer rows by class.  Three launches: the tiles' sums (k_classify_reduce), their
+// exclusive prefix by one workgroup (k_classify_prefix), and the pass that scans, writes and lists (k_classify_scan).
+// (Rounds 2 - 4 did it in ONE launch with a decoupled look-back over the tiles: 55 us for 4.2 M rows — its 1024 tiles wait
+// for each other in a chain — where the three plain launches take ~32: two reads of the records instead of one, no chain.)
 #ifndef SBX_CS_ITEMS
 #define SBX_CS_ITEMS 16
 #endif
 constexpr int CS_ITEMS = SBX_CS_ITEMS;
 constexpr int CS_TILE = 256 * CS_ITEMS;
-template <typename I>
-__global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ rec, I *__restrict__ rpo,
-                                                       I *__restrict__ sp, int64_t nr, I *__restrict__ long_rows,
-                                                       I *__restrict__ block_rows, int64_t block_stride, int block_cap,
-                                                       PermState *__restrict__ st, unsigned long long *status,
-                                                       int64_t tiles, int rpo_aligned) {
-  constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
-  __shared__ unsigned s_cnt[NC], s_base[NC];
-  __shared__ unsigned long long s_long_nnz, s_block_nnz;
-  __shared__ I s_rows[NC][RC_STAGE];
-  __shared__ unsigned long long s_red[2][4];
-  __shared__ unsigned long long s_before[2];
-  __shared__ unsigned s_tile;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd((unsigned *)(status + tiles), 1u);
-  if (tid < NC) s_cnt[tid] = 0;
-  if (tid == 0) s_long_nnz = s_block_nnz = 0;
-  __syncthreads();
-  const int64_t tile = s_tile;
-  const int64_t base = tile * CS_TILE + (int64_t)tid * CS_ITEMS;  // this thread's first row
-  int d[CS_ITEMS];
+// a thread's CS_ITEMS row lengths: two (length, source) records per 16-byte load
+__device__ __forceinline__ void cs_load_lengths(const int2 *__restrict__ rec, int64_t base, int64_t nr, int (&d)[CS_ITEMS]) {
 #pragma unroll
-  for (int k = 0; k < CS_ITEMS; k += 2) {  // two (length, source) records per 16-byte load
+  for (int k = 0; k < CS_ITEMS; k += 2) {
     int4 q = make_int4(0, 0, 0, 0);
     if (base + k + 1 < nr) q = *(const int4 *)(rec + base + k);
     else if (base + k < nr) q.x = rec[base + k].x;
     d[k] = q.x;
     d[k + 1] = q.z;
   }
+}
+
+// tile_sum[2 t] / [2 t + 1] = sum of all / of the short rows' lengths of tile t
+__global__ __launch_bounds__(256) void k_classify_reduce(const int2 *__restrict__ rec, int64_t nr,
+                                                         unsigned long long *__restrict__ tile_sum) {
+  __shared__ unsigned long long s_red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int d[CS_ITEMS];
+  cs_load_lengths(rec, (int64_t)blockIdx.x * CS_TILE + (int64_t)tid * CS_ITEMS, nr, d);
+  unsigned long long a = 0, sh = 0;
+#pragma unroll
+  for (int k = 0; k < CS_ITEMS; k++) {
+    a += (unsigned)d[k];
+    sh += d[k] <= PT_LMAX ? (unsigned)d[k] : 0u;
+  }
+  a = sbx_wave_sum(a), sh = sbx_wave_sum(sh);
+  if (lane == 0) s_red[0][wv] = a, s_red[1][wv] = sh;
+  __syncthreads();
+  if (tid == 0) {
+    tile_sum[2 * (size_t)blockIdx.x] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    tile_sum[2 * (size_t)blockIdx.x + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  }
+}
+
+// in place: tile_sum -> the exclusive prefixes of both sums; the grand totals close rpo / sp and go to st->total
+template <typename I>
+__global__ __launch_bounds__(1024) void k_classify_prefix(unsigned long long *__restrict__ tile_sum, int64_t tiles,
+                                                          I *__restrict__ rpo, I *__restrict__ sp, int64_t nr,
+                                                          PermState *__restrict__ st) {
+  __shared__ unsigned long long s_w[2][16];
+  __shared__ unsigned long long s_carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 2) s_carry[tid] = 0;
+  __syncthreads();
+  for (int64_t t0 = 0; t0 < tiles; t0 += 1024) {
+    const int64_t t = t0 + tid;
+    const unsigned long long a = t < tiles ? tile_sum[2 * t] : 0ull, sh = t < tiles ? tile_sum[2 * t + 1] : 0ull;
+    const unsigned long long ia = sbx_wave_inclusive_sum(a), is = sbx_wave_inclusive_sum(sh);
+    if (lane == 63) s_w[0][wv] = ia, s_w[1][wv] = is;
+    __syncthreads();
+    unsigned long long ba = s_carry[0], bs = s_carry[1], ta = 0, ts = 0;
+    for (int i = 0; i < 16; i++) {
+      if (i < wv) ba += s_w[0][i], bs += s_w[1][i];
+      ta += s_w[0][i], ts += s_w[1][i];
+    }
+    if (t < tiles) tile_sum[2 * t] = ba + ia - a, tile_sum[2 * t + 1] = bs + is - sh;
+    __syncthreads();
+    if (tid == 0) s_carry[0] += ta, s_carry[1] += ts;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (rpo) rpo[nr] = (I)s_carry[0];
+    sp[nr] = (I)s_carry[1];
+    st->total = s_carry[0];
+  }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ rec, I *__restrict__ rpo,
+                                                       I *__restrict__ sp, int64_t nr, I *__restrict__ long_rows,
+                                                       I *__restrict__ block_rows, int64_t block_stride, int block_cap,
+                                                       PermState *__restrict__ st,
+                                                       const unsigned long long *__restrict__ tile_prefix, int rpo_aligned,
+                                                       I *__restrict__ tile_first) {
+  constexpr int NC = BR_CLASSES + 1;  // class BR_CLASSES = rows for the global radix path
+  __shared__ unsigned s_base[NC];
+  __shared__ unsigned long long s_red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t base = tile * CS_TILE + (int64_t)tid * CS_ITEMS;  // this thread's first row
+  int d[CS_ITEMS];
+  cs_load_lengths(rec, base, nr, d);
   unsigned long long sum_all = 0, sum_short = 0;
   unsigned long long loc_all[CS_ITEMS], loc_short[CS_ITEMS];
 #pragma unroll
@@ -178,55 +230,12 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
     s_red[1][wv] = inc_s;
   }
   __syncthreads();
-  unsigned long long off_a = inc_a - sum_all, off_s = inc_s - sum_short, tot_a = 0, tot_s = 0;
+  unsigned long long off_a = inc_a - sum_all, off_s = inc_s - sum_short;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 4; i++)
     if (i < wv) off_a += s_red[0][i], off_s += s_red[1][i];
-    tot_a += s_red[0][i], tot_s += s_red[1][i];
-  }
-  // decoupled look-back by the first wave, 64 predecessors per step.  One status word per tile:
-  // (sum of lengths << 33) | (sum of short lengths << 2) | flag — both sums stay below 2^31 (32-bit indices) —
-  // flag 1 = the tile's own aggregate, 2 = inclusive prefix.
-  if (wv == 0) {
-    unsigned long long before_a = 0, before_s = 0;
-    if (tile > 0) {
-      if (lane == 0)
-        __hip_atomic_store(status + tile, (tot_a << 33) | (tot_s << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t t0 = tile - 1;
-      while (true) {
-        const int64_t t = t0 - lane;
-        const unsigned long long w =
-            t >= 0 ? __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;  // before tile 0: empty prefix
-        const unsigned flag = (unsigned)(w & 3ull);
-        const uint64_t inc = __ballot(flag == 2u), missing = __ballot(flag == 0u);
-        const int first_inc = inc ? __builtin_ctzll(inc) : 64;  // nearest predecessor that knows its inclusive prefix
-        const uint64_t needed = first_inc < 63 ? (((uint64_t)1 << (first_inc + 1)) - 1) : ~(uint64_t)0;
-        if (missing & needed) {  // someone in between has not published yet: look again
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        const bool take = lane <= first_inc;
-        before_a += sbx_wave_sum(take ? (w >> 33) : 0ull);
-        before_s += sbx_wave_sum(take ? ((w >> 2) & 0x7FFFFFFFull) : 0ull);
-        if (first_inc < 64) break;
-        t0 -= 64;
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(status + tile, ((before_a + tot_a) << 33) | ((before_s + tot_s) << 2) | 2ull, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      s_before[0] = before_a;
-      s_before[1] = before_s;
-      if (tile == tiles - 1) {  // the grand totals close both arrays
-        if (rpo) rpo[nr] = (I)(before_a + tot_a);
-        sp[nr] = (I)(before_s + tot_s);
-        st->total = before_a + tot_a;
-      }
-    }
-  }
-  __syncthreads();
-  off_a += s_before[0];
-  off_s += s_before[1];
+  off_a += tile_prefix[2 * tile];
+  off_s += tile_prefix[2 * tile + 1];
   if (base < nr) {
     I oa[CS_ITEMS], os[CS_ITEMS];
 #pragma unroll
@@ -254,50 +263,94 @@ __global__ __launch_bounds__(256) void k_classify_scan(const int2 *__restrict__ 
       }
     }
   }
-  // the lists of rows too long for the tile kernel, staged per workgroup (one reservation per class and flush)
+  // tile_first[t] = first row whose range in the short rows' entry space starts at or behind t * PT_W (what the tile
+  // kernel's tiles are cut by; k_tile_first finds the same by binary search): the row in front of it is the short row
+  // that reaches or crosses that position — at most one t per row, a row being shorter than a window.  The entries
+  // behind the last tile keep the caller's fill (nr).
+  if (tile_first) {
+    if (base == 0 && tid == 0) tile_first[0] = 0;
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; k++) {
+      const unsigned len = (base + k < nr && d[k] > 0 && d[k] <= PT_LMAX) ? (unsigned)d[k] : 0u;
+      if (len) {
+        const unsigned long long s0 = off_s + loc_short[k], t = (s0 + len) / (unsigned)PT_W;
+        if (t * (unsigned)PT_W > s0) tile_first[t] = (I)(base + k + 1);
+      }
+    }
+  }
+  // the lists of rows too long for the tile kernel: every thread counts its rows per class (seven 16-bit counters in two
+  // words: a workgroup holds 4096 rows), ONE scan of the packed counters gives each thread its place inside the
+  // workgroup's stretch of every list, one reservation per class and workgroup, and the rows are written where they
+  // belong.  (Until round 5 the rows were staged in LDS sixteen rounds of barriers long: 25 of the kernel's 40 us.)
   if (block_rows == nullptr) return;
-  auto flush = [&]() {  // all threads; leaves the stage empty
-    __syncthreads();
-    if (tid < NC && s_cnt[tid]) {
-      unsigned *const hot = ((PermAll *)st)->hot;  // (tid == BR_CLASSES: the long rows' slot, PH_LONG)
-      s_base[tid] = atomicAdd(&hot[tid * PH_STRIDE], s_cnt[tid]);
-    }
-    if (tid == 0 && s_long_nnz) {
-      atomicAdd((unsigned long long *)&((PermAll *)st)->hot[PH_LONG_NNZ * PH_STRIDE], s_long_nnz);
-      s_long_nnz = 0;
-    }
-    if (tid == 1 && s_block_nnz) {
-      atomicAdd((unsigned long long *)&((PermAll *)st)->hot[PH_BLOCK_NNZ * PH_STRIDE], s_block_nnz);
-      s_block_nnz = 0;
-    }
-    __syncthreads();
-    for (int c = 0; c < NC; c++) {
-      I *list = c < BR_CLASSES ? block_rows + (int64_t)c * block_stride : long_rows;
-      for (unsigned k = tid; k < s_cnt[c]; k += 256) list[s_base[c] + k] = s_rows[c][k];
-    }
-    __syncthreads();
-    if (tid < NC) s_cnt[tid] = 0;
-    __syncthreads();
-  };
-#pragma unroll 1
-  for (int k = 0; k < CS_ITEMS; k++) {  // 256 rows per round: the stage (RC_STAGE per class) cannot overflow inside one
-    const int64_t i = base + k;
+  static_assert(NC <= 8 && CS_TILE < 65536, "seven 16-bit counters in two words");
+  unsigned long long c_lo = 0, c_hi = 0, lnz = 0, bnz = 0;
+#pragma unroll
+  for (int k = 0; k < CS_ITEMS; k++) {
     const int dd = d[k];
-    if (i < nr && dd > PT_LMAX) {
+    if (base + k < nr && dd > PT_LMAX) {
       int cls = BR_CLASSES;
       if (dd <= block_cap) {
         cls = 0;
         while (dd > br_cap(cls)) cls++;
       }
-      s_rows[cls][atomicAdd(&s_cnt[cls], 1u)] = (I)i;
-      atomicAdd(cls == BR_CLASSES ? &s_long_nnz : &s_block_nnz, (unsigned long long)dd);
+      if (cls < 4) c_lo += 1ull << (16 * cls);
+      else c_hi += 1ull << (16 * (cls - 4));
+      if (cls == BR_CLASSES) lnz += (unsigned)dd;
+      else bnz += (unsigned)dd;
     }
-    __syncthreads();
-    bool full = false;
-    for (int c = 0; c < NC; c++) full |= s_cnt[c] + 256u > (unsigned)RC_STAGE;
-    if (full) flush();  // uniform: every thread reads the same counters behind the barrier
   }
-  flush();
+  __shared__ unsigned long long s_c[2][4], s_nz[2][4];
+  const unsigned long long i_lo = sbx_wave_inclusive_sum(c_lo), i_hi = sbx_wave_inclusive_sum(c_hi);
+  lnz = sbx_wave_sum(lnz), bnz = sbx_wave_sum(bnz);
+  __syncthreads();  // (s_red of the scan above has been read)
+  if (lane == 63) s_c[0][wv] = i_lo, s_c[1][wv] = i_hi;
+  if (lane == 0) s_nz[0][wv] = lnz, s_nz[1][wv] = bnz;
+  __syncthreads();
+  unsigned long long e_lo = i_lo - c_lo, e_hi = i_hi - c_hi, t_lo = 0, t_hi = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; w2++) {
+    if (w2 < wv) e_lo += s_c[0][w2], e_hi += s_c[1][w2];
+    t_lo += s_c[0][w2], t_hi += s_c[1][w2];
+  }
+  if (t_lo == 0 && t_hi == 0) return;  // (uniform: nothing to list in this tile)
+  if (tid < NC) {
+    const unsigned cnt = (unsigned)((tid < 4 ? t_lo >> (16 * tid) : t_hi >> (16 * (tid - 4))) & 0xFFFFull);
+    unsigned *const hot = ((PermAll *)st)->hot;  // (tid == BR_CLASSES: the long rows' slot, PH_LONG)
+    s_base[tid] = cnt ? atomicAdd(&hot[tid * PH_STRIDE], cnt) : 0u;
+  }
+  if (tid == 32) {
+    const unsigned long long all = s_nz[0][0] + s_nz[0][1] + s_nz[0][2] + s_nz[0][3];
+    if (all) atomicAdd((unsigned long long *)&((PermAll *)st)->hot[PH_LONG_NNZ * PH_STRIDE], all);
+  }
+  if (tid == 33) {
+    const unsigned long long all = s_nz[1][0] + s_nz[1][1] + s_nz[1][2] + s_nz[1][3];
+    if (all) atomicAdd((unsigned long long *)&((PermAll *)st)->hot[PH_BLOCK_NNZ * PH_STRIDE], all);
+  }
+  __syncthreads();
+  if (c_lo | c_hi) {
+#pragma unroll
+    for (int k = 0; k < CS_ITEMS; k++) {
+      const int dd = d[k];
+      if (base + k < nr && dd > PT_LMAX) {
+        int cls = BR_CLASSES;
+        if (dd <= block_cap) {
+          cls = 0;
+          while (dd > br_cap(cls)) cls++;
+        }
+        unsigned at;
+        if (cls < 4) {
+          at = (unsigned)((e_lo >> (16 * cls)) & 0xFFFFull);
+          e_lo += 1ull << (16 * cls);
+        } else {
+          at = (unsigned)((e_hi >> (16 * (cls - 4))) & 0xFFFFull);
+          e_hi += 1ull << (16 * (cls - 4));
+        }
+        I *list = cls < BR_CLASSES ? block_rows + (int64_t)cls * block_stride : long_rows;
+        list[s_base[cls] + at] = (I)(base + k);
+      }
+    }
+  }
 }
 
 // ---- row-wise permute: no column relabel, so rows keep their internal order and the
@@ -1160,6 +1213,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile_radix(
                                    col_order, rpo, sp, col_out, val_out, nr, st, col_bits, 0, nullptr);
     __syncthreads();  // the next tile reuses the LDS pool
   }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_fill_index(I *__restrict__ a, int64_t count, I value) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) a[i] = value;
 }
 
 // tile_first[t] = first row r in [0, nr] whose output range starts at or after position t * PT_W
@@ -2381,7 +2441,7 @@ template <typename I, int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_in, const char *val_in,
                const I *col_order, const I *rpo, I *col_out, char *val_out, int64_t nr, int64_t m,
                int64_t total, const I *long_rows, const I *block_rows, int64_t block_stride,
-               const PermState &hs, PermState *st, const I *sp) {
+               const PermState &hs, PermState *st, const I *sp, const I *tile_first_ready = nullptr) {
   if constexpr (sizeof(I) == 8)
     if (m > KEY32_MAX_COLS)
       return wide_rows_path<I, VB>(h, vt, rec, col_in, val_in, col_order, rpo, col_out, val_out, nr, m, total, st);
@@ -2407,10 +2467,13 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_
   const int64_t short_nnz = total - long_nnz - block_nnz;  // entries of the rows the tile kernel sorts
   if (short_nnz > 0) {
     const int64_t tiles = (short_nnz + PT_W - 1) / PT_W;
-    I *tile_first = nullptr;
-    SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tile_first));
-    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), sp, nr, tiles,
-                tile_first);
+    const I *tile_first = tile_first_ready;  // (from the classification pass, where it had the bounds to allocate it)
+    if (!tile_first) {
+      I *tf = nullptr;
+      SBX_TRY(sbx_salloc(h, (size_t)tiles + 1, &tf));
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_tile_first<I>, dim3((unsigned)(tiles / 256 + 1)), dim3(256), sp, nr, tiles, tf);
+      tile_first = tf;
+    }
     unsigned *fb_tiles = nullptr;  // tiles whose rows cluster (listed by the tile kernel, sorted by its radix twin)
     SBX_TRY(sbx_salloc(h, (size_t)tiles, &fb_tiles));
     const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
@@ -2471,8 +2534,11 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_
 // The call's state, the classification's look-back words and the row records in ONE allocation, zeroed by ONE fill
 // (three fills cost three launches of ~4.5 us in front of the first kernel).  status: for classify_and_scan.
 static int64_t cs_tiles(int64_t nr) { return (nr + CS_TILE - 1) / CS_TILE > 0 ? (nr + CS_TILE - 1) / CS_TILE : 1; }
+// The call's state, the classification's tile sums and the row records in ONE allocation, zeroed by ONE fill (three
+// fills cost three launches of ~4.5 us in front of the first kernel; the records of rows a malformed row order never
+// names must read as empty).  status: for classify_and_scan.
 static int perm_prep_alloc(sbx_handle_t h, int64_t nr, PermState **st, unsigned long long **status, int2 **rec) {
-  const size_t status_bytes = sizeof(unsigned long long) * (size_t)(cs_tiles(nr) + 2);
+  const size_t status_bytes = sizeof(unsigned long long) * (size_t)(2 * cs_tiles(nr) + 2);
   const size_t bytes = sizeof(PermAll) + status_bytes + sizeof(int2) * (size_t)nr;
   char *base = nullptr;
   SBX_TRY(sbx_salloc(h, bytes + 128, &base));
@@ -2503,14 +2569,23 @@ static int perm_fetch(sbx_handle_t h, PermState *hs, const PermState *st) {
 // st must have been zeroed by the caller
 template <typename I>
 int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr, I *long_rows, I *block_rows,
-                      int64_t block_stride, int block_cap, PermState *st, unsigned long long *status = nullptr) {
+                      int64_t block_stride, int block_cap, PermState *st, unsigned long long *status = nullptr,
+                      I **tile_first_out = nullptr, int64_t entries_upper = 0) {
   const int64_t tiles = cs_tiles(nr);
-  if (!status) {  // (else: zeroed words from perm_prep_alloc)
-    SBX_TRY(sbx_salloc(h, (size_t)(tiles + 2), &status));
-    SBX_HIP(h, hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 2), h->stream));
+  if (!status) SBX_TRY(sbx_salloc(h, (size_t)(2 * tiles + 2), &status));  // (else: the words from perm_prep_alloc)
+  I *tile_first = nullptr;
+  if (tile_first_out) {  // the tile kernel's row ranges come out of the same pass (entries_upper >= the short rows' entries)
+    const int64_t slots = entries_upper / PT_W + 3;
+    SBX_TRY(sbx_salloc(h, (size_t)slots, &tile_first));
+    SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_fill_index<I>, dim3(sbx_grid_for(slots, 256, 1024)), dim3(256), tile_first, slots,
+                (I)nr);
+    *tile_first_out = tile_first;
   }
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_reduce, dim3((unsigned)tiles), dim3(256), rec, nr, status);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_prefix<I>, dim3(1), dim3(1024), status, tiles, rpo, sp, nr, st);
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_classify_scan<I>, dim3((unsigned)tiles), dim3(256), rec, rpo, sp, nr, long_rows,
-              block_rows, block_stride, block_cap, st, status, tiles, (int)(((uintptr_t)rpo & 15) == 0));
+              block_rows, block_stride, block_cap, st, (const unsigned long long *)status,
+              (int)(((uintptr_t)rpo & 15) == 0), tile_first);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
@@ -2605,8 +2680,9 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
     block_stride = cap_long;
   }
   // lengths -> row_ptr_out, the short rows' prefix sums and the class lists: one launch
+  I *tile_first = nullptr;
   SBX_TRY(classify_and_scan<I>(h, (const int2 *)rec, rpo, sp, nr, long_rows, block_rows, block_stride, block_cap, st,
-                               status));
+                               status, col_order ? &tile_first : nullptr, nnz));
   int64_t total = nnz;  // the full permute keeps every nonzero; a shard has to ask
   PermState hs;
   memset(&hs, 0, sizeof(hs));
@@ -2654,7 +2730,8 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
   int rc;
 #define STAGE(VBX)                                                                                                  \
   rc = sort_stage<I, VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
-                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st, sp)
+                       (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st, sp, \
+                       (const I *)tile_first)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);

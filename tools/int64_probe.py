@@ -27,6 +27,10 @@ for it in (torch.int32, torch.int64):
         p = perm.to(it)
         ms = timed(lambda: ops.permute_csr(n, n, a, b, val, p, p, out=out), reps)
         print("permute2d f64 values, %s indices, %s order: %.3f ms" % (str(it)[6:], name, ms), flush=True)
+for it in (torch.int32, torch.int64):  # RCM reads and writes 64-bit arrays itself (sbx_rcm64.hip): no narrowed copies
+    a, b = rp.to(it), col.to(it)
+    o = torch.empty(n, dtype=it, device="cuda")
+    print("rcm, %s indices: %.3f ms" % (str(it)[6:], timed(lambda: ops.rcm_reorder(a, b, out=o), reps)), flush=True)
 row, c2, v2 = synth.uniform_random_coo_torch(1 << 20, 1 << 20, 10_000_000, seed=3)
 sh = torch.randperm(row.numel(), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
 for it in (torch.int32, torch.int64):

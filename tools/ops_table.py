@@ -81,7 +81,22 @@ add("Permute2DRowWise (random order)", "C3", gpu_ms(lambda: ops.permute_csr(n, n
 add("DegreeReorder", "C3", gpu_ms(lambda: ops.degree_reorder(rp, True)), 8 * n + 4, n, cpu_s(lambda: ref.degree_reorder(crp, True, col=ccol)), ccfg, cn)
 add("Bandwidth + Profile", "C3", gpu_ms(lambda: (ops.csr_bandwidth(rp, col), ops.csr_profile(rp, col))), 2 * (4 * nnz + 4 * n), n,
     cpu_s(lambda: ref.features(crp, ccol)), ccfg + ", all four features", cn)
-del outp, val
+add("GrayReorder device stage (keys)", "C3", gpu_ms(lambda: ops.gray_row_keys(n, rp, col, 32, 10)), 4 * nnz + 16 * n, n)
+add("GrayReorder, ordering on the device (opt-in, stable ties)", "C3", gpu_ms(lambda: ops.gray_reorder(n, rp, col, 32, 10, 4)),
+    4 * nnz + 16 * n, n)
+# the COO constructor's sort at C3 size: the bench matrix's entries, shuffled
+rows_c3 = torch.repeat_interleave(torch.arange(n, device="cuda", dtype=torch.int32), (rp[1:] - rp[:-1]).long())
+p3 = torch.randperm(nnz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+s3 = (rows_c3[p3].contiguous(), col[p3].contiguous(), val[p3].contiguous())
+del rows_c3, p3
+w3 = tuple(torch.empty_like(t) for t in s3)
+def coo_sort_c3():
+    for d, t in zip(w3, s3): d.copy_(t)
+    ops.coo_sort_(n, n, *w3)
+def clone_c3():
+    for d, t in zip(w3, s3): d.copy_(t)
+add("COO constructor sort (shuffled input)", "C3: 105 M entries", gpu_ms(coo_sort_c3, 5) - gpu_ms(clone_c3, 5), 24 * nnz, n)
+del outp, val, s3, w3
 
 # ---------------- C5: banded, Gray device stage (+ CPU reference of the whole GrayReorder on a 1 M-row instance)
 for w, tag in ((64, "C5: banded +-64, n = 4 M"), ((1 << 22) // 16, "C5: banded +-m/16")):
