@@ -21,12 +21,13 @@
  *  - Index type: IDType and NNZType share one width (SBX_I32 or SBX_I64).
  *    uint32 index arrays alias SBX_I32 (all dimensions must be < 2^31).
  *    SBX_I64: the conversions (CSC included), checks, features, degree order,
- *    permutes, both constructor sorts and RCM read and write the 64-bit arrays
- *    themselves (index values of any size where the operation has room for
- *    them; nnz < 2^31 for the permutes, sorts, CSC and RCM, whose ids, offsets
- *    and queue positions are 32-bit inside: n < 2^31 - 1); the Gray keys and
- *    the text parsers work on narrowed copies and return SBX_ERR_UNSUPPORTED
- *    for an index value >= 2^31.
+ *    permutes, both constructor sorts, RCM and the Gray keys read and write
+ *    the 64-bit arrays themselves (index values of any size where the
+ *    operation has room for them; nnz < 2^31 for the permutes, sorts, CSC,
+ *    RCM and the Gray keys, whose ids, offsets and positions are 32-bit inside:
+ *    n < 2^31 - 1, m < 2^31 there — larger dimensions return
+ *    SBX_ERR_UNSUPPORTED); only the text parsers write int32 scratch outputs
+ *    that are widened afterwards.
  *  - Value type: the 0/4/8-byte payload that follows each nonzero.  The
  *    arithmetic type matters only where the reference compares values
  *    (std::less<pair<col,val>> between duplicate columns, format/csr.cc:143-156).

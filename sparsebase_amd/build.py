@@ -50,7 +50,11 @@ def build(force=False, verbose=False):
     for src in _sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_rcm.hip")) if src.endswith("sbx_rcm64.hip") else 0  # (it includes that file)
+        dep_m = 0  # (the 64-bit twins include their 32-bit files)
+        if src.endswith("sbx_rcm64.hip"):
+            dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_rcm.hip"))
+        if src.endswith("sbx_gray64.hip"):
+            dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_gray.hip"))
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m, dep_m)
         if stale:
             jobs.append((src, obj))

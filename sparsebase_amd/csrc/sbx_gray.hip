@@ -22,6 +22,17 @@
 
 namespace {
 
+// element type of the CALLER's arrays — row_ptr, col, degree_out: this file is compiled twice, for 32-bit index arrays
+// (sbx_gray.hip) and, through sbx_gray64.hip, for 64-bit ones, which are read and written as they are; every value is a
+// 32-bit offset, column or degree once it is in a register (nnz < 2^31, m < 2^31: checked by the entry point)
+#ifdef SBX_GRAY_I64
+typedef int64_t X;
+#define SBX_GRAY_ENTRY sbx_gray_row_keys_x64
+#else
+typedef int32_t X;
+#define SBX_GRAY_ENTRY sbx_gray_row_keys_x32
+#endif
+
 __device__ __forceinline__ uint64_t gray_decode(uint64_t g) {
   // prefix xor from the top: b = g ^ g>>1 ^ g>>2 ...
   g ^= g >> 1; g ^= g >> 2; g ^= g >> 4; g ^= g >> 8; g ^= g >> 16; g ^= g >> 32;
@@ -56,8 +67,8 @@ __device__ __forceinline__ bool gray_counted(int64_t d, int bits, int nnz_thresh
 }
 
 // degree_out, keys of empty rows, and tile_row[t] = last row r with row_ptr[r] <= min(t*GT_TILE, nnz)
-__global__ __launch_bounds__(256) void k_gray_prep(const int32_t *__restrict__ rp, int64_t n, int64_t nnz,
-                                                   int64_t ntiles, int32_t *__restrict__ degree_out,
+__global__ __launch_bounds__(256) void k_gray_prep(const X *__restrict__ rp, int64_t n, int64_t nnz,
+                                                   int64_t ntiles, X *__restrict__ degree_out,
                                                    unsigned long long *__restrict__ key_out,
                                                    int32_t *__restrict__ tile_row) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -80,8 +91,8 @@ __global__ __launch_bounds__(256) void k_gray_prep(const int32_t *__restrict__ r
   }
 }
 
-__global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restrict__ rp,
-                                                          const int32_t *__restrict__ col, int64_t nnz,
+__global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const X *__restrict__ rp,
+                                                          const X *__restrict__ col, int64_t nnz,
                                                           const int32_t *__restrict__ tile_row, uint32_t width,
                                                           uint32_t magic, uint32_t band, int bits, int nnz_threshold,
                                                           unsigned long long *__restrict__ key_out,
@@ -108,13 +119,13 @@ __global__ __launch_bounds__(GT_THREADS) void k_gray_tile(const int32_t *__restr
   // this thread's nonzeros: GT_ITEMS consecutive ones
   const int p0 = tid * GT_ITEMS;
   int32_t c[GT_ITEMS];
-  if (p0 + GT_ITEMS <= cnt && ((uintptr_t)col & 15) == 0) {
+  if (sizeof(X) == 4 && p0 + GT_ITEMS <= cnt && ((uintptr_t)col & 15) == 0) {
     const int4 *src = (const int4 *)(col + t0 + p0);
     const int4 a = src[0], b = src[1];
     c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
   } else {
 #pragma unroll
-    for (int k = 0; k < GT_ITEMS; k++) c[k] = (p0 + k < cnt) ? col[t0 + p0 + k] : 0;
+    for (int k = 0; k < GT_ITEMS; k++) c[k] = (p0 + k < cnt) ? (int32_t)col[t0 + p0 + k] : 0;
   }
   __syncthreads();
   if (r_end - r_lo <= 4 * GT_TILE) {
@@ -325,6 +336,18 @@ __device__ __forceinline__ B gr_shfl_xor(B v, int m) {
 struct __attribute__((packed, aligned(4))) GrU4 {
   unsigned x, y, z, w;
 };
+struct __attribute__((packed, aligned(8))) GrU8 {  // four 64-bit columns: the low words are the columns
+  unsigned x, xh, y, yh, z, zh, w, wh;
+};
+// four consecutive columns from entry `at` on (4- resp. 8-byte aligned: gfx950 loads unaligned vectors)
+__device__ __forceinline__ GrU4 gr_ld4(const X *__restrict__ col, int32_t at) {
+  if constexpr (sizeof(X) == 4) {
+    return *(const GrU4 *)(col + at);
+  } else {
+    const GrU8 v = *(const GrU8 *)(col + at);
+    return GrU4{v.x, v.y, v.z, v.w};
+  }
+}
 __device__ __forceinline__ int32_t gr_clamp4(int32_t j, int32_t nnz) {  // where the 16 bytes for entry j are read
   return j < nnz - 4 ? j : nnz - 4;  // nnz >= 4 (the caller's business) and j >= 0: never negative
 }
@@ -332,13 +355,13 @@ __device__ __forceinline__ int32_t gr_clamp4(int32_t j, int32_t nnz) {  // where
 // serialise the prefetch): the address is clamped into the array; which of the four words are entries of the lane's
 // row, and the shift the clamp caused for the last three entries of the whole array, are sorted out where the words
 // are used (gr_take4).
-__device__ __forceinline__ void gr_load4(const int32_t *__restrict__ col, int32_t j, int32_t nnz, unsigned *c) {
+__device__ __forceinline__ void gr_load4(const X *__restrict__ col, int32_t j, int32_t nnz, unsigned *c) {
 #pragma unroll
   for (int v4 = 0; v4 < GR_VEC; v4++) {
 #if defined(GR_ABLATE) && GR_ABLATE == 4
     const GrU4 v = {(unsigned)j, (unsigned)j + 1u, (unsigned)j + 2u, (unsigned)j + 3u};
 #else
-    const GrU4 v = *(const GrU4 *)(col + gr_clamp4(j + 4 * v4, nnz));
+    const GrU4 v = gr_ld4(col, gr_clamp4(j + 4 * v4, nnz));
 #endif
     c[4 * v4] = v.x, c[4 * v4 + 1] = v.y, c[4 * v4 + 2] = v.z, c[4 * v4 + 3] = v.w;
   }
@@ -367,10 +390,10 @@ __device__ __forceinline__ int gr_take4(int32_t j, int32_t e, int32_t nnz, unsig
 }
 
 template <typename B, int LV, bool POW2>
-__global__ __launch_bounds__(256) void k_gray_rows_short(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_rows_short(const X *__restrict__ rp, const X *__restrict__ col,
                                                          int64_t n, uint32_t width, uint32_t magic, uint32_t band,
                                                          int wshift, int bits, int nnz_threshold,
-                                                         int32_t *__restrict__ degree_out,
+                                                         X *__restrict__ degree_out,
                                                          unsigned long long *__restrict__ key_out,
                                                          GrayCounts *__restrict__ counts, unsigned *nlong,
                                                          int32_t *__restrict__ long_list) {
@@ -618,7 +641,7 @@ __device__ __forceinline__ void gray_emit_units(const int (&d)[G], RowOf row_of,
 // Listing for the banded path (k_gray_rows_short met a few rows of GR_SHORT_MAX + 1 .. GR_MED_MAX entries; the ones
 // above are on its own list for k_gray_long_rows): 4096 rows per workgroup.
 constexpr int GL_ROWS = 4096;
-__global__ __launch_bounds__(256) void k_gray_list_medium(const int32_t *__restrict__ rp, int64_t n,
+__global__ __launch_bounds__(256) void k_gray_list_medium(const X *__restrict__ rp, int64_t n,
                                                           int4 *__restrict__ units, int4 *__restrict__ mrows,
                                                           GrayLists *__restrict__ lc) {
   __shared__ unsigned s_w[4][3], s_b[3];
@@ -655,10 +678,10 @@ constexpr int GB_GROUPS = 4;
 constexpr int GB_ITERS = GB_ITERS_V;      // blocks of 4 x GB_GROUPS x 64 rows per workgroup: one list reservation for all of them
 constexpr int GB_WINDOW = GB_WINDOW_V;  // entries per pass: their row lookups, then their loads, then their ORs
 template <typename B, int LV, bool POW2>
-__global__ __launch_bounds__(256) void k_gray_rows_balanced(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_rows_balanced(const X *__restrict__ rp, const X *__restrict__ col,
                                                             int64_t n, uint32_t width, uint32_t magic, uint32_t band,
                                                             int wshift, int bits, int nnz_threshold,
-                                                            int32_t *__restrict__ degree_out,
+                                                            X *__restrict__ degree_out,
                                                             unsigned long long *__restrict__ key_out,
                                                             GrayCounts *__restrict__ counts, unsigned *nlong,
                                                             int32_t *__restrict__ long_list, int4 *__restrict__ units,
@@ -846,10 +869,10 @@ __device__ __forceinline__ void gr_fix4(int32_t j, int cnt, int32_t nnz, unsigne
 }
 
 template <typename B, bool POW2>
-__global__ __launch_bounds__(256) void k_gray_rows_tiny(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_rows_tiny(const X *__restrict__ rp, const X *__restrict__ col,
                                                         int64_t n, int32_t nnz, uint32_t width, uint32_t magic,
                                                         uint32_t band, int wshift, int nnz_threshold,
-                                                        int32_t *__restrict__ degree_out,
+                                                        X *__restrict__ degree_out,
                                                         unsigned long long *__restrict__ key_out,
                                                         GrayCounts *__restrict__ counts, int4 *__restrict__ units,
                                                         int4 *__restrict__ mrows, GrayLists *__restrict__ lc,
@@ -889,7 +912,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_tiny(const int32_t *__restric
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int32_t at = dt > 4 * k ? rs[i] + 4 * k : (dt > 0 ? rs[i] : first);
-      v[i & 1][k] = *(const GrU4 *)(col + gr_clamp4(at, nnz));
+      v[i & 1][k] = gr_ld4(col, gr_clamp4(at, nnz));
     }
   };
   bounds(0);
@@ -964,11 +987,11 @@ __global__ __launch_bounds__(256) void k_gray_rows_tiny(const int32_t *__restric
 }
 
 template <typename B, int LV, bool POW2>
-__global__ __launch_bounds__(256) void k_gray_rows_listed(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_rows_listed(const X *__restrict__ rp, const X *__restrict__ col,
                                                           const int32_t *__restrict__ list,
                                                           const unsigned *__restrict__ count, int32_t nnz,
                                                           uint32_t width, uint32_t magic, uint32_t band, int wshift,
-                                                          int bits, int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                          int bits, int nnz_threshold, X *__restrict__ degree_out,
                                                           unsigned long long *__restrict__ key_out,
                                                           GrayCounts *__restrict__ counts) {
   __shared__ unsigned long long s_red[4][4];
@@ -986,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_listed(const int32_t *__restr
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // (a vector behind the row's end is read at the row's start: no line nobody needs)
       const int32_t at = 16 * sub + 4 * k < d ? rs + 16 * sub + 4 * k : rs;
-      v[k] = *(const GrU4 *)(col + gr_clamp4(at, nnz));
+      v[k] = gr_ld4(col, gr_clamp4(at, nnz));
     }
     const bool sparse = d <= nnz_threshold;
     unsigned thr = 0;
@@ -1079,12 +1102,12 @@ constexpr int GU_SLOT = 65;   // words of a partial slot: 64 block counts, the b
 // side now each walk the unit table with a cursor of their own, and the adds are unconditional with a value of 0
 // where a lane has nothing to add.)
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_rows_medium(const X *__restrict__ rp, const X *__restrict__ col,
                                                           const int4 *__restrict__ units,
                                                           const GrayLists *__restrict__ lc, uint32_t width,
                                                           uint32_t magic, int wshift, uint32_t band, int bits,
                                                           int nnz_threshold, int32_t nnz,
-                                                          int32_t *__restrict__ degree_out,
+                                                          X *__restrict__ degree_out,
                                                           unsigned long long *__restrict__ key_out,
                                                           unsigned *__restrict__ partial,
                                                           GrayCounts *__restrict__ counts, unsigned spread) {
@@ -1125,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
     GrU4 R[GM_DEPTH];
     auto fetch = [&](int u) {
       const int32_t jj = f_k < blk ? f_j + 4 * lane : 0;
-      R[u] = *(const GrU4 *)(col + gr_clamp4(jj, nnz));  // (only 4-byte aligned: gfx950 loads unaligned vectors)
+      R[u] = gr_ld4(col, gr_clamp4(jj, nnz));  // (only 4-byte aligned: gfx950 loads unaligned vectors)
       if (f_k < blk) {
         f_j += GM_STEP;
         if (f_j >= f_b) {  // next unit
@@ -1249,10 +1272,10 @@ __global__ __launch_bounds__(256) void k_gray_rows_medium(const int32_t *__restr
 }
 
 // The rows of more than one unit, a wave each: lane b adds block b's count over the row's partial slots.
-__global__ __launch_bounds__(256) void k_gray_units_finish(const int32_t *__restrict__ rp, const int4 *__restrict__ mrows,
+__global__ __launch_bounds__(256) void k_gray_units_finish(const X *__restrict__ rp, const int4 *__restrict__ mrows,
                                                            const GrayLists *__restrict__ lc,
                                                            const unsigned *__restrict__ partial, int bits,
-                                                           int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                           int nnz_threshold, X *__restrict__ degree_out,
                                                            unsigned long long *__restrict__ key_out,
                                                            GrayCounts *__restrict__ counts, unsigned n_spread) {
   __shared__ unsigned long long s_red[4][4];
@@ -1312,7 +1335,7 @@ __global__ __launch_bounds__(64) void k_gray_fold(const GrayCounts *__restrict__
 // then into the row's global slot (64 counters + the band count), finished by k_gray_long_finish.  The number of listed
 // rows is read from the device (the power-law path launches this without a read-back in between): the workgroups loop.
 constexpr int GR_PARTS = 32;
-__global__ __launch_bounds__(256) void k_gray_long_rows(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256) void k_gray_long_rows(const X *__restrict__ rp, const X *__restrict__ col,
                                                         const int32_t *__restrict__ list,
                                                         const unsigned *__restrict__ n_long, uint32_t width,
                                                         uint32_t magic, uint32_t band, unsigned *__restrict__ slots) {
@@ -1360,10 +1383,10 @@ __global__ __launch_bounds__(256) void k_gray_long_rows(const int32_t *__restric
   }
 }
 
-__global__ __launch_bounds__(256) void k_gray_long_finish(const int32_t *__restrict__ rp, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(256) void k_gray_long_finish(const X *__restrict__ rp, const int32_t *__restrict__ list,
                                                           const unsigned *__restrict__ n_long,
                                                           const unsigned *__restrict__ slots, int bits,
-                                                          int nnz_threshold, int32_t *__restrict__ degree_out,
+                                                          int nnz_threshold, X *__restrict__ degree_out,
                                                           unsigned long long *__restrict__ key_out,
                                                           GrayCounts *__restrict__ counts) {
   const unsigned nl = *n_long;
@@ -1393,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_gray_long_finish(const int32_t *__restr
 }
 
 // rows cut by a tile boundary: key from the slot of the tile they start in; band counters summed
-__global__ __launch_bounds__(256) void k_gray_finish(const int32_t *__restrict__ rp, int bits, int nnz_threshold,
+__global__ __launch_bounds__(256) void k_gray_finish(const X *__restrict__ rp, int bits, int nnz_threshold,
                                                      const int32_t *__restrict__ fix_row,
                                                      const unsigned *__restrict__ slot_acc,
                                                      const unsigned *__restrict__ tile_counts, int64_t ntiles,
@@ -1431,15 +1454,27 @@ __global__ __launch_bounds__(256) void k_gray_finish(const int32_t *__restrict__
 
 }  // namespace
 
+int sbx_gray_row_keys_x32(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out, int64_t *counts_host);
+int sbx_gray_row_keys_x64(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out, int64_t *counts_host);
+#ifndef SBX_GRAY_I64
 extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, int64_t nnz,
                                  const void *row_ptr, const void *col, int resolution, int nnz_threshold,
                                  void *degree_out, uint64_t *key_out, int64_t *counts_host) {
   if (!h) return SBX_ERR_BAD_ARG;
   if (n < 0 || m < 0 || !row_ptr || !counts_host || (n > 0 && (!degree_out || !key_out)) || (nnz > 0 && !col))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_row_keys: bad argument");
-  if (it == SBX_I64)
-    return sbx_i64_gray_row_keys(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, degree_out, key_out,
-                                 counts_host);
+  // (offsets, columns and degrees are 32-bit inside, whatever the width of the arrays)
+  if (it == SBX_I64 && (n >= ((int64_t)1 << 31) - 1 || m >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)))
+    SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_gray_row_keys: dimension exceeds int32");
+  return it == SBX_I64 ? sbx_gray_row_keys_x64(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, degree_out, key_out, counts_host)
+                       : sbx_gray_row_keys_x32(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, degree_out, key_out, counts_host);
+}
+#endif
+
+int SBX_GRAY_ENTRY(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col, int resolution,
+                   int nnz_threshold, void *degree_out, uint64_t *key_out, int64_t *counts_host) {
   int bits = resolution;
   if (m < bits) bits = (int)m;  // gray_reorder.cc:206-208
   if (bits <= 0 || bits > 64) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_row_keys: resolution must be in 1..64");
@@ -1476,7 +1511,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   // c / width = umulhi(c, magic) or that + 1 (c < 2^31): magic = floor(2^32 / width), saturated for width 1
   const uint64_t mg = ((uint64_t)1 << 32) / (uint64_t)width;
   const uint32_t magic = mg > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mg;
-  const int32_t *rp = (const int32_t *)row_ptr, *cl = (const int32_t *)col;
+  const X *rp = (const X *)row_ptr, *cl = (const X *)col;
   unsigned long long *keys = (unsigned long long *)key_out;
   {
     // short-row fast path, tried first: the kernel lists the rows above GR_SHORT_MAX entries it meets; up to
@@ -1499,11 +1534,11 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   do {                                                                                                             \
     if (wshift >= 0)                                                                                               \
       SBX_KLAUNCH(h, SBX_K_GRAY, (K<B, LV, true>), dim3(GRID), dim3(256), rp, cl, n, (uint32_t)width, magic,        \
-                  (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong, long_list,  \
+                  (uint32_t)band, wshift, bits, nnz_threshold, (X *)degree_out, keys, cnt, nlong, long_list,  \
                   ##__VA_ARGS__);                                                                                  \
     else                                                                                                           \
       SBX_KLAUNCH(h, SBX_K_GRAY, (K<B, LV, false>), dim3(GRID), dim3(256), rp, cl, n, (uint32_t)width, magic,       \
-                  (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, cnt, nlong, long_list,       \
+                  (uint32_t)band, 0, bits, nnz_threshold, (X *)degree_out, keys, cnt, nlong, long_list,       \
                   ##__VA_ARGS__);                                                                                  \
   } while (0)
 #define GRAY_ROWS_BY_LEVELS(K, GRID, ...)                                                                           \
@@ -1551,11 +1586,11 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     if (wshift >= 0)                                                                                               \
       SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium<true>, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,       \
                   (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,     \
-                  nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, COUNTS, NSPREAD);              \
+                  nnz_threshold, (int32_t)nnz, (X *)degree_out, keys, partial, COUNTS, NSPREAD);              \
     else                                                                                                           \
       SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_rows_medium<false>, dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl,      \
                   (const int4 *)units, (const GrayLists *)lc, (uint32_t)width, magic, wsh, (uint32_t)band, bits,     \
-                  nnz_threshold, (int32_t)nnz, (int32_t *)degree_out, keys, partial, COUNTS, NSPREAD);              \
+                  nnz_threshold, (int32_t)nnz, (X *)degree_out, keys, partial, COUNTS, NSPREAD);              \
   } while (0)
       auto alloc_lists = [&]() -> int {
         SBX_TRY(sbx_salloc(h, max_units, &units));
@@ -1580,11 +1615,11 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   do {                                                                                                               \
     if (wshift >= 0)                                                                                                 \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_tiny<B, true>), dim3(bgrid), dim3(256), rp, cl, n, (int32_t)nnz,        \
-                  (uint32_t)width, magic, (uint32_t)band, wshift, nnz_threshold, (int32_t *)degree_out, keys, spread, \
+                  (uint32_t)width, magic, (uint32_t)band, wshift, nnz_threshold, (X *)degree_out, keys, spread, \
                   units, mrows, lc, mid_list, &all->mid_count);                                                      \
     else                                                                                                             \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_tiny<B, false>), dim3(bgrid), dim3(256), rp, cl, n, (int32_t)nnz,       \
-                  (uint32_t)width, magic, (uint32_t)band, 0, nnz_threshold, (int32_t *)degree_out, keys, spread, units, \
+                  (uint32_t)width, magic, (uint32_t)band, 0, nnz_threshold, (X *)degree_out, keys, spread, units, \
                   mrows, lc, mid_list, &all->mid_count);                                                             \
   } while (0)
           if (bits <= 32) GRAY_TINY(uint32_t);
@@ -1595,11 +1630,11 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
     if (wshift >= 0)                                                                                                 \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_listed<B, LV, true>), dim3((unsigned)h->num_cus * 8), dim3(256), rp, cl, \
                   (const int32_t *)mid_list, (const unsigned *)&all->mid_count, (int32_t)nnz, (uint32_t)width, magic, \
-                  (uint32_t)band, wshift, bits, nnz_threshold, (int32_t *)degree_out, keys, spread);                 \
+                  (uint32_t)band, wshift, bits, nnz_threshold, (X *)degree_out, keys, spread);                 \
     else                                                                                                             \
       SBX_KLAUNCH(h, SBX_K_GRAY, (k_gray_rows_listed<B, LV, false>), dim3((unsigned)h->num_cus * 8), dim3(256), rp,   \
                   cl, (const int32_t *)mid_list, (const unsigned *)&all->mid_count, (int32_t)nnz, (uint32_t)width,   \
-                  magic, (uint32_t)band, 0, bits, nnz_threshold, (int32_t *)degree_out, keys, spread);               \
+                  magic, (uint32_t)band, 0, bits, nnz_threshold, (X *)degree_out, keys, spread);               \
   } while (0)
           if (bits <= 32) {
             if (lv <= 1) GRAY_LISTED(uint32_t, 1);
@@ -1617,7 +1652,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
         GRAY_MEDIUM(spread, (unsigned)GR_SPREAD);
         SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3((unsigned)h->num_cus * 4), dim3(256), rp,
                     (const int4 *)mrows, (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold,
-                    (int32_t *)degree_out, keys, spread, (unsigned)GR_SPREAD);
+                    (X *)degree_out, keys, spread, (unsigned)GR_SPREAD);
         SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_fold, dim3(1), dim3(64), (const GrayCounts *)spread, &all->total2);
         SBX_LAUNCH_CHECK(h);
         SBX_TRY(sbx_readback(h, &hb.c, &all->total2, sizeof(GrayCounts)));
@@ -1630,7 +1665,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
                       units, mrows, lc);
           GRAY_MEDIUM(cnt, 1u);
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_units_finish, dim3(64), dim3(256), rp, (const int4 *)mrows,
-                      (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (int32_t *)degree_out, keys,
+                      (const GrayLists *)lc, (const unsigned *)partial, bits, nnz_threshold, (X *)degree_out, keys,
                       cnt, 1u);
         }
         if (hlong) {
@@ -1641,7 +1676,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
                       (const int32_t *)long_list, (const unsigned *)nlong, (uint32_t)width, magic, (uint32_t)band, slots);
           SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_long_finish, dim3((hlong + 3) / 4), dim3(256), rp,
                       (const int32_t *)long_list, (const unsigned *)nlong, (const unsigned *)slots, bits, nnz_threshold,
-                      (int32_t *)degree_out, keys, cnt);
+                      (X *)degree_out, keys, cnt);
         }
         SBX_LAUNCH_CHECK(h);
         SBX_TRY(fetch_both());
@@ -1673,7 +1708,7 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
   SBX_HIP(h, hipMemsetAsync(slot_acc, 0, (size_t)(ntiles + 1) * 64 * sizeof(unsigned), h->stream));
   const int64_t prep_items = n > ntiles + 1 ? n : ntiles + 1;
   SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_prep, dim3(sbx_grid_for(prep_items, 256, (int64_t)h->num_cus * 16)), dim3(256),
-              rp, n, nnz, ntiles, (int32_t *)degree_out, keys, tile_row);
+              rp, n, nnz, ntiles, (X *)degree_out, keys, tile_row);
   if (ntiles > 0) {
     SBX_KLAUNCH(h, SBX_K_GRAY, k_gray_tile, dim3((unsigned)ntiles), dim3(GT_THREADS), rp, cl, nnz,
                 (const int32_t *)tile_row, (uint32_t)width, magic, (uint32_t)band, bits, nnz_threshold, keys, fix_row,

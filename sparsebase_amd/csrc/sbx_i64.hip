@@ -137,14 +137,3 @@ int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_
   return sbx_widen_i32(h, c, col_out, dims_nnz_host[2]);
 }
 
-int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
-                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
-                          int64_t *counts_host) {
-  I64_BEGIN();
-  NARROW(rp, row_ptr, n + 1);
-  NARROW(c, col, nnz);
-  SCRATCH32(deg, n, true);
-  SBX_TRY(sbx_i64_check(h, ovf));
-  SBX_TRY(sbx_gray_row_keys(h, SBX_I32, n, m, nnz, rp, c, resolution, nnz_threshold, deg, key_out, counts_host));
-  return sbx_widen_i32(h, deg, degree_out, n);
-}

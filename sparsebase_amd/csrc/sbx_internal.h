@@ -280,7 +280,4 @@ int sbx_i64_mtx_parse_coordinate(sbx_handle_t h, sbx_value_type vt, const void *
 int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_dev, int64_t bytes, int64_t entries,
                             int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
                             int64_t *dims_nnz_host);
-int sbx_i64_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
-                          int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out,
-                          int64_t *counts_host);
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);

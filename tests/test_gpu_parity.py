@@ -1106,6 +1106,36 @@ def test_rcm_int64_arrays_native(ops, oracle):
     assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
 
 
+def test_gray_row_keys_int64_arrays_native(ops, oracle):
+    """The Gray key stage on 64-bit index arrays: sbx_gray.hip compiled for int64 row_ptr / col / degree_out
+    (sbx_gray64.hip) reads them as they are — four columns are two 16-byte loads — through every kernel family: the
+    banded kernel (4 lanes per row), the power-law kernels (tiny / listed / unit / finish), the general tile kernel
+    (resolution below 16), rows beyond 8192 entries; a dimension the 32-bit values inside cannot hold is refused."""
+    from sparsebase_amd import capi
+    g = np.random.default_rng(41)
+    cases = [(synth.banded_symmetric(8192, 40, 9, 3), 32, 10), (synth.banded_symmetric(4096, 1024, 11, 5), 16, 0),
+             (synth.rmat_symmetric(14, 16, seed=2), 32, 10), (synth.rmat_symmetric(13, 8, seed=6), 64, 3),
+             (synth.rmat_symmetric(12, 8, seed=7), 8, 2)]
+    n_l = 1 << 15  # a few rows of ~20 000 entries among short ones
+    lens = g.integers(0, 12, n_l)
+    lens[[5, 700, 9000]] = (20000, 9000, 30000)
+    rp_l = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col_l = np.concatenate([np.sort(g.choice(n_l, l, replace=False)) for l in lens]).astype(np.int32)
+    cases.append(((rp_l, col_l), 32, 10))
+    for (rp, col), res, thr in cases:
+        n = len(rp) - 1
+        deg, key, counts = ops.gray_row_keys(n, dev(rp.astype(np.int64)), dev(col.astype(np.int64)), res, thr)
+        wdeg, wkey, wcounts = oracle.gray_row_keys(rp, col, n, res, thr)
+        assert deg.dtype == torch.int64
+        assert np.array_equal(host(deg), wdeg.astype(np.int64)), (res, thr)
+        assert np.array_equal(host(key).view(np.uint64), wkey), (res, thr)
+        assert list(counts) == wcounts.tolist()
+    (rp, col), res, thr = cases[0]
+    with pytest.raises(capi.SbxError) as e:
+        ops.gray_row_keys(1 << 32, dev(rp.astype(np.int64)), dev(col.astype(np.int64)), res, thr)
+    assert e.value.status == 5  # SBX_ERR_UNSUPPORTED
+
+
 def test_int64_values_beyond_int32(ops, oracle):
     """64-bit indices with values >= 2^31.  The conversions COO <-> CSR and the two sortedness checks run native 64-bit
     kernels: column ids of any size are accepted and the results are the oracle's, bit for bit; so do both constructor

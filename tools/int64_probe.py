@@ -31,6 +31,9 @@ for it in (torch.int32, torch.int64):  # RCM reads and writes 64-bit arrays itse
     a, b = rp.to(it), col.to(it)
     o = torch.empty(n, dtype=it, device="cuda")
     print("rcm, %s indices: %.3f ms" % (str(it)[6:], timed(lambda: ops.rcm_reorder(a, b, out=o), reps)), flush=True)
+for it in (torch.int32, torch.int64):  # the Gray key stage likewise (sbx_gray64.hip)
+    a, b = rp.to(it), col.to(it)
+    print("gray keys, %s indices: %.3f ms" % (str(it)[6:], timed(lambda: ops.gray_row_keys(n, a, b, 32, 10), reps)), flush=True)
 row, c2, v2 = synth.uniform_random_coo_torch(1 << 20, 1 << 20, 10_000_000, seed=3)
 sh = torch.randperm(row.numel(), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
 for it in (torch.int32, torch.int64):
