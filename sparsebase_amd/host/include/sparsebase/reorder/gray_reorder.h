@@ -28,6 +28,33 @@ namespace sparsebase::reorder {
 
 enum BitMapSize { BitSize16 = 16, BitSize32 = 32, BitSize64 = 64 };
 
+namespace detail {
+// f(begin, end) over [0, count) in contiguous pieces on up to 16 threads (element-wise loops of the Gray host stage:
+// they touch several million rows each and are bound by memory latency, not by the sorts' order)
+template <typename F>
+inline void GrayParallelFor(int64_t count, F f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t workers = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), (count + (1 << 16) - 1) >> 16);
+  if (workers <= 1) {
+    f((int64_t)0, count);
+    return;
+  }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> errors((size_t)workers);
+  for (int64_t w = 0; w < workers; w++)
+    pool.emplace_back([&, w]() {
+      try {
+        f(count * w / workers, count * (w + 1) / workers);
+      } catch (...) {
+        errors[(size_t)w] = std::current_exception();
+      }
+    });
+  for (auto &t : pool) t.join();
+  for (auto &e : errors)
+    if (e) std::rethrow_exception(e);
+}
+}  // namespace detail
+
 struct GrayReorderParams : utils::Parameters {
   BitMapSize resolution;
   int nnz_threshold;
@@ -112,11 +139,32 @@ class GrayReorder : public Reorderer<IDType> {
     } host_stage_timer{t_host};
     // ---- host ordering stage (see header comment)
     const int group_size = params->sparse_density_group_size;
+    // sparse / dense split in id order (gray_reorder.cc:138-170): counted per piece, then written at the pieces' offsets
     std::vector<IDType> sparse_rows, dense_rows;
-    sparse_rows.reserve((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-      if (deg[i] <= (IDType)params->nnz_threshold) sparse_rows.push_back((IDType)i);
-      else dense_rows.push_back((IDType)i);
+    {
+      const IDType thr = (IDType)params->nnz_threshold;
+      const int64_t pieces = std::max<int64_t>(1, std::min<int64_t>(64, n >> 16));
+      std::vector<int64_t> cnt((size_t)pieces + 1, 0);
+      detail::GrayParallelFor(pieces, [&](int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; p++) {
+          int64_t c = 0;
+          for (int64_t i = n * p / pieces; i < n * (p + 1) / pieces; i++) c += deg[i] <= thr;
+          cnt[(size_t)p + 1] = c;
+        }
+      });
+      for (int64_t p = 0; p < pieces; p++) cnt[(size_t)p + 1] += cnt[(size_t)p];
+      sparse_rows.resize((size_t)cnt[(size_t)pieces]);
+      dense_rows.resize((size_t)(n - cnt[(size_t)pieces]));
+      detail::GrayParallelFor(pieces, [&](int64_t p0, int64_t p1) {
+        for (int64_t p = p0; p < p1; p++) {
+          const int64_t b = n * p / pieces;
+          int64_t s = cnt[(size_t)p], d = b - s;
+          for (int64_t i = b; i < n * (p + 1) / pieces; i++) {
+            if (deg[i] <= thr) sparse_rows[(size_t)s++] = (IDType)i;
+            else dense_rows[(size_t)d++] = (IDType)i;
+          }
+        }
+      });
     }
     // the reference keeps these counters in `int` (gray_reorder.cc:134-137)
     const bool sparse_banded = double((int)counts[1]) / (int)counts[0] > 0.3;
@@ -149,11 +197,29 @@ class GrayReorder : public Reorderer<IDType> {
       // gray_reorder.cc:199-203: std::sort of the row ids by degree.  The (degree, id) pairs are sorted instead, with a
       // comparator that looks at the degree only: every comparison answers what `deg[a] < deg[b]` answers, so the
       // elements make the same moves, without two dependent loads per comparison.
-      typedef std::pair<IDType, IDType> deg_row;  // (degree, row)
-      std::vector<deg_row> byd(sparse_rows.size());
-      for (size_t a = 0; a < sparse_rows.size(); a++) byd[a] = deg_row(deg[sparse_rows[a]], sparse_rows[a]);
-      std::sort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
-      for (size_t a = 0; a < sparse_rows.size(); a++) sparse_rows[a] = byd[a].second;
+      const int64_t ns0 = (int64_t)sparse_rows.size();
+      if (params->nnz_threshold < 256 && n <= ((int64_t)1 << 24)) {
+        // ... packed into ONE 32-bit word when they fit (degree << 24 | row): half the bytes to move, the same moves
+        std::vector<uint32_t> byd((size_t)ns0);
+        detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
+          for (int64_t a = a0; a < a1; a++)
+            byd[(size_t)a] = ((uint32_t)deg[sparse_rows[(size_t)a]] << 24) | (uint32_t)sparse_rows[(size_t)a];
+        });
+        std::sort(byd.begin(), byd.end(), [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); });
+        detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
+          for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = (IDType)(byd[(size_t)a] & 0xFFFFFFu);
+        });
+      } else {
+        typedef std::pair<IDType, IDType> deg_row;  // (degree, row)
+        std::vector<deg_row> byd((size_t)ns0);
+        detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
+          for (int64_t a = a0; a < a1; a++) byd[(size_t)a] = deg_row(deg[sparse_rows[(size_t)a]], sparse_rows[(size_t)a]);
+        });
+        std::sort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
+        detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
+          for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = byd[(size_t)a].second;
+        });
+      }
     }
 
     if (!sparse_banded) {
@@ -223,9 +289,11 @@ class GrayReorder : public Reorderer<IDType> {
     if (dense_thread.joinable()) dense_thread.join();
     if (dense_error) std::rethrow_exception(dense_error);
     IDType *order = new IDType[n > 0 ? n : 1]();
-    int64_t pos = 0;
-    for (IDType r : sparse_rows) order[r] = (IDType)pos++;
-    for (IDType r : dense_rows) order[r] = (IDType)pos++;
+    const int64_t ns_all = (int64_t)sparse_rows.size();
+    detail::GrayParallelFor(n, [&](int64_t p0, int64_t p1) {  // (every row is written once: disjoint stores)
+      for (int64_t pos = p0; pos < p1; pos++)
+        order[pos < ns_all ? sparse_rows[(size_t)pos] : dense_rows[(size_t)(pos - ns_all)]] = (IDType)pos;
+    });
     return order;
   }
   static IDType *GrayReorderingCSR(std::vector<format::Format *> formats, utils::Parameters *params) {
