@@ -1192,6 +1192,17 @@ def test_int64_values_beyond_int32(ops, oracle):
     lo, hi = want[0][n // 3], want[0][n // 2]
     assert np.array_equal(host(srp), want[0][n // 3:n // 2 + 1] - lo) and np.array_equal(host(scol), want[1][lo:hi])
     assert np.array_equal(host(sval), want[2][lo:hi])
+    # RCM and the Gray keys read 64-bit arrays natively as well (sbx_rcm64.hip, sbx_gray64.hip: no narrowed copies); their
+    # ids and offsets are 32-bit inside, so a dimension beyond int32 is refused instead of truncated
+    grp_, gcol_ = synth.rmat_symmetric(10, 6, seed=8)
+    assert np.array_equal(host(ops.rcm_reorder(dev(grp_.astype(np.int64)), dev(gcol_.astype(np.int64)))),
+                          oracle.rcm_reorder(grp_, gcol_).astype(np.int64))
+    gd, gk, gc = ops.gray_row_keys(len(grp_) - 1, dev(grp_.astype(np.int64)), dev(gcol_.astype(np.int64)), 16, 4)
+    wd_, wk_, wc_ = oracle.gray_row_keys(grp_, gcol_, len(grp_) - 1, 16, 4)
+    assert np.array_equal(host(gd), wd_.astype(np.int64)) and np.array_equal(host(gk).view(np.uint64), wk_) and list(gc) == wc_.tolist()
+    with pytest.raises(capi.SbxError) as e:
+        ops.gray_row_keys(m, dev(rp), dev(col), 16, 4)   # m = 2^40 columns
+    assert e.value.status == 5
     # the COO constructor's sort is native: coordinates of any size inside the matrix (packed keys: 9 + 40 bits here)
     for v in (v_u, v_u.astype(np.float32), None):
         r_s, c_s, v_s = dev(r_u.copy()), dev(c_u.copy()), dev(v)
