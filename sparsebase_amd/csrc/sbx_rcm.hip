@@ -190,6 +190,7 @@ __global__ __launch_bounds__(1024) void k_deg_reduce(const unsigned *__restrict_
     }
     dv->max_deg = mx;
     dv->first_vertex = fv;
+    dv->root = fv == UNSEEN ? 0u : fv;  // the first sweep starts here without the host having seen it (sbx_rcm_reorder)
     dv->n_nonempty = cnt;
     dv->n_top = top;
   }
@@ -1994,6 +1995,10 @@ struct BfsBuffers {
   RcmDev *dv;
   int64_t n;
   unsigned max_deg;  // largest degree of the graph: no hub kernel launches when nothing exceeds RCM_LIGHT
+  // the call's first read-back rides on the first sweep's (saves a round trip at the head of every call): when set, the
+  // first read-back of run_ubfs also delivers the degree counts k_deg_reduce left (max_deg above is not known before)
+  RcmDev *late_counts;
+  bool *late_counts_ready;
   // work the host still has to enqueue elsewhere (the degree ranks on their side stream): run once, right after a sweep's
   // first launch and before the host waits for it, so that its enqueue time hides behind the kernel (bfs_first_launch)
   std::function<int()> *after_first_launch;
@@ -3218,6 +3223,10 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_TRY(bfs_first_launch(b, 40));
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
+      if (b.late_counts && !*b.late_counts_ready) {
+        *b.late_counts = hs;
+        *b.late_counts_ready = true;
+      }
       if (hs.gb_abort) {  // a grid barrier gave up (gb_wait): this sweep is redone by the ordered kernels
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
         h->rcm_gb_backoff = gb_backoff_calls();
@@ -3260,7 +3269,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       if (grid < 1) grid = 1;
       SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<1>, dim3(grid), dim3(256), b.rp, b.col, (const I *)(b.q + off),
                   fsize, level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list, b.heavy, b.hub_dir, b.dv, us, 0);
-      if (b.max_deg > (unsigned)RCM_LIGHT)
+      if ((b.late_counts ? b.late_counts->max_deg : b.max_deg) > (unsigned)RCM_LIGHT)
         SBX_KLAUNCH(h, SBX_K_BFS_HEAVY, k_bfs_expand_heavy<1>, dim3(heavy_grid), dim3(256), b.rp, b.col,
                     (const I *)(b.q + off), level + 1, (const unsigned *)b.vbits, b.ppos, b.nf_list,
                     (const uint64_t *)b.heavy, (const uint2 *)b.hub_dir, grid, b.dv, us);
@@ -3511,9 +3520,22 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_count, dim3(DEG_UNITS / 4), dim3(256), rp, n, ucnt, csize, dist, ppos);
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_deg_reduce, dim3(1), dim3(1024), (const unsigned *)ucnt, dv);
   SBX_LAUNCH_CHECK(h);
+  // after a grid barrier gave up (a GPU shared with another process, see gb_wait) the next few calls on this handle do
+  // not try the persistent kernels again
+  const bool unordered_ok = rcm_unordered() && h->rcm_gb_backoff == 0;
+  if (h->rcm_gb_backoff > 0) h->rcm_gb_backoff--;
+  // The degree counts (non-empty rows, largest degree, first non-empty vertex) are read back with the first sweep's first
+  // round trip when that sweep is an unordered one: it starts from dv->root, which k_deg_reduce set, and needs nothing
+  // else the host does not know yet.  (~17 us per call: a read-back kernel and a launch gap.)
+  // (only with the side stream: without one the degree ranks are enqueued before the first sweep and need the counts)
+  const bool lazy_counts = unordered_ok && !h->prof_on && rcm_overlap();
   RcmDev hd0;
-  SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
-  const int64_t n_ranked = (int64_t)hd0.n_nonempty;  // vertices that get a degree rank
+  bool hd0_ready = false;
+  if (!lazy_counts) {
+    SBX_TRY(sbx_readback(h, &hd0, dv, sizeof(RcmDev)));
+    hd0_ready = true;
+  }
+  int64_t n_ranked = hd0_ready ? (int64_t)hd0.n_nonempty : 0;  // vertices that get a degree rank
   // Only the Cuthill-McKee sweep reads the degree ranks: they are built on a side stream while the plain sweeps —
   // launch- and latency-bound — run on the caller's stream, and joined before the first Cuthill-McKee sweep.
   const uint32_t *dorder = nullptr;
@@ -3544,7 +3566,9 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     int rc = SBX_OK;
     // one stable counting pass on min(degree, 255) over the rows in id order + the last bucket by its full degree
     // (sbx_degree.hip): 0.09 ms where a generic sort of (degree, id) pairs took 0.31
-    rc = sbx_degree_ranks(h, SBX_RCM_IT, rp, n, n_ranked, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
+    // (hd0 — not the locals derived from it: this hook may run inside the first sweep, right behind the read-back that
+    // delivered the counts)
+    rc = sbx_degree_ranks(h, SBX_RCM_IT, rp, n, (int64_t)hd0.n_nonempty, (int64_t)hd0.n_top, hd0.max_deg, drank, did_a);
     dorder = did_a;
     b.dorder = dorder;
     if (side && rc == SBX_OK && hipEventRecord(h->aux_event[1], h->stream) != hipSuccess) rc = SBX_ERR_HIP;
@@ -3577,15 +3601,15 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 + 1, &b.wcnt));
   SBX_TRY(sbx_salloc(h, (size_t)(n + 63) / 64 / RCM_FW_WORDS + 2, &b.woff));
   SBX_TRY(sbx_salloc(h, sbx_cs::scratch_words(std::min<int64_t>(n, RCM_COUNT_SORT_MAX)), &b.cs_scratch));
-  b.max_deg = hd0.max_deg;
+  b.max_deg = hd0_ready ? hd0.max_deg : 0u;
+  b.late_counts = hd0_ready ? nullptr : &hd0;
+  b.late_counts_ready = &hd0_ready;
   // (2) The smallest non-isolated vertex v0 is the smallest id of its component, i.e. the
   // start of that component's pseudo-peripheral search.  Its first BFS sweep is needed
   // anyway and yields the component's membership for free, so the union-find below only
   // has to label what that sweep did not reach (for power-law inputs: a sliver).
-  const I v0 = hd0.first_vertex == UNSEEN ? (I)-1 : (I)hd0.first_vertex;
   BfsResult r0;
   r0.count = 0;
-  if (v0 < 0) SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));  // (else: a copy of the first sweep's visited bitmap)
   // sweeps of the pseudo-peripheral search run unordered (level sets only, run_ubfs) unless the component turns out
   // deep and narrow
   unsigned char *claim8 = nullptr;
@@ -3594,16 +3618,24 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &nbits));
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
   bool r0_unordered = false;
-  // after a grid barrier gave up (a GPU shared with another process, see gb_wait) the next few calls on this handle do
-  // not try the persistent kernels again
-  const bool unordered_ok = rcm_unordered() && h->rcm_gb_backoff == 0;
-  if (h->rcm_gb_backoff > 0) h->rcm_gb_backoff--;
+  bool deep0 = true;
+  if (!hd0_ready) {  // the first sweep, from the root on the device; the counts come back with its first read-back
+    SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, (I)-1, (I)-1, &r0, &deep0));
+    if (!hd0_ready) SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_rcm_reorder: the first sweep returned without a read-back");
+    n_ranked = (int64_t)hd0.n_nonempty;
+    b.n_ranked = n_ranked;
+    b.max_deg = hd0.max_deg;
+    b.late_counts = nullptr;
+  }
+  const I v0 = hd0.first_vertex == UNSEEN ? (I)-1 : (I)hd0.first_vertex;
+  if (v0 < 0) {  // not one edge: the sweep above (if any) started from an empty row and means nothing
+    r0.count = 0;
+    deep0 = true;
+    SBX_HIP(h, hipMemsetAsync(cbits, 0, bm_bytes, h->stream));  // (else: a copy of the first sweep's visited bitmap)
+  }
   if (v0 >= 0) {
-    bool deep = true;
-    if (unordered_ok) {
-      SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, v0, (I)-1, &r0, &deep));
-      r0_unordered = !deep;
-    }
+    bool deep = deep0;
+    r0_unordered = !deep;
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
     SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
   }
