@@ -2288,6 +2288,7 @@ static double ubu_ratio() {
 }
 
 constexpr unsigned UR_GRID = 64;
+constexpr unsigned UR_CONTINUE = 0, UR_DONE = 1, UR_STOP = 2, UR_DEEP = 3;  // how a persistent run ended (DEEP: too many levels in one launch)
 constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
 constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
 // what the next kernel of a device-driven chain is to be: nothing more (the sweep is over), a bottom-up level, the
@@ -2746,8 +2747,13 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const X *__restrict__ 
                                                           const unsigned *__restrict__ vbits,
                                                           const unsigned *__restrict__ dist,
                                                           const unsigned *__restrict__ cone, unsigned levels,
-                                                          RcmDev *dv) {
+                                                          RcmDev *dv, int behind_cone_run) {
   if (dv->tie_done) return;  // (one candidate: k_ubfs_ties_small has named the next root)
+  // launched straight behind k_ubfs_cone_run, before the host has seen how that ended: only a finished cone is walked
+  // (written by the kernel in front or, gb_abort, through agent-scope atomics: the same for every workgroup)
+  if (behind_cone_run && (dv->cone_status != UR_DONE || dv->unsym ||
+                          __hip_atomic_load(&dv->gb_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+    return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     __hip_atomic_store(&dv->desc[0], dv->root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&dv->desc[1], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2820,7 +2826,6 @@ __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
 #define SBX_UR_HEAVY 2048
 #endif
 constexpr unsigned UR_HEAVY = SBX_UR_HEAVY;  // frontier vertices above this degree are scanned by the whole grid
-constexpr unsigned UR_CONTINUE = 0, UR_DONE = 1, UR_STOP = 2, UR_DEEP = 3;  // DEEP: too many levels in one launch
 
 template <typename T>
 __device__ __forceinline__ T ur_load(const T *p) {
@@ -2999,6 +3004,15 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const X *__restrict__ rp
 // The frontier bitmap of an unordered sweep rebuilt from what every level kernel leaves behind — frontier = visited
 // vertices at distance `level` — in one streaming pass that writes every word (a fill of the bitmap + a scatter of the
 // frontier's bits were four launches: hipMemsetAsync splits into three).  Unvisited vertices may hold stale distances.
+// (a 512 KB device-to-device hipMemcpyAsync costs the host ~25 us of enqueueing around a 4 us blit: on the call's
+// latency chain, between the first sweep and its tie-break)
+__global__ __launch_bounds__(256) void k_copy_words(unsigned *__restrict__ dst, const unsigned *__restrict__ src,
+                                                    int64_t words) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < words; i += stride) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_ubfs_fbits_from_dist(const unsigned *__restrict__ vbits,
                                                               const unsigned *__restrict__ dist, unsigned level,
                                                               int64_t n, unsigned *__restrict__ fbits) {
@@ -3405,16 +3419,20 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   for (unsigned k = r.levels - 1; k >= 2;) {  // level 0 is the root: every T_1 member hangs under it
     SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_cone_run, dim3(UR_GRID), dim3(256), b.rp, b.col, (const unsigned *)b.vbits,
                 (const unsigned *)b.lpos, cone, list, (I *)b.heavy, b.dv, k);
+    // the walk down the cone goes out behind it at once: it runs if the cone is finished (the usual end of this loop) and
+    // leaves otherwise — one round trip for both instead of one each
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
+                (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv, 1);
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(bfs_first_launch(b, 40));
-    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
     if (hd.gb_abort) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_gb_reset, dim3(1), dim3(1), b.dv);
       h->rcm_gb_backoff = gb_backoff_calls();
       *aborted = true;
       return SBX_OK;
     }
-    if (hd.cone_status == UR_DONE || hd.unsym) break;
+    if (hd.cone_status == UR_DONE || hd.unsym) return SBX_OK;
     k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
     SBX_KLAUNCH(h, SBX_K_BFS_EXPAND, k_bfs_expand<2>, dim3(cone_grid), dim3(256), b.rp, b.col, (const I *)list, 0u, k,
@@ -3427,7 +3445,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     k--;
   }
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_descend_all, dim3(UB_DESC_GRID), dim3(256), b.rp, b.col,
-              (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv);
+              (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const unsigned *)cone, r.levels, b.dv, 0);
   SBX_LAUNCH_CHECK(h);
   SBX_TRY(bfs_first_launch(b, 40));
   SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));  // (the walk must be known to have finished: see gb_wait)
@@ -3637,7 +3655,9 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     bool deep = deep0;
     r0_unordered = !deep;
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
-    SBX_HIP(h, hipMemcpyAsync(cbits, vbits, bm_bytes, hipMemcpyDeviceToDevice, h->stream));
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_copy_words, dim3(sbx_grid_for((int64_t)(bm_bytes / sizeof(unsigned)), 256, 1024)),
+                dim3(256), cbits, (const unsigned *)vbits, (int64_t)(bm_bytes / sizeof(unsigned)));
+    SBX_LAUNCH_CHECK(h);
   }
   // Pseudo-peripheral search and Cuthill-McKee sweep of one host-ordered component (root = its smallest vertex): leaves
   // the component's order in q.
