@@ -17,7 +17,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -52,6 +54,115 @@ inline void GrayParallelFor(int64_t count, F f) {
   for (auto &t : pool) t.join();
   for (auto &e : errors)
     if (e) std::rethrow_exception(e);
+}
+
+// std::sort(first, last, comp) as libstdc++ runs it, with the two sides of its partitions on different threads.
+// The reference's orderings are whatever libstdc++'s introsort leaves on heavily tied keys (gray_reorder.cc:199-203 sorts
+// 4 M row ids by degree alone), so the exact mode cannot use another algorithm — but introsort's recursion works on
+// disjoint ranges: std::__introsort_loop partitions [first, last) around a pivot, recurses into the right part and loops
+// on the left one.  Here that loop is the library's own code path by path (std::__unguarded_partition_pivot,
+// std::__partial_sort at the depth limit, std::__introsort_loop itself below the grain), only the recursive call goes
+// to a pool; std::__final_insertion_sort closes as in std::sort.  Same comparisons on the same elements in every range,
+// hence the same permutation: compared with std::sort on tied, sorted, reversed and random inputs by
+// host/tests/test_host_logic.cc (GraySort.ParallelReplicaOfStdSort).  Other standard libraries: plain std::sort.
+#if defined(__GLIBCXX__)
+template <typename It, typename WrappedCompare>
+class GrayIntroSortPool {
+ public:
+  GrayIntroSortPool(WrappedCompare comp, int64_t grain) : comp_(comp), grain_(grain) {}
+  void Run(It first, It last, unsigned threads) {
+    Push(first, last, (long)std::__lg(last - first) * 2);
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < threads; i++) pool.emplace_back([this]() { Work(); });
+    for (auto &t : pool) t.join();
+    if (error_) std::rethrow_exception(error_);
+  }
+
+ private:
+  struct Task {
+    It first, last;
+    long depth_limit;
+  };
+  void Push(It first, It last, long depth_limit) {
+    pending_++;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      queue_.push_back(Task{first, last, depth_limit});
+    }
+    cv_.notify_one();
+  }
+  void Loop(It first, It last, long depth_limit) {  // std::__introsort_loop, its recursive call handed to the pool
+    while (last - first > 16) {                     // (_S_threshold)
+      if (last - first <= grain_) {
+        std::__introsort_loop(first, last, depth_limit, comp_);
+        return;
+      }
+      if (depth_limit == 0) {
+        std::__partial_sort(first, last, last, comp_);
+        return;
+      }
+      --depth_limit;
+      It cut = std::__unguarded_partition_pivot(first, last, comp_);
+      Push(cut, last, depth_limit);
+      last = cut;
+    }
+  }
+  void Work() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this]() { return done_ || !queue_.empty(); });
+        if (queue_.empty()) return;
+        t = queue_.back();
+        queue_.pop_back();
+      }
+      try {
+        Loop(t.first, t.last, t.depth_limit);
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+      if (--pending_ == 0) {
+        std::lock_guard<std::mutex> g(mu_);
+        done_ = true;
+        cv_.notify_all();
+      }
+    }
+  }
+  WrappedCompare comp_;
+  const int64_t grain_;
+  std::atomic<int64_t> pending_{0};
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Task> queue_;
+  bool done_ = false;
+  std::exception_ptr error_;
+};
+#endif
+
+/// grain: ranges up to this many elements are sorted by the calling task (0: chosen from the size and the threads)
+template <typename It, typename Compare>
+inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0, int64_t grain = 0) {
+#if defined(__GLIBCXX__)
+  const int64_t count = last - first;
+  if (threads == 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    threads = std::min<unsigned>(hw ? hw : 1u, 16u);
+  }
+  if (grain <= 0) grain = std::max<int64_t>((int64_t)1 << 15, count / ((int64_t)threads * 8));
+  if (threads <= 1 || count <= grain) {
+    std::sort(first, last, comp);
+    return;
+  }
+  auto wrapped = __gnu_cxx::__ops::__iter_comp_iter(comp);
+  GrayIntroSortPool<It, decltype(wrapped)> pool(wrapped, grain);
+  pool.Run(first, last, threads);
+  std::__final_insertion_sort(first, last, wrapped);
+#else
+  (void)threads, (void)grain;
+  std::sort(first, last, comp);
+#endif
 }
 }  // namespace detail
 
@@ -182,7 +293,7 @@ class GrayReorder : public Reorderer<IDType> {
           std::vector<row_grey_pair> d;
           d.reserve(dense_rows.size());
           for (IDType r : dense_rows) d.push_back(row_grey_pair(r, (unsigned long)key[r]));
-          std::sort(d.begin(), d.end(), asc_comparator);
+          detail::GrayIntroSort(d.begin(), d.end(), asc_comparator);
           for (size_t a = 0; a < dense_rows.size(); a++) dense_rows[a] = d[a].first;
         } catch (...) {
           dense_error = std::current_exception();
@@ -205,7 +316,7 @@ class GrayReorder : public Reorderer<IDType> {
           for (int64_t a = a0; a < a1; a++)
             byd[(size_t)a] = ((uint32_t)deg[sparse_rows[(size_t)a]] << 24) | (uint32_t)sparse_rows[(size_t)a];
         });
-        std::sort(byd.begin(), byd.end(), [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); });
+        detail::GrayIntroSort(byd.begin(), byd.end(), [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); });
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
           for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = (IDType)(byd[(size_t)a] & 0xFFFFFFu);
         });
@@ -215,7 +326,7 @@ class GrayReorder : public Reorderer<IDType> {
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
           for (int64_t a = a0; a < a1; a++) byd[(size_t)a] = deg_row(deg[sparse_rows[(size_t)a]], sparse_rows[(size_t)a]);
         });
-        std::sort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
+        detail::GrayIntroSort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
           for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = byd[(size_t)a].second;
         });
@@ -261,8 +372,10 @@ class GrayReorder : public Reorderer<IDType> {
         section.reserve((size_t)(sc.end - sc.start));
         for (int64_t a = sc.start; a < sc.end; a++)
           section.push_back(row_grey_pair(sparse_rows[a], (unsigned long)key[sparse_rows[a]]));
-        if (!sc.descending) std::sort(section.begin(), section.end(), asc_comparator);
-        else std::sort(section.begin(), section.end(), desc_comparator);
+        // (a section of a million rows — the rows of one entry of a power-law matrix — is the pool's longest job)
+        const unsigned th = sc.end - sc.start >= ((int64_t)1 << 18) ? 0u : 1u;  // (1: plain std::sort)
+        if (!sc.descending) detail::GrayIntroSort(section.begin(), section.end(), asc_comparator, th);
+        else detail::GrayIntroSort(section.begin(), section.end(), desc_comparator, th);
         for (int64_t a = sc.start; a < sc.end; a++) sparse_rows[a] = section[a - sc.start].first;
       };
       const unsigned hw = std::thread::hardware_concurrency();

@@ -224,6 +224,55 @@ TEST(Format, OwnershipAndCasting) {
   EXPECT_TRUE(cpu.IsEquivalent(borrowed.get_context()));
 }
 
+// The exact Gray mode's sorts must leave what libstdc++'s std::sort leaves (ties included): the threaded form against
+// the library call on the kinds of input the reorderer sorts, with grains small enough to split every range many times.
+TEST(GraySort, ParallelReplicaOfStdSort) {
+  unsigned long long state = 88172645463325252ull;
+  auto rnd = [&state]() {
+    state ^= state << 13, state ^= state >> 7, state ^= state << 17;
+    return state;
+  };
+  auto by_degree = [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); };
+  typedef std::pair<int, unsigned long> row_key;
+  auto asc = [](const row_key &l, const row_key &r) -> bool { return l.second < r.second; };
+  auto desc = [](const row_key &l, const row_key &r) -> bool { return l.second > r.second; };
+  int differing = 0;
+  for (int round = 0; round < 60; round++) {
+    const size_t count = round < 4 ? (size_t)round * 8 : 1 + (size_t)(rnd() % 200000);
+    const unsigned distinct = 1u + (unsigned)(rnd() % (round % 3 == 0 ? 3 : round % 3 == 1 ? 200 : 1u << 20));
+    const int64_t grain = round % 2 ? 64 : 1 + (int64_t)(rnd() % 5000);
+    const unsigned threads = 2 + (unsigned)(rnd() % 7);
+    std::vector<uint32_t> packed(count);
+    for (size_t i = 0; i < count; i++) packed[i] = ((uint32_t)(rnd() % distinct % 256) << 24) | (uint32_t)(i & 0xFFFFFF);
+    if (round % 7 == 0) std::sort(packed.begin(), packed.end());
+    if (round % 11 == 0) std::reverse(packed.begin(), packed.end());
+    std::vector<uint32_t> expect = packed;
+    std::sort(expect.begin(), expect.end(), by_degree);
+    reorder::detail::GrayIntroSort(packed.begin(), packed.end(), by_degree, threads, grain);
+    differing += packed != expect;
+    std::vector<row_key> pairs(count);
+    for (size_t i = 0; i < count; i++) pairs[i] = row_key((int)i, (unsigned long)(rnd() % distinct));
+    std::vector<row_key> expect_pairs = pairs;
+    if (round % 2) {
+      std::sort(expect_pairs.begin(), expect_pairs.end(), asc);
+      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), asc, threads, grain);
+    } else {
+      std::sort(expect_pairs.begin(), expect_pairs.end(), desc);
+      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), desc, threads, grain);
+    }
+    differing += pairs != expect_pairs;
+  }
+  EXPECT_EQ(differing, 0);
+  // an adversarial input for the median-of-three pivot drives introsort to its depth limit (heap sort of the range)
+  std::vector<uint32_t> killer(1 << 16), killer_expect;
+  for (size_t i = 0; i < killer.size(); i++)
+    killer[i] = (uint32_t)((i % 2 ? i : killer.size() - i) % 251) << 24 | (uint32_t)i;
+  killer_expect = killer;
+  std::sort(killer_expect.begin(), killer_expect.end(), by_degree);
+  reorder::detail::GrayIntroSort(killer.begin(), killer.end(), by_degree, 4, 32);
+  EXPECT_TRUE(killer == killer_expect);
+}
+
 TEST(Device, FailsLoudlyWithoutAGpu) {
   if (hip::DeviceCount() > 0) return;  // only meaningful in the CPU-only container
   EXPECT_THROW(context::HIPContext bad(0), utils::HIPDeviceException);
