@@ -148,6 +148,8 @@ int main(int argc, char **argv) {
     std::printf("%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (kind == "gray") {  // the stages of that call: device key stage, keys to the host, host ordering (ms)
       const double *st = reorder::GrayReorder<int, int, void>::last_stage_ms();
+      std::fprintf(stderr, "gray host stage (ms): split %.2f, sort by degree %.2f, sections %.2f, dense rows + order %.2f\n", st[3],
+                   st[4], st[5], st[6]);
       std::printf("%.4f %.4f %.4f\n", st[0], st[1], st[2]);
     }
   }

@@ -62,7 +62,7 @@ inline void GrayParallelFor(int64_t count, F f) {
 // disjoint ranges: std::__introsort_loop partitions [first, last) around a pivot, recurses into the right part and loops
 // on the left one.  Here that loop is the library's own code path by path (std::__unguarded_partition_pivot,
 // std::__partial_sort at the depth limit, std::__introsort_loop itself below the grain), only the recursive call goes
-// to a pool; std::__final_insertion_sort closes as in std::sort.  Same comparisons on the same elements in every range,
+// to a pool; the closing insertion sort (std::__final_insertion_sort) runs piecewise between the tasks' cuts.  Same comparisons on the same elements in every range,
 // hence the same permutation: compared with std::sort on tied, sorted, reversed and random inputs by
 // host/tests/test_host_logic.cc (GraySort.ParallelReplicaOfStdSort).  Other standard libraries: plain std::sort.
 #if defined(__GLIBCXX__)
@@ -74,6 +74,24 @@ class GrayIntroSortPool {
     Push(first, last, (long)std::__lg(last - first) * 2);
     std::vector<std::thread> pool;
     for (unsigned i = 0; i < threads; i++) pool.emplace_back([this]() { Work(); });
+    for (auto &t : pool) t.join();
+    if (error_) std::rethrow_exception(error_);
+    // std::__final_insertion_sort: one stable insertion sort over everything.  No element crosses a partition's cut (what
+    // lies left of it does not compare greater than what lies right of it), so the pieces between the cuts the tasks were
+    // split at are insertion-sorted on their own, concurrently, to the same result.
+    cuts_.push_back(last);
+    std::sort(cuts_.begin(), cuts_.end());
+    std::atomic<size_t> next{0};
+    pool.clear();
+    for (unsigned i = 0; i < threads; i++)
+      pool.emplace_back([this, &next]() {
+        try {
+          for (size_t k = next++; k + 1 < cuts_.size(); k = next++) std::__insertion_sort(cuts_[k], cuts_[k + 1], comp_);
+        } catch (...) {
+          std::lock_guard<std::mutex> g(mu_);
+          if (!error_) error_ = std::current_exception();
+        }
+      });
     for (auto &t : pool) t.join();
     if (error_) std::rethrow_exception(error_);
   }
@@ -88,6 +106,7 @@ class GrayIntroSortPool {
     {
       std::lock_guard<std::mutex> g(mu_);
       queue_.push_back(Task{first, last, depth_limit});
+      cuts_.push_back(first);
     }
     cv_.notify_one();
   }
@@ -136,6 +155,7 @@ class GrayIntroSortPool {
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<Task> queue_;
+  std::vector<It> cuts_;  // where a range was split between two tasks (and the start of the whole)
   bool done_ = false;
   std::exception_ptr error_;
 };
@@ -158,7 +178,6 @@ inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0,
   auto wrapped = __gnu_cxx::__ops::__iter_comp_iter(comp);
   GrayIntroSortPool<It, decltype(wrapped)> pool(wrapped, grain);
   pool.Run(first, last, threads);
-  std::__final_insertion_sort(first, last, wrapped);
 #else
   (void)threads, (void)grain;
   std::sort(first, last, comp);
@@ -196,9 +215,10 @@ class GrayReorder : public Reorderer<IDType> {
   }
   /// Wall time of the last call's stages in this process, in ms: the device key stage (sbx_gray_row_keys, which ends
   /// with a blocking read-back), the copy of degrees and keys to the host, the host ordering stage.  (Not in the
-  /// reference: what bench.py reports as Gray end to end.)
+  /// reference: what bench.py reports as Gray end to end.)  [3..6]: the host stage's parts — sparse / dense split, the
+  /// sort by degree, the sections (walk and sorts), joining the dense rows' sort and writing the order.
   static double *last_stage_ms() {
-    static thread_local double ms[3] = {0, 0, 0};  // (per thread: concurrent reorder calls do not share it)
+    static thread_local double ms[7] = {0, 0, 0, 0, 0, 0, 0};  // (per thread: concurrent reorder calls do not share it)
     return ms;
   }
 
@@ -277,6 +297,8 @@ class GrayReorder : public Reorderer<IDType> {
         }
       });
     }
+    last_stage_ms()[3] = ms_since(t_host);
+    auto t_part = clock::now();
     // the reference keeps these counters in `int` (gray_reorder.cc:134-137)
     const bool sparse_banded = double((int)counts[1]) / (int)counts[0] > 0.3;
     const bool dense_banded = double((int)counts[3]) / (int)counts[2] > 0.2;
@@ -290,11 +312,14 @@ class GrayReorder : public Reorderer<IDType> {
     if (!dense_banded && !dense_rows.empty()) {
       dense_thread = std::thread([&]() {
         try {
-          std::vector<row_grey_pair> d;
-          d.reserve(dense_rows.size());
-          for (IDType r : dense_rows) d.push_back(row_grey_pair(r, (unsigned long)key[r]));
+          std::vector<row_grey_pair> d(dense_rows.size());
+          detail::GrayParallelFor((int64_t)d.size(), [&](int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++) d[(size_t)a] = row_grey_pair(dense_rows[(size_t)a], (unsigned long)key[dense_rows[(size_t)a]]);
+          });
           detail::GrayIntroSort(d.begin(), d.end(), asc_comparator);
-          for (size_t a = 0; a < dense_rows.size(); a++) dense_rows[a] = d[a].first;
+          detail::GrayParallelFor((int64_t)d.size(), [&](int64_t a0, int64_t a1) {
+            for (int64_t a = a0; a < a1; a++) dense_rows[(size_t)a] = d[(size_t)a].first;
+          });
         } catch (...) {
           dense_error = std::current_exception();
         }
@@ -304,11 +329,13 @@ class GrayReorder : public Reorderer<IDType> {
       std::thread &t;
       ~JoinGuard() { if (t.joinable()) t.join(); }
     } dense_guard{dense_thread};
+    std::vector<IDType> sorted_deg;
     {
       // gray_reorder.cc:199-203: std::sort of the row ids by degree.  The (degree, id) pairs are sorted instead, with a
       // comparator that looks at the degree only: every comparison answers what `deg[a] < deg[b]` answers, so the
       // elements make the same moves, without two dependent loads per comparison.
       const int64_t ns0 = (int64_t)sparse_rows.size();
+      sorted_deg.resize((size_t)ns0);  // (the section walk below reads the degrees in this order)
       if (params->nnz_threshold < 256 && n <= ((int64_t)1 << 24)) {
         // ... packed into ONE 32-bit word when they fit (degree << 24 | row): half the bytes to move, the same moves
         std::vector<uint32_t> byd((size_t)ns0);
@@ -318,7 +345,10 @@ class GrayReorder : public Reorderer<IDType> {
         });
         detail::GrayIntroSort(byd.begin(), byd.end(), [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); });
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
-          for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = (IDType)(byd[(size_t)a] & 0xFFFFFFu);
+          for (int64_t a = a0; a < a1; a++) {
+            sparse_rows[(size_t)a] = (IDType)(byd[(size_t)a] & 0xFFFFFFu);
+            sorted_deg[(size_t)a] = (IDType)(byd[(size_t)a] >> 24);
+          }
         });
       } else {
         typedef std::pair<IDType, IDType> deg_row;  // (degree, row)
@@ -328,10 +358,15 @@ class GrayReorder : public Reorderer<IDType> {
         });
         detail::GrayIntroSort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
-          for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)a] = byd[(size_t)a].second;
+          for (int64_t a = a0; a < a1; a++) {
+            sparse_rows[(size_t)a] = byd[(size_t)a].second;
+            sorted_deg[(size_t)a] = byd[(size_t)a].first;
+          }
         });
       }
     }
+    last_stage_ms()[4] = ms_since(t_part);
+    t_part = clock::now();
 
     if (!sparse_banded) {
       struct Section { int64_t start, end; bool descending; };
@@ -346,14 +381,14 @@ class GrayReorder : public Reorderer<IDType> {
         descending = !descending;
       };
       for (int64_t i = 0; i < ns; i++) {
-        const IDType d = deg[sparse_rows[i]];
+        const IDType d = sorted_deg[(size_t)i];
         if (i == 0) {
           last_deg = d;
           start = 0;
         }
         if (d == 0) {  // empty rows never enter a section
           start = i + 1;
-          if (i + 1 < ns) last_deg = deg[sparse_rows[i + 1]];
+          if (i + 1 < ns) last_deg = sorted_deg[(size_t)i + 1];
           continue;
         }
         if (i != 0 && last_deg != d) {
@@ -368,15 +403,18 @@ class GrayReorder : public Reorderer<IDType> {
         if (i == ns - 1) flush(ns);
       }
       auto sort_section = [&](const Section &sc) {
-        std::vector<row_grey_pair> section;
-        section.reserve((size_t)(sc.end - sc.start));
-        for (int64_t a = sc.start; a < sc.end; a++)
-          section.push_back(row_grey_pair(sparse_rows[a], (unsigned long)key[sparse_rows[a]]));
+        std::vector<row_grey_pair> section((size_t)(sc.end - sc.start));
+        detail::GrayParallelFor(sc.end - sc.start, [&](int64_t a0, int64_t a1) {  // (one piece below 64 K rows)
+          for (int64_t a = a0; a < a1; a++)
+            section[(size_t)a] = row_grey_pair(sparse_rows[(size_t)(sc.start + a)], (unsigned long)key[sparse_rows[(size_t)(sc.start + a)]]);
+        });
         // (a section of a million rows — the rows of one entry of a power-law matrix — is the pool's longest job)
         const unsigned th = sc.end - sc.start >= ((int64_t)1 << 18) ? 0u : 1u;  // (1: plain std::sort)
         if (!sc.descending) detail::GrayIntroSort(section.begin(), section.end(), asc_comparator, th);
         else detail::GrayIntroSort(section.begin(), section.end(), desc_comparator, th);
-        for (int64_t a = sc.start; a < sc.end; a++) sparse_rows[a] = section[a - sc.start].first;
+        detail::GrayParallelFor(sc.end - sc.start, [&](int64_t a0, int64_t a1) {
+          for (int64_t a = a0; a < a1; a++) sparse_rows[(size_t)(sc.start + a)] = section[(size_t)a].first;
+        });
       };
       const unsigned hw = std::thread::hardware_concurrency();
       const size_t workers = std::min<size_t>(sections.size(), std::min<unsigned>(hw ? hw : 1u, 16u));
@@ -399,6 +437,8 @@ class GrayReorder : public Reorderer<IDType> {
           if (e) std::rethrow_exception(e);
       }
     }
+    last_stage_ms()[5] = ms_since(t_part);
+    t_part = clock::now();
     if (dense_thread.joinable()) dense_thread.join();
     if (dense_error) std::rethrow_exception(dense_error);
     IDType *order = new IDType[n > 0 ? n : 1]();
@@ -407,6 +447,7 @@ class GrayReorder : public Reorderer<IDType> {
       for (int64_t pos = p0; pos < p1; pos++)
         order[pos < ns_all ? sparse_rows[(size_t)pos] : dense_rows[(size_t)(pos - ns_all)]] = (IDType)pos;
     });
+    last_stage_ms()[6] = ms_since(t_part);
     return order;
   }
   static IDType *GrayReorderingCSR(std::vector<format::Format *> formats, utils::Parameters *params) {

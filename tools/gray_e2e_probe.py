@@ -25,6 +25,9 @@ for name, make in cases.items():
         lines = p.stdout.strip().splitlines()
         r["gpu_path_s"] = float(lines[-2])
         r["stages_ms(device keys, keys to host, host ordering)"] = [float(x) for x in lines[-1].split()]
+        host = [l for l in p.stderr.splitlines() if l.startswith("gray host stage")]
+        if host:
+            r["host_stage"] = host[-1]
         got = np.fromfile(o, np.int32)
         if ref is not None:
             t = time.perf_counter(); want = ref.gray_reorder(rp, col, n, *params); r["reference_s"] = round(time.perf_counter() - t, 3)
