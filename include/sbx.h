@@ -284,6 +284,8 @@ typedef struct sbx_rcm_stats {
   int64_t largest_component;
   int64_t reference_sweeps; /* sweeps the reference's serial algorithm runs over the largest component:
                                pseudo-peripheral iterations (rcm_reorder.cc:34) + 1 — the B of the roofline figure */
+  int64_t unordered_sweeps; /* sweeps of the pseudo-peripheral search (over all components the host orders) that kept
+                               the level SETS only; 0 when every sweep kept the order inside its levels */
 } sbx_rcm_stats;
 int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz,
                     const void *row_ptr, const void *col, void *inv_perm_out,

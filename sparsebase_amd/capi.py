@@ -29,7 +29,7 @@ class SbxError(RuntimeError):
 class RcmStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("components", "isolated", "small_components", "large_components",
                                          "bfs_sweeps", "bfs_levels", "edges_scanned", "edges_scanned_bottom_up",
-                                         "largest_component", "reference_sweeps")]
+                                         "largest_component", "reference_sweeps", "unordered_sweeps")]
 
 
 # every symbol include/sbx.h declares (tests/test_abi.py checks header <-> library <-> this table)

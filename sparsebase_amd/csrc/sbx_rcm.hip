@@ -3637,6 +3637,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   SBX_TRY(sbx_salloc(h, (size_t)(bm_bytes / sizeof(unsigned)) + 2, &cone));
   bool r0_unordered = false;
   bool deep0 = true;
+  int64_t unordered_sweeps = 0;  // sweeps that kept the level sets only (statistics; the tests check the path was taken)
   if (!hd0_ready) {  // the first sweep, from the root on the device; the counts come back with its first read-back
     SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, (I)-1, (I)-1, &r0, &deep0));
     if (!hd0_ready) SBX_FAIL(h, SBX_ERR_INTERNAL, "sbx_rcm_reorder: the first sweep returned without a read-back");
@@ -3653,7 +3654,9 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   }
   if (v0 >= 0) {
     bool deep = deep0;
+    if (!lazy_counts && unordered_ok) SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, v0, (I)-1, &r0, &deep));
     r0_unordered = !deep;
+    unordered_sweeps += r0_unordered;
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_copy_words, dim3(sbx_grid_for((int64_t)(bm_bytes / sizeof(unsigned)), 256, 1024)),
                 dim3(256), cbits, (const unsigned *)vbits, (int64_t)(bm_bytes / sizeof(unsigned)));
@@ -3703,6 +3706,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
         if (!deep) {
           SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, root, &r, &deep));
           unordered = !deep;
+          unordered_sweeps += unordered;
         }
         if (deep) SBX_TRY(run_bfs<false>(h, b, fixed, root, &r));
       }
@@ -3960,6 +3964,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     stats_host->components = (int64_t)hd.n_components;
     stats_host->isolated = (int64_t)hd.n_empty_rows;
     stats_host->reference_sweeps = ref_sweeps_max;
+    stats_host->unordered_sweeps = unordered_sweeps;
   }
   return SBX_OK;
 }

@@ -1506,9 +1506,17 @@ def test_rcm_sweep_variants_in_a_child(mode):
         "cases = [synth.rmat_symmetric(16, 8, seed=3), synth.rmat_symmetric(14, 3, seed=5), synth.rmat_symmetric(19, 12, seed=2),\n"
         "         synth.random_symmetric_graph(30000, avg_deg=3, seed=2, n_blocks=3, isolated_frac=0.1),\n"
         "         synth.banded_symmetric(40000, 6, per_row=4, seed=1), synth.grid_graph(150, 150, shuffle_seed=4)]\n"
+        "took = []\n"
         "for rp, col in cases:\n"
-        "    assert np.array_equal(ops.rcm_reorder(d(rp), d(col)).cpu().numpy(), orc.rcm_reorder(rp, col))\n"
-        "print('rcm variant ok')\n" % (root, os.path.join(root, "tests")))
+        "    got, stats = ops.rcm_reorder(d(rp), d(col), return_stats=True)\n"
+        "    assert np.array_equal(got.cpu().numpy(), orc.rcm_reorder(rp, col))\n"
+        "    took.append(stats['unordered_sweeps'])\n"
+        "ops.profile_enable(True)  # (a call under the handle's profiler runs without side streams)\n"
+        "got, stats = ops.rcm_reorder(d(cases[0][0]), d(cases[0][1]), return_stats=True)\n"
+        "ops.profile_enable(False)\n"
+        "assert np.array_equal(got.cpu().numpy(), orc.rcm_reorder(*cases[0]))\n"
+        "print('rcm variant ok', 'unordered sweeps:', took, 'profiled:', stats['unordered_sweeps'])\n"
+        % (root, os.path.join(root, "tests")))
     extra = {"barriers_give_up": {"SBX_DEBUG_GB_SPINS": "0"}, "ordered_sweeps": {"SBX_RCM_UNORDERED": "0"},
              "unordered_everywhere": {"SBX_DEBUG_UB_MAX_LEVELS": "1000000"},
              "bottom_up_early": {"SBX_DEBUG_BU_RATIO": "0.3", "SBX_RCM_UNORDERED": "0"},
@@ -1518,6 +1526,20 @@ def test_rcm_sweep_variants_in_a_child(mode):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "rcm variant ok" in r.stdout, r.stdout + r.stderr
+    # which sweeps ran (sbx_rcm_stats.unordered_sweeps): the power-law graphs' searches are unordered wherever the mode
+    # allows it — with and without side streams, under the profiler — and never where it does not (a build that quietly
+    # fell back to ordered sweeps without its side stream still produced the right orders)
+    line = [l for l in r.stdout.splitlines() if l.startswith("rcm variant ok")][-1]
+    took = eval(line.split("unordered sweeps:")[1].split("profiled:")[0])
+    profiled = int(line.split("profiled:")[1])
+    if mode in ("ordered_sweeps", "bottom_up_early", "barriers_give_up"):
+        assert took == [0] * len(took) and profiled == 0, line
+    elif mode == "chain_tail_gives_up":
+        assert len(took) == 6, line  # (sweeps are thrown away at the chain's tail: how many survive is not fixed)
+    else:
+        assert all(t >= 1 for t in took[:3]) and profiled >= 1, line
+    if mode == "unordered_everywhere":
+        assert all(t >= 1 for t in took), line
 
 
 @pytest.mark.parametrize("spins", [1, 2, 3, 5, 8, 13, 21, 34])
