@@ -19,5 +19,5 @@ python3 tools/timeline.py /tmp/c2b_kt k_coo_is_sorted --all > gpurun_out/r5_sort
 python tools/c4_probe.py > gpurun_out/r5_c4_probe.json 2> gpurun_out/r5_c4_probe.err
 python tools/ops_table.py --gpu-only > gpurun_out/r5_ops_table.txt 2>&1
 python tools/int64_probe.py > gpurun_out/r5_int64_probe.log 2>&1
-python tools/gray_e2e_probe.py > gpurun_out/r5_gray_e2e.json 2>&1
+python tools/gray_e2e_probe.py > gpurun_out/r5_gray_e2e.json 2> gpurun_out/r5_gray_e2e.err
 tail -1 gpurun_out/r5_rcm_timeline.txt; tail -c 400 gpurun_out/r5_c4_probe.json; tail -c 300 gpurun_out/r5_bench_line.json
