@@ -263,14 +263,24 @@ TEST(GraySort, ParallelReplicaOfStdSort) {
     differing += pairs != expect_pairs;
   }
   EXPECT_EQ(differing, 0);
-  // an adversarial input for the median-of-three pivot drives introsort to its depth limit (heap sort of the range)
-  std::vector<uint32_t> killer(1 << 16), killer_expect;
-  for (size_t i = 0; i < killer.size(); i++)
-    killer[i] = (uint32_t)((i % 2 ? i : killer.size() - i) % 251) << 24 | (uint32_t)i;
-  killer_expect = killer;
-  std::sort(killer_expect.begin(), killer_expect.end(), by_degree);
-  reorder::detail::GrayIntroSort(killer.begin(), killer.end(), by_degree, 4, 32);
-  EXPECT_TRUE(killer == killer_expect);
+  // Musser's adversary for the median-of-three pivot drives introsort to its depth limit (99 ranges of this input end in
+  // the heap sort of std::__partial_sort): above the grain that is the pool's own branch, below it the library's
+  {
+    const int count = 1 << 16, half = count / 2;
+    std::vector<uint32_t> killer((size_t)count, 0u), killer_expect;
+    for (int i = 1; i <= half; i++) {
+      if (i % 2) killer[(size_t)i - 1] = (uint32_t)i, killer[(size_t)i] = (uint32_t)(half + i);
+      killer[(size_t)(half + i - 1)] = (uint32_t)(2 * i);
+    }
+    auto less = [](uint32_t l, uint32_t r) -> bool { return l < r; };
+    for (int64_t grain : {(int64_t)32, (int64_t)4096}) {
+      std::vector<uint32_t> work = killer;
+      killer_expect = killer;
+      std::sort(killer_expect.begin(), killer_expect.end(), less);
+      reorder::detail::GrayIntroSort(work.begin(), work.end(), less, 4, grain);
+      EXPECT_TRUE(work == killer_expect);
+    }
+  }
 }
 
 TEST(Device, FailsLoudlyWithoutAGpu) {
