@@ -19,8 +19,10 @@
 #include <chrono>
 #include <condition_variable>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -31,6 +33,31 @@ namespace sparsebase::reorder {
 enum BitMapSize { BitSize16 = 16, BitSize32 = 32, BitSize64 = 64 };
 
 namespace detail {
+// n elements left uninitialised: the stage writes every element it later reads, and a std::vector would zero-fill
+// 14 - 50 MB a piece on one thread first (eight of them: ~20 ms of the call on the 4 M-row matrices).
+template <typename T>
+class GrayBuffer {
+ public:
+  GrayBuffer() = default;
+  explicit GrayBuffer(size_t n) { reset(n); }
+  void reset(size_t n) {
+    static_assert(std::is_trivially_default_constructible<T>::value, "new T[n] must not initialise");
+    p_.reset(n ? new T[n] : nullptr);
+    n_ = n;
+  }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T *data() { return p_.get(); }
+  T *begin() { return p_.get(); }
+  T *end() { return p_.get() + n_; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+
+ private:
+  std::unique_ptr<T[]> p_;
+  size_t n_ = 0;
+};
+
 // f(begin, end) over [0, count) in contiguous pieces on up to 16 threads (element-wise loops of the Gray host stage:
 // they touch several million rows each and are bound by memory latency, not by the sorts' order)
 template <typename F>
@@ -200,7 +227,10 @@ struct GrayReorderParams : utils::Parameters {
 
 template <typename IDType, typename NNZType, typename ValueType>
 class GrayReorder : public Reorderer<IDType> {
-  typedef std::pair<IDType, unsigned long> row_grey_pair;
+  struct row_grey_pair {  // (the reference's std::pair<IDType, unsigned long>, without a constructor that zero-fills arrays)
+    IDType first;
+    unsigned long second;
+  };
 
  public:
   typedef GrayReorderParams ParamsType;
@@ -243,8 +273,8 @@ class GrayReorder : public Reorderer<IDType> {
     using clock = std::chrono::steady_clock;
     auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
     // ---- device stage
-    std::vector<IDType> deg((size_t)n);
-    std::vector<uint64_t> key((size_t)n);
+    detail::GrayBuffer<IDType> deg((size_t)n);
+    detail::GrayBuffer<uint64_t> key((size_t)n);
     int64_t counts[4] = {0, 0, 0, 0};
     {
       hip::Staged<IDType> d_deg(*v.dev, (size_t)n);
@@ -271,7 +301,7 @@ class GrayReorder : public Reorderer<IDType> {
     // ---- host ordering stage (see header comment)
     const int group_size = params->sparse_density_group_size;
     // sparse / dense split in id order (gray_reorder.cc:138-170): counted per piece, then written at the pieces' offsets
-    std::vector<IDType> sparse_rows, dense_rows;
+    detail::GrayBuffer<IDType> sparse_rows, dense_rows;
     {
       const IDType thr = (IDType)params->nnz_threshold;
       const int64_t pieces = std::max<int64_t>(1, std::min<int64_t>(64, n >> 16));
@@ -284,8 +314,8 @@ class GrayReorder : public Reorderer<IDType> {
         }
       });
       for (int64_t p = 0; p < pieces; p++) cnt[(size_t)p + 1] += cnt[(size_t)p];
-      sparse_rows.resize((size_t)cnt[(size_t)pieces]);
-      dense_rows.resize((size_t)(n - cnt[(size_t)pieces]));
+      sparse_rows.reset((size_t)cnt[(size_t)pieces]);
+      dense_rows.reset((size_t)(n - cnt[(size_t)pieces]));
       detail::GrayParallelFor(pieces, [&](int64_t p0, int64_t p1) {
         for (int64_t p = p0; p < p1; p++) {
           const int64_t b = n * p / pieces;
@@ -312,9 +342,9 @@ class GrayReorder : public Reorderer<IDType> {
     if (!dense_banded && !dense_rows.empty()) {
       dense_thread = std::thread([&]() {
         try {
-          std::vector<row_grey_pair> d(dense_rows.size());
+          detail::GrayBuffer<row_grey_pair> d(dense_rows.size());
           detail::GrayParallelFor((int64_t)d.size(), [&](int64_t a0, int64_t a1) {
-            for (int64_t a = a0; a < a1; a++) d[(size_t)a] = row_grey_pair(dense_rows[(size_t)a], (unsigned long)key[dense_rows[(size_t)a]]);
+            for (int64_t a = a0; a < a1; a++) d[(size_t)a] = row_grey_pair{dense_rows[(size_t)a], (unsigned long)key[dense_rows[(size_t)a]]};
           });
           detail::GrayIntroSort(d.begin(), d.end(), asc_comparator);
           detail::GrayParallelFor((int64_t)d.size(), [&](int64_t a0, int64_t a1) {
@@ -329,16 +359,16 @@ class GrayReorder : public Reorderer<IDType> {
       std::thread &t;
       ~JoinGuard() { if (t.joinable()) t.join(); }
     } dense_guard{dense_thread};
-    std::vector<IDType> sorted_deg;
+    detail::GrayBuffer<IDType> sorted_deg;
     {
       // gray_reorder.cc:199-203: std::sort of the row ids by degree.  The (degree, id) pairs are sorted instead, with a
       // comparator that looks at the degree only: every comparison answers what `deg[a] < deg[b]` answers, so the
       // elements make the same moves, without two dependent loads per comparison.
       const int64_t ns0 = (int64_t)sparse_rows.size();
-      sorted_deg.resize((size_t)ns0);  // (the section walk below reads the degrees in this order)
+      sorted_deg.reset((size_t)ns0);  // (the section walk below reads the degrees in this order)
       if (params->nnz_threshold < 256 && n <= ((int64_t)1 << 24)) {
         // ... packed into ONE 32-bit word when they fit (degree << 24 | row): half the bytes to move, the same moves
-        std::vector<uint32_t> byd((size_t)ns0);
+        detail::GrayBuffer<uint32_t> byd((size_t)ns0);
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
           for (int64_t a = a0; a < a1; a++)
             byd[(size_t)a] = ((uint32_t)deg[sparse_rows[(size_t)a]] << 24) | (uint32_t)sparse_rows[(size_t)a];
@@ -351,10 +381,12 @@ class GrayReorder : public Reorderer<IDType> {
           }
         });
       } else {
-        typedef std::pair<IDType, IDType> deg_row;  // (degree, row)
-        std::vector<deg_row> byd((size_t)ns0);
+        struct deg_row {  // (degree, row)
+          IDType first, second;
+        };
+        detail::GrayBuffer<deg_row> byd((size_t)ns0);
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
-          for (int64_t a = a0; a < a1; a++) byd[(size_t)a] = deg_row(deg[sparse_rows[(size_t)a]], sparse_rows[(size_t)a]);
+          for (int64_t a = a0; a < a1; a++) byd[(size_t)a] = deg_row{deg[sparse_rows[(size_t)a]], sparse_rows[(size_t)a]};
         });
         detail::GrayIntroSort(byd.begin(), byd.end(), [](const deg_row &l, const deg_row &r) -> bool { return l.first < r.first; });
         detail::GrayParallelFor(ns0, [&](int64_t a0, int64_t a1) {
@@ -403,10 +435,10 @@ class GrayReorder : public Reorderer<IDType> {
         if (i == ns - 1) flush(ns);
       }
       auto sort_section = [&](const Section &sc) {
-        std::vector<row_grey_pair> section((size_t)(sc.end - sc.start));
+        detail::GrayBuffer<row_grey_pair> section((size_t)(sc.end - sc.start));
         detail::GrayParallelFor(sc.end - sc.start, [&](int64_t a0, int64_t a1) {  // (one piece below 64 K rows)
           for (int64_t a = a0; a < a1; a++)
-            section[(size_t)a] = row_grey_pair(sparse_rows[(size_t)(sc.start + a)], (unsigned long)key[sparse_rows[(size_t)(sc.start + a)]]);
+            section[(size_t)a] = row_grey_pair{sparse_rows[(size_t)(sc.start + a)], (unsigned long)key[sparse_rows[(size_t)(sc.start + a)]]};
         });
         // (a section of a million rows — the rows of one entry of a power-law matrix — is the pool's longest job)
         const unsigned th = sc.end - sc.start >= ((int64_t)1 << 18) ? 0u : 1u;  // (1: plain std::sort)
@@ -441,7 +473,7 @@ class GrayReorder : public Reorderer<IDType> {
     t_part = clock::now();
     if (dense_thread.joinable()) dense_thread.join();
     if (dense_error) std::rethrow_exception(dense_error);
-    IDType *order = new IDType[n > 0 ? n : 1]();
+    IDType *order = n > 0 ? new IDType[n] : new IDType[1]();  // (every row gets its position below)
     const int64_t ns_all = (int64_t)sparse_rows.size();
     detail::GrayParallelFor(n, [&](int64_t p0, int64_t p1) {  // (every row is written once: disjoint stores)
       for (int64_t pos = p0; pos < p1; pos++)
