@@ -382,7 +382,7 @@ def op_fractions(ops, n, nnz, rp, col, val, order, out, stats, steps):
     if b_ref:
         alg_r = b_ref * (4 * nnz + 16 * n)
         res["rcm"] = {"ms": t_rcm * 1e3, "reference_sweeps": b_ref, "executed_sweeps": stats.get("bfs_sweeps"),
-                      "alg_bytes": alg_r, "alg_gbs": alg_r / t_rcm / 1e9,
+                      "unordered_sweeps": stats.get("unordered_sweeps"), "alg_bytes": alg_r, "alg_gbs": alg_r / t_rcm / 1e9,
                       "frac_of_hbm_peak": alg_r / t_rcm / 1e9 / HBM_PEAK_GBS}
     else:
         res["rcm"] = {"ms": t_rcm * 1e3}
