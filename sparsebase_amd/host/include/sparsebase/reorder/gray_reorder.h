@@ -21,6 +21,7 @@
 #include <exception>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -58,6 +59,25 @@ class GrayBuffer {
   size_t n_ = 0;
 };
 
+// job(w) for w in [0, workers): worker 0 is the calling thread; a thread the system refuses to create (resource limits
+// in a container) leaves its job to the caller instead of ending the process through a joinable thread's destructor
+template <typename Job>
+inline void GrayRunWorkers(unsigned workers, Job job) {
+  std::vector<std::thread> pool;
+  std::vector<unsigned> inline_jobs;
+  pool.reserve(workers);
+  for (unsigned w = 1; w < workers; w++) {
+    try {
+      pool.emplace_back([&job, w]() { job(w); });
+    } catch (const std::system_error &) {
+      inline_jobs.push_back(w);
+    }
+  }
+  job(0u);
+  for (unsigned w : inline_jobs) job(w);
+  for (auto &t : pool) t.join();
+}
+
 // f(begin, end) over [0, count) in contiguous pieces on up to 16 threads (element-wise loops of the Gray host stage:
 // they touch several million rows each and are bound by memory latency, not by the sorts' order)
 template <typename F>
@@ -68,17 +88,14 @@ inline void GrayParallelFor(int64_t count, F f) {
     f((int64_t)0, count);
     return;
   }
-  std::vector<std::thread> pool;
   std::vector<std::exception_ptr> errors((size_t)workers);
-  for (int64_t w = 0; w < workers; w++)
-    pool.emplace_back([&, w]() {
-      try {
-        f(count * w / workers, count * (w + 1) / workers);
-      } catch (...) {
-        errors[(size_t)w] = std::current_exception();
-      }
-    });
-  for (auto &t : pool) t.join();
+  GrayRunWorkers((unsigned)workers, [&](unsigned w) {
+    try {
+      f(count * (int64_t)w / workers, count * ((int64_t)w + 1) / workers);
+    } catch (...) {
+      errors[(size_t)w] = std::current_exception();
+    }
+  });
   for (auto &e : errors)
     if (e) std::rethrow_exception(e);
 }
@@ -99,9 +116,7 @@ class GrayIntroSortPool {
   GrayIntroSortPool(WrappedCompare comp, int64_t grain) : comp_(comp), grain_(grain) {}
   void Run(It first, It last, unsigned threads) {
     Push(first, last, (long)std::__lg(last - first) * 2);
-    std::vector<std::thread> pool;
-    for (unsigned i = 0; i < threads; i++) pool.emplace_back([this]() { Work(); });
-    for (auto &t : pool) t.join();
+    GrayRunWorkers(threads, [this](unsigned) { Work(); });
     if (error_) std::rethrow_exception(error_);
     // std::__final_insertion_sort: one stable insertion sort over everything.  No element crosses a partition's cut (what
     // lies left of it does not compare greater than what lies right of it), so the pieces between the cuts the tasks were
@@ -109,17 +124,14 @@ class GrayIntroSortPool {
     cuts_.push_back(last);
     std::sort(cuts_.begin(), cuts_.end());
     std::atomic<size_t> next{0};
-    pool.clear();
-    for (unsigned i = 0; i < threads; i++)
-      pool.emplace_back([this, &next]() {
-        try {
-          for (size_t k = next++; k + 1 < cuts_.size(); k = next++) std::__insertion_sort(cuts_[k], cuts_[k + 1], comp_);
-        } catch (...) {
-          std::lock_guard<std::mutex> g(mu_);
-          if (!error_) error_ = std::current_exception();
-        }
-      });
-    for (auto &t : pool) t.join();
+    GrayRunWorkers(threads, [this, &next](unsigned) {
+      try {
+        for (size_t k = next++; k + 1 < cuts_.size(); k = next++) std::__insertion_sort(cuts_[k], cuts_[k + 1], comp_);
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+    });
     if (error_) std::rethrow_exception(error_);
   }
 
@@ -455,16 +467,13 @@ class GrayReorder : public Reorderer<IDType> {
       } else {
         std::atomic<size_t> next{0};
         std::vector<std::exception_ptr> errors(workers);
-        std::vector<std::thread> pool;
-        for (size_t w = 0; w < workers; w++)
-          pool.emplace_back([&, w]() {
-            try {
-              for (size_t k = next++; k < sections.size(); k = next++) sort_section(sections[k]);
-            } catch (...) {
-              errors[w] = std::current_exception();
-            }
-          });
-        for (auto &t : pool) t.join();
+        detail::GrayRunWorkers((unsigned)workers, [&](unsigned w) {
+          try {
+            for (size_t k = next++; k < sections.size(); k = next++) sort_section(sections[k]);
+          } catch (...) {
+            errors[w] = std::current_exception();
+          }
+        });
         for (auto &e : errors)
           if (e) std::rethrow_exception(e);
       }
