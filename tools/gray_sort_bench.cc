@@ -7,13 +7,35 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <sys/resource.h>
 #include <vector>
 #include "sparsebase/sparsebase.h"
 using namespace sparsebase;
 using clk = std::chrono::steady_clock;
 static double ms(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
-int main() {
+int main(int argc, char **argv) {
   unsigned long long state = 88172645463325252ull;
+  if (argc > 1 && !strcmp(argv[1], "--starve")) {
+    // no new threads for this user (RLIMIT_NPROC = 1; not enforced for root): every std::thread the sort asks for fails
+    // with EAGAIN and its share must fall to the calling thread — same permutation, no std::terminate
+    struct rlimit rl = {1, 1};
+    if (setrlimit(RLIMIT_NPROC, &rl) != 0) std::perror("setrlimit");
+    std::vector<uint32_t> a(2000000), e;
+    unsigned long long st = 12345;
+    for (auto &x : a) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; x = (uint32_t)((st % 11) << 24) | (uint32_t)(st >> 40); }
+    e = a;
+    auto cmp = [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); };
+    std::sort(e.begin(), e.end(), cmp);
+    bool spawned = true;
+    try { std::thread t([] {}); t.join(); } catch (const std::system_error &) { spawned = false; }
+    reorder::detail::GrayIntroSort(a.begin(), a.end(), cmp, 8, 1000);
+    int64_t sum = 0;
+    reorder::detail::GrayParallelFor((int64_t)a.size(), [&](int64_t b0, int64_t b1) { int64_t s = 0; for (int64_t i = b0; i < b1; i++) s += a[(size_t)i] >> 24; __atomic_fetch_add(&sum, s, __ATOMIC_RELAXED); });
+    std::printf("starved of threads (a probe thread %s): sort %s, parallel-for sum %lld\n", spawned ? "COULD still be created" : "could not be created",
+                a == e ? "identical to std::sort" : "DIFFERS", (long long)sum);
+    return a == e ? 0 : 1;
+  }
   auto rnd = [&state]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
   auto by_degree = [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); };
   typedef std::pair<int, unsigned long> row_key;
