@@ -351,8 +351,8 @@ class GrayReorder : public Reorderer<IDType> {
     // over the degree-sorted rows has found their bounds they are sorted concurrently.
     std::thread dense_thread;
     std::exception_ptr dense_error;
-    if (!dense_banded && !dense_rows.empty()) {
-      dense_thread = std::thread([&]() {
+    bool dense_inline = false;  // (no thread to be had: the dense rows are sorted where the thread would be joined)
+    auto sort_dense_rows = [&]() {
         try {
           detail::GrayBuffer<row_grey_pair> d(dense_rows.size());
           detail::GrayParallelFor((int64_t)d.size(), [&](int64_t a0, int64_t a1) {
@@ -365,7 +365,13 @@ class GrayReorder : public Reorderer<IDType> {
         } catch (...) {
           dense_error = std::current_exception();
         }
-      });
+    };
+    if (!dense_banded && !dense_rows.empty()) {
+      try {
+        dense_thread = std::thread(sort_dense_rows);
+      } catch (const std::system_error &) {
+        dense_inline = true;
+      }
     }
     struct JoinGuard {  // (the ordering stage may leave through an exception)
       std::thread &t;
@@ -481,6 +487,7 @@ class GrayReorder : public Reorderer<IDType> {
     last_stage_ms()[5] = ms_since(t_part);
     t_part = clock::now();
     if (dense_thread.joinable()) dense_thread.join();
+    if (dense_inline) sort_dense_rows();
     if (dense_error) std::rethrow_exception(dense_error);
     IDType *order = n > 0 ? new IDType[n] : new IDType[1]();  // (every row gets its position below)
     const int64_t ns_all = (int64_t)sparse_rows.size();
