@@ -7,11 +7,13 @@
 //   host    the ordering of the n row keys.  The reference orders rows with unstable
 //           std::sort calls on heavily tied keys (gray_reorder.cc:199,294-299,355-358,
 //           404); its result therefore depends on libstdc++'s introsort visiting
-//           order, which no parallel sort reproduces.  To stay bit-exact this stage
+//           order, which no other sort reproduces.  To stay bit-exact this stage
 //           issues the same std::sort calls, on the same sequences, over the
 //           device-computed keys (O(n log n) on rows, nothing touches the nonzeros);
 //           calls that do not depend on each other (the sections, the dense rows) run on
-//           threads of their own.
+//           threads of their own, and a big call runs as that very introsort with the two
+//           sides of its partitions on different threads (detail::GrayIntroSort: the
+//           library's own routines on disjoint ranges, hence the same permutation).
 #ifndef SPARSEBASE_REORDER_GRAY_REORDER_H_
 #define SPARSEBASE_REORDER_GRAY_REORDER_H_
 #include <algorithm>
