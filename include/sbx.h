@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SBX_VERSION 100 /* 0.1.0 */
+#define SBX_VERSION 101 /* 0.1.1: sbx_rcm_stats grew by unordered_sweeps, sbx_gray_reorder added */
 
 typedef struct sbx_handle_s *sbx_handle_t;
 
