@@ -248,7 +248,13 @@ int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void 
 /* ------------------------------------------------------------------ *
  * A7  RCMReorder::GetReorderCSR — reorder/rcm_reorder.cc:83-166 (+ :22-81)
  * Parity is defined for structurally symmetric patterns with column-sorted
- * rows (what the CSR constructor guarantees).  Synchronous.
+ * rows (what the CSR constructor guarantees).  Synchronous for the status and
+ * the statistics: both are final on return.  inv_perm_out is complete IN STREAM
+ * ORDER like every output of this library: when one component holds all the
+ * work the host drives, the kernel that writes its positions is enqueued behind
+ * the call's last read-back and may still run when the call returns (anything
+ * enqueued on the handle's stream afterwards, sbx_memcpy_d2h and sbx_sync
+ * included, sees the finished array).
  *
  * Grid barriers.  Three of the call's kernels (the small-level runs of the
  * pseudo-peripheral sweeps and the two tie-break walks, sbx_rcm.hip: gb_wait)

@@ -3836,16 +3836,20 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[3], 0));
     cc_forked = false;
     if (ranks_joined || !ranks_enqueued) h->aux_dirty = false;
-    // the component's order is complete in q: written at once, its place read from the size scan on the device — when
-    // it is the only one the host orders, the read-back below is the call's last
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(sd0.r.count, 256, 4096)), dim3(256), (const I *)q,
-                sd0.r.count, (I)0, inv, (const I *)(cbase + v0));
-    SBX_LAUNCH_CHECK(h);
     small_on_side = true;
   } else {
     SBX_TRY(enqueue_cc_kernels(2));
   }
   SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
+  if (comp0_searched) {
+    // the component's order is complete in q: written now, its place read from the size scan on the device — BEHIND the
+    // read-back of the labelling's counters: when this component is the only one the host orders that read-back was the
+    // call's last and the kernel finishes in stream order after the call has returned (outputs are complete in stream
+    // order, as for every entry point that does not end in a read-back)
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_write_component, dim3(sbx_grid_for(sd0.r.count, 256, 4096)), dim3(256), (const I *)q,
+                sd0.r.count, (I)0, inv, (const I *)(cbase + v0));
+    SBX_LAUNCH_CHECK(h);
+  }
   if (hd.unsym)
     SBX_FAIL(h, SBX_ERR_BAD_ARG,
              "sbx_rcm_reorder: the pattern is not structurally symmetric (a vertex hangs under the first component "
