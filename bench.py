@@ -147,17 +147,23 @@ def main():
         alg = kernel_alg_bytes(dom, n, nnz, stats, launches_step)
         if alg is None:
             alg = declared.get(dom)   # groups whose record counts only the library knows (radix passes)
-        traffic = None
+        # HBM bytes per launch from the PMC counters: NOT measured in this run (counters need their own rocprofv3 passes) but
+        # read from the committed profile of the same command — traffic_source says which collection that was
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            meta = tj.get("_meta", {})
+            traffic_source = ("profiles/pmc_traffic.json (collected %s, build %s; tools/collect_profiles.sh)"
+                              % (meta.get("collected", "?"), meta.get("build", "?")))
         roofline = {
             "bound": "hbm", "kernel": dom,
             "achieved": None if alg is None else alg / launches_step / (ms_step / launches_step) / 1e6,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if alg is None else alg / ms_step / 1e6 / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": ms_step / launches_step, "launches_per_step": launches_step,
             "measured": f"HIP events around every launch over {args.steps} further steps of the same loop "
                         f"({wall_events / args.steps * 1e3:.2f} ms/step with the events in place; the permute's "

@@ -117,7 +117,12 @@ def build_tuning(verbose=False):
     for src in _sources():
         obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+        dep_m = 0  # (the 64-bit twins include their 32-bit files)
+        if src.endswith("sbx_rcm64.hip"):
+            dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_rcm.hip"))
+        if src.endswith("sbx_gray64.hip"):
+            dep_m = os.path.getmtime(os.path.join(CSRC, "sbx_gray.hip"))
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m, dep_m):
             jobs.append((src, obj))
 
     def one(so):

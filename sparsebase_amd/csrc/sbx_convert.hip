@@ -439,11 +439,6 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
     if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
   } while (0)
 
-#define SBX_ONLY_I32(h, it)                                                                  \
-  do {                                                                                       \
-    if ((it) != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "%s: 64-bit indices not built yet", __func__); \
-  } while (0)
-
 template <typename I>
 static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, const void *col, int *sorted_host,
                                int64_t n = -1, int64_t m = -1, int *in_range_host = nullptr) {

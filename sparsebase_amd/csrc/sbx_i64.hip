@@ -70,7 +70,7 @@ int sbx_i64_check(sbx_handle_t h, const int *overflow_flag_dev) {
   SBX_TRY(sbx_readback(h, &f, overflow_flag_dev, sizeof(int)));
   if (f)
     SBX_FAIL(h, SBX_ERR_UNSUPPORTED,
-             "64-bit index array holds a value outside [0, 2^31): native 64-bit kernels are not built yet");
+             "64-bit index array holds a value outside [0, 2^31) on a path that sorts 32-bit keys (coordinates outside the matrix, text ingest)");
   return SBX_OK;
 }
 

@@ -2078,9 +2078,14 @@ static int permute_grid_factor() {  // SBX_PERMUTE_GRID_FACTOR: workgroups launc
   return f < 1 ? 1 : f;
 }
 
-static int permute_force_radix() {  // SBX_PERMUTE_FORCE_RADIX=1: every tile / row takes the radix path (tests)
-  static const int on = (sbx_env_test("SBX_PERMUTE_FORCE_RADIX") ? atoi(sbx_env_test("SBX_PERMUTE_FORCE_RADIX")) & 0xFF : 0) |
-                        (sbx_env_test("SBX_DEBUG_TILE_STOP") ? atoi(sbx_env_test("SBX_DEBUG_TILE_STOP")) << 8 : 0);
+// SBX_PERMUTE_FORCE_RADIX=1: every tile / row takes the radix path (tests; a path production takes for clustered columns).
+// The timing ablations — bits 1 - 3 of the same variable (rows stream out unsorted / no relabel gathers / ...) and
+// SBX_DEBUG_TILE_STOP (leave the tile kernel behind phase k) — produce WRONG matrices and exist in the tuning build only.
+static int permute_force_radix() {
+  static const int on =
+      (sbx_env_test("SBX_PERMUTE_FORCE_RADIX") ? atoi(sbx_env_test("SBX_PERMUTE_FORCE_RADIX")) & 0x01 : 0) |
+      (sbx_env_tuning("SBX_PERMUTE_FORCE_RADIX") ? atoi(sbx_env_tuning("SBX_PERMUTE_FORCE_RADIX")) & 0xFE : 0) |
+      (sbx_env_tuning("SBX_DEBUG_TILE_STOP") ? atoi(sbx_env_tuning("SBX_DEBUG_TILE_STOP")) << 8 : 0);
   return on;
 }
 
@@ -2595,10 +2600,6 @@ int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr
 #define SBX_REQUIRE(h, cond, msg)                                       \
   do {                                                                  \
     if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
-  } while (0)
-#define SBX_ONLY_I32(h, it)                                                                              \
-  do {                                                                                                   \
-    if ((it) != SBX_I32) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "%s: 64-bit indices not built yet", __func__); \
   } while (0)
 
 extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_t n, const void *perm,

@@ -14,6 +14,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port the OS hands out as free right now (parallel test runs must not meet on a fixed one)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, gather_entries, balanced, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,7 +62,7 @@ def _worker(rank, world, port, gather_entries, balanced, q):
 @pytest.mark.parametrize("gather_entries,balanced", [(False, False), (True, False), (False, True)])
 def test_sharded_permute_two_ranks_gloo(gather_entries, balanced):
     world = 2
-    port = 29500 + (os.getpid() % 500) + (7 if gather_entries else 0) + (13 if balanced else 0)
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, gather_entries, balanced, q)) for r in range(world)]
@@ -111,7 +119,7 @@ def _convert_worker(rank, world, port, q):
 
 def test_sharded_conversions_two_ranks_gloo():
     world = 2
-    port = 30100 + (os.getpid() % 500)
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_convert_worker, args=(r, world, port, q)) for r in range(world)]

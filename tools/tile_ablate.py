@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import torch
+    from sparsebase_amd import capi
+    # SBX_DEBUG_TILE_STOP is live in the tuning build only (python -m sparsebase_amd.build --tuning)
+    capi.LIB_PATH = os.path.join(ROOT, "sparsebase_amd", "lib", f"libsbx_{os.environ.get('SBX_PROBE_LIB', 'tuning')}.so")
     from sparsebase_amd import ops, synth
     rp, col = synth.rmat_symmetric_torch(22, 13, seed=1)
     n, nnz = rp.numel() - 1, col.numel()

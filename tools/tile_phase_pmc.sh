@@ -4,7 +4,7 @@
 # --pmc pass per counter set and stop.  usage (gpurun, repo root): tools/tile_phase_pmc.sh [--rcm] -> gpurun_out/tile_phase_pmc.txt
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
-export TMPDIR=/tmp SBX_PERMUTE_OVERLAP=0
+export TMPDIR=/tmp SBX_PERMUTE_OVERLAP=0 SBX_PROBE_LIB=${SBX_PROBE_LIB:-tuning}  # SBX_DEBUG_TILE_STOP: tuning build only
 : > "$OUT/tile_phase_pmc.txt"
 for stop in 1 2 3 4 5 0; do
   i=0
