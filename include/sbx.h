@@ -12,9 +12,18 @@
  *  - No entry point allocates memory it hands back: the caller owns inputs and
  *    outputs.  Scratch comes from the handle's grow-only arena (sbx_reserve
  *    pre-sizes it, so steady-state calls never call hipMalloc).
- *  - Work is enqueued on the handle's stream.  Functions documented as
- *    "synchronous" wait for the stream internally (they need a device->host
- *    read-back); all others return as soon as the work is enqueued.
+ *  - Work is enqueued on the handle's stream, and DEVICE outputs of every
+ *    entry point are complete IN STREAM ORDER: anything enqueued on the
+ *    handle's stream afterwards (sbx_memcpy_d2h and sbx_sync included), or
+ *    ordered behind an event recorded on it, sees the finished arrays; a
+ *    consumer on another stream, or a host copy that does not go through the
+ *    handle's stream, must order itself that way first.  Functions documented
+ *    as "synchronous" need device->host read-backs and wait for those
+ *    internally: their status and everything they return through `_host`
+ *    pointers are final when they return — their device outputs keep the
+ *    stream-order guarantee and no more (sbx_rcm_reorder and
+ *    sbx_gray_reorder return with their last kernel enqueued, not finished).
+ *    All other functions return as soon as the work is enqueued.
  *  - Return value: SBX_OK (0) or an sbx_status error code; nothing throws
  *    across this boundary.  sbx_last_error() gives a message for the last
  *    failing call on the handle.
@@ -42,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SBX_VERSION 101 /* 0.1.1: sbx_rcm_stats grew by unordered_sweeps, sbx_gray_reorder added */
+#define SBX_VERSION 102 /* 0.1.2: sbx_set_oom_hook added (101: sbx_rcm_stats.unordered_sweeps, sbx_gray_reorder) */
 
 typedef struct sbx_handle_s *sbx_handle_t;
 
@@ -99,6 +108,12 @@ int sbx_get_device(sbx_handle_t h, int *device_host);
 int sbx_reserve(sbx_handle_t h, size_t scratch_bytes);
 int sbx_sync(sbx_handle_t h);
 const char *sbx_last_error(sbx_handle_t h);
+/* A caller that caches freed device blocks (the C++ host layer's pool, hip/device.h) registers a hook: when a device
+ * allocation of the library's own (scratch arena, radix slots) fails for lack of memory the hook is called ONCE with
+ * the size wanted; if it returns non-zero (it gave memory back to the driver) the allocation is tried again before
+ * the entry point returns SBX_ERR_OOM.  The hook runs on the calling thread and must not call into the handle. */
+typedef int (*sbx_oom_hook)(void *user, size_t bytes_wanted);
+int sbx_set_oom_hook(sbx_handle_t h, sbx_oom_hook hook, void *user);
 
 /* Optional per-kernel profiler: when enabled every kernel the library launches is
  * bracketed by HIP events on the handle's stream.  sbx_profile_query(index) drains
@@ -248,13 +263,13 @@ int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, const void 
 /* ------------------------------------------------------------------ *
  * A7  RCMReorder::GetReorderCSR — reorder/rcm_reorder.cc:83-166 (+ :22-81)
  * Parity is defined for structurally symmetric patterns with column-sorted
- * rows (what the CSR constructor guarantees).  Synchronous for the status and
- * the statistics: both are final on return.  inv_perm_out is complete IN STREAM
- * ORDER like every output of this library: when one component holds all the
- * work the host drives, the kernel that writes its positions is enqueued behind
- * the call's last read-back and may still run when the call returns (anything
- * enqueued on the handle's stream afterwards, sbx_memcpy_d2h and sbx_sync
- * included, sees the finished array).
+ * rows (what the CSR constructor guarantees).  Synchronous (status and
+ * statistics final on return); inv_perm_out is complete in stream order (see
+ * Conventions): when one component holds all the work the host drives, the
+ * kernel that writes its positions is enqueued behind the call's last
+ * read-back and may still run when the call returns.  The host layer's
+ * RCMReorder::GetReorder (reorder/reorderer.h:53-117: a host array, synchronous)
+ * downloads through sbx_memcpy_d2h on the handle's stream and is synchronous.
  *
  * Grid barriers.  Three of the call's kernels (the small-level runs of the
  * pseudo-peripheral sweeps and the two tie-break walks, sbx_rcm.hip: gb_wait)
@@ -322,7 +337,7 @@ int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, i
  * libstdc++'s introsort order.  exact_ties != 0 is refused with SBX_ERR_UNSUPPORTED: the exact mode — the default of
  * reorder::GrayReorder — issues the reference's own std::sort calls in the host layer over the device-computed keys
  * (DESIGN.md section 5).  inv_perm_out[n] (index type `it`) on the device.  m must be a multiple of the resolution
- * (see sbx_gray_row_keys).  Synchronous. */
+ * (see sbx_gray_row_keys).  Synchronous (status); inv_perm_out complete in stream order. */
 int sbx_gray_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t m, int64_t nnz,
                      const void *row_ptr, const void *col, int resolution, int nnz_threshold,
                      int group_size, int exact_ties, void *inv_perm_out);

@@ -38,6 +38,8 @@ _H = C.c_void_p
 COMM_ID_BYTES = 128
 # int (*sbx_allgather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes, void *stream)
 ALLGATHER_FN = C.CFUNCTYPE(_int, _vp, _vp, _vp, _sz, _vp)
+# int (*sbx_oom_hook)(void *user, size_t bytes_wanted)
+OOM_HOOK_FN = C.CFUNCTYPE(_int, _vp, _sz)
 PROTOTYPES = {
     "sbx_version": ([], _int),
     "sbx_status_string": ([_int], C.c_char_p),
@@ -50,6 +52,7 @@ PROTOTYPES = {
     "sbx_reserve": ([_H, _sz], _int),
     "sbx_sync": ([_H], _int),
     "sbx_last_error": ([_H], C.c_char_p),
+    "sbx_set_oom_hook": ([_H, OOM_HOOK_FN, _vp], _int),
     "sbx_profile_enable": ([_H, _int], _int),
     "sbx_profile_kernel_count": ([], _int),
     "sbx_profile_kernel_name": ([_int], C.c_char_p),

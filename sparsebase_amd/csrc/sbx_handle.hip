@@ -102,6 +102,8 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->rs_override = nullptr;
   h->rs_pool = nullptr;
   h->rs_next = 0;
+  h->oom_hook = nullptr;
+  h->oom_user = nullptr;
   {
     const char *e = sbx_env_tuning("SBX_READBACK_POLL");
     h->rb_poll = !(e && e[0] == '0');
@@ -168,11 +170,29 @@ extern "C" int sbx_sync(sbx_handle_t h) {
   return SBX_OK;
 }
 
+// hipMalloc for the library's own blocks (arena, radix slot pool): when the driver is out of memory the caller's hook
+// (sbx_set_oom_hook: e.g. the host layer's pool of idle device blocks) is asked once to give some back
+static hipError_t internal_malloc(sbx_handle_t h, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && h->oom_hook) {
+    (void)hipGetLastError();
+    if (h->oom_hook(h->oom_user, bytes)) e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
+extern "C" int sbx_set_oom_hook(sbx_handle_t h, sbx_oom_hook hook, void *user) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  h->oom_hook = hook;
+  h->oom_user = user;
+  return SBX_OK;
+}
+
 static int arena_add_block(sbx_handle_t h, size_t bytes) {
   sbx_block b;
   b.cap = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
   b.ptr = nullptr;
-  hipError_t e = hipMalloc((void **)&b.ptr, b.cap);
+  hipError_t e = internal_malloc(h, (void **)&b.ptr, b.cap);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     SBX_FAIL(h, SBX_ERR_OOM, "scratch arena: hipMalloc(%zu) failed: %s", b.cap, hipGetErrorString(e));
@@ -249,7 +269,7 @@ int sbx_radix_slot(sbx_handle_t h, void **slot) {
     return SBX_OK;
   }
   if (!h->rs_pool) {
-    SBX_HIP(h, hipMalloc(&h->rs_pool, (size_t)SBX_RS_SLOTS * SBX_RS_SLOT_BYTES));
+    SBX_HIP(h, internal_malloc(h, &h->rs_pool, (size_t)SBX_RS_SLOTS * SBX_RS_SLOT_BYTES));
     h->rs_next = SBX_RS_SLOTS;  // forces the first memset
   }
   if (h->rs_next >= SBX_RS_SLOTS) {

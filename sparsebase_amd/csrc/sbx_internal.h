@@ -76,6 +76,8 @@ struct sbx_handle_s {
   void *pow5;       // device table of 5^k for the exact decimal conversion (sbx_mtx.hip), built on first use
   unsigned rb_seq;  // sequence number of the last polled read-back (sbx_readback)
   bool rb_poll;     // SBX_READBACK_POLL=0 selects the copy-engine path
+  sbx_oom_hook oom_hook;  // asked once when a device allocation of the library's own fails (sbx_set_oom_hook)
+  void *oom_user;
   int rcm_gb_backoff;  // RCM calls left to run without the persistent (grid-barrier) kernels after one of them gave up
   int num_cus;
   // side streams for independent stages of one call (permute: tile / block-row / long-row paths), created on

@@ -2,7 +2,8 @@
 // files and writes the inverse permutation; used by tests/test_host_layer.py to check the
 // C++ API end to end (Gray's device keys + host ordering stage in particular) against
 // fixtures produced by the real reference.
-// Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time]
+// Usage: reorder_cli <rcm|degree_asc|degree_desc|gray> <row_ptr.bin> <col.bin> <out.bin> <n> <m> [res thr grp] [--device] [--time] [--stable]
+// --stable (gray): the opt-in ordering on the device with stable ties (GrayReorderParams::stable_device_ordering)
 // --time repeats the call five times and prints the last (warm) call's wall time in seconds on stdout (gray: and, on a
 // second line, the ms of its device key stage, of the copy of the keys to the host and of the host ordering stage)
 //        reorder_cli pipeline <row_ptr.bin> <col.bin> <out.bin> <n> <m>
@@ -34,7 +35,12 @@ static std::vector<int> read_bin(const char *path) {
 
 static int pipeline(const std::vector<int> &rp, const std::vector<int> &col, int n, int m, const char *out_path) {
   using clock = std::chrono::steady_clock;
-  auto ms = [](clock::time_point a) { return std::chrono::duration<double, std::milli>(clock::now() - a).count(); };
+  // (device outputs are complete in stream order, and some calls return with their last kernels still running: the
+  // clock is read behind a sync, so that every kernel is charged to the call that enqueued it)
+  auto ms = [](clock::time_point a) {
+    hip::Device::Get(0).Sync();
+    return std::chrono::duration<double, std::milli>(clock::now() - a).count();
+  };
   utils::Logger::set_level(utils::LOG_LVL_NONE);
   std::vector<float> val(col.size());
   for (size_t i = 0; i < val.size(); i++) val[i] = (float)(i % 1021);
@@ -102,10 +108,11 @@ int main(int argc, char **argv) {
   auto col = read_bin(argv[3]);
   const int n = atoi(argv[5]), m = atoi(argv[6]);
   if (kind == "pipeline") return pipeline(rp, col, n, m, argv[4]);
-  bool on_device = false, timed = false;
+  bool on_device = false, timed = false, stable = false;
   for (int i = 7; i < argc; i++) {
     on_device |= !strcmp(argv[i], "--device");
     timed |= !strcmp(argv[i], "--time");
+    stable |= !strcmp(argv[i], "--stable");  // gray: GrayReorderParams::stable_device_ordering (sbx_gray_reorder)
   }
   utils::Logger::set_level(utils::LOG_LVL_NONE);
   context::CPUContext cpu;
@@ -130,7 +137,9 @@ int main(int argc, char **argv) {
       return r.GetReorder(input, ctxs, false);
     }
     if (kind == "gray") {
-      reorder::GrayReorder<int, int, void> r((reorder::BitMapSize)atoi(argv[7]), atoi(argv[8]), atoi(argv[9]));
+      reorder::GrayReorderParams gp((reorder::BitMapSize)atoi(argv[7]), atoi(argv[8]), atoi(argv[9]));
+      gp.stable_device_ordering = stable;
+      reorder::GrayReorder<int, int, void> r(gp);
       return r.GetReorder(input, ctxs, false);
     }
     return nullptr;
@@ -146,7 +155,7 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     order = run();
     std::printf("%.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    if (kind == "gray") {  // the stages of that call: device key stage, keys to the host, host ordering (ms)
+    if (kind == "gray" && !stable) {  // the stages of that call: device key stage, keys to the host, host ordering (ms)
       const double *st = reorder::GrayReorder<int, int, void>::last_stage_ms();
       std::fprintf(stderr, "gray host stage (ms): split %.2f, sort by degree %.2f, sections %.2f, dense rows + order %.2f\n", st[3],
                    st[4], st[5], st[6]);

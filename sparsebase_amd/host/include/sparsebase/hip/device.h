@@ -143,7 +143,10 @@ class Device {
   }
 
  private:
-  Device(int id, sbx_handle_t h) : id_(id), h_(h) {}
+  Device(int id, sbx_handle_t h) : id_(id), h_(h) {
+    // the library's own allocations (scratch arena growth, radix slots) must not fail while this pool sits on idle blocks
+    sbx_set_oom_hook(h_, [](void *self, size_t) -> int { return static_cast<Device *>(self)->TrimPool(0) ? 1 : 0; }, this);
+  }
   int id_;
   sbx_handle_t h_;
   mutable std::mutex pool_mu_;

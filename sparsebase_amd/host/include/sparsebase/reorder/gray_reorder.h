@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "sparsebase/reorder/reorderer.h"
+#include "sparsebase/utils/logger.h"
 
 namespace sparsebase::reorder {
 
@@ -82,10 +83,11 @@ inline void GrayRunWorkers(unsigned workers, Job job) {
 
 // f(begin, end) over [0, count) in contiguous pieces on up to 16 threads (element-wise loops of the Gray host stage:
 // they touch several million rows each and are bound by memory latency, not by the sorts' order)
+// grain: the fewest items worth a thread of their own (65 536 rows; 1 where an item is itself a piece of that size)
 template <typename F>
-inline void GrayParallelFor(int64_t count, F f) {
+inline void GrayParallelFor(int64_t count, F f, int64_t grain = (int64_t)1 << 16) {
   const unsigned hw = std::thread::hardware_concurrency();
-  const int64_t workers = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), (count + (1 << 16) - 1) >> 16);
+  const int64_t workers = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), (count + grain - 1) / grain);
   if (workers <= 1) {
     f((int64_t)0, count);
     return;
@@ -110,8 +112,56 @@ inline void GrayParallelFor(int64_t count, F f) {
 // std::__partial_sort at the depth limit, std::__introsort_loop itself below the grain), only the recursive call goes
 // to a pool; the closing insertion sort (std::__final_insertion_sort) runs piecewise between the tasks' cuts.  Same comparisons on the same elements in every range,
 // hence the same permutation: compared with std::sort on tied, sorted, reversed and random inputs by
-// host/tests/test_host_logic.cc (GraySort.ParallelReplicaOfStdSort).  Other standard libraries: plain std::sort.
-#if defined(__GLIBCXX__)
+// host/tests/test_host_logic.cc (GraySort.ParallelReplicaOfStdSort).
+// The routines called are libstdc++ INTERNALS (std::__introsort_loop, std::__unguarded_partition_pivot,
+// std::__partial_sort, std::__insertion_sort, __gnu_cxx::__ops::__iter_comp_iter, _S_threshold = 16), so the replica is
+// compiled only inside the window of releases whose <bits/stl_algo.h> was read and tested (GCC 9 - 14: the introsort is
+// unchanged there; developed and run on 11.4) — any other standard library or release gets plain std::sort — and the
+// first big sort of a process checks the replica against std::sort on 200 K heavily tied keys (GraySortReplicaAgrees):
+// a library inside the window that nevertheless sorts differently (another threshold or pivot rule) is noticed, logged,
+// and the process falls back to plain std::sort (slower, still exact).  -DSBX_GRAY_NO_SORT_REPLICA forces that.
+#if defined(__GLIBCXX__) && defined(_GLIBCXX_RELEASE) && !defined(SBX_GRAY_NO_SORT_REPLICA)
+#if _GLIBCXX_RELEASE >= 9 && _GLIBCXX_RELEASE <= 14
+#define SBX_GRAY_SORT_REPLICA 1
+#endif
+#endif
+
+// One budget of sort threads per process: the dense rows' sort, the degree sort and up to 16 section workers may each
+// ask for a parallel sort at the same time; together they get at most GrayThreadBudget::kMax extra threads (a lease
+// that finds the budget spent sorts on its caller's thread).
+class GrayThreadBudget {
+ public:
+  static constexpr int kMax = 32;
+  explicit GrayThreadBudget(unsigned want) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int cap = (int)std::min<unsigned>(hw ? hw : 1u, (unsigned)kMax);
+    int cur = in_use().load();
+    for (;;) {
+      const int room = std::max(0, cap - cur);
+      got_ = std::min<int>((int)want - 1, room);  // (the caller's own thread is not counted)
+      if (got_ <= 0) {
+        got_ = 0;
+        break;
+      }
+      if (in_use().compare_exchange_weak(cur, cur + got_)) break;
+    }
+  }
+  ~GrayThreadBudget() {
+    if (got_) in_use() -= got_;
+  }
+  GrayThreadBudget(const GrayThreadBudget &) = delete;
+  GrayThreadBudget &operator=(const GrayThreadBudget &) = delete;
+  unsigned threads() const { return (unsigned)got_ + 1u; }
+
+ private:
+  static std::atomic<int> &in_use() {
+    static std::atomic<int> v{0};
+    return v;
+  }
+  int got_ = 0;
+};
+
+#if defined(SBX_GRAY_SORT_REPLICA)
 template <typename It, typename WrappedCompare>
 class GrayIntroSortPool {
  public:
@@ -200,17 +250,77 @@ class GrayIntroSortPool {
   bool done_ = false;
   std::exception_ptr error_;
 };
+
+// once per process: the replica against std::sort on 200 000 words with eleven distinct keys (the degree sort's shape)
+// and on (id, key) records in descending order of a tied key, four threads, a grain that forces ~50 tasks
+inline bool GraySortReplicaAgrees() {
+  static const bool ok = [] {
+    try {
+      const size_t count = 200000;
+      std::vector<uint32_t> a(count), b;
+      uint64_t x = 0x9E3779B97F4A7C15ull;
+      for (size_t i = 0; i < count; i++) {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        a[i] = ((uint32_t)((x >> 40) % 11u) << 24) | (uint32_t)i;
+      }
+      b = a;
+      auto by_key = [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); };
+      std::sort(a.begin(), a.end(), by_key);
+      {
+        auto w = __gnu_cxx::__ops::__iter_comp_iter(by_key);
+        GrayIntroSortPool<std::vector<uint32_t>::iterator, decltype(w)> pool(w, 4096);
+        pool.Run(b.begin(), b.end(), 4);
+      }
+      if (a != b) return false;
+      struct Rec { uint32_t first; unsigned long second; };
+      std::vector<Rec> c(count), d;
+      for (size_t i = 0; i < count; i++) {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        c[i] = Rec{(uint32_t)i, (unsigned long)((x >> 33) % 977u)};
+      }
+      d = c;
+      auto desc = [](const Rec &l, const Rec &r) -> bool { return l.second > r.second; };
+      std::sort(c.begin(), c.end(), desc);
+      {
+        auto w = __gnu_cxx::__ops::__iter_comp_iter(desc);
+        GrayIntroSortPool<typename std::vector<Rec>::iterator, decltype(w)> pool(w, 4096);
+        pool.Run(d.begin(), d.end(), 4);
+      }
+      for (size_t i = 0; i < count; i++)
+        if (c[i].first != d[i].first) return false;
+      return true;
+    } catch (...) {
+      return false;
+    }
+  }();
+  static const bool logged = [] {
+    if (!ok)
+      utils::Logger(typeid(GrayThreadBudget))
+          .Log("the parallel replica of std::sort does not reproduce this libstdc++'s std::sort: GrayReorder falls back "
+               "to plain std::sort (exact, slower)", utils::LOG_LVL_WARNING);
+    return true;
+  }();
+  (void)logged;
+  return ok;
+}
 #endif
 
 /// grain: ranges up to this many elements are sorted by the calling task (0: chosen from the size and the threads)
 template <typename It, typename Compare>
 inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0, int64_t grain = 0) {
-#if defined(__GLIBCXX__)
+#if defined(SBX_GRAY_SORT_REPLICA)
   const int64_t count = last - first;
+  const bool budgeted = threads == 0;  // (an explicit thread count — the tests — is taken as given)
   if (threads == 0) {
     const unsigned hw = std::thread::hardware_concurrency();
     threads = std::min<unsigned>(hw ? hw : 1u, 16u);
   }
+  if (threads <= 1 || count <= std::max<int64_t>(grain, budgeted ? ((int64_t)1 << 15) : 1) || !GraySortReplicaAgrees()) {
+    std::sort(first, last, comp);
+    return;
+  }
+  GrayThreadBudget lease(budgeted ? threads : 1u);
+  if (budgeted) threads = lease.threads();
   if (grain <= 0) grain = std::max<int64_t>((int64_t)1 << 15, count / ((int64_t)threads * 8));
   if (threads <= 1 || count <= grain) {
     std::sort(first, last, comp);
@@ -326,7 +436,7 @@ class GrayReorder : public Reorderer<IDType> {
           for (int64_t i = n * p / pieces; i < n * (p + 1) / pieces; i++) c += deg[i] <= thr;
           cnt[(size_t)p + 1] = c;
         }
-      });
+      }, 1);  // (an item is a piece of >= 65 536 rows)
       for (int64_t p = 0; p < pieces; p++) cnt[(size_t)p + 1] += cnt[(size_t)p];
       sparse_rows.reset((size_t)cnt[(size_t)pieces]);
       dense_rows.reset((size_t)(n - cnt[(size_t)pieces]));
@@ -339,7 +449,7 @@ class GrayReorder : public Reorderer<IDType> {
             else dense_rows[(size_t)d++] = (IDType)i;
           }
         }
-      });
+      }, 1);
     }
     last_stage_ms()[3] = ms_since(t_host);
     auto t_part = clock::now();

@@ -12,8 +12,10 @@ inline int &checks() { static int c = 0; return c; }
 struct Test { const char *name; void (*fn)(); };
 inline std::vector<Test> &registry() { static std::vector<Test> r; return r; }
 struct Registrar { Registrar(const char *n, void (*f)()) { registry().push_back({n, f}); } };
-inline int run_all() {
+// filter: only the tests whose "Suite.Name" starts with it (nullptr: all)
+inline int run_all(const char *filter = nullptr) {
   for (auto &t : registry()) {
+    if (filter && std::string(t.name).rfind(filter, 0) != 0) continue;
     const int before = failures();
     try { t.fn(); }
     catch (std::exception &e) { std::printf("  uncaught exception in %s: %s\n", t.name, e.what()); failures()++; }

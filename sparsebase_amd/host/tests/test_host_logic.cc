@@ -226,6 +226,22 @@ TEST(Format, OwnershipAndCasting) {
 
 // The exact Gray mode's sorts must leave what libstdc++'s std::sort leaves (ties included): the threaded form against
 // the library call on the kinds of input the reorderer sorts, with grains small enough to split every range many times.
+TEST(GraySort, ReplicaSelfCheckPassesOnThisLibrary) {
+  // (the once-per-process check GrayIntroSort runs before its first parallel sort; compiled out — and trivially absent —
+  // outside the window of libstdc++ releases the replica is built for)
+#if defined(SBX_GRAY_SORT_REPLICA)
+  EXPECT_TRUE(reorder::detail::GraySortReplicaAgrees());
+#endif
+  // the shared budget: leases never hand out more than kMax extra threads together, and give them back
+  {
+    reorder::detail::GrayThreadBudget a(16), b(16), c(16);
+    EXPECT_TRUE(a.threads() >= 1 && b.threads() >= 1 && c.threads() >= 1);
+    EXPECT_TRUE(a.threads() + b.threads() + c.threads() - 3 <= (unsigned)reorder::detail::GrayThreadBudget::kMax);
+  }
+  reorder::detail::GrayThreadBudget again(2);
+  EXPECT_TRUE(again.threads() >= 1);
+}
+
 TEST(GraySort, ParallelReplicaOfStdSort) {
   unsigned long long state = 88172645463325252ull;
   auto rnd = [&state]() {
@@ -294,4 +310,4 @@ TEST(Device, FailsLoudlyWithoutAGpu) {
   EXPECT_THROW(COO3 unsorted(4, 4, 4, r, c, v, format::kNotOwned), utils::HIPDeviceException);
 }
 
-int main() { return minitest::run_all(); }
+int main(int argc, char **argv) { return minitest::run_all(argc > 1 ? argv[1] : nullptr); }

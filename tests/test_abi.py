@@ -42,7 +42,7 @@ def test_ctypes_table_matches_header(lib_path):
     from sparsebase_amd import capi
     assert sorted(capi.PROTOTYPES) == header_functions()
     lib = capi.load()
-    assert lib.sbx_version() == 101
+    assert lib.sbx_version() == 102
     assert lib.sbx_status_string(2) == b"no usable HIP device"
     names = [lib.sbx_profile_kernel_name(i).decode() for i in range(lib.sbx_profile_kernel_count())]
     assert "permute_tile" in names and "bfs_expand" in names

@@ -205,6 +205,71 @@ def test_c5_gray_end_to_end_100m_banded(oracle, tmp_path, half_bandwidth):
         assert np.array_equal(got, want), (half_bandwidth, params)
 
 
+def _check_gray_device_ordering(ops, oracle, rp, col, n, params, idx64):
+    """sbx_gray_reorder (stable ties) against the numpy statement of that order row for row, and against the
+    reference-exact oracle on every row whose place the reference's comparators decide."""
+    from test_gpu_parity import _gray_stable_model
+    res, thr, grp = params
+    hrp, hcol = rp.cpu().numpy(), col.cpu().numpy()
+    drp, dcol = (rp.long(), col.long()) if idx64 else (rp, col)
+    inv_t = ops.gray_reorder(n, drp, dcol, res, thr, grp)
+    assert inv_t.dtype == (torch.int64 if idx64 else torch.int32)
+    inv = inv_t.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(inv), np.arange(n))
+    deg, key, counts = oracle.gray_row_keys(hrp, hcol, n, res, thr)
+    model, group = _gray_stable_model(deg, key, counts, min(res, n), thr, grp)
+    assert np.array_equal(inv, model), (params, idx64)
+    # rows with a unique (class, section, key): the reference's comparators decide their place
+    g = np.ascontiguousarray(group).view([("", group.dtype)] * group.shape[1]).ravel()
+    _, first, cnt = np.unique(g, return_index=True, return_counts=True)
+    decided = first[cnt == 1]
+    want = oracle.gray_reorder(hrp, hcol, n, res, thr, grp).astype(np.int64)
+    assert np.array_equal(inv[decided], want[decided]), (params, idx64, len(decided))
+    return len(decided)
+
+
+@pytest.mark.parametrize("idx64", [False, True])
+def test_c3_gray_device_ordering_100m(ops, oracle, c3, idx64):
+    """sbx_gray_reorder at the size the bench line times it (4.2 M rows, 105 M nnz: the radix sorts take their one-sweep
+    paths, the key stage its power-law kernels), 32- and 64-bit index arrays."""
+    rp, col, _ = c3
+    n = rp.numel() - 1
+    decided = _check_gray_device_ordering(ops, oracle, rp, col, n, (32, 10, 4), idx64)
+    assert decided > 1000
+
+
+@pytest.mark.parametrize("half_bandwidth,idx64", [(64, False), ((1 << 22) // 16, False), ((1 << 22) // 16, True)])
+def test_c5_gray_device_ordering_100m_banded(ops, oracle, half_bandwidth, idx64):
+    """The same at BASELINE config 5 (both half-bandwidths: the "highly banded" early-out and the full bitmap path)."""
+    n = 1 << 22
+    rp, col = synth.banded_symmetric_torch(n, half_bandwidth, per_row=12, seed=2)
+    for params in ((32, 10, 4), (16, 20, max(1, (col.numel() // n) // 16))):
+        _check_gray_device_ordering(ops, oracle, rp, col, n, params, idx64)
+
+
+def test_gray_stable_device_ordering_through_cpp(oracle, tmp_path):
+    """GrayReorderParams::stable_device_ordering through the C++ layer (reorder_cli gray --device --stable): the same
+    order as the C ABI's, on the power-law mid-size instance and on a banded one."""
+    import subprocess
+    from test_gpu_parity import _gray_stable_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "sparsebase_amd", "host", "bin", "reorder_cli")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "sparsebase_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for (rp, col), params in ((synth.rmat_symmetric(17, 10, seed=3), (32, 10, 4)),
+                              (synth.banded_symmetric(1 << 18, 4096, 12, 5), (16, 20, 2))):
+        n = len(rp) - 1
+        a, b, o = (str(tmp_path / x) for x in ("rp.bin", "col.bin", "out.bin"))
+        rp.tofile(a)
+        col.tofile(b)
+        for where in (["--device"], []):  # device-resident HIPCSR, and a host CSR staged through the GPU
+            subprocess.run([cli, "gray", a, b, o, str(n), str(n), *map(str, params), *where, "--stable"], check=True,
+                           env=env, timeout=600)
+            got = np.fromfile(o, np.int32).astype(np.int64)
+            deg, key, counts = oracle.gray_row_keys(rp, col, n, params[0], params[1])
+            model, _ = _gray_stable_model(deg, key, counts, min(params[0], n), params[1], params[2])
+            assert np.array_equal(got, model), (params, where)
+
+
 def test_c4_one_of_eight_shards_of_1b_nnz(ops, oracle):
     """BASELINE config 4's per-rank workload on this one GPU: the scale-25 RMAT instance (~1.18 B nnz, 33.5 M rows),
     a seeded random permutation, one of the 8 new-row shards through sbx_permute_csr_rows — the properties of

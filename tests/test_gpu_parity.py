@@ -1625,3 +1625,69 @@ def test_rcm_refuses_unsymmetric_patterns(ops, oracle):
     deg = np.diff(rp)
     assert stats["isolated"] == int((deg == 0).sum()) and stats["components"] >= stats["isolated"] + 1
     assert stats["reference_sweeps"] >= 2 or stats["large_components"] == 0
+
+
+@pytest.mark.gpu
+def test_rcm_on_a_callers_nonblocking_stream_the_way_a_c_caller_reads_it(oracle):
+    """include/sbx.h, Conventions: device outputs are complete in the order of the handle's stream, and sbx_rcm_reorder
+    returns with the kernel that writes the big component's positions enqueued behind its last read-back.  A C caller
+    with its own NON-BLOCKING stream (no implicit ordering against the null stream) reads inv_perm_out three legal
+    ways — sbx_sync then a blocking hipMemcpy on the null stream; an event recorded on the handle's stream that another
+    non-blocking stream waits for before its own copy; sbx_memcpy_d2h — and must get the finished order every time,
+    call after call (the window is a ~30 us kernel: 30 rounds)."""
+    import ctypes as C
+    from sparsebase_amd import capi
+    lib = capi.load()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipEventDestroy.argtypes = [C.c_void_p]
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    NONBLOCKING, D2H = 1, 2
+    rp, col = synth.rmat_symmetric(18, 12, seed=21)   # one big component: the deferred kernel writes most of the order
+    n = len(rp) - 1
+    want = oracle.rcm_reorder(rp, col)
+    d_rp, d_col = dev(rp), dev(col)
+    d_inv = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    s_user, s_other, ev = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(s_user), NONBLOCKING) == 0
+    assert hip.hipStreamCreateWithFlags(C.byref(s_other), NONBLOCKING) == 0
+    assert hip.hipEventCreateWithFlags(C.byref(ev), 2) == 0   # hipEventDisableTiming
+    h = C.c_void_p()
+    assert lib.sbx_create(0, C.byref(h)) == 0
+    try:
+        assert lib.sbx_set_stream(h, s_user) == 0
+        got = np.empty(n, np.int32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        for rnd in range(30):
+            mode = rnd % 3
+            assert hip.hipMemsetAsync(p(d_inv), 0xFF, n * 4, s_user) == 0   # (on the handle's stream: ordered before the call)
+            st = capi.RcmStats()
+            rc = lib.sbx_rcm_reorder(h, 0, n, len(col), p(d_rp), p(d_col), p(d_inv), C.byref(st))
+            assert rc == 0, lib.sbx_last_error(h)
+            assert st.largest_component > n // 2
+            got[:] = -2
+            if mode == 0:
+                assert lib.sbx_sync(h) == 0
+                assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), p(d_inv), n * 4, D2H) == 0
+            elif mode == 1:
+                assert hip.hipEventRecord(ev, s_user) == 0
+                assert hip.hipStreamWaitEvent(s_other, ev, 0) == 0
+                assert hip.hipMemcpyAsync(got.ctypes.data_as(C.c_void_p), p(d_inv), n * 4, D2H, s_other) == 0
+                assert hip.hipStreamSynchronize(s_other) == 0
+            else:
+                assert lib.sbx_memcpy_d2h(h, got.ctypes.data_as(C.c_void_p), p(d_inv), n * 4) == 0
+            assert np.array_equal(got, want), (rnd, mode, int((got != want).sum()))
+    finally:
+        lib.sbx_sync(h)
+        lib.sbx_destroy(h)
+        hip.hipEventDestroy(ev)
+        hip.hipStreamDestroy(s_other)
+        hip.hipStreamDestroy(s_user)
