@@ -476,10 +476,11 @@ def cpp_legs(n, nnz, rp, col, op):
                 lines = r.stdout.split("\n")
                 dev_ms, d2h_ms, host_ms = (float(x) for x in lines[1].split())
                 res["gray"] = dict(op["gray"], end_to_end={
-                    "ms": float(lines[0]) * 1e3, "device_key_stage_ms_incl_clock_ramp": dev_ms, "keys_to_host_ms": d2h_ms,
+                    "ms": float(lines[0]) * 1e3, "device_key_stage_ms": dev_ms, "keys_to_host_ms": d2h_ms,
                     "host_ordering_ms": host_ms, "via": "host/bin/reorder_cli --device --time (warm call)",
-                    "note": "the key stage reads milliseconds here against key_stage.ms in-process: the GPU clocks down "
-                            "while the host stage of the call before sorts"})
+                    "note": "degrees and keys are downloaded into page-locked, pooled host blocks: with pageable targets "
+                            "(rounds 3 - 5) the runtime's unpinning of the previous call's targets held this call's first "
+                            "kernel back by 14 - 25 ms (tools/gray_kt2.sh, tools/gray_stall_probe.sh)"})
             except Exception as e:  # noqa: BLE001
                 res["gray"] = dict(op["gray"], end_to_end={"error": repr(e)[:200]})
     except Exception as e:  # noqa: BLE001

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SBX_VERSION 102 /* 0.1.2: sbx_set_oom_hook added (101: sbx_rcm_stats.unordered_sweeps, sbx_gray_reorder) */
+#define SBX_VERSION 102 /* 0.1.2: sbx_set_oom_hook, sbx_host_alloc / sbx_host_free added (101: sbx_rcm_stats.unordered_sweeps, sbx_gray_reorder) */
 
 typedef struct sbx_handle_s *sbx_handle_t;
 
@@ -129,6 +129,12 @@ int sbx_profile_query_bytes(sbx_handle_t h, int index, int64_t *alg_bytes_host);
 
 int sbx_malloc(sbx_handle_t h, size_t bytes, void **dev_ptr_host);
 int sbx_free(sbx_handle_t h, void *dev_ptr);
+/* Page-locked host memory for the blocking copies below (the reference stages through pageable arrays; a pageable
+ * target is pinned and unpinned by the runtime around every copy, and on this platform the unpinning of a target that
+ * is then freed stalls the process's next GPU submission by milliseconds: tools/gray_kt2.sh).  Plain host pointers,
+ * readable and writable by the host like any other; freed with sbx_host_free only. */
+int sbx_host_alloc(sbx_handle_t h, size_t bytes, void **host_ptr_host);
+int sbx_host_free(sbx_handle_t h, void *host_ptr);
 /* blocking copies (stream-ordered after prior work on the handle's stream) */
 int sbx_memcpy_h2d(sbx_handle_t h, void *dst_dev, const void *src_host, size_t bytes);
 int sbx_memcpy_d2h(sbx_handle_t h, void *dst_host, const void *src_dev, size_t bytes);

@@ -60,6 +60,8 @@ PROTOTYPES = {
     "sbx_profile_query_bytes": ([_H, _int, C.POINTER(_i64)], _int),
     "sbx_malloc": ([_H, _sz, C.POINTER(_vp)], _int),
     "sbx_free": ([_H, _vp], _int),
+    "sbx_host_alloc": ([_H, _sz, C.POINTER(_vp)], _int),
+    "sbx_host_free": ([_H, _vp], _int),
     "sbx_memcpy_h2d": ([_H, _vp, _vp, _sz], _int),
     "sbx_memcpy_d2h": ([_H, _vp, _vp, _sz], _int),
     "sbx_memcpy_d2d": ([_H, _vp, _vp, _sz], _int),

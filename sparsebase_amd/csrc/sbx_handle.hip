@@ -351,6 +351,23 @@ extern "C" int sbx_free(sbx_handle_t h, void *dev_ptr) {
   return SBX_OK;
 }
 
+extern "C" int sbx_host_alloc(sbx_handle_t h, size_t bytes, void **host_ptr_host) {
+  if (!h || !host_ptr_host) return SBX_ERR_BAD_ARG;
+  SBX_HIP(h, hipSetDevice(h->device));
+  *host_ptr_host = nullptr;
+  if (bytes == 0) bytes = 1;
+  SBX_HIP(h, hipHostMalloc(host_ptr_host, bytes, hipHostMallocDefault));
+  return SBX_OK;
+}
+
+extern "C" int sbx_host_free(sbx_handle_t h, void *host_ptr) {
+  if (!h) return SBX_ERR_BAD_ARG;
+  if (!host_ptr) return SBX_OK;
+  SBX_HIP(h, hipSetDevice(h->device));
+  SBX_HIP(h, hipHostFree(host_ptr));
+  return SBX_OK;
+}
+
 static int copy_blocking(sbx_handle_t h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (!h || (bytes && (!dst || !src))) return SBX_ERR_BAD_ARG;
   if (bytes == 0) return SBX_OK;

@@ -109,10 +109,12 @@ int main(int argc, char **argv) {
   const int n = atoi(argv[5]), m = atoi(argv[6]);
   if (kind == "pipeline") return pipeline(rp, col, n, m, argv[4]);
   bool on_device = false, timed = false, stable = false;
+  int idle_ms = 0;
   for (int i = 7; i < argc; i++) {
     on_device |= !strcmp(argv[i], "--device");
     timed |= !strcmp(argv[i], "--time");
     stable |= !strcmp(argv[i], "--stable");  // gray: GrayReorderParams::stable_device_ordering (sbx_gray_reorder)
+    if (!strcmp(argv[i], "--idle-ms") && i + 1 < argc) idle_ms = atoi(argv[i + 1]);  // (diagnostic: busy host between calls)
   }
   utils::Logger::set_level(utils::LOG_LVL_NONE);
   context::CPUContext cpu;
@@ -151,6 +153,10 @@ int main(int argc, char **argv) {
     for (int warm = 0; warm < 4; warm++) {  // (the library's scratch arena settles into one block over the first calls)
       order = run();
       delete[] order;
+    }
+    if (idle_ms > 0) {
+      const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(idle_ms);
+      while (std::chrono::steady_clock::now() < until) {}
     }
     const auto t0 = std::chrono::steady_clock::now();
     order = run();

@@ -6,6 +6,7 @@
 #define SPARSEBASE_HIP_DEVICE_H_
 #include <cstdlib>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -122,6 +123,53 @@ class Device {
     }();
     return lim;
   }
+  // Page-locked host blocks for downloads the host layer consumes itself (GrayReorder's degrees and keys), pooled like
+  // the device blocks (same limit variable, counted apart): a pageable target is pinned and unpinned by the runtime
+  // around every copy, and freeing it afterwards stalled the process's next GPU submission by 14 - 22 ms
+  // (tools/gray_kt2.sh).  SBX_HOST_PINNED_STAGING=0: pageable arrays as before (diagnostic).
+  static bool pinned_staging() {
+    static const bool on = [] {
+      const char *e = std::getenv("SBX_HOST_PINNED_STAGING");
+      return !(e && e[0] == '0');
+    }();
+    return on;
+  }
+  void *HostMalloc(size_t bytes) const {
+    if (bytes == 0) bytes = 1;
+    {
+      std::lock_guard<std::mutex> lock(pool_mu_);
+      auto it = host_free_.find(bytes);
+      if (it != host_free_.end() && !it->second.empty()) {
+        void *p = it->second.back();
+        it->second.pop_back();
+        host_pooled_bytes_ -= bytes;
+        host_live_[p] = bytes;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    Check(sbx_host_alloc(h_, bytes, &p));
+    std::lock_guard<std::mutex> lock(pool_mu_);
+    host_live_[p] = bytes;
+    return p;
+  }
+  void HostFree(void *p) const {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lock(pool_mu_);
+      auto it = host_live_.find(p);
+      if (it != host_live_.end()) {
+        const size_t bytes = it->second;
+        host_live_.erase(it);
+        if (host_pooled_bytes_ + bytes <= pool_limit() / 4) {  // (at most a quarter of the device pool's limit: 1 GB)
+          host_free_[bytes].push_back(p);
+          host_pooled_bytes_ += bytes;
+          return;
+        }
+      }
+    }
+    sbx_host_free(h_, p);
+  }
   void ToDevice(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_h2d(h_, dst, src, bytes)); }
   void ToHost(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2h(h_, dst, src, bytes)); }
   void Copy(void *dst, const void *src, size_t bytes) const { Check(sbx_memcpy_d2d(h_, dst, src, bytes)); }
@@ -153,6 +201,36 @@ class Device {
   mutable std::unordered_map<void *, size_t> pool_live_;       // blocks handed out by Malloc: their sizes
   mutable std::map<size_t, std::vector<void *>> pool_free_;    // released blocks by size
   mutable size_t pooled_bytes_ = 0;
+  mutable std::unordered_map<void *, size_t> host_live_;       // page-locked host blocks, the same way
+  mutable std::map<size_t, std::vector<void *>> host_free_;
+  mutable size_t host_pooled_bytes_ = 0;
+};
+
+// n elements of page-locked (or, with SBX_HOST_PINNED_STAGING=0, plain) host memory, left uninitialised: the target of a
+// download whose contents the host layer reads itself
+template <typename T>
+class HostStaging {
+ public:
+  HostStaging(const Device &d, size_t n) : d_(d), n_(n), pinned_(Device::pinned_staging()) {
+    static_assert(std::is_trivially_default_constructible<T>::value && std::is_trivially_destructible<T>::value, "raw storage");
+    p_ = n ? (pinned_ ? static_cast<T *>(d.HostMalloc(n * sizeof(T))) : new T[n]) : nullptr;
+  }
+  ~HostStaging() {
+    if (pinned_) d_.HostFree(p_);
+    else delete[] p_;
+  }
+  HostStaging(const HostStaging &) = delete;
+  HostStaging &operator=(const HostStaging &) = delete;
+  size_t size() const { return n_; }
+  T *data() { return p_; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+
+ private:
+  const Device &d_;
+  size_t n_;
+  bool pinned_;
+  T *p_;
 };
 
 // RAII device allocation used for staging host-resident formats through the GPU

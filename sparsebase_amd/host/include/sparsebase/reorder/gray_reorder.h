@@ -397,8 +397,8 @@ class GrayReorder : public Reorderer<IDType> {
     using clock = std::chrono::steady_clock;
     auto ms_since = [](clock::time_point t) { return std::chrono::duration<double, std::milli>(clock::now() - t).count(); };
     // ---- device stage
-    detail::GrayBuffer<IDType> deg((size_t)n);
-    detail::GrayBuffer<uint64_t> key((size_t)n);
+    hip::HostStaging<IDType> deg(*v.dev, (size_t)n);   // (page-locked and pooled: see hip/device.h)
+    hip::HostStaging<uint64_t> key(*v.dev, (size_t)n);
     int64_t counts[4] = {0, 0, 0, 0};
     {
       hip::Staged<IDType> d_deg(*v.dev, (size_t)n);
@@ -411,7 +411,13 @@ class GrayReorder : public Reorderer<IDType> {
       t0 = clock::now();
       if (rc == SBX_OK && n > 0) {
         d_deg.ToHost(deg.data());
-        d_key.ToHost(key.data());
+        // the keys are read by the sections' sorts (unless the sparse rows are "highly banded", gray_reorder.cc:223) and by
+        // the dense rows' sort (unless those are, :369, or there are none: with a threshold >= 0 a dense row has entries):
+        // a banded matrix that takes both early-outs never looks at them, and their copy is two thirds of the download
+        const bool sparse_early_out = double((int)counts[1]) / (int)counts[0] > 0.3;
+        const bool dense_early_out = double((int)counts[3]) / (int)counts[2] > 0.2;
+        const bool no_dense_rows = counts[2] == 0 && params->nnz_threshold >= 0;
+        if (!(sparse_early_out && (dense_early_out || no_dense_rows))) d_key.ToHost(key.data());
       }
       last_stage_ms()[1] = ms_since(t0);
       v.Release();
