@@ -27,7 +27,19 @@
  *  - Return value: SBX_OK (0) or an sbx_status error code; nothing throws
  *    across this boundary.  sbx_last_error() gives a message for the last
  *    failing call on the handle.
- *  - Index type: IDType and NNZType share one width (SBX_I32 or SBX_I64).
+ *  - Index type: SBX_I32 / SBX_I64 — IDType and NNZType share one width — or
+ *    SBX_I32_N64, the tuple a matrix with fewer than 2^31 rows and columns and
+ *    64-bit offsets uses (the reference pre-instantiates it, CMakeLists.txt:15-17:
+ *    <int | unsigned int ids, long long | unsigned long long offsets>): every
+ *    OFFSET array — row_ptr, col_ptr, their outputs — holds 64-bit words, every
+ *    ID array (row, col, orders, inverse permutations, degrees) 32-bit words.
+ *    COO <-> CSR, the degree order and the row-pointer features read and write
+ *    the 64-bit offsets natively (nnz of any size); the other entry points that
+ *    take offsets (permutes, constructor sort of CSR, CSC conversions, RCM, Gray)
+ *    keep 32-bit offsets inside: nnz < 2^31, the offsets are narrowed to scratch
+ *    and widened back (n + 1 words each way), larger nnz is SBX_ERR_UNSUPPORTED.
+ *    Entry points without an offset array treat SBX_I32_N64 as SBX_I32; the
+ *    sharded (multi-GPU) entry points do not take it.
  *    uint32 index arrays alias SBX_I32 (all dimensions must be < 2^31).
  *    SBX_I64: the conversions (CSC included), checks, features, degree order,
  *    permutes, both constructor sorts, RCM and the Gray keys read and write
@@ -51,7 +63,7 @@
 extern "C" {
 #endif
 
-#define SBX_VERSION 102 /* 0.1.2: sbx_set_oom_hook, sbx_host_alloc / sbx_host_free added (101: sbx_rcm_stats.unordered_sweeps, sbx_gray_reorder) */
+#define SBX_VERSION 102 /* 0.1.2: sbx_set_oom_hook, sbx_host_alloc / sbx_host_free, SBX_I32_N64 added (101: sbx_rcm_stats.unordered_sweeps, sbx_gray_reorder) */
 
 typedef struct sbx_handle_s *sbx_handle_t;
 
@@ -65,7 +77,11 @@ typedef enum sbx_status {
   SBX_ERR_INTERNAL = 6
 } sbx_status;
 
-typedef enum sbx_index_type { SBX_I32 = 0, SBX_I64 = 1 } sbx_index_type;
+typedef enum sbx_index_type {
+  SBX_I32 = 0,    /* 32-bit ids, 32-bit offsets */
+  SBX_I64 = 1,    /* 64-bit ids, 64-bit offsets */
+  SBX_I32_N64 = 2 /* 32-bit ids, 64-bit offsets (row_ptr / col_ptr arrays) */
+} sbx_index_type;
 
 typedef enum sbx_value_type {
   SBX_V_NONE = 0, /* ValueType = void, or vals == nullptr */

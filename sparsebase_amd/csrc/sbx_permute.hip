@@ -1215,6 +1215,408 @@ __global__ __launch_bounds__(PT_THREADS) void k_permute_tile_radix(
   }
 }
 
+// ---- the tile kernel of the permutes that relabel (round 6) ---------------------------------------------------------
+// What the kernel above spends its instructions on is not the sort alone: with sort and gathers switched off it streams
+// its 458 MB at 1.85 TB/s (the row classes: 4) — the row map (LDS scan, two more LDS round trips), 64-bit address
+// arithmetic for every load and store, a predicate around every per-entry statement, the rows' min / max.  This kernel
+// keeps the formulation (a wave per tile of up to 512 entries, 8 per lane at position k * 64 + lane, bucket-rank sort)
+// and removes those:
+//   * row map from BALLOTS: a row marks its first position in a 512-bit mask (one LDS atomic) and leaves ONE 16-byte
+//     record there (source - position, output - position, length, log2 buckets); the mask's 16 words become scalars, an
+//     entry finds its row's head with a count-leading-zeros on the lanes below it, and reads that one record;
+//   * loads, gathers and stores through BUFFER descriptors with 32-bit offsets (the caller checks that the arrays fit
+//     4 GB): one multiply per address, and a dead position is an out-of-range offset — loads return 0, stores are
+//     dropped — so nothing in the kernel carries a predicate except the counter index of the dead positions;
+//   * the neighbour key for the order and duplicate checks comes through DPP, not LDS;
+//   * buckets from the key-distribution map F (below: k_cdf_sample) instead of the row's min / max: no min / max pass,
+//     and no second level — under an ordering like RCM's 61 % of the entries shared an equal-width bucket with more
+//     than four others and every tile took the interpolating level; with F 1 % do, and a fuller bucket is ranked by a
+//     loop (a bucket holds at most a row: 128);
+//   * the count pass returns the arrival number, placement = bucket start + arrival (no second atomic sweep); four
+//     neighbour words ranked unrolled; sorted (column, value) pairs through LDS as 8-byte accesses.
+// Words are key << 7 | arrival (distinct; duplicates fall in arrival order and are ordered by value afterwards,
+// k_fix_dup_runs), so the ids must fit CDF_MAX_COL_BITS bits.  Anything else — wider ids, arrays beyond 4 GB, callers
+// that sort without relabelling (they need stable sorts) — keeps the kernel above.
+//
+// The key-distribution map.  Relabelled columns are not spread evenly: a column turns up in proportion to its degree,
+// and an ordering that means something packs the heavy columns together (RCM: the hubs of a power-law graph sit in a
+// few BFS levels).  What all rows have in common is the GLOBAL distribution of the new ids, and that is cheap to
+// estimate: k_cdf_sample relabels 2^18 entries taken at regular distances from the column array and counts them in
+// CDF_K bins of the new id space; k_cdf_table turns the counts (mixed with 1/9 of a uniform distribution: no bin is
+// flat) into a monotone piecewise-linear F: [0, m) -> [0, 2^32), (base, slope / 2^16) per bin, which the tile kernel
+// keeps in LDS: bucket = F(key) >> (32 - log2 buckets).  The map only balances buckets — any monotone F sorts right.
+constexpr int CDF_K = 256;
+constexpr int CDF_LOG_K = 8;
+constexpr int CDF_MAX_COL_BITS = 25;
+constexpr int CDF_SAMPLE_BLOCKS = 64, CDF_SAMPLE_ITEMS = 16;  // x 256 threads = 2^18 samples
+constexpr uint64_t PT2_MAX_BYTES = 0xFFFFFFC0ull;             // arrays addressed by 32-bit byte offsets
+constexpr unsigned PT2_DEAD_ELEM = 0x3FFFFFFCu;               // x 4 or x 8 (mod 2^32) lies behind every such array
+
+struct CdfMap {
+  const uint2 *table;  // CDF_K x (base, slope >> 16); nullptr: no map (the equal-width kernels run)
+  int shift;           // bin = key >> shift
+  int fsh;             // position inside the bin, 16 bits: (key << fsh) >> 16
+};
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_cdf_sample(const I *__restrict__ col_in, const I *__restrict__ col_order,
+                                                    int64_t nnz, int64_t m, int shift, unsigned *__restrict__ hist) {
+  static_assert(CDF_K == 256, "one bin per thread");
+  __shared__ unsigned s_h[CDF_K];
+  const int tid = threadIdx.x;
+  s_h[tid] = 0;
+  __syncthreads();
+  const int64_t S = (int64_t)gridDim.x * 256 * CDF_SAMPLE_ITEMS;
+  const int64_t stride = nnz >= S ? nnz / S : 1;
+  unsigned c[CDF_SAMPLE_ITEMS], k[CDF_SAMPLE_ITEMS];
+#pragma unroll
+  for (int u = 0; u < CDF_SAMPLE_ITEMS; u++) {
+    const int64_t j = ((int64_t)blockIdx.x * CDF_SAMPLE_ITEMS + u) * 256 + tid;
+    const int64_t pos = j * stride;
+    c[u] = pos < nnz ? (unsigned)col_in[pos] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int u = 0; u < CDF_SAMPLE_ITEMS; u++)
+    k[u] = (uint64_t)c[u] < (uint64_t)m ? (unsigned)col_order[c[u]] : 0xFFFFFFFFu;
+#pragma unroll
+  for (int u = 0; u < CDF_SAMPLE_ITEMS; u++) {
+    if ((uint64_t)k[u] < (uint64_t)m) {
+      const unsigned bin = k[u] >> shift;
+      atomicAdd(&s_h[bin < (unsigned)CDF_K ? bin : (unsigned)CDF_K - 1u], 1u);
+    }
+  }
+  __syncthreads();
+  if (s_h[tid]) atomicAdd(&hist[tid], s_h[tid]);
+}
+
+__global__ __launch_bounds__(CDF_K) void k_cdf_table(const unsigned *__restrict__ hist, uint2 *__restrict__ table,
+                                                     int flat) {
+  __shared__ unsigned long long s_scan[CDF_K / 64 + 1];
+  const int tid = threadIdx.x;
+  const unsigned long long hcnt = hist[tid];
+  const unsigned long long total = sbx_block_sum<unsigned long long, CDF_K>(hcnt, s_scan);
+  const unsigned long long w = hcnt * (8ull * CDF_K) + total + 1ull;  // eight parts sample, one part uniform
+  unsigned long long W = 0;
+  const unsigned long long cum = sbx_block_exclusive_sum<unsigned long long, CDF_K>(w, s_scan, &W);
+  const unsigned long long b0 = (cum << 32) / W, b1 = tid == CDF_K - 1 ? (1ull << 32) : ((cum + w) << 32) / W;
+  // F(key) = base + (slope >> 16) * (16-bit position inside the bin) < base + slope = the next bin's base
+  // (flat: fewer ids than bins — every id is a bin of its own)
+  table[tid] = make_uint2((unsigned)b0, flat ? 0u : (unsigned)((b1 - b0) >> 16));
+}
+
+// enqueues the map's kernels on h->stream; map->table == nullptr afterwards: not applicable
+template <typename I>
+static int build_cdf_map(sbx_handle_t h, const I *col_in, const I *col_order, int64_t nnz, int64_t m, CdfMap *map) {
+  map->table = nullptr, map->shift = 0, map->fsh = 0;
+  const int col_bits = sbx_bits_for(m > 0 ? (uint64_t)(m - 1) : 0);
+  if (col_bits > CDF_MAX_COL_BITS || nnz <= 0 || !col_order) return SBX_OK;
+  unsigned *hist = nullptr;
+  uint2 *table = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)CDF_K, &hist));
+  SBX_TRY(sbx_salloc(h, (size_t)CDF_K, &table));
+  SBX_HIP(h, hipMemsetAsync(hist, 0, sizeof(unsigned) * CDF_K, h->stream));
+  const int shift = col_bits > CDF_LOG_K ? col_bits - CDF_LOG_K : 0;
+  const int64_t want = (nnz + 256 * CDF_SAMPLE_ITEMS - 1) / (256 * CDF_SAMPLE_ITEMS);
+  const unsigned blocks = (unsigned)(want < CDF_SAMPLE_BLOCKS ? want : CDF_SAMPLE_BLOCKS);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_cdf_sample<I>, dim3(blocks), dim3(256), col_in, col_order, nnz, m, shift, hist);
+  SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_cdf_table, dim3(1), dim3(CDF_K), (const unsigned *)hist, table, shift == 0 ? 1 : 0);
+  SBX_LAUNCH_CHECK(h);
+  map->table = table, map->shift = shift, map->fsh = shift ? 32 - shift : 0;
+  return SBX_OK;
+}
+
+#define PT2_RSRC_FLAGS 0x00020000  // raw buffer, 32-bit data format (gfx9 descriptor word 3)
+typedef unsigned pt2_u2 __attribute__((ext_vector_type(2)));
+
+template <typename I, int VB>
+__global__ __launch_bounds__(PT_THREADS, 4) void k_permute_tile2(
+    const int2 *__restrict__ rec, const I *col_in, const char *val_in, const I *__restrict__ col_order,
+    const I *__restrict__ rpo, const I *__restrict__ sp, const I *__restrict__ tile_first, I *col_out, char *val_out,
+    int64_t nr, PermState *__restrict__ st, int64_t tiles, unsigned in_bytes_c, unsigned in_bytes_v, unsigned out_bytes_c,
+    unsigned out_bytes_v, unsigned table_bytes, const CdfMap cdf) {
+  typedef typename ValT<VB>::type V;
+  constexpr bool HASV = VB != 0;
+  constexpr int IB = (int)sizeof(I);
+  constexpr int ITEMS = 8, CAP = 512;
+  static_assert(PT_THREADS == 64 && PT_CAP == CAP && PT_ITEMS == ITEMS && PT_LMAX <= 128, "one wave, 8 entries per lane, rows of at most 128");
+  // LDS words of the wave's pool, by phase (6.2 KB: the waves per CU follow from it):
+  //   row map   [0, 2 CAP)  the rows' records, 8 bytes per head position
+  //   sort      [0, W_WRD)  counters (2 per position, the dead positions' word, pad); [W_WRD, POOL) the placed words
+  //   out       [0, ...)    the sorted keys (VB 4: (key, value) pairs; VB 8: keys, then the 8-byte values)
+  constexpr int W_WRD = 2 * CAP + 8, POOL = W_WRD + CAP + 8;
+  constexpr int JUNK = 2 * CAP + 4;
+  static_assert(2 * (CAP + 1) <= W_WRD && (CAP + 8) + 2 * (CAP + 1) <= POOL, "the sorted entries fit where the sort's arrays were");
+  __shared__ __attribute__((aligned(16))) unsigned s_pool[POOL];
+  __shared__ unsigned s_mask[16];
+  __shared__ uint2 s_cdf[CDF_K];
+  uint2 *const s_rr = (uint2 *)s_pool;
+  unsigned *const s_c = s_pool;
+  unsigned *const s_w = s_pool + W_WRD;
+  unsigned *const s_key = s_pool;
+  uint2 *const s_pair = (uint2 *)s_pool;
+  uint64_t *const s_v8 = (uint64_t *)(s_pool + CAP + 8);
+#define T2_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  const int lane = threadIdx.x;
+  const uint64_t le = ((uint64_t)2 << lane) - 1;  // lanes 0 .. lane
+  const __amdgpu_buffer_rsrc_t b_ci = __builtin_amdgcn_make_buffer_rsrc((void *)col_in, 0, (int)in_bytes_c, PT2_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t b_vi = __builtin_amdgcn_make_buffer_rsrc((void *)val_in, 0, (int)in_bytes_v, PT2_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t b_tab = __builtin_amdgcn_make_buffer_rsrc((void *)col_order, 0, (int)table_bytes, PT2_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t b_co = __builtin_amdgcn_make_buffer_rsrc((void *)col_out, 0, (int)out_bytes_c, PT2_RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t b_vo = __builtin_amdgcn_make_buffer_rsrc((void *)val_out, 0, (int)out_bytes_v, PT2_RSRC_FLAGS);
+  for (int i = lane; i < CDF_K; i += 64) s_cdf[i] = cdf.table[i];
+  const int cdf_shift = cdf.shift, cdf_fsh = cdf.fsh;
+
+  const int64_t G = gridDim.x, last = tiles - 1;
+  auto clampt = [&](int64_t x) { return x < last ? x : last; };
+  auto clampr = [&](int64_t x) { return x < nr - 1 ? x : nr - 1; };
+  int64_t t = blockIdx.x;
+  TileIn<I> cur = tile_in_now<I>(clampt(t), rec, rpo, sp, tile_first, nr);
+  I ra1 = tile_first[clampt(t + G)], rb1 = tile_first[clampt(t + G) + 1];
+  bool any_uns = false, any_dup = false;
+  for (; t < tiles; t += G) {
+    // issued now, read after the current tile: range of the tile after next, bounds and row records of the next one
+    const I ra2 = tile_first[clampt(t + 2 * G)], rb2 = tile_first[clampt(t + 2 * G) + 1];
+    TileIn<I> nx;
+    nx.ra = ra1, nx.rb = rb1;
+    nx.e0 = sp[ra1];
+    nx.e1 = sp[rb1];
+    const int64_t r1 = clampr((int64_t)ra1 + lane);
+    nx.rc = rec[r1];
+    nx.sp_r = sp[r1];
+    nx.rpo_r = rpo[r1];
+    const TileIn<I> in = cur;
+    cur = nx;
+    ra1 = ra2, rb1 = rb2;
+
+    const int64_t ra = in.ra, rb = in.rb;
+    if (ra >= rb) continue;
+    const int64_t e0 = in.e0;
+    const int cnt = (int)((int64_t)in.e1 - e0);
+    if (cnt <= 0) continue;
+    // ---- row map: heads mark the mask and leave their record
+    if (lane < 16) s_mask[lane] = 0;
+    auto put_head = [&](const int p, const int2 rc, const I rpo_r) {
+      atomicOr(&s_mask[p >> 5], 1u << (p & 31));
+      const unsigned len = (unsigned)rc.x;
+      const unsigned lg = len > (unsigned)BK_SHORT ? (unsigned)bits_u32(len - 1u) : 0u;  // 2^lg buckets, 2^lg < 2 len; lg <= 7
+      // (source - position) << 3 | lg: the source array holds fewer than 2^28 entries (the caller checked)
+      s_rr[p] = make_uint2(((unsigned)(rc.y - p) << 3) | lg, (unsigned)((int)rpo_r - p));
+    };
+    if (rb - ra <= 4 * CAP) {
+      int64_t r = ra + lane;
+      if (r < rb) {  // the first row of every lane arrived with the tile's bounds
+        if (in.rc.x > 0 && in.rc.x <= PT_LMAX) put_head((int)((int64_t)in.sp_r - e0), in.rc, in.rpo_r);
+        r += 64;
+      }
+      for (; r < rb; r += 64) {
+        const int2 rc = rec[r];
+        if (rc.x > 0 && rc.x <= PT_LMAX) put_head((int)((int64_t)sp[r] - e0), rc, rpo[r]);
+      }
+    } else {  // a window of mostly empty rows: every position looks for the row that starts there
+      for (int p = lane; p < cnt; p += 64) {
+        const int64_t target = e0 + p;
+        int64_t lo = ra, hi = rb;
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if ((int64_t)sp[mid] <= target) lo = mid;
+          else hi = mid;
+        }
+        if ((int64_t)sp[lo] == target) {
+          const int2 rc = rec[lo];
+          if (rc.x > 0 && rc.x <= PT_LMAX) put_head(p, rc, rpo[lo]);
+        }
+      }
+    }
+    T2_SYNC();
+    const unsigned mw = s_mask[lane & 15];
+    T2_SYNC();
+    // ---- per entry: its row's head (the highest mask bit at or below its position), the row's record, the loads
+    unsigned c[ITEMS], oidx[ITEMS], meta[ITEMS];  // meta: position in the row | (31 - lg) << 8
+    unsigned hpv[ITEMS];
+    V kv[HASV ? ITEMS : 1];
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint64_t mk = (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mw, 2 * k) |
+                          ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)mw, 2 * k + 1) << 32);
+      const uint64_t x = mk & le;
+      const int hp = x ? k * 64 + 63 - __builtin_clzll(x) : carry;
+      if (mk) carry = k * 64 + 63 - __builtin_clzll(mk);
+      const int p = k * 64 + lane;
+      const bool live = p < cnt;
+      const uint2 rr = s_rr[hp];
+      const unsigned pin = (unsigned)(p - hp);
+      hpv[k] = (unsigned)hp;
+      meta[k] = pin | ((31u - (rr.x & 7u)) << 8);
+      const unsigned sidx = live ? (unsigned)(((int)rr.x >> 3) + p) : PT2_DEAD_ELEM;
+      oidx[k] = live ? rr.y + (unsigned)p : PT2_DEAD_ELEM;
+      c[k] = __builtin_amdgcn_raw_buffer_load_b32(b_ci, sidx * (unsigned)IB, 0, 2);
+      if (HASV) {
+        if (VB == 4) {
+          kv[k] = (V)__builtin_amdgcn_raw_buffer_load_b32(b_vi, sidx * 4u, 0, 2);
+        } else {
+          const pt2_u2 v2 = __builtin_amdgcn_raw_buffer_load_b64(b_vi, sidx * 8u, 0, 2);
+          kv[k] = (V)(((uint64_t)v2.y << 32) | v2.x);
+        }
+      }
+    }
+    unsigned kc[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) kc[k] = __builtin_amdgcn_raw_buffer_load_b32(b_tab, c[k] * (unsigned)IB, 0, 0);
+    // ---- order inside the rows (csr.cc:102-116): the neighbour in front through DPP
+    bool uns = false, dupq = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const unsigned first = k ? (unsigned)__builtin_amdgcn_readlane((int)kc[k - 1], 63) : 0u;
+      const unsigned prev = (unsigned)sbx_wave_shift_up1((int)kc[k], (int)first);
+      const bool inrow = (meta[k] & 0xFFu) != 0u && k * 64 + lane < cnt;
+      uns |= inrow & (kc[k] < prev);
+      dupq |= inrow & (kc[k] == prev);
+    }
+    if (!__any(uns)) {
+      // every row of the tile is in column order already: a sort would not move anything
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        if (IB == 4) {
+          __builtin_amdgcn_raw_buffer_store_b32(kc[k], b_co, oidx[k] * 4u, 0, 0);
+        } else {
+          pt2_u2 w2;
+          w2.x = kc[k], w2.y = 0u;
+          __builtin_amdgcn_raw_buffer_store_b64(w2, b_co, oidx[k] * 8u, 0, 0);
+        }
+        if (HASV) {
+          if (VB == 4) {
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)kv[k], b_vo, oidx[k] * 4u, 0, 0);
+          } else {
+            pt2_u2 w2;
+            w2.x = (unsigned)kv[k], w2.y = (unsigned)((uint64_t)kv[k] >> 32);
+            __builtin_amdgcn_raw_buffer_store_b64(w2, b_vo, oidx[k] * 8u, 0, 0);
+          }
+        }
+      }
+      any_dup |= dupq;
+      continue;
+    }
+    any_uns = true;
+    // ---- bucket-rank sort.  Counters: the row whose head is at hp owns the words [2 hp, 2 hp + 2^lg)
+    T2_SYNC();  // (the records have been read: the counters take their place)
+#pragma unroll
+    for (int i = 0; i < (2 * CAP) / 256; i++) *(uint4 *)&s_c[i * 256 + 4 * lane] = make_uint4(0, 0, 0, 0);
+    if (lane < 2) *(uint4 *)&s_c[2 * CAP + 4 * lane] = make_uint4(0, 0, 0, 0);
+    unsigned ci[ITEMS], ar[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint2 tb = s_cdf[kc[k] >> cdf_shift];
+      const unsigned f = tb.x + __umul24(tb.y, (kc[k] << cdf_fsh) >> 16);
+      const unsigned b = (f >> 1) >> (meta[k] >> 8);  // = f >> (32 - lg); lg = 0: 0
+      ci[k] = k * 64 + lane < cnt ? 2u * hpv[k] + b : (unsigned)JUNK;
+    }
+    T2_SYNC();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) ar[k] = atomicAdd(&s_c[ci[k]], 1u);
+    T2_SYNC();
+    {  // exclusive scan of the 2 cnt counters in place: a lane owns 16 consecutive ones
+      unsigned v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const uint4 q = *(const uint4 *)&s_c[16 * lane + i];
+        v[i] = q.x, v[i + 1] = q.y, v[i + 2] = q.z, v[i + 3] = q.w;
+      }
+      unsigned sum = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const unsigned y = v[i];
+        v[i] = sum;
+        sum += y;
+      }
+      const unsigned ex = sbx_wave_inclusive_sum(sum) - sum;
+#pragma unroll
+      for (int i = 0; i < 16; i += 4)
+        *(uint4 *)&s_c[16 * lane + i] = make_uint4(v[i] + ex, v[i + 1] + ex, v[i + 2] + ex, v[i + 3] + ex);
+      // (the words behind the counters: s_c[2 CAP] must read as the total for the last bucket's end)
+      if (lane == 63) s_c[2 * CAP] = ex + sum;
+    }
+    T2_SYNC();
+    // placement: slot = bucket start + arrival; the word orders a bucket by (column, arrival)
+    unsigned s0[ITEMS], cb[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const unsigned a0 = s_c[ci[k]], a1 = s_c[ci[k] + 1];
+      const bool live = k * 64 + lane < cnt;
+      s0[k] = a0;
+      cb[k] = live ? a1 - a0 : 0u;
+      s_w[live ? a0 + ar[k] : (unsigned)CAP + 4u] = (kc[k] << 7) | ar[k];  // (dead positions: a word of the pad)
+    }
+    T2_SYNC();
+    unsigned fin[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const unsigned me = (kc[k] << 7) | ar[k];
+      const unsigned w0 = s_w[s0[k]], w1 = s_w[s0[k] + 1], w2 = s_w[s0[k] + 2], w3 = s_w[s0[k] + 3];
+      unsigned r = (unsigned)(w0 < me) + ((w1 < me) & (cb[k] > 1u)) + ((w2 < me) & (cb[k] > 2u)) + ((w3 < me) & (cb[k] > 3u));
+      if (__any(cb[k] > 4u)) {
+        for (unsigned j = 4; __any(j < cb[k]); j++) r += (j < cb[k]) & (s_w[s0[k] + (j < cb[k] ? j : 0u)] < me);
+      }
+      fin[k] = k * 64 + lane < cnt ? s0[k] + r : (unsigned)CAP;  // (dead positions: the slot behind the last one)
+    }
+    T2_SYNC();  // (the placed words and the bounds have been read)
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (VB == 4) {
+        s_pair[fin[k]] = make_uint2(kc[k], (unsigned)kv[k]);
+      } else {
+        s_key[fin[k]] = kc[k];
+        if (VB == 8) s_v8[fin[k]] = (uint64_t)kv[k];
+      }
+    }
+    T2_SYNC();
+    // ---- out: position p holds the p-th entry of the tile in (row, column) order; rows keep their position ranges
+    bool dup = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int p = k * 64 + lane;
+      unsigned key;
+      V val = (V)0;
+      if (VB == 4) {
+        const uint2 pr = s_pair[p];
+        key = pr.x, val = (V)pr.y;
+      } else {
+        key = s_key[p];
+        if (VB == 8) val = (V)s_v8[p];
+      }
+      c[k] = key;
+      if (HASV) kv[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const unsigned first = k ? (unsigned)__builtin_amdgcn_readlane((int)c[k - 1], 63) : 0u;
+      const unsigned prev = (unsigned)sbx_wave_shift_up1((int)c[k], (int)first);
+      dup |= ((meta[k] & 0xFFu) != 0u) & (k * 64 + lane < cnt) & (c[k] == prev);
+      if (IB == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(c[k], b_co, oidx[k] * 4u, 0, 0);
+      } else {
+        pt2_u2 w2;
+        w2.x = c[k], w2.y = 0u;
+        __builtin_amdgcn_raw_buffer_store_b64(w2, b_co, oidx[k] * 8u, 0, 0);
+      }
+      if (HASV) {
+        if (VB == 4) {
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)kv[k], b_vo, oidx[k] * 4u, 0, 0);
+        } else {
+          pt2_u2 w2;
+          w2.x = (unsigned)kv[k], w2.y = (unsigned)((uint64_t)kv[k] >> 32);
+          __builtin_amdgcn_raw_buffer_store_b64(w2, b_vo, oidx[k] * 8u, 0, 0);
+        }
+      }
+    }
+    any_dup |= dup;
+    T2_SYNC();  // (the sorted entries have been read: the next tile's records take their place)
+  }
+  if (__any(any_uns) && lane == 0) st->any_unsorted = 1;
+  if (__any(any_dup) && lane == 0) st->any_dup = 1;
+#undef T2_SYNC
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void k_fill_index(I *__restrict__ a, int64_t count, I value) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2446,7 +2848,12 @@ template <typename I, int VB>
 int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_in, const char *val_in,
                const I *col_order, const I *rpo, I *col_out, char *val_out, int64_t nr, int64_t m,
                int64_t total, const I *long_rows, const I *block_rows, int64_t block_stride,
-               const PermState &hs, PermState *st, const I *sp, const I *tile_first_ready = nullptr) {
+               const PermState &hs, PermState *st, const I *sp, const I *tile_first_ready = nullptr,
+               int64_t nnz_in = 0 /* entries of col_in / val_in */, const CdfMap *cdf = nullptr, bool cdf_on_side = false) {
+  if (cdf_on_side) {  // the map was built on side stream 1: everything from here on comes behind it
+    SBX_HIP(h, hipStreamWaitEvent(h->stream, h->aux_event[2], 0));
+    h->aux_dirty = false;
+  }
   if constexpr (sizeof(I) == 8)
     if (m > KEY32_MAX_COLS)
       return wide_rows_path<I, VB>(h, vt, rec, col_in, val_in, col_order, rpo, col_out, val_out, nr, m, total, st);
@@ -2485,12 +2892,25 @@ int sort_stage(sbx_handle_t h, sbx_value_type vt, const int2 *rec, const I *col_
     // persistent waves, 15 per CU (the LDS of a tile) times 12 (measured: 1 ... 2 per slot lose 10 % to imbalance — a
     // tile is 30 ... 512 entries —, 8 ... 16 are level, one wave per tile is 7 % slower): each walks its tiles as a pipeline
     const int64_t tile_grid = (int64_t)h->num_cus * 15 * tile_grid_factor();
+    // the relabelling permutes whose arrays fit 32-bit byte offsets and whose ids fit the map's words: k_permute_tile2
+    constexpr uint64_t EB = sizeof(I) > (size_t)VB ? sizeof(I) : (size_t)VB;
+    const bool tile2 = cdf && cdf->table && col_order && permute_force_radix() == 0 && nnz_in < ((int64_t)1 << 28) &&
+                       (uint64_t)nnz_in * EB <= PT2_MAX_BYTES && (uint64_t)total * EB <= PT2_MAX_BYTES &&
+                       (uint64_t)m * sizeof(I) <= PT2_MAX_BYTES;
+    if (tile2) {
+      SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile2<I, VB>), dim3((unsigned)(tiles < tile_grid ? tiles : tile_grid)),
+                  dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
+                  st, (int64_t)tiles, (unsigned)((uint64_t)nnz_in * sizeof(I)), (unsigned)((uint64_t)nnz_in * VB),
+                  (unsigned)((uint64_t)total * sizeof(I)), (unsigned)((uint64_t)total * VB),
+                  (unsigned)((uint64_t)m * sizeof(I)), *cdf);
+    } else {
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile<I, VB>), dim3((unsigned)(tiles < tile_grid ? tiles : tile_grid)),
                 dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
                 st, col_bits, permute_force_radix(), fb_tiles, (int64_t)tiles);
     SBX_KLAUNCH(h, SBX_K_PERMUTE_TILE, (k_permute_tile_radix<I, VB>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)),
                 dim3(PT_THREADS), rec, col_in, val_in, col_order, rpo, sp, (const I *)tile_first, col_out, val_out, nr,
                 st, col_bits, (const unsigned *)fb_tiles);
+    }
     SBX_LAUNCH_CHECK(h);
     SBX_PROF_BYTES(h, SBX_K_PERMUTE_TILE, short_nnz * (int64_t)(2 * (sizeof(I) + VB)));
     if ((permute_force_radix() >> 8) == 9) {  // diagnostic: print and clear the phase stamps
@@ -2667,6 +3087,28 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
   int2 *rec = nullptr;
   unsigned long long *status = nullptr;
   SBX_TRY(perm_prep_alloc(h, nr, &st, &status, &rec));
+  // the key-distribution map of the relabelled columns (k_cdf_sample): needs nothing but the caller's arrays, so it is
+  // built beside the preparation — on side stream 1, behind an event that orders it after the caller's earlier work
+  CdfMap cdf;
+  cdf.table = nullptr, cdf.shift = 0, cdf.fsh = 0;
+  bool cdf_on_side = false;
+  if (col_order && nnz > 0 && !sbx_env_test("SBX_PERMUTE_NO_TILE2")) {
+    if (!h->prof_on && permute_overlap() && sbx_aux_streams(h) == SBX_OK) {
+      hipStream_t main_stream = h->stream;
+      SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));
+      SBX_HIP(h, hipStreamWaitEvent(h->aux_stream[1], h->aux_event[0], 0));
+      h->aux_dirty = true;
+      h->stream = h->aux_stream[1];
+      const int rc_cdf = build_cdf_map<I>(h, (const I *)col, (const I *)col_order, nnz, m, &cdf);
+      const hipError_t e_cdf = rc_cdf == SBX_OK ? hipEventRecord(h->aux_event[2], h->stream) : hipSuccess;
+      h->stream = main_stream;
+      SBX_TRY(rc_cdf);
+      if (e_cdf != hipSuccess) SBX_FAIL(h, SBX_ERR_HIP, "hipEventRecord failed");
+      cdf_on_side = true;
+    } else {
+      SBX_TRY(build_cdf_map<I>(h, (const I *)col, (const I *)col_order, nnz, m, &cdf));
+    }
+  }
   SBX_KLAUNCH(h, SBX_K_PERMUTE_PREP, k_rowwise_prep<I>, dim3(sbx_grid_for((n + 3) / 4, 256, 8192)), dim3(256),
               (const I *)row_ptr, (const I *)row_order, n, row_begin, nr, rec);
   I *long_rows = nullptr, *block_rows = nullptr, *sp = nullptr;
@@ -2732,7 +3174,7 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
 #define STAGE(VBX)                                                                                                  \
   rc = sort_stage<I, VBX>(h, vt, (const int2 *)rec, (const I *)col, (const char *)val, (const I *)col_order, rpo,      \
                        (I *)col_out, (char *)val_out, nr, m, total, long_rows, block_rows, block_stride, hs, st, sp, \
-                       (const I *)tile_first)
+                       (const I *)tile_first, nnz, &cdf, cdf_on_side)
   if (vb == 0) STAGE(0);
   else if (vb == 4) STAGE(4);
   else STAGE(8);
