@@ -432,4 +432,51 @@ int ref_sbff_read_array(const char *path, int64_t cap, float *vals, int64_t *n) 
   }
   return 0;
 }
+// ---- the tuple with sizeof(IDType) != sizeof(NNZType) the reference pre-instantiates (CMakeLists.txt:15-17):
+// <int ids, long long offsets, float values> — COO -> CSR -> COO, Permute2D, DegreeReorder, RCMReorder.  What the
+// SBX_I32_N64 tests assume — the same results as <int, int, float> with the offsets widened — is pinned against this
+// (tests/test_oracle.py::test_reference_mixed_width_tuple_equals_the_32_bit_one).
+int ref_mixed_pipeline(int64_t n, int64_t m, int64_t nnz, int *row, int *col, float *val, int *row_order, int *col_order,
+                       long long *rp_out, int *row_back, long long *prp_out, int *pcol_out, float *pval_out, int *deg_asc,
+                       int *rcm_out /* may be NULL: RCM wants a symmetric pattern */) {
+  typedef int I;
+  typedef long long N;
+  typedef float V;
+  try {
+    context::CPUContext cpu;
+    format::COO<I, N, V> coo((I)n, (I)m, (N)nnz, row, col, val, format::kNotOwned, true);
+    auto *csr = coo.Convert<format::CSR>(&cpu);
+    memcpy(rp_out, csr->get_row_ptr(), (n + 1) * sizeof(N));
+    auto *back = csr->Convert<format::COO>(&cpu);
+    memcpy(row_back, back->get_row(), nnz * sizeof(I));
+    delete back;
+    permute::PermuteOrderTwo<I, N, V> p(row_order, col_order);
+    auto *out = p.GetPermutation(csr, {&cpu}, false);
+    auto *ocsr = out->As<format::CSR>();
+    memcpy(prp_out, ocsr->get_row_ptr(), (n + 1) * sizeof(N));
+    memcpy(pcol_out, ocsr->get_col(), nnz * sizeof(I));
+    memcpy(pval_out, ocsr->get_vals(), nnz * sizeof(V));
+    N *a = ocsr->get_row_ptr();
+    I *b = ocsr->get_col();
+    V *c = ocsr->get_vals();
+    delete ocsr;
+    delete[] a;
+    delete[] b;
+    delete[] c;
+    reorder::DegreeReorder<I, N, V> d(true);
+    I *o = d.GetReorder(csr, {&cpu}, false);
+    memcpy(deg_asc, o, n * sizeof(I));
+    delete[] o;
+    if (rcm_out) {
+      reorder::RCMReorder<I, N, V> r;
+      I *q = r.GetReorder(csr, {&cpu}, false);
+      memcpy(rcm_out, q, n * sizeof(I));
+      delete[] q;
+    }
+    delete csr;
+  } catch (const std::exception &e) {
+    return -4;
+  }
+  return 0;
+}
 }  // extern "C"

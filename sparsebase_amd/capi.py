@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsbx.so")
 
 SBX_OK = 0
-SBX_I32, SBX_I64 = 0, 1
+SBX_I32, SBX_I64, SBX_I32_N64 = 0, 1, 2
 V_NONE, V_I32, V_U32, V_F32, V_I64, V_U64, V_F64 = range(7)
 FLAG_MOVE, FLAG_ROWS_SORTED = 1, 2
 

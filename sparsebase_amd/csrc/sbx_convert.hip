@@ -211,10 +211,11 @@ __device__ __forceinline__ void emit_row_starts(I *__restrict__ rp, int64_t prev
   }
 }
 
-// One thread = 4 consecutive nonzeros.  MOVE: only row_ptr is produced.
-template <typename I, int VB, bool MOVE, bool ALIGNED16>
+// One thread = 4 consecutive nonzeros.  MOVE: only row_ptr is produced.  I: the id arrays' word, O: row_ptr's (the
+// tuples with sizeof(IDType) != sizeof(NNZType): SBX_I32_N64).
+template <typename I, typename O, int VB, bool MOVE, bool ALIGNED16>
 __global__ __launch_bounds__(CV_THREADS) void k_coo_to_csr(const I *__restrict__ row, const I *__restrict__ col,
-                                                           const char *__restrict__ val, I *__restrict__ rp,
+                                                           const char *__restrict__ val, O *__restrict__ rp,
                                                            I *__restrict__ col_out, char *__restrict__ val_out,
                                                            int64_t n, int64_t nnz, GapEntry *__restrict__ gaps,
                                                            unsigned *__restrict__ ngaps, unsigned gap_cap,
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(CV_THREADS) void k_coo_to_csr(const I *__restrict__
       if (i < nnz) {
         const int64_t cur = (int64_t)r[k];
         bad |= cur < prev;
-        emit_row_starts<I>(rp, prev, cur, i, gaps, ngaps, gap_cap);
+        emit_row_starts<O>(rp, prev, cur, i, gaps, ngaps, gap_cap);
         prev = cur;
-        if (i == nnz - 1) emit_row_starts<I>(rp, cur, n, nnz, gaps, ngaps, gap_cap);
+        if (i == nnz - 1) emit_row_starts<O>(rp, cur, n, nnz, gaps, ngaps, gap_cap);
       }
     }
   }
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(CV_THREADS) void k_ex_tile_spans(const I *__restric
 }
 constexpr int64_t EX_SPAN_MIN_TILES = 8192;  // from 16 M nonzeros on
 
-template <typename I, int VB, bool MOVE, bool ALIGNED16>
-__global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__ rp, const I *__restrict__ col,
+template <typename I, typename O, int VB, bool MOVE, bool ALIGNED16>
+__global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const O *__restrict__ rp, const I *__restrict__ col,
                                                            const char *__restrict__ val, I *__restrict__ row_out,
                                                            I *__restrict__ col_out, char *__restrict__ val_out,
                                                            int64_t n, int64_t nnz, const int2 *__restrict__ span) {
@@ -337,10 +338,10 @@ __global__ __launch_bounds__(CV_THREADS) void k_csr_to_coo(const I *__restrict__
       s_span[1] = sp.y;
     }
   } else if (tid < 64) {
-    const int64_t lo = sbx_wave_upper_bound<I>(rp, n + 1, (I)t0) - 1;
+    const int64_t lo = sbx_wave_upper_bound<O>(rp, n + 1, (O)t0) - 1;
     if (tid == 0) s_span[0] = lo;
   } else if (tid < 128) {
-    const int64_t hi = sbx_wave_upper_bound<I>(rp, n + 1, (I)(t1 - 1)) - 1;
+    const int64_t hi = sbx_wave_upper_bound<O>(rp, n + 1, (O)(t1 - 1)) - 1;
     if (tid == 64) s_span[1] = hi;
   }
   __syncthreads();
@@ -462,6 +463,7 @@ static int coo_is_sorted_typed(sbx_handle_t h, int64_t nnz, const void *row, con
 extern "C" int sbx_coo_is_sorted(sbx_handle_t h, sbx_index_type it, int64_t nnz, const void *row, const void *col,
                                  int *sorted_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, sorted_host && nnz >= 0 && (nnz == 0 || (row && col)), "bad argument");
   if (it == SBX_I64) return coo_is_sorted_typed<int64_t>(h, nnz, row, col, sorted_host);
   return coo_is_sorted_typed<int32_t>(h, nnz, row, col, sorted_host);
@@ -491,6 +493,7 @@ static int csr_rows_sorted_typed(sbx_handle_t h, int64_t n, const void *row_ptr,
 extern "C" int sbx_csr_rows_sorted(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
                                    const void *col, int *sorted_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_csr_rows_sorted(h, n, row_ptr, col, sorted_host);
   SBX_REQUIRE(h, sorted_host && n >= 0 && row_ptr, "bad argument");
   SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
   if (it == SBX_I64) return csr_rows_sorted_typed<int64_t>(h, n, row_ptr, col, sorted_host);
@@ -573,6 +576,7 @@ static int coo_sort_i64(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m,
 extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz,
                             void *row, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, nnz >= 0 && n >= 0 && m >= 0 && (nnz == 0 || (row && col)), "bad argument");
   if (it == SBX_I64) return coo_sort_i64(h, vt, n, m, nnz, row, col, val);
   const int vb = val ? sbx_value_bytes(vt) : 0;
@@ -668,49 +672,49 @@ extern "C" int sbx_coo_sort(sbx_handle_t h, sbx_index_type it, sbx_value_type vt
 
 namespace {
 
-template <typename I, int VB, bool MOVE>
-int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const I *row, const I *col, const char *val, I *rp,
+template <typename I, typename O, int VB, bool MOVE>
+int launch_coo_to_csr(sbx_handle_t h, int64_t n, int64_t nnz, const I *row, const I *col, const char *val, O *rp,
                       I *col_out, char *val_out, GapEntry *gaps, unsigned *ngaps, unsigned gap_cap, int *unsorted) {
   const bool al = aligned16(row) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const int64_t nquads = (nnz + 3) >> 2;
   const unsigned grid = sbx_grid_for(nquads, CV_THREADS, (int64_t)h->num_cus * 32);
   if (al)
-    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, O, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   else
-    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), row, col,
+    SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_coo_to_csr<I, O, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), row, col,
                        val, rp, col_out, val_out, n, nnz, gaps, ngaps, gap_cap, unsorted);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
-template <typename I, int VB, bool MOVE>
-int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const I *rp, const I *col, const char *val, I *row_out,
+template <typename I, typename O, int VB, bool MOVE>
+int launch_csr_to_coo(sbx_handle_t h, int64_t n, int64_t nnz, const O *rp, const I *col, const char *val, I *row_out,
                       I *col_out, char *val_out) {
   const bool al = aligned16(row_out) && (MOVE || (aligned16(col) && aligned16(col_out) && aligned16(val) && aligned16(val_out)));
   const unsigned grid = (unsigned)((nnz + EX_TILE - 1) / EX_TILE);
   int2 *span = nullptr;
   if ((int64_t)grid >= EX_SPAN_MIN_TILES) {
     SBX_TRY(sbx_salloc(h, (size_t)grid, &span));
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, k_ex_tile_spans<I>, dim3((grid + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS),
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, k_ex_tile_spans<O>, dim3((grid + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS),
                 rp, n, nnz, (int64_t)grid, span);
   }
   if (al)
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, O, VB, MOVE, true>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   else
-    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
+    SBX_KLAUNCH(h, SBX_K_CSR_TO_COO, (k_csr_to_coo<I, O, VB, MOVE, false>), dim3(grid), dim3(CV_THREADS), rp, col,
                        val, row_out, col_out, val_out, n, nnz, (const int2 *)span);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;
 }
 
-template <typename I>
-__global__ __launch_bounds__(CV_THREADS) void k_row_hist(const I *__restrict__ row, I *__restrict__ cnt, int64_t nnz) {
+template <typename I, typename O>
+__global__ __launch_bounds__(CV_THREADS) void k_row_hist(const I *__restrict__ row, O *__restrict__ cnt, int64_t nnz) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < nnz; i += stride) {
-    if constexpr (sizeof(I) == 4) atomicAdd((int *)&cnt[row[i]], 1);
+    if constexpr (sizeof(O) == 4) atomicAdd((int *)&cnt[row[i]], 1);
     else atomicAdd((unsigned long long *)&cnt[row[i]], 1ull);
   }
 }
@@ -737,16 +741,16 @@ int scan_index(sbx_handle_t h, I *a, int64_t count) {
   else return sbx_exclusive_scan_i64(h, (const int64_t *)a, (int64_t *)a, count, nullptr);
 }
 
-// A2 for either index width (64-bit indices run natively: values of any size, no narrowed copies)
-template <typename I>
+// A2 for every index tuple (64-bit words run natively: values of any size, no narrowed copies)
+template <typename I, typename O = I>
 int coo_to_csr_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row, const void *col,
                      const void *val, void *row_ptr_out, void *col_out, void *val_out, unsigned flags) {
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
   const int vb = (val && val_out && !move) ? sbx_value_bytes(vt) : 0;
   if (vb < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr: unknown value type");
   SBX_TRY(sbx_arena_begin(h));
-  I *rp = (I *)row_ptr_out;
-  if (nnz == 0) return fill_index<I>(h, rp, 0, n + 1);
+  O *rp = (O *)row_ptr_out;
+  if (nnz == 0) return fill_index<O>(h, rp, 0, n + 1);
   const unsigned gap_cap = (unsigned)((n + 1) / GAP_INLINE + 2);
   GapEntry *gaps = nullptr;
   unsigned *ngaps = nullptr;
@@ -769,12 +773,12 @@ int coo_to_csr_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, 
     if (f) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr: a row id lies outside [0, n)");
   }
   int rc;
-  if (move) rc = launch_coo_to_csr<I, 0, true>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else if (vb == 0) rc = launch_coo_to_csr<I, 0, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else if (vb == 4) rc = launch_coo_to_csr<I, 4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
-  else rc = launch_coo_to_csr<I, 8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  if (move) rc = launch_coo_to_csr<I, O, 0, true>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 0) rc = launch_coo_to_csr<I, O, 0, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else if (vb == 4) rc = launch_coo_to_csr<I, O, 4, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
+  else rc = launch_coo_to_csr<I, O, 8, false>(h, n, nnz, r, c, v, rp, co, vo, gaps, ngaps, gap_cap, unsorted);
   SBX_TRY(rc);
-  SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_fill_gaps<I>, dim3(256), dim3(CV_THREADS), rp, (const GapEntry *)gaps,
+  SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_fill_gaps<O>, dim3(256), dim3(CV_THREADS), rp, (const GapEntry *)gaps,
               (const unsigned *)ngaps, gap_cap);
   SBX_LAUNCH_CHECK(h);
   if (!(flags & SBX_FLAG_ROWS_SORTED)) {
@@ -783,17 +787,17 @@ int coo_to_csr_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, 
     int f = 0;
     SBX_TRY(sbx_readback(h, &f, unsorted, sizeof(int)));
     if (f) {
-      SBX_TRY(fill_index<I>(h, rp, 0, n + 1));
-      SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, k_row_hist<I>, dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r, rp,
+      SBX_TRY(fill_index<O>(h, rp, 0, n + 1));
+      SBX_KLAUNCH(h, SBX_K_COO_TO_CSR, (k_row_hist<I, O>), dim3(sbx_grid_for(nnz, CV_THREADS, 8192)), dim3(CV_THREADS), r, rp,
                   nnz);
       SBX_LAUNCH_CHECK(h);
-      SBX_TRY(scan_index<I>(h, rp, n + 1));
+      SBX_TRY(scan_index<O>(h, rp, n + 1));
     }
   }
   return SBX_OK;
 }
 
-template <typename I>
+template <typename I, typename O = I>
 int csr_to_coo_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
                      const void *val, void *row_out, void *col_out, void *val_out, unsigned flags) {
   const bool move = (flags & SBX_FLAG_MOVE) != 0;
@@ -801,14 +805,15 @@ int csr_to_coo_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t nnz, 
   if (vb < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_csr_to_coo: unknown value type");
   SBX_TRY(sbx_arena_begin(h));
   if (nnz == 0) return SBX_OK;
-  const I *rp = (const I *)row_ptr, *c = (const I *)col;
+  const O *rp = (const O *)row_ptr;
+  const I *c = (const I *)col;
   const char *v = (const char *)val;
   I *ro = (I *)row_out, *co = (I *)col_out;
   char *vo = (char *)val_out;
-  if (move) return launch_csr_to_coo<I, 0, true>(h, n, nnz, rp, c, v, ro, co, vo);
-  if (vb == 0) return launch_csr_to_coo<I, 0, false>(h, n, nnz, rp, c, v, ro, co, vo);
-  if (vb == 4) return launch_csr_to_coo<I, 4, false>(h, n, nnz, rp, c, v, ro, co, vo);
-  return launch_csr_to_coo<I, 8, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (move) return launch_csr_to_coo<I, O, 0, true>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 0) return launch_csr_to_coo<I, O, 0, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  if (vb == 4) return launch_csr_to_coo<I, O, 4, false>(h, n, nnz, rp, c, v, ro, co, vo);
+  return launch_csr_to_coo<I, O, 8, false>(h, n, nnz, rp, c, v, ro, co, vo);
 }
 
 // ---------------------------------------------------------------- A14 COO -> CSC helpers
@@ -1004,6 +1009,8 @@ extern "C" int sbx_coo_to_csr(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
   if (it == SBX_I64)  // native 64-bit kernels: column ids and nnz of any size
     return coo_to_csr_typed<int64_t>(h, vt, n, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
+  if (it == SBX_I32_N64)  // 32-bit ids, 64-bit row_ptr: native, nnz of any size
+    return coo_to_csr_typed<int32_t, int64_t>(h, vt, n, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31), "nnz exceeds int32");
   return coo_to_csr_typed<int32_t>(h, vt, n, nnz, row, col, val, row_ptr_out, col_out, val_out, flags);
 }
@@ -1019,6 +1026,8 @@ extern "C" int sbx_csr_to_coo(sbx_handle_t h, sbx_index_type it, sbx_value_type 
   SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1, "row count exceeds int32");
   if (it == SBX_I64)
     return csr_to_coo_typed<int64_t>(h, vt, n, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
+  if (it == SBX_I32_N64)
+    return csr_to_coo_typed<int32_t, int64_t>(h, vt, n, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31), "nnz exceeds int32");
   return csr_to_coo_typed<int32_t>(h, vt, n, nnz, row_ptr, col, val, row_out, col_out, val_out, flags);
 }
@@ -1029,6 +1038,7 @@ extern "C" int sbx_coo_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type 
                               const void *row, const void *col, const void *val, void *col_ptr_out, void *row_out,
                               void *val_out) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_coo_to_csc(h, vt, n, m, nnz, row, col, val, col_ptr_out, row_out, val_out);
   SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && col_ptr_out && (nnz == 0 || (row && col && row_out)), "bad argument");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,
               "dimension exceeds int32");
@@ -1047,6 +1057,7 @@ extern "C" int sbx_csr_to_csc(sbx_handle_t h, sbx_index_type it, sbx_value_type 
                               const void *row_ptr, const void *col, const void *val, void *col_ptr_out, void *row_out,
                               void *val_out) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_csr_to_csc(h, vt, n, m, nnz, row_ptr, col, val, col_ptr_out, row_out, val_out);
   SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && col_ptr_out && (nnz == 0 || (col && row_out)),
               "bad argument");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) - 1,

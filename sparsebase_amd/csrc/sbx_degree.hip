@@ -240,12 +240,13 @@ __global__ void k_degree_one(I *inv) { inv[0] = 0; }
 
 }  // namespace
 
-template <typename I>
+// I: row_ptr's word; P: the word of the inverse permutation (SBX_I32_N64: 64-bit offsets, 32-bit ids)
+template <typename I, typename P = I>
 static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, int ascending, void *inv_perm_out) {
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
   if (n == 1) {  // (the radix sort wants two keys)
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_one<I>, dim3(1), dim3(1), (I *)inv_perm_out);
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_one<P>, dim3(1), dim3(1), (P *)inv_perm_out);
     SBX_LAUNCH_CHECK(h);
     return SBX_OK;
   }
@@ -263,8 +264,8 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   const unsigned grid = (unsigned)n_tiles;
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_count<I>, dim3(grid), dim3(256), rp, n, n_tiles, cnt, wmax);
   SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_scan, dim3(DG_BINS), dim3(256), cnt, (const unsigned *)wmax, n_tiles, total, st);
-  SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_place<I>, dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
-              (const unsigned *)total, (I *)inv_perm_out, ta, ia, ascending, (uint32_t *)nullptr);
+  SBX_KLAUNCH(h, SBX_K_DEGREE, (k_degree_place<I, false, P>), dim3(grid), dim3(256), rp, n, n_tiles, (const unsigned *)cnt,
+              (const unsigned *)total, (P *)inv_perm_out, ta, ia, ascending, (uint32_t *)nullptr);
   SBX_LAUNCH_CHECK(h);
   DegState hs;
   SBX_TRY(sbx_readback(h, &hs, st, sizeof(hs)));
@@ -275,15 +276,15 @@ static int degree_reorder_typed(sbx_handle_t h, int64_t n, const void *row_ptr, 
   SBX_TRY(sbx_salloc(h, (size_t)top, &tb));
   SBX_TRY(sbx_salloc(h, (size_t)top, &ib));
   if (top <= sbx_cs::MAX_PAIRS) {
-    const DegreeTailEmit<I> emit = {(I *)inv_perm_out, n - top, n, ascending};
+    const DegreeTailEmit<P> emit = {(P *)inv_perm_out, n - top, n, ascending};
     SBX_TRY(sbx_cs::sort_emit(h, SBX_K_DEGREE, ta, ia, tb, ib, top, sbx_bits_for(hs.max_deg), emit));
   } else {  // (millions of rows of 255+ entries: the generic sort's staged stores win; then a scatter)
     sbx_radix_pass passes[16];
     const int np = sbx_radix_plan(0, sbx_bits_for(hs.max_deg), 0, 0, passes);
     int in_b = 0;
     SBX_TRY(sbx_radix_sort(h, 4, 4, ta, tb, ia, ib, top, passes, np, &in_b));
-    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<I>, dim3(sbx_grid_for(top, 256, 2048)), dim3(256),
-                (const uint32_t *)(in_b ? ib : ia), (I *)inv_perm_out, top, n - top, n, ascending);
+    SBX_KLAUNCH(h, SBX_K_DEGREE, k_degree_tail_emit<P>, dim3(sbx_grid_for(top, 256, 2048)), dim3(256),
+                (const uint32_t *)(in_b ? ib : ia), (P *)inv_perm_out, top, n - top, n, ascending);
     SBX_LAUNCH_CHECK(h);
   }
   return SBX_OK;
@@ -358,7 +359,7 @@ static int degree_ranks_typed(sbx_handle_t h, const I *rp, int64_t n, int64_t n_
 // rank[id] / order[rank] of the non-empty rows by (degree, id): the degree ranks of the RCM (row_ptr of either width)
 int sbx_degree_ranks(sbx_handle_t h, sbx_index_type it, const void *rp, int64_t n, int64_t n_nonempty, int64_t n_top,
                      unsigned max_deg, uint32_t *rank, uint32_t *order) {
-  return it == SBX_I64 ? degree_ranks_typed<int64_t>(h, (const int64_t *)rp, n, n_nonempty, n_top, max_deg, rank, order)
+  return it != SBX_I32 ? degree_ranks_typed<int64_t>(h, (const int64_t *)rp, n, n_nonempty, n_top, max_deg, rank, order)
                        : degree_ranks_typed<int32_t>(h, (const int32_t *)rp, n, n_nonempty, n_top, max_deg, rank, order);
 }
 
@@ -369,6 +370,7 @@ extern "C" int sbx_degree_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, 
   // (vertex ids travel in the low word of the sort keys and degrees in 32 bits: n and every row length below 2^32;
   // row_ptr VALUES — nnz — are not limited for 64-bit indices)
   if (n >= ((int64_t)1 << 31)) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_degree_reorder: dimension exceeds int32");
+  if (it == SBX_I32_N64) return degree_reorder_typed<int64_t, int32_t>(h, n, row_ptr, ascending, inv_perm_out);
   return it == SBX_I64 ? degree_reorder_typed<int64_t>(h, n, row_ptr, ascending, inv_perm_out)
                        : degree_reorder_typed<int32_t>(h, n, row_ptr, ascending, inv_perm_out);
 }

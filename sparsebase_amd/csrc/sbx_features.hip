@@ -19,11 +19,11 @@ namespace {
 constexpr int FT_THREADS = 256;
 constexpr int FT_ITEMS = 8;
 
-template <typename I>
-__global__ __launch_bounds__(FT_THREADS) void k_degrees(const I *__restrict__ rp, I *__restrict__ out, int64_t n) {
+template <typename I, typename D = I>  // (D: the degrees' word — an id type: SBX_I32_N64 reads 64-bit offsets, writes 32-bit degrees)
+__global__ __launch_bounds__(FT_THREADS) void k_degrees(const I *__restrict__ rp, D *__restrict__ out, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = rp[i + 1] - rp[i];
+  for (; i < n; i += stride) out[i] = (D)(rp[i + 1] - rp[i]);
 }
 
 // dist[i] = degree / (FeatureType)num_edges, one IEEE division per row (degree_distribution.cc:163)
@@ -314,12 +314,12 @@ int expand_rows(sbx_handle_t h, int64_t n, int64_t nnz, const I *rp, I **rows) {
     if (!(cond)) SBX_FAIL(h, SBX_ERR_BAD_ARG, "%s: %s", __func__, msg); \
   } while (0)
 
-template <typename I>
+template <typename I, typename D = I>
 static int csr_degrees_typed(sbx_handle_t h, int64_t n, const void *row_ptr, void *degrees_out) {
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
-  SBX_KLAUNCH(h, SBX_K_FEATURE, k_degrees<I>, dim3(sbx_grid_for(n, FT_THREADS, 8192)), dim3(FT_THREADS), (const I *)row_ptr,
-              (I *)degrees_out, n);
+  SBX_KLAUNCH(h, SBX_K_FEATURE, (k_degrees<I, D>), dim3(sbx_grid_for(n, FT_THREADS, 8192)), dim3(FT_THREADS), (const I *)row_ptr,
+              (D *)degrees_out, n);
   SBX_LAUNCH_CHECK(h);
   SBX_PROF_BYTES(h, SBX_K_FEATURE, 2 * (int64_t)sizeof(I) * n + (int64_t)sizeof(I));
   return SBX_OK;
@@ -328,6 +328,7 @@ static int csr_degrees_typed(sbx_handle_t h, int64_t n, const void *row_ptr, voi
 extern "C" int sbx_csr_degrees(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr, void *degrees_out) {
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && row_ptr && (n == 0 || degrees_out), "bad argument");
+  if (it == SBX_I32_N64) return csr_degrees_typed<int64_t, int32_t>(h, n, row_ptr, degrees_out);
   return it == SBX_I64 ? csr_degrees_typed<int64_t>(h, n, row_ptr, degrees_out)
                        : csr_degrees_typed<int32_t>(h, n, row_ptr, degrees_out);
 }
@@ -354,7 +355,7 @@ extern "C" int sbx_csr_degree_distribution(sbx_handle_t h, sbx_index_type it, in
   if (!h) return SBX_ERR_BAD_ARG;
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (n == 0 || dist_out), "bad argument");
   SBX_REQUIRE(h, feature_bytes == 4 || feature_bytes == 8, "feature type must be float or double");
-  return it == SBX_I64 ? csr_degree_distribution_typed<int64_t>(h, n, nnz, row_ptr, feature_bytes, dist_out)
+  return it != SBX_I32 ? csr_degree_distribution_typed<int64_t>(h, n, nnz, row_ptr, feature_bytes, dist_out)  // (SBX_I32_N64: 64-bit offsets, no id array)
                        : csr_degree_distribution_typed<int32_t>(h, n, nnz, row_ptr, feature_bytes, dist_out);
 }
 
@@ -392,6 +393,7 @@ static int csr_bandwidth_typed(sbx_handle_t h, int64_t n, int64_t nnz, const voi
 extern "C" int sbx_csr_bandwidth(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
                                  const void *col, int64_t *bandwidth_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_csr_bandwidth(h, n, nnz, row_ptr, col, bandwidth_host);
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && bandwidth_host && (nnz == 0 || col), "bad argument");
   SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1 && (it == SBX_I64 || nnz < ((int64_t)1 << 31)) &&
                      nnz / FT_TILE < ((int64_t)1 << 31), "dimension exceeds what the index type holds");
@@ -457,6 +459,7 @@ static int csr_profile_typed(sbx_handle_t h, int64_t n, int64_t nnz, const void 
 extern "C" int sbx_csr_profile(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
                                const void *col, int64_t *profile_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_csr_profile(h, n, nnz, row_ptr, col, profile_host);
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && profile_host && (nnz == 0 || col), "bad argument");
   SBX_REQUIRE(h, n < ((int64_t)1 << 31) - 1 && (it == SBX_I64 || nnz < ((int64_t)1 << 31)) &&
                      nnz / FT_TILE < ((int64_t)1 << 31), "dimension exceeds what the index type holds");

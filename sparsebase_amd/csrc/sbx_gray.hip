@@ -1463,6 +1463,8 @@ extern "C" int sbx_gray_row_keys(sbx_handle_t h, sbx_index_type it, int64_t n, i
                                  const void *row_ptr, const void *col, int resolution, int nnz_threshold,
                                  void *degree_out, uint64_t *key_out, int64_t *counts_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64)
+    return sbx_mixed_gray_row_keys(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, degree_out, key_out, counts_host);
   if (n < 0 || m < 0 || !row_ptr || !counts_host || (n > 0 && (!degree_out || !key_out)) || (nnz > 0 && !col))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_row_keys: bad argument");
   // (offsets, columns and degrees are 32-bit inside, whatever the width of the arrays)

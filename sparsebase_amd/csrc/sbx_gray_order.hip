@@ -172,6 +172,8 @@ extern "C" int sbx_gray_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, in
                                 const void *row_ptr, const void *col, int resolution, int nnz_threshold,
                                 int group_size, int exact_ties, void *inv_perm_out) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64)
+    return sbx_mixed_gray_reorder(h, n, m, nnz, row_ptr, col, resolution, nnz_threshold, group_size, exact_ties, inv_perm_out);
   if (n < 0 || m < 0 || !row_ptr || (n > 0 && !inv_perm_out) || (nnz > 0 && !col) || group_size < 1)
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_gray_reorder: bad argument");
   if (exact_ties)

@@ -137,3 +137,113 @@ int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_
   return sbx_widen_i32(h, c, col_out, dims_nnz_host[2]);
 }
 
+
+// ---------------------------------------------------------------------------
+// SBX_I32_N64 — 32-bit ids with 64-bit offsets (the reference's <int | unsigned int, long long | unsigned long long, V>
+// tuples, CMakeLists.txt:15-17).  COO <-> CSR, DegreeReorder and the degree features read and write the 64-bit offsets
+// themselves (sbx_convert.hip, sbx_degree.hip, sbx_features.hip).  Every other entry point that takes an offset array
+// keeps 32-bit offsets inside: the adapters below narrow row_ptr / col_ptr (n + 1 words; nnz < 2^31 is required and
+// checked where the call does not state nnz), run the SBX_I32 entry point and widen the offset outputs.  The id arrays
+// are 32-bit already and pass through untouched.
+// ---------------------------------------------------------------------------
+#define MIXED_NNZ_LIMIT(name)                                                                                        \
+  if (nnz >= ((int64_t)1 << 31))                                                                                     \
+  SBX_FAIL(h, SBX_ERR_UNSUPPORTED, name ": 64-bit offsets with nnz >= 2^31 (the offsets inside this operation are 32-bit)")
+
+int sbx_mixed_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SBX_TRY(sbx_i64_check(h, ovf));  // (the call does not state nnz)
+  return sbx_csr_rows_sorted(h, SBX_I32, n, rp, col, sorted_host);
+}
+
+int sbx_mixed_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                            void *col, void *val) {
+  MIXED_NNZ_LIMIT("sbx_csr_sort_rows");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_csr_sort_rows(h, SBX_I32, vt, n, m, nnz, rp, col, val);
+}
+
+int sbx_mixed_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
+                         const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
+  MIXED_NNZ_LIMIT("sbx_coo_to_csc");
+  I64_BEGIN();
+  (void)ovf;
+  SCRATCH32(cp, m + 1, true);
+  SBX_TRY(sbx_coo_to_csc(h, SBX_I32, vt, n, m, nnz, row, col, val, cp, row_out, val_out));
+  return sbx_widen_i32(h, cp, col_ptr_out, m + 1);
+}
+
+int sbx_mixed_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                         const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out) {
+  MIXED_NNZ_LIMIT("sbx_csr_to_csc");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SCRATCH32(cp, m + 1, true);
+  SBX_TRY(sbx_csr_to_csc(h, SBX_I32, vt, n, m, nnz, rp, col, val, cp, row_out, val_out));
+  return sbx_widen_i32(h, cp, col_ptr_out, m + 1);
+}
+
+int sbx_mixed_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                            int64_t *bandwidth_host) {
+  MIXED_NNZ_LIMIT("sbx_csr_bandwidth");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_csr_bandwidth(h, SBX_I32, n, nnz, rp, col, bandwidth_host);
+}
+
+int sbx_mixed_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                          int64_t *profile_host) {
+  MIXED_NNZ_LIMIT("sbx_csr_profile");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_csr_profile(h, SBX_I32, n, nnz, rp, col, profile_host);
+}
+
+int sbx_mixed_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col, void *inv_perm_out,
+                          sbx_rcm_stats *stats_host) {
+  MIXED_NNZ_LIMIT("sbx_rcm_reorder");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_rcm_reorder(h, SBX_I32, n, nnz, rp, col, inv_perm_out, stats_host);
+}
+
+int sbx_mixed_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                            int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out, int64_t *counts_host) {
+  MIXED_NNZ_LIMIT("sbx_gray_row_keys");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_gray_row_keys(h, SBX_I32, n, m, nnz, rp, col, resolution, nnz_threshold, degree_out, key_out, counts_host);
+}
+
+int sbx_mixed_gray_reorder(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                           int resolution, int nnz_threshold, int group_size, int exact_ties, void *inv_perm_out) {
+  MIXED_NNZ_LIMIT("sbx_gray_reorder");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  return sbx_gray_reorder(h, SBX_I32, n, m, nnz, rp, col, resolution, nnz_threshold, group_size, exact_ties, inv_perm_out);
+}
+
+int sbx_mixed_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                               const void *col, const void *val, const void *row_order, const void *col_order,
+                               int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                               int64_t out_capacity, int64_t *shard_nnz_host) {
+  MIXED_NNZ_LIMIT("sbx_permute_csr_rows");
+  if (row_begin < 0 || row_end < row_begin || row_end > n) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows: bad row range");
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  const int64_t nr = row_end - row_begin;
+  SCRATCH32(rpo, nr + 1, true);
+  SBX_TRY(sbx_permute_csr_rows(h, SBX_I32, vt, n, m, nnz, rp, col, val, row_order, col_order, row_begin, row_end, rpo,
+                               col_out, val_out, out_capacity, shard_nnz_host));
+  return sbx_widen_i32(h, rpo, row_ptr_out, nr + 1);
+}
+
+int sbx_mixed_permute_csr_rows_nnz(sbx_handle_t h, int64_t n, const void *row_ptr, const void *row_order, int64_t row_begin,
+                                   int64_t row_end, int64_t *nnz_host) {
+  I64_BEGIN();
+  NARROW(rp, row_ptr, n + 1);
+  SBX_TRY(sbx_i64_check(h, ovf));  // (the call does not state nnz)
+  return sbx_permute_csr_rows_nnz(h, SBX_I32, n, rp, row_order, row_begin, row_end, nnz_host);
+}

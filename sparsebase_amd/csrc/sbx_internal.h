@@ -283,3 +283,28 @@ int sbx_i64_edge_list_parse(sbx_handle_t h, sbx_value_type vt, const void *text_
                             int weighted, unsigned flags, int64_t capacity, void *row_out, void *col_out, void *val_out,
                             int64_t *dims_nnz_host);
 int sbx_fill_i64(sbx_handle_t h, int64_t *dst, int64_t value, int64_t count);
+
+// ---- SBX_I32_N64 (32-bit ids, 64-bit offsets): adapters of the entry points whose offsets are 32-bit inside (sbx_i64.hip)
+int sbx_mixed_csr_rows_sorted(sbx_handle_t h, int64_t n, const void *row_ptr, const void *col, int *sorted_host);
+int sbx_mixed_csr_sort_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                            void *col, void *val);
+int sbx_mixed_coo_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row,
+                         const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
+int sbx_mixed_csr_to_csc(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                         const void *col, const void *val, void *col_ptr_out, void *row_out, void *val_out);
+int sbx_mixed_csr_bandwidth(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                            int64_t *bandwidth_host);
+int sbx_mixed_csr_profile(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col,
+                          int64_t *profile_host);
+int sbx_mixed_rcm_reorder(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, const void *col, void *inv_perm_out,
+                          sbx_rcm_stats *stats_host);
+int sbx_mixed_gray_row_keys(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                            int resolution, int nnz_threshold, void *degree_out, uint64_t *key_out, int64_t *counts_host);
+int sbx_mixed_gray_reorder(sbx_handle_t h, int64_t n, int64_t m, int64_t nnz, const void *row_ptr, const void *col,
+                           int resolution, int nnz_threshold, int group_size, int exact_ties, void *inv_perm_out);
+int sbx_mixed_permute_csr_rows(sbx_handle_t h, sbx_value_type vt, int64_t n, int64_t m, int64_t nnz, const void *row_ptr,
+                               const void *col, const void *val, const void *row_order, const void *col_order,
+                               int64_t row_begin, int64_t row_end, void *row_ptr_out, void *col_out, void *val_out,
+                               int64_t out_capacity, int64_t *shard_nnz_host);
+int sbx_mixed_permute_csr_rows_nnz(sbx_handle_t h, int64_t n, const void *row_ptr, const void *row_order, int64_t row_begin,
+                                   int64_t row_end, int64_t *nnz_host);

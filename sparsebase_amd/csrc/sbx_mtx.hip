@@ -303,6 +303,7 @@ extern "C" int sbx_mtx_parse_coordinate(sbx_handle_t h, sbx_index_type it, sbx_v
                                         int symmetry, unsigned flags, int64_t capacity, void *row_out, void *col_out,
                                         void *val_out, int64_t *nnz_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, nnz_host && bytes >= 0 && entries >= 0 && (entries == 0 || (text_dev && row_out && col_out)),
               "bad argument");
   SBX_REQUIRE(h, fields == 2 || fields == 3, "an entry has 2 (pattern) or 3 tokens");
@@ -428,6 +429,7 @@ extern "C" int sbx_edge_list_parse(sbx_handle_t h, sbx_index_type it, sbx_value_
                                    int64_t bytes, int64_t entries, int weighted, unsigned flags, int64_t capacity,
                                    void *row_out, void *col_out, void *val_out, int64_t *dims_nnz_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, dims_nnz_host && bytes >= 0 && entries >= 0 && (entries == 0 || (text_dev && row_out && col_out)),
               "bad argument");
   const bool undirected = (flags & SBX_EDGES_UNDIRECTED) != 0, remove_self = (flags & SBX_EDGES_REMOVE_SELF) != 0;

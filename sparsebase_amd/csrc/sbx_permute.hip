@@ -3025,6 +3025,7 @@ int classify_and_scan(sbx_handle_t h, const int2 *rec, I *rpo, I *sp, int64_t nr
 extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_t n, const void *perm,
                                        void *inv_out) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (perm && inv_out)), "bad argument");
   SBX_TRY(sbx_arena_begin(h));
   if (n == 0) return SBX_OK;
@@ -3041,6 +3042,7 @@ extern "C" int sbx_inverse_permutation(sbx_handle_t h, sbx_index_type it, int64_
 extern "C" int sbx_permute_array(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, const void *order,
                                  const void *vals, void *out) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) it = SBX_I32;  // (no offset array)
   SBX_REQUIRE(h, n >= 0 && (n == 0 || (order && vals && out)), "bad argument");
   const int vb = sbx_value_bytes(vt);
   SBX_REQUIRE(h, vb == 4 || vb == 8, "value type must be 4 or 8 bytes");
@@ -3188,6 +3190,9 @@ extern "C" int sbx_permute_csr_rows(sbx_handle_t h, sbx_index_type it, sbx_value
                                     void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
                                     int64_t *shard_nnz_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64)
+    return sbx_mixed_permute_csr_rows(h, vt, n, m, nnz, row_ptr, col, val, row_order, col_order, row_begin, row_end,
+                                      row_ptr_out, col_out, val_out, out_capacity, shard_nnz_host);
   SBX_REQUIRE(h, n >= 0 && m >= 0 && nnz >= 0 && row_ptr && row_ptr_out, "bad argument");
   SBX_REQUIRE(h, 0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range");
   SBX_REQUIRE(h, nnz == 0 || (col && col_out), "col/col_out required");
@@ -3290,6 +3295,7 @@ static int csr_sort_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, int
 extern "C" int sbx_csr_sort_rows(sbx_handle_t h, sbx_index_type it, sbx_value_type vt, int64_t n, int64_t m,
                                  int64_t nnz, const void *row_ptr, void *col, void *val) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_csr_sort_rows(h, vt, n, m, nnz, row_ptr, col, val);
   SBX_REQUIRE(h, n >= 0 && nnz >= 0 && row_ptr && (nnz == 0 || col), "bad argument");
   SBX_REQUIRE(h, nnz < ((int64_t)1 << 31) && n < ((int64_t)1 << 31) - 1, "dimension exceeds int32");
   if (it == SBX_I64) return csr_sort_rows_typed<int64_t>(h, vt, n, m, nnz, row_ptr, col, val);

@@ -3479,6 +3479,7 @@ int sbx_rcm_reorder_x64(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_
 extern "C" int sbx_rcm_reorder(sbx_handle_t h, sbx_index_type it, int64_t n, int64_t nnz, const void *row_ptr,
                                const void *col_v, void *inv_perm_out, sbx_rcm_stats *stats_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_rcm_reorder(h, n, nnz, row_ptr, col_v, inv_perm_out, stats_host);
   if (n < 0 || nnz < 0 || !row_ptr || (n > 0 && !inv_perm_out) || (nnz > 0 && !col_v))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_rcm_reorder: bad argument");
   // (ids, offsets and queue positions are 32-bit inside, whatever the width of the arrays)

@@ -375,6 +375,7 @@ extern "C" int sbx_comm_rank(sbx_comm_t c, int *rank, int *world) {
 extern "C" int sbx_permute_csr_rows_nnz(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
                                         const void *row_order, int64_t row_begin, int64_t row_end, int64_t *nnz_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) return sbx_mixed_permute_csr_rows_nnz(h, n, row_ptr, row_order, row_begin, row_end, nnz_host);
   if (!row_ptr || !nnz_host || n < 0 || row_begin < 0 || row_begin > row_end || row_end > n)
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_rows_nnz: bad argument");
   SBX_TRY(sbx_arena_begin(h));
@@ -403,6 +404,7 @@ extern "C" int sbx_permute_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_inde
                                        void *row_ptr_out, void *col_out, void *val_out, int64_t out_capacity,
                                        int64_t *shard_offsets_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_permute_csr_sharded: SBX_I32_N64 is not taken by the sharded entry points");
   if (!comm || !row_ptr || !row_ptr_out || n < 0) SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_permute_csr_sharded: bad argument");
   Splits sp;
   int64_t chunk = 1;
@@ -431,6 +433,7 @@ extern "C" int sbx_coo_to_csr_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index
                                       const int64_t *row_splits, void *row_ptr_out, void *col_out, void *val_out,
                                       int64_t out_capacity, int64_t *shard_offsets_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_coo_to_csr_sharded: SBX_I32_N64 is not taken by the sharded entry points");
   if (!comm || !row_ptr_out || n < 0 || nnz < 0 || (nnz > 0 && (!row || !col)))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_coo_to_csr_sharded: bad argument");
   Splits sp;
@@ -494,6 +497,7 @@ extern "C" int sbx_csr_to_coo_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index
                                       const int64_t *row_splits, void *row_out, void *col_out, void *val_out,
                                       int64_t out_capacity, int64_t *shard_offsets_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_csr_to_coo_sharded: SBX_I32_N64 is not taken by the sharded entry points");
   if (!comm || !row_ptr || n < 0 || nnz < 0 || (nnz > 0 && (!col || !row_out || !col_out)))
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_csr_to_coo_sharded: bad argument");
   Splits sp;
@@ -548,6 +552,7 @@ extern "C" int sbx_csr_to_coo_sharded(sbx_handle_t h, sbx_comm_t comm, sbx_index
 extern "C" int sbx_balanced_row_splits(sbx_handle_t h, sbx_index_type it, int64_t n, const void *row_ptr,
                                        const void *row_order, int world, int64_t *splits_host) {
   if (!h) return SBX_ERR_BAD_ARG;
+  if (it == SBX_I32_N64) SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_balanced_row_splits: SBX_I32_N64 is not taken by the sharded entry points");
   if (!row_ptr || !splits_host || n < 0 || world < 1 || world > MAX_WORLD)
     SBX_FAIL(h, SBX_ERR_BAD_ARG, "sbx_balanced_row_splits: bad argument (world 1..%d)", MAX_WORLD);
   SBX_TRY(sbx_arena_begin(h));

@@ -15,6 +15,7 @@
 // applied on the device before anything is copied back.
 #ifndef SPARSEBASE_CONVERTER_CONVERTER_ORDER_TWO_H_
 #define SPARSEBASE_CONVERTER_CONVERTER_ORDER_TWO_H_
+#include <type_traits>
 #include <vector>
 
 #include "sparsebase/context/cpu_context.h"
@@ -74,10 +75,10 @@ format::Format *CooCsrFunctionConditional(format::Format *source, context::Conte
   hip::Staged<I> d_col_out(dev, nnz);
   void *d_val = detail::UploadValues<V>(dev, coo->get_vals(), nnz);
   void *d_val_out = d_val ? dev.Malloc(nnz * hip::ValueBytes<V>()) : nullptr;
-  int rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row.get(),
+  int rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row.get(),
                           d_col.get(), d_val, d_rp.get(), d_col_out.get(), d_val_out, 0u);
   if (rc == SBX_OK)  // destination constructor semantics on the device
-    rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
+    rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
                            d_col_out.get(), d_val_out);
   N *row_ptr = nullptr;
   I *col = nullptr;
@@ -102,7 +103,7 @@ format::Format *CooCsrMoveConditionalFunction(format::Format *source, context::C
   auto &dev = hip::Device::Get(hip::DefaultDevice());
   hip::Staged<I> d_row(dev, coo->get_row(), nnz);
   hip::Staged<N> d_rp(dev, (size_t)n + 1);
-  dev.Check(sbx_coo_to_csr(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row.get(),
+  dev.Check(sbx_coo_to_csr(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row.get(),
                            nullptr, nullptr, d_rp.get(), nullptr, nullptr, SBX_FLAG_MOVE));
   N *row_ptr = dev.Download(d_rp.get(), (size_t)n + 1);
   I *col = coo->release_col();    // pointer hand-off (converter_order_two.cc:225-226)
@@ -122,10 +123,10 @@ format::Format *CsrCooFunctionConditional(format::Format *source, context::Conte
   hip::Staged<I> d_col(dev, csr->get_col(), nnz), d_row_out(dev, nnz), d_col_out(dev, nnz);
   void *d_val = detail::UploadValues<V>(dev, csr->get_vals(), nnz);
   void *d_val_out = d_val ? dev.Malloc(nnz * hip::ValueBytes<V>()) : nullptr;
-  int rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
+  int rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
                           d_col.get(), d_val, d_row_out.get(), d_col_out.get(), d_val_out, 0u);
   if (rc == SBX_OK)  // COO constructor semantics (check, sort if a row was out of order)
-    rc = sbx_coo_sort(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row_out.get(),
+    rc = sbx_coo_sort(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_row_out.get(),
                       d_col_out.get(), d_val_out);
   I *row = nullptr, *col = nullptr;
   V *vals = nullptr;
@@ -149,7 +150,7 @@ format::Format *CsrCooMoveConditionalFunction(format::Format *source, context::C
   auto &dev = hip::Device::Get(hip::DefaultDevice());
   hip::Staged<N> d_rp(dev, csr->get_row_ptr(), (size_t)n + 1);
   hip::Staged<I> d_row_out(dev, nnz);
-  dev.Check(sbx_csr_to_coo(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
+  dev.Check(sbx_csr_to_coo(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, d_rp.get(),
                            nullptr, nullptr, d_row_out.get(), nullptr, nullptr, SBX_FLAG_MOVE));
   I *row = dev.Download(d_row_out.get(), nnz);
   I *col = csr->release_col();    // converter_order_two.cc:134-135
@@ -175,9 +176,9 @@ void ToCscOnDevice(const hip::Device &dev, I n, I m, size_t nnz, const void *d_f
   N *cp = (N *)dev.Malloc((pc + 1) * sizeof(N));
   I *row = (I *)dev.Malloc((nnz ? nnz : 1) * sizeof(I));
   void *val = d_val ? dev.Malloc(nnz * hip::ValueBytes<V>()) : nullptr;
-  const int rc = FROM_CSR ? sbx_csr_to_csc(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
+  const int rc = FROM_CSR ? sbx_csr_to_csc(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
                                            d_first, d_col, d_val, cp, row, val)
-                          : sbx_coo_to_csc(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
+                          : sbx_coo_to_csc(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz,
                                            d_first, d_col, d_val, cp, row, val);
   if (rc != SBX_OK) {
     dev.Free(cp);
@@ -193,7 +194,9 @@ void ToCscOnDevice(const hip::Device &dev, I n, I m, size_t nnz, const void *d_f
 template <typename I, typename N, typename V, bool FROM_CSR>
 format::Format *StagedToCsc(I n, I m, size_t nnz, const void *first, size_t first_count, const I *col, const V *vals) {
   auto &dev = hip::Device::Get(hip::DefaultDevice());
-  hip::Staged<I> d_first(dev, (const I *)first, first_count), d_col(dev, col, nnz);
+  typedef typename std::conditional<FROM_CSR, N, I>::type F;  // (first: row_ptr — offsets — or the COO's row ids)
+  hip::Staged<F> d_first(dev, (const F *)first, first_count);
+  hip::Staged<I> d_col(dev, col, nnz);
   void *d_val = UploadValues<V>(dev, vals, nnz);
   N *d_cp = nullptr;
   I *d_row = nullptr;
@@ -219,7 +222,6 @@ format::Format *StagedToCsc(I n, I m, size_t nnz, const void *first, size_t firs
 
 template <typename I, typename N, typename V>
 format::Format *CooCscFunctionConditional(format::Format *source, context::Context *) {
-  static_assert(sizeof(I) == sizeof(N), "IDType and NNZType must have the same width");
   auto *coo = source->AsAbsolute<format::COO<I, N, V>>();
   const auto dims = coo->get_dimensions();
   const size_t nnz = coo->get_num_nnz();
@@ -228,7 +230,6 @@ format::Format *CooCscFunctionConditional(format::Format *source, context::Conte
 }
 template <typename I, typename N, typename V>
 format::Format *CsrCscFunctionConditional(format::Format *source, context::Context *) {
-  static_assert(sizeof(I) == sizeof(N), "IDType and NNZType must have the same width");
   auto *csr = source->AsAbsolute<format::CSR<I, N, V>>();
   const auto dims = csr->get_dimensions();
   return detail::StagedToCsc<I, N, V, true>((I)dims[0], (I)dims[1], csr->get_num_nnz(), csr->get_row_ptr(),
@@ -354,7 +355,7 @@ format::Format *HIPCooHIPCsrFunction(format::Format *source, context::Context *)
   unsigned flags = coo->rows_known_sorted() ? SBX_FLAG_ROWS_SORTED : 0u;
   int rc;
   if (MOVE) {
-    rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, coo->get_row(),
+    rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, coo->get_row(),
                         nullptr, nullptr, rp, nullptr, nullptr, flags | SBX_FLAG_MOVE);
     if (rc == SBX_OK) {
       col = coo->release_col();
@@ -363,7 +364,7 @@ format::Format *HIPCooHIPCsrFunction(format::Format *source, context::Context *)
   } else {
     col = (I *)dev.Malloc(nnz * sizeof(I));
     if (coo->get_vals()) val = (V *)dev.Malloc(nnz * hip::ValueBytes<V>());
-    rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, coo->get_row(),
+    rc = sbx_coo_to_csr(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, coo->get_row(),
                         coo->get_col(), coo->get_vals(), rp, col, val, flags);
   }
   if (rc != SBX_OK) {
@@ -390,7 +391,7 @@ format::Format *HIPCsrHIPCooFunction(format::Format *source, context::Context *)
   V *val = nullptr;
   int rc;
   if (MOVE) {
-    rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, csr->get_row_ptr(),
+    rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, csr->get_row_ptr(),
                         nullptr, nullptr, row, nullptr, nullptr, SBX_FLAG_MOVE);
     if (rc == SBX_OK) {
       col = csr->release_col();
@@ -399,7 +400,7 @@ format::Format *HIPCsrHIPCooFunction(format::Format *source, context::Context *)
   } else {
     col = (I *)dev.Malloc(nnz * sizeof(I));
     if (csr->get_vals()) val = (V *)dev.Malloc(nnz * hip::ValueBytes<V>());
-    rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, csr->get_row_ptr(),
+    rc = sbx_csr_to_coo(dev.handle(), hip::IndexTag<I, N>(), hip::ValueTag<V>(), n, m, (int64_t)nnz, csr->get_row_ptr(),
                         csr->get_col(), csr->get_vals(), row, col, val, 0u);
   }
   if (rc != SBX_OK) {

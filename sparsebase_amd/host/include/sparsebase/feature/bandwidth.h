@@ -55,7 +55,7 @@ class Bandwidth : public FeaturePreprocessType<int *> {
   // max over the nonzeros of |i - j| + 1 (bandwidth.cc:93-112); caller frees with delete
   static int *Run(View v) {
     int64_t bw = 0;
-    const int rc = sbx_csr_bandwidth(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr, v.col, &bw);
+    const int rc = sbx_csr_bandwidth(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.nnz, v.row_ptr, v.col, &bw);
     v.Release();
     v.dev->Check(rc);
     return new int((int)bw);

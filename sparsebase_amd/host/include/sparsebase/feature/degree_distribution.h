@@ -59,7 +59,7 @@ class DegreeDistribution : public FeaturePreprocessType<FeatureType *> {
     static_assert(std::is_same_v<FeatureType, float> || std::is_same_v<FeatureType, double>,
                   "FeatureType must be float or double");
     hip::Staged<FeatureType> d_out(*v.dev, (size_t)v.n);
-    const int rc = sbx_csr_degree_distribution(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr,
+    const int rc = sbx_csr_degree_distribution(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.nnz, v.row_ptr,
                                                (int)sizeof(FeatureType), d_out.get());
     FeatureType *out = nullptr;
     if (rc == SBX_OK) out = v.dev->Download(d_out.get(), (size_t)v.n);

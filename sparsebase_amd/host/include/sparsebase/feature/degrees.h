@@ -56,7 +56,7 @@ class Degrees : public FeaturePreprocessType<IDType *> {
   // degrees[i] = row_ptr[i+1] - row_ptr[i] (degrees.cc:93-105); new IDType[n], caller frees with delete[]
   static IDType *Run(View v) {
     hip::Staged<IDType> d_out(*v.dev, (size_t)v.n);
-    const int rc = sbx_csr_degrees(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, d_out.get());
+    const int rc = sbx_csr_degrees(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.row_ptr, d_out.get());
     IDType *out = nullptr;
     if (rc == SBX_OK) out = v.dev->Download(d_out.get(), (size_t)v.n);
     v.Release();

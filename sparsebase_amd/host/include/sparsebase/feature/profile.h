@@ -56,7 +56,7 @@ class Profile : public FeaturePreprocessType<IDType *> {
   // narrowed to IDType here, which is where the reference's IDType accumulator wraps; caller frees with delete
   static IDType *Run(View v) {
     int64_t sum = 0;
-    const int rc = sbx_csr_profile(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr, v.col, &sum);
+    const int rc = sbx_csr_profile(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.nnz, v.row_ptr, v.col, &sum);
     v.Release();
     v.dev->Check(rc);
     return new IDType((IDType)sum);

@@ -91,14 +91,13 @@ class CSC : public utils::IdentifiableImplementation<CSC<IDType, NNZType, ValueT
     return p.get_deleter().target_type() != typeid(BlankDeleter<T>);
   }
   void SortOnDevice(NNZType *col_ptr, IDType *row, ValueType *vals) {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
     const size_t nnz = (size_t)this->nnz_, ncols = ptr_count();
     if (nnz <= 1) return;
     auto &dev = hip::Device::Get(hip::DefaultDevice());
     hip::Staged<NNZType> d_cp(dev, col_ptr, ncols + 1);
     hip::Staged<IDType> d_row(dev, row, nnz);
     int sorted = 1;
-    dev.Check(sbx_csr_rows_sorted(dev.handle(), hip::IndexTag<IDType>(), (int64_t)ncols, d_cp.get(), d_row.get(),
+    dev.Check(sbx_csr_rows_sorted(dev.handle(), hip::IndexTag<IDType, NNZType>(), (int64_t)ncols, d_cp.get(), d_row.get(),
                                   &sorted));
     if (sorted) return;
     utils::Logger(typeid(this)).Log("CSC column array must be sorted. Sorting...", utils::LOG_LVL_WARNING);
@@ -108,7 +107,7 @@ class CSC : public utils::IdentifiableImplementation<CSC<IDType, NNZType, ValueT
       d_val = dev.Malloc(nnz * vb);
       dev.ToDevice(d_val, vals, nnz * vb);
     }
-    const int rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(),
+    const int rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(),
                                      (int64_t)ncols, (int64_t)this->dimension_[0], (int64_t)nnz, d_cp.get(),
                                      d_row.get(), d_val);
     if (rc == SBX_OK) {

@@ -80,14 +80,13 @@ class CSR : public utils::IdentifiableImplementation<CSR<IDType, NNZType, ValueT
     return p.get_deleter().target_type() != typeid(BlankDeleter<T>);
   }
   void SortOnDevice(IDType n, IDType m, NNZType *row_ptr, IDType *col, ValueType *vals) {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
     const size_t nnz = (size_t)row_ptr[n];
     if (nnz <= 1) return;
     auto &dev = hip::Device::Get(hip::DefaultDevice());
     hip::Staged<NNZType> d_rp(dev, row_ptr, (size_t)n + 1);
     hip::Staged<IDType> d_col(dev, col, nnz);
     int sorted = 1;
-    dev.Check(sbx_csr_rows_sorted(dev.handle(), hip::IndexTag<IDType>(), n, d_rp.get(), d_col.get(), &sorted));
+    dev.Check(sbx_csr_rows_sorted(dev.handle(), hip::IndexTag<IDType, NNZType>(), n, d_rp.get(), d_col.get(), &sorted));
     if (sorted) return;
     utils::Logger(typeid(this)).Log("CSR column array must be sorted. Sorting...", utils::LOG_LVL_WARNING);
     constexpr size_t vb = hip::ValueBytes<ValueType>();
@@ -96,7 +95,7 @@ class CSR : public utils::IdentifiableImplementation<CSR<IDType, NNZType, ValueT
       d_val = dev.Malloc(nnz * vb);
       dev.ToDevice(d_val, vals, nnz * vb);
     }
-    const int rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), n, m,
+    const int rc = sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(), n, m,
                                      (int64_t)nnz, d_rp.get(), d_col.get(), d_val);
     if (rc == SBX_OK) {
       d_col.ToHost(col);

@@ -46,14 +46,13 @@ class HIPCSR : public utils::IdentifiableImplementation<HIPCSR<IDType, NNZType, 
       : row_ptr_(detail::HoldDevice(row_ptr, own, context.device_id)),
         col_(detail::HoldDevice(col, own, context.device_id)),
         vals_(detail::HoldDevice(vals, own, context.device_id)) {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
     this->order_ = 2;
     this->dimension_ = {(DimensionType)n, (DimensionType)m};
     this->nnz_ = (DimensionType)nnz;
     this->context_ = std::unique_ptr<context::Context>(new context::HIPContext(context));
     if (!ignore_sort && nnz > 1) {  // format/csr.cc:99-157 on the device
       auto &dev = device();
-      dev.Check(sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), n, m,
+      dev.Check(sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(), n, m,
                                   (int64_t)nnz, row_ptr, col, vals));
     }
   }
@@ -119,7 +118,7 @@ class HIPCOO : public utils::IdentifiableImplementation<HIPCOO<IDType, NNZType, 
     if (!ignore_sort) {  // format/coo.cc:96-157 on the device
       auto &dev = device();
       if (nnz > 1)
-        dev.Check(sbx_coo_sort(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), n, m, (int64_t)nnz,
+        dev.Check(sbx_coo_sort(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(), n, m, (int64_t)nnz,
                                row, col, vals));
       rows_sorted_ = true;
     }
@@ -180,14 +179,13 @@ class HIPCSC : public utils::IdentifiableImplementation<HIPCSC<IDType, NNZType, 
       : col_ptr_(detail::HoldDevice(col_ptr, own, context.device_id)),
         row_(detail::HoldDevice(row, own, context.device_id)),
         vals_(detail::HoldDevice(vals, own, context.device_id)) {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
     this->order_ = 2;
     this->dimension_ = {(DimensionType)n, (DimensionType)m};
     this->nnz_ = (DimensionType)nnz;
     this->context_ = std::unique_ptr<context::Context>(new context::HIPContext(context));
     if (!ignore_sort && nnz > 1) {  // format/csc.cc:99-157 on the device
       auto &dev = device();
-      dev.Check(sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(),
+      dev.Check(sbx_csr_sort_rows(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(),
                                   (int64_t)PtrCount(n, m), n, (int64_t)nnz, col_ptr, row, vals));
     }
   }

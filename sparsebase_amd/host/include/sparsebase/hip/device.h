@@ -259,6 +259,14 @@ constexpr sbx_index_type IndexTag() {
   static_assert(sizeof(IDType) == 4 || sizeof(IDType) == 8, "index type must be 32 or 64 bit");
   return sizeof(IDType) == 4 ? SBX_I32 : SBX_I64;
 }
+// ... for a format's (IDType, NNZType) pair: equal widths, or 32-bit ids with 64-bit offsets (SBX_I32_N64: the id arrays
+// — row, col, orders — hold 32-bit words, the offset arrays — row_ptr, col_ptr — 64-bit ones)
+template <typename IDType, typename NNZType>
+constexpr sbx_index_type IndexTag() {
+  static_assert(sizeof(IDType) == sizeof(NNZType) || (sizeof(IDType) == 4 && sizeof(NNZType) == 8),
+                "index tuples of the device path: IDType and NNZType of one width, or 32-bit ids with 64-bit offsets");
+  return sizeof(IDType) == sizeof(NNZType) ? IndexTag<IDType>() : SBX_I32_N64;
+}
 template <typename V>
 constexpr sbx_value_type ValueTag() {
   if constexpr (std::is_same_v<V, void>) return SBX_V_NONE;

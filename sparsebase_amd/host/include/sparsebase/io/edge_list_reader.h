@@ -40,7 +40,7 @@ class EdgeListReader {
         converter::HIPCsrCsrConditionalFunction<IDType, NNZType, ValueType>(dcsr.get(), &cpu));
   }
   format::HIPCOO<IDType, NNZType, ValueType> *ReadHIPCOO(context::HIPContext ctx) const {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
+    (void)hip::IndexTag<IDType, NNZType>();  // (a COO holds id arrays only: any tuple the device path takes)
     if constexpr (std::is_same_v<ValueType, void>)
       if (weighted_) throw utils::ReaderException("Cannot read weights into ValueType void");
     std::ifstream fin(filename_, std::ios::binary);

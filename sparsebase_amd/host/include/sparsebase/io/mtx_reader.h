@@ -48,7 +48,7 @@ class MTXReader {
   }
   // the same matrix left in HBM (what a GPU pipeline wants: no host copy of the entries at all)
   format::HIPCOO<IDType, NNZType, ValueType> *ReadHIPCOO(context::HIPContext ctx) const {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "IDType and NNZType must have the same width");
+    (void)hip::IndexTag<IDType, NNZType>();  // (a COO holds id arrays only: any tuple the device path takes)
     if (options_.format != kCoordinate)
       throw utils::ReaderException("array-format Matrix Market files are not read by this library");
     std::ifstream fin(filename_, std::ios::binary);

@@ -102,7 +102,7 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
     out.col = (IDType *)dev.Malloc((size_t)(v.nnz ? v.nnz : 1) * sizeof(IDType));
     out.vals = nullptr;
     if (v.vals) out.vals = (ValueType *)dev.Malloc((size_t)v.nnz * hip::ValueBytes<ValueType>());
-    const int rc = sbx_permute_csr(dev.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), v.n, v.m, v.nnz,
+    const int rc = sbx_permute_csr(dev.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(), v.n, v.m, v.nnz,
                                    v.row_ptr, v.col, v.vals, d_ro, d_co, out.row_ptr, out.col, out.vals);
     if (!on_device) {
       if (d_co && d_co != d_ro) dev.Free(d_co);
@@ -149,7 +149,6 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
   ShardedHIPCSR<IDType, NNZType, ValueType> *GetPermutationSharded(format::HIPCSR<IDType, NNZType, ValueType> *csr,
                                                                     context::HIPCommunicator &comm,
                                                                     const int64_t *row_splits = nullptr) {
-    static_assert(sizeof(IDType) == sizeof(NNZType), "index and offset types of one width");
     auto *params = static_cast<PermuteOrderTwoParams<IDType> *>(this->params_.get());
     auto v = reorder::detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(csr);
     auto &dev = *v.dev;
@@ -159,7 +158,7 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
     if (row_splits) {
       for (int r = 0; r <= world; r++) splits[r] = row_splits[r];
     } else {
-      const int rs = sbx_balanced_row_splits(dev.handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, d_ro, world, splits.data());
+      const int rs = sbx_balanced_row_splits(dev.handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.row_ptr, d_ro, world, splits.data());
       if (rs != SBX_OK) {
         if (d_ro) dev.Free(d_ro);
         dev.Check(rs);
@@ -170,7 +169,7 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
                                       ? d_ro
                                       : dev.Upload(params->col_order, (size_t)v.m);
     int64_t cap = 0;
-    int rc = sbx_permute_csr_rows_nnz(dev.handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, d_ro, splits[rank],
+    int rc = sbx_permute_csr_rows_nnz(dev.handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.row_ptr, d_ro, splits[rank],
                                       splits[rank + 1], &cap);
     typedef typename std::conditional<std::is_same<ValueType, void>::value, char, ValueType>::type Stored;
     NNZType *rp = nullptr;
@@ -182,7 +181,7 @@ class PermuteOrderTwo : public Permuter<format::FormatOrderTwo<IDType, NNZType, 
       rp = (NNZType *)dev.Malloc(((size_t)v.n + 1) * sizeof(NNZType));
       col = (IDType *)dev.Malloc((size_t)(cap ? cap : 1) * sizeof(IDType));
       if (v.vals) vals = (Stored *)dev.Malloc((size_t)(cap ? cap : 1) * hip::ValueBytes<ValueType>());
-      rc = sbx_permute_csr_sharded(dev.handle(), comm.handle(), hip::IndexTag<IDType>(), hip::ValueTag<ValueType>(), v.n,
+      rc = sbx_permute_csr_sharded(dev.handle(), comm.handle(), hip::IndexTag<IDType, NNZType>(), hip::ValueTag<ValueType>(), v.n,
                                    v.m, v.nnz, v.row_ptr, v.col, v.vals, d_ro, d_co, splits.data(), rp, col, vals, cap,
                                    out->entry_offsets.data());
     }

@@ -32,7 +32,7 @@ class DegreeReorder : public Reorderer<IDType> {
     auto v = detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(format->template AsAbsolute<D>());
     const bool ascending = static_cast<DegreeReorderParams *>(this->params_.get())->ascending;
     IDType *d_inv = (IDType *)v.dev->Malloc((size_t)(v.n ? v.n : 1) * sizeof(IDType));
-    const int rc = sbx_degree_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, ascending ? 1 : 0, d_inv);
+    const int rc = sbx_degree_reorder(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.row_ptr, ascending ? 1 : 0, d_inv);
     if (rc != SBX_OK) {
       v.dev->Free(d_inv);
       v.dev->Check(rc);
@@ -45,7 +45,7 @@ class DegreeReorder : public Reorderer<IDType> {
     const bool ascending = static_cast<DegreeReorderParams *>(params)->ascending;
     hip::Staged<IDType> d_inv(*v.dev, (size_t)v.n);
     const int rc =
-        sbx_degree_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.row_ptr, ascending ? 1 : 0, d_inv.get());
+        sbx_degree_reorder(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.row_ptr, ascending ? 1 : 0, d_inv.get());
     IDType *inv = nullptr;
     if (rc == SBX_OK) inv = v.dev->Download(d_inv.get(), (size_t)v.n);
     v.Release();

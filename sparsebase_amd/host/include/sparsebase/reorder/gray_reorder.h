@@ -385,7 +385,7 @@ class GrayReorder : public Reorderer<IDType> {
     const int64_t n = v.n;
     if (params->stable_device_ordering) {  // (opt-in: see GrayReorderParams)
       hip::Staged<IDType> d_inv(*v.dev, (size_t)(n ? n : 1));
-      const int rc = sbx_gray_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
+      const int rc = sbx_gray_reorder(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
                                       (int)params->resolution, params->nnz_threshold, params->sparse_density_group_size,
                                       0, d_inv.get());
       IDType *inv = nullptr;
@@ -404,7 +404,7 @@ class GrayReorder : public Reorderer<IDType> {
       hip::Staged<IDType> d_deg(*v.dev, (size_t)n);
       hip::Staged<uint64_t> d_key(*v.dev, (size_t)n);
       auto t0 = clock::now();
-      const int rc = sbx_gray_row_keys(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
+      const int rc = sbx_gray_row_keys(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.m, v.nnz, v.row_ptr, v.col,
                                        (int)params->resolution, params->nnz_threshold, d_deg.get(), d_key.get(),
                                        counts);  // (returns after its last read-back: the stage is complete)
       last_stage_ms()[0] = ms_since(t0);

@@ -25,7 +25,7 @@ class RCMReorder : public Reorderer<IDType> {
       return Reorderer<IDType>::GetReorderDevice(format, context, convert_input);
     auto v = detail::DeviceCsrView<IDType, NNZType, ValueType>::Borrow(format->template AsAbsolute<D>());
     IDType *d_inv = (IDType *)v.dev->Malloc((size_t)(v.n ? v.n : 1) * sizeof(IDType));
-    const int rc = sbx_rcm_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr, v.col, d_inv, nullptr);
+    const int rc = sbx_rcm_reorder(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.nnz, v.row_ptr, v.col, d_inv, nullptr);
     if (rc != SBX_OK) {
       v.dev->Free(d_inv);
       v.dev->Check(rc);
@@ -36,7 +36,7 @@ class RCMReorder : public Reorderer<IDType> {
  protected:
   static IDType *Run(detail::DeviceCsrView<IDType, NNZType, ValueType> v) {
     hip::Staged<IDType> d_inv(*v.dev, (size_t)v.n);
-    const int rc = sbx_rcm_reorder(v.dev->handle(), hip::IndexTag<IDType>(), v.n, v.nnz, v.row_ptr, v.col,
+    const int rc = sbx_rcm_reorder(v.dev->handle(), hip::IndexTag<IDType, NNZType>(), v.n, v.nnz, v.row_ptr, v.col,
                                    d_inv.get(), nullptr);
     IDType *inv = nullptr;
     if (rc == SBX_OK) inv = v.dev->Download(d_inv.get(), (size_t)v.n);

@@ -142,6 +142,62 @@ TEST(ConverterOrderTwo, VoidValuesAndOtherTuples) {
   delete ucsr;
 }
 
+// The tuples with sizeof(IDType) != sizeof(NNZType) the reference pre-instantiates (CMakeLists.txt:15-17): 32-bit ids,
+// 64-bit offsets — <int, long long, V> and <unsigned int, unsigned long long, V> — through the whole path
+// (SBX_I32_N64: row_ptr / col_ptr are 64-bit arrays, every id array 32-bit).
+template <typename I, typename N>
+static void mixed_tuple_path() {
+  typedef float V;
+  I r[7], c[7];
+  V v[7];
+  for (int i = 0; i < 7; i++) r[i] = (I)coo_row[i], c[i] = (I)coo_col[i], v[i] = (V)coo_vals[i];
+  format::COO<I, N, V> coo(cn, cm, cnnz, r, c, v, format::kNotOwned);
+  std::unique_ptr<format::CSR<I, N, V>> csr(coo.template Convert<format::CSR>(&cpu_context));
+  EXPECT_TRUE(same(csr->get_row_ptr(), csr_row_ptr, cn + 1));
+  EXPECT_TRUE(same(csr->get_col(), csr_col, cnnz) && same(csr->get_vals(), csr_vals, cnnz));
+  std::unique_ptr<format::COO<I, N, V>> back(csr->template Convert<format::COO>(&cpu_context));
+  EXPECT_TRUE(same(back->get_row(), coo_row, cnnz) && same(back->get_col(), coo_col, cnnz));
+  std::unique_ptr<format::CSC<I, N, V>> csc(csr->template Convert<format::CSC>(&cpu_context));
+  EXPECT_TRUE(same(csc->get_col_ptr(), csc_col_ptr, cn + 1) && same(csc->get_row(), csc_row, cnnz) &&
+              same(csc->get_vals(), csc_vals, cnnz));
+  // device formats, reorderers, permute: the 3 x 3 fixture of functionality_common.inc
+  N rp3[4];
+  I c3[4];
+  V v3[4];
+  for (int i = 0; i < 4; i++) rp3[i] = (N)row_ptr[i], c3[i] = (I)cols[i], v3[i] = (V)vals[i];
+  format::CSR<I, N, V> small(n, n, rp3, c3, v3, format::kNotOwned);
+  std::unique_ptr<format::HIPCSR<I, N, V>> dsmall(small.template Convert<format::HIPCSR>(hip_context.get()));
+  auto &dev = hip::Device::Get(hip_context->device_id);
+  EXPECT_TRUE(same(fetch(dev, dsmall->get_row_ptr(), n + 1).data(), row_ptr, n + 1));
+  reorder::DegreeReorder<I, N, V> deg(true);
+  std::unique_ptr<I[]> o_deg(deg.GetReorder(dsmall.get(), {hip_context.get()}, false));
+  const int want_deg[3] = {2, 1, 0};
+  EXPECT_TRUE(same(o_deg.get(), want_deg, n));
+  reorder::RCMReorder<I, N, V> rcm;
+  std::unique_ptr<I[]> o_rcm(rcm.GetReorder(&small, {hip_context.get()}, true));
+  const int want_rcm[3] = {1, 2, 0};
+  EXPECT_TRUE(same(o_rcm.get(), want_rcm, n));
+  reorder::GrayReorder<I, N, V> gray(reorder::BitSize16, 100, 10);
+  std::unique_ptr<I[]> o_gray(gray.GetReorder(dsmall.get(), {hip_context.get()}, false));
+  const int want_gray[3] = {2, 0, 1};
+  EXPECT_TRUE(same(o_gray.get(), want_gray, n));
+  I ro[3], co[3];
+  for (int i = 0; i < 3; i++) ro[i] = (I)r_reorder_vector[i], co[i] = (I)c_reorder_vector[i];
+  permute::PermuteOrderTwo<I, N, V> perm(ro, co);
+  std::unique_ptr<format::FormatOrderTwo<I, N, V>> out(perm.GetPermutation(dsmall.get(), {hip_context.get()}, false));
+  auto *pc = out->template AsAbsolute<format::HIPCSR<I, N, V>>();
+  EXPECT_TRUE(same(fetch(dev, pc->get_row_ptr(), n + 1).data(), rc_row_ptr, n + 1));
+  EXPECT_TRUE(same(fetch(dev, pc->get_col(), nnz).data(), rc_cols, nnz) && same(fetch(dev, pc->get_vals(), nnz).data(), rc_vals, nnz));
+  std::unique_ptr<format::FormatOrderTwo<I, N, V>> hout(perm.GetPermutation(&small, {hip_context.get()}, true));
+  auto *hc = hout->template AsAbsolute<format::CSR<I, N, V>>();
+  EXPECT_TRUE(same(hc->get_row_ptr(), rc_row_ptr, n + 1) && same(hc->get_col(), rc_cols, nnz));
+  static_assert(sizeof(*hc->get_row_ptr()) == 8 && sizeof(*hc->get_col()) == 4, "64-bit offsets over 32-bit ids");
+}
+TEST(ConverterOrderTwo, MixedWidthTuples) {
+  mixed_tuple_path<int, long long>();
+  mixed_tuple_path<unsigned int, unsigned long long>();
+}
+
 // converter_order_two_tests.cc:49-160: compare_cscs checks n + 1 entries of col_ptr (common.inc:68)
 static void expect_csc(format::Format *f) {
   auto *csc = f->AsAbsolute<CSC3>();

@@ -25,10 +25,16 @@ def _vt(val):
     return _VT[val.dtype]
 
 
-def _it(t):
+def _it(t, ids=None):
+    """Index tuple of a call: `t` is the call's offset array where it has one (row_ptr / col_ptr), else an id array;
+    `ids` an id array of the same call (col, row): int64 offsets over int32 ids are SBX_I32_N64."""
     if t.dtype == torch.int32:
+        if ids is not None and ids.dtype != torch.int32:
+            raise TypeError("32-bit offsets with 64-bit ids: not a tuple the library takes")
         return capi.SBX_I32
     if t.dtype == torch.int64:
+        if ids is not None and ids.dtype == torch.int32:
+            return capi.SBX_I32_N64
         return capi.SBX_I64
     raise TypeError(f"index tensors must be int32/int64, got {t.dtype}")
 
@@ -123,28 +129,29 @@ def coo_sort_(n, m, row, col, val=None):
 def csr_rows_sorted(row_ptr, col):
     hd = handle_for(_check_dev(row_ptr, col))
     out = C.c_int(0)
-    hd.check(hd.lib.sbx_csr_rows_sorted(hd.h, _it(row_ptr), row_ptr.numel() - 1, _p(row_ptr), _p(col), C.byref(out)))
+    hd.check(hd.lib.sbx_csr_rows_sorted(hd.h, _it(row_ptr, col), row_ptr.numel() - 1, _p(row_ptr), _p(col), C.byref(out)))
     return bool(out.value)
 
 
 def csr_sort_rows_(n, m, row_ptr, col, val=None):
     """In place, like the CSR constructor (format/csr.cc:99-157)."""
     hd = handle_for(_check_dev(row_ptr, col, val))
-    hd.check(hd.lib.sbx_csr_sort_rows(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val)))
+    hd.check(hd.lib.sbx_csr_sort_rows(hd.h, _it(row_ptr, col), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val)))
 
 
 # ----------------------------------------------------------------------------- A2 / A3
-def coo_to_csr(n, m, row, col, val=None, move=False, rows_sorted=False, out=None):
+def coo_to_csr(n, m, row, col, val=None, move=False, rows_sorted=False, out=None, offset_dtype=None):
+    """offset_dtype=torch.int64 with int32 ids: the <32-bit ids, 64-bit offsets> tuple (SBX_I32_N64)."""
     hd = handle_for(_check_dev(row, col, val))
     nnz = row.numel()
     if out is None:
-        rp = torch.empty(n + 1, dtype=row.dtype, device=row.device)
+        rp = torch.empty(n + 1, dtype=offset_dtype or row.dtype, device=row.device)
         co = None if move else torch.empty_like(col)
         vo = None if (move or val is None) else torch.empty_like(val)
     else:
         rp, co, vo = out
     flags = (capi.FLAG_MOVE if move else 0) | (capi.FLAG_ROWS_SORTED if rows_sorted else 0)
-    hd.check(hd.lib.sbx_coo_to_csr(hd.h, _it(row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(rp), _p(co),
+    hd.check(hd.lib.sbx_coo_to_csr(hd.h, _it(rp, row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(rp), _p(co),
                                    _p(vo), flags))
     return (rp, col, val) if move else (rp, co, vo)
 
@@ -153,25 +160,25 @@ def csr_to_coo(n, m, row_ptr, col, val=None, move=False, out=None):
     hd = handle_for(_check_dev(row_ptr, col, val))
     nnz = col.numel()
     if out is None:
-        ro = torch.empty(nnz, dtype=row_ptr.dtype, device=row_ptr.device)
+        ro = torch.empty(nnz, dtype=col.dtype if col is not None else row_ptr.dtype, device=row_ptr.device)
         co = None if move else torch.empty_like(col)
         vo = None if (move or val is None) else torch.empty_like(val)
     else:
         ro, co, vo = out
     flags = capi.FLAG_MOVE if move else 0
-    hd.check(hd.lib.sbx_csr_to_coo(hd.h, _it(row_ptr), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(ro),
+    hd.check(hd.lib.sbx_csr_to_coo(hd.h, _it(row_ptr, ro), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(ro),
                                    _p(co), _p(vo), flags))
     return (ro, col, val) if move else (ro, co, vo)
 
 
-def coo_to_csc(n, m, row, col, val=None):
+def coo_to_csc(n, m, row, col, val=None, offset_dtype=None):
     """COO -> CSC (col_ptr[m+1], row[nnz], val[nnz]); converter_order_two.cc:21-70."""
     hd = handle_for(_check_dev(row, col, val))
     nnz = col.numel()
-    cp = torch.empty(m + 1, dtype=row.dtype, device=row.device)
+    cp = torch.empty(m + 1, dtype=offset_dtype or row.dtype, device=row.device)
     ro = torch.empty_like(row)
     vo = None if val is None else torch.empty_like(val)
-    hd.check(hd.lib.sbx_coo_to_csc(hd.h, _it(row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(cp), _p(ro), _p(vo)))
+    hd.check(hd.lib.sbx_coo_to_csc(hd.h, _it(cp, row), _vt(val), n, m, nnz, _p(row), _p(col), _p(val), _p(cp), _p(ro), _p(vo)))
     return cp, ro, vo
 
 
@@ -182,7 +189,7 @@ def csr_to_csc(n, m, row_ptr, col, val=None):
     cp = torch.empty(m + 1, dtype=row_ptr.dtype, device=row_ptr.device)
     ro = torch.empty_like(col)
     vo = None if val is None else torch.empty_like(val)
-    hd.check(hd.lib.sbx_csr_to_csc(hd.h, _it(row_ptr), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(cp),
+    hd.check(hd.lib.sbx_csr_to_csc(hd.h, _it(row_ptr, col), _vt(val), n, m, nnz, _p(row_ptr), _p(col), _p(val), _p(cp),
                                    _p(ro), _p(vo)))
     return cp, ro, vo
 
@@ -235,11 +242,12 @@ def edge_list_parse(text, weighted=False, remove_duplicates=False, remove_self_e
 
 
 # ----------------------------------------------------------------------------- features
-def csr_degrees(row_ptr):
+def csr_degrees(row_ptr, id_dtype=None):
+    """id_dtype=torch.int32 over an int64 row_ptr: the <32-bit ids, 64-bit offsets> tuple (degrees are ids)."""
     hd = handle_for(_check_dev(row_ptr))
     n = row_ptr.numel() - 1
-    out = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
-    hd.check(hd.lib.sbx_csr_degrees(hd.h, _it(row_ptr), n, _p(row_ptr), _p(out)))
+    out = torch.empty(n, dtype=id_dtype or row_ptr.dtype, device=row_ptr.device)
+    hd.check(hd.lib.sbx_csr_degrees(hd.h, _it(row_ptr, out), n, _p(row_ptr), _p(out)))
     return out
 
 
@@ -254,7 +262,7 @@ def csr_degree_distribution(row_ptr, nnz, dtype=torch.float32):
 def csr_bandwidth(row_ptr, col):
     hd = handle_for(_check_dev(row_ptr, col))
     out = C.c_int64(0)
-    hd.check(hd.lib.sbx_csr_bandwidth(hd.h, _it(row_ptr), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
+    hd.check(hd.lib.sbx_csr_bandwidth(hd.h, _it(row_ptr, col), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
                                       C.byref(out)))
     return out.value
 
@@ -262,26 +270,26 @@ def csr_bandwidth(row_ptr, col):
 def csr_profile(row_ptr, col):
     hd = handle_for(_check_dev(row_ptr, col))
     out = C.c_int64(0)
-    hd.check(hd.lib.sbx_csr_profile(hd.h, _it(row_ptr), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
+    hd.check(hd.lib.sbx_csr_profile(hd.h, _it(row_ptr, col), row_ptr.numel() - 1, col.numel(), _p(row_ptr), _p(col),
                                     C.byref(out)))
     return out.value
 
 
 # ----------------------------------------------------------------------------- reorderers
-def degree_reorder(row_ptr, ascending=True, out=None):
+def degree_reorder(row_ptr, ascending=True, out=None, id_dtype=None):
     hd = handle_for(_check_dev(row_ptr))
     n = row_ptr.numel() - 1
-    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device) if out is None else out
-    hd.check(hd.lib.sbx_degree_reorder(hd.h, _it(row_ptr), n, _p(row_ptr), int(bool(ascending)), _p(inv)))
+    inv = torch.empty(n, dtype=id_dtype or row_ptr.dtype, device=row_ptr.device) if out is None else out
+    hd.check(hd.lib.sbx_degree_reorder(hd.h, _it(row_ptr, inv), n, _p(row_ptr), int(bool(ascending)), _p(inv)))
     return inv
 
 
 def rcm_reorder(row_ptr, col, out=None, return_stats=False):
     hd = handle_for(_check_dev(row_ptr, col))
     n = row_ptr.numel() - 1
-    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device) if out is None else out
+    inv = torch.empty(n, dtype=col.dtype, device=row_ptr.device) if out is None else out
     stats = capi.RcmStats()
-    hd.check(hd.lib.sbx_rcm_reorder(hd.h, _it(row_ptr), n, col.numel(), _p(row_ptr), _p(col), _p(inv),
+    hd.check(hd.lib.sbx_rcm_reorder(hd.h, _it(row_ptr, col), n, col.numel(), _p(row_ptr), _p(col), _p(inv),
                                     C.byref(stats)))
     if return_stats:
         return inv, {k: getattr(stats, k) for k, _ in capi.RcmStats._fields_}
@@ -291,10 +299,10 @@ def rcm_reorder(row_ptr, col, out=None, return_stats=False):
 def gray_row_keys(m, row_ptr, col, resolution, nnz_threshold):
     hd = handle_for(_check_dev(row_ptr, col))
     n = row_ptr.numel() - 1
-    deg = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
+    deg = torch.empty(n, dtype=col.dtype, device=row_ptr.device)
     key = torch.empty(n, dtype=torch.int64, device=row_ptr.device)  # uint64 bit pattern
     counts = (C.c_int64 * 4)()
-    hd.check(hd.lib.sbx_gray_row_keys(hd.h, _it(row_ptr), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
+    hd.check(hd.lib.sbx_gray_row_keys(hd.h, _it(row_ptr, col), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
                                       int(nnz_threshold), _p(deg), _p(key), counts))
     return deg, key, list(counts)
 
@@ -304,8 +312,8 @@ def gray_reorder(m, row_ptr, col, resolution, nnz_threshold, group_size, exact_t
     exact mode is the host layer's reorder::GrayReorder)."""
     hd = handle_for(_check_dev(row_ptr, col))
     n = row_ptr.numel() - 1
-    inv = torch.empty(n, dtype=row_ptr.dtype, device=row_ptr.device)
-    hd.check(hd.lib.sbx_gray_reorder(hd.h, _it(row_ptr), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
+    inv = torch.empty(n, dtype=col.dtype, device=row_ptr.device)
+    hd.check(hd.lib.sbx_gray_reorder(hd.h, _it(row_ptr, col), n, m, col.numel(), _p(row_ptr), _p(col), int(resolution),
                                      int(nnz_threshold), int(group_size), 1 if exact_ties else 0, _p(inv)))
     return inv
 
@@ -326,7 +334,7 @@ def permute_csr(n, m, row_ptr, col, val, row_order, col_order, out=None):
         vo = None if val is None else torch.empty_like(val)
     else:
         rpo, co, vo = out
-    hd.check(hd.lib.sbx_permute_csr(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val),
+    hd.check(hd.lib.sbx_permute_csr(hd.h, _it(row_ptr, col), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col), _p(val),
                                     _p(row_order), _p(col_order), _p(rpo), _p(co), _p(vo)))
     return rpo, co, vo
 
@@ -335,7 +343,7 @@ def permute_csr_rows_nnz(n, row_ptr, row_order, row_begin, row_end):
     """Entries of the new rows [row_begin, row_end): the size of that shard's col / val slab."""
     hd = handle_for(_check_dev(row_ptr, row_order))
     got = C.c_int64(0)
-    hd.check(hd.lib.sbx_permute_csr_rows_nnz(hd.h, _it(row_ptr), n, _p(row_ptr), _p(row_order), row_begin, row_end,
+    hd.check(hd.lib.sbx_permute_csr_rows_nnz(hd.h, _it(row_ptr, row_order), n, _p(row_ptr), _p(row_order), row_begin, row_end,
                                              C.byref(got)))
     return got.value
 
@@ -350,7 +358,7 @@ def permute_csr_rows(n, m, row_ptr, col, val, row_order, col_order, row_begin, r
     co = torch.empty(max(capacity, 1), dtype=col.dtype, device=col.device)  # (an empty slab still needs an address)
     vo = None if val is None else torch.empty(max(capacity, 1), dtype=val.dtype, device=val.device)
     got = C.c_int64(0)
-    hd.check(hd.lib.sbx_permute_csr_rows(hd.h, _it(row_ptr), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
+    hd.check(hd.lib.sbx_permute_csr_rows(hd.h, _it(row_ptr, col), _vt(val), n, m, col.numel(), _p(row_ptr), _p(col),
                                          _p(val), _p(row_order), _p(col_order), row_begin, row_end, _p(rpo), _p(co),
                                          _p(vo), capacity, C.byref(got)))
     k = got.value

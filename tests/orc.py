@@ -225,6 +225,24 @@ class Ref:
         if rc != 0:
             raise TypeError("type tuple not built into oracle/_ref/libsbref.so")
 
+    def mixed_pipeline(self, n, m, row, col, val, row_order, col_order, with_rcm):
+        """The real reference instantiated for <int ids, long long offsets, float>: COO -> CSR (row_ptr int64) -> COO,
+        Permute2D, DegreeReorder(ascending), RCMReorder (ref_driver.cc: ref_mixed_pipeline)."""
+        nnz = len(row)
+        rp = np.empty(n + 1, np.int64)
+        back = np.empty(nnz, np.int32)
+        prp = np.empty(n + 1, np.int64)
+        pcol = np.empty(nnz, np.int32)
+        pval = np.empty(nnz, np.float32)
+        deg = np.empty(n, np.int32)
+        rcm = np.empty(n, np.int32) if with_rcm else None
+        rc = self.lib.ref_mixed_pipeline(C.c_int64(n), C.c_int64(m), C.c_int64(nnz), _p(row.copy()), _p(col.copy()),
+                                         _p(val.copy()), _p(row_order.copy()), _p(col_order.copy()), _p(rp), _p(back),
+                                         _p(prp), _p(pcol), _p(pval), _p(deg), _p(rcm))
+        if rc != 0:
+            raise RuntimeError("ref_mixed_pipeline failed: %d" % rc)
+        return rp, back, (prp, pcol, pval), deg, rcm
+
     def coo_sort(self, row, col, val=None, n=None, m=None):
         row, col = row.copy(), col.copy()
         val = None if val is None else val.copy()

@@ -378,3 +378,30 @@ def test_int64_permute_column_map_beyond_2_31(ops, oracle):
         assert torch.equal(r2, key // mm) and torch.equal(c2, key % mm)
         # equal coordinates keep no particular order in the reference (std::sort on (row, col) only): compare as sets
         assert torch.equal(torch.sort(v2)[0], v) and torch.equal(row[v2.long()], r2) and torch.equal(colr[v2.long()], c2)
+
+
+def test_mixed_width_coo_csr_beyond_2_31_nonzeros(ops):
+    """SBX_I32_N64 where it matters: 32-bit ids, more nonzeros than an int counts (2^31 + 2^20; 2^20 rows of 2049
+    entries).  COO -> CSR writes 64-bit offsets natively (copy and move), CSR -> COO reads them; the degree order and
+    the degree features take the same row_ptr.  (The permutes, sorts, RCM and Gray keep 32-bit offsets inside and refuse
+    nnz >= 2^31: tests/test_gpu_parity.py::test_mixed_width_tuple_int32_ids_int64_offsets.)"""
+    n, per = 1 << 20, 2049
+    nnz = n * per
+    assert nnz > (1 << 31)
+    idx = torch.arange(nnz, dtype=torch.int64, device="cuda")
+    row = torch.div(idx, per, rounding_mode="floor").to(torch.int32)
+    col = torch.remainder(idx, per).to(torch.int32)
+    del idx
+    want_rp = torch.arange(n + 1, dtype=torch.int64, device="cuda") * per
+    rp = ops.coo_to_csr(n, per, row, None, None, move=True, rows_sorted=True, offset_dtype=torch.int64)[0]
+    assert rp.dtype == torch.int64 and torch.equal(rp, want_rp)
+    rp2, co, _ = ops.coo_to_csr(n, per, row, col, None, offset_dtype=torch.int64)
+    assert torch.equal(rp2, want_rp) and torch.equal(co, col)
+    del co, rp2
+    back = ops.csr_to_coo(n, per, rp, col, None, move=True)[0]
+    assert back.dtype == torch.int32 and torch.equal(back, row)
+    del back, row
+    deg = ops.csr_degrees(rp, id_dtype=torch.int32)
+    assert deg.dtype == torch.int32 and int(deg.min()) == per and int(deg.max()) == per
+    inv = ops.degree_reorder(rp, True, id_dtype=torch.int32)   # equal degrees: descending id inside the degree
+    assert torch.equal(inv, torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda"))

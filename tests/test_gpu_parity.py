@@ -1691,3 +1691,111 @@ def test_rcm_on_a_callers_nonblocking_stream_the_way_a_c_caller_reads_it(oracle)
         hip.hipEventDestroy(ev)
         hip.hipStreamDestroy(s_other)
         hip.hipStreamDestroy(s_user)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rmat", "rect_dups", "empty_rows"])
+def test_mixed_width_tuple_int32_ids_int64_offsets(ops, oracle, case):
+    """SBX_I32_N64 — 32-bit ids with 64-bit offsets, the tuple the reference pre-instantiates for matrices with fewer than
+    2^31 rows and more offsets than an int holds (CMakeLists.txt:15-17: <int | unsigned int, long long | unsigned long
+    long, V>): every entry point that takes or writes row_ptr / col_ptr against the oracle's 32-bit run with the offsets
+    widened.  COO <-> CSR, DegreeReorder and the degree features run the 64-bit offsets natively, the rest through the
+    narrowing adapters (sbx_i64.hip)."""
+    if case == "rmat":
+        rp, col = synth.rmat_symmetric(12, 8, seed=31)
+        n = m = len(rp) - 1
+    elif case == "rect_dups":
+        n, m = 3000, 5000
+        rp, col = synth.random_rect_csr(n, m, 60000, 8, dup_frac=0.05)
+    else:
+        n = m = 4096
+        rp, col = synth.random_rect_csr(n, m, 9000, 12)
+        lens = np.diff(rp)
+        lens[::3] = 0                                   # a third of the rows empty
+        keep = np.repeat(lens > 0, np.diff(rp))
+        col = col[keep]
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = len(col)
+    val = (np.arange(nnz) % 97).astype(np.float32)
+    rp64 = rp.astype(np.int64)
+    d_rp, d_col, d_val = dev(rp64), dev(col), dev(val)
+    assert d_rp.dtype == torch.int64 and d_col.dtype == torch.int32
+
+    # ---- conversions (native 64-bit offsets)
+    row, c2, v2 = oracle.csr_to_coo(rp, col, val)
+    g_row, g_c, g_v = ops.csr_to_coo(n, m, d_rp, d_col, d_val)
+    assert g_row.dtype == torch.int32
+    same((g_row, g_c, g_v), (row, c2, v2))
+    g_rp, g_c, g_v = ops.coo_to_csr(n, m, dev(row), dev(c2), dev(v2), offset_dtype=torch.int64)
+    assert g_rp.dtype == torch.int64 and np.array_equal(host(g_rp), rp64)
+    same((g_c, g_v), (col, val))
+    assert np.array_equal(host(ops.coo_to_csr(n, m, dev(row), dev(c2), None, move=True, rows_sorted=True,
+                                              offset_dtype=torch.int64)[0]), rp64)
+    if nnz > 1:  # unsorted row[] (ignore_sort): exclusive scan of the histogram (converter_order_two.cc:180-192)
+        p = synth.random_permutation(nnz, 3)
+        w = oracle.coo_to_csr(n, row[p], c2[p], v2[p])
+        g = ops.coo_to_csr(n, m, dev(row[p]), dev(c2[p]), dev(v2[p]), offset_dtype=torch.int64)
+        assert np.array_equal(host(g[0]), w[0].astype(np.int64))
+        same(g[1:], w[1:])
+    # ---- CSC (col_ptr is the 64-bit array)
+    w = oracle.csr_to_csc(m, rp, col, val)
+    g = ops.csr_to_csc(n, m, d_rp, d_col, d_val)
+    assert g[0].dtype == torch.int64 and np.array_equal(host(g[0]), w[0].astype(np.int64))
+    same(g[1:], w[1:])
+    g = ops.coo_to_csc(n, m, dev(row), dev(c2), dev(v2), offset_dtype=torch.int64)
+    assert np.array_equal(host(g[0]), w[0].astype(np.int64))
+    same(g[1:], w[1:])
+    # ---- checks, constructor sort, features
+    assert ops.csr_rows_sorted(d_rp, d_col) == bool(oracle.csr_rows_sorted(rp, col))
+    g = np.random.default_rng(5)
+    scr = col.copy()
+    for r in range(n):  # shuffle inside the rows
+        a, b = rp[r], rp[r + 1]
+        scr[a:b] = scr[a:b][g.permutation(b - a)]
+    if case != "rect_dups":  # (distinct columns: the sorted row is unique)
+        sv = (np.arange(nnz) % 53).astype(np.float32)
+        w = oracle.csr_sort_rows(rp, scr, sv, m=m)
+        sc, svd = dev(scr), dev(sv)
+        ops.csr_sort_rows_(n, m, d_rp, sc, svd)
+        same((sc, svd), w)
+    same((ops.csr_degrees(d_rp, id_dtype=torch.int32),), (oracle.csr_degrees(rp),))
+    assert ops.csr_bandwidth(d_rp, d_col) == oracle.csr_bandwidth(rp, col)
+    assert ops.csr_profile(d_rp, d_col) == oracle.csr_profile(rp, col)
+    dist = host(ops.csr_degree_distribution(d_rp, nnz, torch.float64))
+    assert np.array_equal(dist, np.diff(rp).astype(np.float64) / np.float64(nnz))
+    # ---- reorderers: the inverse permutations are id arrays (32-bit)
+    for asc in (True, False):
+        inv = ops.degree_reorder(d_rp, asc, id_dtype=torch.int32)
+        assert inv.dtype == torch.int32 and np.array_equal(host(inv), oracle.degree_reorder(rp, asc))
+    if n == m:
+        if case == "rmat":  # (RCM is defined for symmetric patterns; others are refused)
+            order = ops.rcm_reorder(d_rp, d_col)
+            assert order.dtype == torch.int32
+            assert np.array_equal(host(order), oracle.rcm_reorder(rp, col))
+        deg, key, counts = ops.gray_row_keys(m, d_rp, d_col, 32, 10)
+        wd, wk, wc = oracle.gray_row_keys(rp, col, m, 32, 10)
+        assert np.array_equal(host(deg), wd) and np.array_equal(host(key).view(np.uint64), wk) and list(counts) == wc.tolist()
+        inv = host(ops.gray_reorder(m, d_rp, d_col, 32, 10, 4))
+        assert np.array_equal(inv, host(ops.gray_reorder(m, dev(rp), d_col, 32, 10, 4)))   # = the SBX_I32 call
+    # ---- permutes: row_ptr_out is 64-bit
+    ro = synth.random_permutation(n, 21)
+    co = synth.random_permutation(m, 22)
+    for row_o, col_o in ((ro, co), (ro, None), (None, co)):
+        w = oracle.permute_csr(rp, col, val, row_o, col_o, m=m)
+        g = ops.permute_csr(n, m, d_rp, d_col, d_val, dev(row_o), dev(col_o))
+        assert g[0].dtype == torch.int64 and np.array_equal(host(g[0]), w[0].astype(np.int64))
+        same(g[1:], w[1:])
+    lo, hi = n // 3, (2 * n) // 3
+    w = oracle.permute_csr(rp, col, val, ro, co, m=m)
+    g = ops.permute_csr_rows(n, m, d_rp, d_col, d_val, dev(ro), dev(co), lo, hi)
+    a, b = w[0][lo], w[0][hi]
+    assert np.array_equal(host(g[0]), (w[0][lo:hi + 1] - a).astype(np.int64))
+    same(g[1:], (w[1][a:b], w[2][a:b]))
+    # ---- nnz >= 2^31 is refused where the offsets inside are 32-bit (before anything is touched)
+    import ctypes as C
+    hd = ops.handle_for(d_rp.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    out_rp = torch.empty_like(d_rp)
+    rc = hd.lib.sbx_permute_csr(hd.h, 2, 3, n, m, 1 << 31, p(d_rp), p(d_col), p(d_val), p(dev(ro)), p(dev(co)), p(out_rp),
+                                p(torch.empty_like(d_col)), p(torch.empty_like(d_val)))
+    assert rc == 5, rc  # SBX_ERR_UNSUPPORTED
