@@ -2006,6 +2006,15 @@ struct BfsBuffers {
   // work in front of the next read-back — a chain of big levels (run_ubfs) or an ordered sweep's launches — and not
   // behind a 40 us kernel, which it would outlast with the caller's stream idle
   bool hook_wants_long_cover;
+  // the labelling of the other components runs on a side stream (sbx_rcm_reorder); its counters live in *dv.  Once both
+  // of its halves are enqueued (*side_stage >= 2) a Cuthill-McKee sweep joins that stream at its start — the work
+  // finished long before — so that the sweep's own last read-back of *dv also delivers those counters (*last_read,
+  // *last_read_joined) and the call needs no read-back of its own for them
+  const int *side_stage;
+  hipEvent_t side_event;
+  bool *side_joined;
+  RcmDev *last_read;
+  bool *last_read_joined;
 };
 
 // cover_us: roughly how long the kernels just enqueued keep the GPU busy before the host's next read-back returns
@@ -2033,6 +2042,10 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
   // (also the bitmap the level ordering scatters into: k_rank_scatter)
   const StartClear sc = {b.vbits, (unsigned long long)((b.fbits - b.vbits) + bm_bytes / sizeof(unsigned)),
                          (unsigned *)b.fresh64, (unsigned long long)(2 * ((b.n + 63) / 64 + 1)), nullptr, 0};
+  if (CM && b.side_stage && *b.side_stage >= 2 && !*b.side_joined) {
+    SBX_HIP(h, hipStreamWaitEvent(h->stream, b.side_event, 0));
+    *b.side_joined = true;
+  }
   SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_bfs_start, dim3(RCM_START_GRID), dim3(256), b.rp, b.vbits, b.fbits, b.lpos, b.ppos, b.q,
               b.dv, fixed_root, sc);
   unsigned off = 0, fsize = 1, level = 0, total = 1;
@@ -2059,6 +2072,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       SBX_LAUNCH_CHECK(h);
       SBX_TRY(bfs_first_launch(b));
       SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+      if (b.last_read) *b.last_read = hd, *b.last_read_joined = b.side_joined && *b.side_joined;
       remaining -= (int64_t)hd.sl_edges;
       if (remaining < 0) remaining = 0;
       off = hd.sl_off;
@@ -2133,6 +2147,7 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
     SBX_LAUNCH_CHECK(h);
     SBX_TRY(bfs_first_launch(b));
     SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+    if (b.last_read) *b.last_read = hd, *b.last_read_joined = b.side_joined && *b.side_joined;
     }
     frontier_unmarked = false;
     const unsigned nf = hd.nf;
@@ -3612,6 +3627,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   b.claim_clean = &claim_clean;
   b.after_first_launch = &enqueue_ranks;
   b.hook_wants_long_cover = true;  // (~15 launches)
+  b.side_stage = nullptr, b.side_event = nullptr, b.side_joined = nullptr, b.last_read = nullptr, b.last_read_joined = nullptr;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy; b.heavy_cap = heavy_cap;
   SBX_TRY(sbx_salloc(h, (size_t)std::max<int64_t>((int64_t)h->num_cus * 8, RCM_DIR_MAX), &b.hub_dir));
@@ -3774,6 +3790,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   // Cuthill-McKee sweep, which are bound by launches and latency, not by bandwidth.  The search needs no labels (a sweep
   // cannot leave its component; unlabelled, the bottom-up levels merely look at the other components' vertices too).
   cc_forked = side && v0 >= 0 && r0.count > (unsigned)RCM_MID && r0_unordered && rcm_cc_overlap();
+  bool counters_read = false;
   // (in two halves: on the side stream each half is enqueued behind one of the tie-break's ~45 us kernels)
   auto enqueue_cc_kernels = [&](int half) -> int {
   const unsigned gcount = gn < 1024u ? gn : 1024u;
@@ -3804,6 +3821,10 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     SBX_HIP(h, hipEventRecord(h->aux_event[2], main_stream));
     h->aux_dirty = true;
     int cc_stage = 0;  // halves of the labelling enqueued so far
+    bool cc_joined = false, last_read_joined = false;
+    RcmDev last_read;
+    b.side_stage = &cc_stage, b.side_event = h->aux_event[3], b.side_joined = &cc_joined;
+    b.last_read = &last_read, b.last_read_joined = &last_read_joined;
     std::function<int()> enqueue_cc = [&]() -> int {
       SBX_TRY(enqueue_ranks());
       if (cc_stage >= 2) return SBX_OK;
@@ -3827,6 +3848,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     const int src = search_component(v0, (I)r0.count, true, sd0);
     b.after_first_launch = &enqueue_ranks;
     b.hook_wants_long_cover = true;
+    b.side_stage = nullptr, b.side_joined = nullptr, b.last_read = nullptr, b.last_read_joined = nullptr;
     if (src != SBX_OK) {  // (the side stream must not be left waiting for a half that never comes)
       h->stream = main_stream;
       return src;
@@ -3834,14 +3856,17 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     SBX_TRY(enqueue_cc());  // (a search that never waited for anything)
     SBX_TRY(enqueue_cc());
     comp0_searched = true;
-    SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[3], 0));
+    if (!cc_joined) SBX_HIP(h, hipStreamWaitEvent(main_stream, h->aux_event[3], 0));
     cc_forked = false;
     if (ranks_joined || !ranks_enqueued) h->aux_dirty = false;
     small_on_side = true;
+    // (the search's last sweep joined the side stream at its start and read *dv behind that: the labelling's counters
+    // are in that read-back already)
+    if (cc_joined && last_read_joined) hd = last_read, counters_read = true;
   } else {
     SBX_TRY(enqueue_cc_kernels(2));
   }
-  SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
+  if (!counters_read) SBX_TRY(sbx_readback(h, &hd, dv, sizeof(RcmDev)));
   if (comp0_searched) {
     // the component's order is complete in q: written now, its place read from the size scan on the device — BEHIND the
     // read-back of the labelling's counters: when this component is the only one the host orders that read-back was the
