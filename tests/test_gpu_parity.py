@@ -1799,3 +1799,43 @@ def test_mixed_width_tuple_int32_ids_int64_offsets(ops, oracle, case):
     rc = hd.lib.sbx_permute_csr(hd.h, 2, 3, n, m, 1 << 31, p(d_rp), p(d_col), p(d_val), p(dev(ro)), p(dev(co)), p(out_rp),
                                 p(torch.empty_like(d_col)), p(torch.empty_like(d_val)))
     assert rc == 5, rc  # SBX_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_permute_tile2_boundaries(ops, oracle, idt):
+    """k_permute_tile2 (the tile kernel of the relabelling permutes, round 6) at its edges: ids of exactly
+    CDF_MAX_COL_BITS = 25 bits (the last width it takes) and one more (the equal-width kernel takes over: same result),
+    a window of thousands of empty rows between short ones (every position searches for its row), rows of 1 ... 8
+    entries (one bucket), of exactly 128 (the longest a tile holds) and 129 (the first row class), duplicate columns
+    with values, every value width, and a column map that sends all of a row's columns into one bin of the
+    key-distribution map (consecutive new ids: the ranking loop runs through the whole row)."""
+    g = np.random.default_rng(77)
+    for m in ((1 << 25), (1 << 25) + 1, 5000):
+        n = 9000
+        lens = g.integers(0, 12, n)
+        lens[100:6000] = 0                                  # a window of empty rows
+        lens[[10, 11, 12, 13]] = (128, 129, 127, 1)
+        lens[6100:6200] = g.integers(100, 129, 100)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(idt)
+        w = min(4000, m // 2)
+        cols = [np.sort(g.choice(w, l, replace=False)) for l in lens]
+        col = (np.concatenate(cols) if len(cols) else np.zeros(0)).astype(idt)
+        nnz = len(col)
+        # column map: the ids below w go to CONSECUTIVE new ids in the middle of the range (one bin of the map)
+        co = np.arange(m, dtype=np.int64)
+        base = m // 2
+        co[:w], co[base:base + w] = np.arange(base, base + w), np.arange(w)
+        co = co.astype(idt)
+        ro = synth.random_permutation(n, 5, idt)
+        for val in ((np.arange(nnz) % 31).astype(np.float32), None, g.random(nnz), (np.arange(nnz) % 7).astype(np.int64)):
+            want = oracle.permute_csr(rp, col, val, ro, co, m=m)
+            same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co)), want)
+    # duplicate columns inside short rows, values decide (csr.cc:143-156)
+    n = m = 3000
+    lens = g.integers(2, 40, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(idt)
+    col = np.concatenate([np.sort(g.integers(0, 50, l)) for l in lens]).astype(idt)   # 50 distinct ids: many duplicates
+    val = g.integers(0, 5, len(col)).astype(np.float32)
+    ro, co = synth.random_permutation(n, 6, idt), synth.random_permutation(m, 7, idt)
+    same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co)), oracle.permute_csr(rp, col, val, ro, co, m=m))
