@@ -3094,7 +3094,8 @@ static int permute_csr_rows_typed(sbx_handle_t h, sbx_value_type vt, int64_t n, 
   CdfMap cdf;
   cdf.table = nullptr, cdf.shift = 0, cdf.fsh = 0;
   bool cdf_on_side = false;
-  if (col_order && nnz > 0 && !sbx_env_test("SBX_PERMUTE_NO_TILE2")) {
+  static const bool tile2_off = sbx_env_test("SBX_PERMUTE_NO_TILE2") != nullptr;  // (tests: the equal-width tile kernel)
+  if (col_order && nnz > 0 && !tile2_off) {
     if (!h->prof_on && permute_overlap() && sbx_aux_streams(h) == SBX_OK) {
       hipStream_t main_stream = h->stream;
       SBX_HIP(h, hipEventRecord(h->aux_event[0], main_stream));

@@ -676,6 +676,11 @@ def test_permute_forced_radix_path():
     env = dict(os.environ, SBX_PERMUTE_FORCE_RADIX="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced-radix ok" in r.stdout, r.stdout + r.stderr
+    # SBX_PERMUTE_NO_TILE2=1: the relabelling permutes keep the equal-width tile kernel (what wider ids and arrays beyond
+    # 4 GB take in production) on inputs where the key-distribution kernel would run
+    env = dict(os.environ, SBX_PERMUTE_NO_TILE2="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced-radix ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_permute_rowwise_copy_path(ops, oracle):
