@@ -109,6 +109,7 @@ struct RcmDev {
   // unordered sweeps, levels chained on the device (run_ubfs): the frontier that is current for the next kernel of the
   // chain, the unvisited edges, what that kernel is to be (UC_*), and how often the chain swapped the frontier bitmaps
   unsigned uc_off, uc_size, uc_level, uc_total, uc_mode, uc_flips, uc_small_ran, uc_done;
+  unsigned uc_head;  // a chain was begun on the device behind a sweep's head small-level run (k_ubfs_chain_from_small)
   unsigned long long uc_fe;
   long long uc_remaining;
   // unordered sweeps: size and degree sum of level l in slot l & 1 (the collect kernel of level l clears the other one)
@@ -2006,6 +2007,11 @@ struct BfsBuffers {
   // work in front of the next read-back — a chain of big levels (run_ubfs) or an ordered sweep's launches — and not
   // behind a 40 us kernel, which it would outlast with the caller's stream idle
   bool hook_wants_long_cover;
+  // an unordered sweep enqueues its first chain of big levels right behind its head small-level run (run_ubfs): set for
+  // the call's first sweep only — it starts at the first non-empty row, the later ones at a vertex of smallest degree in
+  // a deepest level, whose first big frontier is a thin one for the top-down kernels (the chain's launches would all
+  // leave at once, ~35 us of empty launches; measured on the bench matrix, NOTES section 4.5-r6)
+  bool head_chain;
   // the labelling of the other components runs on a side stream (sbx_rcm_reorder); its counters live in *dv.  Once both
   // of its halves are enqueued (*side_stage >= 2) a Cuthill-McKee sweep joins that stream at its start — the work
   // finished long before — so that the sweep's own last read-back of *dv also delivers those counters (*last_read,
@@ -3030,7 +3036,12 @@ __global__ __launch_bounds__(256) void k_copy_words(unsigned *__restrict__ dst, 
 
 __global__ __launch_bounds__(256) void k_ubfs_fbits_from_dist(const unsigned *__restrict__ vbits,
                                                               const unsigned *__restrict__ dist, unsigned level,
-                                                              int64_t n, unsigned *__restrict__ fbits) {
+                                                              int64_t n, unsigned *__restrict__ fbits,
+                                                              const RcmDev *__restrict__ chain = nullptr) {
+  if (chain) {  // in front of a chain begun on the device: only if its first link is a bottom-up level, for its frontier
+    if (chain->uc_mode != UC_BU) return;
+    level = chain->uc_level;
+  }
   const int64_t words = (n + 31) / 32;
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // (a multiple of 64: a wave covers two whole words)
@@ -3180,6 +3191,26 @@ __global__ void k_ubfs_chain_next(RcmDev *dv, ChainInit ci) {
   uc_advance(dv, ci.bu_ratio);
 }
 
+// The chain begun on the DEVICE, behind the small-level run at a sweep's head: when that run stopped at a frontier too
+// big for it (UR_STOP, having moved) the host used to read back, decide the direction and launch the big level with the
+// chain behind it.  The decision needs nothing the device does not have: this one-thread kernel takes the run's
+// hand-over state as the chain's frontier and applies the host loop's rule; the frontier bitmap, the bottom-up links
+// and the tail run are enqueued behind it and run if it says so — one read-back serves the head run and the chain.
+__global__ void k_ubfs_chain_from_small(RcmDev *dv, long long remaining_before, double bu_ratio, unsigned level_in) {
+  dv->uc_flips = 0;
+  dv->uc_small_ran = 0;
+  dv->uc_head = 0;
+  dv->uc_mode = UC_HOST;  // (the links and the tail run leave unless told otherwise)
+  if (dv->gb_abort || dv->ur_status != UR_STOP || dv->ur_level == level_in) return;
+  long long rem = remaining_before - (long long)dv->ur_esum;
+  if (rem < 0) rem = 0;
+  dv->uc_off = dv->ur_off, dv->uc_size = dv->ur_size, dv->uc_level = dv->ur_level, dv->uc_total = dv->ur_total;
+  dv->uc_remaining = rem;
+  dv->uc_fe = dv->ur_fe;
+  dv->uc_head = 1;
+  if (dv->ur_size >= 1024 && (double)dv->ur_fe > bu_ratio * (double)rem) dv->uc_mode = UC_BU;
+}
+
 // SBX_DEBUG_RCM_CHECK=1: after an unordered sweep, every edge that leaves its visited set (there must be none) is counted
 // and the first few are recorded: (visited end, unvisited end, the visited end's level).
 __global__ __launch_bounds__(256) void k_check_closed(const X *__restrict__ rp, const X *__restrict__ col,
@@ -3248,8 +3279,33 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       // small levels: as many as stay small, in one launch
       SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
                   (I *)b.heavy, b.dv, off, fsize, level, total, (long long)frontier_edges, ub_max_levels(), 0);
+      // At a sweep's start on a big graph this run usually ends at a frontier for the bottom-up kernels: the chain that
+      // follows is enqueued now and begun on the device (k_ubfs_chain_from_small) — one read-back for the head run and the
+      // chain instead of two.  Where the run ends otherwise (the sweep is over, a top-down level is due, too deep) the
+      // half-dozen launches leave at once: only where it can pay (BfsBuffers::head_chain, a graph that is not small).
+      static const bool head_chain_on = !(sbx_env_test("SBX_RCM_HEAD_CHAIN") && atoi(sbx_env_test("SBX_RCM_HEAD_CHAIN")) == 0);
+      const int spec_len =
+          (head_chain_on && b.head_chain && frontier_edges < 0 && b.n >= ((int64_t)1 << 17)) ? ubfs_chain() : 0;
+      if (spec_len > 0) {
+        const ChainInit ci0 = {0u, 0u, 0u, 0u, 0ll, ubu_ratio()};
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_chain_from_small, dim3(1), dim3(1), b.dv, (long long)remaining, ubu_ratio(),
+                    level);
+        SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_fbits_from_dist, dim3(sbx_grid_for(b.n, 256, 4096)), dim3(256),
+                    (const unsigned *)b.vbits, (const unsigned *)dist, 0u, b.n, cur_f, (const RcmDev *)b.dv);
+        unsigned *cf = cur_f, *cn = cur_n;
+        for (int i = 0; i <= spec_len; i++) {
+          SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
+                      b.vbits, (const unsigned *)cf, cn, dist, 0u, b.q, b.n, b.dv, 1, ci0);
+          std::swap(cf, cn);
+        }
+        static const int tail_mode0 = sbx_env_test("SBX_DEBUG_CHAIN_TAIL_ABORT") && atoi(sbx_env_test("SBX_DEBUG_CHAIN_TAIL_ABORT")) ? 2 : 1;
+        SBX_KLAUNCH(h, SBX_K_BFS_SMALL, k_ubfs_small_run, dim3(UR_GRID), dim3(256), b.rp, b.col, b.vbits, dist, b.q,
+                    (I *)b.heavy, b.dv, 0u, 0u, 0u, 0u, 0ll, ub_max_levels(), tail_mode0);
+      }
       SBX_LAUNCH_CHECK(h);
-      SBX_TRY(bfs_first_launch(b, 40));
+      // (the hook's work needs the degree counts: while this read-back is the one that delivers them it waits for the
+      // next launch with a long cover)
+      SBX_TRY(bfs_first_launch(b, spec_len > 0 && (!b.late_counts || *b.late_counts_ready) ? 150 : 40));
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
       if (b.late_counts && !*b.late_counts_ready) {
@@ -3261,6 +3317,30 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
         h->rcm_gb_backoff = gb_backoff_calls();
         *too_deep = true;
         return SBX_OK;
+      }
+      if (spec_len > 0 && hs.uc_head) {
+        // the head run stopped at a big frontier and the chain went on from there: as behind a chain the host launched
+        note("small_run(head) + chain", hs.uc_flips, hs.uc_mode, (long long)hs.uc_remaining);
+        if (hs.uc_flips & 1u) std::swap(cur_f, cur_n);
+        rounds += hs.uc_flips;
+        remaining = (int64_t)hs.uc_remaining;
+        fbits_valid = hs.uc_flips > 0;  // (no link ran: the frontier is the head run's, its bitmap was not built)
+        if (hs.uc_small_ran) {
+          const bool moved2 = hs.ur_level != hs.uc_level;
+          off = hs.ur_off, fsize = hs.ur_size, level = hs.ur_level, total = hs.ur_total;
+          frontier_edges = (int64_t)hs.ur_fe;
+          if (moved2) fbits_valid = false;
+          if (hs.ur_status == UR_DONE) break;
+          if (hs.ur_status == UR_DEEP) {
+            *too_deep = true;
+            return SBX_OK;
+          }
+          continue;
+        }
+        off = hs.uc_off, fsize = hs.uc_size, level = hs.uc_level, total = hs.uc_total;
+        if (hs.uc_mode == UC_DONE) break;
+        frontier_edges = (int64_t)hs.uc_fe;
+        continue;
       }
       const bool moved = hs.ur_level != level;
       note("small_run(before)", hs.ur_status, hs.ur_level, (long long)hs.ur_esum);
@@ -3286,7 +3366,7 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
     if (bottom_up) {
       if (!fbits_valid)
         SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_fbits_from_dist, dim3(sbx_grid_for(b.n, 256, 4096)), dim3(256),
-                    (const unsigned *)b.vbits, (const unsigned *)dist, level, b.n, cur_f);
+                    (const unsigned *)b.vbits, (const unsigned *)dist, level, b.n, cur_f, (const RcmDev *)nullptr);
       // publishes the level itself (bitmaps, distances, queue): no collection pass
       SBX_KLAUNCH(h, SBX_K_BFS_BOTTOMUP, k_ubfs_bottom_up, dim3(max_grid), dim3(256), b.rp, b.col, b.label, comp_label,
                   b.vbits, (const unsigned *)cur_f, cur_n, dist, level + 1, q_next, b.n, b.dv, chain_len > 0 ? 2 : 0, ci);
@@ -3627,6 +3707,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   b.claim_clean = &claim_clean;
   b.after_first_launch = &enqueue_ranks;
   b.hook_wants_long_cover = true;  // (~15 launches)
+  b.head_chain = true;  // (until the first sweep has run)
   b.side_stage = nullptr, b.side_event = nullptr, b.side_joined = nullptr, b.last_read = nullptr, b.last_read_joined = nullptr;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy; b.heavy_cap = heavy_cap;
@@ -3663,6 +3744,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     b.max_deg = hd0.max_deg;
     b.late_counts = nullptr;
   }
+  if (hd0_ready && lazy_counts) b.head_chain = false;
   const I v0 = hd0.first_vertex == UNSEEN ? (I)-1 : (I)hd0.first_vertex;
   if (v0 < 0) {  // not one edge: the sweep above (if any) started from an empty row and means nothing
     r0.count = 0;
@@ -3672,6 +3754,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   if (v0 >= 0) {
     bool deep = deep0;
     if (!lazy_counts && unordered_ok) SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, v0, (I)-1, &r0, &deep));
+    b.head_chain = false;
     r0_unordered = !deep;
     unordered_sweeps += r0_unordered;
     if (deep) SBX_TRY(run_bfs<false>(h, b, v0, (I)-1, &r0));
