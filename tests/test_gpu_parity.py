@@ -1846,3 +1846,55 @@ def test_permute_tile2_boundaries(ops, oracle, idt):
     val = g.integers(0, 5, len(col)).astype(np.float32)
     ro, co = synth.random_permutation(n, 6, idt), synth.random_permutation(m, 7, idt)
     same(ops.permute_csr(n, m, dev(rp), dev(col), dev(val), dev(ro), dev(co)), oracle.permute_csr(rp, col, val, ro, co, m=m))
+
+
+def test_page_locked_host_blocks_and_the_oom_hook_through_the_c_abi(oracle):
+    """include/sbx.h: sbx_host_alloc / sbx_host_free hand out page-locked host blocks (the download targets of the host
+    layer: a pageable target is pinned and unpinned by the runtime around every copy, and the unpinning holds the
+    process's next submission back for milliseconds — NOTES section 5-r6); sbx_set_oom_hook: when an allocation of the
+    library's own fails, the hook is asked ONCE to give memory back, the allocation is tried again, and the entry point
+    returns SBX_ERR_OOM if that fails too — with the handle still usable.  The failing request is one no GPU can serve
+    (2^46 bytes): nothing is allocated by it."""
+    import ctypes as C
+    from sparsebase_amd import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.sbx_create(0, C.byref(h)) == 0
+    calls = []
+    def hook(user, wanted):
+        calls.append(int(wanted))
+        return 1   # "something was freed": the library tries once more
+    cb = capi.OOM_HOOK_FN(hook)
+    try:
+        rp, col = synth.rmat_symmetric(14, 6, seed=9)
+        n = len(rp) - 1
+        d_rp, d_col = dev(rp), dev(col)
+        d_deg = torch.empty(n, dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        # a page-locked block as the target of the library's own download
+        blk = C.c_void_p()
+        assert lib.sbx_host_alloc(h, n * 4, C.byref(blk)) == 0 and blk.value
+        assert lib.sbx_csr_degrees(h, 0, n, p(d_rp), p(d_deg)) == 0, lib.sbx_last_error(h)
+        assert lib.sbx_memcpy_d2h(h, blk, p(d_deg), n * 4) == 0
+        got = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_int32)), shape=(n,)).copy()
+        assert np.array_equal(got, np.diff(rp).astype(np.int32))
+        assert lib.sbx_host_free(h, blk) == 0
+        assert lib.sbx_host_free(h, None) == 0   # (like free(NULL))
+        # the hook
+        assert lib.sbx_set_oom_hook(h, cb, None) == 0
+        rc = lib.sbx_reserve(h, 1 << 46)
+        assert rc == 4, (rc, lib.sbx_last_error(h))   # SBX_ERR_OOM
+        assert len(calls) == 1 and calls[0] >= (1 << 46), calls
+        # the handle goes on working (its arena was given up by the failed reservation: the next call grows a new one)
+        d_inv = torch.empty(n, dtype=torch.int32, device="cuda")
+        st = capi.RcmStats()
+        assert lib.sbx_rcm_reorder(h, 0, n, len(col), p(d_rp), p(d_col), p(d_inv), C.byref(st)) == 0, lib.sbx_last_error(h)
+        assert lib.sbx_sync(h) == 0
+        assert np.array_equal(d_inv.cpu().numpy(), oracle.rcm_reorder(rp, col))
+        assert len(calls) == 1
+        # without a hook: the same error, nobody asked
+        assert lib.sbx_set_oom_hook(h, C.cast(None, capi.OOM_HOOK_FN), None) == 0
+        assert lib.sbx_reserve(h, 1 << 46) == 4 and len(calls) == 1
+    finally:
+        lib.sbx_sync(h)
+        lib.sbx_destroy(h)
