@@ -411,7 +411,7 @@ def gray_fractions(ops, n, nnz, rp, col, steps):
     alg = 4 * nnz + 16 * n
     out = {"params": [res_, thr, grp],
            "key_stage": {"ms": t_keys * 1e3, "alg_bytes": alg, "frac_of_hbm_peak": alg / t_keys / 1e9 / HBM_PEAK_GBS}}
-    try:  # the opt-in ordering on the device (sbx_gray_reorder, stable ties): key stage + three radix sorts of (key, row) pairs
+    try:  # the opt-in ordering on the device (sbx_gray_reorder, stable ties): key stage + one radix sort of composite keys
         ops.gray_reorder(n, rp, col, res_, thr, grp)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

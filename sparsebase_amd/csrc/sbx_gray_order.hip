@@ -17,6 +17,13 @@
 // (:181-190) keeps the reference's early-outs: sparse rows by degree only, dense rows in their original order.
 // Wherever the reference's comparators decide the order — no two rows of a section with equal keys — the result is the
 // reference's; among tied rows it is the stable order instead of introsort's.
+//
+// ONE sort where the criteria fit one word (round 6): class / section, signed key and degree are fields of a single
+// 64-bit key built in row order — no gathers through a half-sorted id list between the sorts, one histogram, one
+// read-back less (the number of sections only sizes the class field: its bound, ceil(threshold / group_size), does) —
+// and (key, row id) pairs go through the radix sort once: five 8-bit passes for the bench line's parameters (3 + 32 + 4
+// bits) where the three sorts took six, with three histograms and three gather kernels around them.  Parameters whose
+// fields need more than 64 bits (resolution 64; a threshold in the millions) keep the three sorts.
 #include "sbx_device.h"
 #include "sbx_internal.h"
 
@@ -96,6 +103,115 @@ __global__ __launch_bounds__(256) void k_go_emit(const uint32_t *__restrict__ id
   for (; p < n; p += stride) inv[id[p]] = (I)p;
 }
 
+// the degrees the sparse rows have (the one-sort path: the sections must be known before any key is built)
+template <typename I>
+__global__ __launch_bounds__(256) void k_go_present(const I *__restrict__ deg, int64_t n, int64_t thr,
+                                                    uint32_t *__restrict__ present) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t d = (int64_t)deg[i];
+    if (d <= thr && d > 0 && present[d] == 0) present[d] = 1;  // (a benign race: every writer stores 1)
+  }
+}
+
+// one key per row, in row order: class / section << (kbits + dbits) | signed key << dbits | degree (sparse rows)
+template <typename I>
+__global__ __launch_bounds__(256) void k_go_composite(const I *__restrict__ deg, const uint64_t *__restrict__ gkey, int64_t n,
+                                                      int64_t thr, const uint32_t *__restrict__ section, int sparse_banded,
+                                                      int dense_banded, uint64_t mask, uint32_t dense_class, int kbits,
+                                                      int dbits, int idbits, uint64_t *__restrict__ key,
+                                                      uint32_t *__restrict__ id) {
+  // id == nullptr: the row id is the key's low field (idbits wide) and the sort has no payload
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t d = (int64_t)deg[i];
+    uint64_t cls, k = 0, dk = 0;
+    if (d > thr) {
+      cls = dense_class;
+      if (!dense_banded) k = gkey[i] & mask;
+    } else {
+      const uint32_t sec = sparse_banded ? 0u : section[d];
+      cls = sec;
+      dk = (uint64_t)d;
+      if (d > 0 && !sparse_banded) k = ((sec - 1u) & 1u) ? (~gkey[i]) & mask : gkey[i] & mask;
+    }
+    if (kbits == 0) k = 0;  // (both classes "highly banded": the keys are no criterion)
+    const uint64_t comp = (cls << (kbits + dbits)) | (k << dbits) | dk;
+    if (id) {
+      key[i] = comp;
+      id[i] = (uint32_t)i;
+    } else {
+      key[i] = (comp << idbits) | (uint64_t)i;
+    }
+  }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void k_go_widen(const uint32_t *__restrict__ in, int64_t n, I *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = (I)in[i];
+}
+
+static bool gray_three_sorts() {  // SBX_GRAY_ORDER_THREE_SORTS=1: the ordering keeps its three sorts whatever the parameters (tests, A/B)
+  static const bool on = sbx_env_test("SBX_GRAY_ORDER_THREE_SORTS") && atoi(sbx_env_test("SBX_GRAY_ORDER_THREE_SORTS")) != 0;
+  return on;
+}
+
+template <typename I>
+int gray_order_one_sort(sbx_handle_t h, int64_t n, const I *deg, const uint64_t *gkey, bool sparse_banded, bool dense_banded,
+                        int kbits, int dbits, int cbits, uint32_t dense_class, int64_t dmax, int64_t thr, int group_size,
+                        uint64_t mask, I *inv_out) {
+  const unsigned grid = sbx_grid_for(n, 256, (int64_t)h->num_cus * 16);
+  uint32_t *ia = nullptr, *ib = nullptr, *present = nullptr, *rank = nullptr, *section = nullptr;
+  uint64_t *qa = nullptr, *qb = nullptr;
+  SBX_TRY(sbx_salloc(h, (size_t)n, &ia));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &ib));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &qa));
+  SBX_TRY(sbx_salloc(h, (size_t)n, &qb));
+  SBX_TRY(sbx_salloc(h, (size_t)dmax + 2, &section));
+  if (!sparse_banded && dmax > 0) {  // the sections of the degrees (a "highly banded" sparse class has none)
+    SBX_TRY(sbx_salloc(h, (size_t)dmax + 2, &present));
+    SBX_TRY(sbx_salloc(h, (size_t)dmax + 2, &rank));
+    SBX_HIP(h, hipMemsetAsync(present, 0, sizeof(uint32_t) * (size_t)(dmax + 2), h->stream));
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_go_present<I>, dim3(grid), dim3(256), deg, n, thr, present);
+    SBX_TRY(sbx_exclusive_scan_u32(h, present, rank, dmax + 1, nullptr));
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_go_sections, dim3((unsigned)((dmax + 1 + 255) / 256)), dim3(256), (const uint32_t *)present,
+                (const uint32_t *)rank, dmax + 1, (uint32_t)group_size, section);
+  } else {
+    SBX_HIP(h, hipMemsetAsync(section, 0, sizeof(uint32_t) * (size_t)(dmax + 2), h->stream));
+  }
+  sbx_radix_pass passes[16];
+  // Where the row id fits below the criteria (bench line: 39 + 22 bits) it is the key's low field: the sort moves 8-byte
+  // keys without a payload, and its last pass writes inv[id] = position itself (sbx_radix_emit::pos_of) — no emit kernel
+  const int idbits = sbx_bits_for((uint64_t)(n - 1));
+  if (cbits + kbits + dbits + idbits <= 64) {
+    SBX_KLAUNCH(h, SBX_K_GRAY, k_go_composite<I>, dim3(grid), dim3(256), deg, gkey, n, thr, (const uint32_t *)section,
+                sparse_banded ? 1 : 0, dense_banded ? 1 : 0, mask, dense_class, kbits, dbits, idbits, qa, (uint32_t *)nullptr);
+    SBX_LAUNCH_CHECK(h);
+    const int np = sbx_radix_plan(idbits, idbits + cbits + kbits + dbits, 0, 0, passes);
+    const sbx_radix_emit em = {nullptr, ia, nullptr, nullptr, sizeof(I) == 4 ? (unsigned *)inv_out : (unsigned *)ib,
+                               idbits < 32 ? (1u << idbits) - 1u : 0u};
+    SBX_TRY(sbx_radix_sort_emit(h, qa, qb, n, passes, np, &em));
+    if (sizeof(I) != 4) {
+      SBX_KLAUNCH(h, SBX_K_GRAY, k_go_widen<I>, dim3(grid), dim3(256), (const uint32_t *)ib, n, inv_out);
+      SBX_LAUNCH_CHECK(h);
+    }
+    return SBX_OK;
+  }
+  SBX_KLAUNCH(h, SBX_K_GRAY, k_go_composite<I>, dim3(grid), dim3(256), deg, gkey, n, thr, (const uint32_t *)section,
+              sparse_banded ? 1 : 0, dense_banded ? 1 : 0, mask, dense_class, kbits, dbits, 0, qa, ia);
+  SBX_LAUNCH_CHECK(h);
+  int in_b = 0;
+  const int np = sbx_radix_plan(0, cbits + kbits + dbits, 0, 0, passes);
+  SBX_TRY(sbx_radix_sort(h, 8, 4, qa, qb, ia, ib, n, passes, np, &in_b));
+  SBX_KLAUNCH(h, SBX_K_GRAY, k_go_emit<I>, dim3(grid), dim3(256), (const uint32_t *)(in_b ? ib : ia), n, inv_out);
+  SBX_LAUNCH_CHECK(h);
+  return SBX_OK;
+}
+
 template <typename I>
 int gray_order_typed(sbx_handle_t h, int64_t n, int64_t nnz, const I *deg, const uint64_t *gkey, const int64_t *counts,
                      int bits, int64_t thr, int group_size, I *inv_out) {
@@ -108,6 +224,16 @@ int gray_order_typed(sbx_handle_t h, int64_t n, int64_t nnz, const I *deg, const
   if (dmax > ((int64_t)1 << 28))
     SBX_FAIL(h, SBX_ERR_UNSUPPORTED, "sbx_gray_reorder: nnz_threshold %lld: the degree tables would need %lld entries",
              (long long)thr, (long long)dmax);
+  {
+    // the one-sort form: do the three fields fit a word?  (at most dmax degrees are present: that many sections at most)
+    const int64_t gs = group_size > 0 ? group_size : 1;
+    const uint32_t dense_class_1 = sparse_banded ? 1u : (uint32_t)((dmax + gs - 1) / gs) + 1u;
+    const int cbits = sbx_bits_for((uint64_t)dense_class_1), dbits1 = sbx_bits_for((uint64_t)dmax);
+    const int kbits = (sparse_banded && dense_banded) ? 0 : bits;
+    if (cbits + kbits + dbits1 <= 64 && !gray_three_sorts())
+      return gray_order_one_sort<I>(h, n, deg, gkey, sparse_banded, dense_banded, kbits, dbits1, cbits, dense_class_1, dmax,
+                                    thr, (int)gs, bits >= 64 ? ~0ull : ((1ull << bits) - 1ull), inv_out);
+  }
   const unsigned grid = sbx_grid_for(n, 256, (int64_t)h->num_cus * 16);
   uint32_t *ka = nullptr, *kb = nullptr, *ia = nullptr, *ib = nullptr, *present = nullptr, *rank = nullptr, *section = nullptr;
   uint64_t *qa = nullptr, *qb = nullptr;

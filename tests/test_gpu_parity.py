@@ -1898,3 +1898,34 @@ def test_page_locked_host_blocks_and_the_oom_hook_through_the_c_abi(oracle):
     finally:
         lib.sbx_sync(h)
         lib.sbx_destroy(h)
+
+
+def test_gray_device_ordering_one_sort_equals_three_sorts(ops):
+    """sbx_gray_reorder orders (class / section, signed key, degree, row id) with ONE radix sort over a composite key where
+    the fields fit 64 bits, with three stable sorts otherwise (and under SBX_GRAY_ORDER_THREE_SORTS=1, read once per
+    process: hence the child): the same inverse permutation either way, on power-law, banded and wide-band inputs."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np, torch; sys.path[:0] = [%r]\n"
+        "from sparsebase_amd import ops, synth\n"
+        "d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "cases = [(synth.rmat_symmetric(15, 9, seed=4), (32, 10, 4)), (synth.rmat_symmetric(15, 9, seed=4), (16, 20, 2)),\n"
+        "         (synth.rmat_symmetric(14, 5, seed=6), (8, 3, 1)), (synth.banded_symmetric(20000, 40, 9, 3), (32, 10, 4)),\n"
+        "         (synth.banded_symmetric(20000, 3000, 9, 4), (16, 0, 1)), (synth.rmat_symmetric(14, 5, seed=6), (32, -1, 3))]\n"
+        "for (rp, col), (res, thr, grp) in cases:\n"
+        "    n = len(rp) - 1\n"
+        "    for wide in (False, True):\n"
+        "        a, b = (d(rp).long(), d(col).long()) if wide else (d(rp), d(col))\n"
+        "        inv = ops.gray_reorder(n, a, b, res, thr, grp).cpu().numpy().astype(np.int64)\n"
+        "        print('digest', hashlib.sha256(inv.tobytes()).hexdigest())\n"
+        % (root,))
+    outs = []
+    for extra in ({}, {"SBX_GRAY_ORDER_THREE_SORTS": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("digest")])
+    assert len(outs[0]) == 12 and outs[0] == outs[1]
