@@ -194,7 +194,10 @@ int gray_order_one_sort(sbx_handle_t h, int64_t n, const I *deg, const uint64_t 
     const int np = sbx_radix_plan(idbits, idbits + cbits + kbits + dbits, 0, 0, passes);
     const sbx_radix_emit em = {nullptr, ia, nullptr, nullptr, sizeof(I) == 4 ? (unsigned *)inv_out : (unsigned *)ib,
                                idbits < 32 ? (1u << idbits) - 1u : 0u};
-    SBX_TRY(sbx_radix_sort_emit(h, qa, qb, n, passes, np, &em));
+    h->rs_tied_hint = true;  // (class and degree fields of a handful of values, Gray keys shared by many rows)
+    const int rc_sort = sbx_radix_sort_emit(h, qa, qb, n, passes, np, &em);
+    h->rs_tied_hint = false;
+    SBX_TRY(rc_sort);
     if (sizeof(I) != 4) {
       SBX_KLAUNCH(h, SBX_K_GRAY, k_go_widen<I>, dim3(grid), dim3(256), (const uint32_t *)ib, n, inv_out);
       SBX_LAUNCH_CHECK(h);
@@ -206,7 +209,10 @@ int gray_order_one_sort(sbx_handle_t h, int64_t n, const I *deg, const uint64_t 
   SBX_LAUNCH_CHECK(h);
   int in_b = 0;
   const int np = sbx_radix_plan(0, cbits + kbits + dbits, 0, 0, passes);
-  SBX_TRY(sbx_radix_sort(h, 8, 4, qa, qb, ia, ib, n, passes, np, &in_b));
+  h->rs_tied_hint = true;
+  const int rc_sort = sbx_radix_sort(h, 8, 4, qa, qb, ia, ib, n, passes, np, &in_b);
+  h->rs_tied_hint = false;
+  SBX_TRY(rc_sort);
   SBX_KLAUNCH(h, SBX_K_GRAY, k_go_emit<I>, dim3(grid), dim3(256), (const uint32_t *)(in_b ? ib : ia), n, inv_out);
   SBX_LAUNCH_CHECK(h);
   return SBX_OK;

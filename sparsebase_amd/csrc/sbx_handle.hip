@@ -99,6 +99,7 @@ extern "C" int sbx_create(int device, sbx_handle_t *out) {
   h->pow5 = nullptr;
   h->aux_ready = false;
   h->aux_dirty = false;
+  h->rs_tied_hint = false;
   h->rs_override = nullptr;
   h->rs_pool = nullptr;
   h->rs_next = 0;

@@ -86,6 +86,7 @@ struct sbx_handle_s {
   hipEvent_t aux_event[SBX_AUX_STREAMS + 1];
   bool aux_ready;
   bool aux_dirty;     // a side stream may still be running work of a call that returned early (error path)
+  bool rs_tied_hint;  // set around a sort whose keys are heavily tied (Gray's composite keys): k_onesweep_hist aggregates per wave
   void *rs_override;  // next radix sort takes this zeroed slot instead of one from the pool (sorts on a side stream
                       // must not share the pool with the main stream: the pool is re-zeroed in stream order)
   // profiler: when on, every kernel launch is bracketed by HIP events on the

@@ -169,6 +169,7 @@ typedef unsigned long long rs_word;  // look-back status word: (count << 2) | fl
 
 struct RadixPlan {
   int n;
+  int tied;  // the caller expects heavily tied digits (sbx_handle::rs_tied_hint): the histogram aggregates inside a wave
   int shift[RS_MAX_PASSES];
   int bits[RS_MAX_PASSES];
 };
@@ -206,8 +207,21 @@ __global__ __launch_bounds__(RSH_THREADS) void k_onesweep_hist(const K *__restri
     for (int u = 0; u < HU; u++) k[u] = key_at(i + u * stride);
 #pragma unroll
     for (int u = 0; u < HU; u++)
-      for (int p = 0; p < plan.n; p++)
-        atomicAdd(&lh[p][(unsigned)(k[u] >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
+      for (int p = 0; p < plan.n; p++) {
+        // Tied keys (class and degree fields, the Gray keys of a power-law matrix) send most lanes of a wave to ONE
+        // counter, and LDS adds to one address go one lane at a time: the lanes that share the first lane's digit are
+        // counted with a ballot and added once.
+        // (only where the caller says so: on keys without ties the ballots cost the 105 M-key sorts 1 - 2 %)
+        const unsigned d = (unsigned)(k[u] >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u);
+        if (!plan.tied) {
+          atomicAdd(&lh[p][d], 1u);
+        } else {
+          const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+          const unsigned long long same = __ballot(d == d0);
+          if (d != d0) atomicAdd(&lh[p][d], 1u);
+          else if ((same & sbx_lanemask_lt()) == 0) atomicAdd(&lh[p][d0], (unsigned)__popcll(same));
+        }
+      }
   }
   for (; i < count; i += stride) {
     const K k = key_at(i);
@@ -564,6 +578,7 @@ static int radix_sort_impl(sbx_handle_t h, K *ka, K *kb, P *va, P *vb, int64_t c
   const int64_t tiles = (count + TILE - 1) / TILE;
   RadixPlan plan;
   plan.n = np;
+  plan.tied = h->rs_tied_hint ? 1 : 0;
   for (int p = 0; p < np; p++) {
     plan.shift[p] = passes[p].shift;
     plan.bits[p] = passes[p].bits;
@@ -624,6 +639,7 @@ static int radix_sort_io_impl(sbx_handle_t h, const sbx_radix_side *src, K *ka, 
   const int64_t tiles = (count + TILE - 1) / TILE;
   RadixPlan plan;
   plan.n = np;
+  plan.tied = h->rs_tied_hint ? 1 : 0;
   for (int p = 0; p < np; p++) {
     plan.shift[p] = passes[p].shift;
     plan.bits[p] = passes[p].bits;

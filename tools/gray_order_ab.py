@@ -1,5 +1,8 @@
 import os, sys, time, torch
 sys.path.insert(0, "/root/repo")
+from sparsebase_amd import capi
+if os.environ.get("SBX_PROBE_LIB"):  # a variant built by tools/build_variant.py
+    capi.LIB_PATH = os.path.join("/root/repo", "sparsebase_amd", "lib", f"libsbx_{os.environ['SBX_PROBE_LIB']}.so")
 from sparsebase_amd import ops, synth
 rp, col = synth.rmat_symmetric_torch(22, 13, seed=1)
 n = rp.numel() - 1

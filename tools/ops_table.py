@@ -5,6 +5,9 @@ Prints JSON and a markdown table."""
 import json, os, sys, time, statistics, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sparsebase_amd import capi
+if os.environ.get("SBX_PROBE_LIB"):  # a variant built by tools/build_variant.py
+    capi.LIB_PATH = os.path.join(ROOT, "sparsebase_amd", "lib", f"libsbx_{os.environ['SBX_PROBE_LIB']}.so")
 from sparsebase_amd import ops, synth
 import orc
 ref = orc.Ref() if (orc.ref_available() and "--gpu-only" not in sys.argv) else None
