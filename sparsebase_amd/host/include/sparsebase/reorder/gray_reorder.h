@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -126,12 +127,24 @@ inline void GrayParallelFor(int64_t count, F f, int64_t grain = (int64_t)1 << 16
 #endif
 #endif
 
+// threads one sort asks for at most (SBX_GRAY_SORT_THREADS: 1 .. 64; default: 32 on hosts of 64 hardware threads and
+// more, else 16 — with the team's partitions a sort of 3 M records still gains from 16 -> 32 threads: 12.5 -> 9.3 ms for
+// 16-byte records on the 256-thread host of the GPU box; without them nothing beyond 16 did)
+inline unsigned GraySortThreadCap() {
+  static const unsigned cap = [] {
+    const char *e = std::getenv("SBX_GRAY_SORT_THREADS");
+    const long v = e ? std::atol(e) : (std::thread::hardware_concurrency() >= 64 ? 32 : 16);
+    return (unsigned)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }();
+  return cap;
+}
+
 // One budget of sort threads per process: the dense rows' sort, the degree sort and up to 16 section workers may each
 // ask for a parallel sort at the same time; together they get at most GrayThreadBudget::kMax extra threads (a lease
 // that finds the budget spent sorts on its caller's thread).
 class GrayThreadBudget {
  public:
-  static constexpr int kMax = 32;
+  static constexpr int kMax = 64;
   explicit GrayThreadBudget(unsigned want) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int cap = (int)std::min<unsigned>(hw ? hw : 1u, (unsigned)kMax);
@@ -162,13 +175,53 @@ class GrayThreadBudget {
 };
 
 #if defined(SBX_GRAY_SORT_REPLICA)
+// The partitions of the BIG ranges — the first of them walks the whole array on one thread, the next two a half each:
+// a third of a sort of 4 M heavily tied keys — are run by all the threads together, to the sequential routine's result:
+// std::__unguarded_partition(first, last, pivot) moves a left pointer up to the next element that is not less than the
+// pivot, a right pointer down to the next one that is not greater, swaps the two and goes on until the pointers meet.
+// Between two swaps the pointers only see elements no swap has touched, so the k-th stop of the left pointer is the k-th
+// position (from the left) whose ORIGINAL element is not less than the pivot, L[k], the k-th stop of the right pointer
+// the k-th such position from the right for "not greater", R[k]; the swaps are exactly the pairs (L[k], R[k]) with
+// L[k] < R[k], k = 0 .. K - 1 (L rises and R falls: a prefix), all 2 K positions distinct; and the routine returns where
+// the left pointer stops next: L[K] if that lies in front of R[K - 1], else R[K - 1] (which now holds an element that is
+// not less than the pivot).  The threads list both kinds of positions for a stretch of the range each, K is found by a
+// binary search over k, and the swaps are shared out.  (Elements equal to the pivot stop both pointers, as they do in
+// the library: with eleven distinct keys nearly every position is in both lists.)
 template <typename It, typename WrappedCompare>
 class GrayIntroSortPool {
  public:
-  GrayIntroSortPool(WrappedCompare comp, int64_t grain) : comp_(comp), grain_(grain) {}
+  // par_min: ranges of at least this many elements are partitioned by the whole team (0: never)
+  GrayIntroSortPool(WrappedCompare comp, int64_t grain, int64_t par_min = 0)
+      : comp_(comp), grain_(grain), par_min_(par_min > 0 ? std::max<int64_t>(par_min, 64) : 0) {}
   void Run(It first, It last, unsigned threads) {
-    Push(first, last, (long)std::__lg(last - first) * 2);
-    GrayRunWorkers(threads, [this](unsigned) { Work(); });
+    const long depth0 = (long)std::__lg(last - first) * 2;
+    if (par_min_ > 0 && last - first >= par_min_ && (uint64_t)(last - first) < ((uint64_t)1 << 32) && threads > 1) {
+      // the team: threads that could not be created are simply not part of it (a barrier counts on every member)
+      big_.push_back(Task{first, last, depth0});
+      std::vector<std::thread> team;
+      std::atomic<int> gate{0};  // 0: wait; > 0: the team's size; < 0: leave
+      unsigned made = 0;
+      for (unsigned w = 1; w < threads; w++) {
+        try {
+          team.emplace_back([this, &gate, w]() {
+            int size;
+            while ((size = gate.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+            if (size < 0 || (int)w >= size) return;
+            TeamMain(w, (unsigned)size);
+          });
+          made++;
+        } catch (const std::system_error &) {
+          break;  // (members are numbered 1 .. made: the ones created so far)
+        }
+      }
+      team_.reset(new TeamState(made + 1));
+      gate.store((int)made + 1, std::memory_order_release);
+      TeamMain(0u, made + 1);
+      for (auto &t : team) t.join();
+    } else {
+      Push(first, last, depth0);
+      GrayRunWorkers(threads, [this](unsigned) { Work(); });
+    }
     if (error_) std::rethrow_exception(error_);
     // std::__final_insertion_sort: one stable insertion sort over everything.  No element crosses a partition's cut (what
     // lies left of it does not compare greater than what lies right of it), so the pieces between the cuts the tasks were
@@ -217,6 +270,168 @@ class GrayIntroSortPool {
       last = cut;
     }
   }
+  // ---- the team's part: big ranges, one at a time, every partition by all members ----------------------------------
+  struct TeamState {
+    // a member's lists: offsets (from job_first) whose element stops the left / the right pointer.  The lists themselves
+    // are the members' own (locals of TeamMain: vectors whose headers shared cache lines made every push_back a
+    // coherence miss — 7 x slower than the sequential partition); here only where they are and how long
+    struct alignas(64) Lists {
+      const uint32_t *l = nullptr, *r = nullptr;
+      size_t nl = 0, nr = 0;
+    };
+    explicit TeamState(unsigned size_) : size(size_), lists(size_), pl(size_ + 1), pr(size_ + 1) {}
+    const unsigned size;
+    alignas(64) std::atomic<unsigned> arrived{0};
+    alignas(64) std::atomic<unsigned> phase{0};
+    std::vector<Lists> lists;
+    std::vector<uint64_t> pl, pr;  // running counts of the lists' lengths over the members
+    It job_first{}, job_last{}, pivot{};      // the range being partitioned: [job_first, job_last), pivot outside it
+    uint64_t swaps = 0;
+    bool done = false;
+    void Barrier() {  // sense-reversing; spins briefly, then yields (a team of at most 16 on a busy host)
+      const unsigned my = phase.load(std::memory_order_acquire);
+      if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == size) {
+        arrived.store(0, std::memory_order_relaxed);
+        phase.store(my + 1, std::memory_order_release);
+        return;
+      }
+      for (unsigned spin = 0; phase.load(std::memory_order_acquire) == my; spin++)
+        if (spin > 200) std::this_thread::yield();
+    }
+  };
+  uint32_t SelL(uint64_t k) const {  // L[k]
+    const TeamState &t = *team_;
+    const size_t w = (size_t)(std::upper_bound(t.pl.begin(), t.pl.end(), k) - t.pl.begin()) - 1;
+    return t.lists[w].l[(size_t)(k - t.pl[w])];
+  }
+  uint32_t SelR(uint64_t k) const {  // R[k]: the k-th from the right
+    const TeamState &t = *team_;
+    const uint64_t g = t.pr[t.size] - 1 - k;
+    const size_t w = (size_t)(std::upper_bound(t.pr.begin(), t.pr.end(), g) - t.pr.begin()) - 1;
+    return t.lists[w].r[(size_t)(g - t.pr[w])];
+  }
+  // member 0, between two barriers: the next big range, its pivot; false: none left
+  bool NextJob() {
+    TeamState &t = *team_;
+    while (!big_.empty()) {
+      Task b = big_.back();
+      big_.pop_back();
+      if (b.last - b.first < par_min_) {  // (std::__introsort_loop's own test — above 16 elements — is the task's)
+        Push(b.first, b.last, b.depth_limit);
+        continue;
+      }
+      if (b.depth_limit == 0) {
+        std::__partial_sort(b.first, b.last, b.last, comp_);
+        continue;
+      }
+      cur_ = b;
+      cur_.depth_limit--;
+      // std::__unguarded_partition_pivot
+      It mid = b.first + (b.last - b.first) / 2;
+      std::__move_median_to_first(b.first, b.first + 1, mid, b.last - 1, comp_);
+      t.job_first = b.first + 1, t.job_last = b.last, t.pivot = b.first;
+      return true;
+    }
+    return false;
+  }
+  void TeamMain(unsigned w, unsigned size) {
+    TeamState &t = *team_;
+    std::vector<uint32_t> l, r;
+    for (;;) {
+      if (w == 0) {
+        try {
+          t.done = !NextJob();
+        } catch (...) {
+          t.done = true;
+          std::lock_guard<std::mutex> g(mu_);
+          if (!error_) error_ = std::current_exception();
+        }
+      }
+      t.Barrier();
+      if (t.done) break;
+      // 1: the positions of this member's stretch that stop the left / the right pointer
+      const int64_t count = t.job_last - t.job_first;
+      const int64_t c0 = count * (int64_t)w / size, c1 = count * ((int64_t)w + 1) / size;
+      if (l.size() < (size_t)(c1 - c0) + 1) l.resize((size_t)(c1 - c0) + 1), r.resize((size_t)(c1 - c0) + 1);
+      size_t nl = 0, nr = 0;
+      try {
+        uint32_t *lp = l.data(), *rp = r.data();
+        for (int64_t i = c0; i < c1; i++) {  // (every position is stored, the counters move for the ones that stop a pointer)
+          It it = t.job_first + i;
+          lp[nl] = (uint32_t)i;
+          nl += comp_(it, t.pivot) ? 0u : 1u;
+          rp[nr] = (uint32_t)i;
+          nr += comp_(t.pivot, it) ? 0u : 1u;
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!error_) error_ = std::current_exception();
+      }
+      t.lists[w].l = l.data(), t.lists[w].nl = nl, t.lists[w].r = r.data(), t.lists[w].nr = nr;
+      t.Barrier();
+      // 2: how many swaps (member 0)
+      if (w == 0) {
+        t.pl[0] = t.pr[0] = 0;
+        for (unsigned m = 0; m < size; m++) t.pl[m + 1] = t.pl[m] + t.lists[m].nl, t.pr[m + 1] = t.pr[m] + t.lists[m].nr;
+        uint64_t lo = 0, hi = std::min(t.pl[size], t.pr[size]);  // K in [lo, hi]: L[k] < R[k] for k < K
+        while (lo < hi) {
+          const uint64_t mid = (lo + hi) / 2;
+          if (SelL(mid) < SelR(mid)) lo = mid + 1;
+          else hi = mid;
+        }
+        t.swaps = lo;
+      }
+      t.Barrier();
+      // 3: the swaps, shared out
+      {
+        const uint64_t K = t.swaps, k0 = K * w / size, k1 = K * ((uint64_t)w + 1) / size;
+        if (k0 < k1) {
+          // cursors instead of a search per swap: L[k] walks its lists upwards, R[k] its lists downwards
+          size_t lw = (size_t)(std::upper_bound(t.pl.begin(), t.pl.end(), k0) - t.pl.begin()) - 1;
+          size_t li = (size_t)(k0 - t.pl[lw]);
+          const uint64_t g0 = t.pr[size] - 1 - k0;
+          size_t rw = (size_t)(std::upper_bound(t.pr.begin(), t.pr.end(), g0) - t.pr.begin()) - 1;
+          size_t ri = (size_t)(g0 - t.pr[rw]);
+          for (uint64_t k = k0; k < k1; k++) {
+            while (li >= t.lists[lw].nl) lw++, li = 0;
+            std::iter_swap(t.job_first + t.lists[lw].l[li], t.job_first + t.lists[rw].r[ri]);
+            li++;
+            if (k + 1 < k1) {
+              while (ri == 0) {
+                rw--;
+                ri = t.lists[rw].nr;
+              }
+              ri--;
+            }
+          }
+        }
+      }
+      t.Barrier();
+      if (w == 0) {
+        const uint64_t K = t.swaps;
+        // where the left pointer stops next (the median-of-three pivot guarantees both lists are non-empty)
+        uint32_t at;
+        if (K < t.pl[size] && (K == 0 || SelL(K) < SelR(K - 1))) at = SelL(K);
+        else at = SelR(K - 1);
+        It cut = t.job_first + at;
+        {
+          std::lock_guard<std::mutex> g(mu_);
+          cuts_.push_back(cut);
+        }
+        // std::__introsort_loop: the right part is the recursive call's, the left part the loop's next round
+        big_.push_back(Task{cut, cur_.last, cur_.depth_limit});
+        big_.push_back(Task{cur_.first, cut, cur_.depth_limit});
+      }
+    }
+    // the ranges below par_min are in the queue: the members become the pool's workers
+    if (w == 0 && pending_.load() == 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      done_ = true;
+      cv_.notify_all();
+    }
+    Work();
+  }
+
   void Work() {
     for (;;) {
       Task t;
@@ -241,7 +456,10 @@ class GrayIntroSortPool {
     }
   }
   WrappedCompare comp_;
-  const int64_t grain_;
+  const int64_t grain_, par_min_;
+  std::unique_ptr<TeamState> team_;
+  std::vector<Task> big_;  // member 0's: ranges still to be partitioned by the team
+  Task cur_{};
   std::atomic<int64_t> pending_{0};
   std::mutex mu_;
   std::condition_variable cv_;
@@ -268,7 +486,7 @@ inline bool GraySortReplicaAgrees() {
       std::sort(a.begin(), a.end(), by_key);
       {
         auto w = __gnu_cxx::__ops::__iter_comp_iter(by_key);
-        GrayIntroSortPool<std::vector<uint32_t>::iterator, decltype(w)> pool(w, 4096);
+        GrayIntroSortPool<std::vector<uint32_t>::iterator, decltype(w)> pool(w, 4096, 20000);
         pool.Run(b.begin(), b.end(), 4);
       }
       if (a != b) return false;
@@ -283,7 +501,7 @@ inline bool GraySortReplicaAgrees() {
       std::sort(c.begin(), c.end(), desc);
       {
         auto w = __gnu_cxx::__ops::__iter_comp_iter(desc);
-        GrayIntroSortPool<typename std::vector<Rec>::iterator, decltype(w)> pool(w, 4096);
+        GrayIntroSortPool<typename std::vector<Rec>::iterator, decltype(w)> pool(w, 4096, 20000);
         pool.Run(d.begin(), d.end(), 4);
       }
       for (size_t i = 0; i < count; i++)
@@ -305,15 +523,16 @@ inline bool GraySortReplicaAgrees() {
 }
 #endif
 
-/// grain: ranges up to this many elements are sorted by the calling task (0: chosen from the size and the threads)
+/// grain: ranges up to this many elements are sorted by the calling task (0: chosen from the size and the threads);
+/// par_min: ranges of at least this many elements are partitioned by all threads together (0: 2^18; < 0: never)
 template <typename It, typename Compare>
-inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0, int64_t grain = 0) {
+inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0, int64_t grain = 0, int64_t par_min = 0) {
 #if defined(SBX_GRAY_SORT_REPLICA)
   const int64_t count = last - first;
   const bool budgeted = threads == 0;  // (an explicit thread count — the tests — is taken as given)
   if (threads == 0) {
     const unsigned hw = std::thread::hardware_concurrency();
-    threads = std::min<unsigned>(hw ? hw : 1u, 16u);
+    threads = std::min<unsigned>(hw ? hw : 1u, GraySortThreadCap());
   }
   if (threads <= 1 || count <= std::max<int64_t>(grain, budgeted ? ((int64_t)1 << 15) : 1) || !GraySortReplicaAgrees()) {
     std::sort(first, last, comp);
@@ -327,10 +546,11 @@ inline void GrayIntroSort(It first, It last, Compare comp, unsigned threads = 0,
     return;
   }
   auto wrapped = __gnu_cxx::__ops::__iter_comp_iter(comp);
-  GrayIntroSortPool<It, decltype(wrapped)> pool(wrapped, grain);
+  if (par_min == 0) par_min = (int64_t)1 << 18;
+  GrayIntroSortPool<It, decltype(wrapped)> pool(wrapped, grain, par_min < 0 ? 0 : std::max<int64_t>(par_min, grain));
   pool.Run(first, last, threads);
 #else
-  (void)threads, (void)grain;
+  (void)threads, (void)grain, (void)par_min;
   std::sort(first, last, comp);
 #endif
 }

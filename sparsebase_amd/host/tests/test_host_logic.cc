@@ -264,17 +264,19 @@ TEST(GraySort, ParallelReplicaOfStdSort) {
     if (round % 11 == 0) std::reverse(packed.begin(), packed.end());
     std::vector<uint32_t> expect = packed;
     std::sort(expect.begin(), expect.end(), by_degree);
-    reorder::detail::GrayIntroSort(packed.begin(), packed.end(), by_degree, threads, grain);
+    // (par_min: every third round the ranges above a few thousand elements are partitioned by the whole team)
+    const int64_t par_min = round % 3 == 0 ? 200 + (int64_t)(rnd() % 20000) : (round % 3 == 1 ? -1 : 0);
+    reorder::detail::GrayIntroSort(packed.begin(), packed.end(), by_degree, threads, grain, par_min);
     differing += packed != expect;
     std::vector<row_key> pairs(count);
     for (size_t i = 0; i < count; i++) pairs[i] = row_key((int)i, (unsigned long)(rnd() % distinct));
     std::vector<row_key> expect_pairs = pairs;
     if (round % 2) {
       std::sort(expect_pairs.begin(), expect_pairs.end(), asc);
-      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), asc, threads, grain);
+      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), asc, threads, grain, par_min);
     } else {
       std::sort(expect_pairs.begin(), expect_pairs.end(), desc);
-      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), desc, threads, grain);
+      reorder::detail::GrayIntroSort(pairs.begin(), pairs.end(), desc, threads, grain, par_min);
     }
     differing += pairs != expect_pairs;
   }
@@ -290,11 +292,13 @@ TEST(GraySort, ParallelReplicaOfStdSort) {
     }
     auto less = [](uint32_t l, uint32_t r) -> bool { return l < r; };
     for (int64_t grain : {(int64_t)32, (int64_t)4096}) {
-      std::vector<uint32_t> work = killer;
-      killer_expect = killer;
-      std::sort(killer_expect.begin(), killer_expect.end(), less);
-      reorder::detail::GrayIntroSort(work.begin(), work.end(), less, 4, grain);
-      EXPECT_TRUE(work == killer_expect);
+      for (int64_t par_min : {(int64_t)-1, (int64_t)300}) {  // (300: the depth limit is reached inside the team's part)
+        std::vector<uint32_t> work = killer;
+        killer_expect = killer;
+        std::sort(killer_expect.begin(), killer_expect.end(), less);
+        reorder::detail::GrayIntroSort(work.begin(), work.end(), less, 4, grain, par_min);
+        EXPECT_TRUE(work == killer_expect);
+      }
     }
   }
 }
