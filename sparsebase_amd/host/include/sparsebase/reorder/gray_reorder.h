@@ -32,6 +32,10 @@
 
 #include "sparsebase/reorder/reorderer.h"
 #include "sparsebase/utils/logger.h"
+#if defined(__linux__)
+#include <sched.h>
+#include <cstdio>
+#endif
 
 namespace sparsebase::reorder {
 
@@ -61,6 +65,77 @@ class GrayBuffer {
  private:
   std::unique_ptr<T[]> p_;
   size_t n_ = 0;
+};
+
+// While one of these lives, the calling thread — and every thread created under it, which inherit its mask and are placed
+// inside it from the start — stays on the NUMA node it is running on; the destructor gives the thread its mask back.
+// The ordering stage's threads share their arrays, barrier words and lists: on the GPU box's host (2 sockets x 64 cores)
+// a sort of 3 M records takes 9.4 ms spread over both sockets and 7.2 ms inside one (taskset), and one call in three or four
+// was an outlier of +7 ... +18 ms.  (Setting the mask of threads AFTER their creation was tried first and was much worse:
+// 32 threads restricted one by one start out stacked on a few CPUs and their spin barriers fight for them — 83 ms for a
+// 9 ms sort.)  Linux only; SBX_GRAY_SORT_PIN=0, a single node, a mask that is already inside one node, or any call that
+// fails: nothing happens.
+class GrayNodeScope {
+ public:
+  GrayNodeScope() {
+#if defined(__linux__)
+    const char *e = std::getenv("SBX_GRAY_SORT_PIN");
+    if (e && std::atoi(e) == 0) return;
+    cpu_set_t cur;
+    CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return;
+    for (int node = 0; node < 64; node++) {
+      char path[96];
+      std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+      FILE *f = std::fopen(path, "r");
+      if (!f) break;
+      char buf[4096];
+      const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+      std::fclose(f);
+      buf[got] = 0;
+      cpu_set_t m;
+      CPU_ZERO(&m);
+      bool mine = false;
+      for (const char *p = buf; *p;) {  // "0-63,128-191"
+        char *end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+          b = std::strtol(p + 1, &end, 10);
+          p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+          if (c >= 0) {
+            mine |= c == cpu;
+            if (CPU_ISSET((int)c, &cur)) CPU_SET((int)c, &m);
+          }
+        while (*p == ',' || *p == '\n' || *p == ' ') p++;
+      }
+      if (!mine) continue;
+      // (a sliver of a node is worse than the whole machine; a mask that already lies inside the node needs nothing)
+      if (CPU_COUNT(&m) < 8 || CPU_EQUAL(&m, &cur)) return;
+      if (sched_setaffinity(0, sizeof(m), &m) == 0) saved_ = cur, restore_ = true;
+      return;
+    }
+#endif
+  }
+  ~GrayNodeScope() {
+#if defined(__linux__)
+    if (restore_) (void)sched_setaffinity(0, sizeof(saved_), &saved_);
+#endif
+  }
+  GrayNodeScope(const GrayNodeScope &) = delete;
+  GrayNodeScope &operator=(const GrayNodeScope &) = delete;
+
+ private:
+#if defined(__linux__)
+  cpu_set_t saved_;
+#endif
+  bool restore_ = false;
 };
 
 // job(w) for w in [0, workers): worker 0 is the calling thread; a thread the system refuses to create (resource limits
@@ -198,6 +273,7 @@ class GrayIntroSortPool {
     if (par_min_ > 0 && last - first >= par_min_ && (uint64_t)(last - first) < ((uint64_t)1 << 32) && threads > 1) {
       // the team: threads that could not be created are simply not part of it (a barrier counts on every member)
       big_.push_back(Task{first, last, depth0});
+      whole_last_ = last;
       std::vector<std::thread> team;
       std::atomic<int> gate{0};  // 0: wait; > 0: the team's size; < 0: leave
       unsigned made = 0;
@@ -226,17 +302,11 @@ class GrayIntroSortPool {
     // std::__final_insertion_sort: one stable insertion sort over everything.  No element crosses a partition's cut (what
     // lies left of it does not compare greater than what lies right of it), so the pieces between the cuts the tasks were
     // split at are insertion-sorted on their own, concurrently, to the same result.
+    if (insertion_done_) return;  // (the team went on to it itself: one set of threads per sort, not two)
     cuts_.push_back(last);
     std::sort(cuts_.begin(), cuts_.end());
-    std::atomic<size_t> next{0};
-    GrayRunWorkers(threads, [this, &next](unsigned) {
-      try {
-        for (size_t k = next++; k + 1 < cuts_.size(); k = next++) std::__insertion_sort(cuts_[k], cuts_[k + 1], comp_);
-      } catch (...) {
-        std::lock_guard<std::mutex> g(mu_);
-        if (!error_) error_ = std::current_exception();
-      }
-    });
+    ins_next_ = 0;
+    GrayRunWorkers(threads, [this](unsigned) { InsertionPieces(); });
     if (error_) std::rethrow_exception(error_);
   }
 
@@ -245,6 +315,14 @@ class GrayIntroSortPool {
     It first, last;
     long depth_limit;
   };
+  void InsertionPieces() {
+    try {
+      for (size_t k = ins_next_++; k + 1 < cuts_.size(); k = ins_next_++) std::__insertion_sort(cuts_[k], cuts_[k + 1], comp_);
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu_);
+      if (!error_) error_ = std::current_exception();
+    }
+  }
   void Push(It first, It last, long depth_limit) {
     pending_++;
     {
@@ -336,7 +414,7 @@ class GrayIntroSortPool {
   }
   void TeamMain(unsigned w, unsigned size) {
     TeamState &t = *team_;
-    std::vector<uint32_t> l, r;
+    GrayBuffer<uint32_t> l, r;  // (not zero-filled: every entry that is read was written by the scan below)
     for (;;) {
       if (w == 0) {
         try {
@@ -352,7 +430,7 @@ class GrayIntroSortPool {
       // 1: the positions of this member's stretch that stop the left / the right pointer
       const int64_t count = t.job_last - t.job_first;
       const int64_t c0 = count * (int64_t)w / size, c1 = count * ((int64_t)w + 1) / size;
-      if (l.size() < (size_t)(c1 - c0) + 1) l.resize((size_t)(c1 - c0) + 1), r.resize((size_t)(c1 - c0) + 1);
+      if (l.size() < (size_t)(c1 - c0) + 1) l.reset((size_t)(c1 - c0) + 1), r.reset((size_t)(c1 - c0) + 1);
       size_t nl = 0, nr = 0;
       try {
         uint32_t *lp = l.data(), *rp = r.data();
@@ -430,6 +508,16 @@ class GrayIntroSortPool {
       cv_.notify_all();
     }
     Work();
+    // ... and go on to the closing insertion sort (Run): the pieces between the cuts, shared out
+    t.Barrier();
+    if (w == 0) {
+      cuts_.push_back(whole_last_);
+      std::sort(cuts_.begin(), cuts_.end());
+      ins_next_ = 0;
+      insertion_done_ = true;
+    }
+    t.Barrier();
+    InsertionPieces();
   }
 
   void Work() {
@@ -460,6 +548,9 @@ class GrayIntroSortPool {
   std::unique_ptr<TeamState> team_;
   std::vector<Task> big_;  // member 0's: ranges still to be partitioned by the team
   Task cur_{};
+  It whole_last_{};
+  std::atomic<size_t> ins_next_{0};
+  bool insertion_done_ = false;
   std::atomic<int64_t> pending_{0};
   std::mutex mu_;
   std::condition_variable cv_;
@@ -649,6 +740,7 @@ class GrayReorder : public Reorderer<IDType> {
       ~HostStageTimer() { last_stage_ms()[2] = std::chrono::duration<double, std::milli>(clock::now() - t).count(); }
     } host_stage_timer{t_host};
     // ---- host ordering stage (see header comment)
+    detail::GrayNodeScope on_one_node;  // (until the stage returns, by whichever way)
     const int group_size = params->sparse_density_group_size;
     // sparse / dense split in id order (gray_reorder.cc:138-170): counted per piece, then written at the pieces' offsets
     detail::GrayBuffer<IDType> sparse_rows, dense_rows;
@@ -790,6 +882,14 @@ class GrayReorder : public Reorderer<IDType> {
         }
         if (i == ns - 1) flush(ns);
       }
+      // Threads of the sections' sorts: shared out by size BEFORE any of them starts (left to the budget's first come,
+      // first served, small sections — whose records are packed sooner — can take the threads of the section of a million
+      // rows).
+      int64_t big_rows = 0;
+      for (const Section &sc : sections)
+        if (sc.end - sc.start >= ((int64_t)1 << 18)) big_rows += sc.end - sc.start;
+      const unsigned hw_all = std::thread::hardware_concurrency();
+      const unsigned share_total = std::min<unsigned>(hw_all ? hw_all : 1u, 2u * detail::GraySortThreadCap());
       auto sort_section = [&](const Section &sc) {
         detail::GrayBuffer<row_grey_pair> section((size_t)(sc.end - sc.start));
         detail::GrayParallelFor(sc.end - sc.start, [&](int64_t a0, int64_t a1) {  // (one piece below 64 K rows)
@@ -797,7 +897,10 @@ class GrayReorder : public Reorderer<IDType> {
             section[(size_t)a] = row_grey_pair{sparse_rows[(size_t)(sc.start + a)], (unsigned long)key[sparse_rows[(size_t)(sc.start + a)]]};
         });
         // (a section of a million rows — the rows of one entry of a power-law matrix — is the pool's longest job)
-        const unsigned th = sc.end - sc.start >= ((int64_t)1 << 18) ? 0u : 1u;  // (1: plain std::sort)
+        unsigned th = 1u;  // (1: plain std::sort)
+        if (sc.end - sc.start >= ((int64_t)1 << 18))
+          th = std::max<unsigned>(2u, std::min<unsigned>(detail::GraySortThreadCap(),
+                                                         (unsigned)((int64_t)share_total * (sc.end - sc.start) / big_rows)));
         if (!sc.descending) detail::GrayIntroSort(section.begin(), section.end(), asc_comparator, th);
         else detail::GrayIntroSort(section.begin(), section.end(), desc_comparator, th);
         detail::GrayParallelFor(sc.end - sc.start, [&](int64_t a0, int64_t a1) {

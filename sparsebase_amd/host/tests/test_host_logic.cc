@@ -242,6 +242,34 @@ TEST(GraySort, ReplicaSelfCheckPassesOnThisLibrary) {
   EXPECT_TRUE(again.threads() >= 1);
 }
 
+#if defined(__linux__)
+TEST(GraySort, NodeScopeGivesTheCallersMaskBack) {
+  // the ordering stage keeps its threads on the caller's NUMA node by narrowing the calling thread's affinity mask for the
+  // stage's duration (threads created meanwhile inherit it): whatever it did, the caller has its own mask afterwards
+  cpu_set_t before, during, after;
+  CPU_ZERO(&before);
+  CPU_ZERO(&during);
+  CPU_ZERO(&after);
+  EXPECT_EQ(sched_getaffinity(0, sizeof(before), &before), 0);
+  {
+    reorder::detail::GrayNodeScope scope;
+    EXPECT_EQ(sched_getaffinity(0, sizeof(during), &during), 0);
+    EXPECT_TRUE(CPU_COUNT(&during) >= 1 && CPU_COUNT(&during) <= CPU_COUNT(&before));
+    for (int c = 0; c < CPU_SETSIZE; c++)
+      if (CPU_ISSET(c, &during)) EXPECT_TRUE(CPU_ISSET(c, &before));  // (never a CPU the caller could not use)
+    std::thread t([&]() {  // a thread created inside the scope starts with the narrowed mask
+      cpu_set_t child;
+      CPU_ZERO(&child);
+      EXPECT_EQ(sched_getaffinity(0, sizeof(child), &child), 0);
+      EXPECT_TRUE(CPU_EQUAL(&child, &during));
+    });
+    t.join();
+  }
+  EXPECT_EQ(sched_getaffinity(0, sizeof(after), &after), 0);
+  EXPECT_TRUE(CPU_EQUAL(&before, &after));
+}
+#endif
+
 TEST(GraySort, ParallelReplicaOfStdSort) {
   unsigned long long state = 88172645463325252ull;
   auto rnd = [&state]() {
