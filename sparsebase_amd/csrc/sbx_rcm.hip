@@ -109,6 +109,8 @@ struct RcmDev {
   // unordered sweeps, levels chained on the device (run_ubfs): the frontier that is current for the next kernel of the
   // chain, the unvisited edges, what that kernel is to be (UC_*), and how often the chain swapped the frontier bitmaps
   unsigned uc_off, uc_size, uc_level, uc_total, uc_mode, uc_flips, uc_small_ran, uc_done;
+  unsigned tie_walk_exit;  // where tie_walk left (0: it named the root; SBX_DEBUG_TIE_WALK=1 prints it)
+  unsigned tie_walk_arg;
   unsigned uc_head;  // a chain was begun on the device behind a sweep's head small-level run (k_ubfs_chain_from_small)
   unsigned long long uc_fe;
   long long uc_remaining;
@@ -2598,10 +2600,425 @@ __global__ __launch_bounds__(256) void k_ubfs_bottom_up(const X *__restrict__ rp
 // deepest level: smallest degree, then the vertices that have it — marked in the cone bitmap, listed (the list counter
 // is dv->nf), their number and smallest id.  A level of up to UB_TIES_SMALL vertices (the usual case: a handful) is one
 // workgroup's job; larger ones take three launches.
+// (agent-scope relaxed loads and stores: what the persistent kernels below exchange their words with)
+template <typename T>
+__device__ __forceinline__ T ur_load(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void ur_store(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr unsigned UB_TIES_SMALL = 8192;
+
+// ---- the whole tie-break in the candidates' workgroup, where the cone is small ------------------------------------
+// On the bench matrix the cones ARE small — sweep 1: |T_k| = 6, 6, 6, 8, ~1200 for k = 5 .. 1; sweep 2 (from a vertex of
+// degree 1: levels of 1, 1, 1, 1, 850, 622 K, 1.6 M, 43 K, 189, 2 vertices): 2, 2, 2, 2, 42, ~400, 1, 1, 1 — and the
+// persistent kernels spent 146 + 212 us per call on them: grid barriers level by level, a hand-over to the expansion
+// kernels where T_4's hubs own 2.4 M adjacency entries, the walk down scanning the root's 140 K entries on 64
+// workgroups, two or three round trips.  This routine does marking and walk in ONE workgroup, with the direction of
+// every step chosen by its cost:
+//   * the leading levels that hold ONE vertex (the path out of a peripheral root) are found first, walking down from the
+//     root (chain[k]): T_k of such a level is that vertex, whatever T_{k+1} owns, and under such a level every member of
+//     T_{k+1} hangs — w_{k+1} is simply the smallest id in T_{k+1}, so of the first level that holds more than one
+//     vertex only the SMALLEST member of its T is ever needed (no set, no limit on its size);
+//   * T_{k-1} from T_k: the members' adjacency entries are shared out flat over the threads (prefix sums of the degrees,
+//     a branch-free binary search per entry, eight entries in flight per thread), members are deduplicated through an
+//     LDS hash set;
+//   * w_k from w_{k-1}: either w_{k-1}'s adjacency is scanned for members of T_k (the hash set), or the members'
+//     adjacency for w_{k-1} — whichever owns fewer entries.
+// One workgroup gathers at one CU's rate: a step over 73 K entries (T_5's 42 hubs in the bench matrix's second sweep,
+// looking for the smallest level-4 neighbour) took it 124 us.  Such a step — more than TS_SINGLE entries, and of the
+// smallest-member kind — is handed to a grid (k_tie_heavy_min, enqueued behind this kernel either way: 6 us for the 73 K
+// entries), and k_tie_walk_resume, one workgroup again, takes the walk up from the state left in TieWalkState.
+// Anything beyond the limits (TS_CAP members in a level, TS_GATHER entries in an ordinary step, TS_EDGES in a handed-over
+// one or a scan of one vertex's entries, TS_LEVELS levels, a second step to hand over) and anything odd (an empty T_{k-1}, no
+// candidate under w_{k-1}: a pattern that is not symmetric) makes it LEAVE with nothing changed — the T_k live in the
+// scratch behind the candidates' list and in LDS, not in the cone bitmap — and the persistent kernels, which are enqueued
+// behind it either way and leave at once when it has named the root (dv->tie_done), take over.
+constexpr unsigned TS_CAP = 1024, TS_LEVELS = 64, TS_EDGES = 1u << 17, TS_HASH = 4096;
+constexpr unsigned TS_SINGLE = 1u << 13;  // entries of a smallest-member step the one workgroup still scans itself
+constexpr unsigned TS_GATHER = 1u << 14;  // entries of an ordinary marking step (visited word + level gathered per entry)
+struct TieWalkState {  // between k_ubfs_ties_small, k_tie_heavy_min and k_tie_walk_resume (device memory)
+  unsigned req;        // 1: the step k -> k - 1 is the grid's; anything else: nothing to resume
+  unsigned k, P, cursor, L, n_ties, begin, count, edges;
+  unsigned min_id;     // the grid's result (atomicMin)
+  unsigned chain[TS_LEVELS + 2], lvl_begin[TS_LEVELS + 2], lvl_count[TS_LEVELS + 2];
+};
+struct TieWalkLds {
+  unsigned pref[TS_CAP + 1];  // exclusive prefix of the members' degrees
+  unsigned mem[TS_CAP];       // the members of the level at hand
+  X start[TS_CAP];            // rp[member]
+  unsigned hash[TS_HASH];     // open addressing, 0xFFFFFFFF = empty
+  unsigned lvl_begin[TS_LEVELS + 2], lvl_count[TS_LEVELS + 2];  // T_k in the scratch list
+  unsigned chain[TS_LEVELS + 2];
+  unsigned red[16], red2[16];
+  unsigned new_count;
+};
+__device__ __forceinline__ bool tw_visited_at(const unsigned *__restrict__ vbits, const unsigned *__restrict__ dist, unsigned c,
+                                              unsigned k) {
+  return ((vbits[c >> 5] >> (c & 31)) & 1u) && dist[c] == k;
+}
+template <int THREADS>
+__device__ __forceinline__ unsigned tw_block_min(unsigned v, unsigned *red) {
+  v = sbx_wave_min(v);
+  if (sbx_lane() == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned m = 0xFFFFFFFFu;
+  for (int i = 0; i < THREADS / 64; i++) m = red[i] < m ? red[i] : m;
+  __syncthreads();
+  return m;
+}
+__device__ __forceinline__ unsigned tw_block_max(unsigned v, unsigned *red) {  // (1024 threads)
+  v = sbx_wave_max(v);
+  if (sbx_lane() == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned m = 0;
+  for (int i = 0; i < 16; i++) m = red[i] > m ? red[i] : m;
+  __syncthreads();
+  return m;
+}
+// members of list[begin, begin + count) into LDS with their degree prefix; returns the degree sum (same for all threads)
+__device__ __forceinline__ unsigned tw_load_members(TieWalkLds &t, const X *__restrict__ rp, const I *list, unsigned begin,
+                                                    unsigned count) {
+  unsigned d = 0;
+  if (threadIdx.x < count) {
+    const unsigned v = (unsigned)ur_load(&list[begin + threadIdx.x]);
+    const X s0 = rp[v];
+    t.mem[threadIdx.x] = v;
+    t.start[threadIdx.x] = s0;
+    d = (unsigned)(rp[v + 1] - s0);
+  }
+  unsigned total;
+  const unsigned ex = sbx_block_exclusive_sum<unsigned, 1024>(d, t.red, &total);
+  if (threadIdx.x < count) t.pref[threadIdx.x] = ex;
+  if (threadIdx.x == 0) t.pref[count] = total;
+  __syncthreads();
+  return total;
+}
+__device__ __forceinline__ void tw_hash_clear(TieWalkLds &t) {
+  for (unsigned i = threadIdx.x; i < TS_HASH; i += 1024) t.hash[i] = 0xFFFFFFFFu;
+  __syncthreads();
+}
+// true: v was not in the set (a set that is full — the caller stops inserting long before — takes nothing more)
+__device__ __forceinline__ bool tw_hash_insert(TieWalkLds &t, unsigned v) {
+  unsigned slot = (v * 2654435761u) >> 20;  // 12 bits
+  for (unsigned probes = 0; probes < TS_HASH; probes++) {
+    const unsigned old = atomicCAS(&t.hash[slot], 0xFFFFFFFFu, v);
+    if (old == 0xFFFFFFFFu) return true;
+    if (old == v) return false;
+    slot = (slot + 1) & (TS_HASH - 1);
+  }
+  return false;
+}
+__device__ __forceinline__ bool tw_hash_has(const TieWalkLds &t, unsigned v) {
+  unsigned slot = (v * 2654435761u) >> 20;
+  for (unsigned probes = 0; probes < TS_HASH; probes++) {
+    const unsigned cur = t.hash[slot];
+    if (cur == v) return true;
+    if (cur == 0xFFFFFFFFu) return false;
+    slot = (slot + 1) & (TS_HASH - 1);
+  }
+  return false;
+}
+// entry e of the members' concatenated adjacency lists: the index of its member (last j < count with pref[j] <= e).
+// (a fixed number of steps and no branch: eight of these per thread are in flight together)
+__device__ __forceinline__ unsigned tw_member_of(const unsigned *pref, unsigned count, unsigned e) {
+  unsigned lo = 0;
+#pragma unroll
+  for (unsigned step = TS_CAP / 2; step >= 1; step >>= 1) {
+    const unsigned probe = lo + step;
+    const unsigned at = probe < count ? probe : 0u;
+    lo = (probe < count && pref[at] <= e) ? probe : lo;
+  }
+  return lo;
+}
+// phase 0: from the candidates on; phase 1: behind the grid's step (k_tie_walk_resume).  Returns true when the next root
+// is in dv->root_next (dv->tie_done = 1).
+__device__ bool tie_walk(TieWalkLds &t, const X *__restrict__ rp, const X *__restrict__ col, const unsigned *__restrict__ vbits,
+                         const unsigned *__restrict__ dist, I *list, unsigned n_ties, unsigned levels, RcmDev *dv,
+                         TieWalkState *st, unsigned max_edges, unsigned max_cap, unsigned max_single, int phase) {
+  // (max_edges <= TS_EDGES, max_cap <= TS_CAP: the limits, lowered by the tests so that small graphs reach every exit)
+#define TW_LEAVE(code, arg)                                                               \
+  do {                                                                                    \
+    if (threadIdx.x == 0) dv->tie_walk_exit = (code), dv->tie_walk_arg = (unsigned)(arg); \
+    return false;                                                                         \
+  } while (0)
+  constexpr int TW_U = 8;  // entries in flight per thread
+  const unsigned single = max_edges < max_single ? max_edges : max_single;  // (max_single <= TS_SINGLE)
+  const unsigned gather = max_edges < TS_GATHER ? max_edges : TS_GATHER;
+  const unsigned root = dv->root;
+  unsigned L, P, cursor, k_from;
+  if (phase == 0) {
+    L = levels - 1;  // the deepest level
+    if (threadIdx.x == 0) st->req = 0;
+    if (levels < 2 || L > TS_LEVELS || n_ties > max_cap) TW_LEAVE(1, n_ties);
+    // ---- the leading levels of one vertex
+    if (threadIdx.x == 0) t.chain[0] = root;
+    __syncthreads();
+    P = 1;  // levels 0 .. P - 1 hold one vertex each: chain[]
+    for (unsigned k = 1; k <= L; k++) {
+      const unsigned u = t.chain[k - 1];
+      const X s0 = rp[u], e0 = rp[u + 1];
+      if ((uint64_t)(e0 - s0) > (uint64_t)single) break;
+      unsigned lo = 0xFFFFFFFFu, hi = 0;
+      for (X a = s0 + (X)threadIdx.x; a < e0; a += 1024) {
+        const unsigned c = (unsigned)col[a];
+        if (tw_visited_at(vbits, dist, c, k)) lo = c < lo ? c : lo, hi = c > hi ? c : hi;
+      }
+      lo = tw_block_min<1024>(lo, t.red);
+      hi = tw_block_max(hi, t.red2);
+      if (lo == 0xFFFFFFFFu || lo != hi) break;
+      if (threadIdx.x == 0) t.chain[k] = lo;
+      __syncthreads();
+      P = k + 1;
+    }
+    if (threadIdx.x == 0) t.lvl_begin[L] = 0, t.lvl_count[L] = n_ties;  // T_L = the candidates, list[0, n_ties)
+    __syncthreads();
+    cursor = n_ties;  // the scratch behind the candidates
+    k_from = L;
+  } else {
+    if (st->req != 1) return false;  // (nothing was handed over: the walk is finished or has left)
+    L = st->L, P = st->P, cursor = st->cursor;
+    const unsigned k = st->k, m = st->min_id;
+    for (unsigned i = threadIdx.x; i < TS_LEVELS + 2; i += 1024)
+      t.chain[i] = st->chain[i], t.lvl_begin[i] = st->lvl_begin[i], t.lvl_count[i] = st->lvl_count[i];
+    __syncthreads();
+    if (threadIdx.x == 0) st->req = 2;
+    if (m == 0xFFFFFFFFu) TW_LEAVE(7 | (k << 8), st->edges);
+    if (threadIdx.x == 0) {
+      ur_store(&list[cursor], (I)m);
+      t.lvl_begin[k - 1] = cursor, t.lvl_count[k - 1] = 1;
+    }
+    __syncthreads();
+    cursor += 1;
+    k_from = k - 1;
+  }
+  // ---- marking: T_{k-1} from T_k, k = L .. 2
+  for (unsigned k = k_from; k >= 2; k--) {
+    if (k - 1 < P) {
+      if (threadIdx.x == 0) {
+        ur_store(&list[cursor], (I)t.chain[k - 1]);
+        t.lvl_begin[k - 1] = cursor, t.lvl_count[k - 1] = 1;
+      }
+      __syncthreads();
+      cursor += 1;
+      continue;
+    }
+    const unsigned count = t.lvl_count[k];
+    const unsigned edges = tw_load_members(t, rp, list, t.lvl_begin[k], count);
+    // Under a level of one vertex only the SMALLEST member of T_{k-1} is ever asked for (w_{k-1}; T_{k-2} is that one
+    // vertex whatever T_{k-1} holds): no set, no limit on its size
+    const bool min_only = k - 2 < P;
+    if (min_only && edges > single) {
+      // the grid's step: the state goes to device memory, k_tie_heavy_min finds the smallest member, k_tie_walk_resume goes on
+      if (phase != 0 || edges > max_edges) TW_LEAVE(2 | (k << 8), edges);
+      for (unsigned i = threadIdx.x; i < TS_LEVELS + 2; i += 1024)
+        st->chain[i] = t.chain[i], st->lvl_begin[i] = t.lvl_begin[i], st->lvl_count[i] = t.lvl_count[i];
+      if (threadIdx.x == 0) {
+        st->k = k, st->P = P, st->cursor = cursor, st->L = L, st->n_ties = n_ties;
+        st->begin = t.lvl_begin[k], st->count = count, st->edges = edges, st->min_id = 0xFFFFFFFFu;
+        st->req = 1;
+        dv->tie_walk_exit = 8 | (k << 8), dv->tie_walk_arg = edges;  // (overwritten by whoever finishes or leaves)
+      }
+      return false;
+    }
+    if (edges > (min_only ? single : gather)) TW_LEAVE(3 | (k << 8), edges);
+    tw_hash_clear(t);
+    if (threadIdx.x == 0) t.new_count = 0;
+    __syncthreads();
+    unsigned my_min = 0xFFFFFFFFu;
+    for (unsigned e0 = threadIdx.x; e0 < edges; e0 += 1024 * TW_U) {
+      // (every search and every load is issued whatever the entry: under a condition each would be a block of its own and
+      // the eight would run one after the other; entries past the end read the last one and are dropped afterwards)
+      unsigned c[TW_U], vb[TW_U], dd[TW_U], jj[TW_U];
+#pragma unroll
+      for (int u = 0; u < TW_U; u++) {
+        const unsigned e = e0 + (unsigned)u * 1024u;
+        jj[u] = tw_member_of(t.pref, count, e < edges ? e : edges - 1u);
+      }
+#pragma unroll
+      for (int u = 0; u < TW_U; u++) {
+        const unsigned e = e0 + (unsigned)u * 1024u, ee = e < edges ? e : edges - 1u;
+        c[u] = (unsigned)col[t.start[jj[u]] + (X)(ee - t.pref[jj[u]])];
+      }
+#pragma unroll
+      for (int u = 0; u < TW_U; u++) vb[u] = vbits[c[u] >> 5];
+#pragma unroll
+      for (int u = 0; u < TW_U; u++) dd[u] = ((vb[u] >> (c[u] & 31)) & 1u) ? dist[c[u]] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int u = 0; u < TW_U; u++) {
+        if (dd[u] != k - 1 || e0 + (unsigned)u * 1024u >= edges) continue;
+        if (min_only) {
+          my_min = c[u] < my_min ? c[u] : my_min;
+        } else if (__hip_atomic_load(&t.new_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= max_cap &&
+                   tw_hash_insert(t, c[u])) {
+          // (the count is re-read every time: past the cap nothing is inserted any more, the set of 4096 never fills)
+          const unsigned pos = atomicAdd(&t.new_count, 1u);
+          if (pos < max_cap) ur_store(&list[cursor + pos], (I)c[u]);
+        }
+      }
+    }
+    if (min_only) {
+      const unsigned m = tw_block_min<1024>(my_min, t.red);
+      if (m == 0xFFFFFFFFu) TW_LEAVE(7 | (k << 8), edges);
+      if (threadIdx.x == 0) {
+        ur_store(&list[cursor], (I)m);
+        t.lvl_begin[k - 1] = cursor, t.lvl_count[k - 1] = 1;
+      }
+      __syncthreads();
+      cursor += 1;
+      continue;
+    }
+    __syncthreads();
+    const unsigned got = t.new_count;
+    if (got == 0 || got > max_cap) TW_LEAVE(4 | (k << 8), got);
+    if (threadIdx.x == 0) t.lvl_begin[k - 1] = cursor, t.lvl_count[k - 1] = got;
+    __syncthreads();
+    cursor += got;
+  }
+  // ---- the walk down: w_0 = root, w_k = the smallest id among the members of T_k adjacent to w_{k-1}
+  unsigned w = root;
+  for (unsigned k = 1; k <= L; k++) {
+    const unsigned count = t.lvl_count[k], begin = t.lvl_begin[k];
+    unsigned best = 0xFFFFFFFFu;
+    if (k - 1 < P) {  // (under a level of one vertex hangs the whole next level)
+      if (threadIdx.x < count) best = (unsigned)ur_load(&list[begin + threadIdx.x]);
+    } else {
+      const unsigned edges = tw_load_members(t, rp, list, begin, count);
+      const X ws = rp[w], we = rp[w + 1];
+      if ((uint64_t)(we - ws) <= (uint64_t)edges) {
+        if ((uint64_t)(we - ws) > (uint64_t)max_edges) TW_LEAVE(5 | (k << 8), we - ws);
+        tw_hash_clear(t);
+        if (threadIdx.x < count) (void)tw_hash_insert(t, t.mem[threadIdx.x]);
+        __syncthreads();
+        for (X a0 = ws + (X)threadIdx.x; a0 < we; a0 += (X)1024 * TW_U) {
+          unsigned c[TW_U], first[TW_U];
+#pragma unroll
+          for (int u = 0; u < TW_U; u++) {
+            const X a = a0 + (X)u * 1024;
+            c[u] = a < we ? (unsigned)col[a] : 0xFFFFFFFEu;  // (no vertex id: it is in no set)
+          }
+#pragma unroll
+          for (int u = 0; u < TW_U; u++) first[u] = t.hash[(c[u] * 2654435761u) >> 20];  // the first probe of all eight
+#pragma unroll
+          for (int u = 0; u < TW_U; u++) {
+            const bool hit = first[u] == c[u] || (first[u] != 0xFFFFFFFFu && tw_hash_has(t, c[u]));
+            if (hit) best = c[u] < best ? c[u] : best;
+          }
+        }
+      } else {
+        if (edges > max_edges) TW_LEAVE(6 | (k << 8), edges);
+        for (unsigned e0 = threadIdx.x; e0 < edges; e0 += 1024 * TW_U) {
+          unsigned cc[TW_U], jj[TW_U];
+#pragma unroll
+          for (int u = 0; u < TW_U; u++) {
+            const unsigned e = e0 + (unsigned)u * 1024u;
+            jj[u] = tw_member_of(t.pref, count, e < edges ? e : edges - 1u);
+          }
+#pragma unroll
+          for (int u = 0; u < TW_U; u++) {
+            const unsigned e = e0 + (unsigned)u * 1024u, ee = e < edges ? e : edges - 1u;
+            cc[u] = (unsigned)col[t.start[jj[u]] + (X)(ee - t.pref[jj[u]])];
+          }
+#pragma unroll
+          for (int u = 0; u < TW_U; u++)
+            if (cc[u] == w && e0 + (unsigned)u * 1024u < edges) best = t.mem[jj[u]] < best ? t.mem[jj[u]] : best;
+        }
+      }
+    }
+    best = tw_block_min<1024>(best, t.red);
+    if (best == 0xFFFFFFFFu) TW_LEAVE(9 | (k << 8), count);
+    w = best;
+  }
+  if (threadIdx.x == 0) {
+    dv->root_next = w;
+    dv->root_pending = 1;
+    dv->tie_done = 1;
+    dv->tie_walk_exit = 0;
+  }
+  return true;
+#undef TW_LEAVE
+}
+
+// the step the one workgroup handed over: the smallest level-(k - 1) neighbour of T_k's members, st->min_id
+__global__ __launch_bounds__(256) void k_tie_heavy_min(const X *__restrict__ rp, const X *__restrict__ col,
+                                                       const unsigned *__restrict__ vbits, const unsigned *__restrict__ dist,
+                                                       const I *list, TieWalkState *st) {
+  if (st->req != 1) return;
+  __shared__ unsigned s_pref[TS_CAP + 1], s_red[4], s_scan[4];
+  __shared__ X s_start[TS_CAP];
+  const unsigned count = st->count, begin = st->begin, edges = st->edges, want = st->k - 1;
+  unsigned carry = 0;
+  for (unsigned base = 0; base < count; base += 256) {  // (count <= TS_CAP: four rounds at most)
+    const unsigned i = base + threadIdx.x;
+    unsigned d = 0;
+    if (i < count) {
+      const unsigned v = (unsigned)list[begin + i];
+      const X s0 = rp[v];
+      s_start[i] = s0;
+      d = (unsigned)(rp[v + 1] - s0);
+    }
+    unsigned total;
+    const unsigned ex = sbx_block_exclusive_sum<unsigned, 256>(d, s_scan, &total);
+    if (i < count) s_pref[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) s_pref[count] = carry;
+  __syncthreads();
+  constexpr int U = 4;
+  unsigned my_min = 0xFFFFFFFFu;
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned e0 = blockIdx.x * 256u + threadIdx.x; e0 < edges; e0 += stride * U) {
+    unsigned c[U], vb[U], jj[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = e0 + (unsigned)u * stride;
+      jj[u] = tw_member_of(s_pref, count, e < edges ? e : edges - 1u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = e0 + (unsigned)u * stride, ee = e < edges ? e : edges - 1u;
+      c[u] = (unsigned)col[s_start[jj[u]] + (X)(ee - s_pref[jj[u]])];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) vb[u] = vbits[c[u] >> 5];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (((vb[u] >> (c[u] & 31)) & 1u) && dist[c[u]] == want && e0 + (unsigned)u * stride < edges)
+        my_min = c[u] < my_min ? c[u] : my_min;
+  }
+  const unsigned m = tw_block_min<256>(my_min, s_red);
+  if (threadIdx.x == 0 && m != 0xFFFFFFFFu) atomicMin(&st->min_id, m);
+}
+
+static bool rcm_tie_walk() {  // SBX_RCM_TIE_WALK=0: every tie-break through the persistent kernels (tests, A/B)
+  static const bool on = !(sbx_env_test("SBX_RCM_TIE_WALK") && atoi(sbx_env_test("SBX_RCM_TIE_WALK")) == 0);
+  return on;
+}
+// SBX_DEBUG_TIE_EDGES / SBX_DEBUG_TIE_CAP: the walk's limits, lowered (tests: small graphs then leave it at every exit)
+static unsigned tie_walk_edges() {
+  static const unsigned v = sbx_env_test("SBX_DEBUG_TIE_EDGES") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_TIE_EDGES")) : TS_EDGES;
+  return v < TS_EDGES ? v : TS_EDGES;
+}
+static unsigned tie_walk_single() {  // SBX_DEBUG_TIE_SINGLE: entries above which a smallest-member step goes to the grid
+  static const unsigned v = sbx_env_test("SBX_DEBUG_TIE_SINGLE") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_TIE_SINGLE")) : TS_SINGLE;
+  return v < TS_SINGLE ? v : TS_SINGLE;
+}
+static unsigned tie_walk_cap() {
+  static const unsigned v = sbx_env_test("SBX_DEBUG_TIE_CAP") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_TIE_CAP")) : TS_CAP;
+  return v < TS_CAP ? v : TS_CAP;
+}
+
+// walk: 0, or the sweep's number of levels — the workgroup then goes on to tie_walk (col / vbits / dist are its inputs)
 __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const X *__restrict__ rp, const I *__restrict__ level,
                                                           unsigned count, unsigned *__restrict__ cone,
-                                                          I *__restrict__ list, RcmDev *__restrict__ dv) {
+                                                          I *__restrict__ list, RcmDev *__restrict__ dv,
+                                                          const X *__restrict__ col, const unsigned *__restrict__ vbits,
+                                                          const unsigned *__restrict__ dist, unsigned walk,
+                                                          unsigned walk_edges, unsigned walk_cap, unsigned walk_single,
+                                                          TieWalkState *st) {
+  __shared__ TieWalkLds s_walk;
   __shared__ unsigned s_red[16], s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   unsigned best = 0xFFFFFFFFu;
@@ -2646,6 +3063,20 @@ __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const X *__restrict__ 
       dv->root_pending = 1;
     }
   }
+  __syncthreads();
+  if (walk >= 2) {
+    if (s_cnt > 1) (void)tie_walk(s_walk, rp, col, vbits, dist, list, s_cnt, walk, dv, st, walk_edges, walk_cap, walk_single, 0);
+    else if (threadIdx.x == 0) st->req = 0;  // (one candidate: nothing for the kernels behind)
+  }
+}
+// the walk taken up behind the grid's step (k_tie_heavy_min); leaves at once unless a step was handed over
+__global__ __launch_bounds__(1024) void k_tie_walk_resume(const X *__restrict__ rp, const X *__restrict__ col,
+                                                          const unsigned *__restrict__ vbits, const unsigned *__restrict__ dist,
+                                                          I *list, RcmDev *dv, TieWalkState *st, unsigned walk_edges,
+                                                          unsigned walk_cap, unsigned walk_single) {
+  __shared__ TieWalkLds s_walk;
+  if (st->req != 1) return;
+  (void)tie_walk(s_walk, rp, col, vbits, dist, list, 0u, 0u, dv, st, walk_edges, walk_cap, walk_single, 1);
 }
 __global__ void k_ubfs_ties_init(RcmDev *__restrict__ dv) {
   dv->tie_done = 0;
@@ -2848,14 +3279,6 @@ __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
 #endif
 constexpr unsigned UR_HEAVY = SBX_UR_HEAVY;  // frontier vertices above this degree are scanned by the whole grid
 
-template <typename T>
-__device__ __forceinline__ T ur_load(const T *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ void ur_store(T *p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ bool ur_barrier(RcmDev *dv, unsigned &epoch) {
   epoch++;
   return gb_wait(dv, &dv->ur_bar, epoch * gridDim.x);
@@ -3478,7 +3901,19 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
   I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level after level, one growing list
   // (the cone bitmap was cleared by the sweep's start kernel)
   if (r.last_size <= UB_TIES_SMALL) {
-    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_small, dim3(1), dim3(1024), b.rp, last, r.last_size, cone, list, b.dv);
+    // (the candidates' workgroup goes on to the whole tie-break where the cone is small: tie_walk; the two kernels behind
+    // it leave at once unless it handed a step over to them)
+    TieWalkState *tw = nullptr;
+    SBX_TRY(sbx_salloc(h, 1, &tw));
+    SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_small, dim3(1), dim3(1024), b.rp, last, r.last_size, cone, list, b.dv, b.col,
+                (const unsigned *)b.vbits, (const unsigned *)b.lpos, rcm_tie_walk() ? r.levels : 0u, tie_walk_edges(),
+                tie_walk_cap(), tie_walk_single(), tw);
+    if (rcm_tie_walk()) {
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_heavy_min, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
+                  (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const I *)list, tw);
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_walk_resume, dim3(1), dim3(1024), b.rp, b.col, (const unsigned *)b.vbits,
+                  (const unsigned *)b.lpos, list, b.dv, tw, tie_walk_edges(), tie_walk_cap(), tie_walk_single());
+    }
   } else {
     const unsigned g = sbx_grid_for(r.last_size, 256, 1024);
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_init, dim3(1), dim3(1), b.dv);
@@ -3527,6 +3962,10 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
       *aborted = true;
       return SBX_OK;
     }
+    static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
+    if (tw_dbg && k == r.levels - 1)  // (exits: see TW_LEAVE in tie_walk; 0: it named the root)
+      fprintf(stderr, "[rcm tie walk] levels %u, candidates %u: exit %u at level %u (%u)\n", r.levels, hd.tie_count,
+              hd.tie_walk_exit & 0xFFu, hd.tie_walk_exit >> 8, hd.tie_walk_arg);
     if (hd.cone_status == UR_DONE || hd.unsym) return SBX_OK;
     k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};

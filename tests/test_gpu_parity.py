@@ -1485,7 +1485,8 @@ def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
 
 
 @pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere", "bottom_up_early",
-                                  "no_chain", "chain_of_one", "chain_tail_gives_up", "in_line", "no_head_chain"])
+                                  "no_chain", "chain_of_one", "chain_tail_gives_up", "in_line", "no_head_chain", "no_tie_walk",
+                                  "tie_walk_tight", "tie_walk_few_members", "tie_walk_hands_over"])
 def test_rcm_sweep_variants_in_a_child(mode):
     """The switches of the RCM's pseudo-peripheral sweeps are read once per process, hence the children:
     SBX_DEBUG_GB_SPINS=0 makes every grid barrier of the persistent kernels give up at once (what a barrier does when its
@@ -1500,7 +1501,12 @@ def test_rcm_sweep_variants_in_a_child(mode):
     at the tail of a chain gives up at its first grid barrier, after claiming vertices and before it could report that
     it ran — the sweep must be thrown away all the same; SBX_RCM_HEAD_CHAIN=0: the call's first sweep reads back behind
     its head small-level run instead of beginning its chain on the device (the scale-19 graph is the one above the 2^17
-    vertices the head chain asks for: every other mode runs WITH it there); "in_line": no side streams inside the call (SBX_RCM_CC_OVERLAP=0,
+    vertices the head chain asks for: every other mode runs WITH it there); SBX_RCM_TIE_WALK=0: every tie-break through the persistent cone kernels (by
+    default the candidates' workgroup does marking and walk itself where the cone is small: k_ubfs_ties_small / tie_walk);
+    SBX_DEBUG_TIE_EDGES=40 / SBX_DEBUG_TIE_CAP=3: that walk's limits lowered until these graphs leave it at every one of
+    its exits — after the leading levels, in the middle of the marking, in the walk down — and the persistent kernels must
+    find everything as the candidates' kernel alone leaves it; SBX_DEBUG_TIE_SINGLE=8: every smallest-member step of more
+    than eight entries is handed to the grid kernel and taken up again by k_tie_walk_resume; "in_line": no side streams inside the call (SBX_RCM_CC_OVERLAP=0,
     SBX_RCM_SPLIT_EXPAND=0, SBX_RCM_OVERLAP=0: the other components are labelled, a wide frontier's light rows expanded
     and the degree ranks built on the caller's stream — what a call under the handle's profiler does)."""
     import subprocess
@@ -1529,6 +1535,8 @@ def test_rcm_sweep_variants_in_a_child(mode):
              "bottom_up_early": {"SBX_DEBUG_BU_RATIO": "0.3", "SBX_RCM_UNORDERED": "0"},
              "no_chain": {"SBX_RCM_UBFS_CHAIN": "0"}, "chain_of_one": {"SBX_RCM_UBFS_CHAIN": "1"},
              "chain_tail_gives_up": {"SBX_DEBUG_CHAIN_TAIL_ABORT": "1"}, "no_head_chain": {"SBX_RCM_HEAD_CHAIN": "0"},
+             "no_tie_walk": {"SBX_RCM_TIE_WALK": "0"}, "tie_walk_tight": {"SBX_DEBUG_TIE_EDGES": "40"},
+             "tie_walk_few_members": {"SBX_DEBUG_TIE_CAP": "3"}, "tie_walk_hands_over": {"SBX_DEBUG_TIE_SINGLE": "8"},
              "in_line": {"SBX_RCM_CC_OVERLAP": "0", "SBX_RCM_SPLIT_EXPAND": "0", "SBX_RCM_OVERLAP": "0"}}[mode]
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
                        timeout=900)
