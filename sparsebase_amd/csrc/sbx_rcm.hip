@@ -3913,6 +3913,17 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
                   (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const I *)list, tw);
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_walk_resume, dim3(1), dim3(1024), b.rp, b.col, (const unsigned *)b.vbits,
                   (const unsigned *)b.lpos, list, b.dv, tw, tie_walk_edges(), tie_walk_cap(), tie_walk_single());
+      // Usually that was the whole tie-break: the host looks before it enqueues the persistent kernels (a round trip more
+      // where the walk left — rare — against two launches that find nothing to do in every other tie-break)
+      SBX_LAUNCH_CHECK(h);
+      SBX_TRY(bfs_first_launch(b, 40));
+      RcmDev hw;
+      SBX_TRY(sbx_readback(h, &hw, b.dv, sizeof(RcmDev)));
+      static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
+      if (tw_dbg)  // (exits: see TW_LEAVE in tie_walk; 0: it named the root)
+        fprintf(stderr, "[rcm tie walk] levels %u, candidates %u: exit %u at level %u (%u)\n", r.levels, hw.tie_count,
+                hw.tie_walk_exit & 0xFFu, hw.tie_walk_exit >> 8, hw.tie_walk_arg);
+      if (hw.tie_done) return SBX_OK;
     }
   } else {
     const unsigned g = sbx_grid_for(r.last_size, 256, 1024);
@@ -3962,10 +3973,6 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
       *aborted = true;
       return SBX_OK;
     }
-    static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
-    if (tw_dbg && k == r.levels - 1)  // (exits: see TW_LEAVE in tie_walk; 0: it named the root)
-      fprintf(stderr, "[rcm tie walk] levels %u, candidates %u: exit %u at level %u (%u)\n", r.levels, hd.tie_count,
-              hd.tie_walk_exit & 0xFFu, hd.tie_walk_exit >> 8, hd.tie_walk_arg);
     if (hd.cone_status == UR_DONE || hd.unsym) return SBX_OK;
     k = hd.cone_k;  // its list is long: one level with the big kernels, then the persistent one again
     const UnorderedSweep us = {nullptr, cone, b.lpos, k - 1};
