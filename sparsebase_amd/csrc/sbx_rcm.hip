@@ -3916,7 +3916,9 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
       // Usually that was the whole tie-break: the host looks before it enqueues the persistent kernels (a round trip more
       // where the walk left — rare — against two launches that find nothing to do in every other tie-break)
       SBX_LAUNCH_CHECK(h);
-      SBX_TRY(bfs_first_launch(b, 40));
+      // (no bfs_first_launch here: the three kernels are over in tens of microseconds, the hook's enqueues — the other
+      // components' labelling, a dozen launches — would hold the read-back up with the caller's stream idle; the next
+      // sweep's first launch takes the hook along behind a whole chain of levels)
       RcmDev hw;
       SBX_TRY(sbx_readback(h, &hw, b.dv, sizeof(RcmDev)));
       static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
@@ -4354,6 +4356,9 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
     RcmDev last_read;
     b.side_stage = &cc_stage, b.side_event = h->aux_event[3], b.side_joined = &cc_joined;
     b.last_read = &last_read, b.last_read_joined = &last_read_joined;
+    // (a half per firing, behind any launch: both halves at one go behind a chain of big levels only — tried when the
+    // tie-breaks stopped being 80 us of persistent kernels to hide behind — looked better under the profiler, whose
+    // launches take 10 us of host time each, and cost 28 us on the wall clock: the side work simply started later)
     std::function<int()> enqueue_cc = [&]() -> int {
       SBX_TRY(enqueue_ranks());
       if (cc_stage >= 2) return SBX_OK;
@@ -4372,6 +4377,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
       h->stream = main_stream;
       return rc;
     };
+
     b.after_first_launch = &enqueue_cc;
     b.hook_wants_long_cover = false;  // (half a dozen launches per call)
     const int src = search_component(v0, (I)r0.count, true, sd0);
