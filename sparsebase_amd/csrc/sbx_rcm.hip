@@ -109,6 +109,11 @@ struct RcmDev {
   // unordered sweeps, levels chained on the device (run_ubfs): the frontier that is current for the next kernel of the
   // chain, the unvisited edges, what that kernel is to be (UC_*), and how often the chain swapped the frontier bitmaps
   unsigned uc_off, uc_size, uc_level, uc_total, uc_mode, uc_flips, uc_small_ran, uc_done;
+  // The sweep behind a tie walk is enqueued before the host has seen how the walk ended: its first kernels (the start
+  // kernel and the small-level kernel of either kind) leave at once while this is set and tie_done is not — nothing of the
+  // finished sweep is then touched and the persistent cone kernels can still take the tie-break over (ubfs_pick_root_slow).
+  // Set by k_ubfs_ties_small, cleared by a start kernel that goes ahead.
+  unsigned spec_guard;
   unsigned tie_walk_exit;  // where tie_walk left (0: it named the root; SBX_DEBUG_TIE_WALK=1 prints it)
   unsigned tie_walk_arg;
   unsigned uc_head;  // a chain was begun on the device behind a sweep's head small-level run (k_ubfs_chain_from_small)
@@ -556,6 +561,9 @@ struct StartClear {
   unsigned *c;
   unsigned long long nc;
 };
+// (see RcmDev::spec_guard; both words were written by kernels in front: the same answer in every workgroup)
+#define SBX_SPEC_GUARD_LEAVE(dv) \
+  if ((dv)->spec_guard && !(dv)->tie_done) return
 __device__ __forceinline__ bool start_clear_elect(const StartClear &sc, RcmDev *__restrict__ dv) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -576,7 +584,9 @@ __global__ __launch_bounds__(256) void k_bfs_start(const X *__restrict__ rp, uns
                                                    unsigned *__restrict__ fbits, unsigned *__restrict__ lpos,
                                                    unsigned *__restrict__ ppos, I *__restrict__ q,
                                                    RcmDev *__restrict__ dv, I fixed_root, StartClear sc) {
+  SBX_SPEC_GUARD_LEAVE(dv);
   if (!start_clear_elect(sc, dv)) return;
+  dv->spec_guard = 0;
   const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
   dv->root_pending = 0;
   dv->root = (unsigned)r;
@@ -1571,6 +1581,7 @@ __global__ __launch_bounds__(1024) void k_bfs_small_levels(const X *__restrict__
                                                            const uint32_t *__restrict__ dorder, unsigned off,
                                                            unsigned fsize, unsigned level, unsigned total,
                                                            RcmDev *dv) {
+  SBX_SPEC_GUARD_LEAVE(dv);  // (the start kernel in front left: so does this one)
   __shared__ uint64_t s_key[SL_CAP];
   __shared__ I s_front[SL_MAXF];
   __shared__ I s_start[SL_MAXF];          // rp[u] of every frontier vertex
@@ -2014,6 +2025,10 @@ struct BfsBuffers {
   // a deepest level, whose first big frontier is a thin one for the top-down kernels (the chain's launches would all
   // leave at once, ~35 us of empty launches; measured on the bench matrix, NOTES section 4.5-r6)
   bool head_chain;
+  // the tie-break in front of this sweep was left unverified (ubfs_pick_root): the sweep's first read-back says whether
+  // the walk named the root (tie_done) — if not, the sweep's first kernels have left (RcmDev::spec_guard), the sweep
+  // returns with *spec_failed set and the caller lets the persistent cone kernels finish the tie-break
+  bool *tie_unverified;
   // the labelling of the other components runs on a side stream (sbx_rcm_reorder); its counters live in *dv.  Once both
   // of its halves are enqueued (*side_stage >= 2) a Cuthill-McKee sweep joins that stream at its start — the work
   // finished long before — so that the sweep's own last read-back of *dv also delivers those counters (*last_read,
@@ -2044,7 +2059,8 @@ struct BfsResult {
 // level: top-down (frontier pushes) unless the frontier is large and owns more than
 // four times as many edges as the still-unvisited remainder — then bottom-up (pull).
 template <bool CM>
-int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out) {
+int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, BfsResult *out, bool *spec_failed = nullptr) {
+  if (spec_failed) *spec_failed = false;
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   // vbits and fbits are adjacent pieces of one allocation (sbx_rcm_reorder): one fill clears both
   // (also the bitmap the level ordering scatters into: k_rank_scatter)
@@ -2080,6 +2096,14 @@ int run_bfs(sbx_handle_t h, const BfsBuffers &b, I fixed_root, I comp_label, Bfs
       SBX_LAUNCH_CHECK(h);
       SBX_TRY(bfs_first_launch(b));
       SBX_TRY(sbx_readback(h, &hd, b.dv, sizeof(RcmDev)));
+      if (b.tie_unverified && *b.tie_unverified) {  // (the sweep's first read-back: see BfsBuffers::tie_unverified)
+        *b.tie_unverified = false;
+        if (!hd.tie_done) {
+          if (!spec_failed) SBX_FAIL(h, SBX_ERR_INTERNAL, "run_bfs: an unverified tie-break in front of a sweep that cannot be redone");
+          *spec_failed = true;
+          return SBX_OK;
+        }
+      }
       if (b.last_read) *b.last_read = hd, *b.last_read_joined = b.side_joined && *b.side_joined;
       remaining -= (int64_t)hd.sl_edges;
       if (remaining < 0) remaining = 0;
@@ -2369,7 +2393,9 @@ __global__ __launch_bounds__(256) void k_ubfs_start(const X *__restrict__ rp, un
                                                     unsigned *__restrict__ fbits, unsigned *__restrict__ dist,
                                                     I *__restrict__ q, RcmDev *__restrict__ dv, I fixed_root,
                                                     unsigned gb_spins, StartClear sc) {
+  SBX_SPEC_GUARD_LEAVE(dv);
   if (!start_clear_elect(sc, dv)) return;
+  dv->spec_guard = 0;
   const I r = fixed_root >= 0 ? fixed_root : (dv->root_pending ? (I)dv->root_next : (I)dv->root);
   dv->root_pending = 0;
   dv->root = (unsigned)r;
@@ -3017,7 +3043,8 @@ __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const X *__restrict__ 
                                                           const X *__restrict__ col, const unsigned *__restrict__ vbits,
                                                           const unsigned *__restrict__ dist, unsigned walk,
                                                           unsigned walk_edges, unsigned walk_cap, unsigned walk_single,
-                                                          TieWalkState *st) {
+                                                          TieWalkState *st, unsigned spec) {
+  // (spec: the next sweep is enqueued behind this tie-break without a look at its outcome — RcmDev::spec_guard)
   __shared__ TieWalkLds s_walk;
   __shared__ unsigned s_red[16], s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
@@ -3057,6 +3084,7 @@ __global__ __launch_bounds__(1024) void k_ubfs_ties_small(const X *__restrict__ 
     dv->cone_begin = 0;
     dv->cone_end = s_cnt;
     dv->bar = 0;
+    dv->spec_guard = spec;
     dv->tie_done = s_cnt <= 1 ? 1u : 0u;  // one candidate: it is the next root, nothing to walk
     if (s_cnt <= 1) {
       dv->root_next = m;
@@ -3248,6 +3276,7 @@ __global__ __launch_bounds__(256) void k_ubfs_descend_all(const X *__restrict__ 
 // after a grid barrier gave up: the words the persistent kernels leave zero when they finish normally
 __global__ void k_gb_reset(RcmDev *__restrict__ dv) {
   dv->gb_abort = 0;
+  dv->spec_guard = 0;
   dv->root_pending = 0;
   dv->tie_done = 0;
   dv->bar = 0;
@@ -3293,6 +3322,7 @@ __global__ __launch_bounds__(256) void k_ubfs_small_run(const X *__restrict__ rp
                                                         unsigned *vbits, unsigned *dist, I *q, I *hq, RcmDev *dv,
                                                         unsigned off, unsigned size, unsigned level, unsigned total,
                                                         long long fe_in, unsigned max_levels, int from_dev) {
+  SBX_SPEC_GUARD_LEAVE(dv);  // (the start kernel in front left: so does this one)
   if (from_dev) {  // the tail of a device-driven chain (run_ubfs): the frontier is the chain's, if it asks for this kernel at all
     if (dv->uc_mode != UC_SMALL) return;
     // (tests, SBX_DEBUG_CHAIN_TAIL_ABORT: the grid barriers of this launch give up — after the workgroups have claimed
@@ -3656,7 +3686,9 @@ __global__ __launch_bounds__(256) void k_check_closed(const X *__restrict__ rp, 
 // One unordered sweep from fixed_root (>= 0) or dv->root: level sets only.  *too_deep is set when the sweep passed the
 // depth limit (ub_max_levels) and was abandoned: the caller runs the ordered sweep instead.
 static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, unsigned *nbits_buf, unsigned *cone,
-                    I fixed_root, I comp_label, BfsResult *out, bool *too_deep) {
+                    I fixed_root, I comp_label, BfsResult *out, bool *too_deep, bool *spec_failed = nullptr) {
+  if (spec_failed) *spec_failed = false;
+  const bool claim_was_clean = *b.claim_clean;
   const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const int64_t words = (b.n + 63) / 64;
   const int64_t fw_blocks = (words + RCM_FW_WORDS - 1) / RCM_FW_WORDS;
@@ -3731,6 +3763,15 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
       SBX_TRY(bfs_first_launch(b, spec_len > 0 && (!b.late_counts || *b.late_counts_ready) ? 150 : 40));
       RcmDev hs;
       SBX_TRY(sbx_readback(h, &hs, b.dv, sizeof(RcmDev)));
+      if (b.tie_unverified && *b.tie_unverified) {  // (the sweep's first read-back: see BfsBuffers::tie_unverified)
+        *b.tie_unverified = false;
+        if (!hs.tie_done) {
+          if (!spec_failed) SBX_FAIL(h, SBX_ERR_INTERNAL, "run_ubfs: an unverified tie-break in front of a sweep that cannot be redone");
+          *b.claim_clean = claim_was_clean;  // (the start kernel left before it cleared anything)
+          *spec_failed = true;
+          return SBX_OK;
+        }
+      }
       if (b.late_counts && !*b.late_counts_ready) {
         *b.late_counts = hs;
         *b.late_counts_ready = true;
@@ -3894,9 +3935,18 @@ static int run_ubfs(sbx_handle_t h, const BfsBuffers &b, unsigned char *claim8, 
 
 // the next candidate root after an unordered sweep: first vertex in queue order among the deepest level's vertices of
 // smallest degree (see the comment above k_ubfs_start); left in dv->root
-static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r, bool *aborted) {
+__global__ void k_clear_spec_guard(RcmDev *__restrict__ dv) { dv->spec_guard = 0; }
+static bool rcm_tie_spec() {  // SBX_RCM_TIE_SPEC=0: the host looks at every tie walk's outcome before it enqueues the next sweep
+  static const bool on = !(sbx_env_test("SBX_RCM_TIE_SPEC") && atoi(sbx_env_test("SBX_RCM_TIE_SPEC")) == 0);
+  return on;
+}
+static int ubfs_pick_root_slow(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r, bool *aborted,
+                               bool clear_guard);
+// allow_unverified: the caller's next sweep can be redone (run_ubfs / run_bfs with spec_failed): a tie walk is then left
+// unverified (*b.tie_unverified) and the next sweep is enqueued straight behind it
+static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r, bool *aborted,
+                          bool allow_unverified) {
   *aborted = false;
-  const size_t bm_bytes = (size_t)((b.n + 31) / 32) * sizeof(unsigned);
   const I *last = b.q + r.last_offset;
   I *list = b.nf_list;  // free during an unordered sweep: the marked vertices, level after level, one growing list
   // (the cone bitmap was cleared by the sweep's start kernel)
@@ -3905,23 +3955,31 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     // it leave at once unless it handed a step over to them)
     TieWalkState *tw = nullptr;
     SBX_TRY(sbx_salloc(h, 1, &tw));
+    static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
+    const bool spec = allow_unverified && rcm_tie_walk() && rcm_tie_spec() && !tw_dbg && b.tie_unverified;
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_ties_small, dim3(1), dim3(1024), b.rp, last, r.last_size, cone, list, b.dv, b.col,
                 (const unsigned *)b.vbits, (const unsigned *)b.lpos, rcm_tie_walk() ? r.levels : 0u, tie_walk_edges(),
-                tie_walk_cap(), tie_walk_single(), tw);
+                tie_walk_cap(), tie_walk_single(), tw, spec ? 1u : 0u);
     if (rcm_tie_walk()) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_heavy_min, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
                   (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const I *)list, tw);
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_walk_resume, dim3(1), dim3(1024), b.rp, b.col, (const unsigned *)b.vbits,
                   (const unsigned *)b.lpos, list, b.dv, tw, tie_walk_edges(), tie_walk_cap(), tie_walk_single());
-      // Usually that was the whole tie-break: the host looks before it enqueues the persistent kernels (a round trip more
-      // where the walk left — rare — against two launches that find nothing to do in every other tie-break)
+      // Usually that was the whole tie-break — so the next sweep goes out behind it unseen: its first kernels leave if the
+      // walk did (RcmDev::spec_guard), its first read-back tells, and the caller then comes back for the persistent
+      // kernels (ubfs_pick_root_slow).  One round trip per tie-break saved.
       SBX_LAUNCH_CHECK(h);
+      if (spec) {
+        *b.tie_unverified = true;
+        return SBX_OK;
+      }
+      // Otherwise the host looks before it enqueues the persistent kernels (a round trip more where the walk left — rare —
+      // against two launches that find nothing to do in every other tie-break)
       // (no bfs_first_launch here: the three kernels are over in tens of microseconds, the hook's enqueues — the other
       // components' labelling, a dozen launches — would hold the read-back up with the caller's stream idle; the next
       // sweep's first launch takes the hook along behind a whole chain of levels)
       RcmDev hw;
       SBX_TRY(sbx_readback(h, &hw, b.dv, sizeof(RcmDev)));
-      static const bool tw_dbg = sbx_env_test("SBX_DEBUG_TIE_WALK") != nullptr;
       if (tw_dbg)  // (exits: see TW_LEAVE in tie_walk; 0: it named the root)
         fprintf(stderr, "[rcm tie walk] levels %u, candidates %u: exit %u at level %u (%u)\n", r.levels, hw.tie_count,
                 hw.tie_walk_exit & 0xFFu, hw.tie_walk_exit >> 8, hw.tie_walk_arg);
@@ -3933,6 +3991,15 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_min_degree, dim3(g), dim3(256), b.rp, last, r.last_size, b.dv);
     SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_ubfs_mark_ties, dim3(g), dim3(256), b.rp, last, r.last_size, cone, list, b.dv);
   }
+  return ubfs_pick_root_slow(h, b, cone, r, aborted, false);
+}
+// the tie-break by the persistent cone kernels, behind the kernels that found and marked the candidates (clear_guard: ...
+// and behind a next sweep whose first kernels left: RcmDev::spec_guard)
+static int ubfs_pick_root_slow(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, const BfsResult &r, bool *aborted,
+                               bool clear_guard) {
+  *aborted = false;
+  I *list = b.nf_list;
+  if (clear_guard) SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_clear_spec_guard, dim3(1), dim3(1), b.dv);
   SBX_LAUNCH_CHECK(h);
   RcmDev hd;
   if (r.last_size > UB_TIES_SMALL) {
@@ -4156,6 +4223,8 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
   b.after_first_launch = &enqueue_ranks;
   b.hook_wants_long_cover = true;  // (~15 launches)
   b.head_chain = true;  // (until the first sweep has run)
+  bool tie_unverified = false;
+  b.tie_unverified = &tie_unverified;
   b.side_stage = nullptr, b.side_event = nullptr, b.side_joined = nullptr, b.last_read = nullptr, b.last_read_joined = nullptr;
   b.rp = rp; b.col = col; b.vbits = vbits; b.fbits = fbits; b.lpos = lpos; b.ppos = ppos; b.label = nullptr;
   b.nnz = nnz; b.q = q; b.nf_list = nf_list; b.heavy = heavy; b.heavy_cap = heavy_cap;
@@ -4237,9 +4306,30 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
         unordered = r0_unordered;
         if (!unordered) deep = true;
       } else {
+        // (a sweep behind an unverified tie walk comes back at once when the walk had left: the persistent kernels then
+        // finish the tie-break on the sweep r still describes — exactly what followed the tie-break before — and the
+        // sweep is enqueued again)
+        auto settle_tie = [&]() -> int {
+          bool ab = false;
+          SBX_TRY(ubfs_pick_root_slow(h, b, cone, r, &ab, true));
+          if (ab) {  // a grid barrier of the tie-break gave up: the same sweep again, ordered (dv->root still is its root)
+            deep = true;
+            SBX_TRY(run_bfs<false>(h, b, -1, root, &r));
+            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_pick_root, dim3(sbx_grid_for(r.last_size, 256, 1024)), dim3(256), rp,
+                        (const I *)(q + r.last_offset), r.last_size, dv);
+            SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_set_root_from_best, dim3(1), dim3(1), (const I *)(q + r.last_offset), dv);
+            SBX_TRY(reset_ppos(h, (const I *)q, r.count, ppos, n));
+          }
+          return SBX_OK;
+        };
         if (candidate >= rcm_speculate_from()) {
           SBX_TRY(join_ranks());
-          SBX_TRY(run_bfs<true>(h, b, fixed, root, &r));
+          bool sf = false;
+          SBX_TRY(run_bfs<true>(h, b, fixed, root, &r, &sf));
+          if (sf) {
+            SBX_TRY(settle_tie());
+            SBX_TRY(run_bfs<true>(h, b, (I)-1, root, &r));
+          }
           sweeps++;
           levels += r.levels;
           const int64_t e = (int64_t)r.levels - 1;
@@ -4252,7 +4342,12 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
           fixed = -1;  // k_bfs_start left the root on the device
         }
         if (!deep) {
-          SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, root, &r, &deep));
+          bool sf = false;
+          SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, fixed, root, &r, &deep, &sf));
+          if (sf) {
+            SBX_TRY(settle_tie());
+            if (!deep) SBX_TRY(run_ubfs(h, b, claim8, nbits, cone, (I)-1, root, &r, &deep));
+          }
           unordered = !deep;
           unordered_sweeps += unordered;
         }
@@ -4267,7 +4362,7 @@ int SBX_RCM_ENTRY(sbx_handle_t h, int64_t n, int64_t nnz, const void *row_ptr, c
       const bool path = (int64_t)r.count == ecc + 1;
       if (!path && prev_ecc != ecc) {
         bool tie_aborted = false;
-        if (unordered) SBX_TRY(ubfs_pick_root(h, b, cone, r, &tie_aborted));
+        if (unordered) SBX_TRY(ubfs_pick_root(h, b, cone, r, &tie_aborted, true));
         if (unordered && tie_aborted) {
           // a grid barrier of the tie-break gave up: the same sweep again, ordered (dv->root still is its root)
           deep = true;

@@ -1486,7 +1486,8 @@ def test_rcm_small_level_after_a_wide_one(ops, oracle, shape):
 
 @pytest.mark.parametrize("mode", ["barriers_give_up", "ordered_sweeps", "unordered_everywhere", "bottom_up_early",
                                   "no_chain", "chain_of_one", "chain_tail_gives_up", "in_line", "no_head_chain", "no_tie_walk",
-                                  "tie_walk_tight", "tie_walk_few_members", "tie_walk_hands_over"])
+                                  "tie_walk_tight", "tie_walk_few_members", "tie_walk_hands_over",
+                                  "no_tie_spec"])
 def test_rcm_sweep_variants_in_a_child(mode):
     """The switches of the RCM's pseudo-peripheral sweeps are read once per process, hence the children:
     SBX_DEBUG_GB_SPINS=0 makes every grid barrier of the persistent kernels give up at once (what a barrier does when its
@@ -1506,7 +1507,10 @@ def test_rcm_sweep_variants_in_a_child(mode):
     SBX_DEBUG_TIE_EDGES=40 / SBX_DEBUG_TIE_CAP=3: that walk's limits lowered until these graphs leave it at every one of
     its exits — after the leading levels, in the middle of the marking, in the walk down — and the persistent kernels must
     find everything as the candidates' kernel alone leaves it; SBX_DEBUG_TIE_SINGLE=8: every smallest-member step of more
-    than eight entries is handed to the grid kernel and taken up again by k_tie_walk_resume; "in_line": no side streams inside the call (SBX_RCM_CC_OVERLAP=0,
+    than eight entries is handed to the grid kernel and taken up again by k_tie_walk_resume; SBX_RCM_TIE_SPEC=0: the host
+    looks at every tie walk's outcome before it enqueues the next sweep (by default the sweep goes out behind the walk
+    unseen, its first kernels leave if the walk did, and the persistent kernels are called in afterwards: what the modes
+    with lowered limits exercise on every second tie-break); "in_line": no side streams inside the call (SBX_RCM_CC_OVERLAP=0,
     SBX_RCM_SPLIT_EXPAND=0, SBX_RCM_OVERLAP=0: the other components are labelled, a wide frontier's light rows expanded
     and the degree ranks built on the caller's stream — what a call under the handle's profiler does)."""
     import subprocess
@@ -1537,6 +1541,7 @@ def test_rcm_sweep_variants_in_a_child(mode):
              "chain_tail_gives_up": {"SBX_DEBUG_CHAIN_TAIL_ABORT": "1"}, "no_head_chain": {"SBX_RCM_HEAD_CHAIN": "0"},
              "no_tie_walk": {"SBX_RCM_TIE_WALK": "0"}, "tie_walk_tight": {"SBX_DEBUG_TIE_EDGES": "40"},
              "tie_walk_few_members": {"SBX_DEBUG_TIE_CAP": "3"}, "tie_walk_hands_over": {"SBX_DEBUG_TIE_SINGLE": "8"},
+             "no_tie_spec": {"SBX_RCM_TIE_SPEC": "0"},
              "in_line": {"SBX_RCM_CC_OVERLAP": "0", "SBX_RCM_SPLIT_EXPAND": "0", "SBX_RCM_OVERLAP": "0"}}[mode]
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True,
                        timeout=900)
