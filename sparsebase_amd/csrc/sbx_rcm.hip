@@ -2668,7 +2668,8 @@ constexpr unsigned TS_GATHER = 1u << 14;  // entries of an ordinary marking step
 struct TieWalkState {  // between k_ubfs_ties_small, k_tie_heavy_min and k_tie_walk_resume (device memory)
   unsigned req;        // 1: the step k -> k - 1 is the grid's; anything else: nothing to resume
   unsigned k, P, cursor, L, n_ties, begin, count, edges;
-  unsigned min_id;     // the grid's result (atomicMin)
+  unsigned min_id;     // the grid's result (atomicMin): the smallest member of T_{k-1}, i.e. w_{k-1}
+  unsigned next_id;    // ... and w_k: the smallest member of T_k adjacent to it (k_tie_heavy_adj)
   unsigned chain[TS_LEVELS + 2], lvl_begin[TS_LEVELS + 2], lvl_count[TS_LEVELS + 2];
 };
 struct TieWalkLds {
@@ -2775,6 +2776,9 @@ __device__ bool tie_walk(TieWalkLds &t, const X *__restrict__ rp, const X *__res
   const unsigned gather = max_edges < TS_GATHER ? max_edges : TS_GATHER;
   const unsigned root = dv->root;
   unsigned L, P, cursor, k_from;
+  // (behind the grid's step the walk's step at that level is known as well: the same members' entries, scanned for
+  // w_{k-1} by the same grid — on one workgroup that step alone took 35 us)
+  unsigned walk_known_level = 0, walk_known = 0xFFFFFFFFu;
   if (phase == 0) {
     L = levels - 1;  // the deepest level
     if (threadIdx.x == 0) st->req = 0;
@@ -2807,6 +2811,7 @@ __device__ bool tie_walk(TieWalkLds &t, const X *__restrict__ rp, const X *__res
     if (st->req != 1) return false;  // (nothing was handed over: the walk is finished or has left)
     L = st->L, P = st->P, cursor = st->cursor;
     const unsigned k = st->k, m = st->min_id;
+    walk_known_level = k, walk_known = st->next_id;
     for (unsigned i = threadIdx.x; i < TS_LEVELS + 2; i += 1024)
       t.chain[i] = st->chain[i], t.lvl_begin[i] = st->lvl_begin[i], t.lvl_count[i] = st->lvl_count[i];
     __syncthreads();
@@ -2844,6 +2849,7 @@ __device__ bool tie_walk(TieWalkLds &t, const X *__restrict__ rp, const X *__res
       if (threadIdx.x == 0) {
         st->k = k, st->P = P, st->cursor = cursor, st->L = L, st->n_ties = n_ties;
         st->begin = t.lvl_begin[k], st->count = count, st->edges = edges, st->min_id = 0xFFFFFFFFu;
+        st->next_id = 0xFFFFFFFFu;
         st->req = 1;
         dv->tie_walk_exit = 8 | (k << 8), dv->tie_walk_arg = edges;  // (overwritten by whoever finishes or leaves)
       }
@@ -2908,6 +2914,10 @@ __device__ bool tie_walk(TieWalkLds &t, const X *__restrict__ rp, const X *__res
   for (unsigned k = 1; k <= L; k++) {
     const unsigned count = t.lvl_count[k], begin = t.lvl_begin[k];
     unsigned best = 0xFFFFFFFFu;
+    if (k == walk_known_level && walk_known != 0xFFFFFFFFu) {
+      w = walk_known;
+      continue;
+    }
     if (k - 1 < P) {  // (under a level of one vertex hangs the whole next level)
       if (threadIdx.x < count) best = (unsigned)ur_load(&list[begin + threadIdx.x]);
     } else {
@@ -3034,6 +3044,55 @@ static unsigned tie_walk_single() {  // SBX_DEBUG_TIE_SINGLE: entries above whic
 static unsigned tie_walk_cap() {
   static const unsigned v = sbx_env_test("SBX_DEBUG_TIE_CAP") ? (unsigned)atoll(sbx_env_test("SBX_DEBUG_TIE_CAP")) : TS_CAP;
   return v < TS_CAP ? v : TS_CAP;
+}
+
+// ... and, behind it, the walk's step at the same level: the smallest member of T_k adjacent to w_{k-1} = st->min_id (the
+// members' entries again — consecutive ones, coalesced — compared with one vertex: no gathers)
+__global__ __launch_bounds__(256) void k_tie_heavy_adj(const X *__restrict__ rp, const X *__restrict__ col, const I *list,
+                                                       TieWalkState *st) {
+  if (st->req != 1 || st->min_id == 0xFFFFFFFFu) return;
+  __shared__ unsigned s_pref[TS_CAP + 1], s_mem[TS_CAP], s_red[4], s_scan[4];
+  __shared__ X s_start[TS_CAP];
+  const unsigned count = st->count, begin = st->begin, edges = st->edges, w = st->min_id;
+  unsigned carry = 0;
+  for (unsigned base = 0; base < count; base += 256) {
+    const unsigned i = base + threadIdx.x;
+    unsigned d = 0;
+    if (i < count) {
+      const unsigned v = (unsigned)list[begin + i];
+      const X s0 = rp[v];
+      s_mem[i] = v;
+      s_start[i] = s0;
+      d = (unsigned)(rp[v + 1] - s0);
+    }
+    unsigned total;
+    const unsigned ex = sbx_block_exclusive_sum<unsigned, 256>(d, s_scan, &total);
+    if (i < count) s_pref[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) s_pref[count] = carry;
+  __syncthreads();
+  constexpr int U = 4;
+  unsigned my_min = 0xFFFFFFFFu;
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned e0 = blockIdx.x * 256u + threadIdx.x; e0 < edges; e0 += stride * U) {
+    unsigned c[U], jj[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = e0 + (unsigned)u * stride;
+      jj[u] = tw_member_of(s_pref, count, e < edges ? e : edges - 1u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = e0 + (unsigned)u * stride, ee = e < edges ? e : edges - 1u;
+      c[u] = (unsigned)col[s_start[jj[u]] + (X)(ee - s_pref[jj[u]])];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (c[u] == w && e0 + (unsigned)u * stride < edges) my_min = s_mem[jj[u]] < my_min ? s_mem[jj[u]] : my_min;
+  }
+  const unsigned m = tw_block_min<256>(my_min, s_red);
+  if (threadIdx.x == 0 && m != 0xFFFFFFFFu) atomicMin(&st->next_id, m);
 }
 
 // walk: 0, or the sweep's number of levels — the workgroup then goes on to tie_walk (col / vbits / dist are its inputs)
@@ -3963,6 +4022,7 @@ static int ubfs_pick_root(sbx_handle_t h, const BfsBuffers &b, unsigned *cone, c
     if (rcm_tie_walk()) {
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_heavy_min, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col,
                   (const unsigned *)b.vbits, (const unsigned *)b.lpos, (const I *)list, tw);
+      SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_heavy_adj, dim3((unsigned)h->num_cus), dim3(256), b.rp, b.col, (const I *)list, tw);
       SBX_KLAUNCH(h, SBX_K_RCM_MISC, k_tie_walk_resume, dim3(1), dim3(1024), b.rp, b.col, (const unsigned *)b.vbits,
                   (const unsigned *)b.lpos, list, b.dv, tw, tie_walk_edges(), tie_walk_cap(), tie_walk_single());
       // Usually that was the whole tie-break — so the next sweep goes out behind it unseen: its first kernels leave if the
