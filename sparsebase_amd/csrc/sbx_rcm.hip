@@ -2334,7 +2334,10 @@ static double ubu_ratio() {
   return r;
 }
 
-constexpr unsigned UR_GRID = 64;
+#ifndef SBX_UR_GRID
+#define SBX_UR_GRID 64  // (128: +1 %, 256: +4 % on the bench matrix's RCM, measured again in round 6 with tools/build_variant.py)
+#endif
+constexpr unsigned UR_GRID = SBX_UR_GRID;
 constexpr unsigned UR_CONTINUE = 0, UR_DONE = 1, UR_STOP = 2, UR_DEEP = 3;  // how a persistent run ended (DEEP: too many levels in one launch)
 constexpr unsigned UR_MAX_E = 1u << 18;   // a frontier owning more adjacency entries than this is the host loop's
 constexpr unsigned UR_MAX_N = 1024;       // ... or holding more vertices (a wave takes a vertex: 256 waves)
