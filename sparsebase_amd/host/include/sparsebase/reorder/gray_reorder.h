@@ -42,6 +42,60 @@ namespace sparsebase::reorder {
 enum BitMapSize { BitSize16 = 16, BitSize32 = 32, BitSize64 = 64 };
 
 namespace detail {
+// The stage's scratch — a dozen arrays of 12 - 70 MB per call on the 4 M-row matrices — comes from a process-wide pool of
+// blocks it has used before: fresh memory costs a page fault per 4 KB at its first touch, ~150 MB of them per call, taken
+// by two dozen threads at once (and given back to the system by free() behind every call).  Blocks of 1 MB and more,
+// sizes rounded up to 2 MB, at most SBX_GRAY_SCRATCH_MB (default 512; 0: plain new / delete) kept between calls.
+class GrayScratchPool {
+ public:
+  static GrayScratchPool &Get() {
+    static GrayScratchPool *pool = new GrayScratchPool;  // (never destroyed: worker threads may outlive static destruction)
+    return *pool;
+  }
+  void *Acquire(size_t bytes, size_t *capacity) {
+    if (bytes < kMin || limit_ == 0) {
+      *capacity = 0;  // (not the pool's)
+      return ::operator new(bytes ? bytes : 1);
+    }
+    const size_t cap = (bytes + kRound - 1) / kRound * kRound;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t i = free_.size(); i-- > 0;)
+        if (free_[i].second == cap) {
+          void *p = free_[i].first;
+          free_.erase(free_.begin() + (std::ptrdiff_t)i);
+          held_ -= cap;
+          *capacity = cap;
+          return p;
+        }
+    }
+    *capacity = cap;
+    return ::operator new(cap);
+  }
+  void Release(void *p, size_t capacity) {
+    if (!p) return;
+    if (capacity) {
+      std::lock_guard<std::mutex> g(mu_);
+      if (held_ + capacity <= limit_) {
+        free_.emplace_back(p, capacity);
+        held_ += capacity;
+        return;
+      }
+    }
+    ::operator delete(p);
+  }
+
+ private:
+  GrayScratchPool() {
+    const char *e = std::getenv("SBX_GRAY_SCRATCH_MB");
+    limit_ = (size_t)(e ? std::atoll(e) : 512) << 20;
+  }
+  static constexpr size_t kMin = (size_t)1 << 20, kRound = (size_t)2 << 20;
+  std::mutex mu_;
+  std::vector<std::pair<void *, size_t>> free_;
+  size_t held_ = 0, limit_ = 0;
+};
+
 // n elements left uninitialised: the stage writes every element it later reads, and a std::vector would zero-fill
 // 14 - 50 MB a piece on one thread first (eight of them: ~20 ms of the call on the 4 M-row matrices).
 template <typename T>
@@ -49,22 +103,30 @@ class GrayBuffer {
  public:
   GrayBuffer() = default;
   explicit GrayBuffer(size_t n) { reset(n); }
+  ~GrayBuffer() { GrayScratchPool::Get().Release(p_, cap_); }
+  GrayBuffer(const GrayBuffer &) = delete;
+  GrayBuffer &operator=(const GrayBuffer &) = delete;
   void reset(size_t n) {
-    static_assert(std::is_trivially_default_constructible<T>::value, "new T[n] must not initialise");
-    p_.reset(n ? new T[n] : nullptr);
-    n_ = n;
+    static_assert(std::is_trivially_default_constructible<T>::value && std::is_trivially_destructible<T>::value,
+                  "raw storage: the elements are neither constructed nor destroyed");
+    GrayScratchPool::Get().Release(p_, cap_);
+    p_ = nullptr, cap_ = 0, n_ = 0;
+    if (n) {
+      p_ = static_cast<T *>(GrayScratchPool::Get().Acquire(n * sizeof(T), &cap_));
+      n_ = n;
+    }
   }
   size_t size() const { return n_; }
   bool empty() const { return n_ == 0; }
-  T *data() { return p_.get(); }
-  T *begin() { return p_.get(); }
-  T *end() { return p_.get() + n_; }
+  T *data() { return p_; }
+  T *begin() { return p_; }
+  T *end() { return p_ + n_; }
   T &operator[](size_t i) { return p_[i]; }
   const T &operator[](size_t i) const { return p_[i]; }
 
  private:
-  std::unique_ptr<T[]> p_;
-  size_t n_ = 0;
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
 };
 
 // While one of these lives, the calling thread — and every thread created under it, which inherit its mask and are placed
@@ -366,7 +428,10 @@ class GrayIntroSortPool {
     It job_first{}, job_last{}, pivot{};      // the range being partitioned: [job_first, job_last), pivot outside it
     uint64_t swaps = 0;
     bool done = false;
-    void Barrier() {  // sense-reversing; spins briefly, then yields (a team of at most 16 on a busy host)
+    // sense-reversing; spins briefly, then yields (a team of at most 32 on a busy host).  (A waiter that sleeps on a
+    // condition variable instead — tried against the occasional sort that takes 34 ms for 9 — made every barrier a
+    // thundering herd on the mutex: 13 -> 46 ms for the 3 M-key sort on 8 cores.)
+    void Barrier() {
       const unsigned my = phase.load(std::memory_order_acquire);
       if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == size) {
         arrived.store(0, std::memory_order_relaxed);
