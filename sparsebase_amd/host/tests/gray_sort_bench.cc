@@ -10,6 +10,10 @@ using namespace sparsebase;
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? atol(argv[1]) : 3000000;
+  // "gpu" as second argument: a device handle first — the sorts then run in a process that holds a HIP context with its
+  // runtime threads, as they do inside GrayReorder (does that explain the occasional sort that takes 3 x its time?)
+  sbx_handle_t h = nullptr;
+  if (argc > 2 && std::string(argv[2]) == "gpu" && sbx_create(0, &h) != SBX_OK) { printf("no device\n"); return 1; }
   unsigned long long state = 88172645463325252ull;
   auto rnd = [&state]() { state ^= state << 13, state ^= state >> 7, state ^= state << 17; return state; };
   auto by_degree = [](uint32_t l, uint32_t r) -> bool { return (l >> 24) < (r >> 24); };
@@ -20,8 +24,10 @@ int main(int argc, char **argv) {
   std::vector<P> pb(n), pc(n);
   for (size_t i = 0; i < n; i++) pb[i] = P{(int)i, (unsigned long)(rnd() % 5000)};
   for (size_t i = 0; i < n; i++) pc[i] = P{(int)i, (unsigned long)(rnd() & 0xFFFFFFFF)};
-  for (int rep = 0; rep < 3; rep++)
+  const int reps = argc > 3 ? atoi(argv[3]) : 3;
+  for (int rep = 0; rep < reps; rep++)
     for (int64_t pm : {(int64_t)-1, (int64_t)0, (int64_t)(1 << 18), (int64_t)(1 << 19), (int64_t)(1 << 20)}) {
+      if (reps > 3 && pm != 0) continue;  // (many repetitions: the default threshold only)
       std::vector<uint32_t> a = base;
       double t0 = now();
       reorder::detail::GrayIntroSort(a.begin(), a.end(), by_degree, 0, 0, pm);
