@@ -327,11 +327,13 @@ class GrayThreadBudget {
 template <typename It, typename WrappedCompare>
 class GrayIntroSortPool {
  public:
+  static constexpr unsigned kMaxTeam = 64;  // (GraySortThreadCap's ceiling)
   // par_min: ranges of at least this many elements are partitioned by the whole team (0: never)
   GrayIntroSortPool(WrappedCompare comp, int64_t grain, int64_t par_min = 0)
       : comp_(comp), grain_(grain), par_min_(par_min > 0 ? std::max<int64_t>(par_min, 64) : 0) {}
   void Run(It first, It last, unsigned threads) {
     const long depth0 = (long)std::__lg(last - first) * 2;
+    if (threads > kMaxTeam) threads = kMaxTeam;
     if (par_min_ > 0 && last - first >= par_min_ && (uint64_t)(last - first) < ((uint64_t)1 << 32) && threads > 1) {
       // the team: threads that could not be created are simply not part of it (a barrier counts on every member)
       big_.push_back(Task{first, last, depth0});
@@ -419,14 +421,12 @@ class GrayIntroSortPool {
       const uint32_t *l = nullptr, *r = nullptr;
       size_t nl = 0, nr = 0;
     };
-    explicit TeamState(unsigned size_) : size(size_), lists(size_), pl(size_ + 1), pr(size_ + 1) {}
+    explicit TeamState(unsigned size_) : size(size_), lists(size_) {}
     const unsigned size;
     alignas(64) std::atomic<unsigned> arrived{0};
     alignas(64) std::atomic<unsigned> phase{0};
     std::vector<Lists> lists;
-    std::vector<uint64_t> pl, pr;  // running counts of the lists' lengths over the members
     It job_first{}, job_last{}, pivot{};      // the range being partitioned: [job_first, job_last), pivot outside it
-    uint64_t swaps = 0;
     bool done = false;
     // sense-reversing; spins briefly, then yields (a team of at most 32 on a busy host).  (A waiter that sleeps on a
     // condition variable instead — tried against the occasional sort that takes 34 ms for 9 — made every barrier a
@@ -442,17 +442,6 @@ class GrayIntroSortPool {
         if (spin > 200) std::this_thread::yield();
     }
   };
-  uint32_t SelL(uint64_t k) const {  // L[k]
-    const TeamState &t = *team_;
-    const size_t w = (size_t)(std::upper_bound(t.pl.begin(), t.pl.end(), k) - t.pl.begin()) - 1;
-    return t.lists[w].l[(size_t)(k - t.pl[w])];
-  }
-  uint32_t SelR(uint64_t k) const {  // R[k]: the k-th from the right
-    const TeamState &t = *team_;
-    const uint64_t g = t.pr[t.size] - 1 - k;
-    const size_t w = (size_t)(std::upper_bound(t.pr.begin(), t.pr.end(), g) - t.pr.begin()) - 1;
-    return t.lists[w].r[(size_t)(g - t.pr[w])];
-  }
   // member 0, between two barriers: the next big range, its pivot; false: none left
   bool NextJob() {
     TeamState &t = *team_;
@@ -512,29 +501,40 @@ class GrayIntroSortPool {
       }
       t.lists[w].l = l.data(), t.lists[w].nl = nl, t.lists[w].r = r.data(), t.lists[w].nr = nr;
       t.Barrier();
-      // 2: how many swaps (member 0)
-      if (w == 0) {
-        t.pl[0] = t.pr[0] = 0;
-        for (unsigned m = 0; m < size; m++) t.pl[m + 1] = t.pl[m] + t.lists[m].nl, t.pr[m + 1] = t.pr[m] + t.lists[m].nr;
-        uint64_t lo = 0, hi = std::min(t.pl[size], t.pr[size]);  // K in [lo, hi]: L[k] < R[k] for k < K
+      // 2: how many swaps — every member for itself, from the lists' lengths (a barrier less per partition than with
+      // member 0 computing it for all: the lists are final, the elements are not looked at)
+      uint64_t pl[kMaxTeam + 1], pr[kMaxTeam + 1];
+      pl[0] = pr[0] = 0;
+      for (unsigned m = 0; m < size; m++) pl[m + 1] = pl[m] + t.lists[m].nl, pr[m + 1] = pr[m] + t.lists[m].nr;
+      auto SelL = [&](uint64_t k) -> uint32_t {  // L[k]
+        const size_t m = (size_t)(std::upper_bound(pl, pl + size + 1, k) - pl) - 1;
+        return t.lists[m].l[(size_t)(k - pl[m])];
+      };
+      auto SelR = [&](uint64_t k) -> uint32_t {  // R[k]: the k-th from the right
+        const uint64_t g = pr[size] - 1 - k;
+        const size_t m = (size_t)(std::upper_bound(pr, pr + size + 1, g) - pr) - 1;
+        return t.lists[m].r[(size_t)(g - pr[m])];
+      };
+      uint64_t K;
+      {
+        uint64_t lo = 0, hi = std::min(pl[size], pr[size]);  // K in [lo, hi]: L[k] < R[k] for k < K
         while (lo < hi) {
           const uint64_t mid = (lo + hi) / 2;
           if (SelL(mid) < SelR(mid)) lo = mid + 1;
           else hi = mid;
         }
-        t.swaps = lo;
+        K = lo;
       }
-      t.Barrier();
       // 3: the swaps, shared out
       {
-        const uint64_t K = t.swaps, k0 = K * w / size, k1 = K * ((uint64_t)w + 1) / size;
+        const uint64_t k0 = K * w / size, k1 = K * ((uint64_t)w + 1) / size;
         if (k0 < k1) {
           // cursors instead of a search per swap: L[k] walks its lists upwards, R[k] its lists downwards
-          size_t lw = (size_t)(std::upper_bound(t.pl.begin(), t.pl.end(), k0) - t.pl.begin()) - 1;
-          size_t li = (size_t)(k0 - t.pl[lw]);
-          const uint64_t g0 = t.pr[size] - 1 - k0;
-          size_t rw = (size_t)(std::upper_bound(t.pr.begin(), t.pr.end(), g0) - t.pr.begin()) - 1;
-          size_t ri = (size_t)(g0 - t.pr[rw]);
+          size_t lw = (size_t)(std::upper_bound(pl, pl + size + 1, k0) - pl) - 1;
+          size_t li = (size_t)(k0 - pl[lw]);
+          const uint64_t g0 = pr[size] - 1 - k0;
+          size_t rw = (size_t)(std::upper_bound(pr, pr + size + 1, g0) - pr) - 1;
+          size_t ri = (size_t)(g0 - pr[rw]);
           for (uint64_t k = k0; k < k1; k++) {
             while (li >= t.lists[lw].nl) lw++, li = 0;
             std::iter_swap(t.job_first + t.lists[lw].l[li], t.job_first + t.lists[rw].r[ri]);
@@ -551,10 +551,9 @@ class GrayIntroSortPool {
       }
       t.Barrier();
       if (w == 0) {
-        const uint64_t K = t.swaps;
         // where the left pointer stops next (the median-of-three pivot guarantees both lists are non-empty)
         uint32_t at;
-        if (K < t.pl[size] && (K == 0 || SelL(K) < SelR(K - 1))) at = SelL(K);
+        if (K < pl[size] && (K == 0 || SelL(K) < SelR(K - 1))) at = SelL(K);
         else at = SelR(K - 1);
         It cut = t.job_first + at;
         {
