@@ -438,8 +438,16 @@ class GrayIntroSortPool {
         phase.store(my + 1, std::memory_order_release);
         return;
       }
-      for (unsigned spin = 0; phase.load(std::memory_order_acquire) == my; spin++)
-        if (spin > 200) std::this_thread::yield();
+      // (pause, not a bare load loop: the waiter's hyperthread sibling may be the member everyone waits for; and a long
+      // stretch of pauses before the first sched_yield: thirty waiters yielding in a loop are thirty system calls
+      // fighting over the run queues' locks)
+      for (unsigned spin = 0; phase.load(std::memory_order_acquire) == my; spin++) {
+#if defined(__x86_64__) || defined(__i386__)
+        if (spin < 4000) __builtin_ia32_pause();
+        else
+#endif
+          if (spin > 200) std::this_thread::yield();
+      }
     }
   };
   // member 0, between two barriers: the next big range, its pivot; false: none left
