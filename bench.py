@@ -471,13 +471,17 @@ def cpp_legs(n, nnz, rp, col, op):
                 res["pipeline_cpp"] = {"error": repr(e)[:200]}
             try:
                 res_, thr, grp = op["gray"]["params"]
-                r = subprocess.run([cli, "gray", a, b, o, str(n), str(n), str(res_), str(thr), str(grp), "--device", "--time"],
+                r = subprocess.run([cli, "gray", a, b, o, str(n), str(n), str(res_), str(thr), str(grp), "--device", "--time",
+                                    "--reps", "5"],
                                    env=env, capture_output=True, text=True, timeout=600, check=True)
                 lines = r.stdout.split("\n")
                 dev_ms, d2h_ms, host_ms = (float(x) for x in lines[1].split())
+                calls = [l for l in r.stderr.splitlines() if l.startswith("timed calls (ms):")]
                 res["gray"] = dict(op["gray"], end_to_end={
                     "ms": float(lines[0]) * 1e3, "device_key_stage_ms": dev_ms, "keys_to_host_ms": d2h_ms,
-                    "host_ordering_ms": host_ms, "via": "host/bin/reorder_cli --device --time (warm call)",
+                    "host_ordering_ms": host_ms,
+                    "via": "host/bin/reorder_cli --device --time --reps 5 (the call of median duration of five warm calls)",
+                    "calls_ms": [float(x) for x in calls[-1].split(":")[1].split()] if calls else None,
                     "note": "degrees and keys are downloaded into page-locked, pooled host blocks: with pageable targets "
                             "(rounds 3 - 5) the runtime's unpinning of the previous call's targets held this call's first "
                             "kernel back by 14 - 25 ms (tools/gray_kt2.sh, tools/gray_stall_probe.sh)"})
